@@ -1,0 +1,1047 @@
+/*
+ * mptrac_oracle.c -- CPU oracle for the MPTRAC per-particle time-step loop.
+ *
+ * TEST INFRASTRUCTURE ONLY (see mptrac_oracle.h).  Plain-C restatement of the
+ * reference algorithm; every function cites the reference lines it follows
+ * (paths relative to the reference repo, mptrac.c = src/mptrac.c,
+ * mptrac.h = src/mptrac.h).
+ *
+ * Build: gcc -O3 -ffp-contract=off -fopenmp (oracle/Makefile).  Contraction is
+ * switched off so that the arithmetic is the reference's gcc/x86-64 arithmetic
+ * (no FMA), operation by operation.
+ */
+#include "mptrac_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- constants (mptrac.h:255-345, 430-460, 535) ------------------------- */
+#define C_G0 9.80665
+#define C_H0 7.0
+#define C_KB 1.3806504e-23
+#define C_MA 28.9644
+#define C_P0 1013.25
+#define C_RI 8.3144598
+#define C_RA (1e3 * C_RI / C_MA)
+#define C_RE 6367.421
+#define C_M_AIR 4.8096e-26
+#define C_TREF 298.15
+#define C_T0 273.15
+#define C_SO2_K1_REF 1.23e-2
+#define C_SO2_K1_TEMP 2.01e3
+#define C_SO2_K2_REF 6e-8
+#define C_SO2_K2_TEMP 1.12e3
+#define C_WD_T_LIQUID C_T0
+#define C_WD_T_ICE 238.15
+#define C_WD_T_LIQUID_BC 270.
+
+#define SQ(x) ((x) * (x))
+
+static void die(const char *msg) {
+  /* the reference's ERRMSG prints and exits (mptrac.h:2406-2410) */
+  printf("\nOracle error: %s\n\n", msg);
+  exit(EXIT_FAILURE);
+}
+
+size_t orc_sizeof_ctl(void) {
+  return sizeof(orc_ctl_t);
+}
+
+/* ---- arithmetic conventions (mptrac.h) ---------------------------------- */
+
+/* FMOD, mptrac.h:1121-1122: truncation through (int), not fmod() */
+static inline double fmod_trunc(double x, double y) {
+  return x - (int) (x / y) * y;
+}
+
+/* DEG2RAD, mptrac.h:857 */
+static inline double deg2rad(double deg) {
+  return deg * (M_PI / 180.0);
+}
+
+/* DX2DEG, mptrac.h:904-906 (dx in km) */
+static inline double dx2deg(double dx, double lat) {
+  if (lat < -89.999 || lat > 89.999)
+    return 0;
+  return dx * 180. / (M_PI * C_RE * cos(deg2rad(lat)));
+}
+
+/* DY2DEG, mptrac.h:922 (dy in km) */
+static inline double dy2deg(double dy) {
+  return dy * 180. / (M_PI * C_RE);
+}
+
+/* DX2COORD / DY2COORD, mptrac.h:966, 989 (distance in m) */
+static inline double dx2coord(int coord_type, double dx, double lat) {
+  return coord_type == 0 ? dx2deg(dx / 1000.0, lat) : dx;
+}
+
+static inline double dy2coord(int coord_type, double dy) {
+  return coord_type == 0 ? dy2deg(dy / 1000.0) : dy;
+}
+
+/* DZ2DP, mptrac.h:941 */
+static inline double dz2dp(double dz, double p) {
+  return -dz * p / C_H0;
+}
+
+/* Z, mptrac.h:2243 */
+static inline double zfromp(double p) {
+  return C_H0 * log(C_P0 / p);
+}
+
+/* LIN, mptrac.h:1351 */
+static inline double lin(double x0, double y0, double x1, double y1, double x) {
+  return y0 + (y1 - y0) / (x1 - x0) * (x - x0);
+}
+
+/* RHO, mptrac.h:1961 */
+static inline double rho_air(double p, double t) {
+  return 100. * p / (C_RA * t);
+}
+
+static inline double dmin(double a, double b) {
+  return a < b ? a : b;
+}
+
+static inline double dmax(double a, double b) {
+  return a > b ? a : b;
+}
+
+/* ---- locate (mptrac.c:3495-3574) ---------------------------------------- */
+
+int orc_locate_irr(const double *xx, int n, double x) {
+  /* mptrac.c:3495-3521: bisection; direction decided at the first midpoint */
+  int lo = 0, hi = n - 1;
+  int mid = (hi + lo) >> 1;
+  if (xx[mid] < xx[mid + 1]) {
+    while (hi > lo + 1) {
+      mid = (hi + lo) >> 1;
+      if (xx[mid] > x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  } else {
+    while (hi > lo + 1) {
+      mid = (hi + lo) >> 1;
+      if (xx[mid] <= x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  }
+  return lo;
+}
+
+int orc_locate_reg(const double *xx, int n, double x) {
+  /* mptrac.c:3559-3574 */
+  const int i = (int) ((x - xx[0]) / (xx[1] - xx[0]));
+  if (i < 0)
+    return 0;
+  if (i > n - 2)
+    return n - 2;
+  return i;
+}
+
+/* ---- interpolation (mptrac.c:2755-3170) --------------------------------- */
+
+/* indices/weights carried between variables: ci[3], cw[4] (mptrac.h:1174) */
+typedef struct {
+  int ip, ix, iy;
+  double wp, wx, wy;
+} stencil_t;
+
+static const stencil_t STENCIL_ZERO = { 0, 0, 0, 0.0, 0.0, 0.0 };
+
+/* mptrac.c:2755-2778 */
+static void check_lon_lat(const orc_met_t *m, double lon, double lat, double *lon2, double *lat2) {
+  double l = fmod_trunc(lon, 360.);
+  if (l < m->lon[0])
+    l += 360;
+  else if (l > m->lon[m->nx - 1])
+    l -= 360;
+  *lon2 = l;
+  if (m->lat[0] < m->lat[m->ny - 1])
+    *lat2 = dmin(dmax(lat, m->lat[0]), m->lat[m->ny - 1]);
+  else
+    *lat2 = dmin(dmax(lat, m->lat[m->ny - 1]), m->lat[0]);
+}
+
+/* mptrac.c:2782-2803 */
+static void check_cartesian(const orc_met_t *m, double lon, double lat, double *lon2, double *lat2) {
+  if (m->lon[0] < m->lon[m->nx - 1])
+    *lon2 = dmin(dmax(lon, m->lon[0]), m->lon[m->nx - 1]);
+  else
+    *lon2 = dmin(dmax(lon, m->lon[m->nx - 1]), m->lon[0]);
+  if (m->lat[0] < m->lat[m->ny - 1])
+    *lat2 = dmin(dmax(lat, m->lat[0]), m->lat[m->ny - 1]);
+  else
+    *lat2 = dmin(dmax(lat, m->lat[m->ny - 1]), m->lat[0]);
+}
+
+static void check_horizontal(const orc_met_t *m, double lon, double lat, double *lon2, double *lat2) {
+  if (m->coord_type == 0)
+    check_lon_lat(m, lon, lat, lon2, lat2);
+  else
+    check_cartesian(m, lon, lat, lon2, lat2);
+}
+
+#define A3(a, m, i, j, k) ((a)[((size_t) (i) * (size_t) (m)->ny + (size_t) (j)) * (size_t) (m)->np + (size_t) (k)])
+#define A2(a, m, i, j) ((a)[(size_t) (i) * (size_t) (m)->ny + (size_t) (j)])
+
+/* intpol_met_space_3d, mptrac.c:2985-3044 */
+static double space_3d(const orc_met_t *m, const float *a, double p, double lon, double lat,
+                       stencil_t *s, int init) {
+  if (init) {
+    double lon2, lat2;
+    check_horizontal(m, lon, lat, &lon2, &lat2);
+    s->ip = orc_locate_irr(m->p, m->np, p);
+    s->ix = orc_locate_reg(m->lon, m->nx, lon2);
+    s->iy = orc_locate_irr(m->lat, m->ny, lat2);
+    s->wp = (m->p[s->ip + 1] - p) / (m->p[s->ip + 1] - m->p[s->ip]);
+    s->wx = (m->lon[s->ix + 1] - lon2) / (m->lon[s->ix + 1] - m->lon[s->ix]);
+    s->wy = (m->lat[s->iy + 1] - lat2) / (m->lat[s->iy + 1] - m->lat[s->iy]);
+  }
+  const int ix = s->ix, iy = s->iy, ip = s->ip;
+  /* vertical first, then latitude, then longitude */
+  const double c00 = s->wp * (A3(a, m, ix, iy, ip) - A3(a, m, ix, iy, ip + 1)) + A3(a, m, ix, iy, ip + 1);
+  const double c01 = s->wp * (A3(a, m, ix, iy + 1, ip) - A3(a, m, ix, iy + 1, ip + 1))
+    + A3(a, m, ix, iy + 1, ip + 1);
+  const double c10 = s->wp * (A3(a, m, ix + 1, iy, ip) - A3(a, m, ix + 1, iy, ip + 1))
+    + A3(a, m, ix + 1, iy, ip + 1);
+  const double c11 = s->wp * (A3(a, m, ix + 1, iy + 1, ip) - A3(a, m, ix + 1, iy + 1, ip + 1))
+    + A3(a, m, ix + 1, iy + 1, ip + 1);
+  const double r0 = s->wy * (c00 - c01) + c01;
+  const double r1 = s->wy * (c10 - c11) + c11;
+  return s->wx * (r0 - r1) + r1;
+}
+
+/* intpol_met_space_2d, mptrac.c:3048-3108 (NaN-aware nearest neighbour) */
+static double space_2d(const orc_met_t *m, const float *a, double lon, double lat,
+                       stencil_t *s, int init) {
+  if (init) {
+    double lon2, lat2;
+    check_horizontal(m, lon, lat, &lon2, &lat2);
+    s->ix = orc_locate_reg(m->lon, m->nx, lon2);
+    s->iy = orc_locate_irr(m->lat, m->ny, lat2);
+    s->wx = (m->lon[s->ix + 1] - lon2) / (m->lon[s->ix + 1] - m->lon[s->ix]);
+    s->wy = (m->lat[s->iy + 1] - lat2) / (m->lat[s->iy + 1] - m->lat[s->iy]);
+  }
+  const double c00 = A2(a, m, s->ix, s->iy);
+  const double c01 = A2(a, m, s->ix, s->iy + 1);
+  const double c10 = A2(a, m, s->ix + 1, s->iy);
+  const double c11 = A2(a, m, s->ix + 1, s->iy + 1);
+  if (isfinite(c00) && isfinite(c01) && isfinite(c10) && isfinite(c11)) {
+    const double r0 = s->wy * (c00 - c01) + c01;
+    const double r1 = s->wy * (c10 - c11) + c11;
+    return s->wx * (r0 - r1) + r1;
+  }
+  if (s->wy < 0.5)
+    return s->wx < 0.5 ? c11 : c01;
+  return s->wx < 0.5 ? c10 : c00;
+}
+
+/* intpol_met_time_3d, mptrac.c:3112-3137: met0 with init, met1 re-using indices */
+static double time_3d(const orc_met_t *m0, const orc_met_t *m1, int f, double ts, double p,
+                      double lon, double lat, stencil_t *s, int init) {
+  const double v0 = space_3d(m0, m0->f3[f], p, lon, lat, s, init);
+  const double v1 = space_3d(m1, m1->f3[f], p, lon, lat, s, 0);
+  const double wt = (m1->time - ts) / (m1->time - m0->time);
+  return wt * (v0 - v1) + v1;
+}
+
+/* intpol_met_time_2d, mptrac.c:3141-3170 */
+static double time_2d(const orc_met_t *m0, const orc_met_t *m1, int f, double ts, double lon,
+                      double lat, stencil_t *s, int init) {
+  const double v0 = space_2d(m0, m0->f2[f], lon, lat, s, init);
+  const double v1 = space_2d(m1, m1->f2[f], lon, lat, s, 0);
+  const double wt = (m1->time - ts) / (m1->time - m0->time);
+  if (isfinite(v0) && isfinite(v1))
+    return wt * (v0 - v1) + v1;
+  return wt < 0.5 ? v1 : v0;
+}
+
+void orc_intpol_met_time_3d(const orc_met_t *met0, const orc_met_t *met1, int field, double ts,
+                            double p, double lon, double lat, double *var) {
+  stencil_t s = STENCIL_ZERO;
+  *var = time_3d(met0, met1, field, ts, p, lon, lat, &s, 1);
+}
+
+void orc_intpol_met_time_2d(const orc_met_t *met0, const orc_met_t *met1, int field, double ts,
+                            double lon, double lat, double *var) {
+  stencil_t s = STENCIL_ZERO;
+  *var = time_2d(met0, met1, field, ts, lon, lat, &s, 1);
+}
+
+/* ---- climatological tropopause and weights ------------------------------ */
+
+/* clim_tropo, mptrac.c:213-237 */
+double orc_clim_tropo(const orc_clim_t *clim, double t, double lat) {
+  double sec = fmod_trunc(t, 365.25 * 86400.);
+  while (sec < 0)
+    sec += 365.25 * 86400.;
+  const int it = orc_locate_irr(clim->tropo_time, clim->tropo_ntime, sec);
+  const int il = orc_locate_reg(clim->tropo_lat, clim->tropo_nlat, lat);
+  const double pa = lin(clim->tropo_lat[il], clim->tropo[it][il],
+                        clim->tropo_lat[il + 1], clim->tropo[it][il + 1], lat);
+  const double pb = lin(clim->tropo_lat[il], clim->tropo[it + 1][il],
+                        clim->tropo_lat[il + 1], clim->tropo[it + 1][il + 1], lat);
+  return lin(clim->tropo_time[it], pa, clim->tropo_time[it + 1], pb, sec);
+}
+
+/* tropo_weight, mptrac.c:12748-12770 */
+double orc_tropo_weight(const orc_ctl_t *ctl, const orc_clim_t *clim, double time, double lat,
+                        double p) {
+  const double pt = orc_clim_tropo(clim, time, ctl->met_coord_type == 0 ? lat : ctl->met_utm_ref_lat);
+  const double p1 = pt * 0.866877899;
+  const double p0 = pt / 0.866877899;
+  if (p > p0)
+    return 1;
+  if (p < p1)
+    return 0;
+  return lin(p0, 1.0, p1, 0.0, p);
+}
+
+/* pbl_weight, mptrac.c:8358-8376 */
+double orc_pbl_weight(const orc_ctl_t *ctl, double p, double pbl, double ps) {
+  const double p1 = pbl - ctl->turb_pbl_trans * (ps - pbl);
+  const double p0 = pbl;
+  if (p > p0)
+    return 1;
+  if (p < p1)
+    return 0;
+  return lin(p0, 1.0, p1, 0.0, p);
+}
+
+/* sedi, mptrac.c:12506-12535 */
+double orc_sedi(double p, double T, double rp, double rhop) {
+  const double r = rp * 1e-6;
+  const double rho = rho_air(p, T);
+  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * pow(T / 296.16, 1.5);
+  const double v = sqrt(8. * C_KB * T / (M_PI * C_M_AIR));
+  const double lambda = 2. * eta / (rho * v);
+  const double K = lambda / r;
+  const double G = 1. + K * (1.249 + 0.42 * exp(-0.87 / K));
+  return 2. * SQ(r) * (rhop - rho) * C_G0 / (9. * eta) * G;
+}
+
+/* ---- random numbers (mptrac.c:5784-5828) -------------------------------- */
+
+/* Squares counter-based RNG (Widynski 2022), five rounds, fixed key;
+ * mptrac.c:5788, 5798-5809 */
+uint64_t orc_squares(uint64_t ctr) {
+  const uint64_t key = 0xc8e4fd154ce32f6dULL;
+  uint64_t x, y, z, t;
+  y = x = ctr * key;
+  z = y + key;
+  x = x * x + y;
+  x = (x >> 32) | (x << 32);
+  x = x * x + z;
+  x = (x >> 32) | (x << 32);
+  x = x * x + y;
+  x = (x >> 32) | (x << 32);
+  t = x = x * x + z;
+  x = (x >> 32) | (x << 32);
+  return t ^ ((x * x + y) >> 32);
+}
+
+/* module_rng, RNG_TYPE=1 branch: n+1 uniforms, counter advanced by n+1, then
+ * Box-Muller over flat pairs with single-precision trig (mptrac.c:5797-5827) */
+void orc_module_rng(const orc_ctl_t *ctl, orc_cache_t *cache, size_t n, int method) {
+  if (ctl->rng_type != 1)
+    die("oracle restates RNG_TYPE=1 (Squares) only");
+  double *rs = cache->rs;
+  const uint64_t base = cache->rng_ctr;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n + 1; ++i)
+    rs[i] = (double) orc_squares(base + i) / (double) UINT64_MAX;
+  cache->rng_ctr += n + 1;
+  if (method == 1) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i += 2) {
+      const double r = sqrt(-2.0 * log(rs[i]));
+      const double phi = 2.0 * M_PI * rs[i + 1];
+      rs[i] = r * cosf((float) phi);
+      rs[i + 1] = r * sinf((float) phi);
+    }
+  }
+}
+
+/* ---- module_timesteps (mptrac.c:5999-6073) ------------------------------ */
+
+void orc_module_timesteps(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                          const orc_atm_t *atm, double t) {
+  /* gsl_stats_min/max over the latitude axis, mptrac.c:6009-6010 */
+  double latmin = met0->lat[0], latmax = met0->lat[0];
+  for (int j = 1; j < met0->ny; j++) {
+    latmin = dmin(latmin, met0->lat[j]);
+    latmax = dmax(latmax, met0->lat[j]);
+  }
+  const int local = (fabs(met0->lon[met0->nx - 1] - met0->lon[0] - 360.0) >= 0.01);
+  const double dir = ctl->direction;
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    const double tp = atm->time[ip];
+    if (dir * (tp - ctl->t_start) >= 0 && dir * (tp - ctl->t_stop) <= 0 && dir * (tp - t) < 0)
+      cache->dt[ip] = t - tp;
+    else
+      cache->dt[ip] = 0.0;
+    if (local && (atm->lon[ip] <= met0->lon[0] || atm->lon[ip] >= met0->lon[met0->nx - 1]
+                  || atm->lat[ip] <= latmin || atm->lat[ip] >= latmax))
+      cache->dt[ip] = 0.0;
+  }
+}
+
+void orc_module_timesteps_init(orc_ctl_t *ctl, const orc_atm_t *atm) {
+  /* mptrac.c:6046-6073 */
+  double tmin = atm->time[0], tmax = atm->time[0];
+  for (int ip = 1; ip < atm->np; ip++) {
+    tmin = dmin(tmin, atm->time[ip]);
+    tmax = dmax(tmax, atm->time[ip]);
+  }
+  if (ctl->direction == 1) {
+    ctl->t_start = tmin;
+    if (ctl->t_stop > 1e99)
+      ctl->t_stop = tmax;
+  } else {
+    ctl->t_start = tmax;
+    if (ctl->t_stop > 1e99)
+      ctl->t_stop = tmin;
+  }
+  if (ctl->direction * (ctl->t_stop - ctl->t_start) <= 0)
+    die("Nothing to do! Check T_STOP and DIRECTION!");
+  if (ctl->direction == 1)
+    ctl->t_start = floor(ctl->t_start / ctl->dt_mod) * ctl->dt_mod;
+  else
+    ctl->t_start = ceil(ctl->t_start / ctl->dt_mod) * ctl->dt_mod;
+}
+
+/* ---- module_position (mptrac.c:5435-5489) ------------------------------- */
+
+void orc_module_position(const orc_cache_t *cache, const orc_met_t *met0, const orc_met_t *met1,
+                         orc_atm_t *atm) {
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    double lon = atm->lon[ip], lat = atm->lat[ip], p = atm->p[ip];
+    if (met0->coord_type == 0) {
+      lon = fmod_trunc(lon, 360.);
+      lat = fmod_trunc(lat, 360.);
+      while (lat < -90 || lat > 90) {
+        if (lat > 90) {
+          lat = 180 - lat;
+          lon += 180;
+        }
+        if (lat < -90) {
+          lat = -180 - lat;
+          lon += 180;
+        }
+      }
+      while (lon < -180)
+        lon += 360;
+      while (lon >= 180)
+        lon -= 360;
+    } else {
+      double lon2, lat2;
+      check_cartesian(met0, lon, lat, &lon2, &lat2);
+      lon = lon2;
+      lat = lat2;
+    }
+    const double ptop = met0->p[met0->np - 1];
+    if (p < ptop) {
+      p = ptop * ptop / p;
+    } else if (p > 300.) {
+      /* INTPOL_2D(ps, 0) on a freshly zeroed stencil (mptrac.c:5449, 5484):
+       * indices 0 and weights 0 select grid node [1][1] -- reference quirk,
+       * reproduced as is. */
+      stencil_t s = STENCIL_ZERO;
+      const double ps = time_2d(met0, met1, ORC_PS, atm->time[ip], lon, lat, &s, 0);
+      if (p > ps)
+        p = ps * ps / p;
+    }
+    atm->lon[ip] = lon;
+    atm->lat[ip] = lat;
+    atm->p[ip] = p;
+  }
+}
+
+/* ---- module_advect, pressure-level branch (mptrac.c:3609-3678) ---------- */
+
+void orc_module_advect(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                       const orc_met_t *met1, orc_atm_t *atm) {
+  if (ctl->advect_vert_coord != 0)
+    die("oracle restates ADVECT_VERT_COORD=0 only");
+  const int ct = met0->coord_type;
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    const double dt = cache->dt[ip];
+    stencil_t s = STENCIL_ZERO;
+    double u[4], v[4], w[4], um = 0, vm = 0, wm = 0;
+    double x0 = 0, x1 = 0, x2 = 0;
+    for (int i = 0; i < ctl->advect; i++) {
+      double dts;
+      if (i == 0) {
+        dts = 0.0;
+        x0 = atm->lon[ip];
+        x1 = atm->lat[ip];
+        x2 = atm->p[ip];
+      } else {
+        dts = (i == 3 ? 1.0 : 0.5) * dt;
+        x0 = atm->lon[ip] + dx2coord(ct, dts * u[i - 1], atm->lat[ip]);
+        x1 = atm->lat[ip] + dy2coord(ct, dts * v[i - 1]);
+        x2 = atm->p[ip] + dts * w[i - 1];
+      }
+      const double tm = atm->time[ip] + dts;
+      u[i] = time_3d(met0, met1, ORC_U, tm, x2, x0, x1, &s, 1);
+      v[i] = time_3d(met0, met1, ORC_V, tm, x2, x0, x1, &s, 0);
+      w[i] = time_3d(met0, met1, ORC_W, tm, x2, x0, x1, &s, 0);
+      double k = 1.0;
+      if (ctl->advect == 2)
+        k = (i == 0 ? 0.0 : 1.0);
+      else if (ctl->advect == 4)
+        k = (i == 0 || i == 3 ? 1.0 / 6.0 : 2.0 / 6.0);
+      um += k * u[i];
+      vm += k * v[i];
+      wm += k * w[i];
+    }
+    atm->time[ip] += dt;
+    atm->lon[ip] += dx2coord(ct, dt * um, (ctl->advect == 2 ? x1 : atm->lat[ip]));
+    atm->lat[ip] += dy2coord(ct, dt * vm);
+    atm->p[ip] += dt * wm;
+  }
+}
+
+/* ---- module_diff_turb (mptrac.c:4588-4734) ------------------------------ */
+
+static double kz_blend(const orc_ctl_t *ctl, const orc_clim_t *clim, double time, double lat,
+                       double p, double pbl, double ps) {
+  /* the Kz expression evaluated at a displaced pressure (mptrac.c:4669-4688);
+   * the reference overwrites atm->p[ip] temporarily, the value is the same */
+  const double wpbl = orc_pbl_weight(ctl, p, pbl, ps);
+  const double wtrop = orc_tropo_weight(ctl, clim, time, lat, p) * (1.0 - wpbl);
+  const double wstrat = 1.0 - wpbl - wtrop;
+  return wpbl * ctl->turb_dz_pbl + wtrop * ctl->turb_dz_trop + wstrat * ctl->turb_dz_strat;
+}
+
+void orc_module_diff_turb(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
+                          const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm) {
+  orc_module_rng(ctl, cache, 3 * (size_t) atm->np, 1);
+  const int ct = met0->coord_type;
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    stencil_t s = STENCIL_ZERO;
+    const double pbl = time_2d(met0, met1, ORC_PBL, atm->time[ip], atm->lon[ip], atm->lat[ip], &s, 1);
+    if (ctl->turb_pbl_scheme > 0 && atm->p[ip] >= pbl)
+      continue;
+    const double ps = time_2d(met0, met1, ORC_PS, atm->time[ip], atm->lon[ip], atm->lat[ip], &s, 0);
+    const double ptop = met0->p[met0->np - 1];
+
+    const double wpbl = orc_pbl_weight(ctl, atm->p[ip], pbl, ps);
+    const double wtrop = orc_tropo_weight(ctl, clim, atm->time[ip], atm->lat[ip], atm->p[ip]) * (1.0 - wpbl);
+    const double wstrat = 1.0 - wpbl - wtrop;
+    const double Kx = wpbl * ctl->turb_dx_pbl + wtrop * ctl->turb_dx_trop + wstrat * ctl->turb_dx_strat;
+    const double Kz = wpbl * ctl->turb_dz_pbl + wtrop * ctl->turb_dz_trop + wstrat * ctl->turb_dz_strat;
+    const double dt_abs = fabs(cache->dt[ip]);
+
+    if (Kx > 0) {
+      const double sigma_h = sqrt(2.0 * Kx * dt_abs);
+      atm->lon[ip] += dx2coord(ct, cache->rs[3 * (size_t) ip] * sigma_h, atm->lat[ip]);
+      atm->lat[ip] += dy2coord(ct, cache->rs[3 * (size_t) ip + 1] * sigma_h);
+    }
+
+    if (Kz > 0) {
+      const double sigma_z = sqrt(2.0 * Kz * dt_abs) * 1e-3;
+      const double p_save = atm->p[ip];
+      const double eps_km = 0.01;
+      const double p_up = p_save + dz2dp(eps_km, p_save);
+      const double p_dn = p_save + dz2dp(-eps_km, p_save);
+      /* note: the latitude used here is the one already displaced above */
+      const double Kz_up = kz_blend(ctl, clim, atm->time[ip], atm->lat[ip],
+                                    dmax(ptop, dmin(ps, p_up)), pbl, ps);
+      const double Kz_dn = kz_blend(ctl, clim, atm->time[ip], atm->lat[ip],
+                                    dmax(ptop, dmin(ps, p_dn)), pbl, ps);
+      const double dKz_dz = (Kz_up - Kz_dn) / (2.0 * eps_km * 1e3);
+      const double dlnrho_dz = -1.0 / (1e3 * C_H0);
+      const double w_drift = dKz_dz + Kz * dlnrho_dz;
+      const double dz_drift = w_drift * dt_abs * 1e-3;
+      const double dz_tot = cache->rs[3 * (size_t) ip + 2] * sigma_z + dz_drift;
+      double ptrial = p_save + dz2dp(dz_tot, p_save);
+      for (int iter = 0; iter < 10; iter++) {
+        if (ptrial > ps)
+          ptrial = ps * ps / ptrial;
+        else if (ptrial < ptop)
+          ptrial = ptop * ptop / ptrial;
+        else
+          break;
+      }
+      atm->p[ip] = dmax(ptop, dmin(ps, ptrial));
+    }
+  }
+}
+
+/* ---- module_diff_meso (mptrac.c:4266-4339) ------------------------------ */
+
+void orc_module_diff_meso(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                          const orc_met_t *met1, orc_atm_t *atm) {
+  orc_module_rng(ctl, cache, 3 * (size_t) atm->np, 1);
+  const int ct = met0->coord_type;
+  const float *u0 = met0->f3[ORC_U], *v0 = met0->f3[ORC_V], *w0 = met0->f3[ORC_W];
+  const float *u1 = met1->f3[ORC_U], *v1 = met1->f3[ORC_V], *w1 = met1->f3[ORC_W];
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    /* raw (un-wrapped) coordinates, mptrac.c:4283-4285 */
+    const int ix = orc_locate_reg(met0->lon, met0->nx, atm->lon[ip]);
+    const int iy = orc_locate_irr(met0->lat, met0->ny, atm->lat[ip]);
+    const int iz = orc_locate_irr(met0->p, met0->np, atm->p[ip]);
+
+    /* single-precision statistics over the 2x2x2x2 neighbourhood, loop order
+     * i (lon), j (lat), k (level), met0 before met1 (mptrac.c:4288-4311) */
+    float umean = 0, usig = 0, vmean = 0, vsig = 0, wmean = 0, wsig = 0;
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++)
+        for (int k = 0; k < 2; k++) {
+          const float a = A3(u0, met0, ix + i, iy + j, iz + k);
+          const float b = A3(v0, met0, ix + i, iy + j, iz + k);
+          const float c = A3(w0, met0, ix + i, iy + j, iz + k);
+          umean += a;
+          usig += a * a;
+          vmean += b;
+          vsig += b * b;
+          wmean += c;
+          wsig += c * c;
+          const float d = A3(u1, met0, ix + i, iy + j, iz + k);
+          const float e = A3(v1, met0, ix + i, iy + j, iz + k);
+          const float f = A3(w1, met0, ix + i, iy + j, iz + k);
+          umean += d;
+          usig += d * d;
+          vmean += e;
+          vsig += e * e;
+          wmean += f;
+          wsig += f * f;
+        }
+    usig = usig / 16.f - SQ(umean / 16.f);
+    usig = (usig > 0 ? sqrtf(usig) : 0);
+    vsig = vsig / 16.f - SQ(vmean / 16.f);
+    vsig = (vsig > 0 ? sqrtf(vsig) : 0);
+    wsig = wsig / 16.f - SQ(wmean / 16.f);
+    wsig = (wsig > 0 ? sqrtf(wsig) : 0);
+
+    const double r = 1 - 2 * fabs(cache->dt[ip]) / ctl->dt_met;
+    const double r2 = sqrt(1 - r * r);
+    float *uvwp = &cache->uvwp[3 * (size_t) ip];
+
+    if (ctl->turb_mesox > 0) {
+      uvwp[0] = (float) (r * uvwp[0] + r2 * cache->rs[3 * (size_t) ip] * ctl->turb_mesox * usig);
+      atm->lon[ip] += dx2coord(ct, uvwp[0] * cache->dt[ip], atm->lat[ip]);
+      uvwp[1] = (float) (r * uvwp[1] + r2 * cache->rs[3 * (size_t) ip + 1] * ctl->turb_mesox * vsig);
+      atm->lat[ip] += dy2coord(ct, uvwp[1] * cache->dt[ip]);
+    }
+    if (ctl->turb_mesoz > 0) {
+      uvwp[2] = (float) (r * uvwp[2] + r2 * cache->rs[3 * (size_t) ip + 2] * ctl->turb_mesoz * wsig);
+      atm->p[ip] += uvwp[2] * cache->dt[ip];
+    }
+  }
+}
+
+/* ---- module_convection (mptrac.c:4102-4171) ----------------------------- */
+
+void orc_module_convection(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                           const orc_met_t *met1, orc_atm_t *atm) {
+  orc_module_rng(ctl, cache, (size_t) atm->np, 0);
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    const double tp = atm->time[ip], lon = atm->lon[ip], lat = atm->lat[ip];
+    stencil_t s = STENCIL_ZERO;
+    const double ps = time_2d(met0, met1, ORC_PS, tp, lon, lat, &s, 1);
+    double pbot = ps, ptop = ps;
+    if (ctl->conv_mix_pbl) {
+      const double pbl = time_2d(met0, met1, ORC_PBL, tp, lon, lat, &s, 0);
+      ptop = pbl - ctl->conv_pbl_trans * (ps - pbl);
+    }
+    if (ctl->conv_cape >= 0) {
+      const double cape = time_2d(met0, met1, ORC_CAPE, tp, lon, lat, &s, 0);
+      const double cin = time_2d(met0, met1, ORC_CIN, tp, lon, lat, &s, 0);
+      const double pel = time_2d(met0, met1, ORC_PEL, tp, lon, lat, &s, 0);
+      if (isfinite(cape) && cape >= ctl->conv_cape
+          && (ctl->conv_cin <= 0 || (isfinite(cin) && cin >= ctl->conv_cin)))
+        ptop = dmin(ptop, pel);     /* GSL_MIN */
+    }
+    if (ptop != pbot && atm->p[ip] >= ptop) {
+      const double tbot = time_3d(met0, met1, ORC_T, tp, pbot, lon, lat, &s, 1);
+      const double ttop = time_3d(met0, met1, ORC_T, tp, ptop, lon, lat, &s, 1);
+      const double rhobot = pbot / tbot;
+      const double rhotop = ptop / ttop;
+      const double rho = rhobot + (rhotop - rhobot) * cache->rs[ip];
+      atm->p[ip] = lin(rhobot, pbot, rhotop, ptop, rho);
+    }
+  }
+}
+
+/* ---- module_sedi (mptrac.c:5859-5883) ----------------------------------- */
+
+void orc_module_sedi(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                     const orc_met_t *met1, orc_atm_t *atm) {
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    stencil_t s = STENCIL_ZERO;
+    const double t = time_3d(met0, met1, ORC_T, atm->time[ip], atm->p[ip], atm->lon[ip],
+                             atm->lat[ip], &s, 1);
+    const double v_s = orc_sedi(atm->p[ip], t, atm->q[ctl->qnt_rp][ip], atm->q[ctl->qnt_rhop][ip]);
+    atm->p[ip] += dz2dp(v_s * cache->dt[ip] / 1000., atm->p[ip]);
+  }
+}
+
+/* ---- module_decay (mptrac.c:4227-4262) ---------------------------------- */
+
+void orc_module_decay(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_clim_t *clim,
+                      orc_atm_t *atm) {
+  if (ctl->qnt_m < 0 && ctl->qnt_vmr < 0)
+    die("Module needs quantity mass or volume mixing ratio!");
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    const double w = orc_tropo_weight(ctl, clim, atm->time[ip], atm->lat[ip], atm->p[ip]);
+    const double tdec = w * ctl->tdec_trop + (1 - w) * ctl->tdec_strat;
+    const double aux = exp(-cache->dt[ip] / tdec);
+    if (ctl->qnt_m >= 0) {
+      if (ctl->qnt_mloss_decay >= 0)
+        atm->q[ctl->qnt_mloss_decay][ip] += atm->q[ctl->qnt_m][ip] * (1 - aux);
+      atm->q[ctl->qnt_m][ip] *= aux;
+      if (ctl->qnt_loss_rate >= 0)
+        atm->q[ctl->qnt_loss_rate][ip] += 1. / tdec;
+    }
+    if (ctl->qnt_vmr >= 0)
+      atm->q[ctl->qnt_vmr][ip] *= aux;
+  }
+}
+
+/* ---- module_mixing (mptrac.c:5169-5347) --------------------------------- */
+
+static void mixing_one(const orc_ctl_t *ctl, const orc_clim_t *clim, orc_atm_t *atm,
+                       const int *ixs, const int *iys, const int *izs, int qnt) {
+  /* module_mixing_help, mptrac.c:5249-5347; the accumulation loop is serial
+   * in the CPU build of the reference (no pragma at l.5289) */
+  const int np = atm->np;
+  const int ngrid = ctl->mixing_nx * ctl->mixing_ny * ctl->mixing_nz;
+  const int use_ens = (ctl->nens > 0);
+  const int nens = use_ens ? ctl->nens : 1;
+  const size_t total = (size_t) ngrid * (size_t) nens;
+  double *cmean = calloc(total, sizeof(double));
+  int *count = calloc(total, sizeof(int));
+  if (!cmean || !count)
+    die("Out of memory!");
+  for (int ip = 0; ip < np; ip++)
+    if (izs[ip] >= 0) {
+      const int ens = use_ens ? (int) atm->q[ctl->qnt_ens][ip] : 0;
+      const int idx = ens * ngrid + (ixs[ip] * ctl->mixing_ny + iys[ip]) * ctl->mixing_nz + izs[ip];
+      cmean[idx] += atm->q[qnt][ip];
+      count[idx]++;
+    }
+  for (size_t i = 0; i < total; i++)
+    if (count[i] > 0)
+      cmean[i] /= count[i];
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < np; ip++)
+    if (izs[ip] >= 0) {
+      const int ens = use_ens ? (int) atm->q[ctl->qnt_ens][ip] : 0;
+      double mixparam = 1.0;
+      if (ctl->mixing_trop < 1 || ctl->mixing_strat < 1) {
+        const double w = orc_tropo_weight(ctl, clim, atm->time[ip], atm->lat[ip], atm->p[ip]);
+        mixparam = w * ctl->mixing_trop + (1.0 - w) * ctl->mixing_strat;
+      }
+      const int idx = ens * ngrid + (ixs[ip] * ctl->mixing_ny + iys[ip]) * ctl->mixing_nz + izs[ip];
+      atm->q[qnt][ip] += (cmean[idx] - atm->q[qnt][ip]) * mixparam;
+    }
+  free(cmean);
+  free(count);
+}
+
+void orc_module_mixing(const orc_ctl_t *ctl, const orc_clim_t *clim, orc_atm_t *atm, double t) {
+  const int np = atm->np;
+  int *ixs = malloc((size_t) np * sizeof(int));
+  int *iys = malloc((size_t) np * sizeof(int));
+  int *izs = malloc((size_t) np * sizeof(int));
+  if (!ixs || !iys || !izs)
+    die("Out of memory!");
+  const double dz = (ctl->mixing_z1 - ctl->mixing_z0) / ctl->mixing_nz;
+  const double dlon = (ctl->mixing_lon1 - ctl->mixing_lon0) / ctl->mixing_nx;
+  const double dlat = (ctl->mixing_lat1 - ctl->mixing_lat0) / ctl->mixing_ny;
+  const double t0 = t - 0.5 * ctl->dt_mod;
+  const double t1 = t + 0.5 * ctl->dt_mod;
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < np; ip++) {
+    const double zpart = zfromp(atm->p[ip]);
+    ixs[ip] = iys[ip] = 0;
+    if (atm->time[ip] < t0 || atm->time[ip] > t1
+        || atm->lon[ip] < ctl->mixing_lon0 || atm->lon[ip] >= ctl->mixing_lon1
+        || atm->lat[ip] < ctl->mixing_lat0 || atm->lat[ip] >= ctl->mixing_lat1
+        || zpart < ctl->mixing_z0 || zpart >= ctl->mixing_z1) {
+      izs[ip] = -1;
+      continue;
+    }
+    ixs[ip] = (int) ((atm->lon[ip] - ctl->mixing_lon0) / dlon);
+    iys[ip] = (int) ((atm->lat[ip] - ctl->mixing_lat0) / dlat);
+    izs[ip] = (int) ((zpart - ctl->mixing_z0) / dz);
+    if (ixs[ip] >= ctl->mixing_nx || iys[ip] >= ctl->mixing_ny || izs[ip] >= ctl->mixing_nz)
+      izs[ip] = -1;
+  }
+  /* of the reference's quantity list (mptrac.c:5223-5230) the hot-path subset
+   * carries mass and volume mixing ratio, in this order */
+  const int quantities[2] = { ctl->qnt_m, ctl->qnt_vmr };
+  for (int i = 0; i < 2; i++)
+    if (quantities[i] >= 0)
+      mixing_one(ctl, clim, atm, ixs, iys, izs, quantities[i]);
+  free(ixs);
+  free(iys);
+  free(izs);
+}
+
+/* ---- deposition (mptrac.c:6155-6290, 4738-4797) ------------------------- */
+
+static void apply_loss(const orc_ctl_t *ctl, orc_atm_t *atm, int ip, double aux, int qnt_mloss,
+                       double rate) {
+  /* common tail of decay / wet / dry deposition (e.g. mptrac.c:6279-6288) */
+  if (ctl->qnt_m >= 0) {
+    if (qnt_mloss >= 0)
+      atm->q[qnt_mloss][ip] += atm->q[ctl->qnt_m][ip] * (1 - aux);
+    atm->q[ctl->qnt_m][ip] *= aux;
+    if (ctl->qnt_loss_rate >= 0)
+      atm->q[ctl->qnt_loss_rate][ip] += rate;
+  }
+  if (ctl->qnt_vmr >= 0)
+    atm->q[ctl->qnt_vmr][ip] *= aux;
+}
+
+void orc_module_wet_depo(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                         const orc_met_t *met1, orc_atm_t *atm) {
+  if (ctl->qnt_m < 0 && ctl->qnt_vmr < 0)
+    die("Module needs quantity mass or volume mixing ratio!");
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    const double tp = atm->time[ip], lon = atm->lon[ip], lat = atm->lat[ip], p = atm->p[ip];
+    stencil_t s = STENCIL_ZERO;
+    const double pct = time_2d(met0, met1, ORC_PCT, tp, lon, lat, &s, 1);
+    if (!isfinite(pct) || p <= pct)
+      continue;
+    const double pcb = time_2d(met0, met1, ORC_PCB, tp, lon, lat, &s, 0);
+    const double cl = time_2d(met0, met1, ORC_CL, tp, lon, lat, &s, 0);
+    const double Is = pow(1. / ctl->wet_depo_pre[0] * cl, 1. / ctl->wet_depo_pre[1]);
+    if (Is < 0.01)
+      continue;
+    const double lwc = time_3d(met0, met1, ORC_LWC, tp, p, lon, lat, &s, 1);
+    const double rwc = time_3d(met0, met1, ORC_RWC, tp, p, lon, lat, &s, 0);
+    const double iwc = time_3d(met0, met1, ORC_IWC, tp, p, lon, lat, &s, 0);
+    const double swc = time_3d(met0, met1, ORC_SWC, tp, p, lon, lat, &s, 0);
+    const int inside = (lwc > 0 || rwc > 0 || iwc > 0 || swc > 0);
+    const double t = time_3d(met0, met1, ORC_T, tp, p, lon, lat, &s, 0);
+
+    double lambda = 0;
+    if (inside) {
+      double eta;
+      if (t > C_WD_T_LIQUID)
+        eta = 1;
+      else if (t <= C_WD_T_ICE)
+        eta = ctl->wet_depo_ic_ret_ratio;
+      else
+        eta = lin(C_WD_T_LIQUID, 1, C_WD_T_ICE, ctl->wet_depo_ic_ret_ratio, t);
+      if (ctl->wet_depo_ic_a > 0)
+        lambda = ctl->wet_depo_ic_a * pow(Is, ctl->wet_depo_ic_b) * eta;
+      else if (ctl->wet_depo_ic_h[0] > 0) {
+        double h = ctl->wet_depo_ic_h[0] * exp(ctl->wet_depo_ic_h[1] * (1. / t - 1. / C_TREF));
+        if (ctl->wet_depo_so2_ph > 0) {
+          const double H_ion = pow(10., -ctl->wet_depo_so2_ph);
+          const double K_1 = C_SO2_K1_REF * exp(C_SO2_K1_TEMP * (1. / t - 1. / C_TREF));
+          const double K_2 = C_SO2_K2_REF * exp(C_SO2_K2_TEMP * (1. / t - 1. / C_TREF));
+          h *= (1. + K_1 / H_ion + K_1 * K_2 / SQ(H_ion));
+        }
+        const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
+        lambda = h * C_RI * t * Is / 3.6e6 / dz * eta;
+      }
+    } else {
+      const double eta = (t > C_WD_T_LIQUID_BC) ? 1 : ctl->wet_depo_bc_ret_ratio;
+      if (ctl->wet_depo_bc_a > 0)
+        lambda = ctl->wet_depo_bc_a * pow(Is, ctl->wet_depo_bc_b) * eta;
+      else if (ctl->wet_depo_bc_h[0] > 0) {
+        const double h = ctl->wet_depo_bc_h[0] * exp(ctl->wet_depo_bc_h[1] * (1. / t - 1. / C_TREF));
+        const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
+        lambda = h * C_RI * t * Is / 3.6e6 / dz * eta;
+      }
+    }
+    const double aux = exp(-cache->dt[ip] * lambda);
+    apply_loss(ctl, atm, ip, aux, ctl->qnt_mloss_wet, lambda);
+  }
+}
+
+void orc_module_dry_depo(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                         const orc_met_t *met1, orc_atm_t *atm) {
+  if (ctl->qnt_m < 0 && ctl->qnt_vmr < 0)
+    die("Module needs quantity mass or volume mixing ratio!");
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    stencil_t s = STENCIL_ZERO;
+    const double ps = time_2d(met0, met1, ORC_PS, atm->time[ip], atm->lon[ip], atm->lat[ip], &s, 1);
+    if (atm->p[ip] < ps - ctl->dry_depo_dp)
+      continue;
+    const double dz = 1000. * (zfromp(ps - ctl->dry_depo_dp) - zfromp(ps));
+    double v_dep;
+    /* the reference tests the quantity indices with "> 0" here (mptrac.c:4769) */
+    if (ctl->qnt_rp > 0 && ctl->qnt_rhop > 0) {
+      const double t = time_3d(met0, met1, ORC_T, atm->time[ip], atm->p[ip], atm->lon[ip],
+                               atm->lat[ip], &s, 1);
+      v_dep = orc_sedi(atm->p[ip], t, atm->q[ctl->qnt_rp][ip], atm->q[ctl->qnt_rhop][ip]);
+    } else
+      v_dep = ctl->dry_depo_vdep;
+    const double aux = exp(-cache->dt[ip] * v_dep / dz);
+    apply_loss(ctl, atm, ip, aux, ctl->qnt_mloss_dry, v_dep / dz);
+  }
+}
+
+/* ---- module_sort (mptrac.c:5887-5995) ----------------------------------- */
+
+typedef struct {
+  long long key;
+  int idx;
+} sort_item_t;
+
+static int sort_cmp(const void *a, const void *b) {
+  const sort_item_t *x = a, *y = b;
+  if (x->key != y->key)
+    return x->key < y->key ? -1 : 1;
+  return (x->idx > y->idx) - (x->idx < y->idx);     /* ties: original index */
+}
+
+void orc_module_sort(const orc_ctl_t *ctl, const orc_met_t *met0, orc_atm_t *atm, double *keys,
+                     int *perm) {
+  const int np = atm->np;
+  sort_item_t *items = malloc((size_t) np * sizeof(sort_item_t));
+  double *help = malloc((size_t) np * sizeof(double));
+  if (!items || !help)
+    die("Out of memory!");
+  /* key on raw coordinates, mptrac.c:5913-5919 */
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < np; ip++) {
+    const int k = (orc_locate_reg(met0->lon, met0->nx, atm->lon[ip]) * met0->ny
+                   + orc_locate_irr(met0->lat, met0->ny, atm->lat[ip])) * met0->np
+      + orc_locate_irr(met0->p, met0->np, atm->p[ip]);
+    items[ip].key = k;
+    items[ip].idx = ip;
+    if (keys)
+      keys[ip] = (double) k;
+  }
+  qsort(items, (size_t) np, sizeof(sort_item_t), sort_cmp);
+  if (perm)
+    for (int ip = 0; ip < np; ip++)
+      perm[ip] = items[ip].idx;
+  /* gather every array through the permutation, mptrac.c:5944-5949, 5980-5988 */
+  double *arrays[4 + ORC_NQ_MAX];
+  int na = 0;
+  arrays[na++] = atm->time;
+  arrays[na++] = atm->p;
+  arrays[na++] = atm->lon;
+  arrays[na++] = atm->lat;
+  for (int iq = 0; iq < ctl->nq; iq++)
+    arrays[na++] = atm->q[iq];
+  for (int a = 0; a < na; a++) {
+#pragma omp parallel for schedule(static)
+    for (int ip = 0; ip < np; ip++)
+      help[ip] = arrays[a][items[ip].idx];
+    memcpy(arrays[a], help, (size_t) np * sizeof(double));
+  }
+  free(items);
+  free(help);
+}
+
+/* ---- scheduler: mptrac_run_timestep (mptrac.c:7851-8001) ---------------- */
+
+void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
+                      const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm, double t) {
+  orc_module_timesteps(ctl, cache, met0, atm, t);
+  if (ctl->sort_dt > 0 && fmod(t, ctl->sort_dt) == 0)
+    orc_module_sort(ctl, met0, atm, NULL, NULL);
+  orc_module_position(cache, met0, met1, atm);
+  if (ctl->advect > 0)
+    orc_module_advect(ctl, cache, met0, met1, atm);
+  if (ctl->diffusion
+      && (ctl->turb_dx_pbl > 0 || ctl->turb_dz_pbl > 0 || ctl->turb_dx_trop > 0
+          || ctl->turb_dz_trop > 0 || ctl->turb_dx_strat > 0 || ctl->turb_dz_strat > 0))
+    orc_module_diff_turb(ctl, cache, clim, met0, met1, atm);
+  if (ctl->diffusion && ctl->turb_pbl_scheme == 1)
+    die("oracle does not restate module_diff_pbl");
+  if (ctl->diffusion && (ctl->turb_mesox > 0 || ctl->turb_mesoz > 0))
+    orc_module_diff_meso(ctl, cache, met0, met1, atm);
+  if ((ctl->conv_mix_pbl || ctl->conv_cape >= 0)
+      && (ctl->conv_dt <= 0 || fmod(t, ctl->conv_dt) == 0))
+    orc_module_convection(ctl, cache, met0, met1, atm);
+  if (ctl->qnt_rp >= 0 && ctl->qnt_rhop >= 0)
+    orc_module_sedi(ctl, cache, met0, met1, atm);
+  orc_module_position(cache, met0, met1, atm);
+  /* zero the total loss rate, mptrac.c:7932-7936 */
+  if (ctl->qnt_loss_rate >= 0)
+    for (int ip = 0; ip < atm->np; ip++)
+      if (cache->dt[ip] != 0)
+        atm->q[ctl->qnt_loss_rate][ip] = 0;
+  if (ctl->tdec_trop > 0 && ctl->tdec_strat > 0)
+    orc_module_decay(ctl, cache, clim, atm);
+  if (ctl->mixing_trop >= 0 && ctl->mixing_strat >= 0
+      && (ctl->mixing_dt <= 0 || fmod(t, ctl->mixing_dt) == 0))
+    orc_module_mixing(ctl, clim, atm, t);
+  if ((ctl->wet_depo_ic_a > 0 || ctl->wet_depo_ic_h[0] > 0)
+      && (ctl->wet_depo_bc_a > 0 || ctl->wet_depo_bc_h[0] > 0))
+    orc_module_wet_depo(ctl, cache, met0, met1, atm);
+  if (ctl->dry_depo_vdep > 0)
+    orc_module_dry_depo(ctl, cache, met0, met1, atm);
+}
+
+/* ---- write_grid binning (mptrac.c:13815-13872) -------------------------- */
+
+void orc_grid_sums(const orc_ctl_t *ctl, const orc_atm_t *atm, double t, int *cnt, double *mean,
+                   double *sigma) {
+  const size_t ncell = (size_t) ctl->grid_nx * (size_t) ctl->grid_ny * (size_t) ctl->grid_nz;
+  memset(cnt, 0, ncell * sizeof(int));
+  memset(mean, 0, ncell * (size_t) ctl->nq * sizeof(double));
+  memset(sigma, 0, ncell * (size_t) ctl->nq * sizeof(double));
+  const double dz = (ctl->grid_z1 - ctl->grid_z0) / ctl->grid_nz;
+  const double dlon = (ctl->grid_lon1 - ctl->grid_lon0) / ctl->grid_nx;
+  const double dlat = (ctl->grid_lat1 - ctl->grid_lat0) / ctl->grid_ny;
+  const double t0 = t - 0.5 * ctl->dt_mod;
+  const double t1 = t + 0.5 * ctl->dt_mod;
+  for (int ip = 0; ip < atm->np; ip++) {
+    const double zpart = zfromp(atm->p[ip]);
+    if (atm->time[ip] < t0 || atm->time[ip] > t1
+        || atm->lon[ip] < ctl->grid_lon0 || atm->lon[ip] >= ctl->grid_lon1
+        || atm->lat[ip] < ctl->grid_lat0 || atm->lat[ip] >= ctl->grid_lat1
+        || zpart < ctl->grid_z0 || zpart >= ctl->grid_z1)
+      continue;
+    const int ix = (int) ((atm->lon[ip] - ctl->grid_lon0) / dlon);
+    const int iy = (int) ((atm->lat[ip] - ctl->grid_lat0) / dlat);
+    const int iz = (int) ((zpart - ctl->grid_z0) / dz);
+    if (ix >= ctl->grid_nx || iy >= ctl->grid_ny || iz >= ctl->grid_nz)
+      continue;
+    const size_t idx = ((size_t) ix * (size_t) ctl->grid_ny + (size_t) iy) * (size_t) ctl->grid_nz + (size_t) iz;
+    const double kernel = 1.0;   /* kernel_weight without a kernel file, mptrac.c:3305-3306 */
+    cnt[idx]++;
+    for (int iq = 0; iq < ctl->nq; iq++) {
+      mean[(size_t) iq * ncell + idx] += kernel * atm->q[iq][ip];
+      sigma[(size_t) iq * ncell + idx] += SQ(kernel * atm->q[iq][ip]);
+    }
+  }
+}

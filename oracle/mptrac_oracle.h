@@ -1,0 +1,170 @@
+/*
+ * mptrac_oracle.h -- CPU oracle for the MPTRAC per-particle time-step loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C (C99 + OpenMP) restatement of
+ * the reference algorithm (slcs-jsc/mptrac, src/mptrac.c / src/mptrac.h); it is
+ * the checker that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg compare the HIP path against.  Nothing in the product path
+ * (mptrac_amd/, include/) may include, link or call it.
+ *
+ * Parity status: the reference itself cannot be compiled in this image
+ * (mptrac.h:174-182 includes GSL and netCDF headers unconditionally and the
+ * image has neither), so the oracle is pinned against the reference's own
+ * golden files instead -- see oracle/README.md for the list of pins.
+ *
+ * Every function cites the reference file:line it follows.  Arithmetic is kept
+ * in the reference's operation order so that results are bit-identical to a
+ * gcc -O3 (no FMA) build of the reference on x86-64.
+ */
+#ifndef MPTRAC_ORACLE_H
+#define MPTRAC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NQ_MAX 16
+
+/* 3-D met fields, each float [nx][ny][np] (level index fastest, mptrac.h:3964) */
+enum { ORC_U = 0, ORC_V, ORC_W, ORC_T, ORC_LWC, ORC_RWC, ORC_IWC, ORC_SWC, ORC_N3D };
+/* 2-D met fields, each float [nx][ny] */
+enum { ORC_PS = 0, ORC_PBL, ORC_CAPE, ORC_CIN, ORC_PEL, ORC_PCT, ORC_PCB, ORC_CL, ORC_N2D };
+
+/* Hot-path subset of ctl_t (mptrac.h:2494-3553).  Field names follow the
+ * reference.  Layout is mirrored 1:1 by the Python ctypes class. */
+typedef struct {
+  /* time control (mptrac.c:7015-7024) */
+  int direction;
+  int met_coord_type;
+  double t_start, t_stop, dt_mod, dt_met;
+  double met_utm_ref_lat;
+  /* quantities (mptrac.c:6737-6971); -1 = not present */
+  int nq;
+  int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens;
+  int qnt_loss_rate, qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry;
+  int nens;
+  /* modules */
+  int advect;             /* 1, 2 or 4 (mptrac.c:7218) */
+  int advect_vert_coord;  /* only 0 (pressure levels) restated */
+  int rng_type;           /* only 1 (Squares) restated */
+  int diffusion;
+  int turb_pbl_scheme;
+  int conv_mix_pbl;
+  double turb_dx_pbl, turb_dx_trop, turb_dx_strat;
+  double turb_dz_pbl, turb_dz_trop, turb_dz_strat;
+  double turb_mesox, turb_mesoz, turb_pbl_trans;
+  double conv_pbl_trans, conv_cape, conv_cin, conv_dt;
+  double sort_dt;
+  double tdec_trop, tdec_strat;
+  double mixing_dt, mixing_trop, mixing_strat;
+  double mixing_z0, mixing_z1, mixing_lon0, mixing_lon1, mixing_lat0, mixing_lat1;
+  int mixing_nx, mixing_ny, mixing_nz;
+  int pad0;
+  double wet_depo_pre[2];
+  double wet_depo_ic_a, wet_depo_ic_b, wet_depo_bc_a, wet_depo_bc_b;
+  double wet_depo_ic_h[2], wet_depo_bc_h[2];
+  double wet_depo_so2_ph, wet_depo_ic_ret_ratio, wet_depo_bc_ret_ratio;
+  double dry_depo_vdep, dry_depo_dp;
+  /* gridded output (mptrac.c:7631-7648) */
+  double grid_z0, grid_z1, grid_lon0, grid_lon1, grid_lat0, grid_lat1;
+  int grid_nx, grid_ny, grid_nz;
+  int pad1;
+} orc_ctl_t;
+
+/* One meteo snapshot: compact view of met_t (mptrac.h:3844-4014). */
+typedef struct {
+  double time;
+  int coord_type;
+  int nx, ny, np;
+  const double *lon, *lat, *p;
+  const float *f3[ORC_N3D];
+  const float *f2[ORC_N2D];
+} orc_met_t;
+
+/* Particle state, SoA as atm_t (mptrac.h:3563-3583). */
+typedef struct {
+  int np;
+  int nq;
+  double *time, *p, *lon, *lat;
+  double *q[ORC_NQ_MAX];
+} orc_atm_t;
+
+/* Per-particle scratch as cache_t (mptrac.h:3618-3641) + the file-static
+ * RNG counter (mptrac.c:35). */
+typedef struct {
+  double *dt;     /* [np]       */
+  double *rs;     /* [3*np + 1] */
+  float *uvwp;    /* [np][3]    */
+  uint64_t rng_ctr;
+} orc_cache_t;
+
+/* Climatological tropopause part of clim_t (mptrac.h:3785-3800). */
+typedef struct {
+  int tropo_ntime, tropo_nlat;
+  double tropo_time[12];
+  double tropo_lat[73];
+  double tropo[12][73];
+} orc_clim_t;
+
+size_t orc_sizeof_ctl(void);
+
+/* --- helpers ------------------------------------------------------------- */
+int orc_locate_irr(const double *xx, int n, double x);           /* mptrac.c:3495 */
+int orc_locate_reg(const double *xx, int n, double x);           /* mptrac.c:3559 */
+double orc_clim_tropo(const orc_clim_t *clim, double t, double lat);  /* mptrac.c:213 */
+double orc_sedi(double p, double T, double rp, double rhop);     /* mptrac.c:12506 */
+double orc_tropo_weight(const orc_ctl_t *ctl, const orc_clim_t *clim,
+                        double time, double lat, double p);      /* mptrac.c:12748 */
+double orc_pbl_weight(const orc_ctl_t *ctl, double p, double pbl, double ps); /* mptrac.c:8358 */
+uint64_t orc_squares(uint64_t ctr);                              /* mptrac.c:5797-5809 */
+void orc_intpol_met_time_3d(const orc_met_t *met0, const orc_met_t *met1, int field,
+                            double ts, double p, double lon, double lat, double *var);
+void orc_intpol_met_time_2d(const orc_met_t *met0, const orc_met_t *met1, int field,
+                            double ts, double lon, double lat, double *var);
+
+/* --- modules (mptrac.c:3598-6293) ---------------------------------------- */
+void orc_module_rng(const orc_ctl_t *ctl, orc_cache_t *cache, size_t n, int method);
+void orc_module_timesteps(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                          const orc_atm_t *atm, double t);
+void orc_module_timesteps_init(orc_ctl_t *ctl, const orc_atm_t *atm);
+void orc_module_position(const orc_cache_t *cache, const orc_met_t *met0,
+                         const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_advect(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                       const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_diff_turb(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
+                          const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_diff_meso(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                          const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_convection(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                           const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_sedi(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                     const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_decay(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_clim_t *clim,
+                      orc_atm_t *atm);
+void orc_module_mixing(const orc_ctl_t *ctl, const orc_clim_t *clim, orc_atm_t *atm, double t);
+void orc_module_wet_depo(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                         const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_dry_depo(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                         const orc_met_t *met1, orc_atm_t *atm);
+/* keys[np] (as the reference's double keys, exact integers) and perm[np] are
+ * optional outputs (may be NULL).  Ties are ordered by original index. */
+void orc_module_sort(const orc_ctl_t *ctl, const orc_met_t *met0, orc_atm_t *atm,
+                     double *keys, int *perm);
+
+/* --- scheduler (mptrac.c:7851-8001) -------------------------------------- */
+void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
+                      const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm, double t);
+
+/* --- write_grid binning (mptrac.c:13815-13872), kernel weight = 1 --------- */
+/* cnt[ncell] (int), mean[nq][ncell], sigma[nq][ncell] hold the raw sums
+ * (before the divide at mptrac.c:13906-13913). */
+void orc_grid_sums(const orc_ctl_t *ctl, const orc_atm_t *atm, double t,
+                   int *cnt, double *mean, double *sigma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+"""Pin the CPU oracle against everything the reference's own tests hold for
+the hot path: the `sedi` known-answer table, the dd_test
+golden trajectories, and the micro-KATs captured from the compiled reference
+during the survey.  CPU only."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+
+import refcases
+from mptrac_amd.clim import load_clim_tropo
+from mptrac_amd.synth import synthetic_met, synthetic_particles
+from oracle import binding as B
+
+GOLD = refcases.GOLD
+
+
+def test_sedi_matches_reference_tools_test_table():
+    """tests/tools_test/data.ref/sedi.tab: 144 cases printed with %g."""
+    txt = open(os.path.join(GOLD, "ref_tools_test", "sedi.tab")).read()
+    blocks = [b for b in txt.split("\n\n") if "v_s=" in b]
+    assert len(blocks) == 144
+    L = B.lib()
+    for b in blocks:
+        val = {k.strip(): v.split()[0] for k, v in (ln.split("=") for ln in b.strip().splitlines())}
+        vs = L.orc_sedi(float(val["p"]), float(val["T"]), float(val["r_p"]), float(val["rho_p"]))
+        assert "%g" % vs == val["v_s"], (val, vs)
+
+
+def _survey():
+    return json.load(open(os.path.join(GOLD, "survey_kats.json")))
+
+
+def test_survey_kats_scalar_helpers():
+    k = _survey()
+    L = B.lib()
+    for p, T, rp, rhop, want in k["sedi"]:
+        assert L.orc_sedi(p, T, rp, rhop) == want
+    xx = np.array(k["locate_axis"], dtype=np.float64)
+    yy = np.ascontiguousarray(xx[::-1])
+    dp = C.POINTER(C.c_double)
+    for x, want in k["locate_irr_asc"]:
+        assert L.orc_locate_irr(xx.ctypes.data_as(dp), len(xx), x) == want
+    for x, want in k["locate_irr_desc"]:
+        assert L.orc_locate_irr(yy.ctypes.data_as(dp), len(yy), x) == want
+    for x, want in k["locate_reg_asc"]:
+        assert L.orc_locate_reg(xx.ctypes.data_as(dp), len(xx), x) == want
+
+
+def _tiny_oracle(**ctl):
+    m0 = synthetic_met("tiny", 0.0, 1.0)
+    m1 = synthetic_met("tiny", 3600.0, 1.2)
+    return B.Oracle(ctl, load_clim_tropo(), m0, m1, synthetic_particles(8))
+
+
+def test_survey_kats_clim_tropo():
+    k = _survey()
+    o = _tiny_oracle()
+    for t, lat, want in k["clim_tropo"]:
+        assert o.lib.orc_clim_tropo(C.byref(o.clim), t, lat) == want
+
+
+def test_survey_kats_squares_rng():
+    k = _survey()
+    o = _tiny_oracle()
+    got = [o.lib.orc_squares(i) / 2.0 ** 64 for i in range(7)]
+    assert got == k["squares_uniform_ctr0_6"]
+    # the same through module_rng (uniform): ctr 0..6 consumed by n = 6 (+1)
+    o.lib.orc_module_rng(C.byref(o.ctl), C.byref(o.cache), 6, 0)
+    assert list(o.rs[:7]) == k["squares_uniform_ctr0_6"] and o.cache.rng_ctr == 7
+    # next call, normal: ctr 7..13, Box-Muller on flat pairs
+    o.lib.orc_module_rng(C.byref(o.ctl), C.byref(o.cache), 6, 1)
+    assert list(o.rs[:6]) == k["squares_normal_ctr7_n6"] and o.cache.rng_ctr == 14
+
+
+def test_dd_test_golden_trajectories():
+    """Midpoint advection through the wind-tool field reproduces the 6-digit
+    golden positions of tests/dd_test at every hourly output."""
+    ctl, atm, t0, gold = refcases.dd_test_case()
+    mets = [refcases.wind_tool_met(t0 + 3600.0 * i) for i in range(8)]
+    o = B.Oracle(ctl, load_clim_tropo(), mets[0], mets[1], atm)
+    o.timesteps_init()
+    assert o.ctl.t_start == t0
+    imet = 0
+    t = t0
+    nbad = 0
+    worst = 0.0
+    while True:
+        # mptrac_get_met: advance the bracketing pair when t passes met1
+        while t > o.met[1].time:
+            imet += 1
+            o.swap_met(mets[imet + 1])
+        o.run_timestep(t)
+        hours = (t - t0) / 3600.0
+        if hours == int(hours):
+            g = gold[int(hours)]
+            idx = o.q[0].astype(int)
+            order = np.argsort(idx)
+            assert np.array_equal(idx[order], g[:, 4].astype(int))
+            for col, arr in ((2, o.lon), (3, o.lat)):
+                for a, b in zip(arr[order], g[:, col]):
+                    if refcases.fmt_g(a) != b:
+                        nbad += 1
+                        worst = max(worst, abs(a - b))
+            z = 7.0 * np.log(1013.25 / o.p[order])
+            assert all(refcases.fmt_g(a) == b for a, b in zip(z, g[:, 1]))
+            assert np.all(o.time == t)
+        if t >= ctl["t_stop"]:
+            break
+        t += ctl["dt_mod"]
+    assert nbad == 0, (nbad, worst)
