@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the MPTRAC per-particle time-step loop on MI355X.
+
+Metric (BASELINE.json): particle-steps/s.  A "step" is one
+mptrac_run_timestep over this rank's particles.  Default workload "C3" is
+BASELINE configs[2]: 10^7 particles per GPU, RK4 advection + turbulent and
+mesoscale diffusion + convection + sedimentation on the synthetic
+0.5 deg x 0.5 deg x 137-level ERA5-shaped grid (721 x 361 x 137 incl. the
+periodic column), fp64, inputs resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, particles sharded by global index range (weak
+scaling: 10^7 per GPU), meteo grids replicated, no communication inside the
+step; one gridded-output reduction (RCCL all-reduce through the C ABI's hook)
+closes the timed region, as BASELINE configs[3] prescribes.
+
+The JSON line also carries the HBM roofline of the fused step kernel
+(algorithmic bytes / measured kernel time, HIP events on the launch stream)
+and a CPU baseline (this repo's OpenMP oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (grid, particles per GPU, control, quantities, meteo fields)
+    "C3": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1),
+           ("m", "rp", "rhop"), ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel")),
+    "C2": ("C2", 10 ** 6, dict(advect=4, dt_mod=180.0, diffusion=1, turb_mesox=0.0, turb_mesoz=0.0, rng_type=1),
+           ("m",), ("u", "v", "w", "ps", "pbl")),
+    "C1": ("C1", 10 ** 4, dict(advect=4, dt_mod=180.0, rng_type=1), ("m",), ("u", "v", "w", "ps")),
+}
+
+
+def algorithmic_bytes_per_pstep(workload, met, np_local):
+    """A = A_state + A_met / np.  A_state = particle state a
+    fused step must read and write once; A_met = every packed grid byte the
+    step can touch, once per launch."""
+    state = {"C3": 64 + 24 + 16,   # time,lon,lat,p R+W; uvwp R+W; rp,rhop R
+             "C2": 64, "C1": 64}[workload]
+    wind = met.nx * met.ny * met.np * 32            # {u,v,w,t} x 2 snapshots, float
+    sfc = met.nx * met.ny * 64                      # 8 surface fields x 2 snapshots
+    return state + (wind + sfc) / float(np_local), state, wind + sfc
+
+
+def build_inputs(workload, rank, world, steps_total):
+    from mptrac_amd.clim import load_clim_tropo
+    from mptrac_amd.ctl import ctl_from_quantities
+    from mptrac_amd.synth import synthetic_met, synthetic_particles
+    grid, n_per_gpu, ctl, quantities, fields = WORKLOADS[workload]
+    ctl = dict(ctl)
+    ctl.update(ctl_from_quantities(quantities))
+    # one meteo interval long enough for all steps (synthetic: no file boundary)
+    dt_met = 3600.0 * max(1, int(np.ceil((steps_total + 1) * ctl["dt_mod"] / 3600.0)))
+    ctl.update(dt_met=dt_met, t_stop=dt_met)
+    met0 = synthetic_met(grid, 0.0, 1.0, fields=fields)
+    met1 = synthetic_met(grid, dt_met, 1.25, fields=fields)
+    n_total = n_per_gpu * world
+    # every rank generates only its own index range of the global seeded set
+    atm = synthetic_particles(n_per_gpu, seed=12345, quantities=quantities, first=rank * n_per_gpu)
+    return ctl, load_clim_tropo(), met0, met1, atm, n_per_gpu, n_total
+
+
+def cpu_baseline(workload, ctl, clim, met0, met1, atm, n_sample, n_steps):
+    """The OpenMP oracle (oracle/, "port") on the first n_sample particles of
+    the same workload, all host cores."""
+    from oracle import binding as B
+    sub = {k: (v[:n_sample].copy() if k != "q" else v[:, :n_sample].copy()) for k, v in atm.items()}
+    o = B.Oracle(ctl, clim, met0, met1, sub)
+    o.timesteps_init()
+    dt = o.ctl.dt_mod
+    o.run_timestep(0.0)            # the dt = 0 first call (moves nothing)
+    o.run_timestep(dt)             # warm-up step
+    t0 = time.time()
+    for k in range(2, 2 + n_steps):
+        o.run_timestep(k * dt)
+    wall = time.time() - t0
+    cores = os.cpu_count() or 1
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env:
+        cores = min(cores, int(env))
+    return {"value": n_sample * n_steps / wall, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_sample} particles of workload {workload}, {n_steps} steps, OpenMP oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=15)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--use-torch", action="store_true", help="go through torch.distributed even at N = 1")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    use_dist = world > 1 or args.use_torch
+
+    dist = None
+    if use_dist:
+        import torch   # noqa: F401  (loads the HIP runtime before the C ABI library)
+        from mptrac_amd import dist as mdist
+        torch.cuda.set_device(local_rank)
+        dist = mdist.init_process_group("nccl")
+
+    from mptrac_amd import hip
+
+    steps_total = args.warmup + args.steps + 1
+    ctl, clim, met0, met1, atm, n_local, n_total = build_inputs(args.workload, rank, world, steps_total)
+    sim = hip.Simulation(ctl, clim, met0, met1, atm, device=local_rank,
+                         shard=(rank * n_local, (rank + 1) * n_local), n_total=n_total)
+    if use_dist:
+        from mptrac_amd import dist as mdist
+        sim.set_allreduce(mdist.make_allreduce_hook("cuda"))
+    sim.timesteps_init(0.0, 0.0)
+    dt = sim.ctl.dt_mod
+
+    def barrier():
+        sim.synchronize()
+        if use_dist:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    # the reference's first call (t = t_start) has dt = 0 and moves nothing
+    sim.run_timestep(0.0)
+    k = 1
+    for _ in range(args.warmup):
+        sim.run_timestep(k * dt)
+        k += 1
+    sim.grid_sums(k * dt)           # warm the reduction path (RCCL communicator set-up)
+    barrier()
+
+    sim.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.run_timestep(k * dt)
+        k += 1
+    cnt, mean, _sig = sim.grid_sums((k - 1) * dt)    # gridded output + all-reduce
+    barrier()
+    wall = time.perf_counter() - t0
+    launches, kernel_ms = sim.profile_end()
+
+    if use_dist:
+        import torch
+        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = tw.item()
+        km = torch.tensor([kernel_ms / max(launches, 1)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kernel_ms_per_launch = km.item()
+    else:
+        kernel_ms_per_launch = kernel_ms / max(launches, 1)
+
+    # sanity: every particle took every step and the output grid saw all of them
+    g = sim.get_atm()
+    assert np.all(g["time"] == (k - 1) * dt), "not all particles advanced"
+    assert np.all(np.isfinite(g["lon"])) and np.all(np.isfinite(g["p"]))
+    assert int(cnt.sum()) >= 0.999 * n_total, (int(cnt.sum()), n_total)   # all ranks' particles binned
+
+    if rank == 0:
+        value = n_total * args.steps / wall
+        a_per, a_state, a_met = algorithmic_bytes_per_pstep(args.workload, met0, n_local)
+        bytes_per_launch = a_per * n_local
+        achieved = bytes_per_launch / (kernel_ms_per_launch * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(args.workload)
+        out = {
+            "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: BASELINE configs[2] -- 1e7 particles/GPU, RK4 advection + "
+                                   "turbulent + mesoscale diffusion + convection + sedimentation, 721x361x137 "
+                                   "synthetic ERA5-shaped grid" if args.workload == "C3" else args.workload,
+                       "particles_per_gpu": n_local, "particles_total": n_total,
+                       "grid": [met0.nx, met0.ny, met0.np], "dt_mod": dt,
+                       "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "step_kernel (fused time step)", "kernel_ms": kernel_ms_per_launch,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "bytes_per_particle_step": a_per},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, ctl, clim, met0, met1, atm,
+                                               min(args.cpu_sample, n_local), args.cpu_steps)
+        print(json.dumps(out), flush=True)
+
+    sim.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

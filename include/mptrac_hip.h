@@ -1,0 +1,192 @@
+/*
+ * mptrac_hip.h -- C ABI of the MI355X (gfx950) back end for MPTRAC's
+ * per-particle time-step loop.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or framework
+ * types.  Each entry point names the reference interface it stands in for
+ * (paths relative to the reference repository; mptrac.c = src/mptrac.c,
+ * mptrac.h = src/mptrac.h).  INTEGRATION.md shows the few lines a maintainer
+ * adds to mptrac.c to route the OpenACC data/compute regions through it.
+ *
+ * Residency contract (same as the reference's OpenACC build, mptrac.c:8005-8113,
+ * 8248-8255): after mphip_update_atm() the device copy of the particles is
+ * authoritative; the host sees it again only through mphip_get_atm().
+ *
+ * Error convention: every int-returning call returns 0 on success and a
+ * non-zero code otherwise; mphip_last_error() gives the text.  The reference
+ * has no error returns on this path (ERRMSG prints and exits,
+ * mptrac.h:2406-2410); a host mirroring that behaviour prints the text and
+ * calls exit(EXIT_FAILURE).  There is no CPU fallback: without a usable HIP
+ * device mphip_create() fails.
+ */
+#ifndef MPTRAC_HIP_H
+#define MPTRAC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPHIP_NQ_MAX 16
+
+/* 3-D meteo fields (met_t, mptrac.h:3962-4012), float [ix][iy][ip] */
+enum { MPHIP_U = 0, MPHIP_V, MPHIP_W, MPHIP_T, MPHIP_LWC, MPHIP_RWC, MPHIP_IWC, MPHIP_SWC, MPHIP_N3D };
+/* 2-D meteo fields (met_t, mptrac.h:3886-3958), float [ix][iy] */
+enum { MPHIP_PS = 0, MPHIP_PBL, MPHIP_CAPE, MPHIP_CIN, MPHIP_PEL, MPHIP_PCT, MPHIP_PCB, MPHIP_CL, MPHIP_N2D };
+
+/* Module bits for mphip_module(); one bit per reference module_* function
+ * (declarations mptrac.h:6140-7205). */
+enum {
+  MPHIP_MOD_TIMESTEPS  = 1 << 0,   /* module_timesteps   mptrac.c:5999 */
+  MPHIP_MOD_POSITION   = 1 << 1,   /* module_position    mptrac.c:5435 (first call, mptrac.c:7884) */
+  MPHIP_MOD_ADVECT     = 1 << 2,   /* module_advect      mptrac.c:3598 */
+  MPHIP_MOD_DIFF_TURB  = 1 << 3,   /* module_diff_turb   mptrac.c:4588 */
+  MPHIP_MOD_DIFF_MESO  = 1 << 4,   /* module_diff_meso   mptrac.c:4266 */
+  MPHIP_MOD_CONVECTION = 1 << 5,   /* module_convection  mptrac.c:4102 */
+  MPHIP_MOD_SEDI       = 1 << 6,   /* module_sedi        mptrac.c:5859 */
+  MPHIP_MOD_POSITION2  = 1 << 7,   /* module_position, second call (mptrac.c:7919) */
+  MPHIP_MOD_LOSS_ZERO  = 1 << 8,   /* q[loss_rate] = 0   mptrac.c:7932-7936 */
+  MPHIP_MOD_DECAY      = 1 << 9,   /* module_decay       mptrac.c:4227 */
+  MPHIP_MOD_WET_DEPO   = 1 << 10,  /* module_wet_depo    mptrac.c:6155 */
+  MPHIP_MOD_DRY_DEPO   = 1 << 11,  /* module_dry_depo    mptrac.c:4738 */
+  MPHIP_MOD_SORT       = 1 << 16,  /* module_sort        mptrac.c:5887 (own kernels) */
+  MPHIP_MOD_MIXING     = 1 << 17   /* module_mixing      mptrac.c:5169 (own kernels) */
+};
+
+/* Hot-path subset of ctl_t (mptrac.h:2494-3553); same field names, meaning
+ * and defaults as mptrac_read_ctl (mptrac.c:6723-7741).  A compact POD is
+ * passed instead of the 469 kB reference struct. */
+typedef struct {
+  int direction;
+  int met_coord_type;
+  double t_start, t_stop, dt_mod, dt_met;
+  double met_utm_ref_lat;
+  int nq;
+  int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens;
+  int qnt_loss_rate, qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry;
+  int nens;
+  int advect;
+  int advect_vert_coord;
+  int rng_type;
+  int diffusion;
+  int turb_pbl_scheme;
+  int conv_mix_pbl;
+  double turb_dx_pbl, turb_dx_trop, turb_dx_strat;
+  double turb_dz_pbl, turb_dz_trop, turb_dz_strat;
+  double turb_mesox, turb_mesoz, turb_pbl_trans;
+  double conv_pbl_trans, conv_cape, conv_cin, conv_dt;
+  double sort_dt;
+  double tdec_trop, tdec_strat;
+  double mixing_dt, mixing_trop, mixing_strat;
+  double mixing_z0, mixing_z1, mixing_lon0, mixing_lon1, mixing_lat0, mixing_lat1;
+  int mixing_nx, mixing_ny, mixing_nz;
+  int pad0;
+  double wet_depo_pre[2];
+  double wet_depo_ic_a, wet_depo_ic_b, wet_depo_bc_a, wet_depo_bc_b;
+  double wet_depo_ic_h[2], wet_depo_bc_h[2];
+  double wet_depo_so2_ph, wet_depo_ic_ret_ratio, wet_depo_bc_ret_ratio;
+  double dry_depo_vdep, dry_depo_dp;
+  double grid_z0, grid_z1, grid_lon0, grid_lon1, grid_lat0, grid_lat1;
+  int grid_nx, grid_ny, grid_nz;
+  int pad1;
+} mphip_ctl_t;
+
+/* View of one met_t snapshot (mptrac.h:3844-4014).  The arrays stay where the
+ * host has them; strides describe the reference's fixed-extent layout
+ * (float u[EX][EY][EP]: sx = EY*EP, sy = EP; float ps[EX][EY]: sx2 = EY) or a
+ * compact one (sx = ny*np, sy = np, sx2 = ny).  A NULL field is "not
+ * provided"; modules that need it then fail with an error. */
+typedef struct {
+  double time;
+  int coord_type;
+  int nx, ny, np;
+  const double *lon, *lat, *p;
+  long long sx, sy, sx2;
+  const float *f3[MPHIP_N3D];
+  const float *f2[MPHIP_N2D];
+} mphip_met_t;
+
+typedef struct mphip_ctx mphip_ctx;
+
+/* Collective hook: called on the host, with the context's stream idle, when a
+ * device buffer of `count` doubles must be summed over all ranks (write_grid
+ * sums, mptrac.c:13862-13872; module_mixing cell sums, mptrac.c:5289-5303).
+ * A single-process run leaves it unset. */
+typedef int (*mphip_allreduce_fn)(void *device_buffer, size_t count, void *user);
+
+size_t mphip_sizeof_ctl(void);
+size_t mphip_sizeof_met(void);
+const char *mphip_version(void);
+
+/* mptrac_alloc / mptrac_free: device side (acc enter/exit data,
+ * mptrac.c:6336-6372, 6398-6430).  `device` is the HIP device ordinal. */
+int mphip_create(mphip_ctx **ctx, int device);
+void mphip_destroy(mphip_ctx *ctx);
+const char *mphip_last_error(const mphip_ctx *ctx);
+
+/* mptrac_update_device(ctl, ...), mptrac.c:8013-8018 */
+int mphip_update_ctl(mphip_ctx *ctx, const mphip_ctl_t *ctl);
+/* mptrac_update_device(..., clim, ...), mptrac.c:8027-8032: tropopause part of
+ * clim_t (mptrac.h:3785-3800); tropo is [ntime][ld] with ld >= nlat. */
+int mphip_update_clim(mphip_ctx *ctx, int ntime, int nlat, const double *tropo_time,
+                      const double *tropo_lat, const double *tropo, int ld);
+/* mptrac_update_device(..., met0, met1, ...), mptrac.c:8034-8048; slot 0 = met0,
+ * slot 1 = met1. */
+int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met);
+/* the met0/met1 pointer swap in mptrac_get_met, mptrac.c:6488-6491 */
+int mphip_swap_met(mphip_ctx *ctx);
+
+/* mptrac_update_device(..., atm), mptrac.c:8050-8055.  This process owns the
+ * particles [ip0, ip0 + np) of a simulation with np_total particles; random
+ * numbers are drawn for the global index so results do not depend on the
+ * sharding.  q[iq] may be NULL for iq >= nq. */
+int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_total, int nq,
+                     const double *time, const double *p, const double *lon, const double *lat,
+                     const double *const *q);
+/* mptrac_update_host(..., atm), mptrac.c:8105-8110 */
+int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *lat,
+                  double *const *q);
+/* mptrac_update_device / _host (cache), mptrac.c:8020-8025, 8076-8081, plus the
+ * file-static rng_ctr (mptrac.c:35).  uvwp is [np][3] as cache_t
+ * (mptrac.h:3633); any pointer may be NULL. */
+int mphip_update_cache(mphip_ctx *ctx, const float *uvwp, const uint64_t *rng_ctr);
+int mphip_get_cache(mphip_ctx *ctx, float *uvwp, double *dt, uint64_t *rng_ctr);
+
+/* mptrac_run_timestep, mptrac.c:7851-8001: the reference's module order and
+ * gating, fused into as few launches as the order allows. */
+int mphip_run_timestep(mphip_ctx *ctx, double t);
+/* One reference module_* on its own (same state hand-over through the device
+ * copy of cache->dt); `modules` is one MPHIP_MOD_* bit or an OR of the
+ * per-particle bits in reference order. */
+int mphip_module(mphip_ctx *ctx, unsigned modules, double t);
+/* Keys (as the reference's double keys) and permutation of the last
+ * module_sort call, for order checks. */
+int mphip_get_sort(mphip_ctx *ctx, double *keys, int *perm);
+
+/* write_grid's binning loop (mptrac.c:13815-13872) on the device: cnt[ncell],
+ * mean[nq][ncell], sigma[nq][ncell] raw sums, summed over ranks through the
+ * all-reduce hook if one is set. */
+int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *sigma);
+
+int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
+int mphip_synchronize(mphip_ctx *ctx);
+
+/* Timing of the fused step kernel with HIP events on the context's stream:
+ * between begin and end every launch is bracketed; end returns the launch
+ * count and the summed device time. */
+int mphip_profile_begin(mphip_ctx *ctx);
+int mphip_profile_end(mphip_ctx *ctx, long long *launches, double *kernel_ms);
+
+/* Device self-tests used by tests/ (single-precision sine/cosine of the
+ * Box-Muller step over a range of float bit patterns; uniform and normal
+ * random numbers for given counters). */
+int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, float *cos_out,
+                       float *sin_out);
+int mphip_test_rng(mphip_ctx *ctx, uint64_t ctr, long long n, int method, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,976 @@
+// mphip_api.hip -- C ABI of the MI355X back end (include/mptrac_hip.h):
+// context, device mirrors of the reference structs, the module scheduler of
+// mptrac_run_timestep and the kernel launches.  Built for gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mphip_kernels.hpp"
+
+using namespace mphip;
+
+namespace {
+
+constexpr unsigned kAdv = MPHIP_MOD_TIMESTEPS | MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_POSITION2;
+constexpr unsigned kAdvTurb = kAdv | MPHIP_MOD_DIFF_TURB;
+constexpr unsigned kAdvDiff = kAdvTurb | MPHIP_MOD_DIFF_MESO;
+constexpr unsigned kAdvTurbConvSedi = kAdvTurb | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
+constexpr unsigned kAdvDiffConvSedi = kAdvDiff | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
+constexpr unsigned kParticleBits = 0xfffu;
+
+struct MetSlot {
+  bool valid = false;
+  double time = 0;
+  float *f3[MPHIP_N3D] = {};
+  float *f2[MPHIP_N2D] = {};
+  bool has3[MPHIP_N3D] = {};
+  bool has2[MPHIP_N2D] = {};
+};
+
+}   // namespace
+
+struct mphip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  mphip_ctl_t ctl;
+  bool have_ctl = false;
+  DevClim *d_clim = nullptr;
+  bool have_clim = false;
+
+  // meteo
+  MetSlot slot[2];
+  int flip = 0;                       // logical slot s lives in slot[s ^ flip]
+  int nx = 0, ny = 0, npl = 0, coord_type = 0;
+  std::vector<double> h_lon, h_lat, h_p;
+  double *d_lon = nullptr, *d_lat = nullptr, *d_p = nullptr;
+  f32x4 *d_wind = nullptr, *d_cloud = nullptr, *d_sfc = nullptr;
+  bool packed_dirty = true;
+
+  // particles
+  long long np = 0, ip0 = 0, np_total = 0, cap = 0;
+  int nq = 0;
+  double *d_arr[4 + MPHIP_NQ_MAX] = {};   // time, p, lon, lat, q[*]
+  double *d_alt[4 + MPHIP_NQ_MAX] = {};   // gather targets (ping-pong)
+  float *d_uvwp[3] = {};
+  double *d_dt = nullptr;
+  uint64_t rng_ctr = 0;
+
+  // sort
+  uint32_t *d_keys[2] = {};
+  int *d_vals[2] = {};
+  uint32_t *d_counts = nullptr;
+  size_t counts_cap = 0;
+  int sorted_buf = -1;                // which d_keys/d_vals pair holds the last result
+
+  // mixing / grid sums
+  int *d_cell = nullptr;
+  double *d_sums = nullptr;
+  size_t sums_cap = 0;
+
+  mphip_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+
+  // profiling of the fused step kernel
+  bool prof = false;
+  std::vector<hipEvent_t> ev;         // start/stop pairs
+  size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(mphip_ctx *ctx, const std::string &msg) {
+  if (ctx)
+    ctx->err = msg;
+  return 1;
+}
+
+#define HIPCHK(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(ctx, std::string(#call) + ": " + hipGetErrorString(e_));                   \
+  } while (0)
+
+template <typename T>
+int dev_alloc(mphip_ctx *ctx, T **p, size_t n) {
+  if (*p) {
+    HIPCHK(hipFree(*p));
+    *p = nullptr;
+  }
+  if (n) {
+    HIPCHK(hipMalloc((void **) p, n * sizeof(T)));
+  }
+  return 0;
+}
+
+void dev_free(void *p) {
+  if (p)
+    (void) hipFree(p);
+}
+
+int grid_for(long long n, int block = 256, int maxb = 8192) {
+  long long b = (n + block - 1) / block;
+  if (b < 1)
+    b = 1;
+  if (b > maxb)
+    b = maxb;
+  return (int) b;
+}
+
+DevAtm dev_atm(const mphip_ctx *c) {
+  DevAtm a;
+  a.time = c->d_arr[0];
+  a.p = c->d_arr[1];
+  a.lon = c->d_arr[2];
+  a.lat = c->d_arr[3];
+  for (int iq = 0; iq < MPHIP_NQ_MAX; iq++)
+    a.q[iq] = iq < c->nq ? c->d_arr[4 + iq] : nullptr;
+  a.up = c->d_uvwp[0];
+  a.vp = c->d_uvwp[1];
+  a.wp = c->d_uvwp[2];
+  a.dt = c->d_dt;
+  a.np = c->np;
+  a.ip0 = c->ip0;
+  a.np_total = c->np_total;
+  return a;
+}
+
+DevMet dev_met(const mphip_ctx *c) {
+  DevMet M;
+  M.wind = c->d_wind;
+  M.cloud = c->d_cloud;
+  M.sfc = c->d_sfc;
+  M.lon = c->d_lon;
+  M.lat = c->d_lat;
+  M.p = c->d_p;
+  M.nx = c->nx;
+  M.ny = c->ny;
+  M.np = c->npl;
+  M.coord_type = c->coord_type;
+  M.time0 = c->slot[0 ^ c->flip].time;
+  M.time1 = c->slot[1 ^ c->flip].time;
+  double latmin = c->h_lat[0], latmax = c->h_lat[0];
+  for (double v : c->h_lat) {
+    latmin = std::min(latmin, v);
+    latmax = std::max(latmax, v);
+  }
+  M.latmin = latmin;
+  M.latmax = latmax;
+  M.local = (std::fabs(c->h_lon[c->nx - 1] - c->h_lon[0] - 360.0) >= 0.01);
+  // direction test of locate_irr at its first midpoint (mptrac.c:3502-3504)
+  const int my = (c->ny - 1) >> 1, mp = (c->npl - 1) >> 1;
+  M.lat_ascending = c->h_lat[my] < c->h_lat[my + 1];
+  M.p_ascending = c->h_p[mp] < c->h_p[mp + 1];
+  return M;
+}
+
+size_t axes_lds_bytes(const mphip_ctx *c) {
+  return (size_t) (c->nx + c->ny + c->npl) * sizeof(double);
+}
+
+// (re)build the packed two-snapshot grids from the per-slot staging copies
+int ensure_packed(mphip_ctx *ctx) {
+  if (!ctx->packed_dirty)
+    return 0;
+  const MetSlot &s0 = ctx->slot[0 ^ ctx->flip], &s1 = ctx->slot[1 ^ ctx->flip];
+  if (!s0.valid || !s1.valid)
+    return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
+  const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
+  PackSrc w, cl;
+  bool any_cloud = false;
+  for (int k = 0; k < 4; k++) {
+    w.f[0][k] = s0.has3[MPHIP_U + k] ? s0.f3[MPHIP_U + k] : nullptr;
+    w.f[1][k] = s1.has3[MPHIP_U + k] ? s1.f3[MPHIP_U + k] : nullptr;
+    cl.f[0][k] = s0.has3[MPHIP_LWC + k] ? s0.f3[MPHIP_LWC + k] : nullptr;
+    cl.f[1][k] = s1.has3[MPHIP_LWC + k] ? s1.f3[MPHIP_LWC + k] : nullptr;
+    any_cloud = any_cloud || cl.f[0][k] || cl.f[1][k];
+  }
+  if (!ctx->d_wind && dev_alloc(ctx, &ctx->d_wind, 2 * ncell))
+    return 1;
+  if (!ctx->d_sfc && dev_alloc(ctx, &ctx->d_sfc, 4 * ncol))
+    return 1;
+  hipLaunchKernelGGL(pack3d_kernel, dim3(grid_for((long long) ncell)), dim3(256), 0, ctx->stream, ctx->d_wind, w, ncell);
+  if (any_cloud) {
+    if (!ctx->d_cloud && dev_alloc(ctx, &ctx->d_cloud, 2 * ncell))
+      return 1;
+    hipLaunchKernelGGL(pack3d_kernel, dim3(grid_for((long long) ncell)), dim3(256), 0, ctx->stream, ctx->d_cloud, cl,
+                       ncell);
+  }
+  PackSrc2 s2;
+  for (int k = 0; k < 8; k++) {
+    s2.f[0][k] = s0.has2[k] ? s0.f2[k] : nullptr;
+    s2.f[1][k] = s1.has2[k] ? s1.f2[k] : nullptr;
+  }
+  hipLaunchKernelGGL(pack2d_kernel, dim3(grid_for((long long) ncol)), dim3(256), 0, ctx->stream, ctx->d_sfc, s2, ncol);
+  HIPCHK(hipGetLastError());
+  ctx->packed_dirty = false;
+  return 0;
+}
+
+bool both_have3(const mphip_ctx *c, int f) {
+  return c->slot[0].has3[f] && c->slot[1].has3[f];
+}
+
+bool both_have2(const mphip_ctx *c, int f) {
+  return c->slot[0].has2[f] && c->slot[1].has2[f];
+}
+
+// every field a module mask reads must have been uploaded for both snapshots
+int check_fields(mphip_ctx *ctx, unsigned mask) {
+  const mphip_ctl_t &c = ctx->ctl;
+  auto need3 = [&](int f, const char *who) {
+    return both_have3(ctx, f) ? 0 : fail(ctx, std::string(who) + ": a required 3-D meteo field was not uploaded");
+  };
+  auto need2 = [&](int f, const char *who) {
+    return both_have2(ctx, f) ? 0 : fail(ctx, std::string(who) + ": a required 2-D meteo field was not uploaded");
+  };
+  if (mask & (MPHIP_MOD_POSITION | MPHIP_MOD_POSITION2))
+    if (need2(MPHIP_PS, "module_position"))
+      return 1;
+  if (mask & (MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_MESO))
+    if (need3(MPHIP_U, "module_advect") || need3(MPHIP_V, "module_advect") || need3(MPHIP_W, "module_advect"))
+      return 1;
+  if (mask & MPHIP_MOD_DIFF_TURB)
+    if (need2(MPHIP_PS, "module_diff_turb") || need2(MPHIP_PBL, "module_diff_turb"))
+      return 1;
+  if (mask & MPHIP_MOD_CONVECTION) {
+    if (need2(MPHIP_PS, "module_convection") || need3(MPHIP_T, "module_convection"))
+      return 1;
+    if (c.conv_mix_pbl && need2(MPHIP_PBL, "module_convection"))
+      return 1;
+    if (c.conv_cape >= 0
+        && (need2(MPHIP_CAPE, "module_convection") || need2(MPHIP_CIN, "module_convection")
+            || need2(MPHIP_PEL, "module_convection")))
+      return 1;
+  }
+  if (mask & MPHIP_MOD_SEDI) {
+    if (need3(MPHIP_T, "module_sedi"))
+      return 1;
+    if (c.qnt_rp < 0 || c.qnt_rhop < 0)
+      return fail(ctx, "module_sedi needs quantities rp and rhop");
+  }
+  if (mask & (MPHIP_MOD_DECAY | MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO))
+    if (c.qnt_m < 0 && c.qnt_vmr < 0)
+      return fail(ctx, "Module needs quantity mass or volume mixing ratio!");
+  if (mask & MPHIP_MOD_WET_DEPO) {
+    if (need2(MPHIP_PCT, "module_wet_depo") || need2(MPHIP_PCB, "module_wet_depo") || need2(MPHIP_CL, "module_wet_depo")
+        || need3(MPHIP_T, "module_wet_depo") || !ctx->d_cloud)
+      return fail(ctx, "module_wet_depo: cloud fields (pct, pcb, cl, lwc, rwc, iwc, swc, t) were not uploaded");
+  }
+  if (mask & MPHIP_MOD_DRY_DEPO)
+    if (need2(MPHIP_PS, "module_dry_depo"))
+      return 1;
+  if ((mask & (MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DECAY)) && !ctx->have_clim)
+    return fail(ctx, "climatological tropopause data were not uploaded");
+  return 0;
+}
+
+int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint64_t ctr_meso, uint64_t ctr_conv) {
+  if (ctx->np == 0)
+    return 0;
+  if (ensure_packed(ctx) || check_fields(ctx, mask))
+    return 1;
+  StepParams S;
+  S.ctl = ctx->ctl;
+  S.met = dev_met(ctx);
+  S.atm = dev_atm(ctx);
+  S.clim = ctx->d_clim;
+  S.t = t;
+  S.mask = mask;
+  int nb = grid_for(ctx->np, 256, 8192);
+  nb = (nb + 7) & ~7;
+  S.nblocks_logical = nb;
+  S.ctr_turb = ctr_turb;
+  S.ctr_meso = ctr_meso;
+  S.ctr_conv = ctr_conv;
+  const size_t lds = axes_lds_bytes(ctx);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->prof) {
+    if (ctx->ev_used + 2 > ctx->ev.size()) {
+      for (int k = 0; k < 2; k++) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        ctx->ev.push_back(e);
+      }
+    }
+    e0 = ctx->ev[ctx->ev_used++];
+    e1 = ctx->ev[ctx->ev_used++];
+    HIPCHK(hipEventRecord(e0, ctx->stream));
+  }
+  const unsigned sel = (ctx->ctl.advect == 4) ? mask : kMaskGeneric;   // specialisations are built for RK4
+  switch (sel) {
+#define STEP_CASE(M)                                                                                  \
+  case M:                                                                                             \
+    hipLaunchKernelGGL(step_kernel<M>, dim3(nb), dim3(256), lds, ctx->stream, S);                     \
+    break;
+    STEP_CASE(kAdv)
+    STEP_CASE(kAdvTurb)
+    STEP_CASE(kAdvDiff)
+    STEP_CASE(kAdvTurbConvSedi)
+    STEP_CASE(kAdvDiffConvSedi)
+#undef STEP_CASE
+  default:
+    hipLaunchKernelGGL(step_kernel<kMaskGeneric>, dim3(nb), dim3(256), lds, ctx->stream, S);
+  }
+  HIPCHK(hipGetLastError());
+  if (ctx->prof)
+    HIPCHK(hipEventRecord(e1, ctx->stream));
+  return 0;
+}
+
+// module_sort, mptrac.c:5887-5957
+int do_sort(mphip_ctx *ctx) {
+  const long long n = ctx->np;
+  if (n == 0)
+    return 0;
+  if (ensure_packed(ctx))
+    return 1;
+  const int ntiles = (int) ((n + kSortTile - 1) / kSortTile);
+  const size_t m = (size_t) kRadix * ntiles;
+  if (m > ctx->counts_cap) {
+    if (dev_alloc(ctx, &ctx->d_counts, m))
+      return 1;
+    ctx->counts_cap = m;
+  }
+  const DevMet M = dev_met(ctx);
+  const DevAtm a = dev_atm(ctx);
+  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a,
+                     ctx->d_keys[0], ctx->d_vals[0]);
+  // number of 8-bit digits that can be non-zero
+  const unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
+  int passes = 1;
+  while (passes < 4 && (kmax >> (8 * passes)) != 0)
+    passes++;
+  int cur = 0;
+  for (int pass = 0; pass < passes; pass++) {
+    const int shift = 8 * pass;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur], n, shift,
+                       ntiles, ctx->d_counts);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_counts, m);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur],
+                       ctx->d_vals[cur], ctx->d_keys[cur ^ 1], ctx->d_vals[cur ^ 1], n, shift, ntiles, ctx->d_counts);
+    cur ^= 1;
+  }
+  ctx->sorted_buf = cur;
+  GatherArgs g;
+  g.narrays = 4 + ctx->nq;
+  for (int k = 0; k < g.narrays; k++) {
+    g.in[k] = ctx->d_arr[k];
+    g.out[k] = ctx->d_alt[k];
+  }
+  hipLaunchKernelGGL(sort_gather_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], n);
+  HIPCHK(hipGetLastError());
+  for (int k = 0; k < g.narrays; k++)
+    std::swap(ctx->d_arr[k], ctx->d_alt[k]);
+  return 0;
+}
+
+int ensure_sums(mphip_ctx *ctx, size_t n) {
+  if (n > ctx->sums_cap) {
+    if (dev_alloc(ctx, &ctx->d_sums, n))
+      return 1;
+    ctx->sums_cap = n;
+  }
+  return 0;
+}
+
+int run_allreduce(mphip_ctx *ctx, double *buf, size_t count) {
+  if (!ctx->allreduce)
+    return 0;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->allreduce(buf, count, ctx->allreduce_user))
+    return fail(ctx, "all-reduce hook reported an error");
+  return 0;
+}
+
+// module_mixing, mptrac.c:5169-5347
+int do_mixing(mphip_ctx *ctx, double t) {
+  const mphip_ctl_t &c = ctx->ctl;
+  if (!ctx->have_clim)
+    return fail(ctx, "climatological tropopause data were not uploaded");
+  const int ngrid = c.mixing_nx * c.mixing_ny * c.mixing_nz;
+  const int nens = c.nens > 0 ? c.nens : 1;
+  const size_t ntot = (size_t) ngrid * nens;
+  if (ensure_sums(ctx, 2 * ntot))
+    return 1;
+  const DevAtm a = dev_atm(ctx);
+  BoxGrid G = { c.mixing_lon0, c.mixing_lon1, c.mixing_lat0, c.mixing_lat1, c.mixing_z0, c.mixing_z1,
+                c.mixing_nx, c.mixing_ny, c.mixing_nz };
+  const int nb = grid_for(std::max<long long>(ctx->np, 1));
+  if (ctx->np)
+    hipLaunchKernelGGL(box_index_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
+                       t + 0.5 * c.dt_mod, ctx->d_cell);
+  const double *ens = (c.nens > 0 && c.qnt_ens >= 0) ? a.q[c.qnt_ens] : nullptr;
+  const int quantities[2] = { c.qnt_m, c.qnt_vmr };   // hot-path subset of mptrac.c:5223-5230
+  for (int k = 0; k < 2; k++) {
+    const int iq = quantities[k];
+    if (iq < 0)
+      continue;
+    HIPCHK(hipMemsetAsync(ctx->d_sums, 0, 2 * ntot * sizeof(double), ctx->stream));
+    if (ctx->np)
+      hipLaunchKernelGGL(mix_accumulate_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, ctx->d_cell, a.q[iq], ens,
+                         ngrid, ntot, ctx->d_sums);
+    if (run_allreduce(ctx, ctx->d_sums, 2 * ntot))
+      return 1;
+    if (ctx->np)
+      hipLaunchKernelGGL(mix_relax_kernel, dim3(nb), dim3(256), 0, ctx->stream, c, ctx->d_clim, a, ctx->d_cell,
+                         a.q[iq], ens, ngrid, ntot, ctx->d_sums);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}   // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+
+extern "C" {
+
+size_t mphip_sizeof_ctl(void) {
+  return sizeof(mphip_ctl_t);
+}
+
+size_t mphip_sizeof_met(void) {
+  return sizeof(mphip_met_t);
+}
+
+const char *mphip_version(void) {
+  return "mptrac_amd 0.1 (gfx950)";
+}
+
+int mphip_create(mphip_ctx **out, int device) {
+  if (!out)
+    return 1;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    fprintf(stderr, "mptrac_hip: no HIP device available (this back end has no CPU fallback)\n");
+    return 2;
+  }
+  if (device < 0 || device >= ndev) {
+    fprintf(stderr, "mptrac_hip: device %d out of range (%d devices)\n", device, ndev);
+    return 3;
+  }
+  mphip_ctx *ctx = new mphip_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    fprintf(stderr, "mptrac_hip: cannot initialise device %d\n", device);
+    delete ctx;
+    return 4;
+  }
+  memset(&ctx->ctl, 0, sizeof(ctx->ctl));
+  *out = ctx;
+  return 0;
+}
+
+void mphip_destroy(mphip_ctx *ctx) {
+  if (!ctx)
+    return;
+  (void) hipSetDevice(ctx->device);
+  (void) hipStreamSynchronize(ctx->stream);
+  for (auto &s : ctx->slot) {
+    for (auto p : s.f3)
+      dev_free(p);
+    for (auto p : s.f2)
+      dev_free(p);
+  }
+  dev_free(ctx->d_clim);
+  dev_free(ctx->d_lon);
+  dev_free(ctx->d_lat);
+  dev_free(ctx->d_p);
+  dev_free(ctx->d_wind);
+  dev_free(ctx->d_cloud);
+  dev_free(ctx->d_sfc);
+  for (auto p : ctx->d_arr)
+    dev_free(p);
+  for (auto p : ctx->d_alt)
+    dev_free(p);
+  for (auto p : ctx->d_uvwp)
+    dev_free(p);
+  dev_free(ctx->d_dt);
+  for (int k = 0; k < 2; k++) {
+    dev_free(ctx->d_keys[k]);
+    dev_free(ctx->d_vals[k]);
+  }
+  dev_free(ctx->d_counts);
+  dev_free(ctx->d_cell);
+  dev_free(ctx->d_sums);
+  for (auto e : ctx->ev)
+    (void) hipEventDestroy(e);
+  (void) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *mphip_last_error(const mphip_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : "no context";
+}
+
+int mphip_update_ctl(mphip_ctx *ctx, const mphip_ctl_t *ctl) {
+  if (!ctx || !ctl)
+    return fail(ctx, "null argument");
+  if (ctl->nq < 0 || ctl->nq > MPHIP_NQ_MAX)
+    return fail(ctx, "nq out of range");
+  if (ctl->rng_type != 1)
+    return fail(ctx, "only RNG_TYPE 1 (Squares) is implemented on the device");
+  if (ctl->advect_vert_coord != 0)
+    return fail(ctx, "only ADVECT_VERT_COORD 0 (pressure levels) is implemented on the device");
+  if (!(ctl->advect == 0 || ctl->advect == 1 || ctl->advect == 2 || ctl->advect == 4))
+    return fail(ctx, "Set ADVECT to 1, 2, or 4!");
+  ctx->ctl = *ctl;
+  ctx->have_ctl = true;
+  return 0;
+}
+
+int mphip_update_clim(mphip_ctx *ctx, int ntime, int nlat, const double *tropo_time, const double *tropo_lat,
+                      const double *tropo, int ld) {
+  if (!ctx || !tropo_time || !tropo_lat || !tropo)
+    return fail(ctx, "null argument");
+  if (ntime < 2 || ntime > 12 || nlat < 2 || nlat > 73 || ld < nlat)
+    return fail(ctx, "tropopause climatology dimensions out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevClim h;
+  memset(&h, 0, sizeof(h));
+  h.ntime = ntime;
+  h.nlat = nlat;
+  for (int i = 0; i < ntime; i++)
+    h.time[i] = tropo_time[i];
+  for (int j = 0; j < nlat; j++)
+    h.lat[j] = tropo_lat[j];
+  for (int i = 0; i < ntime; i++)
+    for (int j = 0; j < nlat; j++)
+      h.tropo[i][j] = tropo[(size_t) i * ld + j];
+  if (!ctx->d_clim)
+    HIPCHK(hipMalloc((void **) &ctx->d_clim, sizeof(DevClim)));
+  HIPCHK(hipMemcpyAsync(ctx->d_clim, &h, sizeof(DevClim), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->have_clim = true;
+  return 0;
+}
+
+int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
+  if (!ctx || !met || slot < 0 || slot > 1)
+    return fail(ctx, "bad argument");
+  if (met->nx < 2 || met->ny < 2 || met->np < 2 || !met->lon || !met->lat || !met->p)
+    return fail(ctx, "meteo grid dimensions out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  const bool new_grid = (met->nx != ctx->nx || met->ny != ctx->ny || met->np != ctx->npl);
+  if (new_grid) {
+    if (ctx->slot[0].valid || ctx->slot[1].valid) {
+      // mptrac_get_met: "Meteo grid dimensions do not match!" (mptrac.c:6543-6546)
+      if (ctx->slot[(slot ^ 1) ^ ctx->flip].valid)
+        return fail(ctx, "Meteo grid dimensions do not match!");
+    }
+    ctx->nx = met->nx;
+    ctx->ny = met->ny;
+    ctx->npl = met->np;
+    dev_free(ctx->d_wind);
+    dev_free(ctx->d_cloud);
+    dev_free(ctx->d_sfc);
+    ctx->d_wind = ctx->d_cloud = ctx->d_sfc = nullptr;
+  }
+  ctx->coord_type = met->coord_type;
+  // the reference interpolates on met0's axes (mptrac.c:3010-3020); slot 0 defines them
+  if (slot == 0 || new_grid || ctx->h_lon.empty()) {
+    ctx->h_lon.assign(met->lon, met->lon + met->nx);
+    ctx->h_lat.assign(met->lat, met->lat + met->ny);
+    ctx->h_p.assign(met->p, met->p + met->np);
+    if (dev_alloc(ctx, &ctx->d_lon, (size_t) met->nx) || dev_alloc(ctx, &ctx->d_lat, (size_t) met->ny)
+        || dev_alloc(ctx, &ctx->d_p, (size_t) met->np))
+      return 1;
+    HIPCHK(hipMemcpyAsync(ctx->d_lon, met->lon, met->nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_lat, met->lat, met->ny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_p, met->p, met->np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  MetSlot &S = ctx->slot[slot ^ ctx->flip];
+  const size_t ncell = (size_t) met->nx * met->ny * met->np, ncol = (size_t) met->nx * met->ny;
+  const bool compact3 = (met->sy == met->np && met->sx == (long long) met->ny * met->np);
+  for (int f = 0; f < MPHIP_N3D; f++) {
+    S.has3[f] = met->f3[f] != nullptr;
+    if (!S.has3[f])
+      continue;
+    if (new_grid || !S.f3[f])
+      if (dev_alloc(ctx, &S.f3[f], ncell))
+        return 1;
+    if (compact3) {
+      HIPCHK(hipMemcpyAsync(S.f3[f], met->f3[f], ncell * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      if (met->sy < met->np || met->sx < met->sy * met->ny || met->sx % met->sy != 0)
+        return fail(ctx, "unsupported 3-D meteo strides");
+      hipMemcpy3DParms p;
+      memset(&p, 0, sizeof(p));
+      p.srcPtr = make_hipPitchedPtr((void *) met->f3[f], (size_t) met->sy * sizeof(float), (size_t) met->np,
+                                    (size_t) (met->sx / met->sy));
+      p.dstPtr = make_hipPitchedPtr(S.f3[f], (size_t) met->np * sizeof(float), (size_t) met->np, (size_t) met->ny);
+      p.extent = make_hipExtent((size_t) met->np * sizeof(float), (size_t) met->ny, (size_t) met->nx);
+      p.kind = hipMemcpyHostToDevice;
+      HIPCHK(hipMemcpy3DAsync(&p, ctx->stream));
+    }
+  }
+  for (int f = 0; f < MPHIP_N2D; f++) {
+    S.has2[f] = met->f2[f] != nullptr;
+    if (!S.has2[f])
+      continue;
+    if (new_grid || !S.f2[f])
+      if (dev_alloc(ctx, &S.f2[f], ncol))
+        return 1;
+    if (met->sx2 == met->ny) {
+      HIPCHK(hipMemcpyAsync(S.f2[f], met->f2[f], ncol * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      if (met->sx2 < met->ny)
+        return fail(ctx, "unsupported 2-D meteo stride");
+      HIPCHK(hipMemcpy2DAsync(S.f2[f], (size_t) met->ny * sizeof(float), met->f2[f], (size_t) met->sx2 * sizeof(float),
+                              (size_t) met->ny * sizeof(float), (size_t) met->nx, hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // the host arrays may be reused by the caller
+  S.time = met->time;
+  S.valid = true;
+  ctx->packed_dirty = true;
+  return 0;
+}
+
+int mphip_swap_met(mphip_ctx *ctx) {
+  if (!ctx)
+    return 1;
+  ctx->flip ^= 1;
+  ctx->packed_dirty = true;
+  return 0;
+}
+
+int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_total, int nq, const double *time,
+                     const double *p, const double *lon, const double *lat, const double *const *q) {
+  if (!ctx || np < 0 || nq < 0 || nq > MPHIP_NQ_MAX || ip0 < 0 || np_total < ip0 + np)
+    return fail(ctx, "bad particle counts");
+  if (np > 2147483647LL)
+    return fail(ctx, "too many particles for one device context");
+  if (np && (!time || !p || !lon || !lat || (nq && !q)))
+    return fail(ctx, "null particle array");
+  HIPCHK(hipSetDevice(ctx->device));
+  const bool fresh = (np != ctx->np || nq != ctx->nq || !ctx->d_arr[0]);
+  if (fresh) {
+    const size_t n = (size_t) std::max<long long>(np, 1);
+    for (int k = 0; k < 4 + MPHIP_NQ_MAX; k++) {
+      const size_t want = k < 4 + nq ? n : 0;
+      if (dev_alloc(ctx, &ctx->d_arr[k], want) || dev_alloc(ctx, &ctx->d_alt[k], want))
+        return 1;
+    }
+    for (int k = 0; k < 3; k++) {
+      if (dev_alloc(ctx, &ctx->d_uvwp[k], n))
+        return 1;
+      HIPCHK(hipMemsetAsync(ctx->d_uvwp[k], 0, n * sizeof(float), ctx->stream));   // calloc'ed cache_t
+    }
+    if (dev_alloc(ctx, &ctx->d_dt, n))
+      return 1;
+    HIPCHK(hipMemsetAsync(ctx->d_dt, 0, n * sizeof(double), ctx->stream));
+    for (int k = 0; k < 2; k++)
+      if (dev_alloc(ctx, &ctx->d_keys[k], n) || dev_alloc(ctx, &ctx->d_vals[k], n))
+        return 1;
+    if (dev_alloc(ctx, &ctx->d_cell, n))
+      return 1;
+    ctx->sorted_buf = -1;
+  }
+  ctx->np = np;
+  ctx->nq = nq;
+  ctx->ip0 = ip0;
+  ctx->np_total = np_total;
+  const double *src[4] = { time, p, lon, lat };
+  for (int k = 0; k < 4 && np; k++)
+    HIPCHK(hipMemcpyAsync(ctx->d_arr[k], src[k], (size_t) np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  for (int iq = 0; iq < nq && np; iq++) {
+    if (!q[iq])
+      return fail(ctx, "null quantity array");
+    HIPCHK(hipMemcpyAsync(ctx->d_arr[4 + iq], q[iq], (size_t) np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *lat, double *const *q) {
+  if (!ctx)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  double *dst[4] = { time, p, lon, lat };
+  for (int k = 0; k < 4; k++)
+    if (dst[k] && ctx->np)
+      HIPCHK(hipMemcpyAsync(dst[k], ctx->d_arr[k], (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  for (int iq = 0; iq < ctx->nq; iq++)
+    if (q && q[iq] && ctx->np)
+      HIPCHK(hipMemcpyAsync(q[iq], ctx->d_arr[4 + iq], (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost,
+                            ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mphip_update_cache(mphip_ctx *ctx, const float *uvwp, const uint64_t *rng_ctr) {
+  if (!ctx)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (rng_ctr)
+    ctx->rng_ctr = *rng_ctr;
+  if (uvwp && ctx->np) {
+    std::vector<float> tmp((size_t) ctx->np);
+    for (int k = 0; k < 3; k++) {
+      for (long long i = 0; i < ctx->np; i++)
+        tmp[(size_t) i] = uvwp[3 * (size_t) i + k];
+      HIPCHK(hipMemcpy(ctx->d_uvwp[k], tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  return 0;
+}
+
+int mphip_get_cache(mphip_ctx *ctx, float *uvwp, double *dt, uint64_t *rng_ctr) {
+  if (!ctx)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (rng_ctr)
+    *rng_ctr = ctx->rng_ctr;
+  if (uvwp && ctx->np) {
+    std::vector<float> tmp((size_t) ctx->np);
+    for (int k = 0; k < 3; k++) {
+      HIPCHK(hipMemcpy(tmp.data(), ctx->d_uvwp[k], tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+      for (long long i = 0; i < ctx->np; i++)
+        uvwp[3 * (size_t) i + k] = tmp[(size_t) i];
+    }
+  }
+  if (dt && ctx->np)
+    HIPCHK(hipMemcpy(dt, ctx->d_dt, (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mphip_run_timestep(mphip_ctx *ctx, double t) {
+  if (!ctx)
+    return 1;
+  if (!ctx->have_ctl)
+    return fail(ctx, "control parameters were not uploaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  const mphip_ctl_t &c = ctx->ctl;
+  const uint64_t n = (uint64_t) ctx->np_total;
+  unsigned mask = MPHIP_MOD_TIMESTEPS;
+
+  // module_timesteps + module_sort (mptrac.c:7877-7881).  The reference
+  // permutes atm but not cache->dt, so on sort steps dt is computed per slot
+  // before the sort and read back per slot afterwards.
+  if (c.sort_dt > 0 && fmod(t, c.sort_dt) == 0) {
+    if (launch_step(ctx, MPHIP_MOD_TIMESTEPS | kStoreDt, t, 0, 0, 0) || do_sort(ctx))
+      return 1;
+    mask = 0;
+  }
+  mask |= MPHIP_MOD_POSITION;
+  if (c.advect > 0)
+    mask |= MPHIP_MOD_ADVECT;
+  uint64_t ctr_turb = 0, ctr_meso = 0, ctr_conv = 0;
+  if (c.diffusion
+      && (c.turb_dx_pbl > 0 || c.turb_dz_pbl > 0 || c.turb_dx_trop > 0 || c.turb_dz_trop > 0 || c.turb_dx_strat > 0
+          || c.turb_dz_strat > 0)) {
+    mask |= MPHIP_MOD_DIFF_TURB;
+    ctr_turb = ctx->rng_ctr;
+    ctx->rng_ctr += 3 * n + 1;   // module_rng(..., 3 * np, 1), mptrac.c:4600, 5812
+  }
+  if (c.diffusion && c.turb_pbl_scheme == 1)
+    return fail(ctx, "module_diff_pbl (TURB_PBL_SCHEME 1) is not implemented on the device");
+  if (c.diffusion && (c.turb_mesox > 0 || c.turb_mesoz > 0)) {
+    mask |= MPHIP_MOD_DIFF_MESO;
+    ctr_meso = ctx->rng_ctr;
+    ctx->rng_ctr += 3 * n + 1;
+  }
+  if ((c.conv_mix_pbl || c.conv_cape >= 0) && (c.conv_dt <= 0 || fmod(t, c.conv_dt) == 0)) {
+    mask |= MPHIP_MOD_CONVECTION;
+    ctr_conv = ctx->rng_ctr;
+    ctx->rng_ctr += n + 1;       // module_rng(..., np, 0), mptrac.c:4113
+  }
+  if (c.qnt_rp >= 0 && c.qnt_rhop >= 0)
+    mask |= MPHIP_MOD_SEDI;
+  mask |= MPHIP_MOD_POSITION2;
+  if (c.qnt_loss_rate >= 0)
+    mask |= MPHIP_MOD_LOSS_ZERO;
+  if (c.tdec_trop > 0 && c.tdec_strat > 0)
+    mask |= MPHIP_MOD_DECAY;
+  unsigned tail = 0;
+  if ((c.wet_depo_ic_a > 0 || c.wet_depo_ic_h[0] > 0) && (c.wet_depo_bc_a > 0 || c.wet_depo_bc_h[0] > 0))
+    tail |= MPHIP_MOD_WET_DEPO;
+  if (c.dry_depo_vdep > 0)
+    tail |= MPHIP_MOD_DRY_DEPO;
+  const bool mixing_now = c.mixing_trop >= 0 && c.mixing_strat >= 0 && (c.mixing_dt <= 0 || fmod(t, c.mixing_dt) == 0);
+  if (!mixing_now)
+    return launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv);
+  if (tail && (mask & MPHIP_MOD_TIMESTEPS))
+    mask |= kStoreDt;
+  if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv) || do_mixing(ctx, t))
+    return 1;
+  if (tail)
+    return launch_step(ctx, tail, t, 0, 0, 0);
+  return 0;
+}
+
+int mphip_module(mphip_ctx *ctx, unsigned modules, double t) {
+  if (!ctx)
+    return 1;
+  if (!ctx->have_ctl)
+    return fail(ctx, "control parameters were not uploaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (modules == MPHIP_MOD_SORT)
+    return do_sort(ctx);
+  if (modules == MPHIP_MOD_MIXING)
+    return do_mixing(ctx, t);
+  if (modules & ~kParticleBits)
+    return fail(ctx, "module_sort / module_mixing must be called on their own");
+  const uint64_t n = (uint64_t) ctx->np_total;
+  uint64_t ctr_turb = 0, ctr_meso = 0, ctr_conv = 0;
+  if (modules & MPHIP_MOD_DIFF_TURB) {
+    ctr_turb = ctx->rng_ctr;
+    ctx->rng_ctr += 3 * n + 1;
+  }
+  if (modules & MPHIP_MOD_DIFF_MESO) {
+    ctr_meso = ctx->rng_ctr;
+    ctx->rng_ctr += 3 * n + 1;
+  }
+  if (modules & MPHIP_MOD_CONVECTION) {
+    ctr_conv = ctx->rng_ctr;
+    ctx->rng_ctr += n + 1;
+  }
+  if (modules & MPHIP_MOD_TIMESTEPS)
+    modules |= kStoreDt;
+  return launch_step(ctx, modules, t, ctr_turb, ctr_meso, ctr_conv);
+}
+
+int mphip_get_sort(mphip_ctx *ctx, double *keys, int *perm) {
+  if (!ctx || ctx->sorted_buf < 0)
+    return fail(ctx, "module_sort has not been run");
+  HIPCHK(hipSetDevice(ctx->device));
+  const long long n = ctx->np;
+  if (perm)
+    HIPCHK(hipMemcpyAsync(perm, ctx->d_vals[ctx->sorted_buf], (size_t) n * sizeof(int), hipMemcpyDeviceToHost,
+                          ctx->stream));
+  if (keys) {
+    double *d_tmp = nullptr;
+    HIPCHK(hipMalloc((void **) &d_tmp, (size_t) n * sizeof(double)));
+    hipLaunchKernelGGL(keys_to_double_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream,
+                       ctx->d_keys[ctx->sorted_buf], d_tmp, n);
+    HIPCHK(hipMemcpyAsync(keys, d_tmp, (size_t) n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_tmp));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *sigma) {
+  if (!ctx || !cnt || !mean || !sigma)
+    return fail(ctx, "null argument");
+  if (!ctx->have_ctl)
+    return fail(ctx, "control parameters were not uploaded");
+  HIPCHK(hipSetDevice(ctx->device));
+  const mphip_ctl_t &c = ctx->ctl;
+  const size_t ncell = (size_t) c.grid_nx * c.grid_ny * c.grid_nz;
+  const size_t total = ncell * (size_t) (1 + 2 * ctx->nq);
+  if (ensure_sums(ctx, total))
+    return 1;
+  HIPCHK(hipMemsetAsync(ctx->d_sums, 0, total * sizeof(double), ctx->stream));
+  if (ctx->np) {
+    const DevAtm a = dev_atm(ctx);
+    BoxGrid G = { c.grid_lon0, c.grid_lon1, c.grid_lat0, c.grid_lat1, c.grid_z0, c.grid_z1, c.grid_nx, c.grid_ny,
+                  c.grid_nz };
+    const int nb = grid_for(ctx->np);
+    hipLaunchKernelGGL(box_index_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
+                       t + 0.5 * c.dt_mod, ctx->d_cell);
+    hipLaunchKernelGGL(grid_accumulate_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, ctx->d_cell, ctx->nq, ncell,
+                       ctx->d_sums);
+    HIPCHK(hipGetLastError());
+  }
+  if (run_allreduce(ctx, ctx->d_sums, total))
+    return 1;
+  std::vector<double> h(total);
+  HIPCHK(hipMemcpyAsync(h.data(), ctx->d_sums, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < ncell; i++)
+    cnt[i] = (int) h[i];
+  memcpy(mean, h.data() + ncell, ncell * (size_t) ctx->nq * sizeof(double));
+  memcpy(sigma, h.data() + ncell * (size_t) (1 + ctx->nq), ncell * (size_t) ctx->nq * sizeof(double));
+  return 0;
+}
+
+int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user) {
+  if (!ctx)
+    return 1;
+  ctx->allreduce = fn;
+  ctx->allreduce_user = user;
+  return 0;
+}
+
+int mphip_synchronize(mphip_ctx *ctx) {
+  if (!ctx)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mphip_profile_begin(mphip_ctx *ctx) {
+  if (!ctx)
+    return 1;
+  ctx->prof = true;
+  ctx->ev_used = 0;
+  return 0;
+}
+
+int mphip_profile_end(mphip_ctx *ctx, long long *launches, double *kernel_ms) {
+  if (!ctx)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double total = 0;
+  for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
+    total += ms;
+  }
+  if (launches)
+    *launches = (long long) (ctx->ev_used / 2);
+  if (kernel_ms)
+    *kernel_ms = total;
+  ctx->prof = false;
+  ctx->ev_used = 0;
+  return 0;
+}
+
+int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, float *cos_out, float *sin_out) {
+  if (!ctx || !cos_out || !sin_out)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  float *dc = nullptr, *ds = nullptr;
+  HIPCHK(hipMalloc((void **) &dc, (size_t) count * sizeof(float)));
+  HIPCHK(hipMalloc((void **) &ds, (size_t) count * sizeof(float)));
+  hipLaunchKernelGGL(test_sincosf_kernel, dim3(grid_for(count)), dim3(256), 0, ctx->stream, bits_first, count, dc, ds);
+  HIPCHK(hipMemcpyAsync(cos_out, dc, (size_t) count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(sin_out, ds, (size_t) count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipFree(dc));
+  HIPCHK(hipFree(ds));
+  return 0;
+}
+
+int mphip_test_rng(mphip_ctx *ctx, uint64_t ctr, long long n, int method, double *out) {
+  if (!ctx || !out || n < 0)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  double *d = nullptr;
+  HIPCHK(hipMalloc((void **) &d, (size_t) std::max<long long>(n, 1) * sizeof(double)));
+  hipLaunchKernelGGL(test_rng_kernel, dim3(grid_for(std::max<long long>(n, 1))), dim3(256), 0, ctx->stream, ctr, n,
+                     method, d);
+  HIPCHK(hipMemcpyAsync(out, d, (size_t) n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipFree(d));
+  return 0;
+}
+
+}   // extern "C"

@@ -1,0 +1,767 @@
+// mphip_device.hpp -- device-side building blocks of the MPTRAC time-step loop
+// for gfx950 (MI355X): arithmetic conventions, axis search, packed-grid
+// interpolation, counter-based random numbers, and one function per reference
+// module.  All state of one particle lives in registers; the only memory
+// traffic is the SoA particle arrays (coalesced) and the gathers from the
+// packed meteo grids.
+//
+// Reference citations are relative to the reference repository
+// (mptrac.c = src/mptrac.c, mptrac.h = src/mptrac.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mptrac_hip.h"
+
+namespace mphip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- constants (mptrac.h:255-345, 430-460, 535) ---------------------------
+constexpr double kG0 = 9.80665;
+constexpr double kH0 = 7.0;
+constexpr double kKB = 1.3806504e-23;
+constexpr double kMA = 28.9644;
+constexpr double kP0 = 1013.25;
+constexpr double kRI = 8.3144598;
+constexpr double kRA = 1e3 * kRI / kMA;
+constexpr double kRE = 6367.421;
+constexpr double kMAir = 4.8096e-26;
+constexpr double kTRef = 298.15;
+constexpr double kT0 = 273.15;
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kSO2K1Ref = 1.23e-2, kSO2K1Temp = 2.01e3, kSO2K2Ref = 6e-8, kSO2K2Temp = 1.12e3;
+constexpr double kWdTLiquid = kT0, kWdTIce = 238.15, kWdTLiquidBC = 270.;
+
+// ---- device views ---------------------------------------------------------
+
+// Both bracketing snapshots packed per grid point so that one particle's
+// eight corners are four 64-byte pieces:
+//   wind [nx][ny][np][2] f32x4 : {u,v,w,t} at met0, then {u,v,w,t} at met1
+//   cloud[nx][ny][np][2] f32x4 : {lwc,rwc,iwc,swc} at met0 / met1 (optional)
+//   sfc  [nx][ny][4]     f32x4 : {ps,pbl,cape,cin}0 {pel,pct,pcb,cl}0 {..}1 {..}1
+struct DevMet {
+  const f32x4 *wind;
+  const f32x4 *cloud;
+  const f32x4 *sfc;
+  const double *lon, *lat, *p;   // axes in global memory (copied to LDS per block)
+  int nx, ny, np, coord_type;
+  double time0, time1;
+  double latmin, latmax;         // module_timesteps, mptrac.c:6009-6010
+  int local;                     // mptrac.c:6012-6013
+  int lat_ascending, p_ascending;
+};
+
+struct DevAtm {
+  double *time, *p, *lon, *lat;
+  double *q[MPHIP_NQ_MAX];
+  float *up, *vp, *wp;           // cache->uvwp, kept SoA on the device
+  double *dt;                    // cache->dt (only used across separate launches)
+  long long np;                  // particles owned by this context
+  long long ip0;                 // global index of the first one
+  long long np_total;            // particles of the whole simulation
+};
+
+struct DevClim {
+  int ntime, nlat;
+  double time[12];
+  double lat[73];
+  double tropo[12][73];
+};
+
+// per-block LDS copy of the three axes
+struct Axes {
+  const double *lon, *lat, *p;
+};
+
+// ---- arithmetic conventions ------------------------------------------------
+
+// FMOD, mptrac.h:1121-1122.  (int)(x / y) is 0 whenever |x| < y, so the
+// division is only executed outside that range; the result is identical.
+__device__ __forceinline__ double fmod_trunc(double x, double y) {
+  if (fabs(x) < y)
+    return x - 0 * y;
+  return x - (int) (x / y) * y;
+}
+
+__device__ __forceinline__ double deg2rad(double deg) {   // mptrac.h:857
+  return deg * (kPi / 180.0);
+}
+
+__device__ __forceinline__ double dx2deg(double dx, double lat) {   // mptrac.h:904-906
+  if (lat < -89.999 || lat > 89.999)
+    return 0;
+  return dx * 180. / (kPi * kRE * cos(deg2rad(lat)));
+}
+
+__device__ __forceinline__ double dy2deg(double dy) {   // mptrac.h:922
+  return dy * 180. / (kPi * kRE);
+}
+
+__device__ __forceinline__ double dx2coord(int coord_type, double dx, double lat) {   // mptrac.h:966
+  return coord_type == 0 ? dx2deg(dx / 1000.0, lat) : dx;
+}
+
+__device__ __forceinline__ double dy2coord(int coord_type, double dy) {   // mptrac.h:989
+  return coord_type == 0 ? dy2deg(dy / 1000.0) : dy;
+}
+
+__device__ __forceinline__ double dz2dp(double dz, double p) {   // mptrac.h:941
+  return -dz * p / kH0;
+}
+
+__device__ __forceinline__ double zfromp(double p) {   // mptrac.h:2243
+  return kH0 * log(kP0 / p);
+}
+
+__device__ __forceinline__ double lin(double x0, double y0, double x1, double y1, double x) {   // mptrac.h:1351
+  return y0 + (y1 - y0) / (x1 - x0) * (x - x0);
+}
+
+__device__ __forceinline__ double rho_air(double p, double t) {   // mptrac.h:1961
+  return 100. * p / (kRA * t);
+}
+
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+
+// ---- axis search (mptrac.c:3495-3574) --------------------------------------
+
+// locate_irr: the bisection of the reference only ever compares interior
+// nodes 1..n-2, so on a monotonic axis its result is "the number of interior
+// nodes on the near side of x".  Same bisection here, on the LDS copy.
+__device__ __forceinline__ int locate_irr(const double *xx, int n, double x, int ascending) {
+  int lo = 0, hi = n - 1;
+  if (ascending) {
+    while (hi > lo + 1) {
+      const int mid = (hi + lo) >> 1;
+      if (xx[mid] > x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  } else {
+    while (hi > lo + 1) {
+      const int mid = (hi + lo) >> 1;
+      if (xx[mid] <= x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  }
+  return lo;
+}
+
+__device__ __forceinline__ int locate_reg(const double *xx, int n, double x) {   // mptrac.c:3559-3574
+  const int i = (int) ((x - xx[0]) / (xx[1] - xx[0]));
+  return i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+}
+
+// ---- interpolation (mptrac.c:2755-3170) ------------------------------------
+
+struct Stencil {   // ci[3], cw[3] of INTPOL_INIT (mptrac.h:1174)
+  int ip, ix, iy;
+  double wp, wx, wy;
+};
+
+__device__ __forceinline__ Stencil stencil_zero() {
+  Stencil s;
+  s.ip = s.ix = s.iy = 0;
+  s.wp = s.wx = s.wy = 0.0;
+  return s;
+}
+
+// intpol_check_lon_lat / intpol_check_cartesian, mptrac.c:2755-2803
+__device__ __forceinline__ void check_horizontal(const DevMet &M, const Axes &A, double lon, double lat,
+                                                 double &lon2, double &lat2) {
+  const double x0 = A.lon[0], x1 = A.lon[M.nx - 1];
+  const double y0 = A.lat[0], y1 = A.lat[M.ny - 1];
+  if (M.coord_type == 0) {
+    lon2 = fmod_trunc(lon, 360.);
+    if (lon2 < x0)
+      lon2 += 360;
+    else if (lon2 > x1)
+      lon2 -= 360;
+  } else {
+    if (x0 < x1)
+      lon2 = dmin(dmax(lon, x0), x1);
+    else
+      lon2 = dmin(dmax(lon, x1), x0);
+  }
+  if (y0 < y1)
+    lat2 = dmin(dmax(lat, y0), y1);
+  else
+    lat2 = dmin(dmax(lat, y1), y0);
+}
+
+// index/weight set-up of intpol_met_space_3d, mptrac.c:2997-3021
+__device__ __forceinline__ void stencil_3d(const DevMet &M, const Axes &A, double p, double lon, double lat,
+                                           Stencil &s) {
+  double lon2, lat2;
+  check_horizontal(M, A, lon, lat, lon2, lat2);
+  s.ip = locate_irr(A.p, M.np, p, M.p_ascending);
+  s.ix = locate_reg(A.lon, M.nx, lon2);
+  s.iy = locate_irr(A.lat, M.ny, lat2, M.lat_ascending);
+  s.wp = (A.p[s.ip + 1] - p) / (A.p[s.ip + 1] - A.p[s.ip]);
+  s.wx = (A.lon[s.ix + 1] - lon2) / (A.lon[s.ix + 1] - A.lon[s.ix]);
+  s.wy = (A.lat[s.iy + 1] - lat2) / (A.lat[s.iy + 1] - A.lat[s.iy]);
+}
+
+// index/weight set-up of intpol_met_space_2d, mptrac.c:3059-3081
+__device__ __forceinline__ void stencil_2d(const DevMet &M, const Axes &A, double lon, double lat, Stencil &s) {
+  double lon2, lat2;
+  check_horizontal(M, A, lon, lat, lon2, lat2);
+  s.ix = locate_reg(A.lon, M.nx, lon2);
+  s.iy = locate_irr(A.lat, M.ny, lat2, M.lat_ascending);
+  s.wx = (A.lon[s.ix + 1] - lon2) / (A.lon[s.ix + 1] - A.lon[s.ix]);
+  s.wy = (A.lat[s.iy + 1] - lat2) / (A.lat[s.iy + 1] - A.lat[s.iy]);
+}
+
+// The eight corners of one stencil for both snapshots: 16 x 16-byte loads,
+// issued together so that they are all in flight before the first use.
+struct Corners {
+  f32x4 lo[2][2][2];   // [di][dj][snapshot] at level ip
+  f32x4 hi[2][2][2];   // at level ip + 1
+};
+
+__device__ __forceinline__ void load_corners(const f32x4 *__restrict__ g, const DevMet &M, const Stencil &s,
+                                             Corners &c) {
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++) {
+      const size_t cell = ((size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj)) * (size_t) M.np
+        + (size_t) s.ip;
+      const f32x4 *q = g + 2 * cell;
+      c.lo[di][dj][0] = q[0];
+      c.lo[di][dj][1] = q[1];
+      c.hi[di][dj][0] = q[2];
+      c.hi[di][dj][1] = q[3];
+    }
+}
+
+// intpol_met_space_3d, mptrac.c:3023-3043, for component k of snapshot t.
+// The difference of the two float corners is taken in single precision, as
+// the reference's C expression does (float - float), and only then widened.
+__device__ __forceinline__ double space_3d(const Corners &c, const Stencil &s, int t, int k) {
+  const double c00 = s.wp * (double) (c.lo[0][0][t][k] - c.hi[0][0][t][k]) + (double) c.hi[0][0][t][k];
+  const double c01 = s.wp * (double) (c.lo[0][1][t][k] - c.hi[0][1][t][k]) + (double) c.hi[0][1][t][k];
+  const double c10 = s.wp * (double) (c.lo[1][0][t][k] - c.hi[1][0][t][k]) + (double) c.hi[1][0][t][k];
+  const double c11 = s.wp * (double) (c.lo[1][1][t][k] - c.hi[1][1][t][k]) + (double) c.hi[1][1][t][k];
+  const double r0 = s.wy * (c00 - c01) + c01;
+  const double r1 = s.wy * (c10 - c11) + c11;
+  return s.wx * (r0 - r1) + r1;
+}
+
+// intpol_met_time_3d, mptrac.c:3112-3137
+__device__ __forceinline__ double time_3d(const Corners &c, const Stencil &s, double wt, int k) {
+  const double v0 = space_3d(c, s, 0, k);
+  const double v1 = space_3d(c, s, 1, k);
+  return wt * (v0 - v1) + v1;
+}
+
+__device__ __forceinline__ double time_weight(const DevMet &M, double ts) {   // mptrac.c:3133
+  return (M.time1 - ts) / (M.time1 - M.time0);
+}
+
+// Four corners of the packed surface record: [ix][iy][4] f32x4.
+struct Corners2 {
+  f32x4 v[2][2][4];
+};
+
+// `which` selects the 16-byte pieces to fetch: bit 0 -> {ps,pbl,cape,cin},
+// bit 1 -> {pel,pct,pcb,cl} (both snapshots each).
+template <int WHICH>
+__device__ __forceinline__ void load_corners2(const DevMet &M, const Stencil &s, Corners2 &c) {
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++) {
+      const f32x4 *q = M.sfc + 4 * ((size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj));
+      if (WHICH & 1) {
+        c.v[di][dj][0] = q[0];
+        c.v[di][dj][2] = q[2];
+      }
+      if (WHICH & 2) {
+        c.v[di][dj][1] = q[1];
+        c.v[di][dj][3] = q[3];
+      }
+    }
+}
+
+// field f (MPHIP_PS ... MPHIP_CL) lives in piece f/4 (+2 for met1), lane f%4
+// intpol_met_space_2d value part, mptrac.c:3083-3107
+__device__ __forceinline__ double space_2d(const Corners2 &c, const Stencil &s, int t, int f) {
+  const int piece = (f >> 2) + 2 * t, k = f & 3;
+  const double c00 = c.v[0][0][piece][k];
+  const double c01 = c.v[0][1][piece][k];
+  const double c10 = c.v[1][0][piece][k];
+  const double c11 = c.v[1][1][piece][k];
+  if (isfinite(c00) && isfinite(c01) && isfinite(c10) && isfinite(c11)) {
+    const double r0 = s.wy * (c00 - c01) + c01;
+    const double r1 = s.wy * (c10 - c11) + c11;
+    return s.wx * (r0 - r1) + r1;
+  }
+  if (s.wy < 0.5)
+    return s.wx < 0.5 ? c11 : c01;
+  return s.wx < 0.5 ? c10 : c00;
+}
+
+// intpol_met_time_2d, mptrac.c:3141-3170
+__device__ __forceinline__ double time_2d(const Corners2 &c, const Stencil &s, double wt, int f) {
+  const double v0 = space_2d(c, s, 0, f);
+  const double v1 = space_2d(c, s, 1, f);
+  if (isfinite(v0) && isfinite(v1))
+    return wt * (v0 - v1) + v1;
+  return wt < 0.5 ? v1 : v0;
+}
+
+// ---- climatological tropopause and weights --------------------------------
+
+// clim_tropo, mptrac.c:213-237
+__device__ __forceinline__ double clim_tropo(const DevClim &C, double t, double lat) {
+  double sec = fmod_trunc(t, 365.25 * 86400.);
+  while (sec < 0)
+    sec += 365.25 * 86400.;
+  const int it = locate_irr(C.time, C.ntime, sec, 1);
+  const int il = locate_reg(C.lat, C.nlat, lat);
+  const double pa = lin(C.lat[il], C.tropo[it][il], C.lat[il + 1], C.tropo[it][il + 1], lat);
+  const double pb = lin(C.lat[il], C.tropo[it + 1][il], C.lat[il + 1], C.tropo[it + 1][il + 1], lat);
+  return lin(C.time[it], pa, C.time[it + 1], pb, sec);
+}
+
+// tropo_weight, mptrac.c:12748-12770
+__device__ __forceinline__ double tropo_weight(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat,
+                                               double p) {
+  const double pt = clim_tropo(C, time, ctl.met_coord_type == 0 ? lat : ctl.met_utm_ref_lat);
+  const double p1 = pt * 0.866877899;
+  const double p0 = pt / 0.866877899;
+  if (p > p0)
+    return 1;
+  if (p < p1)
+    return 0;
+  return lin(p0, 1.0, p1, 0.0, p);
+}
+
+// pbl_weight, mptrac.c:8358-8376
+__device__ __forceinline__ double pbl_weight(const mphip_ctl_t &ctl, double p, double pbl, double ps) {
+  const double p1 = pbl - ctl.turb_pbl_trans * (ps - pbl);
+  const double p0 = pbl;
+  if (p > p0)
+    return 1;
+  if (p < p1)
+    return 0;
+  return lin(p0, 1.0, p1, 0.0, p);
+}
+
+// sedi, mptrac.c:12506-12535
+__device__ __forceinline__ double sedi(double p, double T, double rp, double rhop) {
+  const double r = rp * 1e-6;
+  const double rho = rho_air(p, T);
+  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * pow(T / 296.16, 1.5);
+  const double v = sqrt(8. * kKB * T / (kPi * kMAir));
+  const double lambda = 2. * eta / (rho * v);
+  const double K = lambda / r;
+  const double G = 1. + K * (1.249 + 0.42 * exp(-0.87 / K));
+  return 2. * (r * r) * (rhop - rho) * kG0 / (9. * eta) * G;
+}
+
+// ---- random numbers (mptrac.c:5784-5828) -----------------------------------
+
+// Squares (Widynski 2022), five rounds, the reference's key (mptrac.c:5788)
+__device__ __forceinline__ uint64_t squares(uint64_t ctr) {
+  const uint64_t key = 0xc8e4fd154ce32f6dULL;
+  uint64_t x, y, z, t;
+  y = x = ctr * key;
+  z = y + key;
+  x = x * x + y;
+  x = (x >> 32) | (x << 32);
+  x = x * x + z;
+  x = (x >> 32) | (x << 32);
+  x = x * x + y;
+  x = (x >> 32) | (x << 32);
+  t = x = x * x + z;
+  x = (x >> 32) | (x << 32);
+  return t ^ ((x * x + y) >> 32);
+}
+
+// (double) r / (double) UINT64_MAX, mptrac.c:5810; the divisor is 2^64
+__device__ __forceinline__ double uniform01(uint64_t ctr) {
+  return (double) squares(ctr) * 0x1p-64;
+}
+
+// Single-precision sine / cosine exactly as the C library the reference's CPU
+// build links against computes them (glibc >= 2.28 sinf/cosf, taken from the
+// ARM optimized-routines "sincosf": reduction by multiples of pi/2 and two
+// short polynomials, all in double precision, result rounded to float).
+// Restated from the published algorithm; valid for |x| < 120 (the Box-Muller
+// angle is in [0, 2 pi]).  Bit-identical to glibc 2.35 for every float in
+// [0, 2 pi] (tests/test_sincosf.py).
+struct SinCosTab {
+  double c0, c1, c2, c3, c4, s1, s2, s3;
+};
+
+__device__ __forceinline__ float sincosf_poly(double x, double x2, double csign, int n) {
+  // csign = +1 -> table 0, -1 -> table 1 (cosine polynomial negated)
+  if ((n & 1) == 0) {
+    const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
+    const double x3 = x * x2;
+    const double s1 = s2c + x2 * s3c;
+    const double x7 = x3 * x2;
+    const double s = x + x3 * s1c;
+    return (float) (s + x7 * s1);
+  } else {
+    const double c0 = csign * 0x1p0, c1c = csign * -0x1.ffffffd0c621cp-2, c2c = csign * 0x1.55553e1068f19p-5;
+    const double c3c = csign * -0x1.6c087e89a359dp-10, c4c = csign * 0x1.99343027bf8c3p-16;
+    const double x4 = x2 * x2;
+    const double c2 = c3c + x2 * c4c;
+    const double c1 = c0 + x2 * c1c;
+    const double x6 = x4 * x2;
+    const double c = c1 + x4 * c2c;
+    return (float) (c + x6 * c2);
+  }
+}
+
+__device__ __forceinline__ uint32_t abstop12(float x) {
+  return (__float_as_uint(x) >> 20) & 0x7ff;
+}
+
+// which = 0: sinf(y), which = 1: cosf(y)
+__device__ __forceinline__ float libm_sincosf(float y, int which) {
+  double x = (double) y;
+  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+    if (abstop12(y) < abstop12(0x1p-12f))
+      return which ? 1.0f : y;
+    return sincosf_poly(x, x * x, 1.0, which);
+  }
+  const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+  const double r = x * hpi_inv;
+  const int n = ((int32_t) r + 0x800000) >> 24;
+  x = x - n * hpi;
+  const int q = n & 3;
+  const double sgn = (q == 1 || q == 2) ? -1.0 : 1.0;
+  const double csign = (n & 2) ? -1.0 : 1.0;
+  return sincosf_poly(x * sgn, x * x, csign, n ^ which);
+}
+
+// Element i of the array module_rng(..., method = 1) would have produced for
+// base counter c0 (mptrac.c:5821-5826): Box-Muller over the flat pairs
+// (2j, 2j+1) of the uniform stream.
+__device__ __forceinline__ void normal_pair(uint64_t c0, uint64_t j2, double &even, double &odd) {
+  const double ua = uniform01(c0 + j2);
+  const double ub = uniform01(c0 + j2 + 1);
+  const double r = sqrt(-2.0 * log(ua));
+  const double phi = 2.0 * kPi * ub;
+  const float phif = (float) phi;
+  even = r * libm_sincosf(phif, 1);
+  odd = r * libm_sincosf(phif, 0);
+}
+
+// the three normals rs[3g], rs[3g+1], rs[3g+2] of global particle g
+__device__ __forceinline__ void normal_triple(uint64_t c0, uint64_t g, double &r0, double &r1, double &r2) {
+  const uint64_t i0 = 3 * g;
+  double a, b, c, d;
+  if ((i0 & 1) == 0) {
+    normal_pair(c0, i0, a, b);       // elements i0, i0+1
+    normal_pair(c0, i0 + 2, c, d);   // element i0+2 (and i0+3, unused)
+    r0 = a;
+    r1 = b;
+    r2 = c;
+  } else {
+    normal_pair(c0, i0 - 1, a, b);   // element i0 is the odd member
+    normal_pair(c0, i0 + 1, c, d);   // elements i0+1, i0+2
+    r0 = b;
+    r1 = c;
+    r2 = d;
+  }
+}
+
+// ---- per-particle state -----------------------------------------------------
+
+struct Particle {
+  double time, lon, lat, p, dt;
+};
+
+// module_timesteps, mptrac.c:6016-6041
+__device__ __forceinline__ double timestep_of(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, double time,
+                                              double lon, double lat, double t) {
+  const double dir = ctl.direction;
+  double dt = 0.0;
+  if (dir * (time - ctl.t_start) >= 0 && dir * (time - ctl.t_stop) <= 0 && dir * (time - t) < 0)
+    dt = t - time;
+  if (M.local && (lon <= A.lon[0] || lon >= A.lon[M.nx - 1] || lat <= M.latmin || lat >= M.latmax))
+    dt = 0.0;
+  return dt;
+}
+
+// module_position, mptrac.c:5445-5488
+__device__ __forceinline__ void position(const DevMet &M, const Axes &A, Particle &P) {
+  if (M.coord_type == 0) {
+    double lon = fmod_trunc(P.lon, 360.);
+    double lat = fmod_trunc(P.lat, 360.);
+    while (lat < -90 || lat > 90) {
+      if (lat > 90) {
+        lat = 180 - lat;
+        lon += 180;
+      }
+      if (lat < -90) {
+        lat = -180 - lat;
+        lon += 180;
+      }
+    }
+    while (lon < -180)
+      lon += 360;
+    while (lon >= 180)
+      lon -= 360;
+    P.lon = lon;
+    P.lat = lat;
+  } else {
+    const double x0 = A.lon[0], x1 = A.lon[M.nx - 1], y0 = A.lat[0], y1 = A.lat[M.ny - 1];
+    P.lon = (x0 < x1) ? dmin(dmax(P.lon, x0), x1) : dmin(dmax(P.lon, x1), x0);
+    P.lat = (y0 < y1) ? dmin(dmax(P.lat, y0), y1) : dmin(dmax(P.lat, y1), y0);
+  }
+  const double ptop = A.p[M.np - 1];
+  if (P.p < ptop) {
+    P.p = ptop * ptop / P.p;
+  } else if (P.p > 300.) {
+    // INTPOL_2D(ps, 0) on the zeroed stencil of INTPOL_INIT (mptrac.c:5449,
+    // 5484): indices 0, weights 0 -> the value at grid node [1][1].  Reference
+    // behaviour, reproduced; every lane reads the same four records.
+    const Stencil s = stencil_zero();
+    Corners2 c;
+    load_corners2<1>(M, s, c);
+    const double ps = time_2d(c, s, time_weight(M, P.time), MPHIP_PS);
+    if (P.p > ps)
+      P.p = ps * ps / P.p;
+  }
+}
+
+// module_advect, pressure-level branch, mptrac.c:3612-3677
+template <int ADVECT>
+__device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particle &P) {
+  const int ct = M.coord_type;
+  const double dt = P.dt;
+  double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0;
+  double x0 = 0, x1 = 0, x2 = 0;
+#pragma unroll
+  for (int i = 0; i < ADVECT; i++) {
+    double dts;
+    if (i == 0) {
+      dts = 0.0;
+      x0 = P.lon;
+      x1 = P.lat;
+      x2 = P.p;
+    } else {
+      dts = (i == 3 ? 1.0 : 0.5) * dt;
+      x0 = P.lon + dx2coord(ct, dts * u, P.lat);
+      x1 = P.lat + dy2coord(ct, dts * v);
+      x2 = P.p + dts * w;
+    }
+    const double tm = P.time + dts;
+    Stencil s;
+    stencil_3d(M, A, x2, x0, x1, s);
+    Corners c;
+    load_corners(M.wind, M, s, c);
+    const double wt = time_weight(M, tm);
+    u = time_3d(c, s, wt, 0);
+    v = time_3d(c, s, wt, 1);
+    w = time_3d(c, s, wt, 2);
+    double k = 1.0;
+    if (ADVECT == 2)
+      k = (i == 0 ? 0.0 : 1.0);
+    else if (ADVECT == 4)
+      k = (i == 0 || i == 3 ? 1.0 / 6.0 : 2.0 / 6.0);
+    um += k * u;
+    vm += k * v;
+    wm += k * w;
+  }
+  P.time += dt;
+  P.lon += dx2coord(ct, dt * um, (ADVECT == 2 ? x1 : P.lat));
+  P.lat += dy2coord(ct, dt * vm);
+  P.p += dt * wm;
+}
+
+__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P) {
+  if (ctl.advect == 4)
+    advect_n<4>(M, A, P);
+  else if (ctl.advect == 2)
+    advect_n<2>(M, A, P);
+  else
+    advect_n<1>(M, A, P);
+}
+
+// the Kz blend evaluated at a displaced pressure, mptrac.c:4669-4688
+__device__ __forceinline__ double kz_blend(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat,
+                                           double p, double pbl, double ps) {
+  const double wpbl = pbl_weight(ctl, p, pbl, ps);
+  const double wtrop = tropo_weight(ctl, C, time, lat, p) * (1.0 - wpbl);
+  const double wstrat = 1.0 - wpbl - wtrop;
+  return wpbl * ctl.turb_dz_pbl + wtrop * ctl.turb_dz_trop + wstrat * ctl.turb_dz_strat;
+}
+
+// module_diff_turb, mptrac.c:4603-4733
+__device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevClim &C,
+                                          Particle &P, uint64_t ctr, uint64_t g) {
+  const int ct = M.coord_type;
+  Stencil s = stencil_zero();
+  stencil_2d(M, A, P.lon, P.lat, s);
+  Corners2 c;
+  load_corners2<1>(M, s, c);
+  const double wt = time_weight(M, P.time);
+  const double pbl = time_2d(c, s, wt, MPHIP_PBL);
+  if (ctl.turb_pbl_scheme > 0 && P.p >= pbl)
+    return;
+  const double ps = time_2d(c, s, wt, MPHIP_PS);
+  const double ptop = A.p[M.np - 1];
+
+  const double wpbl = pbl_weight(ctl, P.p, pbl, ps);
+  const double wtrop = tropo_weight(ctl, C, P.time, P.lat, P.p) * (1.0 - wpbl);
+  const double wstrat = 1.0 - wpbl - wtrop;
+  const double Kx = wpbl * ctl.turb_dx_pbl + wtrop * ctl.turb_dx_trop + wstrat * ctl.turb_dx_strat;
+  const double Kz = wpbl * ctl.turb_dz_pbl + wtrop * ctl.turb_dz_trop + wstrat * ctl.turb_dz_strat;
+  const double dt_abs = fabs(P.dt);
+
+  double rs0, rs1, rs2;
+  normal_triple(ctr, g, rs0, rs1, rs2);
+
+  if (Kx > 0) {
+    const double sigma_h = sqrt(2.0 * Kx * dt_abs);
+    P.lon += dx2coord(ct, rs0 * sigma_h, P.lat);
+    P.lat += dy2coord(ct, rs1 * sigma_h);
+  }
+  if (Kz > 0) {
+    const double sigma_z = sqrt(2.0 * Kz * dt_abs) * 1e-3;
+    const double p_save = P.p;
+    const double eps_km = 0.01;
+    const double p_up = p_save + dz2dp(eps_km, p_save);
+    const double p_dn = p_save + dz2dp(-eps_km, p_save);
+    const double Kz_up = kz_blend(ctl, C, P.time, P.lat, dmax(ptop, dmin(ps, p_up)), pbl, ps);
+    const double Kz_dn = kz_blend(ctl, C, P.time, P.lat, dmax(ptop, dmin(ps, p_dn)), pbl, ps);
+    const double dKz_dz = (Kz_up - Kz_dn) / (2.0 * eps_km * 1e3);
+    const double dlnrho_dz = -1.0 / (1e3 * kH0);
+    const double w_drift = dKz_dz + Kz * dlnrho_dz;
+    const double dz_drift = w_drift * dt_abs * 1e-3;
+    const double dz_tot = rs2 * sigma_z + dz_drift;
+    double ptrial = p_save + dz2dp(dz_tot, p_save);
+    for (int iter = 0; iter < 10; iter++) {
+      if (ptrial > ps)
+        ptrial = ps * ps / ptrial;
+      else if (ptrial < ptop)
+        ptrial = ptop * ptop / ptrial;
+      else
+        break;
+    }
+    P.p = dmax(ptop, dmin(ps, ptrial));
+  }
+}
+
+// module_diff_meso, mptrac.c:4280-4338
+__device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                          float &up, float &vp, float &wp, uint64_t ctr, uint64_t g) {
+  // HIP's __fadd_rn / __fmul_rn are plain operators, so contraction has to be
+  // switched off here for the single-precision statistics to round like the
+  // reference's separate multiply and add (the variance is a small difference
+  // of large sums: an FMA changes sigma at the 1e-5 level).
+#pragma clang fp contract(off)
+  const int ct = M.coord_type;
+  // raw (un-wrapped) coordinates, mptrac.c:4283-4285
+  Stencil s;
+  s.ix = locate_reg(A.lon, M.nx, P.lon);
+  s.iy = locate_irr(A.lat, M.ny, P.lat, M.lat_ascending);
+  s.ip = locate_irr(A.p, M.np, P.p, M.p_ascending);
+  Corners c;
+  load_corners(M.wind, M, s, c);
+
+  // single-precision sums in the reference's order: i (lon), j (lat),
+  // k (level), met0 before met1
+  float mean[3] = { 0, 0, 0 }, sig[3] = { 0, 0, 0 };
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const float a = (k == 0 ? c.lo[i][j][t][q] : c.hi[i][j][t][q]);
+            mean[q] = mean[q] + a;
+            sig[q] = sig[q] + a * a;
+          }
+  float sd[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const float m16 = mean[q] / 16.f;
+    const float var = sig[q] / 16.f - m16 * m16;
+    sd[q] = (var > 0 ? sqrtf(var) : 0.f);
+  }
+
+  const double r = 1 - 2 * fabs(P.dt) / ctl.dt_met;
+  const double r2 = sqrt(1 - r * r);
+  double rs0, rs1, rs2;
+  normal_triple(ctr, g, rs0, rs1, rs2);
+
+  if (ctl.turb_mesox > 0) {
+    up = (float) (r * up + r2 * rs0 * ctl.turb_mesox * sd[0]);
+    P.lon += dx2coord(ct, up * P.dt, P.lat);
+    vp = (float) (r * vp + r2 * rs1 * ctl.turb_mesox * sd[1]);
+    P.lat += dy2coord(ct, vp * P.dt);
+  }
+  if (ctl.turb_mesoz > 0) {
+    wp = (float) (r * wp + r2 * rs2 * ctl.turb_mesoz * sd[2]);
+    P.p += wp * P.dt;
+  }
+}
+
+// temperature at (p, lon, lat): INTPOL_3D(t, 1)
+__device__ __forceinline__ double temperature_at(const DevMet &M, const Axes &A, double time, double p, double lon,
+                                                 double lat) {
+  Stencil s;
+  stencil_3d(M, A, p, lon, lat, s);
+  Corners c;
+  load_corners(M.wind, M, s, c);
+  return time_3d(c, s, time_weight(M, time), 3);
+}
+
+// module_convection, mptrac.c:4116-4170
+__device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                           uint64_t ctr, uint64_t g) {
+  Stencil s = stencil_zero();
+  stencil_2d(M, A, P.lon, P.lat, s);
+  Corners2 c;
+  load_corners2<3>(M, s, c);
+  const double wt = time_weight(M, P.time);
+  const double ps = time_2d(c, s, wt, MPHIP_PS);
+  double pbot = ps, ptop = ps;
+  if (ctl.conv_mix_pbl) {
+    const double pbl = time_2d(c, s, wt, MPHIP_PBL);
+    ptop = pbl - ctl.conv_pbl_trans * (ps - pbl);
+  }
+  if (ctl.conv_cape >= 0) {
+    const double cape = time_2d(c, s, wt, MPHIP_CAPE);
+    const double cin = time_2d(c, s, wt, MPHIP_CIN);
+    const double pel = time_2d(c, s, wt, MPHIP_PEL);
+    if (isfinite(cape) && cape >= ctl.conv_cape && (ctl.conv_cin <= 0 || (isfinite(cin) && cin >= ctl.conv_cin)))
+      ptop = dmin(ptop, pel);
+  }
+  if (ptop != pbot && P.p >= ptop) {
+    const double tbot = temperature_at(M, A, P.time, pbot, P.lon, P.lat);
+    const double ttop = temperature_at(M, A, P.time, ptop, P.lon, P.lat);
+    const double rhobot = pbot / tbot;
+    const double rhotop = ptop / ttop;
+    const double rs = uniform01(ctr + g);
+    const double rho = rhobot + (rhotop - rhobot) * rs;
+    P.p = lin(rhobot, pbot, rhotop, ptop, rho);
+  }
+}
+
+// module_sedi, mptrac.c:5869-5882
+__device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Particle &P, double rp, double rhop) {
+  const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
+  const double v_s = sedi(P.p, t, rp, rhop);
+  P.p += dz2dp(v_s * P.dt / 1000., P.p);
+}
+
+}   // namespace mphip

@@ -1,0 +1,528 @@
+// mphip_kernels.hpp -- __global__ kernels of the MI355X back end.
+//
+//   step_kernel      fused per-particle time step (all per-particle modules
+//                    of mptrac_run_timestep selected by a module mask)
+//   pack_*           build the packed two-snapshot meteo grids
+//   sort_*           32-bit LSD radix sort of the grid-cell key + fused gather
+//   mix_* / grid_*   inter-parcel mixing and gridded-output sums
+#pragma once
+
+#include "mphip_device.hpp"
+
+namespace mphip {
+
+// ---------------------------------------------------------------------------
+// fused step
+// ---------------------------------------------------------------------------
+
+struct StepParams {
+  mphip_ctl_t ctl;
+  DevMet met;
+  DevAtm atm;
+  const DevClim *clim;
+  double t;
+  unsigned mask;          // MPHIP_MOD_* bits to run (when the kernel is the generic instantiation)
+  int nblocks_logical;    // multiple of 8
+  uint64_t ctr_turb, ctr_meso, ctr_conv;   // base counters of the module_rng calls
+};
+
+constexpr unsigned kMaskGeneric = 0xffffffffu;
+constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a later launch reads it)
+constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO
+  | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI | MPHIP_MOD_POSITION2;
+
+// common tail of decay / wet / dry deposition (mptrac.c:4251-4260, 6279-6288, 4786-4795)
+__device__ __forceinline__ void apply_loss(const mphip_ctl_t &ctl, const DevAtm &a, long long i, double aux,
+                                           int qnt_mloss, double rate) {
+  if (ctl.qnt_m >= 0) {
+    double m = a.q[ctl.qnt_m][i];
+    if (qnt_mloss >= 0)
+      a.q[qnt_mloss][i] += m * (1 - aux);
+    a.q[ctl.qnt_m][i] = m * aux;
+    if (ctl.qnt_loss_rate >= 0)
+      a.q[ctl.qnt_loss_rate][i] += rate;
+  }
+  if (ctl.qnt_vmr >= 0)
+    a.q[ctl.qnt_vmr][i] *= aux;
+}
+
+// module_wet_depo, mptrac.c:6170-6289
+__device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
+                                         long long i, const Particle &P) {
+  Stencil s = stencil_zero();
+  stencil_2d(M, A, P.lon, P.lat, s);
+  Corners2 c2;
+  load_corners2<2>(M, s, c2);
+  const double wt = time_weight(M, P.time);
+  const double pct = time_2d(c2, s, wt, MPHIP_PCT);
+  if (!isfinite(pct) || P.p <= pct)
+    return;
+  const double pcb = time_2d(c2, s, wt, MPHIP_PCB);
+  const double cl = time_2d(c2, s, wt, MPHIP_CL);
+  const double Is = pow(1. / ctl.wet_depo_pre[0] * cl, 1. / ctl.wet_depo_pre[1]);
+  if (Is < 0.01)
+    return;
+  stencil_3d(M, A, P.p, P.lon, P.lat, s);
+  Corners c;
+  load_corners(M.cloud, M, s, c);
+  const double lwc = time_3d(c, s, wt, 0);
+  const double rwc = time_3d(c, s, wt, 1);
+  const double iwc = time_3d(c, s, wt, 2);
+  const double swc = time_3d(c, s, wt, 3);
+  const bool inside = (lwc > 0 || rwc > 0 || iwc > 0 || swc > 0);
+  load_corners(M.wind, M, s, c);
+  const double t = time_3d(c, s, wt, 3);
+
+  double lambda = 0;
+  if (inside) {
+    double eta;
+    if (t > kWdTLiquid)
+      eta = 1;
+    else if (t <= kWdTIce)
+      eta = ctl.wet_depo_ic_ret_ratio;
+    else
+      eta = lin(kWdTLiquid, 1, kWdTIce, ctl.wet_depo_ic_ret_ratio, t);
+    if (ctl.wet_depo_ic_a > 0)
+      lambda = ctl.wet_depo_ic_a * pow(Is, ctl.wet_depo_ic_b) * eta;
+    else if (ctl.wet_depo_ic_h[0] > 0) {
+      double h = ctl.wet_depo_ic_h[0] * exp(ctl.wet_depo_ic_h[1] * (1. / t - 1. / kTRef));
+      if (ctl.wet_depo_so2_ph > 0) {
+        const double H_ion = pow(10., -ctl.wet_depo_so2_ph);
+        const double K_1 = kSO2K1Ref * exp(kSO2K1Temp * (1. / t - 1. / kTRef));
+        const double K_2 = kSO2K2Ref * exp(kSO2K2Temp * (1. / t - 1. / kTRef));
+        h *= (1. + K_1 / H_ion + K_1 * K_2 / (H_ion * H_ion));
+      }
+      const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
+      lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
+    }
+  } else {
+    const double eta = (t > kWdTLiquidBC) ? 1 : ctl.wet_depo_bc_ret_ratio;
+    if (ctl.wet_depo_bc_a > 0)
+      lambda = ctl.wet_depo_bc_a * pow(Is, ctl.wet_depo_bc_b) * eta;
+    else if (ctl.wet_depo_bc_h[0] > 0) {
+      const double h = ctl.wet_depo_bc_h[0] * exp(ctl.wet_depo_bc_h[1] * (1. / t - 1. / kTRef));
+      const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
+      lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
+    }
+  }
+  const double aux = exp(-P.dt * lambda);
+  apply_loss(ctl, a, i, aux, ctl.qnt_mloss_wet, lambda);
+}
+
+// module_dry_depo, mptrac.c:4753-4796
+__device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
+                                         long long i, const Particle &P) {
+  Stencil s = stencil_zero();
+  stencil_2d(M, A, P.lon, P.lat, s);
+  Corners2 c2;
+  load_corners2<1>(M, s, c2);
+  const double ps = time_2d(c2, s, time_weight(M, P.time), MPHIP_PS);
+  if (P.p < ps - ctl.dry_depo_dp)
+    return;
+  const double dz = 1000. * (zfromp(ps - ctl.dry_depo_dp) - zfromp(ps));
+  double v_dep;
+  if (ctl.qnt_rp > 0 && ctl.qnt_rhop > 0) {   // "> 0" as the reference, mptrac.c:4769
+    const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
+    v_dep = sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
+  } else
+    v_dep = ctl.dry_depo_vdep;
+  const double aux = exp(-P.dt * v_dep / dz);
+  apply_loss(ctl, a, i, aux, ctl.qnt_mloss_dry, v_dep / dz);
+}
+
+// One thread per particle, grid-stride.  Workgroup b of the launch is mapped
+// to logical block (b % 8) * (n / 8) + b / 8 so that each XCD (the dispatcher
+// places workgroup b on XCD b % 8) walks one contiguous eighth of the particle
+// arrays: with cell-sorted particles each XCD's L2 then holds one region of
+// the meteo grid instead of all of it.
+template <unsigned CT>
+__global__ __launch_bounds__(256) void step_kernel(const StepParams S) {
+  extern __shared__ double s_axes[];
+  const unsigned mask = (CT == kMaskGeneric) ? S.mask : CT;
+  const DevMet &M = S.met;
+  const DevAtm &a = S.atm;
+  const mphip_ctl_t &ctl = S.ctl;
+
+  double *s_lon = s_axes, *s_lat = s_axes + M.nx, *s_p = s_axes + M.nx + M.ny;
+  for (int i = threadIdx.x; i < M.nx; i += blockDim.x)
+    s_lon[i] = M.lon[i];
+  for (int i = threadIdx.x; i < M.ny; i += blockDim.x)
+    s_lat[i] = M.lat[i];
+  for (int i = threadIdx.x; i < M.np; i += blockDim.x)
+    s_p[i] = M.p[i];
+  __syncthreads();
+  Axes A;
+  A.lon = s_lon;
+  A.lat = s_lat;
+  A.p = s_p;
+
+  const int nb = S.nblocks_logical;
+  const int lb = (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8);
+  const long long per_block = (a.np + nb - 1) / nb;
+  const long long first = (long long) lb * per_block;
+  long long last = first + per_block;
+  if (last > a.np)
+    last = a.np;
+
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
+    Particle P;
+    P.time = a.time[i];
+    P.lon = a.lon[i];
+    P.lat = a.lat[i];
+    P.p = a.p[i];
+    if (mask & MPHIP_MOD_TIMESTEPS) {
+      P.dt = timestep_of(ctl, M, A, P.time, P.lon, P.lat, S.t);
+      if (mask & kStoreDt)
+        a.dt[i] = P.dt;
+    } else
+      P.dt = a.dt[i];
+    if (P.dt == 0)   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
+      continue;
+    const uint64_t g = (uint64_t) (a.ip0 + i);
+
+    if (mask & MPHIP_MOD_POSITION)
+      position(M, A, P);
+    if (mask & MPHIP_MOD_ADVECT)
+      advect(ctl, M, A, P);
+    if (mask & MPHIP_MOD_DIFF_TURB)
+      diff_turb(ctl, M, A, *S.clim, P, S.ctr_turb, g);
+    if (mask & MPHIP_MOD_DIFF_MESO) {
+      float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
+      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g);
+      a.up[i] = up;
+      a.vp[i] = vp;
+      a.wp[i] = wp;
+    }
+    if (mask & MPHIP_MOD_CONVECTION)
+      convection(ctl, M, A, P, S.ctr_conv, g);
+    if (mask & MPHIP_MOD_SEDI)
+      sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
+    if (mask & MPHIP_MOD_POSITION2)
+      position(M, A, P);
+
+    if (mask & MPHIP_MOD_ADVECT)
+      a.time[i] = P.time;
+    if (mask & kMovers) {
+      a.lon[i] = P.lon;
+      a.lat[i] = P.lat;
+      a.p[i] = P.p;
+    }
+
+    if (mask & MPHIP_MOD_LOSS_ZERO)
+      a.q[ctl.qnt_loss_rate][i] = 0;
+    if (mask & MPHIP_MOD_DECAY) {   // module_decay, mptrac.c:4241-4261
+      const double w = tropo_weight(ctl, *S.clim, P.time, P.lat, P.p);
+      const double tdec = w * ctl.tdec_trop + (1 - w) * ctl.tdec_strat;
+      const double aux = exp(-P.dt / tdec);
+      apply_loss(ctl, a, i, aux, ctl.qnt_mloss_decay, 1. / tdec);
+    }
+    if (mask & MPHIP_MOD_WET_DEPO)
+      wet_depo(ctl, M, A, a, i, P);
+    if (mask & MPHIP_MOD_DRY_DEPO)
+      dry_depo(ctl, M, A, a, i, P);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// packing of the two bracketing snapshots
+// ---------------------------------------------------------------------------
+
+struct PackSrc {
+  const float *f[2][4];   // [snapshot][component]; NULL -> zeros
+};
+
+__global__ void pack3d_kernel(f32x4 *__restrict__ out, PackSrc src, size_t ncell) {
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < ncell; i += (size_t) gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        v[k] = src.f[t][k] ? src.f[t][k][i] : 0.f;
+      out[2 * i + t] = v;
+    }
+  }
+}
+
+struct PackSrc2 {
+  const float *f[2][8];
+};
+
+__global__ void pack2d_kernel(f32x4 *__restrict__ out, PackSrc2 src, size_t ncol) {
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < ncol; i += (size_t) gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          v[k] = src.f[t][4 * h + k] ? src.f[t][4 * h + k][i] : 0.f;
+        out[4 * i + 2 * t + h] = v;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// module_sort: key, radix sort, gather (mptrac.c:5887-5995)
+// ---------------------------------------------------------------------------
+
+// key on the raw coordinates, mptrac.c:5913-5919
+__global__ void sort_key_kernel(DevMet M, DevAtm a, uint32_t *__restrict__ keys, int *__restrict__ idx) {
+  extern __shared__ double s_axes[];
+  double *s_lon = s_axes, *s_lat = s_axes + M.nx, *s_p = s_axes + M.nx + M.ny;
+  for (int i = threadIdx.x; i < M.nx; i += blockDim.x)
+    s_lon[i] = M.lon[i];
+  for (int i = threadIdx.x; i < M.ny; i += blockDim.x)
+    s_lat[i] = M.lat[i];
+  for (int i = threadIdx.x; i < M.np; i += blockDim.x)
+    s_p[i] = M.p[i];
+  __syncthreads();
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
+       i += (long long) gridDim.x * blockDim.x) {
+    const int ix = locate_reg(s_lon, M.nx, a.lon[i]);
+    const int iy = locate_irr(s_lat, M.ny, a.lat[i], M.lat_ascending);
+    const int iz = locate_irr(s_p, M.np, a.p[i], M.p_ascending);
+    keys[i] = (uint32_t) ((ix * M.ny + iy) * M.np + iz);
+    idx[i] = (int) i;
+  }
+}
+
+constexpr int kSortThreads = 256;
+constexpr int kSortRounds = 16;                            // keys per thread
+constexpr int kSortTile = kSortThreads * kSortRounds;      // keys per workgroup
+constexpr int kRadix = 256;
+
+// per-tile digit histogram -> counts[digit * ntiles + tile]
+__global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t *__restrict__ keys, long long n,
+                                                                 int shift, int ntiles, uint32_t *__restrict__ counts) {
+  __shared__ uint32_t h[kRadix];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const long long base = (long long) blockIdx.x * kSortTile;
+#pragma unroll 4
+  for (int r = 0; r < kSortRounds; r++) {
+    const long long i = base + r * kSortThreads + threadIdx.x;
+    if (i < n)
+      atomicAdd(&h[(keys[i] >> shift) & (kRadix - 1)], 1u);
+  }
+  __syncthreads();
+  counts[(size_t) threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive prefix sum over `m` counters, one workgroup, in place
+__global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t *__restrict__ counts, size_t m) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0)
+    carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (size_t base = 0; base < m; base += 1024) {
+    const size_t i = base + threadIdx.x;
+    const uint32_t v = i < m ? counts[i] : 0;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d);
+      if (lane >= d)
+        x += y;
+    }
+    if (lane == 63)
+      wsum[wave] = x;
+    __syncthreads();
+    uint32_t off = carry;
+    for (int w = 0; w < wave; w++)
+      off += wsum[w];
+    if (i < m)
+      counts[i] = off + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023)
+      carry = off + x;
+    __syncthreads();
+  }
+}
+
+// stable scatter of one digit pass
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32_t *__restrict__ keys_in,
+                                                                    const int *__restrict__ vals_in,
+                                                                    uint32_t *__restrict__ keys_out,
+                                                                    int *__restrict__ vals_out, long long n, int shift,
+                                                                    int ntiles, const uint32_t *__restrict__ offsets) {
+  __shared__ uint32_t running[kRadix];      // next free slot per digit
+  __shared__ uint32_t wcnt[4][kRadix];      // per-wave counts of the current round
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  running[threadIdx.x] = offsets[(size_t) threadIdx.x * ntiles + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+    wcnt[w][threadIdx.x] = 0;
+  __syncthreads();
+  const long long base = (long long) blockIdx.x * kSortTile;
+  for (int r = 0; r < kSortRounds; r++) {
+    const long long i = base + r * kSortThreads + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t key = valid ? keys_in[i] : 0xffffffffu;
+    const int val = valid ? vals_in[i] : 0;
+    const uint32_t d = (key >> shift) & (kRadix - 1);
+    // lanes of this wave holding the same digit
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1);
+      peers &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    const unsigned long long below = peers & ((1ull << lane) - 1ull);
+    const uint32_t rank_in_wave = __popcll(below);
+    if (valid && below == 0)
+      wcnt[wave][d] = __popcll(peers);
+    __syncthreads();
+    uint32_t pos = running[d] + rank_in_wave;
+    for (int w = 0; w < wave; w++)
+      pos += wcnt[w][d];
+    if (valid) {
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+    __syncthreads();
+    {
+      const int dd = threadIdx.x;
+      running[dd] += wcnt[0][dd] + wcnt[1][dd] + wcnt[2][dd] + wcnt[3][dd];
+      wcnt[0][dd] = wcnt[1][dd] = wcnt[2][dd] = wcnt[3][dd] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+// fused gather of every particle array through the permutation
+// (module_sort_help for time, p, lon, lat, q[*]; mptrac.c:5944-5949)
+struct GatherArgs {
+  const double *in[4 + MPHIP_NQ_MAX];
+  double *out[4 + MPHIP_NQ_MAX];
+  int narrays;
+};
+
+__global__ void sort_gather_kernel(GatherArgs g, const int *__restrict__ perm, long long n) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+    const int src = perm[i];
+    for (int a = 0; a < g.narrays; a++)
+      g.out[a][i] = g.in[a][src];
+  }
+}
+
+__global__ void keys_to_double_kernel(const uint32_t *__restrict__ k, double *__restrict__ out, long long n) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+    out[i] = (double) k[i];
+}
+
+// ---------------------------------------------------------------------------
+// module_mixing (mptrac.c:5169-5347) and write_grid sums (mptrac.c:13815-13872)
+// ---------------------------------------------------------------------------
+
+struct BoxGrid {
+  double lon0, lon1, lat0, lat1, z0, z1;
+  int nx, ny, nz;
+};
+
+// cell index of every particle, -1 if outside (mptrac.c:5201-5218, 13836-13855)
+__global__ void box_index_kernel(DevAtm a, BoxGrid G, double t0, double t1, int *__restrict__ cell) {
+  const double dz = (G.z1 - G.z0) / G.nz;
+  const double dlon = (G.lon1 - G.lon0) / G.nx;
+  const double dlat = (G.lat1 - G.lat0) / G.ny;
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
+       i += (long long) gridDim.x * blockDim.x) {
+    const double lon = a.lon[i], lat = a.lat[i], time = a.time[i];
+    const double zpart = zfromp(a.p[i]);
+    int c = -1;
+    if (!(time < t0 || time > t1 || lon < G.lon0 || lon >= G.lon1 || lat < G.lat0 || lat >= G.lat1
+          || zpart < G.z0 || zpart >= G.z1)) {
+      const int ix = (int) ((lon - G.lon0) / dlon);
+      const int iy = (int) ((lat - G.lat0) / dlat);
+      const int iz = (int) ((zpart - G.z0) / dz);
+      if (!(ix >= G.nx || iy >= G.ny || iz >= G.nz))
+        c = (ix * G.ny + iy) * G.nz + iz;
+    }
+    cell[i] = c;
+  }
+}
+
+// sums[0 .. ntot) += q, sums[ntot .. 2 ntot) += 1 (counts kept as doubles so
+// that one all-reduce of doubles covers both; exact below 2^53)
+__global__ void mix_accumulate_kernel(DevAtm a, const int *__restrict__ cell, const double *__restrict__ q,
+                                      const double *__restrict__ ens, int ngrid, size_t ntot,
+                                      double *__restrict__ sums) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
+       i += (long long) gridDim.x * blockDim.x) {
+    const int c = cell[i];
+    if (c >= 0) {
+      const size_t idx = (size_t) (ens ? (int) ens[i] : 0) * (size_t) ngrid + (size_t) c;
+      unsafeAtomicAdd(&sums[idx], q[i]);
+      unsafeAtomicAdd(&sums[ntot + idx], 1.0);
+    }
+  }
+}
+
+// q += (mean - q) * mixparam, mptrac.c:5324-5339
+__global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a, const int *__restrict__ cell,
+                                 double *__restrict__ q, const double *__restrict__ ens, int ngrid, size_t ntot,
+                                 const double *__restrict__ sums) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
+       i += (long long) gridDim.x * blockDim.x) {
+    const int c = cell[i];
+    if (c >= 0) {
+      const size_t idx = (size_t) (ens ? (int) ens[i] : 0) * (size_t) ngrid + (size_t) c;
+      double mixparam = 1.0;
+      if (ctl.mixing_trop < 1 || ctl.mixing_strat < 1) {
+        const double w = tropo_weight(ctl, *clim, a.time[i], a.lat[i], a.p[i]);
+        mixparam = w * ctl.mixing_trop + (1.0 - w) * ctl.mixing_strat;
+      }
+      const double cnt = sums[ntot + idx];
+      const double mean = cnt > 0 ? sums[idx] / cnt : sums[idx];
+      const double v = q[i];
+      q[i] = v + (mean - v) * mixparam;
+    }
+  }
+}
+
+// buf[0 .. ncell) += 1, buf[(1 + iq) ncell ..] += q, buf[(1 + nq + iq) ncell ..] += q^2
+__global__ void grid_accumulate_kernel(DevAtm a, const int *__restrict__ cell, int nq, size_t ncell,
+                                       double *__restrict__ buf) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
+       i += (long long) gridDim.x * blockDim.x) {
+    const int c = cell[i];
+    if (c >= 0) {
+      unsafeAtomicAdd(&buf[c], 1.0);
+      for (int iq = 0; iq < nq; iq++) {
+        const double v = 1.0 * a.q[iq][i];   // kernel weight 1 (mptrac.c:3305-3306)
+        unsafeAtomicAdd(&buf[(size_t) (1 + iq) * ncell + c], v);
+        unsafeAtomicAdd(&buf[(size_t) (1 + nq + iq) * ncell + c], v * v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// self-test kernels
+// ---------------------------------------------------------------------------
+
+__global__ void test_sincosf_kernel(uint32_t first, uint32_t count, float *__restrict__ c, float *__restrict__ s) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const float x = __uint_as_float(first + i);
+    c[i] = libm_sincosf(x, 1);
+    s[i] = libm_sincosf(x, 0);
+  }
+}
+
+// out[i], i < n: what module_rng(ctl, rs, n, method) leaves in rs[i]
+__global__ void test_rng_kernel(uint64_t ctr, long long n, int method, double *__restrict__ out) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+    if (method == 0)
+      out[i] = uniform01(ctr + (uint64_t) i);
+    else {
+      double e, o;
+      normal_pair(ctr, (uint64_t) i & ~1ull, e, o);
+      out[i] = (i & 1) ? o : e;
+    }
+  }
+}
+
+}   // namespace mphip

@@ -95,7 +95,7 @@ CTL_FIELDS = [
 
 def make_ctl_struct(name):
     """ctypes mirror of the C struct; one class per consumer so that the
-    product and the oracle do not share a type object."""
+    library bindings do not share a type object."""
     return type(name, (C.Structure,), {"_fields_": [(n, t) for n, t, _ in CTL_FIELDS]})
 
 

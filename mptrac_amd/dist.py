@@ -1,0 +1,58 @@
+"""One process per GPU: process-group plumbing and the all-reduce hook.
+
+PyTorch is used only as plumbing (``torch.distributed`` with backend "nccl",
+which is RCCL on ROCm, over xGMI).  The time-step loop needs no communication
+(particles are sharded by index range with replicated meteo grids,
+SURVEY.md 8(e)); the only exchanges are sums of small gridded buffers:
+write_grid's sums (src/mptrac.c:13862-13872) and module_mixing's cell sums
+(src/mptrac.c:5289-5303).  The C ABI calls back with a raw buffer address and a
+count of doubles; the hook wraps the address as a tensor without copying and
+all-reduces it in place.
+"""
+import ctypes
+import os
+
+
+class _DeviceBuffer:
+    """Minimal __cuda_array_interface__ carrier for a raw device address."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def env_rank_world():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    rank, _, world = env_rank_world()
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return dist
+
+
+def make_allreduce_hook(device_kind):
+    """Returns fn(ptr, count) summing `count` doubles at address `ptr` over all
+    ranks in place.  device_kind "cuda": HIP device memory (RCCL);
+    "cpu": host memory (gloo; used by the CPU tests of the N > 1 logic)."""
+    import torch
+    import torch.distributed as dist
+
+    if device_kind == "cuda":
+        def hook(ptr, count):
+            t = torch.as_tensor(_DeviceBuffer(ptr, count), device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+    else:
+        import numpy as np
+
+        def hook(ptr, count):
+            buf = (ctypes.c_double * count).from_address(int(ptr))
+            t = torch.from_numpy(np.frombuffer(buf, dtype=np.float64))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return hook

@@ -98,7 +98,7 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
     put2("pel", 300.0 + 100.0 * np.sin(lam2) + 0.0 * phi2)
     put2("pct", 400.0 + 100.0 * np.cos(lam2) + 0.0 * phi2)
     put2("pcb", 800.0 + 0.0 * lam2 * phi2)
-    put2("cl", 0.6 + 0.5 * amp * np.sin(lam2) * np.cos(phi2))
+    put2("cl", 0.7 + 0.4 * amp * np.sin(lam2) * np.cos(phi2))
 
     # periodic column is an exact copy of column 0 (mptrac.c:11726-11769)
     for d in (f3, f2):
@@ -107,22 +107,44 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
     return Met(time, lon, lat, p, f3, f2)
 
 
-def lcg_uniform(n, seed=12345):
-    """n uniforms in [0,1) from the 64-bit LCG s <- s*a + c (top 53 bits),
-    vectorised by jump-ahead (all arithmetic wraps mod 2**64)."""
-    a = np.uint64(6364136223846793005)
-    c = np.uint64(1442695040888963407)
+_LCG_A = 6364136223846793005
+_LCG_C = 1442695040888963407
+_M64 = 1 << 64
+
+
+def lcg_skip(seed, k):
+    """State of the LCG after k steps from `seed` (affine map composed by
+    binary exponentiation, Python integers)."""
+    A, C = 1, 0
+    a, c = _LCG_A, _LCG_C
+    while k:
+        if k & 1:
+            A, C = (a * A) % _M64, (a * C + c) % _M64
+        a, c = (a * a) % _M64, (a * c + c) % _M64
+        k >>= 1
+    return (A * seed + C) % _M64
+
+
+def lcg_uniform(n, seed=12345, skip=0):
+    """Uniforms number skip .. skip+n-1 of the 64-bit LCG s <- s*a + c (top 53
+    bits), vectorised by jump-ahead (all arithmetic wraps mod 2**64)."""
+    a = np.uint64(_LCG_A)
+    c = np.uint64(_LCG_C)
+    start = np.uint64(lcg_skip(seed, skip))
+    if n == 0:
+        return np.zeros(0)
     with np.errstate(over="ignore"):
         an = np.cumprod(np.full(n, a, dtype=np.uint64))              # a^1 .. a^n
         geo = np.cumsum(np.concatenate(([np.uint64(1)], an[:-1])))    # 1+a+..+a^(k-1)
-        s = an * np.uint64(seed) + c * geo
+        s = an * start + c * geo
     return (s >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
 def synthetic_particles(n, seed=12345, time=0.0, quantities=("m", "rp", "rhop"),
-                        lon=(-180.0, 180.0), lat=(-85.0, 85.0), z=(0.5, 29.5)):
-    """lon/lat/z uniformly scattered; q[m]=1, q[rp]=1 um, q[rhop]=1000 kg/m3."""
-    r = lcg_uniform(3 * n, seed).reshape(n, 3)
+                        lon=(-180.0, 180.0), lat=(-85.0, 85.0), z=(0.5, 29.5), first=0):
+    """Particles first .. first+n-1 of the seeded global set: lon/lat/z
+    uniformly scattered; q[m] in [0.5, 1.5), q[rp]=1 um, q[rhop]=1000 kg/m3."""
+    r = lcg_uniform(3 * n, seed, skip=3 * first).reshape(n, 3)
     atm = {
         "time": np.full(n, float(time)),
         "lon": lon[0] + (lon[1] - lon[0]) * r[:, 0],

@@ -348,6 +348,14 @@ uint64_t orc_squares(uint64_t ctr) {
   return t ^ ((x * x + y) >> 32);
 }
 
+void orc_libm_sincosf(const float *x, size_t n, float *cos_out, float *sin_out) {
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; i++) {
+    cos_out[i] = cosf(x[i]);
+    sin_out[i] = sinf(x[i]);
+  }
+}
+
 /* module_rng, RNG_TYPE=1 branch: n+1 uniforms, counter advanced by n+1, then
  * Box-Muller over flat pairs with single-precision trig (mptrac.c:5797-5827) */
 void orc_module_rng(const orc_ctl_t *ctl, orc_cache_t *cache, size_t n, int method) {

@@ -120,6 +120,8 @@ double orc_tropo_weight(const orc_ctl_t *ctl, const orc_clim_t *clim,
                         double time, double lat, double p);      /* mptrac.c:12748 */
 double orc_pbl_weight(const orc_ctl_t *ctl, double p, double pbl, double ps); /* mptrac.c:8358 */
 uint64_t orc_squares(uint64_t ctr);                              /* mptrac.c:5797-5809 */
+/* the C library's cosf / sinf, as module_rng calls them (mptrac.c:5824-5825) */
+void orc_libm_sincosf(const float *x, size_t n, float *cos_out, float *sin_out);
 void orc_intpol_met_time_3d(const orc_met_t *met0, const orc_met_t *met1, int field,
                             double ts, double p, double lon, double lat, double *var);
 void orc_intpol_met_time_2d(const orc_met_t *met0, const orc_met_t *met1, int field,

@@ -1,0 +1,70 @@
+"""The C-ABI library builds for gfx950, loads on a CPU-only box, exports every
+symbol include/mptrac_hip.h declares, and refuses to run without a device
+(no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mptrac_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mptrac_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b(mphip_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(n for n in names if not n.endswith("_fn")))
+
+
+def test_library_exports_every_declared_symbol():
+    L = hip.load()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/mptrac_hip.h but not exported"
+
+
+def test_struct_layouts_match_the_python_mirrors():
+    L = hip.load()
+    assert L.mphip_sizeof_ctl() == C.sizeof(hip.MphipCtl)
+    assert L.mphip_sizeof_met() == C.sizeof(hip.MphipMet)
+
+
+def test_header_cites_the_reference_interface():
+    txt = open(os.path.join(ROOT, "include", "mptrac_hip.h")).read()
+    for ref in ("mptrac_update_device", "mptrac_update_host", "mptrac_run_timestep", "mptrac_alloc",
+                "mptrac_get_met", "mptrac.c:7851"):
+        assert ref in txt
+
+
+def _have_gpu():
+    L = hip.load()
+    h = C.c_void_p()
+    rc = L.mphip_create(C.byref(h), 0)
+    if rc == 0:
+        L.mphip_destroy(h)
+    return rc == 0
+
+
+def test_no_cpu_fallback_without_a_device():
+    if _have_gpu():
+        pytest.skip("a HIP device is present")
+    from cases import make_case
+    ctl, clim, m0, m1, atm = make_case("advect", n=10, grid="tiny")
+    with pytest.raises(hip.MphipError):
+        hip.Simulation(ctl, clim, m0, m1, atm)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+    touch oracle/."""
+    pkg = os.path.join(ROOT, "mptrac_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".hpp", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for pat in (r"^\s*(from|import)\s+oracle", r"mptrac_oracle", r"orc_[a-z_]+\(", r"oracle/"):
+                    assert not re.search(pat, txt, flags=re.M), f"{f} reaches into the oracle ({pat})"
