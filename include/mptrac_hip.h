@@ -171,6 +171,15 @@ int mphip_get_sort(mphip_ctx *ctx, double *keys, int *perm);
 int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *sigma);
 
 int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
+
+/* Tuning knobs without a reference counterpart.
+ *   "locality_sort_interval" (default 10): the device keeps the particles stored
+ *   in meteo-grid-cell order and re-sorts every this many time steps so that
+ *   the gathers of neighbouring particles share cache lines.  The order is
+ *   internal: random numbers follow the external slot index and every download
+ *   returns the caller's order, so results do not depend on the value.
+ *   0 switches it off. */
+int mphip_set_option(mphip_ctx *ctx, const char *name, double value);
 int mphip_synchronize(mphip_ctx *ctx);
 
 /* Timing of the fused step kernel with HIP events on the context's stream:

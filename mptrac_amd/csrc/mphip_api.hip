@@ -59,8 +59,17 @@ struct mphip_ctx {
   double *d_arr[4 + MPHIP_NQ_MAX] = {};   // time, p, lon, lat, q[*]
   double *d_alt[4 + MPHIP_NQ_MAX] = {};   // gather targets (ping-pong)
   float *d_uvwp[3] = {};
+  float *d_uvwp_alt[3] = {};
   double *d_dt = nullptr;
+  double *d_dt_alt = nullptr;
   uint64_t rng_ctr = 0;
+
+  // internal locality order: particles are stored sorted by meteo grid cell;
+  // d_ext[i] is the external slot (the reference's ip) of stored particle i
+  int *d_ext = nullptr, *d_ext_alt = nullptr;
+  bool ext_identity = true;
+  int locality_interval = 10;         // re-sort every this many steps (0 = keep the caller's order)
+  int steps_since_resort = 1 << 30;
 
   // sort
   uint32_t *d_keys[2] = {};
@@ -136,6 +145,7 @@ DevAtm dev_atm(const mphip_ctx *c) {
   a.vp = c->d_uvwp[1];
   a.wp = c->d_uvwp[2];
   a.dt = c->d_dt;
+  a.ext = c->ext_identity ? nullptr : c->d_ext;
   a.np = c->np;
   a.ip0 = c->ip0;
   a.np_total = c->np_total;
@@ -325,13 +335,40 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   return 0;
 }
 
-// module_sort, mptrac.c:5887-5957
-int do_sort(mphip_ctx *ctx) {
+PermArgs perm_args(mphip_ctx *ctx, bool with_cache) {
+  PermArgs g;
+  memset(&g, 0, sizeof(g));
+  g.n8 = 4 + ctx->nq;
+  for (int k = 0; k < g.n8; k++) {
+    g.in8[k] = ctx->d_arr[k];
+    g.out8[k] = ctx->d_alt[k];
+  }
+  if (with_cache) {
+    g.in8[g.n8] = ctx->d_dt;
+    g.out8[g.n8] = ctx->d_dt_alt;
+    g.n8++;
+    g.n4 = 3;
+    for (int k = 0; k < 3; k++) {
+      g.in4[k] = ctx->d_uvwp[k];
+      g.out4[k] = ctx->d_uvwp_alt[k];
+    }
+  }
+  return g;
+}
+
+void perm_swap(mphip_ctx *ctx, bool with_cache) {
+  for (int k = 0; k < 4 + ctx->nq; k++)
+    std::swap(ctx->d_arr[k], ctx->d_alt[k]);
+  if (with_cache) {
+    std::swap(ctx->d_dt, ctx->d_dt_alt);
+    for (int k = 0; k < 3; k++)
+      std::swap(ctx->d_uvwp[k], ctx->d_uvwp_alt[k]);
+  }
+}
+
+// keys + stable LSD radix sort of (key, index); returns the buffer holding the result
+int sort_pairs(mphip_ctx *ctx, int wrapped, int *result_buf) {
   const long long n = ctx->np;
-  if (n == 0)
-    return 0;
-  if (ensure_packed(ctx))
-    return 1;
   const int ntiles = (int) ((n + kSortTile - 1) / kSortTile);
   const size_t m = (size_t) kRadix * ntiles;
   if (m > ctx->counts_cap) {
@@ -341,7 +378,7 @@ int do_sort(mphip_ctx *ctx) {
   }
   const DevMet M = dev_met(ctx);
   const DevAtm a = dev_atm(ctx);
-  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a,
+  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, wrapped,
                      ctx->d_keys[0], ctx->d_vals[0]);
   // number of 8-bit digits that can be non-zero
   const unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
@@ -358,17 +395,68 @@ int do_sort(mphip_ctx *ctx) {
                        ctx->d_vals[cur], ctx->d_keys[cur ^ 1], ctx->d_vals[cur ^ 1], n, shift, ntiles, ctx->d_counts);
     cur ^= 1;
   }
-  ctx->sorted_buf = cur;
-  GatherArgs g;
-  g.narrays = 4 + ctx->nq;
-  for (int k = 0; k < g.narrays; k++) {
-    g.in[k] = ctx->d_arr[k];
-    g.out[k] = ctx->d_alt[k];
-  }
-  hipLaunchKernelGGL(sort_gather_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], n);
   HIPCHK(hipGetLastError());
-  for (int k = 0; k < g.narrays; k++)
-    std::swap(ctx->d_arr[k], ctx->d_alt[k]);
+  *result_buf = cur;
+  return 0;
+}
+
+// put every per-particle array back into the external slot order
+int restore_external_order(mphip_ctx *ctx) {
+  if (ctx->ext_identity || ctx->np == 0) {
+    ctx->ext_identity = true;
+    return 0;
+  }
+  PermArgs g = perm_args(ctx, true);
+  hipLaunchKernelGGL(perm_scatter_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, g, ctx->d_ext, ctx->np);
+  HIPCHK(hipGetLastError());
+  perm_swap(ctx, true);
+  ctx->ext_identity = true;
+  ctx->steps_since_resort = 1 << 30;
+  return 0;
+}
+
+// internal locality order: store the particles sorted by the grid cell their
+// interpolation stencil starts in.  Nothing observable changes: random numbers
+// follow the external slot (d_ext) and downloads restore the external order.
+int locality_sort(mphip_ctx *ctx) {
+  if (ctx->np == 0)
+    return 0;
+  if (ensure_packed(ctx))
+    return 1;
+  int cur = 0;
+  if (sort_pairs(ctx, 1, &cur))
+    return 1;
+  PermArgs g = perm_args(ctx, true);
+  g.ext_in = ctx->ext_identity ? nullptr : ctx->d_ext;
+  g.ext_out = ctx->d_ext_alt;
+  hipLaunchKernelGGL(perm_gather_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur],
+                     ctx->np);
+  HIPCHK(hipGetLastError());
+  perm_swap(ctx, true);
+  std::swap(ctx->d_ext, ctx->d_ext_alt);
+  ctx->ext_identity = false;
+  ctx->steps_since_resort = 0;
+  return 0;
+}
+
+// module_sort, mptrac.c:5887-5957: observable re-ordering of atm (time, p, lon,
+// lat, q[*]); cache->uvwp and cache->dt stay with their slots as in the
+// reference.
+int do_sort(mphip_ctx *ctx) {
+  const long long n = ctx->np;
+  if (n == 0)
+    return 0;
+  if (ensure_packed(ctx) || restore_external_order(ctx))
+    return 1;
+  int cur = 0;
+  if (sort_pairs(ctx, 0, &cur))
+    return 1;
+  ctx->sorted_buf = cur;
+  PermArgs g = perm_args(ctx, false);
+  hipLaunchKernelGGL(perm_gather_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], n);
+  HIPCHK(hipGetLastError());
+  perm_swap(ctx, false);
+  ctx->steps_since_resort = 0;   // the observable order is a locality order already
   return 0;
 }
 
@@ -496,7 +584,12 @@ void mphip_destroy(mphip_ctx *ctx) {
     dev_free(p);
   for (auto p : ctx->d_uvwp)
     dev_free(p);
+  for (auto p : ctx->d_uvwp_alt)
+    dev_free(p);
   dev_free(ctx->d_dt);
+  dev_free(ctx->d_dt_alt);
+  dev_free(ctx->d_ext);
+  dev_free(ctx->d_ext_alt);
   for (int k = 0; k < 2; k++) {
     dev_free(ctx->d_keys[k]);
     dev_free(ctx->d_vals[k]);
@@ -664,13 +757,15 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
         return 1;
     }
     for (int k = 0; k < 3; k++) {
-      if (dev_alloc(ctx, &ctx->d_uvwp[k], n))
+      if (dev_alloc(ctx, &ctx->d_uvwp[k], n) || dev_alloc(ctx, &ctx->d_uvwp_alt[k], n))
         return 1;
       HIPCHK(hipMemsetAsync(ctx->d_uvwp[k], 0, n * sizeof(float), ctx->stream));   // calloc'ed cache_t
     }
-    if (dev_alloc(ctx, &ctx->d_dt, n))
+    if (dev_alloc(ctx, &ctx->d_dt, n) || dev_alloc(ctx, &ctx->d_dt_alt, n))
       return 1;
     HIPCHK(hipMemsetAsync(ctx->d_dt, 0, n * sizeof(double), ctx->stream));
+    if (dev_alloc(ctx, &ctx->d_ext, n) || dev_alloc(ctx, &ctx->d_ext_alt, n))
+      return 1;
     for (int k = 0; k < 2; k++)
       if (dev_alloc(ctx, &ctx->d_keys[k], n) || dev_alloc(ctx, &ctx->d_vals[k], n))
         return 1;
@@ -678,6 +773,10 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
       return 1;
     ctx->sorted_buf = -1;
   }
+  if (!fresh && restore_external_order(ctx))   // keep cache->uvwp with its slot across a re-upload
+    return 1;
+  ctx->ext_identity = true;
+  ctx->steps_since_resort = 1 << 30;
   ctx->np = np;
   ctx->nq = nq;
   ctx->ip0 = ip0;
@@ -698,6 +797,8 @@ int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *
   if (!ctx)
     return 1;
   HIPCHK(hipSetDevice(ctx->device));
+  if (restore_external_order(ctx))
+    return 1;
   double *dst[4] = { time, p, lon, lat };
   for (int k = 0; k < 4; k++)
     if (dst[k] && ctx->np)
@@ -716,6 +817,8 @@ int mphip_update_cache(mphip_ctx *ctx, const float *uvwp, const uint64_t *rng_ct
   HIPCHK(hipSetDevice(ctx->device));
   if (rng_ctr)
     ctx->rng_ctr = *rng_ctr;
+  if (uvwp && restore_external_order(ctx))
+    return 1;
   if (uvwp && ctx->np) {
     std::vector<float> tmp((size_t) ctx->np);
     for (int k = 0; k < 3; k++) {
@@ -731,6 +834,8 @@ int mphip_get_cache(mphip_ctx *ctx, float *uvwp, double *dt, uint64_t *rng_ctr) 
   if (!ctx)
     return 1;
   HIPCHK(hipSetDevice(ctx->device));
+  if ((uvwp || dt) && restore_external_order(ctx))
+    return 1;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (rng_ctr)
     *rng_ctr = ctx->rng_ctr;
@@ -761,10 +866,15 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   // permutes atm but not cache->dt, so on sort steps dt is computed per slot
   // before the sort and read back per slot afterwards.
   if (c.sort_dt > 0 && fmod(t, c.sort_dt) == 0) {
-    if (launch_step(ctx, MPHIP_MOD_TIMESTEPS | kStoreDt, t, 0, 0, 0) || do_sort(ctx))
+    if (restore_external_order(ctx) || launch_step(ctx, MPHIP_MOD_TIMESTEPS | kStoreDt, t, 0, 0, 0) || do_sort(ctx))
       return 1;
     mask = 0;
+  } else if (ctx->locality_interval > 0 && ctx->steps_since_resort >= ctx->locality_interval) {
+    if (locality_sort(ctx))
+      return 1;
   }
+  if (ctx->steps_since_resort < (1 << 29))
+    ctx->steps_since_resort++;
   mask |= MPHIP_MOD_POSITION;
   if (c.advect > 0)
     mask |= MPHIP_MOD_ADVECT;
@@ -905,6 +1015,18 @@ int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user) {
   ctx->allreduce = fn;
   ctx->allreduce_user = user;
   return 0;
+}
+
+int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
+  if (!ctx || !name)
+    return 1;
+  if (strcmp(name, "locality_sort_interval") == 0) {
+    if (value < 0)
+      return fail(ctx, "locality_sort_interval must be >= 0");
+    ctx->locality_interval = (int) value;
+    return 0;
+  }
+  return fail(ctx, std::string("unknown option ") + name);
 }
 
 int mphip_synchronize(mphip_ctx *ctx) {

@@ -58,6 +58,7 @@ struct DevAtm {
   double *q[MPHIP_NQ_MAX];
   float *up, *vp, *wp;           // cache->uvwp, kept SoA on the device
   double *dt;                    // cache->dt (only used across separate launches)
+  const int *ext;                // external slot of each stored particle (NULL = identity)
   long long np;                  // particles owned by this context
   long long ip0;                 // global index of the first one
   long long np_total;            // particles of the whole simulation

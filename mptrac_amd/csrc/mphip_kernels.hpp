@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void step_kernel(const StepParams S) {
       P.dt = a.dt[i];
     if (P.dt == 0)   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
       continue;
-    const uint64_t g = (uint64_t) (a.ip0 + i);
+    // random numbers belong to the external slot (rs[3 * ip + k], mptrac.c:4645)
+    const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) a.ext[i] : i));
 
     if (mask & MPHIP_MOD_POSITION)
       position(M, A, P);
@@ -267,8 +268,12 @@ __global__ void pack2d_kernel(f32x4 *__restrict__ out, PackSrc2 src, size_t ncol
 // module_sort: key, radix sort, gather (mptrac.c:5887-5995)
 // ---------------------------------------------------------------------------
 
-// key on the raw coordinates, mptrac.c:5913-5919
-__global__ void sort_key_kernel(DevMet M, DevAtm a, uint32_t *__restrict__ keys, int *__restrict__ idx) {
+// Cell key of every particle.  wrapped = 0: the reference's module_sort key on
+// the raw coordinates (mptrac.c:5913-5919).  wrapped = 1: the same key on the
+// longitude/latitude the interpolation would use (intpol_check_lon_lat), for
+// the internal locality order -- this one is never observable.
+__global__ void sort_key_kernel(DevMet M, DevAtm a, int wrapped, uint32_t *__restrict__ keys,
+                                int *__restrict__ idx) {
   extern __shared__ double s_axes[];
   double *s_lon = s_axes, *s_lat = s_axes + M.nx, *s_p = s_axes + M.nx + M.ny;
   for (int i = threadIdx.x; i < M.nx; i += blockDim.x)
@@ -278,10 +283,21 @@ __global__ void sort_key_kernel(DevMet M, DevAtm a, uint32_t *__restrict__ keys,
   for (int i = threadIdx.x; i < M.np; i += blockDim.x)
     s_p[i] = M.p[i];
   __syncthreads();
+  Axes A;
+  A.lon = s_lon;
+  A.lat = s_lat;
+  A.p = s_p;
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
        i += (long long) gridDim.x * blockDim.x) {
-    const int ix = locate_reg(s_lon, M.nx, a.lon[i]);
-    const int iy = locate_irr(s_lat, M.ny, a.lat[i], M.lat_ascending);
+    double lon = a.lon[i], lat = a.lat[i];
+    if (wrapped) {
+      double lon2, lat2;
+      check_horizontal(M, A, lon, lat, lon2, lat2);
+      lon = lon2;
+      lat = lat2;
+    }
+    const int ix = locate_reg(s_lon, M.nx, lon);
+    const int iy = locate_irr(s_lat, M.ny, lat, M.lat_ascending);
     const int iz = locate_irr(s_p, M.np, a.p[i], M.p_ascending);
     keys[i] = (uint32_t) ((ix * M.ny + iy) * M.np + iz);
     idx[i] = (int) i;
@@ -393,19 +409,39 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
   }
 }
 
-// fused gather of every particle array through the permutation
-// (module_sort_help for time, p, lon, lat, q[*]; mptrac.c:5944-5949)
-struct GatherArgs {
-  const double *in[4 + MPHIP_NQ_MAX];
-  double *out[4 + MPHIP_NQ_MAX];
-  int narrays;
+// Fused re-ordering of every per-particle array in one pass.
+//   gather : out[i] = in[perm[i]]     (module_sort_help, mptrac.c:5944-5949,
+//                                      and the internal locality order)
+//   scatter: out[ext[i]] = in[i]      (back to the external slot order)
+struct PermArgs {
+  const double *in8[4 + MPHIP_NQ_MAX + 1];
+  double *out8[4 + MPHIP_NQ_MAX + 1];
+  const float *in4[3];
+  float *out4[3];
+  const int *ext_in;     // gather only: slot ids travel with the particles
+  int *ext_out;          // (ext_in == NULL means identity)
+  int n8, n4;
 };
 
-__global__ void sort_gather_kernel(GatherArgs g, const int *__restrict__ perm, long long n) {
+__global__ void perm_gather_kernel(PermArgs g, const int *__restrict__ perm, long long n) {
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
     const int src = perm[i];
-    for (int a = 0; a < g.narrays; a++)
-      g.out[a][i] = g.in[a][src];
+    for (int a = 0; a < g.n8; a++)
+      g.out8[a][i] = g.in8[a][src];
+    for (int a = 0; a < g.n4; a++)
+      g.out4[a][i] = g.in4[a][src];
+    if (g.ext_out)
+      g.ext_out[i] = g.ext_in ? g.ext_in[src] : src;
+  }
+}
+
+__global__ void perm_scatter_kernel(PermArgs g, const int *__restrict__ ext, long long n) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+    const int dst = ext[i];
+    for (int a = 0; a < g.n8; a++)
+      g.out8[a][dst] = g.in8[a][i];
+    for (int a = 0; a < g.n4; a++)
+      g.out4[a][dst] = g.in4[a][i];
   }
 }
 

@@ -77,6 +77,7 @@ def load(build=True):
     L.mphip_get_sort.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
     L.mphip_grid_sums.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), _dp, _dp]
     L.mphip_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    L.mphip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.mphip_synchronize.argtypes = [C.c_void_p]
     L.mphip_profile_begin.argtypes = [C.c_void_p]
     L.mphip_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), _dp]
@@ -180,7 +181,8 @@ class Simulation:
         arrs = [np.ascontiguousarray(atm[k][sl], dtype=np.float64) for k in ("time", "p", "lon", "lat")]
         assert all(len(a) == self.n for a in arrs)
         q = np.asarray(atm["q"], dtype=np.float64)
-        q = np.ascontiguousarray(q.reshape(-1, q.shape[-1])[:self.nq, sl])
+        q = q.reshape(-1, q.shape[-1]) if q.size else np.zeros((self.nq, 0))
+        q = np.ascontiguousarray(q[:self.nq, sl])
         qp = (_dp * NQ_MAX)()
         for iq in range(self.nq):
             qp[iq] = _ptr(q[iq], _dp)
@@ -253,6 +255,9 @@ class Simulation:
 
     def synchronize(self):
         self._chk(self.L.mphip_synchronize(self.h))
+
+    def set_option(self, name, value):
+        self._chk(self.L.mphip_set_option(self.h, name.encode(), float(value)))
 
     def set_allreduce(self, fn):
         """fn(device_pointer:int, count:int) -> None; sums `count` doubles at

@@ -49,6 +49,21 @@ size_t orc_sizeof_ctl(void) {
   return sizeof(orc_ctl_t);
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0)
+    omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void) n;
+  return 1;
+#endif
+}
+
 /* ---- arithmetic conventions (mptrac.h) ---------------------------------- */
 
 /* FMOD, mptrac.h:1121-1122: truncation through (int), not fmod() */

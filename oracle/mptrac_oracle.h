@@ -110,6 +110,9 @@ typedef struct {
 } orc_clim_t;
 
 size_t orc_sizeof_ctl(void);
+/* OpenMP team size of the module loops (OMP_NUM_THREADS of the reference run);
+ * returns the value in effect. */
+int orc_set_num_threads(int n);
 
 /* --- helpers ------------------------------------------------------------- */
 int orc_locate_irr(const double *xx, int n, double x);           /* mptrac.c:3495 */

@@ -420,3 +420,34 @@ def test_full_size_subsample_against_oracle_1e6():
         assert cases.rel_err(g[k][pick], ref) <= TOL
     assert np.all(g["time"] == 3600.0)
     s.close()
+
+
+# ---------------------------------------------------------------------------
+# internal locality order (mphip_set_option "locality_sort_interval")
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", ["conv_sedi", "full"])
+def test_locality_order_is_not_observable(case):
+    """The device stores particles in grid-cell order and re-sorts every few
+    steps; random numbers follow the external slot and downloads restore the
+    caller's order, so results are bit-identical with the feature off, on, and
+    on with downloads in between."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=6001)
+    runs = {}
+    for name, interval, peek in (("off", 0, False), ("every3", 3, False), ("every1_peek", 1, True)):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("locality_sort_interval", interval)
+        s.timesteps_init(0.0, 0.0)
+        for k, t in enumerate(cases.step_times(s.ctl)[:9]):
+            s.run_timestep(t)
+            if peek and k % 4 == 1:
+                s.state()               # download in the middle of the run
+        runs[name] = s.state()
+        runs[name]["ctr"] = s.get_cache()["rng_ctr"]
+        s.close()
+    tol_q = 0.0 if case != "full" else 1e-13        # mixing sums use atomics
+    for name in ("every3", "every1_peek"):
+        for k in ("time", "lon", "lat", "p", "uvwp"):
+            assert np.array_equal(runs[name][k], runs["off"][k]), (name, k)
+        assert cases.rel_err(runs[name]["q"], runs["off"]["q"]) <= tol_q
+        assert runs[name]["ctr"] == runs["off"]["ctr"]

@@ -1,0 +1,28 @@
+#!/bin/bash
+# rocprofv3 passes over the default bench command (run on the GPU box):
+#   1. kernel trace + stats                      -> per-kernel time
+#   2..n. PMC passes (separate runs, counters only with --kernel-trace)
+# Usage: tools/profile.sh <tag> [bench args...]     outputs under gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-r01}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
+tail -1 "$OUT/stats.log" > "$OUT/bench_under_profiler.json"
+
+pmc() {  # name, counters...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "step_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
+}
+pmc fetch FETCH_SIZE
+pmc write WRITE_SIZE
+pmc tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
+pmc sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS
+pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
+pmc tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum
+ls -R "$OUT" | head -60
