@@ -37,7 +37,21 @@ def hip_sources():
     return src
 
 
+def build_variant(name, extra_flags, verbose=False):
+    """Experimental build lib/libmptrac_hip_<name>.so (tuning sweeps; select
+    it at run time with MPHIP_LIB=<path>)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = os.path.join(LIBDIR, f"libmptrac_hip_{name}.so")
+    cmd = [_hipcc(), *HIPCC_FLAGS, *extra_flags, "-o", out, os.path.join(CSRC, "mphip_api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_hip(force=False, verbose=False, extra_flags=()):
+    if os.environ.get("MPHIP_LIB"):
+        return os.environ["MPHIP_LIB"]
     os.makedirs(LIBDIR, exist_ok=True)
     if force or _stale(HIP_LIB, hip_sources()):
         if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):

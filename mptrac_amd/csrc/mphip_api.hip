@@ -49,7 +49,9 @@ struct mphip_ctx {
   int flip = 0;                       // logical slot s lives in slot[s ^ flip]
   int nx = 0, ny = 0, npl = 0, coord_type = 0;
   std::vector<double> h_lon, h_lat, h_p;
-  double *d_lon = nullptr, *d_lat = nullptr, *d_p = nullptr;
+  double *d_axes = nullptr;           // axes blob (layout: DevMet::axes)
+  int lut_base = 0, lut_size = 0;
+  size_t axes_bytes = 0;
   f32x4 *d_wind = nullptr, *d_cloud = nullptr, *d_sfc = nullptr;
   bool packed_dirty = true;
 
@@ -157,15 +159,18 @@ DevMet dev_met(const mphip_ctx *c) {
   M.wind = c->d_wind;
   M.cloud = c->d_cloud;
   M.sfc = c->d_sfc;
-  M.lon = c->d_lon;
-  M.lat = c->d_lat;
-  M.p = c->d_p;
+  M.axes = c->d_axes;
+  M.lut_base = c->lut_base;
+  M.lut_size = c->lut_size;
+  M.lat_x0 = c->h_lat[0];
+  M.lat_inv_dx = (c->ny - 1) / (c->h_lat[c->ny - 1] - c->h_lat[0]);
   M.nx = c->nx;
   M.ny = c->ny;
   M.np = c->npl;
   M.coord_type = c->coord_type;
   M.time0 = c->slot[0 ^ c->flip].time;
   M.time1 = c->slot[1 ^ c->flip].time;
+  M.inv_dtime = 1.0 / (M.time1 - M.time0);
   double latmin = c->h_lat[0], latmax = c->h_lat[0];
   for (double v : c->h_lat) {
     latmin = std::min(latmin, v);
@@ -182,7 +187,81 @@ DevMet dev_met(const mphip_ctx *c) {
 }
 
 size_t axes_lds_bytes(const mphip_ctx *c) {
-  return (size_t) (c->nx + c->ny + c->npl) * sizeof(double);
+  return c->axes_bytes;
+}
+
+// the reference's bisection (mptrac.c:3495-3521), host copy for the look-up table
+int host_locate_irr(const std::vector<double> &xx, double x) {
+  const int n = (int) xx.size();
+  int lo = 0, hi = n - 1;
+  int mid = (hi + lo) >> 1;
+  if (xx[mid] < xx[mid + 1]) {
+    while (hi > lo + 1) {
+      mid = (hi + lo) >> 1;
+      if (xx[mid] > x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  } else {
+    while (hi > lo + 1) {
+      mid = (hi + lo) >> 1;
+      if (xx[mid] <= x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  }
+  return lo;
+}
+
+// axes, reciprocal interval widths and the pressure look-up table in one blob
+int upload_axes(mphip_ctx *ctx) {
+  const int nx = ctx->nx, ny = ctx->ny, np = ctx->npl;
+  const size_t nd = 2 * (size_t) (nx + ny + np);
+  std::vector<int16_t> lut;
+  ctx->lut_base = ctx->lut_size = 0;
+  const double pmin = *std::min_element(ctx->h_p.begin(), ctx->h_p.end());
+  const double pmax = *std::max_element(ctx->h_p.begin(), ctx->h_p.end());
+  if (pmin > 0 && std::isfinite(pmax) && np < 32000) {
+    long long kmin, kmax;
+    memcpy(&kmin, &pmin, 8);
+    memcpy(&kmax, &pmax, 8);
+    kmin >>= 45;
+    kmax >>= 45;
+    if (kmax - kmin + 1 <= 8192) {
+      ctx->lut_base = (int) kmin;
+      ctx->lut_size = (int) (kmax - kmin + 1);
+      lut.resize((size_t) ctx->lut_size);
+      for (int j = 0; j < ctx->lut_size; j++) {
+        const long long bits = (kmin + j) << 45;
+        double edge;
+        memcpy(&edge, &bits, 8);
+        lut[(size_t) j] = (int16_t) host_locate_irr(ctx->h_p, edge);
+      }
+    }
+  }
+  const size_t bytes = ((nd * sizeof(double) + lut.size() * sizeof(int16_t)) + 15) & ~(size_t) 15;
+  std::vector<double> blob(bytes / sizeof(double), 0.0);
+  double *b = blob.data();
+  std::copy(ctx->h_lon.begin(), ctx->h_lon.end(), b);
+  std::copy(ctx->h_lat.begin(), ctx->h_lat.end(), b + nx);
+  std::copy(ctx->h_p.begin(), ctx->h_p.end(), b + nx + ny);
+  double *inv = b + nx + ny + np;
+  for (int i = 0; i + 1 < nx; i++)
+    inv[i] = 1.0 / (ctx->h_lon[i + 1] - ctx->h_lon[i]);
+  for (int i = 0; i + 1 < ny; i++)
+    inv[nx + i] = 1.0 / (ctx->h_lat[i + 1] - ctx->h_lat[i]);
+  for (int i = 0; i + 1 < np; i++)
+    inv[nx + ny + i] = 1.0 / (ctx->h_p[i + 1] - ctx->h_p[i]);
+  if (!lut.empty())
+    memcpy(b + nd, lut.data(), lut.size() * sizeof(int16_t));
+  if (dev_alloc(ctx, &ctx->d_axes, blob.size()))
+    return 1;
+  HIPCHK(hipMemcpyAsync(ctx->d_axes, blob.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->axes_bytes = bytes;
+  return 0;
 }
 
 // (re)build the packed two-snapshot grids from the per-slot staging copies
@@ -371,11 +450,15 @@ int sort_pairs(mphip_ctx *ctx, int wrapped, int *result_buf) {
   const long long n = ctx->np;
   const int ntiles = (int) ((n + kSortTile - 1) / kSortTile);
   const size_t m = (size_t) kRadix * ntiles;
-  if (m > ctx->counts_cap) {
-    if (dev_alloc(ctx, &ctx->d_counts, m))
+  const int nchunks = (int) ((m + kScanChunk - 1) / kScanChunk);
+  if (nchunks > kScanThreads)
+    return fail(ctx, "too many particles for the two-level scan of module_sort");
+  if (m + kScanThreads > ctx->counts_cap) {
+    if (dev_alloc(ctx, &ctx->d_counts, m + kScanThreads))   // counters + chunk totals
       return 1;
-    ctx->counts_cap = m;
+    ctx->counts_cap = m + kScanThreads;
   }
+  uint32_t *d_chunks = ctx->d_counts + m;
   const DevMet M = dev_met(ctx);
   const DevAtm a = dev_atm(ctx);
   hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, wrapped,
@@ -390,9 +473,12 @@ int sort_pairs(mphip_ctx *ctx, int wrapped, int *result_buf) {
     const int shift = 8 * pass;
     hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur], n, shift,
                        ntiles, ctx->d_counts);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_counts, m);
+    hipLaunchKernelGGL(sort_scan_local_kernel, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream, ctx->d_counts, m,
+                       d_chunks);
+    hipLaunchKernelGGL(sort_scan_chunks_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_chunks, nchunks);
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur],
-                       ctx->d_vals[cur], ctx->d_keys[cur ^ 1], ctx->d_vals[cur ^ 1], n, shift, ntiles, ctx->d_counts);
+                       ctx->d_vals[cur], ctx->d_keys[cur ^ 1], ctx->d_vals[cur ^ 1], n, shift, ntiles, ctx->d_counts,
+                       d_chunks);
     cur ^= 1;
   }
   HIPCHK(hipGetLastError());
@@ -572,9 +658,7 @@ void mphip_destroy(mphip_ctx *ctx) {
       dev_free(p);
   }
   dev_free(ctx->d_clim);
-  dev_free(ctx->d_lon);
-  dev_free(ctx->d_lat);
-  dev_free(ctx->d_p);
+  dev_free(ctx->d_axes);
   dev_free(ctx->d_wind);
   dev_free(ctx->d_cloud);
   dev_free(ctx->d_sfc);
@@ -676,12 +760,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     ctx->h_lon.assign(met->lon, met->lon + met->nx);
     ctx->h_lat.assign(met->lat, met->lat + met->ny);
     ctx->h_p.assign(met->p, met->p + met->np);
-    if (dev_alloc(ctx, &ctx->d_lon, (size_t) met->nx) || dev_alloc(ctx, &ctx->d_lat, (size_t) met->ny)
-        || dev_alloc(ctx, &ctx->d_p, (size_t) met->np))
+    if (upload_axes(ctx))
       return 1;
-    HIPCHK(hipMemcpyAsync(ctx->d_lon, met->lon, met->nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_lat, met->lat, met->ny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_p, met->p, met->np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   }
   MetSlot &S = ctx->slot[slot ^ ctx->flip];
   const size_t ncell = (size_t) met->nx * met->ny * met->np, ncol = (size_t) met->nx * met->ny;

@@ -45,9 +45,14 @@ struct DevMet {
   const f32x4 *wind;
   const f32x4 *cloud;
   const f32x4 *sfc;
-  const double *lon, *lat, *p;   // axes in global memory (copied to LDS per block)
+  // axes blob in global memory, copied to LDS by every workgroup:
+  //   double lon[nx], lat[ny], p[np], 1/dlon[nx], 1/dlat[ny], 1/dp[np]; int16 p_lut[lut_size]
+  const double *axes;
   int nx, ny, np, coord_type;
+  int lut_base, lut_size;        // pressure look-up table (0 entries = bisection)
+  double lat_x0, lat_inv_dx;     // first guess of the latitude index
   double time0, time1;
+  double inv_dtime;              // 1 / (time1 - time0)
   double latmin, latmax;         // module_timesteps, mptrac.c:6009-6010
   int local;                     // mptrac.c:6012-6013
   int lat_ascending, p_ascending;
@@ -71,10 +76,58 @@ struct DevClim {
   double tropo[12][73];
 };
 
-// per-block LDS copy of the three axes
+// per-block LDS copy of the three axes, the reciprocal interval widths and
+// the pressure look-up table
 struct Axes {
   const double *lon, *lat, *p;
+  const double *inv_lon, *inv_lat, *inv_p;
+  const short *p_lut;
 };
+
+__device__ __forceinline__ size_t axes_doubles(const DevMet &M) {
+  return 2 * (size_t) (M.nx + M.ny + M.np);
+}
+
+// cooperative copy of the axes blob into LDS (call from every thread, then
+// __syncthreads())
+__device__ __forceinline__ Axes load_axes(const DevMet &M, double *smem) {
+  const size_t nd = axes_doubles(M);
+  for (size_t i = threadIdx.x; i < nd; i += blockDim.x)
+    smem[i] = M.axes[i];
+  short *lut = (short *) (smem + nd);
+  const short *glut = (const short *) (M.axes + nd);
+  for (int i = threadIdx.x; i < M.lut_size; i += blockDim.x)
+    lut[i] = glut[i];
+  Axes A;
+  A.lon = smem;
+  A.lat = A.lon + M.nx;
+  A.p = A.lat + M.ny;
+  A.inv_lon = A.p + M.np;
+  A.inv_lat = A.inv_lon + M.nx;
+  A.inv_p = A.inv_lat + M.ny;
+  A.p_lut = lut;
+  return A;
+}
+
+// MPHIP_EXACT_DIV = 1 keeps every IEEE division of the reference; the default
+// multiplies by reciprocals that were rounded once on the host where the
+// divisor is a grid constant (interval widths, 1000, pi * RE, time1 - time0).
+// That moves interpolation weights by at most one ulp (positions ~1e-15
+// relative, far inside the 1e-10 bar); indices that are observable (sort key,
+// mixing / output cells) always use the exact form.
+#ifndef MPHIP_EXACT_DIV
+#define MPHIP_EXACT_DIV 0
+#endif
+
+__device__ __forceinline__ double div_const(double x, double y, double inv_y) {
+#if MPHIP_EXACT_DIV
+  (void) inv_y;
+  return x / y;
+#else
+  (void) y;
+  return x * inv_y;
+#endif
+}
 
 // ---- arithmetic conventions ------------------------------------------------
 
@@ -97,15 +150,15 @@ __device__ __forceinline__ double dx2deg(double dx, double lat) {   // mptrac.h:
 }
 
 __device__ __forceinline__ double dy2deg(double dy) {   // mptrac.h:922
-  return dy * 180. / (kPi * kRE);
+  return div_const(dy * 180., kPi * kRE, 1.0 / (kPi * kRE));
 }
 
 __device__ __forceinline__ double dx2coord(int coord_type, double dx, double lat) {   // mptrac.h:966
-  return coord_type == 0 ? dx2deg(dx / 1000.0, lat) : dx;
+  return coord_type == 0 ? dx2deg(div_const(dx, 1000.0, 1e-3), lat) : dx;
 }
 
 __device__ __forceinline__ double dy2coord(int coord_type, double dy) {   // mptrac.h:989
-  return coord_type == 0 ? dy2deg(dy / 1000.0) : dy;
+  return coord_type == 0 ? dy2deg(div_const(dy, 1000.0, 1e-3)) : dy;
 }
 
 __device__ __forceinline__ double dz2dp(double dz, double p) {   // mptrac.h:941
@@ -130,8 +183,10 @@ __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : 
 // ---- axis search (mptrac.c:3495-3574) --------------------------------------
 
 // locate_irr: the bisection of the reference only ever compares interior
-// nodes 1..n-2, so on a monotonic axis its result is "the number of interior
-// nodes on the near side of x".  Same bisection here, on the LDS copy.
+// nodes 1..n-2, so on a monotonic axis its result is the unique i in [0, n-2]
+// with (i == 0 or node i on the near side of x) and (i == n-2 or node i+1 on
+// the far side).  locate_irr() is that bisection; locate_from() reaches the
+// same index from a first guess with a short linear correction.
 __device__ __forceinline__ int locate_irr(const double *xx, int n, double x, int ascending) {
   int lo = 0, hi = n - 1;
   if (ascending) {
@@ -154,9 +209,54 @@ __device__ __forceinline__ int locate_irr(const double *xx, int n, double x, int
   return lo;
 }
 
+__device__ __forceinline__ int locate_from(const double *xx, int n, double x, int ascending, int guess) {
+  if (!(x == x))
+    return n - 2;   // every comparison of the bisection fails for NaN
+  int g = guess < 0 ? 0 : (guess > n - 2 ? n - 2 : guess);
+  if (ascending) {
+    while (g > 0 && xx[g] > x)
+      g--;
+    while (g < n - 2 && xx[g + 1] <= x)
+      g++;
+  } else {
+    while (g > 0 && xx[g] <= x)
+      g--;
+    while (g < n - 2 && xx[g + 1] > x)
+      g++;
+  }
+  return g;
+}
+
+// latitude: first guess from the mean spacing
+__device__ __forceinline__ int locate_lat(const DevMet &M, const Axes &A, double lat) {
+  return locate_from(A.lat, M.ny, lat, M.lat_ascending, (int) ((lat - M.lat_x0) * M.lat_inv_dx));
+}
+
+// pressure: first guess from a table indexed by the exponent and the top seven
+// mantissa bits of p (128 bins per octave, at most a node or two per bin)
+__device__ __forceinline__ int locate_p(const DevMet &M, const Axes &A, double p) {
+  if (M.lut_size == 0)
+    return locate_irr(A.p, M.np, p, M.p_ascending);
+  int j = (int) (__double_as_longlong(p) >> 45) - M.lut_base;
+  j = j < 0 ? 0 : (j >= M.lut_size ? M.lut_size - 1 : j);
+  return locate_from(A.p, M.np, p, M.p_ascending, (int) A.p_lut[j]);
+}
+
 __device__ __forceinline__ int locate_reg(const double *xx, int n, double x) {   // mptrac.c:3559-3574
   const int i = (int) ((x - xx[0]) / (xx[1] - xx[0]));
   return i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+}
+
+// the same with the reciprocal of the (regular) spacing; may differ from
+// locate_reg when x is within an ulp of a grid line -- used for interpolation
+// stencils only, where both neighbours give the same value
+__device__ __forceinline__ int locate_lon(const DevMet &M, const Axes &A, double x) {
+#if MPHIP_EXACT_DIV
+  return locate_reg(A.lon, M.nx, x);
+#else
+  const int i = (int) ((x - A.lon[0]) * A.inv_lon[0]);
+  return i < 0 ? 0 : (i > M.nx - 2 ? M.nx - 2 : i);
+#endif
 }
 
 // ---- interpolation (mptrac.c:2755-3170) ------------------------------------
@@ -201,22 +301,22 @@ __device__ __forceinline__ void stencil_3d(const DevMet &M, const Axes &A, doubl
                                            Stencil &s) {
   double lon2, lat2;
   check_horizontal(M, A, lon, lat, lon2, lat2);
-  s.ip = locate_irr(A.p, M.np, p, M.p_ascending);
-  s.ix = locate_reg(A.lon, M.nx, lon2);
-  s.iy = locate_irr(A.lat, M.ny, lat2, M.lat_ascending);
-  s.wp = (A.p[s.ip + 1] - p) / (A.p[s.ip + 1] - A.p[s.ip]);
-  s.wx = (A.lon[s.ix + 1] - lon2) / (A.lon[s.ix + 1] - A.lon[s.ix]);
-  s.wy = (A.lat[s.iy + 1] - lat2) / (A.lat[s.iy + 1] - A.lat[s.iy]);
+  s.ip = locate_p(M, A, p);
+  s.ix = locate_lon(M, A, lon2);
+  s.iy = locate_lat(M, A, lat2);
+  s.wp = div_const(A.p[s.ip + 1] - p, A.p[s.ip + 1] - A.p[s.ip], A.inv_p[s.ip]);
+  s.wx = div_const(A.lon[s.ix + 1] - lon2, A.lon[s.ix + 1] - A.lon[s.ix], A.inv_lon[s.ix]);
+  s.wy = div_const(A.lat[s.iy + 1] - lat2, A.lat[s.iy + 1] - A.lat[s.iy], A.inv_lat[s.iy]);
 }
 
 // index/weight set-up of intpol_met_space_2d, mptrac.c:3059-3081
 __device__ __forceinline__ void stencil_2d(const DevMet &M, const Axes &A, double lon, double lat, Stencil &s) {
   double lon2, lat2;
   check_horizontal(M, A, lon, lat, lon2, lat2);
-  s.ix = locate_reg(A.lon, M.nx, lon2);
-  s.iy = locate_irr(A.lat, M.ny, lat2, M.lat_ascending);
-  s.wx = (A.lon[s.ix + 1] - lon2) / (A.lon[s.ix + 1] - A.lon[s.ix]);
-  s.wy = (A.lat[s.iy + 1] - lat2) / (A.lat[s.iy + 1] - A.lat[s.iy]);
+  s.ix = locate_lon(M, A, lon2);
+  s.iy = locate_lat(M, A, lat2);
+  s.wx = div_const(A.lon[s.ix + 1] - lon2, A.lon[s.ix + 1] - A.lon[s.ix], A.inv_lon[s.ix]);
+  s.wy = div_const(A.lat[s.iy + 1] - lat2, A.lat[s.iy + 1] - A.lat[s.iy], A.inv_lat[s.iy]);
 }
 
 // The eight corners of one stencil for both snapshots: 16 x 16-byte loads,
@@ -242,6 +342,30 @@ __device__ __forceinline__ void load_corners(const f32x4 *__restrict__ g, const 
     }
 }
 
+// The eight corners stay in registers between Runge-Kutta stages and modules:
+// a particle rarely leaves its cell within a step (CFL), so most stencils of a
+// step address the same 16 records.  Only lanes whose cell changed reload
+// (the vector-memory data path, not HBM, is what these gathers saturate).
+struct WindCache {
+  Corners c;
+  int ix, iy, ip;   // ip < 0: empty
+};
+
+__device__ __forceinline__ void wind_cache_reset(WindCache &wc) {
+  wc.ix = wc.iy = 0;
+  wc.ip = -1;
+}
+
+__device__ __forceinline__ const Corners &wind_corners(const DevMet &M, const Stencil &s, WindCache &wc) {
+  if (wc.ip != s.ip || wc.iy != s.iy || wc.ix != s.ix) {
+    load_corners(M.wind, M, s, wc.c);
+    wc.ix = s.ix;
+    wc.iy = s.iy;
+    wc.ip = s.ip;
+  }
+  return wc.c;
+}
+
 // intpol_met_space_3d, mptrac.c:3023-3043, for component k of snapshot t.
 // The difference of the two float corners is taken in single precision, as
 // the reference's C expression does (float - float), and only then widened.
@@ -263,7 +387,7 @@ __device__ __forceinline__ double time_3d(const Corners &c, const Stencil &s, do
 }
 
 __device__ __forceinline__ double time_weight(const DevMet &M, double ts) {   // mptrac.c:3133
-  return (M.time1 - ts) / (M.time1 - M.time0);
+  return div_const(M.time1 - ts, M.time1 - M.time0, M.inv_dtime);
 }
 
 // Four corners of the packed surface record: [ix][iy][4] f32x4.
@@ -540,7 +664,7 @@ __device__ __forceinline__ void position(const DevMet &M, const Axes &A, Particl
 
 // module_advect, pressure-level branch, mptrac.c:3612-3677
 template <int ADVECT>
-__device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particle &P) {
+__device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particle &P, WindCache &wc) {
   const int ct = M.coord_type;
   const double dt = P.dt;
   double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0;
@@ -562,8 +686,7 @@ __device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particl
     const double tm = P.time + dts;
     Stencil s;
     stencil_3d(M, A, x2, x0, x1, s);
-    Corners c;
-    load_corners(M.wind, M, s, c);
+    const Corners &c = wind_corners(M, s, wc);
     const double wt = time_weight(M, tm);
     u = time_3d(c, s, wt, 0);
     v = time_3d(c, s, wt, 1);
@@ -583,13 +706,14 @@ __device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particl
   P.p += dt * wm;
 }
 
-__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P) {
+__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                       WindCache &wc) {
   if (ctl.advect == 4)
-    advect_n<4>(M, A, P);
+    advect_n<4>(M, A, P, wc);
   else if (ctl.advect == 2)
-    advect_n<2>(M, A, P);
+    advect_n<2>(M, A, P, wc);
   else
-    advect_n<1>(M, A, P);
+    advect_n<1>(M, A, P, wc);
 }
 
 // the Kz blend evaluated at a displaced pressure, mptrac.c:4669-4688
@@ -659,7 +783,7 @@ __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &
 
 // module_diff_meso, mptrac.c:4280-4338
 __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
-                                          float &up, float &vp, float &wp, uint64_t ctr, uint64_t g) {
+                                          float &up, float &vp, float &wp, uint64_t ctr, uint64_t g, WindCache &wc) {
   // HIP's __fadd_rn / __fmul_rn are plain operators, so contraction has to be
   // switched off here for the single-precision statistics to round like the
   // reference's separate multiply and add (the variance is a small difference
@@ -668,11 +792,10 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
   const int ct = M.coord_type;
   // raw (un-wrapped) coordinates, mptrac.c:4283-4285
   Stencil s;
-  s.ix = locate_reg(A.lon, M.nx, P.lon);
-  s.iy = locate_irr(A.lat, M.ny, P.lat, M.lat_ascending);
-  s.ip = locate_irr(A.p, M.np, P.p, M.p_ascending);
-  Corners c;
-  load_corners(M.wind, M, s, c);
+  s.ix = locate_reg(A.lon, M.nx, P.lon);   // exact: sigma is not continuous across cells
+  s.iy = locate_lat(M, A, P.lat);
+  s.ip = locate_p(M, A, P.p);
+  const Corners &c = wind_corners(M, s, wc);
 
   // single-precision sums in the reference's order: i (lon), j (lat),
   // k (level), met0 before met1
@@ -718,17 +841,16 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
 
 // temperature at (p, lon, lat): INTPOL_3D(t, 1)
 __device__ __forceinline__ double temperature_at(const DevMet &M, const Axes &A, double time, double p, double lon,
-                                                 double lat) {
+                                                 double lat, WindCache &wc) {
   Stencil s;
   stencil_3d(M, A, p, lon, lat, s);
-  Corners c;
-  load_corners(M.wind, M, s, c);
+  const Corners &c = wind_corners(M, s, wc);
   return time_3d(c, s, time_weight(M, time), 3);
 }
 
 // module_convection, mptrac.c:4116-4170
 __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
-                                           uint64_t ctr, uint64_t g) {
+                                           uint64_t ctr, uint64_t g, WindCache &wc) {
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
   Corners2 c;
@@ -748,8 +870,8 @@ __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet 
       ptop = dmin(ptop, pel);
   }
   if (ptop != pbot && P.p >= ptop) {
-    const double tbot = temperature_at(M, A, P.time, pbot, P.lon, P.lat);
-    const double ttop = temperature_at(M, A, P.time, ptop, P.lon, P.lat);
+    const double tbot = temperature_at(M, A, P.time, pbot, P.lon, P.lat, wc);
+    const double ttop = temperature_at(M, A, P.time, ptop, P.lon, P.lat, wc);
     const double rhobot = pbot / tbot;
     const double rhotop = ptop / ttop;
     const double rs = uniform01(ctr + g);
@@ -759,8 +881,9 @@ __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet 
 }
 
 // module_sedi, mptrac.c:5869-5882
-__device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Particle &P, double rp, double rhop) {
-  const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
+__device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Particle &P, double rp, double rhop,
+                                              WindCache &wc) {
+  const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat, wc);
   const double v_s = sedi(P.p, t, rp, rhop);
   P.p += dz2dp(v_s * P.dt / 1000., P.p);
 }

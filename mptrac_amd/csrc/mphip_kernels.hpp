@@ -48,7 +48,7 @@ __device__ __forceinline__ void apply_loss(const mphip_ctl_t &ctl, const DevAtm 
 
 // module_wet_depo, mptrac.c:6170-6289
 __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
-                                         long long i, const Particle &P) {
+                                         long long i, const Particle &P, WindCache &wc) {
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
   Corners2 c2;
@@ -70,8 +70,7 @@ __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M
   const double iwc = time_3d(c, s, wt, 2);
   const double swc = time_3d(c, s, wt, 3);
   const bool inside = (lwc > 0 || rwc > 0 || iwc > 0 || swc > 0);
-  load_corners(M.wind, M, s, c);
-  const double t = time_3d(c, s, wt, 3);
+  const double t = time_3d(wind_corners(M, s, wc), s, wt, 3);
 
   double lambda = 0;
   if (inside) {
@@ -111,7 +110,7 @@ __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M
 
 // module_dry_depo, mptrac.c:4753-4796
 __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
-                                         long long i, const Particle &P) {
+                                         long long i, const Particle &P, WindCache &wc) {
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
   Corners2 c2;
@@ -122,7 +121,7 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
   const double dz = 1000. * (zfromp(ps - ctl.dry_depo_dp) - zfromp(ps));
   double v_dep;
   if (ctl.qnt_rp > 0 && ctl.qnt_rhop > 0) {   // "> 0" as the reference, mptrac.c:4769
-    const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
+    const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat, wc);
     v_dep = sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
   } else
     v_dep = ctl.dry_depo_vdep;
@@ -135,26 +134,19 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
 // places workgroup b on XCD b % 8) walks one contiguous eighth of the particle
 // arrays: with cell-sorted particles each XCD's L2 then holds one region of
 // the meteo grid instead of all of it.
+#ifndef MPHIP_STEP_WAVES_PER_SIMD
+#define MPHIP_STEP_WAVES_PER_SIMD 2
+#endif
 template <unsigned CT>
-__global__ __launch_bounds__(256) void step_kernel(const StepParams S) {
+__global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(const StepParams S) {
   extern __shared__ double s_axes[];
   const unsigned mask = (CT == kMaskGeneric) ? S.mask : CT;
   const DevMet &M = S.met;
   const DevAtm &a = S.atm;
   const mphip_ctl_t &ctl = S.ctl;
 
-  double *s_lon = s_axes, *s_lat = s_axes + M.nx, *s_p = s_axes + M.nx + M.ny;
-  for (int i = threadIdx.x; i < M.nx; i += blockDim.x)
-    s_lon[i] = M.lon[i];
-  for (int i = threadIdx.x; i < M.ny; i += blockDim.x)
-    s_lat[i] = M.lat[i];
-  for (int i = threadIdx.x; i < M.np; i += blockDim.x)
-    s_p[i] = M.p[i];
+  const Axes A = load_axes(M, s_axes);
   __syncthreads();
-  Axes A;
-  A.lon = s_lon;
-  A.lat = s_lat;
-  A.p = s_p;
 
   const int nb = S.nblocks_logical;
   const int lb = (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8);
@@ -181,23 +173,25 @@ __global__ __launch_bounds__(256) void step_kernel(const StepParams S) {
     // random numbers belong to the external slot (rs[3 * ip + k], mptrac.c:4645)
     const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) a.ext[i] : i));
 
+    WindCache wc;
+    wind_cache_reset(wc);
     if (mask & MPHIP_MOD_POSITION)
       position(M, A, P);
     if (mask & MPHIP_MOD_ADVECT)
-      advect(ctl, M, A, P);
+      advect(ctl, M, A, P, wc);
     if (mask & MPHIP_MOD_DIFF_TURB)
       diff_turb(ctl, M, A, *S.clim, P, S.ctr_turb, g);
     if (mask & MPHIP_MOD_DIFF_MESO) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
-      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g);
+      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, wc);
       a.up[i] = up;
       a.vp[i] = vp;
       a.wp[i] = wp;
     }
     if (mask & MPHIP_MOD_CONVECTION)
-      convection(ctl, M, A, P, S.ctr_conv, g);
+      convection(ctl, M, A, P, S.ctr_conv, g, wc);
     if (mask & MPHIP_MOD_SEDI)
-      sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
+      sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i], wc);
     if (mask & MPHIP_MOD_POSITION2)
       position(M, A, P);
 
@@ -218,9 +212,9 @@ __global__ __launch_bounds__(256) void step_kernel(const StepParams S) {
       apply_loss(ctl, a, i, aux, ctl.qnt_mloss_decay, 1. / tdec);
     }
     if (mask & MPHIP_MOD_WET_DEPO)
-      wet_depo(ctl, M, A, a, i, P);
+      wet_depo(ctl, M, A, a, i, P, wc);
     if (mask & MPHIP_MOD_DRY_DEPO)
-      dry_depo(ctl, M, A, a, i, P);
+      dry_depo(ctl, M, A, a, i, P, wc);
   }
 }
 
@@ -275,18 +269,8 @@ __global__ void pack2d_kernel(f32x4 *__restrict__ out, PackSrc2 src, size_t ncol
 __global__ void sort_key_kernel(DevMet M, DevAtm a, int wrapped, uint32_t *__restrict__ keys,
                                 int *__restrict__ idx) {
   extern __shared__ double s_axes[];
-  double *s_lon = s_axes, *s_lat = s_axes + M.nx, *s_p = s_axes + M.nx + M.ny;
-  for (int i = threadIdx.x; i < M.nx; i += blockDim.x)
-    s_lon[i] = M.lon[i];
-  for (int i = threadIdx.x; i < M.ny; i += blockDim.x)
-    s_lat[i] = M.lat[i];
-  for (int i = threadIdx.x; i < M.np; i += blockDim.x)
-    s_p[i] = M.p[i];
+  const Axes A = load_axes(M, s_axes);
   __syncthreads();
-  Axes A;
-  A.lon = s_lon;
-  A.lat = s_lat;
-  A.p = s_p;
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
        i += (long long) gridDim.x * blockDim.x) {
     double lon = a.lon[i], lat = a.lat[i];
@@ -296,9 +280,9 @@ __global__ void sort_key_kernel(DevMet M, DevAtm a, int wrapped, uint32_t *__res
       lon = lon2;
       lat = lat2;
     }
-    const int ix = locate_reg(s_lon, M.nx, lon);
-    const int iy = locate_irr(s_lat, M.ny, lat, M.lat_ascending);
-    const int iz = locate_irr(s_p, M.np, a.p[i], M.p_ascending);
+    const int ix = locate_reg(A.lon, M.nx, lon);
+    const int iy = locate_lat(M, A, lat);
+    const int iz = locate_p(M, A, a.p[i]);
     keys[i] = (uint32_t) ((ix * M.ny + iy) * M.np + iz);
     idx[i] = (int) i;
   }
@@ -326,37 +310,66 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t 
   counts[(size_t) threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive prefix sum over `m` counters, one workgroup, in place
-__global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t *__restrict__ counts, size_t m) {
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t carry;
-  if (threadIdx.x == 0)
-    carry = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (size_t base = 0; base < m; base += 1024) {
-    const size_t i = base + threadIdx.x;
-    const uint32_t v = i < m ? counts[i] : 0;
-    uint32_t x = v;
+// Exclusive prefix sum over the m counters in two levels: every workgroup
+// scans its chunk of kScanChunk counters in place and publishes the chunk
+// total; a single workgroup then scans the chunk totals (m / kScanChunk <=
+// 1024 of them); the scatter kernel adds the two.
+constexpr int kScanThreads = 1024;
+constexpr int kScanPer = 4;
+constexpr int kScanChunk = kScanThreads * kScanPer;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wsum, uint32_t *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  uint32_t x = v;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(x, d);
-      if (lane >= d)
-        x += y;
-    }
-    if (lane == 63)
-      wsum[wave] = x;
-    __syncthreads();
-    uint32_t off = carry;
-    for (int w = 0; w < wave; w++)
-      off += wsum[w];
-    if (i < m)
-      counts[i] = off + x - v;
-    __syncthreads();
-    if (threadIdx.x == 1023)
-      carry = off + x;
-    __syncthreads();
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d);
+    if (lane >= d)
+      x += y;
   }
+  if (lane == 63)
+    wsum[wave] = x;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+  for (int w = 0; w < nwaves; w++) {
+    const uint32_t ws = wsum[w];
+    if (w < wave)
+      off += ws;
+    tot += ws;
+  }
+  *total = tot;
+  return off + x - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void sort_scan_local_kernel(uint32_t *__restrict__ counts, size_t m,
+                                                                       uint32_t *__restrict__ chunk_sums) {
+  __shared__ uint32_t wsum[kScanThreads / 64];
+  const size_t base = (size_t) blockIdx.x * kScanChunk + (size_t) threadIdx.x * kScanPer;
+  uint32_t v[kScanPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; k++) {
+    v[k] = base + k < m ? counts[base + k] : 0;
+    sum += v[k];
+  }
+  uint32_t total;
+  uint32_t off = block_exclusive_scan(sum, wsum, &total);
+#pragma unroll
+  for (int k = 0; k < kScanPer; k++) {
+    if (base + k < m)
+      counts[base + k] = off;
+    off += v[k];
+  }
+  if (threadIdx.x == 0)
+    chunk_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanThreads) void sort_scan_chunks_kernel(uint32_t *__restrict__ chunk_sums, int nchunks) {
+  __shared__ uint32_t wsum[kScanThreads / 64];
+  const uint32_t v = (int) threadIdx.x < nchunks ? chunk_sums[threadIdx.x] : 0;
+  uint32_t total;
+  const uint32_t off = block_exclusive_scan(v, wsum, &total);
+  if ((int) threadIdx.x < nchunks)
+    chunk_sums[threadIdx.x] = off;
 }
 
 // stable scatter of one digit pass
@@ -364,11 +377,15 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
                                                                     const int *__restrict__ vals_in,
                                                                     uint32_t *__restrict__ keys_out,
                                                                     int *__restrict__ vals_out, long long n, int shift,
-                                                                    int ntiles, const uint32_t *__restrict__ offsets) {
+                                                                    int ntiles, const uint32_t *__restrict__ offsets,
+                                                                    const uint32_t *__restrict__ chunk_offsets) {
   __shared__ uint32_t running[kRadix];      // next free slot per digit
   __shared__ uint32_t wcnt[4][kRadix];      // per-wave counts of the current round
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  running[threadIdx.x] = offsets[(size_t) threadIdx.x * ntiles + blockIdx.x];
+  {
+    const size_t slot = (size_t) threadIdx.x * ntiles + blockIdx.x;
+    running[threadIdx.x] = offsets[slot] + chunk_offsets[slot / kScanChunk];
+  }
 #pragma unroll
   for (int w = 0; w < 4; w++)
     wcnt[w][threadIdx.x] = 0;
