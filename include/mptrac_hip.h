@@ -178,7 +178,9 @@ int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
  *   the gathers of neighbouring particles share cache lines.  The order is
  *   internal: random numbers follow the external slot index and every download
  *   returns the caller's order, so results do not depend on the value.
- *   0 switches it off. */
+ *   0 switches it off.
+ *   "locality_tile" (default 8): edge, in grid columns, of the horizontal tiles of
+ *   that order (tile, then level, then column within the tile). */
 int mphip_set_option(mphip_ctx *ctx, const char *name, double value);
 int mphip_synchronize(mphip_ctx *ctx);
 
@@ -194,6 +196,10 @@ int mphip_profile_end(mphip_ctx *ctx, long long *launches, double *kernel_ms);
 int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, float *cos_out,
                        float *sin_out);
 int mphip_test_rng(mphip_ctx *ctx, uint64_t ctr, long long n, int method, double *out);
+/* Gather micro-benchmark over the uploaded particles: `reps` wind stencils per
+ * particle, lane-by-lane (mode 0) or quad-cooperative through LDS (mode 1);
+ * returns the kernel time and a checksum that must not depend on the mode. */
+int mphip_test_gather(mphip_ctx *ctx, int mode, int reps, double *ms, double *checksum);
 
 #ifdef __cplusplus
 }

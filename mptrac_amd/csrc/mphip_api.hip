@@ -71,6 +71,7 @@ struct mphip_ctx {
   int *d_ext = nullptr, *d_ext_alt = nullptr;
   bool ext_identity = true;
   int locality_interval = 10;         // re-sort every this many steps (0 = keep the caller's order)
+  int locality_tile = 8;              // horizontal tile edge of the locality key (columns)
   int steps_since_resort = 1 << 30;
 
   // sort
@@ -379,7 +380,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   S.ctr_turb = ctr_turb;
   S.ctr_meso = ctr_meso;
   S.ctr_conv = ctr_conv;
-  const size_t lds = axes_lds_bytes(ctx);
+  const size_t lds = axes_lds_bytes(ctx) + sizeof(DevClim);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof) {
     if (ctx->ev_used + 2 > ctx->ev.size()) {
@@ -446,7 +447,7 @@ void perm_swap(mphip_ctx *ctx, bool with_cache) {
 }
 
 // keys + stable LSD radix sort of (key, index); returns the buffer holding the result
-int sort_pairs(mphip_ctx *ctx, int wrapped, int *result_buf) {
+int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf) {
   const long long n = ctx->np;
   const int ntiles = (int) ((n + kSortTile - 1) / kSortTile);
   const size_t m = (size_t) kRadix * ntiles;
@@ -461,10 +462,16 @@ int sort_pairs(mphip_ctx *ctx, int wrapped, int *result_buf) {
   uint32_t *d_chunks = ctx->d_counts + m;
   const DevMet M = dev_met(ctx);
   const DevAtm a = dev_atm(ctx);
-  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, wrapped,
+  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
                      ctx->d_keys[0], ctx->d_vals[0]);
   // number of 8-bit digits that can be non-zero
-  const unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
+  unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
+  if (tile > 0) {
+    const unsigned long long ntx = (ctx->nx + tile - 1) / tile, nty = (ctx->ny + tile - 1) / tile;
+    kmax = ntx * nty * ctx->npl * tile * tile;
+  }
+  if (kmax > 0xffffffffULL)
+    return fail(ctx, "meteo grid too large for the 32-bit sort key");
   int passes = 1;
   while (passes < 4 && (kmax >> (8 * passes)) != 0)
     passes++;
@@ -510,7 +517,7 @@ int locality_sort(mphip_ctx *ctx) {
   if (ensure_packed(ctx))
     return 1;
   int cur = 0;
-  if (sort_pairs(ctx, 1, &cur))
+  if (sort_pairs(ctx, ctx->locality_tile, &cur))
     return 1;
   PermArgs g = perm_args(ctx, true);
   g.ext_in = ctx->ext_identity ? nullptr : ctx->d_ext;
@@ -1106,6 +1113,13 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     ctx->locality_interval = (int) value;
     return 0;
   }
+  if (strcmp(name, "locality_tile") == 0) {
+    if (value < 1 || value > 64)
+      return fail(ctx, "locality_tile must be in 1 ... 64");
+    ctx->locality_tile = (int) value;
+    ctx->steps_since_resort = 1 << 30;
+    return 0;
+  }
   return fail(ctx, std::string("unknown option ") + name);
 }
 
@@ -1142,6 +1156,46 @@ int mphip_profile_end(mphip_ctx *ctx, long long *launches, double *kernel_ms) {
     *kernel_ms = total;
   ctx->prof = false;
   ctx->ev_used = 0;
+  return 0;
+}
+
+int mphip_test_gather(mphip_ctx *ctx, int mode, int reps, double *ms, double *checksum) {
+  if (!ctx || !ms)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ensure_packed(ctx))
+    return 1;
+  double *d_out = nullptr;
+  HIPCHK(hipMalloc((void **) &d_out, (size_t) std::max<long long>(ctx->np, 1) * sizeof(double)));
+  HIPCHK(hipMemsetAsync(d_out, 0, (size_t) std::max<long long>(ctx->np, 1) * sizeof(double), ctx->stream));
+  int nb = grid_for(ctx->np, 256, 8192);
+  nb = (nb + 7) & ~7;
+  const size_t lds = axes_lds_bytes(ctx) + 4 * (size_t) kXchgBytesPerWave;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  const DevMet M = dev_met(ctx);
+  const DevAtm a = dev_atm(ctx);
+  hipLaunchKernelGGL(test_gather_kernel, dim3(nb), dim3(256), lds, ctx->stream, M, a, mode, reps, nb, d_out);   // warm
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  hipLaunchKernelGGL(test_gather_kernel, dim3(nb), dim3(256), lds, ctx->stream, M, a, mode, reps, nb, d_out);
+  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float t = 0;
+  HIPCHK(hipEventElapsedTime(&t, e0, e1));
+  *ms = t;
+  if (checksum) {
+    std::vector<double> h((size_t) ctx->np);
+    HIPCHK(hipMemcpy(h.data(), d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double sum = 0;
+    for (double v : h)
+      sum += v;
+    *checksum = sum;
+  }
+  (void) hipEventDestroy(e0);
+  (void) hipEventDestroy(e1);
+  HIPCHK(hipFree(d_out));
   return 0;
 }
 

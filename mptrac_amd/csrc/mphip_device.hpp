@@ -227,19 +227,65 @@ __device__ __forceinline__ int locate_from(const double *xx, int n, double x, in
   return g;
 }
 
+// Index plus the interval it selects.  The three LDS reads are issued together
+// on the first guess; the linear correction only runs when the guess is off.
+struct AxisHit {
+  int i;
+  double x0, x1, inv;   // xx[i], xx[i+1], 1 / (xx[i+1] - xx[i])
+};
+
+__device__ __forceinline__ AxisHit locate_hit(const double *xx, const double *inv, int n, double x, int ascending,
+                                              int guess) {
+  AxisHit h;
+  int g = guess < 0 ? 0 : (guess > n - 2 ? n - 2 : guess);
+  h.x0 = xx[g];
+  h.x1 = xx[g + 1];
+  h.inv = inv[g];
+  bool ok;
+  if (ascending)
+    ok = (g == 0 || h.x0 <= x) && (g == n - 2 || h.x1 > x);
+  else
+    ok = (g == 0 || h.x0 > x) && (g == n - 2 || h.x1 <= x);
+  if (!ok || !(x == x)) {
+    g = locate_from(xx, n, x, ascending, g);
+    h.x0 = xx[g];
+    h.x1 = xx[g + 1];
+    h.inv = inv[g];
+  }
+  h.i = g;
+  return h;
+}
+
 // latitude: first guess from the mean spacing
+__device__ __forceinline__ int lat_guess(const DevMet &M, double lat) {
+  return (int) ((lat - M.lat_x0) * M.lat_inv_dx);
+}
+
 __device__ __forceinline__ int locate_lat(const DevMet &M, const Axes &A, double lat) {
-  return locate_from(A.lat, M.ny, lat, M.lat_ascending, (int) ((lat - M.lat_x0) * M.lat_inv_dx));
+  return locate_from(A.lat, M.ny, lat, M.lat_ascending, lat_guess(M, lat));
 }
 
 // pressure: first guess from a table indexed by the exponent and the top seven
 // mantissa bits of p (128 bins per octave, at most a node or two per bin)
+__device__ __forceinline__ int p_guess(const DevMet &M, const Axes &A, double p) {
+  int j = (int) (__double_as_longlong(p) >> 45) - M.lut_base;
+  j = j < 0 ? 0 : (j >= M.lut_size ? M.lut_size - 1 : j);
+  return (int) A.p_lut[j];
+}
+
 __device__ __forceinline__ int locate_p(const DevMet &M, const Axes &A, double p) {
   if (M.lut_size == 0)
     return locate_irr(A.p, M.np, p, M.p_ascending);
-  int j = (int) (__double_as_longlong(p) >> 45) - M.lut_base;
-  j = j < 0 ? 0 : (j >= M.lut_size ? M.lut_size - 1 : j);
-  return locate_from(A.p, M.np, p, M.p_ascending, (int) A.p_lut[j]);
+  return locate_from(A.p, M.np, p, M.p_ascending, p_guess(M, A, p));
+}
+
+__device__ __forceinline__ AxisHit hit_lat(const DevMet &M, const Axes &A, double lat) {
+  return locate_hit(A.lat, A.inv_lat, M.ny, lat, M.lat_ascending, lat_guess(M, lat));
+}
+
+__device__ __forceinline__ AxisHit hit_p(const DevMet &M, const Axes &A, double p) {
+  const int g = M.lut_size ? p_guess(M, A, p) : locate_irr(A.p, M.np, p, M.p_ascending);
+  return locate_hit(A.p, A.inv_p, M.np, p, M.p_ascending, g);
 }
 
 __device__ __forceinline__ int locate_reg(const double *xx, int n, double x) {   // mptrac.c:3559-3574
@@ -301,22 +347,27 @@ __device__ __forceinline__ void stencil_3d(const DevMet &M, const Axes &A, doubl
                                            Stencil &s) {
   double lon2, lat2;
   check_horizontal(M, A, lon, lat, lon2, lat2);
-  s.ip = locate_p(M, A, p);
+  const AxisHit hp = hit_p(M, A, p);
+  const AxisHit hy = hit_lat(M, A, lat2);
   s.ix = locate_lon(M, A, lon2);
-  s.iy = locate_lat(M, A, lat2);
-  s.wp = div_const(A.p[s.ip + 1] - p, A.p[s.ip + 1] - A.p[s.ip], A.inv_p[s.ip]);
-  s.wx = div_const(A.lon[s.ix + 1] - lon2, A.lon[s.ix + 1] - A.lon[s.ix], A.inv_lon[s.ix]);
-  s.wy = div_const(A.lat[s.iy + 1] - lat2, A.lat[s.iy + 1] - A.lat[s.iy], A.inv_lat[s.iy]);
+  const double lx0 = A.lon[s.ix], lx1 = A.lon[s.ix + 1], linv = A.inv_lon[s.ix];
+  s.ip = hp.i;
+  s.iy = hy.i;
+  s.wp = div_const(hp.x1 - p, hp.x1 - hp.x0, hp.inv);
+  s.wx = div_const(lx1 - lon2, lx1 - lx0, linv);
+  s.wy = div_const(hy.x1 - lat2, hy.x1 - hy.x0, hy.inv);
 }
 
 // index/weight set-up of intpol_met_space_2d, mptrac.c:3059-3081
 __device__ __forceinline__ void stencil_2d(const DevMet &M, const Axes &A, double lon, double lat, Stencil &s) {
   double lon2, lat2;
   check_horizontal(M, A, lon, lat, lon2, lat2);
+  const AxisHit hy = hit_lat(M, A, lat2);
   s.ix = locate_lon(M, A, lon2);
-  s.iy = locate_lat(M, A, lat2);
-  s.wx = div_const(A.lon[s.ix + 1] - lon2, A.lon[s.ix + 1] - A.lon[s.ix], A.inv_lon[s.ix]);
-  s.wy = div_const(A.lat[s.iy + 1] - lat2, A.lat[s.iy + 1] - A.lat[s.iy], A.inv_lat[s.iy]);
+  const double lx0 = A.lon[s.ix], lx1 = A.lon[s.ix + 1], linv = A.inv_lon[s.ix];
+  s.iy = hy.i;
+  s.wx = div_const(lx1 - lon2, lx1 - lx0, linv);
+  s.wy = div_const(hy.x1 - lat2, hy.x1 - hy.x0, hy.inv);
 }
 
 // The eight corners of one stencil for both snapshots: 16 x 16-byte loads,
@@ -342,10 +393,15 @@ __device__ __forceinline__ void load_corners(const f32x4 *__restrict__ g, const 
     }
 }
 
-// The eight corners stay in registers between Runge-Kutta stages and modules:
-// a particle rarely leaves its cell within a step (CFL), so most stencils of a
-// step address the same 16 records.  Only lanes whose cell changed reload
-// (the vector-memory data path, not HBM, is what these gathers saturate).
+// Optional register cache of the last stencil's corners (MPHIP_WIND_CACHE=1):
+// a particle rarely leaves its cell within a step, so only lanes whose cell
+// changed would reload.  Measured on MI355X (C3, 10^7 sorted particles) this
+// LOSES: 256 VGPRs + 368 B/lane scratch and a divergent reload per stage,
+// 1.04 -> 2.34 ms for RK4 advection.  Kept switched off; every stencil reloads.
+#ifndef MPHIP_WIND_CACHE
+#define MPHIP_WIND_CACHE 0
+#endif
+
 struct WindCache {
   Corners c;
   int ix, iy, ip;   // ip < 0: empty
@@ -357,12 +413,16 @@ __device__ __forceinline__ void wind_cache_reset(WindCache &wc) {
 }
 
 __device__ __forceinline__ const Corners &wind_corners(const DevMet &M, const Stencil &s, WindCache &wc) {
+#if MPHIP_WIND_CACHE
   if (wc.ip != s.ip || wc.iy != s.iy || wc.ix != s.ix) {
     load_corners(M.wind, M, s, wc.c);
     wc.ix = s.ix;
     wc.iy = s.iy;
     wc.ip = s.ip;
   }
+#else
+  load_corners(M.wind, M, s, wc.c);
+#endif
   return wc.c;
 }
 

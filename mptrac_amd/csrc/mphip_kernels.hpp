@@ -146,6 +146,16 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
   const mphip_ctl_t &ctl = S.ctl;
 
   const Axes A = load_axes(M, s_axes);
+  // climatological tropopause table next to the axes (7.7 kB): the weights of
+  // module_diff_turb / module_decay index it per lane, several times a step
+  const DevClim *clim = S.clim;
+  if (mask & (MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DECAY)) {
+    double *dst = s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8;
+    const double *src = (const double *) S.clim;
+    for (int i = threadIdx.x; i < (int) (sizeof(DevClim) / sizeof(double)); i += blockDim.x)
+      dst[i] = src[i];
+    clim = (const DevClim *) dst;
+  }
   __syncthreads();
 
   const int nb = S.nblocks_logical;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     if (mask & MPHIP_MOD_ADVECT)
       advect(ctl, M, A, P, wc);
     if (mask & MPHIP_MOD_DIFF_TURB)
-      diff_turb(ctl, M, A, *S.clim, P, S.ctr_turb, g);
+      diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g);
     if (mask & MPHIP_MOD_DIFF_MESO) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
       diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, wc);
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     if (mask & MPHIP_MOD_LOSS_ZERO)
       a.q[ctl.qnt_loss_rate][i] = 0;
     if (mask & MPHIP_MOD_DECAY) {   // module_decay, mptrac.c:4241-4261
-      const double w = tropo_weight(ctl, *S.clim, P.time, P.lat, P.p);
+      const double w = tropo_weight(ctl, *clim, P.time, P.lat, P.p);
       const double tdec = w * ctl.tdec_trop + (1 - w) * ctl.tdec_strat;
       const double aux = exp(-P.dt / tdec);
       apply_loss(ctl, a, i, aux, ctl.qnt_mloss_decay, 1. / tdec);
@@ -262,12 +272,19 @@ __global__ void pack2d_kernel(f32x4 *__restrict__ out, PackSrc2 src, size_t ncol
 // module_sort: key, radix sort, gather (mptrac.c:5887-5995)
 // ---------------------------------------------------------------------------
 
-// Cell key of every particle.  wrapped = 0: the reference's module_sort key on
-// the raw coordinates (mptrac.c:5913-5919).  wrapped = 1: the same key on the
-// longitude/latitude the interpolation would use (intpol_check_lon_lat), for
-// the internal locality order -- this one is never observable.
-__global__ void sort_key_kernel(DevMet M, DevAtm a, int wrapped, uint32_t *__restrict__ keys,
+// Cell key of every particle.  tile = 0: the reference's module_sort key on the
+// raw coordinates (mptrac.c:5913-5919).  tile = T > 0: key of the internal
+// locality order (never observable): computed on the longitude/latitude the
+// interpolation would use (intpol_check_lon_lat), and ordered as (T x T
+// horizontal tile, level, column within the tile) so that the 64 particles of a
+// wavefront sit in a few adjacent columns AND in a few adjacent levels --
+// level-dependent branches (convection below the equilibrium level, vertical
+// diffusion above the tropopause, surface reflection) then go one way per
+// wavefront.
+__global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, uint32_t *__restrict__ keys,
                                 int *__restrict__ idx) {
+  const int wrapped = tile > 0;
+  const int nty = tile > 0 ? (M.ny + tile - 1) / tile : 0;
   extern __shared__ double s_axes[];
   const Axes A = load_axes(M, s_axes);
   __syncthreads();
@@ -283,7 +300,11 @@ __global__ void sort_key_kernel(DevMet M, DevAtm a, int wrapped, uint32_t *__res
     const int ix = locate_reg(A.lon, M.nx, lon);
     const int iy = locate_lat(M, A, lat);
     const int iz = locate_p(M, A, a.p[i]);
-    keys[i] = (uint32_t) ((ix * M.ny + iy) * M.np + iz);
+    if (tile == 0)
+      keys[i] = (uint32_t) ((ix * M.ny + iy) * M.np + iz);
+    else
+      keys[i] = (uint32_t) ((((ix / tile) * nty + iy / tile) * M.np + iz) * (tile * tile)
+                            + (ix % tile) * tile + iy % tile);
     idx[i] = (int) i;
   }
 }
@@ -550,6 +571,90 @@ __global__ void grid_accumulate_kernel(DevAtm a, const int *__restrict__ cell, i
         unsafeAtomicAdd(&buf[(size_t) (1 + nq + iq) * ncell + c], v * v);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// gather micro-benchmark: the wind stencil of every particle, fetched either
+// lane-by-lane (mode 0: each lane issues the 16 x 16-byte loads of its own four
+// columns) or quad-cooperatively (mode 1: four adjacent lanes fetch the four
+// 16-byte pieces of one 64-byte column record, records are exchanged through
+// LDS).  Used to decide the load scheme of the step kernel.
+// ---------------------------------------------------------------------------
+
+constexpr int kXchgStride = 20;   // dwords per particle record in LDS (80 B: conflict-free b128 reads)
+
+// LDS per wave: 64 x 16 B column offsets + 64 x 80 B records
+constexpr int kXchgBytesPerWave = 64 * 16 + 64 * kXchgStride * 4;
+
+__device__ __forceinline__ void coop_fetch(const f32x4 *__restrict__ g, const DevMet &M, const Stencil &s,
+                                           char *wave_lds, Corners &c) {
+  const int lane = threadIdx.x & 63;
+  unsigned *offs = (unsigned *) wave_lds;               // [64][4] record indices (f32x4 units)
+  float *rec = (float *) (wave_lds + 64 * 16);          // [64][kXchgStride]
+  {
+    uint4 o;
+    const size_t base = ((size_t) s.ix * (size_t) M.ny + (size_t) s.iy) * (size_t) M.np + (size_t) s.ip;
+    o.x = (unsigned) (2 * base);
+    o.y = (unsigned) (2 * (base + (size_t) M.np));
+    o.z = (unsigned) (2 * (base + (size_t) M.ny * (size_t) M.np));
+    o.w = (unsigned) (2 * (base + (size_t) M.ny * (size_t) M.np + (size_t) M.np));
+    *(uint4 *) (offs + 4 * lane) = o;
+  }
+  const int piece = lane & 3, sub = lane >> 2;
+#pragma unroll
+  for (int col = 0; col < 4; col++) {
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = 16 * k + sub;
+      v[k] = g[(size_t) offs[4 * p + col] + piece];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int p = 16 * k + sub;
+      *(f32x4 *) (rec + p * kXchgStride + 4 * piece) = v[k];
+    }
+    const f32x4 *mine = (const f32x4 *) (rec + lane * kXchgStride);
+    const int di = col >> 1, dj = col & 1;
+    c.lo[di][dj][0] = mine[0];
+    c.lo[di][dj][1] = mine[1];
+    c.hi[di][dj][0] = mine[2];
+    c.hi[di][dj][1] = mine[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void test_gather_kernel(DevMet M, DevAtm a, int mode, int reps, int nblocks_logical,
+                                                          double *__restrict__ out) {
+  extern __shared__ double s_axes[];
+  const Axes A = load_axes(M, s_axes);
+  char *xchg = (char *) s_axes + (((axes_doubles(M) * 8 + (size_t) M.lut_size * 2) + 15) & ~(size_t) 15);
+  char *wave_lds = xchg + (threadIdx.x >> 6) * kXchgBytesPerWave;
+  __syncthreads();
+  const int nb = nblocks_logical;
+  const int lb = (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8);
+  const long long per_block = (((a.np + nb - 1) / nb) + 63) & ~63LL;
+  const long long first = (long long) lb * per_block;
+  const long long last = first + per_block;
+  for (long long i0 = first; i0 < last; i0 += blockDim.x) {
+    long long i = i0 + threadIdx.x;
+    const bool live = i < a.np && i < last;
+    if (!live)
+      i = a.np - 1;        // keep whole waves active for the cooperative scheme
+    Stencil s;
+    stencil_3d(M, A, a.p[i], a.lon[i], a.lat[i], s);
+    double acc = 0;
+    for (int r = 0; r < reps; r++) {
+      Corners c;
+      if (mode == 0)
+        load_corners(M.wind, M, s, c);
+      else
+        coop_fetch(M.wind, M, s, wave_lds, c);
+      acc += time_3d(c, s, 0.25 + r, 0) + time_3d(c, s, 0.5, 1) + time_3d(c, s, 0.75, 2);
+      s.ip = (s.ip + 1 < M.np - 1) ? s.ip + (r & 1) : s.ip;     // move a level now and then
+    }
+    if (live)
+      out[i] = acc;
   }
 }
 

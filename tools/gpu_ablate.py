@@ -19,11 +19,13 @@ VARIANTS = {
 }
 
 
-def run(name, over, n=None, steps=10, interval=10, workload="C3"):
+def run(name, over, n=None, steps=10, interval=10, workload="C3", tile=None):
     ctl, clim, m0, m1, atm, n_local, n_total = bench.build_inputs(workload, 0, 1, steps + 4)
     ctl.update(over)
     s = hip.Simulation(ctl, clim, m0, m1, atm, n_total=n_total, shard=(0, n_local))
     s.set_option("locality_sort_interval", interval)
+    if tile:
+        s.set_option("locality_tile", tile)
     s.timesteps_init(0.0, 0.0)
     dt = s.ctl.dt_mod
     k = 0
@@ -41,5 +43,10 @@ def run(name, over, n=None, steps=10, interval=10, workload="C3"):
 
 
 if __name__ == "__main__":
-    for name, over in VARIANTS.items():
-        run(name, over)
+    if len(sys.argv) > 1 and sys.argv[1] == "tiles":
+        for tile in (1, 2, 4, 8, 16, 32):
+            for name in ("advect", "full C3"):
+                run(f"tile={tile} {name}", VARIANTS[name], tile=tile)
+    else:
+        for name, over in VARIANTS.items():
+            run(name, over)
