@@ -72,24 +72,11 @@ def build_inputs(workload, rank, world, steps_total):
     return ctl, load_clim_tropo(), met0, met1, atm, n_per_gpu, n_total
 
 
-def usable_cores():
-    """Cores this process may actually use: affinity mask capped by the cgroup
-    CPU quota (os.cpu_count() reports the whole host inside a container)."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return n
-
-
 def cpu_baseline(workload, ctl, clim, met0, met1, atm, n_sample, n_steps):
     """The OpenMP oracle (oracle/, "port") on the first n_sample particles of
     the same workload, all usable host cores."""
     from oracle import binding as B
-    cores = B.lib().orc_set_num_threads(usable_cores())
+    cores = B.lib().orc_set_num_threads(B.usable_cores())
     sub = {k: (v[:n_sample].copy() if k != "q" else v[:, :n_sample].copy()) for k, v in atm.items()}
     o = B.Oracle(ctl, clim, met0, met1, sub)
     o.timesteps_init()

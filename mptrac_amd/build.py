@@ -64,5 +64,35 @@ def build_hip(force=False, verbose=False, extra_flags=()):
     return HIP_LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(LIBDIR, "libmptrac.so")
+TRAC_BIN = os.path.join(LIBDIR, "trac")
+# small test extents by default; production builds pass the reference's -DNP=... -DEX=... values
+HOST_DIMS = {"NP": 200000, "NQ": 12, "EX": 364, "EY": 186, "EP": 64}
+
+
+def build_host(force=False, verbose=False, dims=None):
+    """Host-side C library (the reference's mptrac_* interface on the C ABI)
+    and the trac driver.  Plain gcc; links against libmptrac_hip.so."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    dims = dict(HOST_DIMS, **(dims or {}))
+    src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "mptrac.h", "trac.c")]
+    if not (force or _stale(HOST_LIB, src) or _stale(TRAC_BIN, src)):
+        return HOST_LIB, TRAC_BIN
+    defs = [f"-D{k}={v}" for k, v in dims.items()]
+    defs.append('-DMPTRAC_AMD_DATA_DIR="%s"' % os.path.join(HERE, "data"))
+    common = ["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-W", "-Wno-format-security", "-fPIC", "-mcmodel=medium",
+              *defs]
+    rpath = ["-L" + LIBDIR, "-lmptrac_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    cmds = [common + ["-shared", "-o", HOST_LIB, os.path.join(HOST_DIR, "mptrac.c")] + rpath,
+            common + ["-o", TRAC_BIN, os.path.join(HOST_DIR, "trac.c"), os.path.join(HOST_DIR, "mptrac.c")] + rpath]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_LIB, TRAC_BIN
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

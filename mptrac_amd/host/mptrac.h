@@ -1,0 +1,227 @@
+/*
+ * mptrac.h -- host-side mirror of MPTRAC's high-level interface for the
+ * per-particle time-step loop, on top of the MI355X back end
+ * (include/mptrac_hip.h).
+ *
+ * Same struct names, field names and function signatures as the reference
+ * (src/mptrac.h) for the hot-path subset, so that a driver written against
+ * the reference's high-level interface (docs/manual/high-level-interface.md,
+ * src/trac.c) compiles against this header unchanged.  The structs are NOT
+ * layout-compatible with the reference's (fields outside the hot path are
+ * absent); host code must be compiled against this header.
+ *
+ * All physics runs on the device; there is no CPU implementation of any
+ * module in this library.
+ */
+#ifndef MPTRAC_AMD_HOST_H
+#define MPTRAC_AMD_HOST_H
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- compile-time dimensions (reference: mptrac.h:543-595) -------------- */
+#ifndef EP
+#define EP 140
+#endif
+#ifndef EX
+#define EX 1444
+#endif
+#ifndef EY
+#define EY 724
+#endif
+#ifndef NP
+#define NP 10000000
+#endif
+#ifndef NQ
+#define NQ 15
+#endif
+#ifndef LEN
+#define LEN 5000
+#endif
+#ifndef LOGLEV
+#define LOGLEV 2
+#endif
+
+/* ---- constants and macros (reference: mptrac.h:255-345, 819-989, ...) ---- */
+#ifndef H0
+#define H0 7.0
+#endif
+#ifndef P0
+#define P0 1013.25
+#endif
+#ifndef RE
+#define RE 6367.421
+#endif
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#define P(z) (P0 * exp(-(z) / H0))
+#define Z(p) (H0 * log(P0 / (p)))
+#define SQR(x) ((x) * (x))
+#define DEG2RAD(deg) ((deg) * (M_PI / 180.0))
+#define ARRAY_3D(ix, iy, ny, iz, nz) (((ix) * (ny) + (iy)) * (nz) + (iz))
+
+/* logging as the reference (mptrac.h:2303-2410): ERRMSG prints and exits */
+#define LOG(level, ...) {                                               \
+    if (level >= 2) printf("  ");                                       \
+    if (level <= LOGLEV) { printf(__VA_ARGS__); printf("\n"); }         \
+  }
+#define WARN(...) {                                                     \
+    printf("\nWarning (%s, %s, l%d): ", __FILE__, __func__, __LINE__);  \
+    LOG(0, __VA_ARGS__);                                                \
+  }
+#define ERRMSG(...) {                                                   \
+    printf("\nError (%s, %s, l%d): ", __FILE__, __func__, __LINE__);    \
+    LOG(0, __VA_ARGS__);                                                \
+    exit(EXIT_FAILURE);                                                 \
+  }
+#define ALLOC(ptr, type, n)                                             \
+  if ((ptr = calloc((size_t) (n), sizeof(type))) == NULL)               \
+    ERRMSG("Out of memory!");
+
+/* ---- structs -------------------------------------------------------------- */
+
+/* control parameters, hot-path subset of the reference's ctl_t
+ * (mptrac.h:2494-3553) */
+typedef struct {
+  /* quantities */
+  int nq;
+  char qnt_name[NQ][LEN], qnt_unit[NQ][LEN], qnt_format[NQ][LEN];
+  int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens, qnt_loss_rate;
+  int qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry;
+  /* time and meteo input */
+  int direction, met_coord_type, met_type;
+  double t_start, t_stop, dt_mod, dt_met, met_utm_ref_lat, met_dt_out;
+  char metbase[LEN];
+  /* modules */
+  double sort_dt;
+  int rng_type, advect, advect_vert_coord, diffusion, turb_pbl_scheme;
+  double turb_dx_pbl, turb_dx_trop, turb_dx_strat, turb_dz_pbl, turb_dz_trop, turb_dz_strat;
+  double turb_mesox, turb_mesoz, turb_pbl_trans;
+  int conv_mix_pbl;
+  double conv_pbl_trans, conv_cape, conv_cin, conv_dt;
+  double tdec_trop, tdec_strat;
+  int nens;
+  double mixing_dt, mixing_trop, mixing_strat, mixing_z0, mixing_z1;
+  double mixing_lon0, mixing_lon1, mixing_lat0, mixing_lat1;
+  int mixing_nx, mixing_ny, mixing_nz;
+  double wet_depo_pre[2], wet_depo_ic_a, wet_depo_ic_b, wet_depo_bc_a, wet_depo_bc_b;
+  double wet_depo_ic_h[2], wet_depo_bc_h[2], wet_depo_so2_ph;
+  double wet_depo_ic_ret_ratio, wet_depo_bc_ret_ratio;
+  double dry_depo_vdep, dry_depo_dp;
+  /* output */
+  char atm_basename[LEN];
+  double atm_dt_out;
+  int atm_filter, atm_stride, atm_type, atm_type_out;
+  char grid_basename[LEN];
+  double grid_dt_out;
+  int grid_sparse, grid_stddev;
+  double grid_z0, grid_z1, grid_lon0, grid_lon1, grid_lat0, grid_lat1;
+  int grid_nx, grid_ny, grid_nz;
+  double molmass;
+  /* back-end options (no reference counterpart) */
+  int hip_device;
+  int hip_locality_interval;
+} ctl_t;
+
+/* air parcels, as the reference (mptrac.h:3563-3583) */
+typedef struct {
+  int np;
+  double time[NP];
+  double p[NP];
+  double lon[NP];
+  double lat[NP];
+  double q[NQ][NP];
+} atm_t;
+
+/* per-parcel cache, as the reference (mptrac.h:3618-3641) */
+typedef struct {
+  double iso_var[NP];
+  double iso_ps[NP];
+  double iso_ts[NP];
+  int iso_n;
+  float uvwp[NP][3];
+  double rs[3 * NP + 1];
+  double dt[NP];
+} cache_t;
+
+/* climatological data: tropopause part of the reference's clim_t
+ * (mptrac.h:3785-3800) */
+typedef struct {
+  int tropo_ntime;
+  int tropo_nlat;
+  double tropo_time[12];
+  double tropo_lat[73];
+  double tropo[12][73];
+} clim_t;
+
+/* meteo snapshot: the fields of the reference's met_t (mptrac.h:3844-4014)
+ * that the hot path reads, with the reference's fixed extents */
+typedef struct {
+  double time;
+  int coord_type;
+  int nx, ny, np;
+  double lon[EX], lat[EY], p[EP];
+  float ps[EX][EY], pbl[EX][EY], cape[EX][EY], cin[EX][EY], pel[EX][EY];
+  float pct[EX][EY], pcb[EX][EY], cl[EX][EY];
+  float t[EX][EY][EP], u[EX][EY][EP], v[EX][EY][EP], w[EX][EY][EP];
+  float lwc[EX][EY][EP], rwc[EX][EY][EP], iwc[EX][EY][EP], swc[EX][EY][EP];
+} met_t;
+
+/* not used on the hot path; kept so that the reference's signatures hold */
+typedef struct {
+  int unused;
+} depo_t;
+typedef struct {
+  int unused;
+} dd_t;
+
+/* ---- high-level interface (reference: mptrac.h:7246-7736) ----------------- */
+
+void mptrac_alloc(ctl_t **ctl, cache_t **cache, clim_t **clim, met_t **met0, met_t **met1, atm_t **atm,
+                  depo_t **depo, dd_t **dd);                                   /* mptrac.c:6294 */
+void mptrac_free(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t *met0, met_t *met1, atm_t *atm,
+                 depo_t *depo, dd_t *dd);                                      /* mptrac.c:6377 */
+void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl);  /* mptrac.c:6723 */
+void mptrac_read_clim(const ctl_t *ctl, clim_t *clim);                           /* mptrac.c:6663 */
+int mptrac_read_atm(const char *filename, const ctl_t *ctl, atm_t *atm);         /* mptrac.c:6588 */
+int mptrac_read_met(const char *filename, const ctl_t *ctl, const clim_t *clim, met_t *met,
+                    dd_t *dd);                                                  /* mptrac.c:7742 */
+void mptrac_init(ctl_t *ctl, cache_t *cache, clim_t *clim, atm_t *atm, depo_t *depo,
+                 const int ntask);                                              /* mptrac.c:6563 */
+void mptrac_get_met(ctl_t *ctl, clim_t *clim, const double t, met_t **met0, met_t **met1,
+                    dd_t *dd);                                                  /* mptrac.c:6438 */
+void mptrac_run_timestep(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t **met0, met_t **met1,
+                         atm_t *atm, depo_t *depo, double t, dd_t *dd);         /* mptrac.c:7851 */
+void mptrac_update_device(const ctl_t *ctl, const cache_t *cache, const clim_t *clim, met_t **met0,
+                          met_t **met1, const atm_t *atm);                      /* mptrac.c:8005 */
+void mptrac_update_host(const ctl_t *ctl, const cache_t *cache, const clim_t *clim, met_t **met0,
+                        met_t **met1, const atm_t *atm);                        /* mptrac.c:8061 */
+void mptrac_write_atm(const char *filename, const ctl_t *ctl, const atm_t *atm,
+                      const double t);                                          /* mptrac.c:8117 */
+void mptrac_write_met(const char *filename, const ctl_t *ctl, met_t *met);      /* mptrac.c:8159 */
+void mptrac_write_output(const char *dirname, const ctl_t *ctl, met_t *met0, met_t *met1, atm_t *atm,
+                         depo_t *depo, const double t);                         /* mptrac.c:8230 */
+
+/* utilities of the reference that the driver and tools use */
+double scan_ctl(const char *filename, int argc, char *argv[], const char *varname, const int arridx,
+                const char *defvalue, char *value);                             /* mptrac.c:12434 */
+void jsec2time(const double jsec, int *year, int *mon, int *day, int *hour, int *min, int *sec,
+               double *remain);                                                 /* mptrac.c:3265 */
+void time2jsec(const int year, const int mon, const int day, const int hour, const int min,
+               const int sec, const double remain, double *jsec);               /* mptrac.c:12607 */
+void clim_tropo_init(clim_t *clim);                                             /* mptrac.c:241 */
+void module_timesteps_init(ctl_t *ctl, const atm_t *atm);                       /* mptrac.c:6046 */
+void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1, const atm_t *atm,
+                const double t);                                                /* mptrac.c:13751 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,83 @@
+/*
+ * trac.c -- Lagrangian particle dispersion driver, MI355X build.
+ *
+ * Same command line and the same call sequence of the high-level interface as
+ * the reference's driver (src/trac.c:43-197):
+ *
+ *   trac <dirlist> <ctl> <atm_in> [KEY VALUE ...]
+ *
+ * One process drives one GPU (control key HIP_DEVICE).  The reference's MPI
+ * farm over work directories (trac.c:70-98) is not reproduced: directories
+ * are processed one after the other.
+ */
+#include "mptrac.h"
+
+#include <sys/time.h>
+
+static double wall(void) {
+  struct timeval tv;
+  gettimeofday(&tv, NULL);
+  return (double) tv.tv_sec + 1e-6 * (double) tv.tv_usec;
+}
+
+int main(int argc, char *argv[]) {
+  ctl_t *ctl;
+  cache_t *cache;
+  clim_t *clim;
+  met_t *met0, *met1;
+  atm_t *atm;
+  depo_t *depo;
+  dd_t *dd;
+  FILE *dirlist;
+  char dirname[LEN], filename[2 * LEN];
+
+  if (argc < 4) {
+    printf("\nMPTRAC trac tool (MI355X build).\n\nUsage:\n  trac <dirlist> <ctl> <atm_in> [KEY VALUE ...]\n\n");
+    return EXIT_FAILURE;
+  }
+  if (!(dirlist = fopen(argv[1], "r")))
+    ERRMSG("Cannot open directory list!");
+
+  while (fscanf(dirlist, "%4999s", dirname) != EOF) {
+
+    /* ---- initialise the model run (trac.c:109-125) ---- */
+    mptrac_alloc(&ctl, &cache, &clim, &met0, &met1, &atm, &depo, &dd);
+    sprintf(filename, "%s/%s", dirname, argv[2]);
+    mptrac_read_ctl(filename, argc, argv, ctl);
+    mptrac_read_clim(ctl, clim);
+    sprintf(filename, "%s/%s", dirname, argv[3]);
+    if (!mptrac_read_atm(filename, ctl, atm))
+      ERRMSG("Cannot open file!");
+    mptrac_init(ctl, cache, clim, atm, depo, 0);
+
+    /* ---- loop over time steps (trac.c:131-163) ---- */
+    const double w0 = wall();
+    long nsteps = 0;
+    for (double t = ctl->t_start; ctl->direction * (t - ctl->t_stop) < ctl->dt_mod;
+         t += ctl->direction * ctl->dt_mod) {
+      if (ctl->direction * (t - ctl->t_stop) > 0)
+        t = ctl->t_stop;
+      mptrac_get_met(ctl, clim, t, &met0, &met1, dd);
+      if (ctl->dt_mod > fabs(met0->lon[1] - met0->lon[0]) * 111132. / 150.)
+        WARN("Violation of CFL criterion! Check DT_MOD!");
+      mptrac_run_timestep(ctl, cache, clim, &met0, &met1, atm, depo, t, dd);
+      mptrac_write_output(dirname, ctl, met0, met1, atm, depo, t);
+      nsteps++;
+    }
+    mptrac_update_host(NULL, NULL, NULL, NULL, NULL, atm);   /* also drains the device queue */
+    const double w1 = wall();
+
+    /* ---- report (trac.c:172-188) ---- */
+    LOG(1, "SIZE_NP = %d", atm->np);
+    LOG(1, "SIZE_TASKS = %d", 1);
+    LOG(1, "MEMORY_ATM = %g MByte", sizeof(atm_t) / 1024. / 1024.);
+    LOG(1, "MEMORY_CACHE = %g MByte", sizeof(cache_t) / 1024. / 1024.);
+    LOG(1, "MEMORY_METEO = %g MByte", 2 * sizeof(met_t) / 1024. / 1024.);
+    LOG(1, "TIMER_TIMESTEPS = %.3f s    (%ld calls, %.3e particle-steps/s)", w1 - w0, nsteps,
+        nsteps > 1 ? (double) atm->np * (double) (nsteps - 1) / (w1 - w0) : 0.0);
+
+    mptrac_free(ctl, cache, clim, met0, met1, atm, depo, dd);
+  }
+  fclose(dirlist);
+  return EXIT_SUCCESS;
+}

@@ -51,10 +51,26 @@ def build(force=False):
 _lib = None
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU
+    quota.  Inside a container os.cpu_count() is the whole host; an OpenMP team
+    of that size on a 16-core quota spends its time being throttled."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         _lib = C.CDLL(build())
+        if "OMP_NUM_THREADS" not in os.environ:
+            _lib.orc_set_num_threads(usable_cores())
         _lib.orc_sizeof_ctl.restype = C.c_size_t
         assert _lib.orc_sizeof_ctl() == C.sizeof(OrcCtl), "orc_ctl_t layout mismatch"
         _lib.orc_locate_irr.argtypes = [_dp, C.c_int, C.c_double]

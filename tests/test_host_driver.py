@@ -1,0 +1,95 @@
+"""The C host layer (mptrac_amd/host: the reference's mptrac_* interface and
+the `trac` driver) end to end: files in the reference's formats in, particle
+files out, compared with the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import hostfiles as hf
+from mptrac_amd import build
+from mptrac_amd.clim import load_clim_tropo
+from mptrac_amd.synth import synthetic_met, synthetic_particles
+from oracle import binding as B
+
+T0 = 707443200.0      # 2022-06-02 00:00 UTC, as tests/dd_test of the reference
+QUANT = ("m", "rp", "rhop")
+
+
+def _setup(tmp, n=3000, hours=2, atm_type=1):
+    lib, trac = build.build_host()
+    metbase = os.path.join(tmp, "met")
+    mets = []
+    for k in range(hours + 1):
+        m = synthetic_met("tiny", T0 + 3600.0 * k, 1.0 + 0.1 * k)
+        hf.write_met_bin(hf.met_filename(metbase, m.time), m)
+        mets.append(m)
+    atm = synthetic_particles(n, time=T0, quantities=QUANT)
+    (hf.write_atm_bin if atm_type == 1 else hf.write_atm_asc)(os.path.join(tmp, "atm_in"), atm)
+    keys = {"NQ": 3, "QNT_NAME[0]": "m", "QNT_NAME[1]": "rp", "QNT_NAME[2]": "rhop", "METBASE": metbase,
+            "MET_TYPE": 1, "DT_MET": 3600, "DT_MOD": 180, "ADVECT": 4, "DIFFUSION": 1, "TURB_DZ_TROP": 0.1,
+            "CONV_CAPE": 0, "T_STOP": T0 + 3600.0 * hours, "ATM_TYPE": atm_type, "ATM_TYPE_OUT": 1,
+            "ATM_BASENAME": "atm", "ATM_DT_OUT": 3600, "GRID_BASENAME": "grid", "GRID_DT_OUT": 3600,
+            "GRID_NX": 36, "GRID_NY": 18, "MET_DT_OUT": 0}
+    hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
+    open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
+    return trac, mets, atm
+
+
+def _oracle(mets, atm, hours):
+    ctl = dict(advect=4, dt_mod=180.0, dt_met=3600.0, diffusion=1, turb_dz_trop=0.1, conv_cape=0.0,
+               t_stop=T0 + 3600.0 * hours, nq=3, qnt_m=0, qnt_rp=1, qnt_rhop=2)
+    o = B.Oracle(ctl, load_clim_tropo(), mets[0], mets[1], atm)
+    o.timesteps_init()
+    imet = 0
+    snaps = {}
+    for t in cases.step_times(o.ctl):
+        while t > o.met[1].time:
+            imet += 1
+            o.swap_met(mets[imet + 1])
+        o.run_timestep(t)
+        if (t - T0) % 3600.0 == 0:
+            snaps[t] = o.state()
+    return snaps
+
+
+def test_trac_refuses_to_run_without_a_device(tmp_path):
+    """No CPU fallback: on a box without a GPU the driver stops with an error."""
+    from test_abi import _have_gpu
+    if _have_gpu():
+        pytest.skip("a HIP device is present")
+    trac, mets, atm = _setup(str(tmp_path), n=10, hours=1)
+    r = subprocess.run([trac, os.path.join(str(tmp_path), "dirlist"), "trac.ctl", "atm_in"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode != 0 and "HIP device" in out, out[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("atm_type", [1, 0])
+def test_trac_end_to_end_matches_oracle(tmp_path, atm_type):
+    tmp = str(tmp_path)
+    trac, mets, atm = _setup(tmp, n=3000, hours=2, atm_type=atm_type)
+    r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    if atm_type == 0:
+        # ASCII input carries altitude; the driver converts with P(z) like the reference
+        atm = dict(atm, p=1013.25 * np.exp(-(7.0 * np.log(1013.25 / atm["p"])) / 7.0))
+    snaps = _oracle(mets, atm, 2)
+    for hour in (0, 1, 2):
+        t = T0 + 3600.0 * hour
+        f = os.path.join(tmp, "atm_2022_06_02_%02d_00_00.bin" % hour)
+        got = hf.read_atm_bin(f, 3)
+        ref = snaps[t]
+        tol = 1e-10 if atm_type == 1 else 1e-9     # ASCII input: repr() round trip of z -> p
+        assert np.array_equal(got["time"], ref["time"])
+        for k in ("lon", "lat", "p"):
+            assert cases.rel_err(got[k], ref[k]) <= tol, (hour, k, cases.rel_err(got[k], ref[k]))
+        assert cases.rel_err(got["q"], ref["q"]) <= tol
+        g = os.path.join(tmp, "grid_2022_06_02_%02d_00_00.tab" % hour)
+        rows = [ln.split() for ln in open(g) if ln.strip() and not ln.startswith("#")]
+        assert len(rows) == 36 * 18 and sum(int(r[8]) for r in rows) == 3000
