@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
 
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
-tail -1 "$OUT/stats.log" > "$OUT/bench_under_profiler.json"
+grep "^{" "$OUT/stats.log" | tail -1 > "$OUT/bench_under_profiler.json"
 
 pmc() {  # name, counters...
   local name=$1; shift
@@ -20,6 +20,14 @@ pmc() {  # name, counters...
 }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
+# calibration of FETCH_SIZE / WRITE_SIZE on a kernel with a known byte count:
+# pack3d_kernel reads 32 B and writes 32 B per grid point, fully coalesced
+calib() {
+  local name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "pack3d_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
+}
+calib calib_fetch FETCH_SIZE
+calib calib_write WRITE_SIZE
 pmc tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 pmc sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS

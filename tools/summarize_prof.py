@@ -32,10 +32,42 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "**/*counter_collection.csv"), recursive=True):
         acc = defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "step_kernel" in r.get("Kernel_Name", ""):
+            if "step_kernel" in r.get("Kernel_Name", "") or "pack3d" in r.get("Kernel_Name", ""):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         out.append(f"== PMC {os.path.basename(d)} (step_kernel dispatches, per-dispatch mean) ==")
         for k, v in sorted(acc.items()):
             # rocprofv3 emits one row per dispatch (and per dimension instance); average per dispatch
             out.append(f"  {k:34s} n={len(v):4d} mean={sum(v) / len(v):.6g} min={min(v):.6g} max={max(v):.6g}")
 print("\n".join(out))
+
+# HBM traffic of the step kernel per launch (MI355X_MICROARCH.md, HBM section):
+# FETCH_SIZE / WRITE_SIZE are in KiB; calibrate on pack3d_kernel (known bytes).
+def one(d, name):
+    for f in glob.glob(os.path.join(src, d, "**/*counter_collection.csv"), recursive=True):
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name]
+        return v
+    return []
+
+
+fs, ws = one("pmc_fetch", "FETCH_SIZE"), one("pmc_write", "WRITE_SIZE")
+cf, cw = one("pmc_calib_fetch", "FETCH_SIZE"), one("pmc_calib_write", "WRITE_SIZE")
+if fs and ws:
+    steady_f = sorted(fs)[len(fs) // 2] * 1024.0      # median dispatch (the dt = 0 first call is smaller)
+    steady_w = sorted(ws)[len(ws) // 2] * 1024.0
+    info = {"fetch_bytes_raw": steady_f, "write_bytes_raw": steady_w}
+    grid_bytes = None
+    try:
+        cfg = json.loads(open(bj).read().strip().splitlines()[-1])
+        nx, ny, npl = cfg["config"]["grid"]
+        grid_bytes = nx * ny * npl * 32.0
+    except Exception:
+        pass
+    if cf and cw and grid_bytes:
+        kf, kw = grid_bytes / (max(cf) * 1024.0), grid_bytes / (max(cw) * 1024.0)
+        info.update(calib_fetch_factor=kf, calib_write_factor=kw, calib_known_bytes=grid_bytes)
+        info["traffic_bytes"] = steady_f * kf + steady_w * kw
+    else:
+        info["traffic_bytes"] = steady_f + steady_w
+    print("== HBM traffic of step_kernel per launch ==")
+    print("  " + json.dumps(info))
+    json.dump(info, open(os.path.join(src, "traffic.json"), "w"))
