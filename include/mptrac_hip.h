@@ -196,11 +196,6 @@ int mphip_profile_end(mphip_ctx *ctx, long long *launches, double *kernel_ms);
 int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, float *cos_out,
                        float *sin_out);
 int mphip_test_rng(mphip_ctx *ctx, uint64_t ctr, long long n, int method, double *out);
-/* Gather micro-benchmark over the uploaded particles: `reps` wind stencils per
- * particle, lane-by-lane (mode 0) or quad-cooperative through LDS (mode 1);
- * returns the kernel time and a checksum that must not depend on the mode. */
-int mphip_test_gather(mphip_ctx *ctx, int mode, int reps, double *ms, double *checksum);
-
 #ifdef __cplusplus
 }
 #endif

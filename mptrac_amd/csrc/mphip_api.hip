@@ -52,7 +52,8 @@ struct mphip_ctx {
   double *d_axes = nullptr;           // axes blob (layout: DevMet::axes)
   int lut_base = 0, lut_size = 0;
   size_t axes_bytes = 0;
-  f32x4 *d_wind = nullptr, *d_cloud = nullptr, *d_sfc = nullptr;
+  float *d_wind = nullptr, *d_temp = nullptr;     // packed two-snapshot grids (layouts: mphip_device.hpp)
+  f32x4 *d_cloud = nullptr, *d_sfa = nullptr, *d_sfb = nullptr, *d_sfc = nullptr;
   bool packed_dirty = true;
 
   // particles
@@ -158,7 +159,10 @@ DevAtm dev_atm(const mphip_ctx *c) {
 DevMet dev_met(const mphip_ctx *c) {
   DevMet M;
   M.wind = c->d_wind;
+  M.temp = c->d_temp;
   M.cloud = c->d_cloud;
+  M.sfa = c->d_sfa;
+  M.sfb = c->d_sfb;
   M.sfc = c->d_sfc;
   M.axes = c->d_axes;
   M.lut_base = c->lut_base;
@@ -273,32 +277,33 @@ int ensure_packed(mphip_ctx *ctx) {
   if (!s0.valid || !s1.valid)
     return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
   const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
-  PackSrc w, cl;
+  PackArgs a;
   bool any_cloud = false;
-  for (int k = 0; k < 4; k++) {
-    w.f[0][k] = s0.has3[MPHIP_U + k] ? s0.f3[MPHIP_U + k] : nullptr;
-    w.f[1][k] = s1.has3[MPHIP_U + k] ? s1.f3[MPHIP_U + k] : nullptr;
-    cl.f[0][k] = s0.has3[MPHIP_LWC + k] ? s0.f3[MPHIP_LWC + k] : nullptr;
-    cl.f[1][k] = s1.has3[MPHIP_LWC + k] ? s1.f3[MPHIP_LWC + k] : nullptr;
-    any_cloud = any_cloud || cl.f[0][k] || cl.f[1][k];
+  const MetSlot *ss[2] = { &s0, &s1 };
+  for (int t = 0; t < 2; t++) {
+    for (int f = 0; f < MPHIP_N3D; f++)
+      a.f3[t][f] = ss[t]->has3[f] ? ss[t]->f3[f] : nullptr;
+    for (int f = 0; f < MPHIP_N2D; f++)
+      a.f2[t][f] = ss[t]->has2[f] ? ss[t]->f2[f] : nullptr;
+    for (int f = MPHIP_LWC; f <= MPHIP_SWC; f++)
+      any_cloud = any_cloud || ss[t]->has3[f];
   }
-  if (!ctx->d_wind && dev_alloc(ctx, &ctx->d_wind, 2 * ncell))
+  if (!ctx->d_wind && (dev_alloc(ctx, &ctx->d_wind, 6 * ncell) || dev_alloc(ctx, &ctx->d_temp, 2 * ncell)))
     return 1;
-  if (!ctx->d_sfc && dev_alloc(ctx, &ctx->d_sfc, 4 * ncol))
+  if (!ctx->d_sfa && (dev_alloc(ctx, &ctx->d_sfa, ncol) || dev_alloc(ctx, &ctx->d_sfb, 2 * ncol)
+                      || dev_alloc(ctx, &ctx->d_sfc, 2 * ncol)))
     return 1;
-  hipLaunchKernelGGL(pack3d_kernel, dim3(grid_for((long long) ncell)), dim3(256), 0, ctx->stream, ctx->d_wind, w, ncell);
-  if (any_cloud) {
-    if (!ctx->d_cloud && dev_alloc(ctx, &ctx->d_cloud, 2 * ncell))
-      return 1;
-    hipLaunchKernelGGL(pack3d_kernel, dim3(grid_for((long long) ncell)), dim3(256), 0, ctx->stream, ctx->d_cloud, cl,
-                       ncell);
-  }
-  PackSrc2 s2;
-  for (int k = 0; k < 8; k++) {
-    s2.f[0][k] = s0.has2[k] ? s0.f2[k] : nullptr;
-    s2.f[1][k] = s1.has2[k] ? s1.f2[k] : nullptr;
-  }
-  hipLaunchKernelGGL(pack2d_kernel, dim3(grid_for((long long) ncol)), dim3(256), 0, ctx->stream, ctx->d_sfc, s2, ncol);
+  if (any_cloud && !ctx->d_cloud && dev_alloc(ctx, &ctx->d_cloud, 2 * ncell))
+    return 1;
+  a.wind = ctx->d_wind;
+  a.temp = ctx->d_temp;
+  a.cloud = any_cloud ? ctx->d_cloud : nullptr;
+  a.sfa = ctx->d_sfa;
+  a.sfb = ctx->d_sfb;
+  a.sfc = ctx->d_sfc;
+  a.ncell = ncell;
+  a.ncol = ncol;
+  hipLaunchKernelGGL(pack_kernel, dim3(grid_for((long long) ncell)), dim3(256), 0, ctx->stream, a);
   HIPCHK(hipGetLastError());
   ctx->packed_dirty = false;
   return 0;
@@ -351,7 +356,9 @@ int check_fields(mphip_ctx *ctx, unsigned mask) {
       return fail(ctx, "Module needs quantity mass or volume mixing ratio!");
   if (mask & MPHIP_MOD_WET_DEPO) {
     if (need2(MPHIP_PCT, "module_wet_depo") || need2(MPHIP_PCB, "module_wet_depo") || need2(MPHIP_CL, "module_wet_depo")
-        || need3(MPHIP_T, "module_wet_depo") || !ctx->d_cloud)
+        || need3(MPHIP_T, "module_wet_depo") || need3(MPHIP_LWC, "module_wet_depo")
+        || need3(MPHIP_RWC, "module_wet_depo") || need3(MPHIP_IWC, "module_wet_depo")
+        || need3(MPHIP_SWC, "module_wet_depo"))
       return fail(ctx, "module_wet_depo: cloud fields (pct, pcb, cl, lwc, rwc, iwc, swc, t) were not uploaded");
   }
   if (mask & MPHIP_MOD_DRY_DEPO)
@@ -667,7 +674,10 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_clim);
   dev_free(ctx->d_axes);
   dev_free(ctx->d_wind);
+  dev_free(ctx->d_temp);
   dev_free(ctx->d_cloud);
+  dev_free(ctx->d_sfa);
+  dev_free(ctx->d_sfb);
   dev_free(ctx->d_sfc);
   for (auto p : ctx->d_arr)
     dev_free(p);
@@ -757,9 +767,13 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     ctx->ny = met->ny;
     ctx->npl = met->np;
     dev_free(ctx->d_wind);
+    dev_free(ctx->d_temp);
     dev_free(ctx->d_cloud);
+    dev_free(ctx->d_sfa);
+    dev_free(ctx->d_sfb);
     dev_free(ctx->d_sfc);
-    ctx->d_wind = ctx->d_cloud = ctx->d_sfc = nullptr;
+    ctx->d_wind = ctx->d_temp = nullptr;
+    ctx->d_cloud = ctx->d_sfa = ctx->d_sfb = ctx->d_sfc = nullptr;
   }
   ctx->coord_type = met->coord_type;
   // the reference interpolates on met0's axes (mptrac.c:3010-3020); slot 0 defines them
@@ -1156,46 +1170,6 @@ int mphip_profile_end(mphip_ctx *ctx, long long *launches, double *kernel_ms) {
     *kernel_ms = total;
   ctx->prof = false;
   ctx->ev_used = 0;
-  return 0;
-}
-
-int mphip_test_gather(mphip_ctx *ctx, int mode, int reps, double *ms, double *checksum) {
-  if (!ctx || !ms)
-    return 1;
-  HIPCHK(hipSetDevice(ctx->device));
-  if (ensure_packed(ctx))
-    return 1;
-  double *d_out = nullptr;
-  HIPCHK(hipMalloc((void **) &d_out, (size_t) std::max<long long>(ctx->np, 1) * sizeof(double)));
-  HIPCHK(hipMemsetAsync(d_out, 0, (size_t) std::max<long long>(ctx->np, 1) * sizeof(double), ctx->stream));
-  int nb = grid_for(ctx->np, 256, 8192);
-  nb = (nb + 7) & ~7;
-  const size_t lds = axes_lds_bytes(ctx) + 4 * (size_t) kXchgBytesPerWave;
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
-  const DevMet M = dev_met(ctx);
-  const DevAtm a = dev_atm(ctx);
-  hipLaunchKernelGGL(test_gather_kernel, dim3(nb), dim3(256), lds, ctx->stream, M, a, mode, reps, nb, d_out);   // warm
-  HIPCHK(hipEventRecord(e0, ctx->stream));
-  hipLaunchKernelGGL(test_gather_kernel, dim3(nb), dim3(256), lds, ctx->stream, M, a, mode, reps, nb, d_out);
-  HIPCHK(hipEventRecord(e1, ctx->stream));
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  float t = 0;
-  HIPCHK(hipEventElapsedTime(&t, e0, e1));
-  *ms = t;
-  if (checksum) {
-    std::vector<double> h((size_t) ctx->np);
-    HIPCHK(hipMemcpy(h.data(), d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-    double sum = 0;
-    for (double v : h)
-      sum += v;
-    *checksum = sum;
-  }
-  (void) hipEventDestroy(e0);
-  (void) hipEventDestroy(e1);
-  HIPCHK(hipFree(d_out));
   return 0;
 }
 

@@ -36,15 +36,15 @@ constexpr double kWdTLiquid = kT0, kWdTIce = 238.15, kWdTLiquidBC = 270.;
 
 // ---- device views ---------------------------------------------------------
 
-// Both bracketing snapshots packed per grid point so that one particle's
-// eight corners are four 64-byte pieces:
-//   wind [nx][ny][np][2] f32x4 : {u,v,w,t} at met0, then {u,v,w,t} at met1
-//   cloud[nx][ny][np][2] f32x4 : {lwc,rwc,iwc,swc} at met0 / met1 (optional)
-//   sfc  [nx][ny][4]     f32x4 : {ps,pbl,cape,cin}0 {pel,pct,pcb,cl}0 {..}1 {..}1
+// Both bracketing snapshots packed per grid point (record layouts: see the
+// interpolation section)
 struct DevMet {
-  const f32x4 *wind;
-  const f32x4 *cloud;
-  const f32x4 *sfc;
+  const float *wind;     // [cell][6]
+  const float *temp;     // [cell][2]
+  const f32x4 *cloud;    // [cell][2] (optional)
+  const f32x4 *sfa;      // [col]
+  const f32x4 *sfb;      // [col][2]
+  const f32x4 *sfc;      // [col][2]
   // axes blob in global memory, copied to LDS by every workgroup:
   //   double lon[nx], lat[ny], p[np], 1/dlon[nx], 1/dlat[ny], 1/dp[np]; int16 p_lut[lut_size]
   const double *axes;
@@ -370,79 +370,70 @@ __device__ __forceinline__ void stencil_2d(const DevMet &M, const Axes &A, doubl
   s.wy = div_const(hy.x1 - lat2, hy.x1 - hy.x0, hy.inv);
 }
 
-// The eight corners of one stencil for both snapshots: 16 x 16-byte loads,
-// issued together so that they are all in flight before the first use.
-struct Corners {
-  f32x4 lo[2][2][2];   // [di][dj][snapshot] at level ip
-  f32x4 hi[2][2][2];   // at level ip + 1
+// 16-byte vectors that are only 4-byte aligned in memory (the packed records
+// below start on 8- or 24-byte multiples); gfx950 global loads need dword
+// alignment only.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// Packed grids (both snapshots in one record, level index fastest):
+//   wind [cell][6]  {u,v,w}0 {u,v,w}1      a column's level pair = 48 B = 3 x 16 B
+//   temp [cell][2]  {t}0 {t}1              a column's level pair = 16 B = 1 load
+//   cloud[cell][8]  {lwc,rwc,iwc,swc}0 {..}1   level pair = 64 B (wet deposition only)
+//   sfa  [col][4]   {ps,pbl}0 {ps,pbl}1    one load per corner
+//   sfb  [col][8]   {cape,cin,pel,-}0 {..}1
+//   sfc  [col][8]   {pct,pcb,cl,-}0 {..}1
+// so a wind stencil is 12 loads, a temperature stencil 4, a {ps,pbl} stencil 4.
+
+struct WindCorners {
+  f32x4u r[2][2][3];   // [di][dj][piece]: 12 floats = level ip {u,v,w}0{u,v,w}1, level ip+1 {..}
 };
 
-__device__ __forceinline__ void load_corners(const f32x4 *__restrict__ g, const DevMet &M, const Stencil &s,
-                                             Corners &c) {
+__device__ __forceinline__ size_t cell_of(const DevMet &M, const Stencil &s, int di, int dj) {
+  return ((size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj)) * (size_t) M.np + (size_t) s.ip;
+}
+
+__device__ __forceinline__ void load_wind(const DevMet &M, const Stencil &s, WindCorners &c) {
 #pragma unroll
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++) {
-      const size_t cell = ((size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj)) * (size_t) M.np
-        + (size_t) s.ip;
-      const f32x4 *q = g + 2 * cell;
-      c.lo[di][dj][0] = q[0];
-      c.lo[di][dj][1] = q[1];
-      c.hi[di][dj][0] = q[2];
-      c.hi[di][dj][1] = q[3];
+      const f32x4u *q = (const f32x4u *) (M.wind + 6 * cell_of(M, s, di, dj));
+      c.r[di][dj][0] = q[0];
+      c.r[di][dj][1] = q[1];
+      c.r[di][dj][2] = q[2];
     }
 }
 
-// Optional register cache of the last stencil's corners (MPHIP_WIND_CACHE=1):
-// a particle rarely leaves its cell within a step, so only lanes whose cell
-// changed would reload.  Measured on MI355X (C3, 10^7 sorted particles) this
-// LOSES: 256 VGPRs + 368 B/lane scratch and a divergent reload per stage,
-// 1.04 -> 2.34 ms for RK4 advection.  Kept switched off; every stencil reloads.
-#ifndef MPHIP_WIND_CACHE
-#define MPHIP_WIND_CACHE 0
-#endif
-
-struct WindCache {
-  Corners c;
-  int ix, iy, ip;   // ip < 0: empty
-};
-
-__device__ __forceinline__ void wind_cache_reset(WindCache &wc) {
-  wc.ix = wc.iy = 0;
-  wc.ip = -1;
+// value of component k (0 u, 1 v, 2 w) of snapshot t at level ip + lvl
+__device__ __forceinline__ float wind_elem(const WindCorners &c, int di, int dj, int lvl, int t, int k) {
+  const int e = 6 * lvl + 3 * t + k;
+  return c.r[di][dj][e >> 2][e & 3];
 }
 
-__device__ __forceinline__ const Corners &wind_corners(const DevMet &M, const Stencil &s, WindCache &wc) {
-#if MPHIP_WIND_CACHE
-  if (wc.ip != s.ip || wc.iy != s.iy || wc.ix != s.ix) {
-    load_corners(M.wind, M, s, wc.c);
-    wc.ix = s.ix;
-    wc.iy = s.iy;
-    wc.ip = s.ip;
-  }
-#else
-  load_corners(M.wind, M, s, wc.c);
-#endif
-  return wc.c;
-}
-
-// intpol_met_space_3d, mptrac.c:3023-3043, for component k of snapshot t.
-// The difference of the two float corners is taken in single precision, as
-// the reference's C expression does (float - float), and only then widened.
-__device__ __forceinline__ double space_3d(const Corners &c, const Stencil &s, int t, int k) {
-  const double c00 = s.wp * (double) (c.lo[0][0][t][k] - c.hi[0][0][t][k]) + (double) c.hi[0][0][t][k];
-  const double c01 = s.wp * (double) (c.lo[0][1][t][k] - c.hi[0][1][t][k]) + (double) c.hi[0][1][t][k];
-  const double c10 = s.wp * (double) (c.lo[1][0][t][k] - c.hi[1][0][t][k]) + (double) c.hi[1][0][t][k];
-  const double c11 = s.wp * (double) (c.lo[1][1][t][k] - c.hi[1][1][t][k]) + (double) c.hi[1][1][t][k];
+// intpol_met_space_3d, mptrac.c:3023-3043.  The difference of the two float
+// corners is taken in single precision, as the reference's C expression does
+// (float - float), and only then widened.
+__device__ __forceinline__ double lerp3(const Stencil &s, float l00, float h00, float l01, float h01, float l10,
+                                        float h10, float l11, float h11) {
+  const double c00 = s.wp * (double) (l00 - h00) + (double) h00;
+  const double c01 = s.wp * (double) (l01 - h01) + (double) h01;
+  const double c10 = s.wp * (double) (l10 - h10) + (double) h10;
+  const double c11 = s.wp * (double) (l11 - h11) + (double) h11;
   const double r0 = s.wy * (c00 - c01) + c01;
   const double r1 = s.wy * (c10 - c11) + c11;
   return s.wx * (r0 - r1) + r1;
 }
 
+__device__ __forceinline__ double wind_space_3d(const WindCorners &c, const Stencil &s, int t, int k) {
+  return lerp3(s, wind_elem(c, 0, 0, 0, t, k), wind_elem(c, 0, 0, 1, t, k), wind_elem(c, 0, 1, 0, t, k),
+               wind_elem(c, 0, 1, 1, t, k), wind_elem(c, 1, 0, 0, t, k), wind_elem(c, 1, 0, 1, t, k),
+               wind_elem(c, 1, 1, 0, t, k), wind_elem(c, 1, 1, 1, t, k));
+}
+
 // intpol_met_time_3d, mptrac.c:3112-3137
-__device__ __forceinline__ double time_3d(const Corners &c, const Stencil &s, double wt, int k) {
-  const double v0 = space_3d(c, s, 0, k);
-  const double v1 = space_3d(c, s, 1, k);
+__device__ __forceinline__ double wind_time_3d(const WindCorners &c, const Stencil &s, double wt, int k) {
+  const double v0 = wind_space_3d(c, s, 0, k);
+  const double v1 = wind_space_3d(c, s, 1, k);
   return wt * (v0 - v1) + v1;
 }
 
@@ -450,39 +441,51 @@ __device__ __forceinline__ double time_weight(const DevMet &M, double ts) {   //
   return div_const(M.time1 - ts, M.time1 - M.time0, M.inv_dtime);
 }
 
-// Four corners of the packed surface record: [ix][iy][4] f32x4.
-struct Corners2 {
-  f32x4 v[2][2][4];
+// temperature stencil: one 16-byte load per column = {t0,t1} at ip, {t0,t1} at ip+1
+__device__ __forceinline__ double temp_time_3d(const DevMet &M, const Stencil &s, double wt) {
+  f32x4u v[2][2];
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++)
+      v[di][dj] = *(const f32x4u *) (M.temp + 2 * cell_of(M, s, di, dj));
+  const double v0 = lerp3(s, v[0][0][0], v[0][0][2], v[0][1][0], v[0][1][2], v[1][0][0], v[1][0][2], v[1][1][0],
+                          v[1][1][2]);
+  const double v1 = lerp3(s, v[0][0][1], v[0][0][3], v[0][1][1], v[0][1][3], v[1][0][1], v[1][0][3], v[1][1][1],
+                          v[1][1][3]);
+  return wt * (v0 - v1) + v1;
+}
+
+// cloud water stencil (wet deposition): {lwc,rwc,iwc,swc}0 {..}1 per level
+struct CloudCorners {
+  f32x4 lo[2][2][2];   // [di][dj][snapshot] at level ip
+  f32x4 hi[2][2][2];
 };
 
-// `which` selects the 16-byte pieces to fetch: bit 0 -> {ps,pbl,cape,cin},
-// bit 1 -> {pel,pct,pcb,cl} (both snapshots each).
-template <int WHICH>
-__device__ __forceinline__ void load_corners2(const DevMet &M, const Stencil &s, Corners2 &c) {
+__device__ __forceinline__ void load_cloud(const DevMet &M, const Stencil &s, CloudCorners &c) {
 #pragma unroll
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++) {
-      const f32x4 *q = M.sfc + 4 * ((size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj));
-      if (WHICH & 1) {
-        c.v[di][dj][0] = q[0];
-        c.v[di][dj][2] = q[2];
-      }
-      if (WHICH & 2) {
-        c.v[di][dj][1] = q[1];
-        c.v[di][dj][3] = q[3];
-      }
+      const f32x4 *q = M.cloud + 2 * cell_of(M, s, di, dj);
+      c.lo[di][dj][0] = q[0];
+      c.lo[di][dj][1] = q[1];
+      c.hi[di][dj][0] = q[2];
+      c.hi[di][dj][1] = q[3];
     }
 }
 
-// field f (MPHIP_PS ... MPHIP_CL) lives in piece f/4 (+2 for met1), lane f%4
-// intpol_met_space_2d value part, mptrac.c:3083-3107
-__device__ __forceinline__ double space_2d(const Corners2 &c, const Stencil &s, int t, int f) {
-  const int piece = (f >> 2) + 2 * t, k = f & 3;
-  const double c00 = c.v[0][0][piece][k];
-  const double c01 = c.v[0][1][piece][k];
-  const double c10 = c.v[1][0][piece][k];
-  const double c11 = c.v[1][1][piece][k];
+__device__ __forceinline__ double cloud_time_3d(const CloudCorners &c, const Stencil &s, double wt, int k) {
+  const double v0 = lerp3(s, c.lo[0][0][0][k], c.hi[0][0][0][k], c.lo[0][1][0][k], c.hi[0][1][0][k], c.lo[1][0][0][k],
+                          c.hi[1][0][0][k], c.lo[1][1][0][k], c.hi[1][1][0][k]);
+  const double v1 = lerp3(s, c.lo[0][0][1][k], c.hi[0][0][1][k], c.lo[0][1][1][k], c.hi[0][1][1][k], c.lo[1][0][1][k],
+                          c.hi[1][0][1][k], c.lo[1][1][1][k], c.hi[1][1][1][k]);
+  return wt * (v0 - v1) + v1;
+}
+
+// intpol_met_space_2d value part (mptrac.c:3083-3107): NaN-aware nearest
+// neighbour when a corner is not finite
+__device__ __forceinline__ double bilin_2d(const Stencil &s, double c00, double c01, double c10, double c11) {
   if (isfinite(c00) && isfinite(c01) && isfinite(c10) && isfinite(c11)) {
     const double r0 = s.wy * (c00 - c01) + c01;
     const double r1 = s.wy * (c10 - c11) + c11;
@@ -494,12 +497,52 @@ __device__ __forceinline__ double space_2d(const Corners2 &c, const Stencil &s, 
 }
 
 // intpol_met_time_2d, mptrac.c:3141-3170
-__device__ __forceinline__ double time_2d(const Corners2 &c, const Stencil &s, double wt, int f) {
-  const double v0 = space_2d(c, s, 0, f);
-  const double v1 = space_2d(c, s, 1, f);
+__device__ __forceinline__ double blend_time_2d(double v0, double v1, double wt) {
   if (isfinite(v0) && isfinite(v1))
     return wt * (v0 - v1) + v1;
   return wt < 0.5 ? v1 : v0;
+}
+
+// {ps,pbl} of both snapshots at the four corners: one load each
+struct SurfA {
+  f32x4 v[2][2];   // {ps0, pbl0, ps1, pbl1}
+};
+
+__device__ __forceinline__ void load_sfa(const DevMet &M, const Stencil &s, SurfA &c) {
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++)
+      c.v[di][dj] = M.sfa[(size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj)];
+}
+
+// f = 0: ps, f = 1: pbl
+__device__ __forceinline__ double sfa_time_2d(const SurfA &c, const Stencil &s, double wt, int f) {
+  const double v0 = bilin_2d(s, c.v[0][0][f], c.v[0][1][f], c.v[1][0][f], c.v[1][1][f]);
+  const double v1 = bilin_2d(s, c.v[0][0][2 + f], c.v[0][1][2 + f], c.v[1][0][2 + f], c.v[1][1][2 + f]);
+  return blend_time_2d(v0, v1, wt);
+}
+
+// three-field surface records: {a,b,c,-}0 {a,b,c,-}1 (sfb: cape,cin,pel; sfc: pct,pcb,cl)
+struct SurfB {
+  f32x4 v[2][2][2];   // [di][dj][snapshot]
+};
+
+__device__ __forceinline__ void load_sfb(const f32x4 *__restrict__ g, const DevMet &M, const Stencil &s, SurfB &c) {
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++) {
+      const f32x4 *q = g + 2 * ((size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj));
+      c.v[di][dj][0] = q[0];
+      c.v[di][dj][1] = q[1];
+    }
+}
+
+__device__ __forceinline__ double sfb_time_2d(const SurfB &c, const Stencil &s, double wt, int f) {
+  const double v0 = bilin_2d(s, c.v[0][0][0][f], c.v[0][1][0][f], c.v[1][0][0][f], c.v[1][1][0][f]);
+  const double v1 = bilin_2d(s, c.v[0][0][1][f], c.v[0][1][1][f], c.v[1][0][1][f], c.v[1][1][1][f]);
+  return blend_time_2d(v0, v1, wt);
 }
 
 // ---- climatological tropopause and weights --------------------------------
@@ -714,9 +757,9 @@ __device__ __forceinline__ void position(const DevMet &M, const Axes &A, Particl
     // 5484): indices 0, weights 0 -> the value at grid node [1][1].  Reference
     // behaviour, reproduced; every lane reads the same four records.
     const Stencil s = stencil_zero();
-    Corners2 c;
-    load_corners2<1>(M, s, c);
-    const double ps = time_2d(c, s, time_weight(M, P.time), MPHIP_PS);
+    SurfA c;
+    load_sfa(M, s, c);
+    const double ps = sfa_time_2d(c, s, time_weight(M, P.time), 0);
     if (P.p > ps)
       P.p = ps * ps / P.p;
   }
@@ -724,7 +767,7 @@ __device__ __forceinline__ void position(const DevMet &M, const Axes &A, Particl
 
 // module_advect, pressure-level branch, mptrac.c:3612-3677
 template <int ADVECT>
-__device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particle &P, WindCache &wc) {
+__device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particle &P) {
   const int ct = M.coord_type;
   const double dt = P.dt;
   double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0;
@@ -746,11 +789,12 @@ __device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particl
     const double tm = P.time + dts;
     Stencil s;
     stencil_3d(M, A, x2, x0, x1, s);
-    const Corners &c = wind_corners(M, s, wc);
+    WindCorners c;
+    load_wind(M, s, c);
     const double wt = time_weight(M, tm);
-    u = time_3d(c, s, wt, 0);
-    v = time_3d(c, s, wt, 1);
-    w = time_3d(c, s, wt, 2);
+    u = wind_time_3d(c, s, wt, 0);
+    v = wind_time_3d(c, s, wt, 1);
+    w = wind_time_3d(c, s, wt, 2);
     double k = 1.0;
     if (ADVECT == 2)
       k = (i == 0 ? 0.0 : 1.0);
@@ -766,14 +810,13 @@ __device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particl
   P.p += dt * wm;
 }
 
-__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
-                                       WindCache &wc) {
+__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P) {
   if (ctl.advect == 4)
-    advect_n<4>(M, A, P, wc);
+    advect_n<4>(M, A, P);
   else if (ctl.advect == 2)
-    advect_n<2>(M, A, P, wc);
+    advect_n<2>(M, A, P);
   else
-    advect_n<1>(M, A, P, wc);
+    advect_n<1>(M, A, P);
 }
 
 // the Kz blend evaluated at a displaced pressure, mptrac.c:4669-4688
@@ -791,13 +834,13 @@ __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &
   const int ct = M.coord_type;
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
-  Corners2 c;
-  load_corners2<1>(M, s, c);
+  SurfA c;
+  load_sfa(M, s, c);
   const double wt = time_weight(M, P.time);
-  const double pbl = time_2d(c, s, wt, MPHIP_PBL);
+  const double pbl = sfa_time_2d(c, s, wt, 1);
   if (ctl.turb_pbl_scheme > 0 && P.p >= pbl)
     return;
-  const double ps = time_2d(c, s, wt, MPHIP_PS);
+  const double ps = sfa_time_2d(c, s, wt, 0);
   const double ptop = A.p[M.np - 1];
 
   const double wpbl = pbl_weight(ctl, P.p, pbl, ps);
@@ -843,7 +886,7 @@ __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &
 
 // module_diff_meso, mptrac.c:4280-4338
 __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
-                                          float &up, float &vp, float &wp, uint64_t ctr, uint64_t g, WindCache &wc) {
+                                          float &up, float &vp, float &wp, uint64_t ctr, uint64_t g) {
   // HIP's __fadd_rn / __fmul_rn are plain operators, so contraction has to be
   // switched off here for the single-precision statistics to round like the
   // reference's separate multiply and add (the variance is a small difference
@@ -855,7 +898,8 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
   s.ix = locate_reg(A.lon, M.nx, P.lon);   // exact: sigma is not continuous across cells
   s.iy = locate_lat(M, A, P.lat);
   s.ip = locate_p(M, A, P.p);
-  const Corners &c = wind_corners(M, s, wc);
+  WindCorners c;
+  load_wind(M, s, c);
 
   // single-precision sums in the reference's order: i (lon), j (lat),
   // k (level), met0 before met1
@@ -870,7 +914,7 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
         for (int t = 0; t < 2; t++)
 #pragma unroll
           for (int q = 0; q < 3; q++) {
-            const float a = (k == 0 ? c.lo[i][j][t][q] : c.hi[i][j][t][q]);
+            const float a = wind_elem(c, i, j, k, t, q);
             mean[q] = mean[q] + a;
             sig[q] = sig[q] + a * a;
           }
@@ -901,37 +945,38 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
 
 // temperature at (p, lon, lat): INTPOL_3D(t, 1)
 __device__ __forceinline__ double temperature_at(const DevMet &M, const Axes &A, double time, double p, double lon,
-                                                 double lat, WindCache &wc) {
+                                                 double lat) {
   Stencil s;
   stencil_3d(M, A, p, lon, lat, s);
-  const Corners &c = wind_corners(M, s, wc);
-  return time_3d(c, s, time_weight(M, time), 3);
+  return temp_time_3d(M, s, time_weight(M, time));
 }
 
 // module_convection, mptrac.c:4116-4170
 __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
-                                           uint64_t ctr, uint64_t g, WindCache &wc) {
+                                           uint64_t ctr, uint64_t g) {
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
-  Corners2 c;
-  load_corners2<3>(M, s, c);
+  SurfA c;
+  load_sfa(M, s, c);
   const double wt = time_weight(M, P.time);
-  const double ps = time_2d(c, s, wt, MPHIP_PS);
+  const double ps = sfa_time_2d(c, s, wt, 0);
   double pbot = ps, ptop = ps;
   if (ctl.conv_mix_pbl) {
-    const double pbl = time_2d(c, s, wt, MPHIP_PBL);
+    const double pbl = sfa_time_2d(c, s, wt, 1);
     ptop = pbl - ctl.conv_pbl_trans * (ps - pbl);
   }
   if (ctl.conv_cape >= 0) {
-    const double cape = time_2d(c, s, wt, MPHIP_CAPE);
-    const double cin = time_2d(c, s, wt, MPHIP_CIN);
-    const double pel = time_2d(c, s, wt, MPHIP_PEL);
+    SurfB b;
+    load_sfb(M.sfb, M, s, b);
+    const double cape = sfb_time_2d(b, s, wt, 0);
+    const double cin = sfb_time_2d(b, s, wt, 1);
+    const double pel = sfb_time_2d(b, s, wt, 2);
     if (isfinite(cape) && cape >= ctl.conv_cape && (ctl.conv_cin <= 0 || (isfinite(cin) && cin >= ctl.conv_cin)))
       ptop = dmin(ptop, pel);
   }
   if (ptop != pbot && P.p >= ptop) {
-    const double tbot = temperature_at(M, A, P.time, pbot, P.lon, P.lat, wc);
-    const double ttop = temperature_at(M, A, P.time, ptop, P.lon, P.lat, wc);
+    const double tbot = temperature_at(M, A, P.time, pbot, P.lon, P.lat);
+    const double ttop = temperature_at(M, A, P.time, ptop, P.lon, P.lat);
     const double rhobot = pbot / tbot;
     const double rhotop = ptop / ttop;
     const double rs = uniform01(ctr + g);
@@ -941,9 +986,8 @@ __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet 
 }
 
 // module_sedi, mptrac.c:5869-5882
-__device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Particle &P, double rp, double rhop,
-                                              WindCache &wc) {
-  const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat, wc);
+__device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Particle &P, double rp, double rhop) {
+  const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
   const double v_s = sedi(P.p, t, rp, rhop);
   P.p += dz2dp(v_s * P.dt / 1000., P.p);
 }

@@ -48,29 +48,29 @@ __device__ __forceinline__ void apply_loss(const mphip_ctl_t &ctl, const DevAtm 
 
 // module_wet_depo, mptrac.c:6170-6289
 __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
-                                         long long i, const Particle &P, WindCache &wc) {
+                                         long long i, const Particle &P) {
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
-  Corners2 c2;
-  load_corners2<2>(M, s, c2);
+  SurfB c2;
+  load_sfb(M.sfc, M, s, c2);
   const double wt = time_weight(M, P.time);
-  const double pct = time_2d(c2, s, wt, MPHIP_PCT);
+  const double pct = sfb_time_2d(c2, s, wt, 0);
   if (!isfinite(pct) || P.p <= pct)
     return;
-  const double pcb = time_2d(c2, s, wt, MPHIP_PCB);
-  const double cl = time_2d(c2, s, wt, MPHIP_CL);
+  const double pcb = sfb_time_2d(c2, s, wt, 1);
+  const double cl = sfb_time_2d(c2, s, wt, 2);
   const double Is = pow(1. / ctl.wet_depo_pre[0] * cl, 1. / ctl.wet_depo_pre[1]);
   if (Is < 0.01)
     return;
   stencil_3d(M, A, P.p, P.lon, P.lat, s);
-  Corners c;
-  load_corners(M.cloud, M, s, c);
-  const double lwc = time_3d(c, s, wt, 0);
-  const double rwc = time_3d(c, s, wt, 1);
-  const double iwc = time_3d(c, s, wt, 2);
-  const double swc = time_3d(c, s, wt, 3);
+  CloudCorners c;
+  load_cloud(M, s, c);
+  const double lwc = cloud_time_3d(c, s, wt, 0);
+  const double rwc = cloud_time_3d(c, s, wt, 1);
+  const double iwc = cloud_time_3d(c, s, wt, 2);
+  const double swc = cloud_time_3d(c, s, wt, 3);
   const bool inside = (lwc > 0 || rwc > 0 || iwc > 0 || swc > 0);
-  const double t = time_3d(wind_corners(M, s, wc), s, wt, 3);
+  const double t = temp_time_3d(M, s, wt);
 
   double lambda = 0;
   if (inside) {
@@ -110,18 +110,18 @@ __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M
 
 // module_dry_depo, mptrac.c:4753-4796
 __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
-                                         long long i, const Particle &P, WindCache &wc) {
+                                         long long i, const Particle &P) {
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
-  Corners2 c2;
-  load_corners2<1>(M, s, c2);
-  const double ps = time_2d(c2, s, time_weight(M, P.time), MPHIP_PS);
+  SurfA c2;
+  load_sfa(M, s, c2);
+  const double ps = sfa_time_2d(c2, s, time_weight(M, P.time), 0);
   if (P.p < ps - ctl.dry_depo_dp)
     return;
   const double dz = 1000. * (zfromp(ps - ctl.dry_depo_dp) - zfromp(ps));
   double v_dep;
   if (ctl.qnt_rp > 0 && ctl.qnt_rhop > 0) {   // "> 0" as the reference, mptrac.c:4769
-    const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat, wc);
+    const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
     v_dep = sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
   } else
     v_dep = ctl.dry_depo_vdep;
@@ -183,25 +183,23 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     // random numbers belong to the external slot (rs[3 * ip + k], mptrac.c:4645)
     const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) a.ext[i] : i));
 
-    WindCache wc;
-    wind_cache_reset(wc);
     if (mask & MPHIP_MOD_POSITION)
       position(M, A, P);
     if (mask & MPHIP_MOD_ADVECT)
-      advect(ctl, M, A, P, wc);
+      advect(ctl, M, A, P);
     if (mask & MPHIP_MOD_DIFF_TURB)
       diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g);
     if (mask & MPHIP_MOD_DIFF_MESO) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
-      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, wc);
+      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g);
       a.up[i] = up;
       a.vp[i] = vp;
       a.wp[i] = wp;
     }
     if (mask & MPHIP_MOD_CONVECTION)
-      convection(ctl, M, A, P, S.ctr_conv, g, wc);
+      convection(ctl, M, A, P, S.ctr_conv, g);
     if (mask & MPHIP_MOD_SEDI)
-      sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i], wc);
+      sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
     if (mask & MPHIP_MOD_POSITION2)
       position(M, A, P);
 
@@ -222,9 +220,9 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       apply_loss(ctl, a, i, aux, ctl.qnt_mloss_decay, 1. / tdec);
     }
     if (mask & MPHIP_MOD_WET_DEPO)
-      wet_depo(ctl, M, A, a, i, P, wc);
+      wet_depo(ctl, M, A, a, i, P);
     if (mask & MPHIP_MOD_DRY_DEPO)
-      dry_depo(ctl, M, A, a, i, P, wc);
+      dry_depo(ctl, M, A, a, i, P);
   }
 }
 
@@ -232,39 +230,53 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
 // packing of the two bracketing snapshots
 // ---------------------------------------------------------------------------
 
-struct PackSrc {
-  const float *f[2][4];   // [snapshot][component]; NULL -> zeros
+// One kernel builds every packed record from the per-slot staging copies
+// (NULL source = field not uploaded -> zeros).
+struct PackArgs {
+  const float *f3[2][MPHIP_N3D];   // [snapshot][field]
+  const float *f2[2][MPHIP_N2D];
+  float *wind, *temp;
+  f32x4 *cloud, *sfa, *sfb, *sfc;
+  size_t ncell, ncol;
 };
 
-__global__ void pack3d_kernel(f32x4 *__restrict__ out, PackSrc src, size_t ncell) {
-  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < ncell; i += (size_t) gridDim.x * blockDim.x) {
+__global__ void pack_kernel(PackArgs a) {
+  const size_t stride = (size_t) gridDim.x * blockDim.x;
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < a.ncell; i += stride) {
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-      f32x4 v;
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        v[k] = src.f[t][k] ? src.f[t][k][i] : 0.f;
-      out[2 * i + t] = v;
-    }
-  }
-}
-
-struct PackSrc2 {
-  const float *f[2][8];
-};
-
-__global__ void pack2d_kernel(f32x4 *__restrict__ out, PackSrc2 src, size_t ncol) {
-  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < ncol; i += (size_t) gridDim.x * blockDim.x) {
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
+      for (int k = 0; k < 3; k++)
+        a.wind[6 * i + 3 * t + k] = a.f3[t][MPHIP_U + k] ? a.f3[t][MPHIP_U + k][i] : 0.f;
+      a.temp[2 * i + t] = a.f3[t][MPHIP_T] ? a.f3[t][MPHIP_T][i] : 0.f;
+      if (a.cloud) {
         f32x4 v;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          v[k] = src.f[t][4 * h + k] ? src.f[t][4 * h + k][i] : 0.f;
-        out[4 * i + 2 * t + h] = v;
+          v[k] = a.f3[t][MPHIP_LWC + k] ? a.f3[t][MPHIP_LWC + k][i] : 0.f;
+        a.cloud[2 * i + t] = v;
       }
+    }
+  }
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < a.ncol; i += stride) {
+    f32x4 va;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      va[2 * t] = a.f2[t][MPHIP_PS] ? a.f2[t][MPHIP_PS][i] : 0.f;
+      va[2 * t + 1] = a.f2[t][MPHIP_PBL] ? a.f2[t][MPHIP_PBL][i] : 0.f;
+      f32x4 vb, vc;
+      vb[0] = a.f2[t][MPHIP_CAPE] ? a.f2[t][MPHIP_CAPE][i] : 0.f;
+      vb[1] = a.f2[t][MPHIP_CIN] ? a.f2[t][MPHIP_CIN][i] : 0.f;
+      vb[2] = a.f2[t][MPHIP_PEL] ? a.f2[t][MPHIP_PEL][i] : 0.f;
+      vb[3] = 0.f;
+      vc[0] = a.f2[t][MPHIP_PCT] ? a.f2[t][MPHIP_PCT][i] : 0.f;
+      vc[1] = a.f2[t][MPHIP_PCB] ? a.f2[t][MPHIP_PCB][i] : 0.f;
+      vc[2] = a.f2[t][MPHIP_CL] ? a.f2[t][MPHIP_CL][i] : 0.f;
+      vc[3] = 0.f;
+      a.sfb[2 * i + t] = vb;
+      a.sfc[2 * i + t] = vc;
+    }
+    a.sfa[i] = va;
   }
 }
 
@@ -571,90 +583,6 @@ __global__ void grid_accumulate_kernel(DevAtm a, const int *__restrict__ cell, i
         unsafeAtomicAdd(&buf[(size_t) (1 + nq + iq) * ncell + c], v * v);
       }
     }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// gather micro-benchmark: the wind stencil of every particle, fetched either
-// lane-by-lane (mode 0: each lane issues the 16 x 16-byte loads of its own four
-// columns) or quad-cooperatively (mode 1: four adjacent lanes fetch the four
-// 16-byte pieces of one 64-byte column record, records are exchanged through
-// LDS).  Used to decide the load scheme of the step kernel.
-// ---------------------------------------------------------------------------
-
-constexpr int kXchgStride = 20;   // dwords per particle record in LDS (80 B: conflict-free b128 reads)
-
-// LDS per wave: 64 x 16 B column offsets + 64 x 80 B records
-constexpr int kXchgBytesPerWave = 64 * 16 + 64 * kXchgStride * 4;
-
-__device__ __forceinline__ void coop_fetch(const f32x4 *__restrict__ g, const DevMet &M, const Stencil &s,
-                                           char *wave_lds, Corners &c) {
-  const int lane = threadIdx.x & 63;
-  unsigned *offs = (unsigned *) wave_lds;               // [64][4] record indices (f32x4 units)
-  float *rec = (float *) (wave_lds + 64 * 16);          // [64][kXchgStride]
-  {
-    uint4 o;
-    const size_t base = ((size_t) s.ix * (size_t) M.ny + (size_t) s.iy) * (size_t) M.np + (size_t) s.ip;
-    o.x = (unsigned) (2 * base);
-    o.y = (unsigned) (2 * (base + (size_t) M.np));
-    o.z = (unsigned) (2 * (base + (size_t) M.ny * (size_t) M.np));
-    o.w = (unsigned) (2 * (base + (size_t) M.ny * (size_t) M.np + (size_t) M.np));
-    *(uint4 *) (offs + 4 * lane) = o;
-  }
-  const int piece = lane & 3, sub = lane >> 2;
-#pragma unroll
-  for (int col = 0; col < 4; col++) {
-    f32x4 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int p = 16 * k + sub;
-      v[k] = g[(size_t) offs[4 * p + col] + piece];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int p = 16 * k + sub;
-      *(f32x4 *) (rec + p * kXchgStride + 4 * piece) = v[k];
-    }
-    const f32x4 *mine = (const f32x4 *) (rec + lane * kXchgStride);
-    const int di = col >> 1, dj = col & 1;
-    c.lo[di][dj][0] = mine[0];
-    c.lo[di][dj][1] = mine[1];
-    c.hi[di][dj][0] = mine[2];
-    c.hi[di][dj][1] = mine[3];
-  }
-}
-
-__global__ __launch_bounds__(256) void test_gather_kernel(DevMet M, DevAtm a, int mode, int reps, int nblocks_logical,
-                                                          double *__restrict__ out) {
-  extern __shared__ double s_axes[];
-  const Axes A = load_axes(M, s_axes);
-  char *xchg = (char *) s_axes + (((axes_doubles(M) * 8 + (size_t) M.lut_size * 2) + 15) & ~(size_t) 15);
-  char *wave_lds = xchg + (threadIdx.x >> 6) * kXchgBytesPerWave;
-  __syncthreads();
-  const int nb = nblocks_logical;
-  const int lb = (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8);
-  const long long per_block = (((a.np + nb - 1) / nb) + 63) & ~63LL;
-  const long long first = (long long) lb * per_block;
-  const long long last = first + per_block;
-  for (long long i0 = first; i0 < last; i0 += blockDim.x) {
-    long long i = i0 + threadIdx.x;
-    const bool live = i < a.np && i < last;
-    if (!live)
-      i = a.np - 1;        // keep whole waves active for the cooperative scheme
-    Stencil s;
-    stencil_3d(M, A, a.p[i], a.lon[i], a.lat[i], s);
-    double acc = 0;
-    for (int r = 0; r < reps; r++) {
-      Corners c;
-      if (mode == 0)
-        load_corners(M.wind, M, s, c);
-      else
-        coop_fetch(M.wind, M, s, wave_lds, c);
-      acc += time_3d(c, s, 0.25 + r, 0) + time_3d(c, s, 0.5, 1) + time_3d(c, s, 0.75, 2);
-      s.ip = (s.ip + 1 < M.np - 1) ? s.ip + (r & 1) : s.ip;     // move a level now and then
-    }
-    if (live)
-      out[i] = acc;
   }
 }
 

@@ -83,7 +83,6 @@ def load(build=True):
     L.mphip_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), _dp]
     L.mphip_test_sincosf.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _fp, _fp]
     L.mphip_test_rng.argtypes = [C.c_void_p, C.c_uint64, C.c_longlong, C.c_int, _dp]
-    L.mphip_test_gather.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp]
     if L.mphip_sizeof_ctl() != C.sizeof(MphipCtl):
         raise MphipError("mphip_ctl_t layout mismatch between header and Python mirror")
     if L.mphip_sizeof_met() != C.sizeof(MphipMet):
@@ -288,12 +287,6 @@ class Simulation:
         s = np.empty(count, dtype=np.float32)
         self._chk(self.L.mphip_test_sincosf(self.h, first_bits, count, _ptr(c, _fp), _ptr(s, _fp)))
         return c, s
-
-    def test_gather(self, mode, reps):
-        ms = C.c_double()
-        chk = C.c_double()
-        self._chk(self.L.mphip_test_gather(self.h, mode, reps, C.byref(ms), C.byref(chk)))
-        return ms.value, chk.value
 
     def test_rng(self, ctr, n, method):
         out = np.empty(n)

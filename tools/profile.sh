@@ -21,10 +21,10 @@ pmc() {  # name, counters...
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 # calibration of FETCH_SIZE / WRITE_SIZE on a kernel with a known byte count:
-# pack3d_kernel reads 32 B and writes 32 B per grid point, fully coalesced
+# pack_kernel reads 32 B and writes 32 B per grid point, fully coalesced
 calib() {
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "pack3d_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "pack_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
 }
 calib calib_fetch FETCH_SIZE
 calib calib_write WRITE_SIZE

@@ -32,7 +32,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "**/*counter_collection.csv"), recursive=True):
         acc = defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "step_kernel" in r.get("Kernel_Name", "") or "pack3d" in r.get("Kernel_Name", ""):
+            if "step_kernel" in r.get("Kernel_Name", "") or "pack_kernel" in r.get("Kernel_Name", ""):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         out.append(f"== PMC {os.path.basename(d)} (step_kernel dispatches, per-dispatch mean) ==")
         for k, v in sorted(acc.items()):
@@ -41,7 +41,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
 print("\n".join(out))
 
 # HBM traffic of the step kernel per launch (MI355X_MICROARCH.md, HBM section):
-# FETCH_SIZE / WRITE_SIZE are in KiB; calibrate on pack3d_kernel (known bytes).
+# FETCH_SIZE / WRITE_SIZE are in KiB; calibrate on pack_kernel (known bytes).
 def one(d, name):
     for f in glob.glob(os.path.join(src, d, "**/*counter_collection.csv"), recursive=True):
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name]
