@@ -48,6 +48,21 @@ def make_allreduce_hook(device_kind):
             t = torch.as_tensor(_DeviceBuffer(ptr, count), device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()
+    elif device_kind == "cuda_staged":
+        # device buffer, host collective (gloo): lets several ranks share one
+        # GPU in tests, which RCCL does not allow
+        import numpy as np
+        hiprt = ctypes.CDLL("libamdhip64.so")
+        hiprt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+        def hook(ptr, count):
+            host = np.empty(count, dtype=np.float64)
+            if hiprt.hipMemcpy(host.ctypes.data, ctypes.c_void_p(int(ptr)), count * 8, 2):   # device -> host
+                raise RuntimeError("hipMemcpy D2H failed")
+            t = torch.from_numpy(host)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if hiprt.hipMemcpy(ctypes.c_void_p(int(ptr)), host.ctypes.data, count * 8, 1):   # host -> device
+                raise RuntimeError("hipMemcpy H2D failed")
     else:
         import numpy as np
 
