@@ -451,3 +451,32 @@ def test_locality_order_is_not_observable(case):
             assert np.array_equal(runs[name][k], runs["off"][k]), (name, k)
         assert cases.rel_err(runs[name]["q"], runs["off"]["q"]) <= tol_q
         assert runs[name]["ctr"] == runs["off"]["ctr"]
+
+
+def test_cartesian_coordinates():
+    """MET_COORD_TYPE 1 (x/y in metres, e.g. UTM): DX2COORD/DY2COORD pass
+    distances through, positions are clamped to the domain, the tropopause
+    weight uses MET_UTM_REF_LAT (mptrac.h:966-989, mptrac.c:2782-2803, 12755)."""
+    from mptrac_amd.synth import Met
+    ctl, clim, g0, g1, atm = cases.make_case("conv_sedi", n=4000, grid="tiny")
+
+    def cart(m):
+        x = 600000.0 + 2000.0 * np.arange(m.nx)          # 2 km mesh
+        y = 5200000.0 + 2500.0 * np.arange(m.ny)
+        return Met(m.time, x, y, m.p, m.f3, m.f2, coord_type=1)
+    m0, m1 = cart(g0), cart(g1)
+    rng = np.random.default_rng(7)
+    atm["lon"] = 600000.0 + rng.uniform(-3000.0, 2000.0 * (m0.nx - 1) + 3000.0, 4000)   # some outside: clamped
+    atm["lat"] = 5200000.0 + rng.uniform(-3000.0, 2500.0 * (m0.ny - 1) + 3000.0, 4000)
+    ctl.update(met_coord_type=1, met_utm_ref_lat=48.15, dt_mod=60.0, t_stop=1200.0)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    for t in cases.step_times(o.ctl):
+        o.run_timestep(t)
+        s.run_timestep(t)
+    moved = o.time > 0                       # particles outside the regional domain keep dt = 0
+    assert 0 < moved.sum() < len(moved) and np.ptp(o.lon[moved]) > 1e4
+    _compare(o, s)
+    s.close()
