@@ -32,7 +32,9 @@ extern "C" {
 #define MPHIP_NQ_MAX 16
 
 /* 3-D meteo fields (met_t, mptrac.h:3962-4012), float [ix][iy][ip] */
-enum { MPHIP_U = 0, MPHIP_V, MPHIP_W, MPHIP_T, MPHIP_LWC, MPHIP_RWC, MPHIP_IWC, MPHIP_SWC, MPHIP_N3D };
+enum { MPHIP_U = 0, MPHIP_V, MPHIP_W, MPHIP_T, MPHIP_LWC, MPHIP_RWC, MPHIP_IWC, MPHIP_SWC,
+       /* model-level fields (met_t pl, ul, vl, zetal, zeta_dotl; mptrac.h:3997-4012), float [ix][iy][npl] */
+       MPHIP_PL, MPHIP_UL, MPHIP_VL, MPHIP_ZETAL, MPHIP_ZETA_DOTL, MPHIP_N3D };
 /* 2-D meteo fields (met_t, mptrac.h:3886-3958), float [ix][iy] */
 enum { MPHIP_PS = 0, MPHIP_PBL, MPHIP_CAPE, MPHIP_CIN, MPHIP_PEL, MPHIP_PCT, MPHIP_PCB, MPHIP_CL, MPHIP_N2D };
 
@@ -51,6 +53,7 @@ enum {
   MPHIP_MOD_DECAY      = 1 << 9,   /* module_decay       mptrac.c:4227 */
   MPHIP_MOD_WET_DEPO   = 1 << 10,  /* module_wet_depo    mptrac.c:6155 */
   MPHIP_MOD_DRY_DEPO   = 1 << 11,  /* module_dry_depo    mptrac.c:4738 */
+  MPHIP_MOD_ADVECT_INIT = 1 << 12, /* module_advect_init mptrac.c:3762 (not guarded by dt) */
   MPHIP_MOD_SORT       = 1 << 16,  /* module_sort        mptrac.c:5887 (own kernels) */
   MPHIP_MOD_MIXING     = 1 << 17   /* module_mixing      mptrac.c:5169 (own kernels) */
 };
@@ -66,6 +69,7 @@ typedef struct {
   int nq;
   int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens;
   int qnt_loss_rate, qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry;
+  int qnt_zeta, qnt_eta;
   int nens;
   int advect;
   int advect_vert_coord;
@@ -102,8 +106,10 @@ typedef struct {
   double time;
   int coord_type;
   int nx, ny, np;
+  int npl;                 /* number of model levels of the MPHIP_PL ... fields (0 = none) */
   const double *lon, *lat, *p;
   long long sx, sy, sx2;
+  long long sx_ml, sy_ml;  /* strides of the model-level arrays (same as sx, sy for met_t's [EX][EY][EP]) */
   const float *f3[MPHIP_N3D];
   const float *f2[MPHIP_N2D];
 } mphip_met_t;

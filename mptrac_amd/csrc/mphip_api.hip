@@ -21,7 +21,7 @@ constexpr unsigned kAdvTurb = kAdv | MPHIP_MOD_DIFF_TURB;
 constexpr unsigned kAdvDiff = kAdvTurb | MPHIP_MOD_DIFF_MESO;
 constexpr unsigned kAdvTurbConvSedi = kAdvTurb | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kAdvDiffConvSedi = kAdvDiff | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
-constexpr unsigned kParticleBits = 0xfffu;
+constexpr unsigned kParticleBits = 0x1fffu;
 
 struct MetSlot {
   bool valid = false;
@@ -47,7 +47,9 @@ struct mphip_ctx {
   // meteo
   MetSlot slot[2];
   int flip = 0;                       // logical slot s lives in slot[s ^ flip]
-  int nx = 0, ny = 0, npl = 0, coord_type = 0;
+  int nx = 0, ny = 0, npl = 0, coord_type = 0;   // npl: pressure levels (met_t::np)
+  int nml = 0;                                    // model levels (met_t::npl), 0 = none uploaded
+  float *d_mlw = nullptr;
   std::vector<double> h_lon, h_lat, h_p;
   double *d_axes = nullptr;           // axes blob (layout: DevMet::axes)
   int lut_base = 0, lut_size = 0;
@@ -164,6 +166,12 @@ DevMet dev_met(const mphip_ctx *c) {
   M.sfa = c->d_sfa;
   M.sfb = c->d_sfb;
   M.sfc = c->d_sfc;
+  M.mlw = c->d_mlw;
+  for (int t = 0; t < 2; t++) {
+    M.zl[t] = c->slot[t ^ c->flip].f3[MPHIP_ZETAL];
+    M.pll[t] = c->slot[t ^ c->flip].f3[MPHIP_PL];
+  }
+  M.npl = c->nml;
   M.axes = c->d_axes;
   M.lut_base = c->lut_base;
   M.lut_size = c->lut_size;
@@ -278,7 +286,7 @@ int ensure_packed(mphip_ctx *ctx) {
     return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
   const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
   PackArgs a;
-  bool any_cloud = false;
+  bool any_cloud = false, any_ml = false;
   const MetSlot *ss[2] = { &s0, &s1 };
   for (int t = 0; t < 2; t++) {
     for (int f = 0; f < MPHIP_N3D; f++)
@@ -287,7 +295,12 @@ int ensure_packed(mphip_ctx *ctx) {
       a.f2[t][f] = ss[t]->has2[f] ? ss[t]->f2[f] : nullptr;
     for (int f = MPHIP_LWC; f <= MPHIP_SWC; f++)
       any_cloud = any_cloud || ss[t]->has3[f];
+    any_ml = any_ml || ss[t]->has3[MPHIP_UL] || ss[t]->has3[MPHIP_VL] || ss[t]->has3[MPHIP_ZETA_DOTL];
   }
+  const size_t ncell_ml = (size_t) ctx->nx * ctx->ny * ctx->nml;
+  any_ml = any_ml && ncell_ml > 0;
+  if (any_ml && !ctx->d_mlw && dev_alloc(ctx, &ctx->d_mlw, 6 * ncell_ml))
+    return 1;
   if (!ctx->d_wind && (dev_alloc(ctx, &ctx->d_wind, 6 * ncell) || dev_alloc(ctx, &ctx->d_temp, 2 * ncell)))
     return 1;
   if (!ctx->d_sfa && (dev_alloc(ctx, &ctx->d_sfa, ncol) || dev_alloc(ctx, &ctx->d_sfb, 2 * ncol)
@@ -301,8 +314,10 @@ int ensure_packed(mphip_ctx *ctx) {
   a.sfa = ctx->d_sfa;
   a.sfb = ctx->d_sfb;
   a.sfc = ctx->d_sfc;
+  a.mlw = any_ml ? ctx->d_mlw : nullptr;
   a.ncell = ncell;
   a.ncol = ncol;
+  a.ncell_ml = ncell_ml;
   hipLaunchKernelGGL(pack_kernel, dim3(grid_for((long long) ncell)), dim3(256), 0, ctx->stream, a);
   HIPCHK(hipGetLastError());
   ctx->packed_dirty = false;
@@ -329,9 +344,18 @@ int check_fields(mphip_ctx *ctx, unsigned mask) {
   if (mask & (MPHIP_MOD_POSITION | MPHIP_MOD_POSITION2))
     if (need2(MPHIP_PS, "module_position"))
       return 1;
-  if (mask & (MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_MESO))
+  const bool model_levels = (c.advect_vert_coord == 1 || c.advect_vert_coord == 3);
+  if ((mask & MPHIP_MOD_DIFF_MESO) || ((mask & MPHIP_MOD_ADVECT) && !model_levels))
     if (need3(MPHIP_U, "module_advect") || need3(MPHIP_V, "module_advect") || need3(MPHIP_W, "module_advect"))
       return 1;
+  if (((mask & MPHIP_MOD_ADVECT) && model_levels) || (mask & MPHIP_MOD_ADVECT_INIT)) {
+    if (need3(MPHIP_PL, "module_advect") || need3(MPHIP_ZETAL, "module_advect")
+        || need3(MPHIP_UL, "module_advect") || need3(MPHIP_VL, "module_advect")
+        || need3(MPHIP_ZETA_DOTL, "module_advect") || ctx->nml < 2)
+      return 1;
+    if ((c.advect_vert_coord == 3 ? c.qnt_eta : c.qnt_zeta) < 0)
+      return fail(ctx, "model-level advection needs quantity zeta (ADVECT_VERT_COORD 1) or eta (3)");
+  }
   if (mask & MPHIP_MOD_DIFF_TURB)
     if (need2(MPHIP_PS, "module_diff_turb") || need2(MPHIP_PBL, "module_diff_turb"))
       return 1;
@@ -401,7 +425,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     e1 = ctx->ev[ctx->ev_used++];
     HIPCHK(hipEventRecord(e0, ctx->stream));
   }
-  const unsigned sel = (ctx->ctl.advect == 4) ? mask : kMaskGeneric;   // specialisations are built for RK4
+  const bool ml_ = (ctx->ctl.advect_vert_coord == 1 || ctx->ctl.advect_vert_coord == 3);
+  const unsigned sel = (ctx->ctl.advect == 4 && !ml_) ? mask : kMaskGeneric;   // specialisations: RK4, pressure levels
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
   case M:                                                                                             \
@@ -679,6 +704,7 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_sfa);
   dev_free(ctx->d_sfb);
   dev_free(ctx->d_sfc);
+  dev_free(ctx->d_mlw);
   for (auto p : ctx->d_arr)
     dev_free(p);
   for (auto p : ctx->d_alt)
@@ -715,8 +741,8 @@ int mphip_update_ctl(mphip_ctx *ctx, const mphip_ctl_t *ctl) {
     return fail(ctx, "nq out of range");
   if (ctl->rng_type != 1)
     return fail(ctx, "only RNG_TYPE 1 (Squares) is implemented on the device");
-  if (ctl->advect_vert_coord != 0)
-    return fail(ctx, "only ADVECT_VERT_COORD 0 (pressure levels) is implemented on the device");
+  if (ctl->advect_vert_coord < 0 || ctl->advect_vert_coord > 3)
+    return fail(ctx, "Set ADVECT_VERT_COORD to 0, 1, 2, or 3!");
   if (!(ctl->advect == 0 || ctl->advect == 1 || ctl->advect == 2 || ctl->advect == 4))
     return fail(ctx, "Set ADVECT to 1, 2, or 4!");
   ctx->ctl = *ctl;
@@ -756,7 +782,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
   if (met->nx < 2 || met->ny < 2 || met->np < 2 || !met->lon || !met->lat || !met->p)
     return fail(ctx, "meteo grid dimensions out of range");
   HIPCHK(hipSetDevice(ctx->device));
-  const bool new_grid = (met->nx != ctx->nx || met->ny != ctx->ny || met->np != ctx->npl);
+  const int nml = met->npl > 0 ? met->npl : 0;
+  const bool new_grid = (met->nx != ctx->nx || met->ny != ctx->ny || met->np != ctx->npl || nml != ctx->nml);
   if (new_grid) {
     if (ctx->slot[0].valid || ctx->slot[1].valid) {
       // mptrac_get_met: "Meteo grid dimensions do not match!" (mptrac.c:6543-6546)
@@ -766,6 +793,9 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     ctx->nx = met->nx;
     ctx->ny = met->ny;
     ctx->npl = met->np;
+    ctx->nml = nml;
+    dev_free(ctx->d_mlw);
+    ctx->d_mlw = nullptr;
     dev_free(ctx->d_wind);
     dev_free(ctx->d_temp);
     dev_free(ctx->d_cloud);
@@ -786,25 +816,28 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
   }
   MetSlot &S = ctx->slot[slot ^ ctx->flip];
   const size_t ncell = (size_t) met->nx * met->ny * met->np, ncol = (size_t) met->nx * met->ny;
-  const bool compact3 = (met->sy == met->np && met->sx == (long long) met->ny * met->np);
   for (int f = 0; f < MPHIP_N3D; f++) {
-    S.has3[f] = met->f3[f] != nullptr;
+    const bool is_ml = f >= MPHIP_PL;
+    const long long nlev = is_ml ? nml : met->np;
+    const long long sx = is_ml ? met->sx_ml : met->sx, sy = is_ml ? met->sy_ml : met->sy;
+    S.has3[f] = met->f3[f] != nullptr && nlev > 0;
     if (!S.has3[f])
       continue;
+    const size_t n3 = (size_t) met->nx * met->ny * (size_t) nlev;
     if (new_grid || !S.f3[f])
-      if (dev_alloc(ctx, &S.f3[f], ncell))
+      if (dev_alloc(ctx, &S.f3[f], n3))
         return 1;
-    if (compact3) {
-      HIPCHK(hipMemcpyAsync(S.f3[f], met->f3[f], ncell * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (sy == nlev && sx == (long long) met->ny * nlev) {
+      HIPCHK(hipMemcpyAsync(S.f3[f], met->f3[f], n3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     } else {
-      if (met->sy < met->np || met->sx < met->sy * met->ny || met->sx % met->sy != 0)
+      if (sy < nlev || sx < sy * met->ny || sx % sy != 0)
         return fail(ctx, "unsupported 3-D meteo strides");
       hipMemcpy3DParms p;
       memset(&p, 0, sizeof(p));
-      p.srcPtr = make_hipPitchedPtr((void *) met->f3[f], (size_t) met->sy * sizeof(float), (size_t) met->np,
-                                    (size_t) (met->sx / met->sy));
-      p.dstPtr = make_hipPitchedPtr(S.f3[f], (size_t) met->np * sizeof(float), (size_t) met->np, (size_t) met->ny);
-      p.extent = make_hipExtent((size_t) met->np * sizeof(float), (size_t) met->ny, (size_t) met->nx);
+      p.srcPtr = make_hipPitchedPtr((void *) met->f3[f], (size_t) sy * sizeof(float), (size_t) nlev,
+                                    (size_t) (sx / sy));
+      p.dstPtr = make_hipPitchedPtr(S.f3[f], (size_t) nlev * sizeof(float), (size_t) nlev, (size_t) met->ny);
+      p.extent = make_hipExtent((size_t) nlev * sizeof(float), (size_t) met->ny, (size_t) met->nx);
       p.kind = hipMemcpyHostToDevice;
       HIPCHK(hipMemcpy3DAsync(&p, ctx->stream));
     }
@@ -962,6 +995,11 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   const mphip_ctl_t &c = ctx->ctl;
   const uint64_t n = (uint64_t) ctx->np_total;
   unsigned mask = MPHIP_MOD_TIMESTEPS;
+
+  // module_advect_init at the first call (mptrac.c:7863-7870)
+  if (t == c.t_start && c.advect_vert_coord == 1)
+    if (launch_step(ctx, MPHIP_MOD_ADVECT_INIT, t, 0, 0, 0))
+      return 1;
 
   // module_timesteps + module_sort (mptrac.c:7877-7881).  The reference
   // permutes atm but not cache->dt, so on sort steps dt is computed per slot

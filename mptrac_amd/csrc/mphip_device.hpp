@@ -45,6 +45,10 @@ struct DevMet {
   const f32x4 *sfa;      // [col]
   const f32x4 *sfb;      // [col][2]
   const f32x4 *sfc;      // [col][2]
+  const float *mlw;      // [cellL][6] {ul,vl,zeta_dot}0 {..}1 on model levels (optional)
+  const float *zl[2];    // zetal of met0 / met1, [nx][ny][npl]
+  const float *pll[2];   // pl of met0 / met1
+  int npl;
   // axes blob in global memory, copied to LDS by every workgroup:
   //   double lon[nx], lat[ny], p[np], 1/dlon[nx], 1/dlat[ny], 1/dp[np]; int16 p_lut[lut_size]
   const double *axes;
@@ -545,6 +549,158 @@ __device__ __forceinline__ double sfb_time_2d(const SurfB &c, const Stencil &s, 
   return blend_time_2d(v0, v1, wt);
 }
 
+// ---- model-level interpolation (mptrac.c:2808-2981, 3525-3594) -------------
+
+struct Stencil4 {   // ci[3], cw[4] of intpol_met_4d_zeta
+  int ix, iy, iz;
+  double wx, wy, wz, wt;
+};
+
+// locate_irr_float, mptrac.c:3525-3555
+__device__ __forceinline__ int locate_irr_float(const float *__restrict__ xx, int n, double x, int ig) {
+  if ((xx[ig] <= x && x < xx[ig + 1]) || (xx[ig] >= x && x > xx[ig + 1]))
+    return ig;
+  int lo = 0, hi = n - 1;
+  const int mid0 = (hi + lo) >> 1;
+  if (xx[mid0] < xx[mid0 + 1]) {
+    while (hi > lo + 1) {
+      const int mid = (hi + lo) >> 1;
+      if (xx[mid] > x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  } else {
+    while (hi > lo + 1) {
+      const int mid = (hi + lo) >> 1;
+      if (xx[mid] <= x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  }
+  return lo;
+}
+
+__device__ __forceinline__ size_t col_ml(const DevMet &M, int ix, int iy) {
+  return ((size_t) ix * (size_t) M.ny + (size_t) iy) * (size_t) M.npl;
+}
+
+// time-then-horizontal interpolation of a model-level field pair at level k
+__device__ __forceinline__ double level_value(const DevMet &M, const float *__restrict__ h0,
+                                              const float *__restrict__ h1, const Stencil4 &s, int k) {
+  const size_t c00 = col_ml(M, s.ix, s.iy) + k, c01 = col_ml(M, s.ix, s.iy + 1) + k;
+  const size_t c10 = col_ml(M, s.ix + 1, s.iy) + k, c11 = col_ml(M, s.ix + 1, s.iy + 1) + k;
+  const double v00 = s.wt * (double) (h1[c00] - h0[c00]) + (double) h0[c00];
+  const double v01 = s.wt * (double) (h1[c01] - h0[c01]) + (double) h0[c01];
+  const double v10 = s.wt * (double) (h1[c10] - h0[c10]) + (double) h0[c10];
+  const double v11 = s.wt * (double) (h1[c11] - h0[c11]) + (double) h0[c11];
+  const double a = s.wy * (v01 - v00) + v00;
+  const double b = s.wy * (v11 - v10) + v10;
+  return s.wx * (b - a) + a;
+}
+
+// index/weight set-up of intpol_met_4d_zeta (mptrac.c:2824-2943) with the
+// height field (h0, h1) = zetal or pl of the two snapshots
+__device__ __forceinline__ void stencil_4d(const DevMet &M, const Axes &A, const float *__restrict__ h0,
+                                           const float *__restrict__ h1, double ts, double height, double lon,
+                                           double lat, Stencil4 &s) {
+  double lon2, lat2;
+  check_horizontal(M, A, lon, lat, lon2, lat2);
+  const AxisHit hy = hit_lat(M, A, lat2);
+  s.ix = locate_lon(M, A, lon2);
+  s.iy = hy.i;
+  // locate_vert on both snapshots (mptrac.c:3578-3594), guesses chained as in the reference
+  int kmin = 0, kmax = 0;
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const float *h = t ? h1 : h0;
+    const int i0 = locate_irr_float(h + col_ml(M, s.ix, s.iy), M.npl, height, 0);
+    const int i1 = locate_irr_float(h + col_ml(M, s.ix + 1, s.iy), M.npl, height, i0);
+    const int i2 = locate_irr_float(h + col_ml(M, s.ix, s.iy + 1), M.npl, height, i1);
+    const int i3 = locate_irr_float(h + col_ml(M, s.ix + 1, s.iy + 1), M.npl, height, i2);
+    const int lo = min(min(i0, i1), min(i2, i3)), hi = max(max(i0, i1), max(i2, i3));
+    kmin = t ? min(kmin, lo) : lo;
+    kmax = t ? max(kmax, hi) : hi;
+  }
+  s.iz = kmin;
+  s.wt = div_const(ts - M.time0, M.time1 - M.time0, M.inv_dtime);
+  s.wx = div_const(lon2 - A.lon[s.ix], A.lon[s.ix + 1] - A.lon[s.ix], A.inv_lon[s.ix]);
+  s.wy = div_const(lat2 - hy.x0, hy.x1 - hy.x0, hy.inv);
+  double bot = level_value(M, h0, h1, s, s.iz);
+  double top = level_value(M, h0, h1, s, s.iz + 1);
+  const float g0 = h0[0], g1 = h0[1];   // heights0[0][0][0], heights0[0][0][1]
+  while (((g0 > g1) && ((bot <= height) || (top > height)) && (bot >= height) && (s.iz < kmax))
+         || ((g0 < g1) && ((bot >= height) || (top < height)) && (bot <= height) && (s.iz < kmax))) {
+    s.iz++;
+    bot = top;
+    top = level_value(M, h0, h1, s, s.iz + 1);
+  }
+  s.wz = (height - bot) / (top - bot);
+}
+
+// value part of intpol_met_4d_zeta (mptrac.c:2945-2980): time, longitude,
+// latitude, vertical -- for one of the packed components {ul, vl, zeta_dot}
+__device__ __forceinline__ double ml_combine(const Stencil4 &s, double a000, double a100, double a010, double a110,
+                                             double a001, double a101, double a011, double a111) {
+  const double a00 = s.wx * (a100 - a000) + a000;
+  const double a10 = s.wx * (a110 - a010) + a010;
+  const double a01 = s.wx * (a101 - a001) + a001;
+  const double a11 = s.wx * (a111 - a011) + a011;
+  const double lo = s.wy * (a10 - a00) + a00;
+  const double hi = s.wy * (a11 - a01) + a01;
+  return s.wz * (hi - lo) + lo;
+}
+
+struct MlCorners {
+  f32x4u r[2][2][3];   // as WindCorners: level iz {ul,vl,zd}0{..}1, level iz+1 {..}
+};
+
+__device__ __forceinline__ void load_ml(const DevMet &M, const Stencil4 &s, MlCorners &c) {
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++) {
+      const f32x4u *q = (const f32x4u *) (M.mlw + 6 * (col_ml(M, s.ix + di, s.iy + dj) + s.iz));
+      c.r[di][dj][0] = q[0];
+      c.r[di][dj][1] = q[1];
+      c.r[di][dj][2] = q[2];
+    }
+}
+
+__device__ __forceinline__ double ml_packed(const MlCorners &c, const Stencil4 &s, int k) {
+  double v[2][2][2];   // [di][dj][level], time-interpolated
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        const int e0 = 6 * l + k, e1 = 6 * l + 3 + k;
+        const float a0 = c.r[di][dj][e0 >> 2][e0 & 3], a1 = c.r[di][dj][e1 >> 2][e1 & 3];
+        v[di][dj][l] = s.wt * (double) (a1 - a0) + (double) a0;
+      }
+  return ml_combine(s, v[0][0][0], v[1][0][0], v[0][1][0], v[1][1][0], v[0][0][1], v[1][0][1], v[0][1][1],
+                    v[1][1][1]);
+}
+
+// the same for a plain model-level field pair (zetal or pl used as the array)
+__device__ __forceinline__ double ml_field(const DevMet &M, const float *__restrict__ a0,
+                                           const float *__restrict__ a1, const Stencil4 &s) {
+  double v[2][2][2];
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        const size_t c = col_ml(M, s.ix + di, s.iy + dj) + s.iz + l;
+        v[di][dj][l] = s.wt * (double) (a1[c] - a0[c]) + (double) a0[c];
+      }
+  return ml_combine(s, v[0][0][0], v[1][0][0], v[0][1][0], v[1][1][0], v[0][0][1], v[1][0][1], v[0][1][1],
+                    v[1][1][1]);
+}
+
 // ---- climatological tropopause and weights --------------------------------
 
 // clim_tropo, mptrac.c:213-237
@@ -817,6 +973,71 @@ __device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, 
     advect_n<2>(M, A, P);
   else
     advect_n<1>(M, A, P);
+}
+
+// module_advect, zeta / eta branch (mptrac.c:3681-3757); zeta is the particle's
+// vertical-coordinate quantity q[qnt_zeta | qnt_eta]
+template <int ADVECT>
+__device__ __forceinline__ void advect_ml_n(const DevMet &M, const Axes &A, Particle &P, double &zeta) {
+  const int ct = M.coord_type;
+  const double dt = P.dt;
+  Stencil4 s;
+  stencil_4d(M, A, M.pll[0], M.pll[1], P.time, P.p, P.lon, P.lat, s);
+  zeta = ml_field(M, M.zl[0], M.zl[1], s);
+  double u = 0, v = 0, wdot = 0, um = 0, vm = 0, wdotm = 0, x0 = 0, x1 = 0, x2 = 0;
+#pragma unroll
+  for (int i = 0; i < ADVECT; i++) {
+    double dts;
+    if (i == 0) {
+      dts = 0.0;
+      x0 = P.lon;
+      x1 = P.lat;
+      x2 = zeta;
+    } else {
+      dts = (i == 3 ? 1.0 : 0.5) * dt;
+      x0 = P.lon + dx2coord(ct, dts * u, P.lat);
+      x1 = P.lat + dy2coord(ct, dts * v);
+      x2 = zeta + dts * wdot;
+    }
+    stencil_4d(M, A, M.zl[0], M.zl[1], P.time + dts, x2, x0, x1, s);
+    MlCorners c;
+    load_ml(M, s, c);
+    u = ml_packed(c, s, 0);
+    v = ml_packed(c, s, 1);
+    wdot = ml_packed(c, s, 2);
+    double k = 1.0;
+    if (ADVECT == 2)
+      k = (i == 0 ? 0.0 : 1.0);
+    else if (ADVECT == 4)
+      k = (i == 0 || i == 3 ? 1.0 / 6.0 : 2.0 / 6.0);
+    um += k * u;
+    vm += k * v;
+    wdotm += k * wdot;
+  }
+  P.time += dt;
+  P.lon += dx2coord(ct, dt * um, (ADVECT == 2 ? x1 : P.lat));
+  P.lat += dy2coord(ct, dt * vm);
+  zeta += dt * wdotm;
+  stencil_4d(M, A, M.zl[0], M.zl[1], P.time, zeta, P.lon, P.lat, s);
+  P.p = ml_field(M, M.pll[0], M.pll[1], s);
+}
+
+__device__ __forceinline__ void advect_ml(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                          double &zeta) {
+  if (ctl.advect == 4)
+    advect_ml_n<4>(M, A, P, zeta);
+  else if (ctl.advect == 2)
+    advect_ml_n<2>(M, A, P, zeta);
+  else
+    advect_ml_n<1>(M, A, P, zeta);
+}
+
+// module_advect_init, mptrac.c:3777-3784: pressure consistent with zeta
+__device__ __forceinline__ double pressure_from_zeta(const DevMet &M, const Axes &A, double time, double zeta,
+                                                     double lon, double lat) {
+  Stencil4 s;
+  stencil_4d(M, A, M.zl[0], M.zl[1], time, zeta, lon, lat, s);
+  return ml_field(M, M.pll[0], M.pll[1], s);
 }
 
 // the Kz blend evaluated at a displaced pressure, mptrac.c:4669-4688

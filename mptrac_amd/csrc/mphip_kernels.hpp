@@ -172,6 +172,10 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     P.lon = a.lon[i];
     P.lat = a.lat[i];
     P.p = a.p[i];
+    if (CT == kMaskGeneric && (mask & MPHIP_MOD_ADVECT_INIT)) {   // no dt guard (check_dt = 0)
+      a.p[i] = pressure_from_zeta(M, A, P.time, a.q[ctl.qnt_zeta][i], P.lon, P.lat);
+      continue;
+    }
     if (mask & MPHIP_MOD_TIMESTEPS) {
       P.dt = timestep_of(ctl, M, A, P.time, P.lon, P.lat, S.t);
       if (mask & kStoreDt)
@@ -185,8 +189,16 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
 
     if (mask & MPHIP_MOD_POSITION)
       position(M, A, P);
-    if (mask & MPHIP_MOD_ADVECT)
-      advect(ctl, M, A, P);
+    if (mask & MPHIP_MOD_ADVECT) {
+      // model-level advection (ADVECT_VERT_COORD 1 / 3) runs in the generic instantiation only
+      if (CT == kMaskGeneric && (ctl.advect_vert_coord == 1 || ctl.advect_vert_coord == 3)) {
+        const int qnt = ctl.advect_vert_coord == 1 ? ctl.qnt_zeta : ctl.qnt_eta;
+        double zeta;
+        advect_ml(ctl, M, A, P, zeta);
+        a.q[qnt][i] = zeta;
+      } else
+        advect(ctl, M, A, P);
+    }
     if (mask & MPHIP_MOD_DIFF_TURB)
       diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g);
     if (mask & MPHIP_MOD_DIFF_MESO) {
@@ -237,7 +249,8 @@ struct PackArgs {
   const float *f2[2][MPHIP_N2D];
   float *wind, *temp;
   f32x4 *cloud, *sfa, *sfb, *sfc;
-  size_t ncell, ncol;
+  float *mlw;                      // model-level {ul,vl,zeta_dot} records (NULL: none)
+  size_t ncell, ncol, ncell_ml;
 };
 
 __global__ void pack_kernel(PackArgs a) {
@@ -258,6 +271,14 @@ __global__ void pack_kernel(PackArgs a) {
       }
     }
   }
+  if (a.mlw)
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < a.ncell_ml; i += stride)
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        a.mlw[6 * i + 3 * t + 0] = a.f3[t][MPHIP_UL] ? a.f3[t][MPHIP_UL][i] : 0.f;
+        a.mlw[6 * i + 3 * t + 1] = a.f3[t][MPHIP_VL] ? a.f3[t][MPHIP_VL][i] : 0.f;
+        a.mlw[6 * i + 3 * t + 2] = a.f3[t][MPHIP_ZETA_DOTL] ? a.f3[t][MPHIP_ZETA_DOTL][i] : 0.f;
+      }
   for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < a.ncol; i += stride) {
     f32x4 va;
 #pragma unroll

@@ -28,6 +28,8 @@ CTL_FIELDS = [
     ("qnt_mloss_decay", C.c_int, -1),
     ("qnt_mloss_wet", C.c_int, -1),
     ("qnt_mloss_dry", C.c_int, -1),
+    ("qnt_zeta", C.c_int, -1),
+    ("qnt_eta", C.c_int, -1),
     ("nens", C.c_int, 0),                      # mptrac.c:7610
     # modules, mptrac.c:7196-7263
     ("advect", C.c_int, 2),
@@ -121,7 +123,7 @@ def ctl_from_quantities(names):
     out = {"nq": len(names)}
     table = {"m": "qnt_m", "vmr": "qnt_vmr", "rp": "qnt_rp", "rhop": "qnt_rhop", "ens": "qnt_ens",
              "loss_rate": "qnt_loss_rate", "mloss_decay": "qnt_mloss_decay",
-             "mloss_wet": "qnt_mloss_wet", "mloss_dry": "qnt_mloss_dry"}
+             "mloss_wet": "qnt_mloss_wet", "mloss_dry": "qnt_mloss_dry", "zeta": "qnt_zeta", "eta": "qnt_eta"}
     for i, n in enumerate(names):
         if n in table:
             out[table[n]] = i

@@ -18,7 +18,7 @@ NQ_MAX = 16
 MOD = {
     "timesteps": 1 << 0, "position": 1 << 1, "advect": 1 << 2, "diff_turb": 1 << 3, "diff_meso": 1 << 4,
     "convection": 1 << 5, "sedi": 1 << 6, "position2": 1 << 7, "loss_zero": 1 << 8, "decay": 1 << 9,
-    "wet_depo": 1 << 10, "dry_depo": 1 << 11, "sort": 1 << 16, "mixing": 1 << 17,
+    "wet_depo": 1 << 10, "dry_depo": 1 << 11, "advect_init": 1 << 12, "sort": 1 << 16, "mixing": 1 << 17,
 }
 
 MphipCtl = make_ctl_struct("MphipCtl")
@@ -28,8 +28,9 @@ _fp = C.POINTER(C.c_float)
 
 class MphipMet(C.Structure):
     _fields_ = [("time", C.c_double), ("coord_type", C.c_int), ("nx", C.c_int), ("ny", C.c_int),
-                ("np", C.c_int), ("lon", _dp), ("lat", _dp), ("p", _dp),
+                ("np", C.c_int), ("npl", C.c_int), ("lon", _dp), ("lat", _dp), ("p", _dp),
                 ("sx", C.c_longlong), ("sy", C.c_longlong), ("sx2", C.c_longlong),
+                ("sx_ml", C.c_longlong), ("sy_ml", C.c_longlong),
                 ("f3", _fp * len(FIELDS_3D)), ("f2", _fp * len(FIELDS_2D))]
 
 
@@ -162,6 +163,8 @@ class Simulation:
         m.time, m.coord_type, m.nx, m.ny, m.np = met.time, met.coord_type, met.nx, met.ny, met.np
         m.lon, m.lat, m.p = _ptr(met.lon, _dp), _ptr(met.lat, _dp), _ptr(met.p, _dp)
         m.sx, m.sy, m.sx2 = met.ny * met.np, met.np, met.ny
+        m.npl = met.npl if any(k in met.f3 for k in ("pl", "ul", "vl", "zetal", "zeta_dotl")) else 0
+        m.sx_ml, m.sy_ml = met.ny * met.npl, met.npl
         for i, k in enumerate(FIELDS_3D):
             m.f3[i] = _ptr(met.f3[k], _fp) if k in met.f3 else None
         for i, k in enumerate(FIELDS_2D):

@@ -685,6 +685,7 @@ static void to_device_ctl(const ctl_t *c, mphip_ctl_t *d) {
   CP(grid_z0); CP(grid_z1); CP(grid_lon0); CP(grid_lon1); CP(grid_lat0); CP(grid_lat1);
   CP(grid_nx); CP(grid_ny); CP(grid_nz);
 #undef CP
+  d->qnt_zeta = d->qnt_eta = -1;   /* model-level advection is not wired into the host layer yet */
   for (int k = 0; k < 2; k++) {
     d->wet_depo_pre[k] = c->wet_depo_pre[k];
     d->wet_depo_ic_h[k] = c->wet_depo_ic_h[k];
@@ -733,6 +734,9 @@ static void upload_met(met_t *met, int slot) {
   m.sx = (long long) EY * EP;
   m.sy = EP;
   m.sx2 = EY;
+  m.npl = 0;
+  m.sx_ml = m.sx;
+  m.sy_ml = m.sy;
   m.f3[MPHIP_U] = &met->u[0][0][0];
   m.f3[MPHIP_V] = &met->v[0][0][0];
   m.f3[MPHIP_W] = &met->w[0][0][0];

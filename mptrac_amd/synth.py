@@ -13,7 +13,8 @@ import numpy as np
 P0 = 1013.25   # mptrac.h:305
 H0 = 7.0       # mptrac.h:270
 
-FIELDS_3D = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc")
+FIELDS_3D = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "pl", "ul", "vl", "zetal", "zeta_dotl")
+FIELDS_ML = ("pl", "ul", "vl", "zetal", "zeta_dotl")     # on model levels [nx][ny][npl]
 FIELDS_2D = ("ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl")
 
 GRIDS = {
@@ -42,8 +43,13 @@ class Met:
         self.nx, self.ny, self.np = len(self.lon), len(self.lat), len(self.p)
         self.f3 = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in f3.items()}
         self.f2 = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in f2.items()}
+        self.npl = self.np
         for k, v in self.f3.items():
-            assert v.shape == (self.nx, self.ny, self.np), (k, v.shape)
+            if k in FIELDS_ML:
+                self.npl = v.shape[2]
+                assert v.shape[:2] == (self.nx, self.ny), (k, v.shape)
+            else:
+                assert v.shape == (self.nx, self.ny, self.np), (k, v.shape)
         for k, v in self.f2.items():
             assert v.shape == (self.nx, self.ny), (k, v.shape)
 
@@ -82,6 +88,24 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
     put3("rwc", 2e-6 * amp * np.maximum(0.0, np.cos(lam) * cphi) * (k < npl // 4))
     put3("iwc", 1e-6 * np.maximum(0.0, -np.sin(lam)) * cphi * (k < npl // 3) + 0.0 * k)
     put3("swc", 0.0 * lam * phi * k)
+
+    if want & set(FIELDS_ML):
+        # terrain-following model levels: p = sigma_k * ps (sigma 1 -> ~2e-4), zeta = a potential-temperature-like
+        # monotonic function of p that also varies horizontally and in time, winds analytic in (lon, lat, level)
+        npl_ml = npl + 7
+        kk = np.arange(npl_ml, dtype=np.float64)[None, None, :]
+        sigma = np.exp(-8.5 * kk / (npl_ml - 1))
+        ps3 = (1013.25 - 30.0 * np.sin(lam) ** 2 * np.cos(phi))
+        pl = sigma * ps3
+        zeta = 290.0 * (1000.0 / pl) ** 0.286 * (1.0 + 0.02 * amp * np.cos(lam) * cphi)
+        shape_ml = (nx0 + 1, ny, npl_ml)
+        ml = {"pl": pl, "zetal": zeta,
+              "ul": 25.0 * amp * cphi * (1.0 + 0.2 * np.sin(0.2 * kk)) + 0.0 * lam,
+              "vl": 4.0 * amp * np.sin(2.0 * lam) * cphi + 0.0 * kk,
+              "zeta_dotl": 2e-3 * amp * np.sin(lam) * cphi * np.sin(np.pi * kk / (npl_ml - 1))}
+        for name, expr in ml.items():
+            if name in want:
+                f3[name] = np.broadcast_to(expr, shape_ml).astype(np.float32)
 
     lam2, phi2 = lam[:, :, 0], phi[:, :, 0]
     shape2 = (nx0 + 1, ny)

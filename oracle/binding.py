@@ -23,7 +23,7 @@ _fp = C.POINTER(C.c_float)
 
 class OrcMet(C.Structure):
     _fields_ = [("time", C.c_double), ("coord_type", C.c_int), ("nx", C.c_int), ("ny", C.c_int),
-                ("np", C.c_int), ("lon", _dp), ("lat", _dp), ("p", _dp),
+                ("np", C.c_int), ("npl", C.c_int), ("lon", _dp), ("lat", _dp), ("p", _dp),
                 ("f3", _fp * len(FIELDS_3D)), ("f2", _fp * len(FIELDS_2D))]
 
 
@@ -148,6 +148,7 @@ class Oracle:
         self._mets[slot] = met      # keep arrays alive
         m = self.met[slot]
         m.time, m.coord_type, m.nx, m.ny, m.np = met.time, met.coord_type, met.nx, met.ny, met.np
+        m.npl = met.npl
         m.lon, m.lat, m.p = _ptr(met.lon, _dp), _ptr(met.lat, _dp), _ptr(met.p, _dp)
         for i, k in enumerate(FIELDS_3D):
             m.f3[i] = _ptr(met.f3[k], _fp) if k in met.f3 else None

@@ -494,10 +494,15 @@ void orc_module_position(const orc_cache_t *cache, const orc_met_t *met0, const 
 
 /* ---- module_advect, pressure-level branch (mptrac.c:3609-3678) ---------- */
 
+static void advect_model_levels(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                                const orc_met_t *met1, orc_atm_t *atm);
+
 void orc_module_advect(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
                        const orc_met_t *met1, orc_atm_t *atm) {
-  if (ctl->advect_vert_coord != 0)
-    die("oracle restates ADVECT_VERT_COORD=0 only");
+  if (ctl->advect_vert_coord == 1 || ctl->advect_vert_coord == 3) {
+    advect_model_levels(ctl, cache, met0, met1, atm);
+    return;
+  }
   const int ct = met0->coord_type;
 #pragma omp parallel for schedule(static)
   for (int ip = 0; ip < atm->np; ip++) {
@@ -537,6 +542,183 @@ void orc_module_advect(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc
     atm->lon[ip] += dx2coord(ct, dt * um, (ctl->advect == 2 ? x1 : atm->lat[ip]));
     atm->lat[ip] += dy2coord(ct, dt * vm);
     atm->p[ip] += dt * wm;
+  }
+}
+
+/* ---- model-level interpolation (mptrac.c:2808-2981, 3525-3594) ----------- */
+
+#define AL(a, m, i, j, k) ((a)[((size_t) (i) * (size_t) (m)->ny + (size_t) (j)) * (size_t) (m)->npl + (size_t) (k)])
+
+/* locate_irr_float, mptrac.c:3525-3555: bisection on a float profile with a
+ * first guess */
+static int locate_irr_float(const float *xx, int n, double x, int ig) {
+  int lo = 0, hi = n - 1;
+  int mid = (hi + lo) >> 1;
+  if ((xx[ig] <= x && x < xx[ig + 1]) || (xx[ig] >= x && x > xx[ig + 1]))
+    return ig;
+  if (xx[mid] < xx[mid + 1]) {
+    while (hi > lo + 1) {
+      mid = (hi + lo) >> 1;
+      if (xx[mid] > x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  } else {
+    while (hi > lo + 1) {
+      mid = (hi + lo) >> 1;
+      if (xx[mid] <= x)
+        hi = mid;
+      else
+        lo = mid;
+    }
+  }
+  return lo;
+}
+
+/* indices/weights of intpol_met_4d_zeta: ci[3], cw[4] */
+typedef struct {
+  int ix, iy, iz;
+  double wx, wy, wz, wt;
+} stencil4_t;
+
+/* time-then-horizontal interpolation of the height field at level k */
+static double height_at(const orc_met_t *m0, const float *h0, const float *h1, const stencil4_t *s, int k) {
+  const int ix = s->ix, iy = s->iy;
+  const double h00 = s->wt * (AL(h1, m0, ix, iy, k) - AL(h0, m0, ix, iy, k)) + AL(h0, m0, ix, iy, k);
+  const double h01 = s->wt * (AL(h1, m0, ix, iy + 1, k) - AL(h0, m0, ix, iy + 1, k)) + AL(h0, m0, ix, iy + 1, k);
+  const double h10 = s->wt * (AL(h1, m0, ix + 1, iy, k) - AL(h0, m0, ix + 1, iy, k)) + AL(h0, m0, ix + 1, iy, k);
+  const double h11 = s->wt * (AL(h1, m0, ix + 1, iy + 1, k) - AL(h0, m0, ix + 1, iy + 1, k))
+    + AL(h0, m0, ix + 1, iy + 1, k);
+  const double a = s->wy * (h01 - h00) + h00;
+  const double b = s->wy * (h11 - h10) + h10;
+  return s->wx * (b - a) + a;
+}
+
+/* intpol_met_4d_zeta, mptrac.c:2808-2981 */
+static double intpol_4d_zeta(const orc_met_t *m0, int fh, int fa, const orc_met_t *m1, double ts, double height,
+                             double lon, double lat, stencil4_t *s, int init) {
+  const float *h0 = m0->f3[fh], *h1 = m1->f3[fh];
+  const float *a0 = m0->f3[fa], *a1 = m1->f3[fa];
+  if (init) {
+    double lon2, lat2;
+    check_horizontal(m0, lon, lat, &lon2, &lat2);
+    s->ix = orc_locate_reg(m0->lon, m0->nx, lon2);
+    s->iy = orc_locate_irr(m0->lat, m0->ny, lat2);
+    /* locate_vert on both snapshots, mptrac.c:3578-3594 */
+    int ind[2][4];
+    for (int t = 0; t < 2; t++) {
+      const orc_met_t *m = t ? m1 : m0;
+      const float *h = t ? h1 : h0;
+      ind[t][0] = locate_irr_float(&AL(h, m0, s->ix, s->iy, 0), m->npl, height, 0);
+      ind[t][1] = locate_irr_float(&AL(h, m0, s->ix + 1, s->iy, 0), m->npl, height, ind[t][0]);
+      ind[t][2] = locate_irr_float(&AL(h, m0, s->ix, s->iy + 1, 0), m->npl, height, ind[t][1]);
+      ind[t][3] = locate_irr_float(&AL(h, m0, s->ix + 1, s->iy + 1, 0), m->npl, height, ind[t][2]);
+    }
+    s->iz = ind[0][0];
+    int k_max = ind[0][0];
+    for (int t = 0; t < 2; t++)
+      for (int j = 0; j < 4; j++) {
+        if (s->iz > ind[t][j])
+          s->iz = ind[t][j];
+        if (k_max < ind[t][j])
+          k_max = ind[t][j];
+      }
+    s->wt = (ts - m0->time) / (m1->time - m0->time);
+    s->wx = (lon2 - m0->lon[s->ix]) / (m0->lon[s->ix + 1] - m0->lon[s->ix]);
+    s->wy = (lat2 - m0->lat[s->iy]) / (m0->lat[s->iy + 1] - m0->lat[s->iy]);
+    double height_bot = height_at(m0, h0, h1, s, s->iz);
+    double height_top = height_at(m0, h0, h1, s, s->iz + 1);
+    /* search upward until the height is inside the box, mptrac.c:2905-2938 */
+    const float g0 = h0[0], g1 = h0[1];     /* heights0[0][0][0], heights0[0][0][1] */
+    while (((g0 > g1) && ((height_bot <= height) || (height_top > height)) && (height_bot >= height)
+            && (s->iz < k_max))
+           || ((g0 < g1) && ((height_bot >= height) || (height_top < height)) && (height_bot <= height)
+               && (s->iz < k_max))) {
+      s->iz++;
+      height_bot = height_top;
+      height_top = height_at(m0, h0, h1, s, s->iz + 1);
+    }
+    s->wz = (height - height_bot) / (height_top - height_bot);
+  }
+  /* time first, then longitude, latitude, vertical (mptrac.c:2945-2980) */
+  const int ix = s->ix, iy = s->iy, iz = s->iz;
+#define TI(i, j, k) (s->wt * (AL(a1, m0, i, j, k) - AL(a0, m0, i, j, k)) + AL(a0, m0, i, j, k))
+  const double a000 = TI(ix, iy, iz), a100 = TI(ix + 1, iy, iz), a010 = TI(ix, iy + 1, iz), a110 = TI(ix + 1, iy + 1, iz);
+  const double a001 = TI(ix, iy, iz + 1), a101 = TI(ix + 1, iy, iz + 1), a011 = TI(ix, iy + 1, iz + 1),
+    a111 = TI(ix + 1, iy + 1, iz + 1);
+#undef TI
+  const double a00 = s->wx * (a100 - a000) + a000;
+  const double a10 = s->wx * (a110 - a010) + a010;
+  const double a01 = s->wx * (a101 - a001) + a001;
+  const double a11 = s->wx * (a111 - a011) + a011;
+  const double lo = s->wy * (a10 - a00) + a00;
+  const double hi = s->wy * (a11 - a01) + a01;
+  return s->wz * (hi - lo) + lo;
+}
+
+/* module_advect, zeta / eta branch (mptrac.c:3681-3757) */
+static void advect_model_levels(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                                const orc_met_t *met1, orc_atm_t *atm) {
+  const int qnt = (ctl->advect_vert_coord == 1 ? ctl->qnt_zeta : ctl->qnt_eta);
+  const int ct = met0->coord_type;
+  if (qnt < 0)
+    die("model-level advection needs quantity zeta (or eta)");
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    const double dt = cache->dt[ip];
+    stencil4_t s = { 0, 0, 0, 0, 0, 0, 0 };
+    /* pressure -> vertical coordinate */
+    atm->q[qnt][ip] = intpol_4d_zeta(met0, ORC_PL, ORC_ZETAL, met1, atm->time[ip], atm->p[ip], atm->lon[ip],
+                                     atm->lat[ip], &s, 1);
+    double u[4], v[4], wdot[4], um = 0, vm = 0, wdotm = 0, x0 = 0, x1 = 0, x2 = 0;
+    for (int i = 0; i < ctl->advect; i++) {
+      double dts;
+      if (i == 0) {
+        dts = 0.0;
+        x0 = atm->lon[ip];
+        x1 = atm->lat[ip];
+        x2 = atm->q[qnt][ip];
+      } else {
+        dts = (i == 3 ? 1.0 : 0.5) * dt;
+        x0 = atm->lon[ip] + dx2coord(ct, dts * u[i - 1], atm->lat[ip]);
+        x1 = atm->lat[ip] + dy2coord(ct, dts * v[i - 1]);
+        x2 = atm->q[qnt][ip] + dts * wdot[i - 1];
+      }
+      const double tm = atm->time[ip] + dts;
+      u[i] = intpol_4d_zeta(met0, ORC_ZETAL, ORC_UL, met1, tm, x2, x0, x1, &s, 1);
+      v[i] = intpol_4d_zeta(met0, ORC_ZETAL, ORC_VL, met1, tm, x2, x0, x1, &s, 0);
+      wdot[i] = intpol_4d_zeta(met0, ORC_ZETAL, ORC_ZETA_DOTL, met1, tm, x2, x0, x1, &s, 0);
+      double k = 1.0;
+      if (ctl->advect == 2)
+        k = (i == 0 ? 0.0 : 1.0);
+      else if (ctl->advect == 4)
+        k = (i == 0 || i == 3 ? 1.0 / 6.0 : 2.0 / 6.0);
+      um += k * u[i];
+      vm += k * v[i];
+      wdotm += k * wdot[i];
+    }
+    atm->time[ip] += dt;
+    atm->lon[ip] += dx2coord(ct, dt * um, (ctl->advect == 2 ? x1 : atm->lat[ip]));
+    atm->lat[ip] += dy2coord(ct, dt * vm);
+    atm->q[qnt][ip] += dt * wdotm;
+    /* vertical coordinate -> pressure */
+    atm->p[ip] = intpol_4d_zeta(met0, ORC_ZETAL, ORC_PL, met1, atm->time[ip], atm->q[qnt][ip], atm->lon[ip],
+                                atm->lat[ip], &s, 1);
+  }
+}
+
+/* module_advect_init, mptrac.c:3762-3785: pressure consistent with zeta */
+void orc_module_advect_init(const orc_ctl_t *ctl, const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm) {
+  if (ctl->advect_vert_coord != 1)
+    return;
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    stencil4_t s = { 0, 0, 0, 0, 0, 0, 0 };
+    atm->p[ip] = intpol_4d_zeta(met0, ORC_ZETAL, ORC_PL, met1, atm->time[ip], atm->q[ctl->qnt_zeta][ip],
+                                atm->lon[ip], atm->lat[ip], &s, 1);
   }
 }
 
@@ -997,6 +1179,8 @@ void orc_module_sort(const orc_ctl_t *ctl, const orc_met_t *met0, orc_atm_t *atm
 
 void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
                       const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm, double t) {
+  if (t == ctl->t_start)
+    orc_module_advect_init(ctl, met0, met1, atm);   /* mptrac.c:7863-7870 */
   orc_module_timesteps(ctl, cache, met0, atm, t);
   if (ctl->sort_dt > 0 && fmod(t, ctl->sort_dt) == 0)
     orc_module_sort(ctl, met0, atm, NULL, NULL);

@@ -29,7 +29,9 @@ extern "C" {
 #define ORC_NQ_MAX 16
 
 /* 3-D met fields, each float [nx][ny][np] (level index fastest, mptrac.h:3964) */
-enum { ORC_U = 0, ORC_V, ORC_W, ORC_T, ORC_LWC, ORC_RWC, ORC_IWC, ORC_SWC, ORC_N3D };
+enum { ORC_U = 0, ORC_V, ORC_W, ORC_T, ORC_LWC, ORC_RWC, ORC_IWC, ORC_SWC,
+       /* model-level fields, float [nx][ny][npl] (mptrac.h:3997-4012) */
+       ORC_PL, ORC_UL, ORC_VL, ORC_ZETAL, ORC_ZETA_DOTL, ORC_N3D };
 /* 2-D met fields, each float [nx][ny] */
 enum { ORC_PS = 0, ORC_PBL, ORC_CAPE, ORC_CIN, ORC_PEL, ORC_PCT, ORC_PCB, ORC_CL, ORC_N2D };
 
@@ -45,10 +47,11 @@ typedef struct {
   int nq;
   int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens;
   int qnt_loss_rate, qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry;
+  int qnt_zeta, qnt_eta;
   int nens;
   /* modules */
   int advect;             /* 1, 2 or 4 (mptrac.c:7218) */
-  int advect_vert_coord;  /* only 0 (pressure levels) restated */
+  int advect_vert_coord;  /* 0/2 pressure levels, 1 zeta, 3 eta (mptrac.c:3609, 3681) */
   int rng_type;           /* only 1 (Squares) restated */
   int diffusion;
   int turb_pbl_scheme;
@@ -79,6 +82,7 @@ typedef struct {
   double time;
   int coord_type;
   int nx, ny, np;
+  int npl;                 /* number of model levels (mptrac.h:3862) */
   const double *lon, *lat, *p;
   const float *f3[ORC_N3D];
   const float *f2[ORC_N2D];
@@ -139,6 +143,8 @@ void orc_module_position(const orc_cache_t *cache, const orc_met_t *met0,
                          const orc_met_t *met1, orc_atm_t *atm);
 void orc_module_advect(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
                        const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_advect_init(const orc_ctl_t *ctl, const orc_met_t *met0, const orc_met_t *met1,
+                            orc_atm_t *atm);   /* mptrac.c:3762 */
 void orc_module_diff_turb(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
                           const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm);
 void orc_module_diff_meso(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,

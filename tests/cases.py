@@ -26,16 +26,29 @@ CASES = {
                  mixing_trop=1e-3, mixing_strat=1e-6, mixing_dt=360.0, mixing_nx=36, mixing_ny=18, mixing_nz=20,
                  tdec_trop=259200.0, tdec_strat=259200.0, dry_depo_vdep=0.15,
                  wet_depo_ic_a=1e-4, wet_depo_ic_b=0.8, wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6),
+    # model-level advection: zeta (with module_advect_init) and eta coordinates
+    "advect_zeta": dict(BASE, advect_vert_coord=1),
+    "advect_zeta_midpoint": dict(BASE, advect=2, advect_vert_coord=1),
+    "advect_eta": dict(BASE, advect_vert_coord=3),
+    "zeta_full": dict(BASE, advect_vert_coord=1, diffusion=1, turb_dz_trop=0.1, conv_cape=0.0),
     # Henry-law wet deposition with SO2 pH correction
     "wet_henry": dict(BASE, wet_depo_ic_h=(1.3e-2, 2900.0), wet_depo_bc_h=(1.3e-2, 2900.0),
                       wet_depo_so2_ph=4.5, wet_depo_ic_ret_ratio=0.5, wet_depo_bc_ret_ratio=0.3),
 }
 
 QUANTITIES = ("m", "rp", "rhop", "vmr", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry")
+QUANTITIES_ML = QUANTITIES + ("zeta", "eta")
+PRESSURE_LEVEL_FIELDS = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "ps", "pbl", "cape", "cin", "pel", "pct",
+                         "pcb", "cl")
 
 
-def make_case(name, n=10000, grid="C1", seed=12345, quantities=QUANTITIES, lon0=-180.0, fields=None):
+def make_case(name, n=10000, grid="C1", seed=12345, quantities=None, lon0=-180.0, fields=None):
     ctl = dict(CASES[name])
+    ml = ctl.get("advect_vert_coord", 0) in (1, 3)
+    if quantities is None:
+        quantities = QUANTITIES_ML if ml else QUANTITIES
+    if fields is None and not ml:
+        fields = PRESSURE_LEVEL_FIELDS          # model-level fields only where they are used
     ctl.update(ctl_from_quantities(quantities))
     if name.startswith("advect") or name in ("turb", "diff", "conv_thresh"):
         # no sedimentation in these
@@ -43,6 +56,9 @@ def make_case(name, n=10000, grid="C1", seed=12345, quantities=QUANTITIES, lon0=
     met0 = synthetic_met(grid, 0.0, 1.0, fields=fields, lon0=lon0)
     met1 = synthetic_met(grid, 3600.0, 1.25, fields=fields, lon0=lon0)
     atm = synthetic_particles(n, seed=seed, quantities=quantities)
+    for name_q in ("zeta", "eta"):
+        if name_q in quantities:     # a vertical coordinate inside the range of the synthetic zetal field
+            atm["q"][list(quantities).index(name_q)] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
     return ctl, load_clim_tropo(), met0, met1, atm
 
 

@@ -101,6 +101,7 @@ def test_rng_stream_matches_module_rng(ctr, n):
 # ---------------------------------------------------------------------------
 
 MODULE_CASES = [("position", "advect"), ("advect", "advect"), ("advect", "advect_midpoint"),
+                ("advect", "advect_zeta"), ("advect", "advect_eta"),
                 ("advect", "advect_euler"), ("diff_turb", "turb"), ("diff_meso", "diff"),
                 ("convection", "conv_sedi"), ("convection", "conv_thresh"), ("sedi", "conv_sedi"),
                 ("decay", "full"), ("wet_depo", "full"), ("wet_depo", "wet_henry"), ("dry_depo", "full")]
@@ -162,7 +163,7 @@ def test_met_swap_over_two_intervals():
     """mptrac_get_met's pointer swap (mptrac.c:6486-6499): 2 h with 3 snapshots."""
     ctl, clim, m0, m1, atm = cases.make_case("diff", n=3000)
     ctl["t_stop"] = 7200.0
-    m2 = synthetic_met("C1", 7200.0, 0.8)
+    m2 = synthetic_met("C1", 7200.0, 0.8, fields=cases.PRESSURE_LEVEL_FIELDS)
     o = B.Oracle(ctl, clim, m0, m1, atm)
     o.timesteps_init()
     s = hip.Simulation(ctl, clim, m0, m1, atm)
@@ -309,11 +310,11 @@ def test_regional_domain_stops_particles_outside():
 def test_strided_meteo_upload_matches_compact():
     """met_t holds fixed-extent arrays (float u[EX][EY][EP]); uploading through
     strides must equal uploading a compact copy."""
-    ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=1500, grid="tiny")
+    ctl, clim, m0, m1, atm = cases.make_case("zeta_full", n=1500, grid="tiny")
     a = hip.Simulation(ctl, clim, m0, m1, atm)
     b = hip.Simulation(ctl, clim, m0, m1, atm)
-    EX, EY, EP = m0.nx + 3, m0.ny + 5, m0.np + 4
-    from mptrac_amd.synth import FIELDS_2D, FIELDS_3D
+    EX, EY, EP = m0.nx + 3, m0.ny + 5, m0.npl + 4
+    from mptrac_amd.synth import FIELDS_2D, FIELDS_3D, FIELDS_ML
     keep = []
     for slot, m in ((0, m0), (1, m1)):
         mm = hip.MphipMet()
@@ -321,9 +322,10 @@ def test_strided_meteo_upload_matches_compact():
         dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
         mm.lon, mm.lat, mm.p = m.lon.ctypes.data_as(dp), m.lat.ctypes.data_as(dp), m.p.ctypes.data_as(dp)
         mm.sx, mm.sy, mm.sx2 = EY * EP, EP, EY
+        mm.npl, mm.sx_ml, mm.sy_ml = m.npl, EY * EP, EP
         for i, k in enumerate(FIELDS_3D):
             big = np.full((EX, EY, EP), np.nan, dtype=np.float32)
-            big[:m.nx, :m.ny, :m.np] = m.f3[k]
+            big[:m.nx, :m.ny, :(m.npl if k in FIELDS_ML else m.np)] = m.f3[k]
             keep.append(big)
             mm.f3[i] = big.ctypes.data_as(fp)
         for i, k in enumerate(FIELDS_2D):
