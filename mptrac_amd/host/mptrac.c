@@ -156,14 +156,14 @@ static const struct {
    * hot-path quantities only */
   { "ens", "-" }, { "m", "kg" }, { "vmr", "ppv" }, { "rp", "microns" }, { "rhop", "kg/m^3" },
   { "loss_rate", "s^-1" }, { "mloss_decay", "kg" }, { "mloss_wet", "kg" }, { "mloss_dry", "kg" },
-  { "idx", "-" }, { "stat", "-" }
+  { "idx", "-" }, { "stat", "-" }, { "zeta", "K" }, { "eta", "1" }
 };
 
 static const char *unsupported_qnt[] = {
   /* quantities module_meteo would fill (mptrac.c:5062-5165); not implemented */
   "ps", "ts", "zs", "us", "vs", "pbl", "pt", "tt", "zt", "h2ot", "zg", "p", "t", "rho", "u", "v", "w",
   "h2o", "o3", "lwc", "rwc", "iwc", "swc", "cc", "pct", "pcb", "cl", "plcl", "plfc", "pel", "cape", "cin",
-  "hno3", "oh", "vh", "vz", "rh", "rhice", "theta", "zeta", "zeta_d", "tvirt", "lapse", "pv", "tdew",
+  "hno3", "oh", "vh", "vz", "rh", "rhice", "theta", "zeta_d", "tvirt", "lapse", "pv", "tdew",
   "tice", "tsts", "tnat", NULL
 };
 
@@ -172,7 +172,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
 
   /* quantities, mptrac.c:6737-6971 */
   ctl->qnt_m = ctl->qnt_vmr = ctl->qnt_rp = ctl->qnt_rhop = ctl->qnt_ens = ctl->qnt_loss_rate = -1;
-  ctl->qnt_mloss_decay = ctl->qnt_mloss_wet = ctl->qnt_mloss_dry = -1;
+  ctl->qnt_mloss_decay = ctl->qnt_mloss_wet = ctl->qnt_mloss_dry = ctl->qnt_zeta = ctl->qnt_eta = -1;
   ctl->nq = (int) scan_ctl(filename, argc, argv, "NQ", -1, "0", NULL);
   if (ctl->nq > NQ || ctl->nq > MPHIP_NQ_MAX)
     ERRMSG("Too many quantities!");
@@ -197,6 +197,8 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
     else if (!strcasecmp(n, "mloss_decay")) ctl->qnt_mloss_decay = iq;
     else if (!strcasecmp(n, "mloss_wet")) ctl->qnt_mloss_wet = iq;
     else if (!strcasecmp(n, "mloss_dry")) ctl->qnt_mloss_dry = iq;
+    else if (!strcasecmp(n, "zeta")) ctl->qnt_zeta = iq;
+    else if (!strcasecmp(n, "eta")) ctl->qnt_eta = iq;
   }
 
   /* coordinates, time steps, meteo input (mptrac.c:6974-7030) */
@@ -316,8 +318,12 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   /* what the device does not implement must not be requested silently */
   if (ctl->rng_type != 1)
     ERRMSG("This build implements RNG_TYPE 1 (Squares) only!");
-  if (ctl->advect_vert_coord != 0)
-    ERRMSG("This build implements ADVECT_VERT_COORD 0 (pressure levels) only!");
+  if (ctl->advect_vert_coord < 0 || ctl->advect_vert_coord > 3)
+    ERRMSG("Set ADVECT_VERT_COORD to 0, 1, 2, or 3!");
+  if (ctl->advect_vert_coord == 1 && ctl->qnt_zeta < 0)
+    ERRMSG("Please add zeta to your quantities for diabatic calculations!");   /* mptrac.c:6992 */
+  if (ctl->advect_vert_coord == 3 && ctl->qnt_eta < 0)
+    ERRMSG("Please add eta to your quantities for etadot calculations!");      /* mptrac.c:6994 */
   if (ctl->diffusion && ctl->turb_pbl_scheme == 1)
     ERRMSG("This build does not implement module_diff_pbl (TURB_PBL_SCHEME 1)!");
 }
@@ -685,7 +691,8 @@ static void to_device_ctl(const ctl_t *c, mphip_ctl_t *d) {
   CP(grid_z0); CP(grid_z1); CP(grid_lon0); CP(grid_lon1); CP(grid_lat0); CP(grid_lat1);
   CP(grid_nx); CP(grid_ny); CP(grid_nz);
 #undef CP
-  d->qnt_zeta = d->qnt_eta = -1;   /* model-level advection is not wired into the host layer yet */
+  d->qnt_zeta = c->qnt_zeta;
+  d->qnt_eta = c->qnt_eta;
   for (int k = 0; k < 2; k++) {
     d->wet_depo_pre[k] = c->wet_depo_pre[k];
     d->wet_depo_ic_h[k] = c->wet_depo_ic_h[k];
@@ -734,9 +741,16 @@ static void upload_met(met_t *met, int slot) {
   m.sx = (long long) EY * EP;
   m.sy = EP;
   m.sx2 = EY;
-  m.npl = 0;
+  m.npl = met->npl;
   m.sx_ml = m.sx;
   m.sy_ml = m.sy;
+  if (met->npl > 0) {
+    m.f3[MPHIP_PL] = &met->pl[0][0][0];
+    m.f3[MPHIP_UL] = &met->ul[0][0][0];
+    m.f3[MPHIP_VL] = &met->vl[0][0][0];
+    m.f3[MPHIP_ZETAL] = &met->zetal[0][0][0];
+    m.f3[MPHIP_ZETA_DOTL] = &met->zeta_dotl[0][0][0];
+  }
   m.f3[MPHIP_U] = &met->u[0][0][0];
   m.f3[MPHIP_V] = &met->v[0][0][0];
   m.f3[MPHIP_W] = &met->w[0][0][0];

@@ -94,7 +94,7 @@ typedef struct {
   int nq;
   char qnt_name[NQ][LEN], qnt_unit[NQ][LEN], qnt_format[NQ][LEN];
   int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens, qnt_loss_rate;
-  int qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry;
+  int qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry, qnt_zeta, qnt_eta;
   /* time and meteo input */
   int direction, met_coord_type, met_type;
   double t_start, t_stop, dt_mod, dt_met, met_utm_ref_lat, met_dt_out;
@@ -166,12 +166,14 @@ typedef struct {
 typedef struct {
   double time;
   int coord_type;
-  int nx, ny, np;
+  int nx, ny, np, npl;
   double lon[EX], lat[EY], p[EP];
   float ps[EX][EY], pbl[EX][EY], cape[EX][EY], cin[EX][EY], pel[EX][EY];
   float pct[EX][EY], pcb[EX][EY], cl[EX][EY];
   float t[EX][EY][EP], u[EX][EY][EP], v[EX][EY][EP], w[EX][EY][EP];
   float lwc[EX][EY][EP], rwc[EX][EY][EP], iwc[EX][EY][EP], swc[EX][EY][EP];
+  /* model levels (mptrac.h:3997-4012); not part of the MET_TYPE 1 file format, filled by the caller */
+  float pl[EX][EY][EP], ul[EX][EY][EP], vl[EX][EY][EP], zetal[EX][EY][EP], zeta_dotl[EX][EY][EP];
 } met_t;
 
 /* not used on the hot path; kept so that the reference's signatures hold */
