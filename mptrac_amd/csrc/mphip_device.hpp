@@ -166,7 +166,7 @@ __device__ __forceinline__ double dy2coord(int coord_type, double dy) {   // mpt
 }
 
 __device__ __forceinline__ double dz2dp(double dz, double p) {   // mptrac.h:941
-  return -dz * p / kH0;
+  return div_const(-dz * p, kH0, 1.0 / kH0);
 }
 
 __device__ __forceinline__ double zfromp(double p) {   // mptrac.h:2243
@@ -715,10 +715,14 @@ __device__ __forceinline__ double clim_tropo(const DevClim &C, double t, double 
   return lin(C.time[it], pa, C.time[it + 1], pb, sec);
 }
 
-// tropo_weight, mptrac.c:12748-12770
-__device__ __forceinline__ double tropo_weight(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat,
-                                               double p) {
-  const double pt = clim_tropo(C, time, ctl.met_coord_type == 0 ? lat : ctl.met_utm_ref_lat);
+// tropo_weight, mptrac.c:12748-12770, split so that the climatological
+// tropopause pressure (a function of time and latitude only) is looked up once
+// for several pressures
+__device__ __forceinline__ double tropo_pressure(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat) {
+  return clim_tropo(C, time, ctl.met_coord_type == 0 ? lat : ctl.met_utm_ref_lat);
+}
+
+__device__ __forceinline__ double tropo_weight_pt(double pt, double p) {
   const double p1 = pt * 0.866877899;
   const double p0 = pt / 0.866877899;
   if (p > p0)
@@ -726,6 +730,11 @@ __device__ __forceinline__ double tropo_weight(const mphip_ctl_t &ctl, const Dev
   if (p < p1)
     return 0;
   return lin(p0, 1.0, p1, 0.0, p);
+}
+
+__device__ __forceinline__ double tropo_weight(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat,
+                                               double p) {
+  return tropo_weight_pt(tropo_pressure(ctl, C, time, lat), p);
 }
 
 // pbl_weight, mptrac.c:8358-8376
@@ -743,8 +752,8 @@ __device__ __forceinline__ double pbl_weight(const mphip_ctl_t &ctl, double p, d
 __device__ __forceinline__ double sedi(double p, double T, double rp, double rhop) {
   const double r = rp * 1e-6;
   const double rho = rho_air(p, T);
-  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * pow(T / 296.16, 1.5);
-  const double v = sqrt(8. * kKB * T / (kPi * kMAir));
+  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * pow(div_const(T, 296.16, 1.0 / 296.16), 1.5);
+  const double v = sqrt(div_const(8. * kKB * T, kPi * kMAir, 1.0 / (kPi * kMAir)));
   const double lambda = 2. * eta / (rho * v);
   const double K = lambda / r;
   const double G = 1. + K * (1.249 + 0.42 * exp(-0.87 / K));
@@ -1041,10 +1050,9 @@ __device__ __forceinline__ double pressure_from_zeta(const DevMet &M, const Axes
 }
 
 // the Kz blend evaluated at a displaced pressure, mptrac.c:4669-4688
-__device__ __forceinline__ double kz_blend(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat,
-                                           double p, double pbl, double ps) {
+__device__ __forceinline__ double kz_blend(const mphip_ctl_t &ctl, double pt, double p, double pbl, double ps) {
   const double wpbl = pbl_weight(ctl, p, pbl, ps);
-  const double wtrop = tropo_weight(ctl, C, time, lat, p) * (1.0 - wpbl);
+  const double wtrop = tropo_weight_pt(pt, p) * (1.0 - wpbl);
   const double wstrat = 1.0 - wpbl - wtrop;
   return wpbl * ctl.turb_dz_pbl + wtrop * ctl.turb_dz_trop + wstrat * ctl.turb_dz_strat;
 }
@@ -1085,9 +1093,10 @@ __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &
     const double eps_km = 0.01;
     const double p_up = p_save + dz2dp(eps_km, p_save);
     const double p_dn = p_save + dz2dp(-eps_km, p_save);
-    const double Kz_up = kz_blend(ctl, C, P.time, P.lat, dmax(ptop, dmin(ps, p_up)), pbl, ps);
-    const double Kz_dn = kz_blend(ctl, C, P.time, P.lat, dmax(ptop, dmin(ps, p_dn)), pbl, ps);
-    const double dKz_dz = (Kz_up - Kz_dn) / (2.0 * eps_km * 1e3);
+    const double pt = tropo_pressure(ctl, C, P.time, P.lat);   // latitude already displaced above
+    const double Kz_up = kz_blend(ctl, pt, dmax(ptop, dmin(ps, p_up)), pbl, ps);
+    const double Kz_dn = kz_blend(ctl, pt, dmax(ptop, dmin(ps, p_dn)), pbl, ps);
+    const double dKz_dz = div_const(Kz_up - Kz_dn, 2.0 * eps_km * 1e3, 1.0 / (2.0 * eps_km * 1e3));
     const double dlnrho_dz = -1.0 / (1e3 * kH0);
     const double w_drift = dKz_dz + Kz * dlnrho_dz;
     const double dz_drift = w_drift * dt_abs * 1e-3;
@@ -1210,7 +1219,7 @@ __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet 
 __device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Particle &P, double rp, double rhop) {
   const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
   const double v_s = sedi(P.p, t, rp, rhop);
-  P.p += dz2dp(v_s * P.dt / 1000., P.p);
+  P.p += dz2dp(div_const(v_s * P.dt, 1000., 1e-3), P.p);
 }
 
 }   // namespace mphip
