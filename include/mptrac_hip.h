@@ -34,9 +34,13 @@ extern "C" {
 /* 3-D meteo fields (met_t, mptrac.h:3962-4012), float [ix][iy][ip] */
 enum { MPHIP_U = 0, MPHIP_V, MPHIP_W, MPHIP_T, MPHIP_LWC, MPHIP_RWC, MPHIP_IWC, MPHIP_SWC,
        /* model-level fields (met_t pl, ul, vl, zetal, zeta_dotl; mptrac.h:3997-4012), float [ix][iy][npl] */
-       MPHIP_PL, MPHIP_UL, MPHIP_VL, MPHIP_ZETAL, MPHIP_ZETA_DOTL, MPHIP_N3D };
+       MPHIP_PL, MPHIP_UL, MPHIP_VL, MPHIP_ZETAL, MPHIP_ZETA_DOTL,
+       MPHIP_H2O,   /* water vapour on pressure levels (module_diff_pbl) */
+       MPHIP_N3D };
 /* 2-D meteo fields (met_t, mptrac.h:3886-3958), float [ix][iy] */
-enum { MPHIP_PS = 0, MPHIP_PBL, MPHIP_CAPE, MPHIP_CIN, MPHIP_PEL, MPHIP_PCT, MPHIP_PCB, MPHIP_CL, MPHIP_N2D };
+enum { MPHIP_PS = 0, MPHIP_PBL, MPHIP_CAPE, MPHIP_CIN, MPHIP_PEL, MPHIP_PCT, MPHIP_PCB, MPHIP_CL,
+       MPHIP_ESS, MPHIP_NSS, MPHIP_SHF,   /* surface stresses and sensible heat flux (module_diff_pbl) */
+       MPHIP_N2D };
 
 /* Module bits for mphip_module(); one bit per reference module_* function
  * (declarations mptrac.h:6140-7205). */
@@ -54,6 +58,7 @@ enum {
   MPHIP_MOD_WET_DEPO   = 1 << 10,  /* module_wet_depo    mptrac.c:6155 */
   MPHIP_MOD_DRY_DEPO   = 1 << 11,  /* module_dry_depo    mptrac.c:4738 */
   MPHIP_MOD_ADVECT_INIT = 1 << 12, /* module_advect_init mptrac.c:3762 (not guarded by dt) */
+  MPHIP_MOD_DIFF_PBL   = 1 << 13,  /* module_diff_pbl    mptrac.c:4343 (runs between diff_turb and diff_meso) */
   MPHIP_MOD_SORT       = 1 << 16,  /* module_sort        mptrac.c:5887 (own kernels) */
   MPHIP_MOD_MIXING     = 1 << 17   /* module_mixing      mptrac.c:5169 (own kernels) */
 };

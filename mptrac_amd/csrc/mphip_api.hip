@@ -21,7 +21,7 @@ constexpr unsigned kAdvTurb = kAdv | MPHIP_MOD_DIFF_TURB;
 constexpr unsigned kAdvDiff = kAdvTurb | MPHIP_MOD_DIFF_MESO;
 constexpr unsigned kAdvTurbConvSedi = kAdvTurb | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kAdvDiffConvSedi = kAdvDiff | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
-constexpr unsigned kParticleBits = 0x1fffu;
+constexpr unsigned kParticleBits = 0x3fffu;
 
 struct MetSlot {
   bool valid = false;
@@ -55,7 +55,8 @@ struct mphip_ctx {
   int lut_base = 0, lut_size = 0;
   size_t axes_bytes = 0;
   float *d_wind = nullptr, *d_temp = nullptr;     // packed two-snapshot grids (layouts: mphip_device.hpp)
-  f32x4 *d_cloud = nullptr, *d_sfa = nullptr, *d_sfb = nullptr, *d_sfc = nullptr;
+  f32x4 *d_cloud = nullptr, *d_sfa = nullptr, *d_sfb = nullptr, *d_sfc = nullptr, *d_sfd = nullptr;
+  float *d_h2o = nullptr;
   bool packed_dirty = true;
 
   // particles
@@ -166,6 +167,8 @@ DevMet dev_met(const mphip_ctx *c) {
   M.sfa = c->d_sfa;
   M.sfb = c->d_sfb;
   M.sfc = c->d_sfc;
+  M.sfd = c->d_sfd;
+  M.h2o = c->d_h2o;
   M.mlw = c->d_mlw;
   for (int t = 0; t < 2; t++) {
     M.zl[t] = c->slot[t ^ c->flip].f3[MPHIP_ZETAL];
@@ -286,7 +289,7 @@ int ensure_packed(mphip_ctx *ctx) {
     return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
   const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
   PackArgs a;
-  bool any_cloud = false, any_ml = false;
+  bool any_cloud = false, any_ml = false, any_pbl = false;
   const MetSlot *ss[2] = { &s0, &s1 };
   for (int t = 0; t < 2; t++) {
     for (int f = 0; f < MPHIP_N3D; f++)
@@ -296,6 +299,8 @@ int ensure_packed(mphip_ctx *ctx) {
     for (int f = MPHIP_LWC; f <= MPHIP_SWC; f++)
       any_cloud = any_cloud || ss[t]->has3[f];
     any_ml = any_ml || ss[t]->has3[MPHIP_UL] || ss[t]->has3[MPHIP_VL] || ss[t]->has3[MPHIP_ZETA_DOTL];
+    any_pbl = any_pbl || ss[t]->has3[MPHIP_H2O] || ss[t]->has2[MPHIP_ESS] || ss[t]->has2[MPHIP_NSS]
+      || ss[t]->has2[MPHIP_SHF];
   }
   const size_t ncell_ml = (size_t) ctx->nx * ctx->ny * ctx->nml;
   any_ml = any_ml && ncell_ml > 0;
@@ -308,12 +313,16 @@ int ensure_packed(mphip_ctx *ctx) {
     return 1;
   if (any_cloud && !ctx->d_cloud && dev_alloc(ctx, &ctx->d_cloud, 2 * ncell))
     return 1;
+  if (any_pbl && !ctx->d_sfd && (dev_alloc(ctx, &ctx->d_sfd, 2 * ncol) || dev_alloc(ctx, &ctx->d_h2o, 2 * ncell)))
+    return 1;
   a.wind = ctx->d_wind;
   a.temp = ctx->d_temp;
   a.cloud = any_cloud ? ctx->d_cloud : nullptr;
   a.sfa = ctx->d_sfa;
   a.sfb = ctx->d_sfb;
   a.sfc = ctx->d_sfc;
+  a.sfd = any_pbl ? ctx->d_sfd : nullptr;
+  a.h2o = any_pbl ? ctx->d_h2o : nullptr;
   a.mlw = any_ml ? ctx->d_mlw : nullptr;
   a.ncell = ncell;
   a.ncol = ncol;
@@ -359,6 +368,12 @@ int check_fields(mphip_ctx *ctx, unsigned mask) {
   if (mask & MPHIP_MOD_DIFF_TURB)
     if (need2(MPHIP_PS, "module_diff_turb") || need2(MPHIP_PBL, "module_diff_turb"))
       return 1;
+  if (mask & MPHIP_MOD_DIFF_PBL)
+    if (need2(MPHIP_PS, "module_diff_pbl") || need2(MPHIP_PBL, "module_diff_pbl")
+        || need2(MPHIP_ESS, "module_diff_pbl") || need2(MPHIP_NSS, "module_diff_pbl")
+        || need2(MPHIP_SHF, "module_diff_pbl") || need3(MPHIP_T, "module_diff_pbl")
+        || need3(MPHIP_H2O, "module_diff_pbl"))
+      return 1;
   if (mask & MPHIP_MOD_CONVECTION) {
     if (need2(MPHIP_PS, "module_convection") || need3(MPHIP_T, "module_convection"))
       return 1;
@@ -393,7 +408,8 @@ int check_fields(mphip_ctx *ctx, unsigned mask) {
   return 0;
 }
 
-int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint64_t ctr_meso, uint64_t ctr_conv) {
+int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint64_t ctr_meso, uint64_t ctr_conv,
+                uint64_t ctr_pbl = 0) {
   if (ctx->np == 0)
     return 0;
   if (ensure_packed(ctx) || check_fields(ctx, mask))
@@ -411,6 +427,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   S.ctr_turb = ctr_turb;
   S.ctr_meso = ctr_meso;
   S.ctr_conv = ctr_conv;
+  S.ctr_pbl = ctr_pbl;
   const size_t lds = axes_lds_bytes(ctx) + sizeof(DevClim);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof) {
@@ -426,7 +443,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     HIPCHK(hipEventRecord(e0, ctx->stream));
   }
   const bool ml_ = (ctx->ctl.advect_vert_coord == 1 || ctx->ctl.advect_vert_coord == 3);
-  const unsigned sel = (ctx->ctl.advect == 4 && !ml_) ? mask : kMaskGeneric;   // specialisations: RK4, pressure levels
+  const unsigned sel = (ctx->ctl.advect == 4 && !ml_ && !(mask & MPHIP_MOD_DIFF_PBL)) ? mask : kMaskGeneric;
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
   case M:                                                                                             \
@@ -704,6 +721,8 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_sfa);
   dev_free(ctx->d_sfb);
   dev_free(ctx->d_sfc);
+  dev_free(ctx->d_sfd);
+  dev_free(ctx->d_h2o);
   dev_free(ctx->d_mlw);
   for (auto p : ctx->d_arr)
     dev_free(p);
@@ -802,8 +821,10 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     dev_free(ctx->d_sfa);
     dev_free(ctx->d_sfb);
     dev_free(ctx->d_sfc);
-    ctx->d_wind = ctx->d_temp = nullptr;
-    ctx->d_cloud = ctx->d_sfa = ctx->d_sfb = ctx->d_sfc = nullptr;
+    dev_free(ctx->d_sfd);
+    dev_free(ctx->d_h2o);
+    ctx->d_wind = ctx->d_temp = ctx->d_h2o = nullptr;
+    ctx->d_cloud = ctx->d_sfa = ctx->d_sfb = ctx->d_sfc = ctx->d_sfd = nullptr;
   }
   ctx->coord_type = met->coord_type;
   // the reference interpolates on met0's axes (mptrac.c:3010-3020); slot 0 defines them
@@ -817,7 +838,7 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
   MetSlot &S = ctx->slot[slot ^ ctx->flip];
   const size_t ncell = (size_t) met->nx * met->ny * met->np, ncol = (size_t) met->nx * met->ny;
   for (int f = 0; f < MPHIP_N3D; f++) {
-    const bool is_ml = f >= MPHIP_PL;
+    const bool is_ml = f >= MPHIP_PL && f <= MPHIP_ZETA_DOTL;
     const long long nlev = is_ml ? nml : met->np;
     const long long sx = is_ml ? met->sx_ml : met->sx, sy = is_ml ? met->sy_ml : met->sy;
     S.has3[f] = met->f3[f] != nullptr && nlev > 0;
@@ -1025,8 +1046,12 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
     ctr_turb = ctx->rng_ctr;
     ctx->rng_ctr += 3 * n + 1;   // module_rng(..., 3 * np, 1), mptrac.c:4600, 5812
   }
-  if (c.diffusion && c.turb_pbl_scheme == 1)
-    return fail(ctx, "module_diff_pbl (TURB_PBL_SCHEME 1) is not implemented on the device");
+  uint64_t ctr_pbl = 0;
+  if (c.diffusion && c.turb_pbl_scheme == 1) {
+    mask |= MPHIP_MOD_DIFF_PBL;
+    ctr_pbl = ctx->rng_ctr;
+    ctx->rng_ctr += 3 * n + 1;   // module_rng(..., 3 * np, 1), mptrac.c:4354
+  }
   if (c.diffusion && (c.turb_mesox > 0 || c.turb_mesoz > 0)) {
     mask |= MPHIP_MOD_DIFF_MESO;
     ctr_meso = ctx->rng_ctr;
@@ -1051,10 +1076,10 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
     tail |= MPHIP_MOD_DRY_DEPO;
   const bool mixing_now = c.mixing_trop >= 0 && c.mixing_strat >= 0 && (c.mixing_dt <= 0 || fmod(t, c.mixing_dt) == 0);
   if (!mixing_now)
-    return launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv);
+    return launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl);
   if (tail && (mask & MPHIP_MOD_TIMESTEPS))
     mask |= kStoreDt;
-  if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv) || do_mixing(ctx, t))
+  if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl) || do_mixing(ctx, t))
     return 1;
   if (tail)
     return launch_step(ctx, tail, t, 0, 0, 0);
@@ -1074,9 +1099,13 @@ int mphip_module(mphip_ctx *ctx, unsigned modules, double t) {
   if (modules & ~kParticleBits)
     return fail(ctx, "module_sort / module_mixing must be called on their own");
   const uint64_t n = (uint64_t) ctx->np_total;
-  uint64_t ctr_turb = 0, ctr_meso = 0, ctr_conv = 0;
+  uint64_t ctr_turb = 0, ctr_meso = 0, ctr_conv = 0, ctr_pbl = 0;
   if (modules & MPHIP_MOD_DIFF_TURB) {
     ctr_turb = ctx->rng_ctr;
+    ctx->rng_ctr += 3 * n + 1;
+  }
+  if (modules & MPHIP_MOD_DIFF_PBL) {
+    ctr_pbl = ctx->rng_ctr;
     ctx->rng_ctr += 3 * n + 1;
   }
   if (modules & MPHIP_MOD_DIFF_MESO) {
@@ -1089,7 +1118,7 @@ int mphip_module(mphip_ctx *ctx, unsigned modules, double t) {
   }
   if (modules & MPHIP_MOD_TIMESTEPS)
     modules |= kStoreDt;
-  return launch_step(ctx, modules, t, ctr_turb, ctr_meso, ctr_conv);
+  return launch_step(ctx, modules, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl);
 }
 
 int mphip_get_sort(mphip_ctx *ctx, double *keys, int *perm) {

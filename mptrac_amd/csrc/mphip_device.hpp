@@ -33,6 +33,7 @@ constexpr double kT0 = 273.15;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kSO2K1Ref = 1.23e-2, kSO2K1Temp = 2.01e3, kSO2K2Ref = 6e-8, kSO2K2Temp = 1.12e3;
 constexpr double kWdTLiquid = kT0, kWdTIce = 238.15, kWdTLiquidBC = 270.;
+constexpr double kEps = 18.01528 / kMA, kKappa = 0.286, kCpd = 1003.5, kKarman = 0.40;
 
 // ---- device views ---------------------------------------------------------
 
@@ -45,6 +46,8 @@ struct DevMet {
   const f32x4 *sfa;      // [col]
   const f32x4 *sfb;      // [col][2]
   const f32x4 *sfc;      // [col][2]
+  const f32x4 *sfd;      // [col][2] {ess,nss,shf,-}0 {..}1 (optional)
+  const float *h2o;      // [cell][2] {h2o}0 {h2o}1 (optional)
   const float *mlw;      // [cellL][6] {ul,vl,zeta_dot}0 {..}1 on model levels (optional)
   const float *zl[2];    // zetal of met0 / met1, [nx][ny][npl]
   const float *pll[2];   // pl of met0 / met1
@@ -446,18 +449,23 @@ __device__ __forceinline__ double time_weight(const DevMet &M, double ts) {   //
 }
 
 // temperature stencil: one 16-byte load per column = {t0,t1} at ip, {t0,t1} at ip+1
-__device__ __forceinline__ double temp_time_3d(const DevMet &M, const Stencil &s, double wt) {
+__device__ __forceinline__ double pair_time_3d(const float *__restrict__ g, const DevMet &M, const Stencil &s,
+                                               double wt) {
   f32x4u v[2][2];
 #pragma unroll
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++)
-      v[di][dj] = *(const f32x4u *) (M.temp + 2 * cell_of(M, s, di, dj));
+      v[di][dj] = *(const f32x4u *) (g + 2 * cell_of(M, s, di, dj));
   const double v0 = lerp3(s, v[0][0][0], v[0][0][2], v[0][1][0], v[0][1][2], v[1][0][0], v[1][0][2], v[1][1][0],
                           v[1][1][2]);
   const double v1 = lerp3(s, v[0][0][1], v[0][0][3], v[0][1][1], v[0][1][3], v[1][0][1], v[1][0][3], v[1][1][1],
                           v[1][1][3]);
   return wt * (v0 - v1) + v1;
+}
+
+__device__ __forceinline__ double temp_time_3d(const DevMet &M, const Stencil &s, double wt) {
+  return pair_time_3d(M.temp, M, s, wt);
 }
 
 // cloud water stencil (wet deposition): {lwc,rwc,iwc,swc}0 {..}1 per level
@@ -1112,6 +1120,157 @@ __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &
     }
     P.p = dmax(ptop, dmin(ps, ptrial));
   }
+}
+
+// module_diff_pbl, mptrac.c:4357-4583: Hanna / FLEXPART closure inside the
+// boundary layer (TURB_PBL_SCHEME 1)
+__device__ __forceinline__ double clampd(double v, double lo, double hi) {   // CLAMP, mptrac.h:756
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+__device__ __forceinline__ double tvirt(double t, double h2o) {   // TVIRT, mptrac.h:2199
+  return t * (1. + (1. - kEps) * dmax(h2o, 0.1e-6));
+}
+
+__device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particle &P, float &up, float &vp,
+                                         float &wp, uint64_t ctr, uint64_t g) {
+  const int ct = M.coord_type;
+  double dsigw_dz = 0.0, sig_u = 0.0, sig_v = 0.0, sig_w = 0.0, tau_u = 0.0, tau_v = 0.0, tau_w = 0.0;
+  Stencil s = stencil_zero();
+  stencil_2d(M, A, P.lon, P.lat, s);
+  SurfA ca;
+  load_sfa(M, s, ca);
+  const double wt = time_weight(M, P.time);
+  const double pbl = sfa_time_2d(ca, s, wt, 1);
+  if (P.p < pbl)
+    return;
+  const double ps = sfa_time_2d(ca, s, wt, 0);
+  if (!(ps > 0.0 && pbl > 0.0 && ps > pbl))
+    return;
+  const double p = dmin(P.p, ps);
+  const double zs = zfromp(ps);
+  const double z_raw = 1e3 * (zfromp(p) - zs);
+  const double zi = 1e3 * (zfromp(pbl) - zs);
+  if (!(zi > 1.0))
+    return;
+  const double z = clampd(z_raw, 0.0, zi);
+  const double zeta = clampd(z / zi, 1e-6, 1.0 - 1e-6);
+  const double z_m = dmax(z, 1.0);
+
+  SurfB cd;
+  load_sfb(M.sfd, M, s, cd);
+  const double ess = sfb_time_2d(cd, s, wt, 0);
+  const double nss = sfb_time_2d(cd, s, wt, 1);
+  Stencil s3;
+  stencil_3d(M, A, p, P.lon, P.lat, s3);   // at the clamped pressure
+  const double t = temp_time_3d(M, s3, wt);
+  const double h2o = pair_time_3d(M.h2o, M, s3, wt);
+
+  const double tv = tvirt(t, h2o);
+  const double thetav = tvirt(t * pow(1000. / p, kKappa), dmax(h2o, 0.1e-6));   // THETAVIRT, mptrac.h:2153
+  const double rho = rho_air(p, tv);
+  const double tau = sqrt(ess * ess + nss * nss);
+  if (!(rho > 0.0))
+    return;
+  const double ustar = sqrt(dmax(tau / rho, 0.0));
+  const double ust = dmax(1e-4, ustar);
+  const double shf = sfb_time_2d(cd, s, wt, 2);   // INTPOL_2D(shf, 1): same stencil again
+  double ol = 1e12;
+  if (fabs(shf) > 1e-6)
+    ol = thetav * rho * kCpd * (ust * ust) * ust / (kKarman * kG0 * shf);
+
+  if (zi / fabs(ol) < 1.0) {   // neutral
+    const double corr = z_m / ust;
+    const double sigw0 = 1.3 * ust * exp(-2e-4 * corr);
+    sig_u = dmax(2.0 * ust * exp(-3e-4 * corr), 1e-5);
+    sig_v = dmax(sigw0, 1e-5);
+    sig_w = dmax(sigw0, 1e-5);
+    dsigw_dz = -2e-4 * sigw0 / ust;
+    tau_u = 0.5 * z_m / sig_w / (1.0 + 1.5e-3 * corr);
+    tau_v = tau_u;
+    tau_w = tau_u;
+  } else if (ol < 0.0) {       // unstable
+    const double wstar_arg = -kG0 / thetav * shf / (rho * kCpd) * zi;
+    const double wstar = pow(dmax(wstar_arg, 0.0), 1.0 / 3.0);
+    double dsigw2_dz = 0.0;
+    sig_u = dmax(ust * pow(dmax(12.0 - 0.5 * zi / ol, 0.0), 1.0 / 3.0), 1e-6);
+    sig_v = sig_u;
+    if (zeta < 0.03) {
+      const double arg = dmax(3.0 * zeta - ol / zi, 1e-12);
+      sig_w = 0.96 * wstar * pow(arg, 1.0 / 3.0);
+      dsigw2_dz = 1.8432 * (wstar * wstar) / zi * pow(arg, -1.0 / 3.0);
+    } else if (zeta < 0.4) {
+      const double arg = dmax(3.0 * zeta - ol / zi, 1e-12);
+      const double s1 = 0.96 * pow(arg, 1.0 / 3.0);
+      const double s2 = 0.763 * pow(zeta, 0.175);
+      if (s1 < s2) {
+        sig_w = wstar * s1;
+        dsigw2_dz = 1.8432 * (wstar * wstar) / zi * pow(arg, -1.0 / 3.0);
+      } else {
+        sig_w = wstar * s2;
+        dsigw2_dz = 0.203759 * (wstar * wstar) / zi * pow(zeta, -0.65);
+      }
+    } else if (zeta < 0.96) {
+      sig_w = 0.722 * wstar * pow(1.0 - zeta, 0.207);
+      dsigw2_dz = -0.215812 * (wstar * wstar) / zi * pow(1.0 - zeta, -0.586);
+    } else {
+      sig_w = 0.37 * wstar;
+      dsigw2_dz = 0.0;
+    }
+    sig_w = dmax(sig_w, 1e-6);
+    dsigw_dz = sig_w > 1e-12 ? 0.5 * dsigw2_dz / sig_w : 0.0;
+    tau_u = 0.15 * zi / dmax(sig_u, 1e-12);
+    tau_v = tau_u;
+    if (z_m < fabs(ol)) {
+      const double denom = 0.55 - 0.38 * fabs(z_m / ol);
+      tau_w = 0.1 * z_m / (sig_w * dmax(denom, 0.05));
+    } else if (zeta < 0.1)
+      tau_w = 0.59 * z_m / sig_w;
+    else
+      tau_w = 0.15 * zi / sig_w * (1.0 - exp(-5.0 * zeta));
+  } else {                     // stable
+    sig_u = dmax(2.0 * ust * (1.0 - zeta), 1e-6);
+    sig_v = dmax(1.3 * ust * (1.0 - zeta), 1e-6);
+    sig_w = dmax(1.3 * ust * (1.0 - zeta), 1e-6);
+    dsigw_dz = -1.3 * ust / zi;
+    tau_u = 0.15 * zi / sig_u * sqrt(zeta);
+    tau_v = 0.467 * tau_u;
+    tau_w = 0.1 * zi / sig_w * pow(zeta, 0.8);
+  }
+  tau_u = dmax(tau_u, 10.0);
+  tau_v = dmax(tau_v, 10.0);
+  tau_w = dmax(tau_w, 30.0);
+  if (!(sig_u > 0.0 && sig_v > 0.0 && sig_w > 0.0 && tau_u > 0.0 && tau_v > 0.0 && tau_w > 0.0))
+    return;
+
+  double rs0, rs1, rs2;
+  normal_triple(ctr, g, rs0, rs1, rs2);
+  const double dt = P.dt, dt_abs = fabs(P.dt);
+  const double ru = exp(-dt_abs / tau_u);
+  const double ru2 = sqrt(dmax(0.0, 1.0 - ru * ru));
+  const double rv = exp(-dt_abs / tau_v);
+  const double rv2 = sqrt(dmax(0.0, 1.0 - rv * rv));
+  up = (float) (up * ru + sig_u * ru2 * rs0);
+  vp = (float) (vp * rv + sig_v * rv2 * rs1);
+  const double rw = exp(-dt_abs / tau_w);
+  const double rw2 = sqrt(dmax(0.0, 1.0 - rw * rw));
+  const double rhoaux = -1.0 / (1e3 * kH0);
+  wp = (float) (wp * rw + sig_w * rw2 * rs2 + tau_w * (1.0 - rw) * (2.0 * sig_w * dsigw_dz + rhoaux * (sig_w * sig_w)));
+  P.lon += dx2coord(ct, up * dt, P.lat);
+  P.lat += dy2coord(ct, vp * dt);
+  double znew = z + wp * dt;
+  while (znew < 0.0 || znew > zi) {
+    if (znew < 0.0) {
+      znew = -znew;
+      wp = -wp;
+    }
+    if (znew > zi) {
+      znew = 2.0 * zi - znew;
+      wp = -wp;
+    }
+  }
+  P.p = kP0 * exp(-(zs + znew / 1000.0) / kH0);   // P(z), mptrac.h:1784
+  P.p = clampd(P.p, pbl, ps);
 }
 
 // module_diff_meso, mptrac.c:4280-4338

@@ -23,12 +23,12 @@ struct StepParams {
   double t;
   unsigned mask;          // MPHIP_MOD_* bits to run (when the kernel is the generic instantiation)
   int nblocks_logical;    // multiple of 8
-  uint64_t ctr_turb, ctr_meso, ctr_conv;   // base counters of the module_rng calls
+  uint64_t ctr_turb, ctr_meso, ctr_conv, ctr_pbl;   // base counters of the module_rng calls
 };
 
 constexpr unsigned kMaskGeneric = 0xffffffffu;
 constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a later launch reads it)
-constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO
+constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI | MPHIP_MOD_POSITION2;
 
 // common tail of decay / wet / dry deposition (mptrac.c:4251-4260, 6279-6288, 4786-4795)
@@ -201,6 +201,13 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     }
     if (mask & MPHIP_MOD_DIFF_TURB)
       diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g);
+    if (CT == kMaskGeneric && (mask & MPHIP_MOD_DIFF_PBL)) {
+      float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
+      diff_pbl(M, A, P, up, vp, wp, S.ctr_pbl, g);
+      a.up[i] = up;
+      a.vp[i] = vp;
+      a.wp[i] = wp;
+    }
     if (mask & MPHIP_MOD_DIFF_MESO) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
       diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g);
@@ -248,7 +255,8 @@ struct PackArgs {
   const float *f3[2][MPHIP_N3D];   // [snapshot][field]
   const float *f2[2][MPHIP_N2D];
   float *wind, *temp;
-  f32x4 *cloud, *sfa, *sfb, *sfc;
+  f32x4 *cloud, *sfa, *sfb, *sfc, *sfd;
+  float *h2o;                      // {h2o}0 {h2o}1 (NULL: none)
   float *mlw;                      // model-level {ul,vl,zeta_dot} records (NULL: none)
   size_t ncell, ncol, ncell_ml;
 };
@@ -262,6 +270,8 @@ __global__ void pack_kernel(PackArgs a) {
       for (int k = 0; k < 3; k++)
         a.wind[6 * i + 3 * t + k] = a.f3[t][MPHIP_U + k] ? a.f3[t][MPHIP_U + k][i] : 0.f;
       a.temp[2 * i + t] = a.f3[t][MPHIP_T] ? a.f3[t][MPHIP_T][i] : 0.f;
+      if (a.h2o)
+        a.h2o[2 * i + t] = a.f3[t][MPHIP_H2O] ? a.f3[t][MPHIP_H2O][i] : 0.f;
       if (a.cloud) {
         f32x4 v;
 #pragma unroll
@@ -296,6 +306,14 @@ __global__ void pack_kernel(PackArgs a) {
       vc[3] = 0.f;
       a.sfb[2 * i + t] = vb;
       a.sfc[2 * i + t] = vc;
+      if (a.sfd) {
+        f32x4 vd;
+        vd[0] = a.f2[t][MPHIP_ESS] ? a.f2[t][MPHIP_ESS][i] : 0.f;
+        vd[1] = a.f2[t][MPHIP_NSS] ? a.f2[t][MPHIP_NSS][i] : 0.f;
+        vd[2] = a.f2[t][MPHIP_SHF] ? a.f2[t][MPHIP_SHF][i] : 0.f;
+        vd[3] = 0.f;
+        a.sfd[2 * i + t] = vd;
+      }
     }
     a.sfa[i] = va;
   }

@@ -324,8 +324,6 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
     ERRMSG("Please add zeta to your quantities for diabatic calculations!");   /* mptrac.c:6992 */
   if (ctl->advect_vert_coord == 3 && ctl->qnt_eta < 0)
     ERRMSG("Please add eta to your quantities for etadot calculations!");      /* mptrac.c:6994 */
-  if (ctl->diffusion && ctl->turb_pbl_scheme == 1)
-    ERRMSG("This build does not implement module_diff_pbl (TURB_PBL_SCHEME 1)!");
 }
 
 /* -------------------------------------------------------------------------- */
@@ -581,11 +579,11 @@ static void met_bin_body(FILE *f, int write, met_t *met) {
    * skipped on read and written as zeros */
   float *help;
   ALLOC(help, float, (size_t) met->nx * (size_t) met->ny * (size_t) met->np);
-  float (*s2[24])[EY] = { met->ps, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, met->pbl, NULL, NULL,
+  float (*s2[24])[EY] = { met->ps, NULL, NULL, NULL, NULL, met->ess, met->nss, met->shf, NULL, NULL, met->pbl, NULL, NULL,
     NULL, NULL, met->pct, met->pcb, met->cl, NULL, NULL, met->pel, met->cape, met->cin, NULL };
   for (int k = 0; k < 24; k++)
     bin_2d(f, write, met, s2[k], help);
-  float (*s3[13])[EY][EP] = { NULL, met->t, met->u, met->v, met->w, NULL, NULL, NULL, met->lwc, met->rwc, met->iwc,
+  float (*s3[13])[EY][EP] = { NULL, met->t, met->u, met->v, met->w, NULL, met->h2o, NULL, met->lwc, met->rwc, met->iwc,
     met->swc, NULL };
   const float lo[13] = { -1e34f, 0, -1e34f, -1e34f, -1e34f, -1e34f, 0, 0, 0, 0, 0, 0, 0 };
   const float hi[13] = { 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1 };
@@ -767,6 +765,10 @@ static void upload_met(met_t *met, int slot) {
   m.f2[MPHIP_PCT] = &met->pct[0][0];
   m.f2[MPHIP_PCB] = &met->pcb[0][0];
   m.f2[MPHIP_CL] = &met->cl[0][0];
+  m.f2[MPHIP_ESS] = &met->ess[0][0];
+  m.f2[MPHIP_NSS] = &met->nss[0][0];
+  m.f2[MPHIP_SHF] = &met->shf[0][0];
+  m.f3[MPHIP_H2O] = &met->h2o[0][0][0];
   HIP(mphip_update_met(g_ctx, slot, &m));
 }
 

@@ -169,7 +169,8 @@ typedef struct {
   int nx, ny, np, npl;
   double lon[EX], lat[EY], p[EP];
   float ps[EX][EY], pbl[EX][EY], cape[EX][EY], cin[EX][EY], pel[EX][EY];
-  float pct[EX][EY], pcb[EX][EY], cl[EX][EY];
+  float pct[EX][EY], pcb[EX][EY], cl[EX][EY], ess[EX][EY], nss[EX][EY], shf[EX][EY];
+  float h2o[EX][EY][EP];
   float t[EX][EY][EP], u[EX][EY][EP], v[EX][EY][EP], w[EX][EY][EP];
   float lwc[EX][EY][EP], rwc[EX][EY][EP], iwc[EX][EY][EP], swc[EX][EY][EP];
   /* model levels (mptrac.h:3997-4012); not part of the MET_TYPE 1 file format, filled by the caller */

@@ -13,9 +13,9 @@ import numpy as np
 P0 = 1013.25   # mptrac.h:305
 H0 = 7.0       # mptrac.h:270
 
-FIELDS_3D = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "pl", "ul", "vl", "zetal", "zeta_dotl")
+FIELDS_3D = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "pl", "ul", "vl", "zetal", "zeta_dotl", "h2o")
 FIELDS_ML = ("pl", "ul", "vl", "zetal", "zeta_dotl")     # on model levels [nx][ny][npl]
-FIELDS_2D = ("ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl")
+FIELDS_2D = ("ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "ess", "nss", "shf")
 
 GRIDS = {
     # name: (NX without the periodic column, NY, NP)
@@ -88,6 +88,7 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
     put3("rwc", 2e-6 * amp * np.maximum(0.0, np.cos(lam) * cphi) * (k < npl // 4))
     put3("iwc", 1e-6 * np.maximum(0.0, -np.sin(lam)) * cphi * (k < npl // 3) + 0.0 * k)
     put3("swc", 0.0 * lam * phi * k)
+    put3("h2o", 1e-2 * np.exp(-k * (60.0 / npl) / 2.5) * cphi * (1.0 + 0.2 * amp * np.sin(lam)))
 
     if want & set(FIELDS_ML):
         # terrain-following model levels: p = sigma_k * ps (sigma 1 -> ~2e-4), zeta = a potential-temperature-like
@@ -123,6 +124,10 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
     put2("pct", 400.0 + 100.0 * np.cos(lam2) + 0.0 * phi2)
     put2("pcb", 800.0 + 0.0 * lam2 * phi2)
     put2("cl", 0.7 + 0.4 * amp * np.sin(lam2) * np.cos(phi2))
+    # surface stresses [N/m^2] and sensible heat flux [W/m^2]: all three stability regimes occur
+    put2("ess", 0.15 * amp * np.cos(lam2) * np.cos(phi2))
+    put2("nss", 0.05 * np.sin(2.0 * lam2) + 0.0 * phi2)
+    put2("shf", 60.0 * amp * np.sin(3.0 * lam2) * np.cos(phi2) * (np.abs(np.sin(7.0 * phi2)) > 0.3))
 
     # periodic column is an exact copy of column 0 (mptrac.c:11726-11769)
     for d in (f3, f2):

@@ -182,6 +182,8 @@ class Oracle:
             L.orc_module_advect(ctl, cache, m0, m1, atm)
         elif name == "diff_turb":
             L.orc_module_diff_turb(ctl, cache, clim, m0, m1, atm)
+        elif name == "diff_pbl":
+            L.orc_module_diff_pbl(ctl, cache, m0, m1, atm)
         elif name == "diff_meso":
             L.orc_module_diff_meso(ctl, cache, m0, m1, atm)
         elif name == "convection":

@@ -36,6 +36,11 @@
 #define C_WD_T_LIQUID C_T0
 #define C_WD_T_ICE 238.15
 #define C_WD_T_LIQUID_BC 270.
+#define C_MH2O 18.01528
+#define C_EPS (C_MH2O / C_MA)
+#define C_KAPPA 0.286
+#define C_CPD 1003.5
+#define C_KARMAN 0.40
 
 #define SQ(x) ((x) * (x))
 
@@ -792,6 +797,159 @@ void orc_module_diff_turb(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_cl
   }
 }
 
+/* ---- module_diff_pbl (mptrac.c:4343-4584) ------------------------------- */
+
+static inline double clampd(double v, double lo, double hi) {   /* CLAMP, mptrac.h:756 */
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+/* TVIRT, mptrac.h:2199 */
+static inline double tvirt(double t, double h2o) {
+  return t * (1. + (1. - C_EPS) * dmax(h2o, 0.1e-6));
+}
+
+void orc_module_diff_pbl(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                         const orc_met_t *met1, orc_atm_t *atm) {
+  orc_module_rng(ctl, cache, 3 * (size_t) atm->np, 1);
+  const int ct = met0->coord_type;
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    double dsigw_dz = 0.0, sig_u = 0.0, sig_v = 0.0, sig_w = 0.0, tau_u = 0.0, tau_v = 0.0, tau_w = 0.0;
+    const double tp = atm->time[ip], lon = atm->lon[ip], lat = atm->lat[ip];
+    stencil_t s = STENCIL_ZERO;
+    const double pbl = time_2d(met0, met1, ORC_PBL, tp, lon, lat, &s, 1);
+    if (atm->p[ip] < pbl)
+      continue;
+    const double ps = time_2d(met0, met1, ORC_PS, tp, lon, lat, &s, 0);
+    if (!(ps > 0.0 && pbl > 0.0 && ps > pbl))
+      continue;
+    const double p = dmin(atm->p[ip], ps);
+    const double zs = zfromp(ps);
+    const double z_raw = 1e3 * (zfromp(p) - zs);
+    const double zi = 1e3 * (zfromp(pbl) - zs);
+    if (!(zi > 1.0))
+      continue;
+    const double z = clampd(z_raw, 0.0, zi);
+    const double zeta = clampd(z / zi, 1e-6, 1.0 - 1e-6);
+    const double z_m = dmax(z, 1.0);
+
+    const double ess = time_2d(met0, met1, ORC_ESS, tp, lon, lat, &s, 0);
+    const double nss = time_2d(met0, met1, ORC_NSS, tp, lon, lat, &s, 0);
+    /* INTPOL_3D at the clamped pressure (the reference overwrites atm->p temporarily) */
+    const double t = time_3d(met0, met1, ORC_T, tp, p, lon, lat, &s, 1);
+    const double h2o = time_3d(met0, met1, ORC_H2O, tp, p, lon, lat, &s, 0);
+
+    const double tv = tvirt(t, h2o);
+    const double thetav = tvirt(t * pow(1000. / p, C_KAPPA), dmax(h2o, 0.1e-6));   /* THETAVIRT */
+    const double rho = rho_air(p, tv);
+    const double tau = sqrt(SQ(ess) + SQ(nss));
+    if (!(rho > 0.0))
+      continue;
+    const double ustar = sqrt(dmax(tau / rho, 0.0));
+    const double ust = dmax(1e-4, ustar);
+    const double shf = time_2d(met0, met1, ORC_SHF, tp, lon, lat, &s, 1);
+    double ol = 1e12;
+    if (fabs(shf) > 1e-6)
+      ol = thetav * rho * C_CPD * SQ(ust) * ust / (C_KARMAN * C_G0 * shf);
+
+    if (zi / fabs(ol) < 1.0) {          /* neutral */
+      const double corr = z_m / ust;
+      const double sigw0 = 1.3 * ust * exp(-2e-4 * corr);
+      sig_u = dmax(2.0 * ust * exp(-3e-4 * corr), 1e-5);
+      sig_v = dmax(sigw0, 1e-5);
+      sig_w = dmax(sigw0, 1e-5);
+      dsigw_dz = -2e-4 * sigw0 / ust;
+      tau_u = 0.5 * z_m / sig_w / (1.0 + 1.5e-3 * corr);
+      tau_v = tau_u;
+      tau_w = tau_u;
+    } else if (ol < 0.0) {              /* unstable */
+      const double wstar_arg = -C_G0 / thetav * shf / (rho * C_CPD) * zi;
+      const double wstar = pow(dmax(wstar_arg, 0.0), 1.0 / 3.0);
+      double dsigw2_dz = 0.0;
+      sig_u = dmax(ust * pow(dmax(12.0 - 0.5 * zi / ol, 0.0), 1.0 / 3.0), 1e-6);
+      sig_v = sig_u;
+      if (zeta < 0.03) {
+        const double arg = dmax(3.0 * zeta - ol / zi, 1e-12);
+        sig_w = 0.96 * wstar * pow(arg, 1.0 / 3.0);
+        dsigw2_dz = 1.8432 * SQ(wstar) / zi * pow(arg, -1.0 / 3.0);
+      } else if (zeta < 0.4) {
+        const double arg = dmax(3.0 * zeta - ol / zi, 1e-12);
+        const double s1 = 0.96 * pow(arg, 1.0 / 3.0);
+        const double s2 = 0.763 * pow(zeta, 0.175);
+        if (s1 < s2) {
+          sig_w = wstar * s1;
+          dsigw2_dz = 1.8432 * SQ(wstar) / zi * pow(arg, -1.0 / 3.0);
+        } else {
+          sig_w = wstar * s2;
+          dsigw2_dz = 0.203759 * SQ(wstar) / zi * pow(zeta, -0.65);
+        }
+      } else if (zeta < 0.96) {
+        sig_w = 0.722 * wstar * pow(1.0 - zeta, 0.207);
+        dsigw2_dz = -0.215812 * SQ(wstar) / zi * pow(1.0 - zeta, -0.586);
+      } else {
+        sig_w = 0.37 * wstar;
+        dsigw2_dz = 0.0;
+      }
+      sig_w = dmax(sig_w, 1e-6);
+      dsigw_dz = sig_w > 1e-12 ? 0.5 * dsigw2_dz / sig_w : 0.0;
+      tau_u = 0.15 * zi / dmax(sig_u, 1e-12);
+      tau_v = tau_u;
+      if (z_m < fabs(ol)) {
+        const double denom = 0.55 - 0.38 * fabs(z_m / ol);
+        tau_w = 0.1 * z_m / (sig_w * dmax(denom, 0.05));
+      } else if (zeta < 0.1)
+        tau_w = 0.59 * z_m / sig_w;
+      else
+        tau_w = 0.15 * zi / sig_w * (1.0 - exp(-5.0 * zeta));
+    } else {                            /* stable */
+      sig_u = dmax(2.0 * ust * (1.0 - zeta), 1e-6);
+      sig_v = dmax(1.3 * ust * (1.0 - zeta), 1e-6);
+      sig_w = dmax(1.3 * ust * (1.0 - zeta), 1e-6);
+      dsigw_dz = -1.3 * ust / zi;
+      tau_u = 0.15 * zi / sig_u * sqrt(zeta);
+      tau_v = 0.467 * tau_u;
+      tau_w = 0.1 * zi / sig_w * pow(zeta, 0.8);
+    }
+    tau_u = dmax(tau_u, 10.0);
+    tau_v = dmax(tau_v, 10.0);
+    tau_w = dmax(tau_w, 30.0);
+    if (!(sig_u > 0.0 && sig_v > 0.0 && sig_w > 0.0 && tau_u > 0.0 && tau_v > 0.0 && tau_w > 0.0))
+      continue;
+
+    const double dt = cache->dt[ip];
+    const double dt_abs = fabs(dt);
+    float *uvwp = &cache->uvwp[3 * (size_t) ip];
+    const double ru = exp(-dt_abs / tau_u);
+    const double ru2 = sqrt(dmax(0.0, 1.0 - SQ(ru)));
+    const double rv = exp(-dt_abs / tau_v);
+    const double rv2 = sqrt(dmax(0.0, 1.0 - SQ(rv)));
+    uvwp[0] = (float) (uvwp[0] * ru + sig_u * ru2 * cache->rs[3 * (size_t) ip]);
+    uvwp[1] = (float) (uvwp[1] * rv + sig_v * rv2 * cache->rs[3 * (size_t) ip + 1]);
+    const double rw = exp(-dt_abs / tau_w);
+    const double rw2 = sqrt(dmax(0.0, 1.0 - SQ(rw)));
+    const double rhoaux = -1.0 / (1e3 * C_H0);
+    uvwp[2] = (float) (uvwp[2] * rw + sig_w * rw2 * cache->rs[3 * (size_t) ip + 2]
+                       + tau_w * (1.0 - rw) * (2.0 * sig_w * dsigw_dz + rhoaux * SQ(sig_w)));
+    atm->lon[ip] += dx2coord(ct, uvwp[0] * dt, atm->lat[ip]);
+    atm->lat[ip] += dy2coord(ct, uvwp[1] * dt);
+    double znew = z + uvwp[2] * dt;
+    while (znew < 0.0 || znew > zi) {
+      if (znew < 0.0) {
+        znew = -znew;
+        uvwp[2] = -uvwp[2];
+      }
+      if (znew > zi) {
+        znew = 2.0 * zi - znew;
+        uvwp[2] = -uvwp[2];
+      }
+    }
+    atm->p[ip] = C_P0 * exp(-(zs + znew / 1000.0) / C_H0);     /* P(z), mptrac.h:1784 */
+    atm->p[ip] = clampd(atm->p[ip], pbl, ps);
+  }
+}
+
 /* ---- module_diff_meso (mptrac.c:4266-4339) ------------------------------ */
 
 void orc_module_diff_meso(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
@@ -1192,7 +1350,7 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
           || ctl->turb_dz_trop > 0 || ctl->turb_dx_strat > 0 || ctl->turb_dz_strat > 0))
     orc_module_diff_turb(ctl, cache, clim, met0, met1, atm);
   if (ctl->diffusion && ctl->turb_pbl_scheme == 1)
-    die("oracle does not restate module_diff_pbl");
+    orc_module_diff_pbl(ctl, cache, met0, met1, atm);
   if (ctl->diffusion && (ctl->turb_mesox > 0 || ctl->turb_mesoz > 0))
     orc_module_diff_meso(ctl, cache, met0, met1, atm);
   if ((ctl->conv_mix_pbl || ctl->conv_cape >= 0)

@@ -31,9 +31,11 @@ extern "C" {
 /* 3-D met fields, each float [nx][ny][np] (level index fastest, mptrac.h:3964) */
 enum { ORC_U = 0, ORC_V, ORC_W, ORC_T, ORC_LWC, ORC_RWC, ORC_IWC, ORC_SWC,
        /* model-level fields, float [nx][ny][npl] (mptrac.h:3997-4012) */
-       ORC_PL, ORC_UL, ORC_VL, ORC_ZETAL, ORC_ZETA_DOTL, ORC_N3D };
+       ORC_PL, ORC_UL, ORC_VL, ORC_ZETAL, ORC_ZETA_DOTL,
+       ORC_H2O, ORC_N3D };
 /* 2-D met fields, each float [nx][ny] */
-enum { ORC_PS = 0, ORC_PBL, ORC_CAPE, ORC_CIN, ORC_PEL, ORC_PCT, ORC_PCB, ORC_CL, ORC_N2D };
+enum { ORC_PS = 0, ORC_PBL, ORC_CAPE, ORC_CIN, ORC_PEL, ORC_PCT, ORC_PCB, ORC_CL,
+       ORC_ESS, ORC_NSS, ORC_SHF, ORC_N2D };
 
 /* Hot-path subset of ctl_t (mptrac.h:2494-3553).  Field names follow the
  * reference.  Layout is mirrored 1:1 by the Python ctypes class. */
@@ -147,6 +149,8 @@ void orc_module_advect_init(const orc_ctl_t *ctl, const orc_met_t *met0, const o
                             orc_atm_t *atm);   /* mptrac.c:3762 */
 void orc_module_diff_turb(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
                           const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_diff_pbl(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                         const orc_met_t *met1, orc_atm_t *atm);   /* mptrac.c:4343 */
 void orc_module_diff_meso(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
                           const orc_met_t *met1, orc_atm_t *atm);
 void orc_module_convection(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,

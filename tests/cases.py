@@ -14,6 +14,11 @@ CASES = {
     "advect_euler": dict(BASE, advect=1),
     # + turbulent diffusion (config 1)
     "turb": dict(BASE, diffusion=1, turb_mesox=0.0, turb_mesoz=0.0, turb_dz_trop=0.1, turb_dz_pbl=0.5),
+    # Hanna / FLEXPART closure inside the boundary layer (TURB_PBL_SCHEME 1)
+    "pbl": dict(BASE, diffusion=1, turb_pbl_scheme=1, turb_dz_trop=0.1, turb_mesox=0.0, turb_mesoz=0.0),
+    # (the closure keeps uvwp[2] in m/s, module_diff_meso in hPa/s: with both vertical parts on the reference
+    # itself drives pressures negative, so the combined case keeps the mesoscale part horizontal)
+    "pbl_meso": dict(BASE, diffusion=1, turb_pbl_scheme=1, turb_mesoz=0.0, conv_cape=0.0),
     # + mesoscale diffusion
     "diff": dict(BASE, diffusion=1, turb_dz_trop=0.1),
     # + convection + sedimentation (config 2)
@@ -38,8 +43,8 @@ CASES = {
 
 QUANTITIES = ("m", "rp", "rhop", "vmr", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry")
 QUANTITIES_ML = QUANTITIES + ("zeta", "eta")
-PRESSURE_LEVEL_FIELDS = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "ps", "pbl", "cape", "cin", "pel", "pct",
-                         "pcb", "cl")
+PRESSURE_LEVEL_FIELDS = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "h2o", "ps", "pbl", "cape", "cin", "pel",
+                         "pct", "pcb", "cl", "ess", "nss", "shf")
 
 
 def make_case(name, n=10000, grid="C1", seed=12345, quantities=None, lon0=-180.0, fields=None):
@@ -50,12 +55,14 @@ def make_case(name, n=10000, grid="C1", seed=12345, quantities=None, lon0=-180.0
     if fields is None and not ml:
         fields = PRESSURE_LEVEL_FIELDS          # model-level fields only where they are used
     ctl.update(ctl_from_quantities(quantities))
-    if name.startswith("advect") or name in ("turb", "diff", "conv_thresh"):
+    if name.startswith("advect") or name in ("turb", "diff", "conv_thresh", "pbl"):
         # no sedimentation in these
         ctl["qnt_rp"] = ctl["qnt_rhop"] = -1
     met0 = synthetic_met(grid, 0.0, 1.0, fields=fields, lon0=lon0)
     met1 = synthetic_met(grid, 3600.0, 1.25, fields=fields, lon0=lon0)
     atm = synthetic_particles(n, seed=seed, quantities=quantities)
+    if ctl.get("turb_pbl_scheme", 0):      # half of the particles inside the boundary layer
+        atm["p"][::2] = 1013.25 * np.exp(-(0.02 + 0.9 * (atm["lon"][::2] + 180.0) / 360.0) / 7.0)
     for name_q in ("zeta", "eta"):
         if name_q in quantities:     # a vertical coordinate inside the range of the synthetic zetal field
             atm["q"][list(quantities).index(name_q)] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)

@@ -101,7 +101,7 @@ def test_rng_stream_matches_module_rng(ctr, n):
 # ---------------------------------------------------------------------------
 
 MODULE_CASES = [("position", "advect"), ("advect", "advect"), ("advect", "advect_midpoint"),
-                ("advect", "advect_zeta"), ("advect", "advect_eta"),
+                ("advect", "advect_zeta"), ("advect", "advect_eta"), ("diff_pbl", "pbl"), ("diff_pbl", "pbl_meso"),
                 ("advect", "advect_euler"), ("diff_turb", "turb"), ("diff_meso", "diff"),
                 ("convection", "conv_sedi"), ("convection", "conv_thresh"), ("sedi", "conv_sedi"),
                 ("decay", "full"), ("wet_depo", "full"), ("wet_depo", "wet_henry"), ("dry_depo", "full")]
