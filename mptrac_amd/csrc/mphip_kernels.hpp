@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t 
 // total; a single workgroup then scans the chunk totals (m / kScanChunk <=
 // 1024 of them); the scatter kernel adds the two.
 constexpr int kScanThreads = 1024;
-constexpr int kScanPer = 4;
+constexpr int kScanPer = 16;     // 1024 x 16 counters per chunk, <= 1024 chunks: up to 2.6e8 particles per context
 constexpr int kScanChunk = kScanThreads * kScanPer;
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wsum, uint32_t *total) {

@@ -482,3 +482,44 @@ def test_cartesian_coordinates():
     assert 0 < moved.sum() < len(moved) and np.ptp(o.lon[moved]) > 1e4
     _compare(o, s)
     s.close()
+
+
+def test_full_size_stochastic_parity_1e6():
+    """10^6 particles on the 137-level grid with every stochastic module on
+    (random numbers depend on the global particle index, so the oracle runs the
+    whole set): 6 steps against the 16-thread oracle."""
+    n = 10 ** 6
+    ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=n, grid="C2",
+                                             fields=("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel"),
+                                             quantities=("m", "rp", "rhop"))
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    for t in cases.step_times(o.ctl)[:7]:
+        o.run_timestep(t)
+        s.run_timestep(t)
+    _compare(o, s)
+    s.close()
+
+
+def test_sort_scales_to_1e8_keys():
+    """The radix sort's two-level scan covers 10^8 particles in one context
+    (288 GB of HBM hold them easily): sortedness, permutation, stability."""
+    n = 10 ** 8
+    m0 = synthetic_met("C1", 0.0, 1.0, fields=("u", "v", "w", "ps"))
+    m1 = synthetic_met("C1", 3600.0, 1.2, fields=("u", "v", "w", "ps"))
+    atm = synthetic_particles(n, quantities=())
+    ctl = dict(cases.BASE, nq=0)
+    s = hip.Simulation(ctl, load_clim(), m0, m1, atm)
+    keys, perm = s.sort()
+    assert np.all(np.diff(keys) >= 0)
+    assert np.array_equal(np.bincount(perm, minlength=n), np.ones(n, dtype=np.int64))
+    ties = keys[1:] == keys[:-1]
+    assert np.all(perm[1:][ties] > perm[:-1][ties])
+    s.close()
+
+
+def load_clim():
+    from mptrac_amd.clim import load_clim_tropo
+    return load_clim_tropo()

@@ -18,7 +18,7 @@ T0 = 707443200.0      # 2022-06-02 00:00 UTC, as tests/dd_test of the reference
 QUANT = ("m", "rp", "rhop")
 
 
-def _setup(tmp, n=3000, hours=2, atm_type=1):
+def _setup(tmp, n=3000, hours=2, atm_type=1, pbl=False):
     lib, trac = build.build_host()
     metbase = os.path.join(tmp, "met")
     mets = []
@@ -27,20 +27,26 @@ def _setup(tmp, n=3000, hours=2, atm_type=1):
         hf.write_met_bin(hf.met_filename(metbase, m.time), m)
         mets.append(m)
     atm = synthetic_particles(n, time=T0, quantities=QUANT)
+    if pbl:      # half of the particles inside the boundary layer
+        atm["p"][::2] = 1013.25 * np.exp(-(0.02 + 0.9 * (atm["lon"][::2] + 180.0) / 360.0) / 7.0)
     (hf.write_atm_bin if atm_type == 1 else hf.write_atm_asc)(os.path.join(tmp, "atm_in"), atm)
     keys = {"NQ": 3, "QNT_NAME[0]": "m", "QNT_NAME[1]": "rp", "QNT_NAME[2]": "rhop", "METBASE": metbase,
             "MET_TYPE": 1, "DT_MET": 3600, "DT_MOD": 180, "ADVECT": 4, "DIFFUSION": 1, "TURB_DZ_TROP": 0.1,
             "CONV_CAPE": 0, "T_STOP": T0 + 3600.0 * hours, "ATM_TYPE": atm_type, "ATM_TYPE_OUT": 1,
             "ATM_BASENAME": "atm", "ATM_DT_OUT": 3600, "GRID_BASENAME": "grid", "GRID_DT_OUT": 3600,
             "GRID_NX": 36, "GRID_NY": 18, "MET_DT_OUT": 0}
+    if pbl:
+        keys.update({"TURB_PBL_SCHEME": 1, "TURB_MESOZ": 0})
     hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
     open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
     return trac, mets, atm
 
 
-def _oracle(mets, atm, hours):
+def _oracle(mets, atm, hours, pbl=False):
     ctl = dict(advect=4, dt_mod=180.0, dt_met=3600.0, diffusion=1, turb_dz_trop=0.1, conv_cape=0.0,
                t_stop=T0 + 3600.0 * hours, nq=3, qnt_m=0, qnt_rp=1, qnt_rhop=2)
+    if pbl:
+        ctl.update(turb_pbl_scheme=1, turb_mesoz=0.0)
     o = B.Oracle(ctl, load_clim_tropo(), mets[0], mets[1], atm)
     o.timesteps_init()
     imet = 0
@@ -68,10 +74,10 @@ def test_trac_refuses_to_run_without_a_device(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("atm_type", [1, 0])
-def test_trac_end_to_end_matches_oracle(tmp_path, atm_type):
+@pytest.mark.parametrize("atm_type,pbl", [(1, False), (0, False), (1, True)])
+def test_trac_end_to_end_matches_oracle(tmp_path, atm_type, pbl):
     tmp = str(tmp_path)
-    trac, mets, atm = _setup(tmp, n=3000, hours=2, atm_type=atm_type)
+    trac, mets, atm = _setup(tmp, n=3000, hours=2, atm_type=atm_type, pbl=pbl)
     r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT)
     out = r.stdout.decode()
@@ -79,7 +85,7 @@ def test_trac_end_to_end_matches_oracle(tmp_path, atm_type):
     if atm_type == 0:
         # ASCII input carries altitude; the driver converts with P(z) like the reference
         atm = dict(atm, p=1013.25 * np.exp(-(7.0 * np.log(1013.25 / atm["p"])) / 7.0))
-    snaps = _oracle(mets, atm, 2)
+    snaps = _oracle(mets, atm, 2, pbl=pbl)
     for hour in (0, 1, 2):
         t = T0 + 3600.0 * hour
         f = os.path.join(tmp, "atm_2022_06_02_%02d_00_00.bin" % hour)
