@@ -191,7 +191,9 @@ int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
  *   returns the caller's order, so results do not depend on the value.
  *   0 switches it off.
  *   "locality_tile" (default 8): edge, in grid columns, of the horizontal tiles of
- *   that order (tile, then level, then column within the tile). */
+ *   that order (tile, then level, then column within the tile).
+ *   "step_blocks" (default 8192): upper bound of the step kernel's grid;
+ *   "xcd_map" (default 1): give each XCD one contiguous eighth of the particles. */
 int mphip_set_option(mphip_ctx *ctx, const char *name, double value);
 int mphip_synchronize(mphip_ctx *ctx);
 

@@ -76,6 +76,8 @@ struct mphip_ctx {
   bool ext_identity = true;
   int locality_interval = 10;         // re-sort every this many steps (0 = keep the caller's order)
   int locality_tile = 8;              // horizontal tile edge of the locality key (columns)
+  int step_blocks = 4096;             // upper bound of the step kernel's grid
+  int xcd_map = 1;
   int steps_since_resort = 1 << 30;
 
   // sort
@@ -421,9 +423,10 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   S.clim = ctx->d_clim;
   S.t = t;
   S.mask = mask;
-  int nb = grid_for(ctx->np, 256, 8192);
+  int nb = grid_for(ctx->np, 256, ctx->step_blocks);
   nb = (nb + 7) & ~7;
   S.nblocks_logical = nb;
+  S.xcd_map = ctx->xcd_map;
   S.ctr_turb = ctr_turb;
   S.ctr_meso = ctr_meso;
   S.ctr_conv = ctr_conv;
@@ -787,6 +790,10 @@ int mphip_update_clim(mphip_ctx *ctx, int ntime, int nlat, const double *tropo_t
   for (int i = 0; i < ntime; i++)
     for (int j = 0; j < nlat; j++)
       h.tropo[i][j] = tropo[(size_t) i * ld + j];
+  for (int i = 0; i + 1 < ntime; i++)
+    h.inv_dtime[i] = 1.0 / (h.time[i + 1] - h.time[i]);
+  for (int j = 0; j + 1 < nlat; j++)
+    h.inv_dlat[j] = 1.0 / (h.lat[j + 1] - h.lat[j]);
   if (!ctx->d_clim)
     HIPCHK(hipMalloc((void **) &ctx->d_clim, sizeof(DevClim)));
   HIPCHK(hipMemcpyAsync(ctx->d_clim, &h, sizeof(DevClim), hipMemcpyHostToDevice, ctx->stream));
@@ -1192,6 +1199,16 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (value < 0)
       return fail(ctx, "locality_sort_interval must be >= 0");
     ctx->locality_interval = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "step_blocks") == 0) {
+    if (value < 8 || value > 1048576)
+      return fail(ctx, "step_blocks must be in 8 ... 1048576");
+    ctx->step_blocks = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "xcd_map") == 0) {
+    ctx->xcd_map = value != 0;
     return 0;
   }
   if (strcmp(name, "locality_tile") == 0) {

@@ -81,6 +81,8 @@ struct DevClim {
   double time[12];
   double lat[73];
   double tropo[12][73];
+  double inv_dtime[12];   // 1 / (time[i+1] - time[i])
+  double inv_dlat[73];    // 1 / (lat[i+1] - lat[i])
 };
 
 // per-block LDS copy of the three axes, the reciprocal interval widths and
@@ -718,9 +720,13 @@ __device__ __forceinline__ double clim_tropo(const DevClim &C, double t, double 
     sec += 365.25 * 86400.;
   const int it = locate_irr(C.time, C.ntime, sec, 1);
   const int il = locate_reg(C.lat, C.nlat, lat);
-  const double pa = lin(C.lat[il], C.tropo[it][il], C.lat[il + 1], C.tropo[it][il + 1], lat);
-  const double pb = lin(C.lat[il], C.tropo[it + 1][il], C.lat[il + 1], C.tropo[it + 1][il + 1], lat);
-  return lin(C.time[it], pa, C.time[it + 1], pb, sec);
+  // LIN (mptrac.h:1351) with the reciprocal of the node spacing
+  const double dlat = lat - C.lat[il];
+  const double pa = C.tropo[it][il] + div_const(C.tropo[it][il + 1] - C.tropo[it][il], C.lat[il + 1] - C.lat[il],
+                                                C.inv_dlat[il]) * dlat;
+  const double pb = C.tropo[it + 1][il] + div_const(C.tropo[it + 1][il + 1] - C.tropo[it + 1][il],
+                                                    C.lat[il + 1] - C.lat[il], C.inv_dlat[il]) * dlat;
+  return pa + div_const(pb - pa, C.time[it + 1] - C.time[it], C.inv_dtime[it]) * (sec - C.time[it]);
 }
 
 // tropo_weight, mptrac.c:12748-12770, split so that the climatological
@@ -760,7 +766,12 @@ __device__ __forceinline__ double pbl_weight(const mphip_ctl_t &ctl, double p, d
 __device__ __forceinline__ double sedi(double p, double T, double rp, double rhop) {
   const double r = rp * 1e-6;
   const double rho = rho_air(p, T);
-  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * pow(div_const(T, 296.16, 1.0 / 296.16), 1.5);
+#if MPHIP_EXACT_DIV
+  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * pow(T / 296.16, 1.5);
+#else
+  const double tr = T * (1.0 / 296.16);   // x^1.5 = x sqrt(x): within 2 ulp of pow()
+  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * (tr * sqrt(tr));
+#endif
   const double v = sqrt(div_const(8. * kKB * T, kPi * kMAir, 1.0 / (kPi * kMAir)));
   const double lambda = 2. * eta / (rho * v);
   const double K = lambda / r;
@@ -859,23 +870,21 @@ __device__ __forceinline__ void normal_pair(uint64_t c0, uint64_t j2, double &ev
   odd = r * libm_sincosf(phif, 0);
 }
 
-// the three normals rs[3g], rs[3g+1], rs[3g+2] of global particle g
+// the three normals rs[3g], rs[3g+1], rs[3g+2] of global particle g.  They
+// always come from two consecutive Box-Muller pairs; which three of the four
+// outputs depends on the parity of 3g, i.e. alternates between neighbouring
+// lanes -- so both pairs are evaluated by every lane and the outputs selected,
+// instead of branching on the parity (a branch would run both sides per wave).
 __device__ __forceinline__ void normal_triple(uint64_t c0, uint64_t g, double &r0, double &r1, double &r2) {
   const uint64_t i0 = 3 * g;
-  double a, b, c, d;
-  if ((i0 & 1) == 0) {
-    normal_pair(c0, i0, a, b);       // elements i0, i0+1
-    normal_pair(c0, i0 + 2, c, d);   // element i0+2 (and i0+3, unused)
-    r0 = a;
-    r1 = b;
-    r2 = c;
-  } else {
-    normal_pair(c0, i0 - 1, a, b);   // element i0 is the odd member
-    normal_pair(c0, i0 + 1, c, d);   // elements i0+1, i0+2
-    r0 = b;
-    r1 = c;
-    r2 = d;
-  }
+  const bool odd = (i0 & 1) != 0;
+  const uint64_t ja = i0 - (odd ? 1 : 0);
+  double ea, oa, eb, ob;
+  normal_pair(c0, ja, ea, oa);
+  normal_pair(c0, ja + 2, eb, ob);
+  r0 = odd ? oa : ea;
+  r1 = odd ? eb : oa;
+  r2 = odd ? ob : eb;
 }
 
 // ---- per-particle state -----------------------------------------------------

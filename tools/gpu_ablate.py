@@ -19,13 +19,15 @@ VARIANTS = {
 }
 
 
-def run(name, over, n=None, steps=10, interval=10, workload="C3", tile=None):
+def run(name, over, n=None, steps=10, interval=10, workload="C3", tile=None, opts=None):
     ctl, clim, m0, m1, atm, n_local, n_total = bench.build_inputs(workload, 0, 1, steps + 4)
     ctl.update(over)
     s = hip.Simulation(ctl, clim, m0, m1, atm, n_total=n_total, shard=(0, n_local))
     s.set_option("locality_sort_interval", interval)
     if tile:
         s.set_option("locality_tile", tile)
+    for k, v in (opts or {}).items():
+        s.set_option(k, v)
     s.timesteps_init(0.0, 0.0)
     dt = s.ctl.dt_mod
     k = 0
@@ -43,7 +45,11 @@ def run(name, over, n=None, steps=10, interval=10, workload="C3", tile=None):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "tiles":
+    if len(sys.argv) > 1 and sys.argv[1] == "grid":
+        for blocks in (1024, 2048, 4096, 8192, 16384, 40000):
+            for xm in (1, 0):
+                run(f"blocks={blocks} xcd_map={xm} full C3", VARIANTS["full C3"], opts={"step_blocks": blocks, "xcd_map": xm})
+    elif len(sys.argv) > 1 and sys.argv[1] == "tiles":
         for tile in (1, 2, 4, 8, 16, 32):
             for name in ("advect", "full C3"):
                 run(f"tile={tile} {name}", VARIANTS[name], tile=tile)
