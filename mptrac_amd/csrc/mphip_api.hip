@@ -423,9 +423,13 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   S.clim = ctx->d_clim;
   S.t = t;
   S.mask = mask;
-  int nb = grid_for(ctx->np, 256, ctx->step_blocks);
+  // every block walks a whole number of 256-particle rounds (no half-empty last round)
+  long long per_block = (ctx->np + ctx->step_blocks - 1) / ctx->step_blocks;
+  per_block = std::max<long long>(256, (per_block + 255) / 256 * 256);
+  int nb = (int) ((ctx->np + per_block - 1) / per_block);
   nb = (nb + 7) & ~7;
   S.nblocks_logical = nb;
+  S.per_block = per_block;
   S.xcd_map = ctx->xcd_map;
   S.ctr_turb = ctr_turb;
   S.ctr_meso = ctr_meso;

@@ -839,14 +839,13 @@ __device__ __forceinline__ uint32_t abstop12(float x) {
   return (__float_as_uint(x) >> 20) & 0x7ff;
 }
 
-// which = 0: sinf(y), which = 1: cosf(y)
+// which = 0: sinf(y), which = 1: cosf(y), for 0 <= y < 120.  glibc branches to
+// shorter paths for |y| < pi/4 and |y| < 2^-12; the general path below returns
+// the same bits there (n = 0, x - 0 * hpi = x, and the polynomial rounds to y
+// resp. 1.0f), so it is used for every lane -- one eighth of the Box-Muller
+// angles would otherwise diverge.
 __device__ __forceinline__ float libm_sincosf(float y, int which) {
   double x = (double) y;
-  if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
-    if (abstop12(y) < abstop12(0x1p-12f))
-      return which ? 1.0f : y;
-    return sincosf_poly(x, x * x, 1.0, which);
-  }
   const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
   const double r = x * hpi_inv;
   const int n = ((int32_t) r + 0x800000) >> 24;

@@ -23,6 +23,7 @@ struct StepParams {
   double t;
   unsigned mask;          // MPHIP_MOD_* bits to run (when the kernel is the generic instantiation)
   int nblocks_logical;    // multiple of 8
+  long long per_block;    // particles per logical block, multiple of 256
   int xcd_map;            // 1: workgroup b -> logical block (b % 8) * (n / 8) + b / 8
   uint64_t ctr_turb, ctr_meso, ctr_conv, ctr_pbl;   // base counters of the module_rng calls
 };
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
 
   const int nb = S.nblocks_logical;
   const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
-  const long long per_block = (a.np + nb - 1) / nb;
+  const long long per_block = S.per_block;
   const long long first = (long long) lb * per_block;
   long long last = first + per_block;
   if (last > a.np)
