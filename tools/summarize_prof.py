@@ -62,10 +62,19 @@ if fs and ws:
         grid_bytes = nx * ny * npl * 32.0
     except Exception:
         pass
-    if cf and cw and grid_bytes:
-        kf, kw = grid_bytes / (max(cf) * 1024.0), grid_bytes / (max(cw) * 1024.0)
-        info.update(calib_fetch_factor=kf, calib_write_factor=kw, calib_known_bytes=grid_bytes)
-        info["traffic_bytes"] = steady_f * kf + steady_w * kw
+    if cf and grid_bytes:
+        # FETCH_SIZE: scale by the factor that makes pack_kernel's coalesced reads come out at their known
+        # byte count (~2.0 on gfx950).  WRITE_SIZE: the step kernel's own stores are a known byte count
+        # (time, lon, lat, p + uvwp = 44 B per particle, coalesced) and WRITE_SIZE matches it as is, so no
+        # factor is applied (pack_kernel's 24-byte record stores are not a usable calibration: partial lines).
+        kf = grid_bytes / (max(cf) * 1024.0)
+        info.update(calib_fetch_factor=kf, calib_known_bytes=grid_bytes)
+        try:
+            known_w = 44.0 * cfg["config"]["particles_per_gpu"]
+            info.update(write_known_bytes=known_w, write_raw_over_known=steady_w / known_w)
+        except Exception:
+            pass
+        info["traffic_bytes"] = steady_f * kf + steady_w
     else:
         info["traffic_bytes"] = steady_f + steady_w
     print("== HBM traffic of step_kernel per launch ==")
