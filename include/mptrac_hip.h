@@ -35,12 +35,30 @@ extern "C" {
 enum { MPHIP_U = 0, MPHIP_V, MPHIP_W, MPHIP_T, MPHIP_LWC, MPHIP_RWC, MPHIP_IWC, MPHIP_SWC,
        /* model-level fields (met_t pl, ul, vl, zetal, zeta_dotl; mptrac.h:3997-4012), float [ix][iy][npl] */
        MPHIP_PL, MPHIP_UL, MPHIP_VL, MPHIP_ZETAL, MPHIP_ZETA_DOTL,
-       MPHIP_H2O,   /* water vapour on pressure levels (module_diff_pbl) */
+       MPHIP_H2O,   /* water vapour on pressure levels (module_diff_pbl, module_meteo) */
+       /* read by module_meteo only (INTPOL_TIME_ALL, mptrac.h:1278-1318) */
+       MPHIP_Z, MPHIP_PV, MPHIP_O3, MPHIP_CC,
        MPHIP_N3D };
 /* 2-D meteo fields (met_t, mptrac.h:3886-3958), float [ix][iy] */
 enum { MPHIP_PS = 0, MPHIP_PBL, MPHIP_CAPE, MPHIP_CIN, MPHIP_PEL, MPHIP_PCT, MPHIP_PCB, MPHIP_CL,
        MPHIP_ESS, MPHIP_NSS, MPHIP_SHF,   /* surface stresses and sensible heat flux (module_diff_pbl) */
+       /* read by module_meteo only */
+       MPHIP_TS, MPHIP_ZS, MPHIP_US, MPHIP_VS, MPHIP_LSM, MPHIP_SST, MPHIP_PT, MPHIP_TT, MPHIP_ZT, MPHIP_H2OT,
+       MPHIP_PLCL, MPHIP_PLFC, MPHIP_O3C,
        MPHIP_N2D };
+
+/* Quantities module_meteo fills (SET_ATM list, mptrac.c:5091-5157, in that order); mphip_ctl_t::qnt_met[k]
+ * is the reference's ctl->qnt_<name> (-1 = not requested).  The climatology-based ones (hno3, oh, h2o2,
+ * ho2, o1d, tnat, tsts) belong to the chemistry part and are not provided. */
+enum { MPHIP_MQ_PS = 0, MPHIP_MQ_TS, MPHIP_MQ_ZS, MPHIP_MQ_US, MPHIP_MQ_VS, MPHIP_MQ_ESS, MPHIP_MQ_NSS,
+       MPHIP_MQ_SHF, MPHIP_MQ_LSM, MPHIP_MQ_SST, MPHIP_MQ_PBL, MPHIP_MQ_PT, MPHIP_MQ_TT, MPHIP_MQ_ZT,
+       MPHIP_MQ_H2OT, MPHIP_MQ_ZG, MPHIP_MQ_P, MPHIP_MQ_T, MPHIP_MQ_RHO, MPHIP_MQ_U, MPHIP_MQ_V, MPHIP_MQ_W,
+       MPHIP_MQ_H2O, MPHIP_MQ_O3, MPHIP_MQ_LWC, MPHIP_MQ_RWC, MPHIP_MQ_IWC, MPHIP_MQ_SWC, MPHIP_MQ_CC,
+       MPHIP_MQ_PCT, MPHIP_MQ_PCB, MPHIP_MQ_CL, MPHIP_MQ_PLCL, MPHIP_MQ_PLFC, MPHIP_MQ_PEL, MPHIP_MQ_CAPE,
+       MPHIP_MQ_CIN, MPHIP_MQ_O3C, MPHIP_MQ_VH, MPHIP_MQ_VZ, MPHIP_MQ_PSAT, MPHIP_MQ_PSICE, MPHIP_MQ_PW,
+       MPHIP_MQ_SH, MPHIP_MQ_RH, MPHIP_MQ_RHICE, MPHIP_MQ_THETA, MPHIP_MQ_ZETA_D, MPHIP_MQ_TVIRT,
+       MPHIP_MQ_LAPSE, MPHIP_MQ_PV, MPHIP_MQ_TDEW, MPHIP_MQ_TICE,
+       MPHIP_NMQ };
 
 /* Module bits for mphip_module(); one bit per reference module_* function
  * (declarations mptrac.h:6140-7205). */
@@ -59,6 +77,7 @@ enum {
   MPHIP_MOD_DRY_DEPO   = 1 << 11,  /* module_dry_depo    mptrac.c:4738 */
   MPHIP_MOD_ADVECT_INIT = 1 << 12, /* module_advect_init mptrac.c:3762 (not guarded by dt) */
   MPHIP_MOD_DIFF_PBL   = 1 << 13,  /* module_diff_pbl    mptrac.c:4343 (runs between diff_turb and diff_meso) */
+  MPHIP_MOD_METEO      = 1 << 14,  /* module_meteo       mptrac.c:5062 (own kernel; not guarded by dt) */
   MPHIP_MOD_SORT       = 1 << 16,  /* module_sort        mptrac.c:5887 (own kernels) */
   MPHIP_MOD_MIXING     = 1 << 17   /* module_mixing      mptrac.c:5169 (own kernels) */
 };
@@ -100,6 +119,11 @@ typedef struct {
   double grid_z0, grid_z1, grid_lon0, grid_lon1, grid_lat0, grid_lat1;
   int grid_nx, grid_ny, grid_nz;
   int pad1;
+  /* module_meteo (mptrac.c:7921-7924): runs when met_dt_out > 0 and (met_dt_out < dt_mod or
+   * fmod(t, met_dt_out) == 0); reference default 0.1 (mptrac.c:7197) */
+  double met_dt_out;
+  int qnt_met[MPHIP_NMQ];
+  int pad2;
 } mphip_ctl_t;
 
 /* View of one met_t snapshot (mptrac.h:3844-4014).  The arrays stay where the

@@ -471,6 +471,91 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   return 0;
 }
 
+// ---- module_meteo -------------------------------------------------------------
+
+// meteo fields each module_meteo quantity is computed from (mptrac.c:5091-5157)
+struct MeteoDeps {
+  unsigned need3 = 0, need2 = 0;
+};
+
+MeteoDeps meteo_deps(const mphip_ctl_t &c) {
+  MeteoDeps d;
+  auto q = [&](int k) { return c.qnt_met[k] >= 0; };
+  auto f3 = [&](int k, int f) { if (q(k)) d.need3 |= 1u << f; };
+  auto f2 = [&](int k, int f) { if (q(k)) d.need2 |= 1u << f; };
+  f2(MPHIP_MQ_PS, MPHIP_PS);     f2(MPHIP_MQ_TS, MPHIP_TS);     f2(MPHIP_MQ_ZS, MPHIP_ZS);
+  f2(MPHIP_MQ_US, MPHIP_US);     f2(MPHIP_MQ_VS, MPHIP_VS);     f2(MPHIP_MQ_ESS, MPHIP_ESS);
+  f2(MPHIP_MQ_NSS, MPHIP_NSS);   f2(MPHIP_MQ_SHF, MPHIP_SHF);   f2(MPHIP_MQ_LSM, MPHIP_LSM);
+  f2(MPHIP_MQ_SST, MPHIP_SST);   f2(MPHIP_MQ_PBL, MPHIP_PBL);   f2(MPHIP_MQ_PT, MPHIP_PT);
+  f2(MPHIP_MQ_TT, MPHIP_TT);     f2(MPHIP_MQ_ZT, MPHIP_ZT);     f2(MPHIP_MQ_H2OT, MPHIP_H2OT);
+  f2(MPHIP_MQ_PCT, MPHIP_PCT);   f2(MPHIP_MQ_PCB, MPHIP_PCB);   f2(MPHIP_MQ_CL, MPHIP_CL);
+  f2(MPHIP_MQ_PLCL, MPHIP_PLCL); f2(MPHIP_MQ_PLFC, MPHIP_PLFC); f2(MPHIP_MQ_PEL, MPHIP_PEL);
+  f2(MPHIP_MQ_CAPE, MPHIP_CAPE); f2(MPHIP_MQ_CIN, MPHIP_CIN);   f2(MPHIP_MQ_O3C, MPHIP_O3C);
+  f3(MPHIP_MQ_ZG, MPHIP_Z);      f3(MPHIP_MQ_T, MPHIP_T);       f3(MPHIP_MQ_U, MPHIP_U);
+  f3(MPHIP_MQ_V, MPHIP_V);       f3(MPHIP_MQ_W, MPHIP_W);       f3(MPHIP_MQ_H2O, MPHIP_H2O);
+  f3(MPHIP_MQ_O3, MPHIP_O3);     f3(MPHIP_MQ_LWC, MPHIP_LWC);   f3(MPHIP_MQ_RWC, MPHIP_RWC);
+  f3(MPHIP_MQ_IWC, MPHIP_IWC);   f3(MPHIP_MQ_SWC, MPHIP_SWC);   f3(MPHIP_MQ_CC, MPHIP_CC);
+  f3(MPHIP_MQ_PV, MPHIP_PV);
+  // derived quantities
+  f3(MPHIP_MQ_RHO, MPHIP_T);     f3(MPHIP_MQ_VH, MPHIP_U);      f3(MPHIP_MQ_VH, MPHIP_V);
+  f3(MPHIP_MQ_VZ, MPHIP_W);      f3(MPHIP_MQ_PSAT, MPHIP_T);    f3(MPHIP_MQ_PSICE, MPHIP_T);
+  f3(MPHIP_MQ_PW, MPHIP_H2O);    f3(MPHIP_MQ_SH, MPHIP_H2O);    f3(MPHIP_MQ_RH, MPHIP_T);
+  f3(MPHIP_MQ_RH, MPHIP_H2O);    f3(MPHIP_MQ_RHICE, MPHIP_T);   f3(MPHIP_MQ_RHICE, MPHIP_H2O);
+  f3(MPHIP_MQ_THETA, MPHIP_T);   f3(MPHIP_MQ_ZETA_D, MPHIP_T);  f2(MPHIP_MQ_ZETA_D, MPHIP_PS);
+  f3(MPHIP_MQ_TVIRT, MPHIP_T);   f3(MPHIP_MQ_TVIRT, MPHIP_H2O); f3(MPHIP_MQ_LAPSE, MPHIP_T);
+  f3(MPHIP_MQ_LAPSE, MPHIP_H2O); f3(MPHIP_MQ_TDEW, MPHIP_H2O);  f3(MPHIP_MQ_TICE, MPHIP_H2O);
+  return d;
+}
+
+bool meteo_requested(const mphip_ctl_t &c) {
+  for (int k = 0; k < MPHIP_NMQ; k++)
+    if (c.qnt_met[k] >= 0)
+      return true;
+  return false;
+}
+
+int launch_meteo(mphip_ctx *ctx) {
+  const mphip_ctl_t &c = ctx->ctl;
+  if (ctx->np == 0 || !meteo_requested(c))
+    return 0;   // nothing to set: every SET_ATM of the reference is a no-op
+  for (int k = 0; k < MPHIP_NMQ; k++)
+    if (c.qnt_met[k] >= c.nq)
+      return fail(ctx, "module_meteo: quantity index out of range");
+  const MetSlot &s0 = ctx->slot[0 ^ ctx->flip], &s1 = ctx->slot[1 ^ ctx->flip];
+  if (!s0.valid || !s1.valid)
+    return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
+  static const char *const n3[MPHIP_N3D] = { "u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "pl", "ul", "vl", "zetal",
+                                             "zeta_dotl", "h2o", "z", "pv", "o3", "cc" };
+  static const char *const n2[MPHIP_N2D] = { "ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "ess", "nss", "shf",
+                                             "ts", "zs", "us", "vs", "lsm", "sst", "pt", "tt", "zt", "h2ot", "plcl",
+                                             "plfc", "o3c" };
+  MeteoArgs G;
+  memset(&G, 0, sizeof(G));
+  const MeteoDeps d = meteo_deps(c);
+  for (int f = 0; f < MPHIP_N3D; f++)
+    if ((d.need3 >> f) & 1u) {
+      if (!s0.has3[f] || !s1.has3[f])
+        return fail(ctx, std::string("module_meteo: meteo field ") + n3[f] + " was not uploaded");
+      G.f3[0][f] = s0.f3[f];
+      G.f3[1][f] = s1.f3[f];
+    }
+  for (int f = 0; f < MPHIP_N2D; f++)
+    if ((d.need2 >> f) & 1u) {
+      if (!s0.has2[f] || !s1.has2[f])
+        return fail(ctx, std::string("module_meteo: meteo field ") + n2[f] + " was not uploaded");
+      G.f2[0][f] = s0.f2[f];
+      G.f2[1][f] = s1.f2[f];
+    }
+  G.ctl = c;
+  G.met = dev_met(ctx);
+  G.atm = dev_atm(ctx);
+  G.need3 = d.need3;
+  G.need2 = d.need2;
+  hipLaunchKernelGGL(meteo_kernel, dim3(grid_for(ctx->np, 256, 16384)), dim3(256), axes_lds_bytes(ctx), ctx->stream, G);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 PermArgs perm_args(mphip_ctx *ctx, bool with_cache) {
   PermArgs g;
   memset(&g, 0, sizeof(g));
@@ -1085,16 +1170,23 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
     tail |= MPHIP_MOD_WET_DEPO;
   if (c.dry_depo_vdep > 0)
     tail |= MPHIP_MOD_DRY_DEPO;
+  // module_meteo (mptrac.c:7921-7924) sits between the final module_position and the loss / decay /
+  // mixing / deposition modules; those neither move particles nor touch a quantity it sets, so it
+  // runs after them here (own kernel, every particle)
+  const bool meteo_now = c.met_dt_out > 0 && (c.met_dt_out < c.dt_mod || fmod(t, c.met_dt_out) == 0);
   const bool mixing_now = c.mixing_trop >= 0 && c.mixing_strat >= 0 && (c.mixing_dt <= 0 || fmod(t, c.mixing_dt) == 0);
-  if (!mixing_now)
-    return launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl);
+  if (!mixing_now) {
+    if (launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
+      return 1;
+    return meteo_now ? launch_meteo(ctx) : 0;
+  }
   if (tail && (mask & MPHIP_MOD_TIMESTEPS))
     mask |= kStoreDt;
   if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl) || do_mixing(ctx, t))
     return 1;
-  if (tail)
-    return launch_step(ctx, tail, t, 0, 0, 0);
-  return 0;
+  if (tail && launch_step(ctx, tail, t, 0, 0, 0))
+    return 1;
+  return meteo_now ? launch_meteo(ctx) : 0;
 }
 
 int mphip_module(mphip_ctx *ctx, unsigned modules, double t) {
@@ -1107,8 +1199,10 @@ int mphip_module(mphip_ctx *ctx, unsigned modules, double t) {
     return do_sort(ctx);
   if (modules == MPHIP_MOD_MIXING)
     return do_mixing(ctx, t);
+  if (modules == MPHIP_MOD_METEO)
+    return launch_meteo(ctx);
   if (modules & ~kParticleBits)
-    return fail(ctx, "module_sort / module_mixing must be called on their own");
+    return fail(ctx, "module_sort / module_mixing / module_meteo must be called on their own");
   const uint64_t n = (uint64_t) ctx->np_total;
   uint64_t ctr_turb = 0, ctr_meso = 0, ctr_conv = 0, ctr_pbl = 0;
   if (modules & MPHIP_MOD_DIFF_TURB) {

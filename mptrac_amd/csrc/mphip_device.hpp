@@ -1389,4 +1389,77 @@ __device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Pa
   P.p += dz2dp(div_const(v_s * P.dt, 1000., 1e-3), P.p);
 }
 
+// ---- module_meteo (mptrac.c:5062-5165) --------------------------------------
+// Reads the per-snapshot planar copies ([ix][iy][ip], level index fastest) the
+// context keeps of every uploaded field; a column's level pair is one 8-byte load.
+
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+constexpr double kLv = 2501000.;   // LV, mptrac.h:275
+
+__device__ __forceinline__ double plane_space_3d(const float *__restrict__ a, const DevMet &M, const Stencil &s) {
+  const f32x2u v00 = *(const f32x2u *) (a + cell_of(M, s, 0, 0));
+  const f32x2u v01 = *(const f32x2u *) (a + cell_of(M, s, 0, 1));
+  const f32x2u v10 = *(const f32x2u *) (a + cell_of(M, s, 1, 0));
+  const f32x2u v11 = *(const f32x2u *) (a + cell_of(M, s, 1, 1));
+  return lerp3(s, v00[0], v00[1], v01[0], v01[1], v10[0], v10[1], v11[0], v11[1]);
+}
+
+// intpol_met_time_3d with init = 0 (mptrac.c:3112-3137)
+__device__ __forceinline__ double plane_time_3d(const float *__restrict__ a0, const float *__restrict__ a1,
+                                                const DevMet &M, const Stencil &s, double wt) {
+  const double v0 = plane_space_3d(a0, M, s);
+  const double v1 = plane_space_3d(a1, M, s);
+  return wt * (v0 - v1) + v1;
+}
+
+__device__ __forceinline__ double plane_space_2d(const float *__restrict__ a, const DevMet &M, const Stencil &s) {
+  const size_t c0 = (size_t) s.ix * (size_t) M.ny + (size_t) s.iy, c1 = c0 + (size_t) M.ny;
+  return bilin_2d(s, a[c0], a[c0 + 1], a[c1], a[c1 + 1]);
+}
+
+// intpol_met_time_2d with init = 0 (mptrac.c:3141-3170)
+__device__ __forceinline__ double plane_time_2d(const float *__restrict__ a0, const float *__restrict__ a1,
+                                                const DevMet &M, const Stencil &s, double wt) {
+  return blend_time_2d(plane_space_2d(a0, M, s), plane_space_2d(a1, M, s), wt);
+}
+
+__device__ __forceinline__ double pw_of(double p, double h2o) {   // PW, mptrac.h:1859
+  return p * dmax(h2o, 0.1e-6) / (1. + (1. - kEps) * dmax(h2o, 0.1e-6));
+}
+
+__device__ __forceinline__ double psat_of(double t) {   // PSAT, mptrac.h:1808
+  return 6.112 * exp(17.62 * (t - kT0) / (243.12 + t - kT0));
+}
+
+__device__ __forceinline__ double psice_of(double t) {   // PSICE, mptrac.h:1832
+  return 6.112 * exp(22.46 * (t - kT0) / (272.62 + t - kT0));
+}
+
+__device__ __forceinline__ double sh_of(double h2o) {   // SH, mptrac.h:2024
+  return kEps * dmax(h2o, 0.1e-6);
+}
+
+__device__ __forceinline__ double tdew_of(double p, double h2o) {   // TDEW, mptrac.h:2075
+  const double l = log(pw_of(p, h2o) / 6.112);
+  return kT0 + 243.12 * l / (17.62 - l);
+}
+
+__device__ __forceinline__ double tice_of(double p, double h2o) {   // TICE, mptrac.h:2100
+  const double l = log(pw_of(p, h2o) / 6.112);
+  return kT0 + 272.62 * l / (22.46 - l);
+}
+
+__device__ __forceinline__ double theta_of(double p, double t) {   // THETA, mptrac.h:2124
+  return t * pow(1000. / p, kKappa);
+}
+
+__device__ __forceinline__ double zeta_of(double ps, double p, double t) {   // ZETA, mptrac.h:2293
+  return (p / ps <= 0.3 ? 1. : sin(kPi / 2. * (1. - p / ps) / (1. - 0.3))) * theta_of(p, t);
+}
+
+__device__ __forceinline__ double lapse_rate(double t, double h2o) {   // lapse_rate, mptrac.c:3324-3338
+  const double a = kRA * t * t, r = sh_of(h2o) / (1. - sh_of(h2o));
+  return 1e3 * kG0 * (a + kLv * r * t) / (kCpd * a + kLv * kLv * r * kEps);
+}
+
 }   // namespace mphip

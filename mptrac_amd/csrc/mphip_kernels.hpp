@@ -628,6 +628,102 @@ __global__ void grid_accumulate_kernel(DevAtm a, const int *__restrict__ cell, i
 }
 
 // ---------------------------------------------------------------------------
+// module_meteo (mptrac.c:5062-5165): sample the meteo fields at every particle
+// (no dt guard) into the requested quantities.  Only the fields a requested
+// quantity depends on are read (need3 / need2, set by the host); the values are
+// those INTPOL_TIME_ALL (mptrac.h:1278-1318) produces -- one index / weight
+// set from the first 3-D call, re-used by all other 3-D and 2-D calls.
+// ---------------------------------------------------------------------------
+
+struct MeteoArgs {
+  mphip_ctl_t ctl;
+  DevMet met;
+  DevAtm atm;
+  const float *f3[2][MPHIP_N3D];
+  const float *f2[2][MPHIP_N2D];
+  unsigned need3, need2;
+};
+
+__global__ __launch_bounds__(256) void meteo_kernel(const MeteoArgs G) {
+  extern __shared__ double s_axes[];
+  const DevMet &M = G.met;
+  const DevAtm &a = G.atm;
+  const int *qm = G.ctl.qnt_met;
+  const Axes A = load_axes(M, s_axes);
+  __syncthreads();
+  const unsigned n3 = G.need3, n2 = G.need2;
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np; i += (long long) gridDim.x * blockDim.x) {
+    const double tm = a.time[i], p = a.p[i], lon = a.lon[i], lat = a.lat[i];
+    Stencil s = stencil_zero();
+    stencil_3d(M, A, p, lon, lat, s);
+    const double wt = time_weight(M, tm);
+#define F3(f) (((n3 >> (f)) & 1u) ? plane_time_3d(G.f3[0][f], G.f3[1][f], M, s, wt) : 0.0)
+#define F2(f) (((n2 >> (f)) & 1u) ? plane_time_2d(G.f2[0][f], G.f2[1][f], M, s, wt) : 0.0)
+#define SETQ(k, val)                                                                          \
+  if (qm[k] >= 0)                                                                             \
+    a.q[qm[k]][i] = (val)
+    const double t = F3(MPHIP_T), u = F3(MPHIP_U), v = F3(MPHIP_V), w = F3(MPHIP_W), h2o = F3(MPHIP_H2O);
+    const double ps = F2(MPHIP_PS);
+    SETQ(MPHIP_MQ_PS, ps);
+    SETQ(MPHIP_MQ_TS, F2(MPHIP_TS));
+    SETQ(MPHIP_MQ_ZS, F2(MPHIP_ZS));
+    SETQ(MPHIP_MQ_US, F2(MPHIP_US));
+    SETQ(MPHIP_MQ_VS, F2(MPHIP_VS));
+    SETQ(MPHIP_MQ_ESS, F2(MPHIP_ESS));
+    SETQ(MPHIP_MQ_NSS, F2(MPHIP_NSS));
+    SETQ(MPHIP_MQ_SHF, F2(MPHIP_SHF));
+    SETQ(MPHIP_MQ_LSM, F2(MPHIP_LSM));
+    SETQ(MPHIP_MQ_SST, F2(MPHIP_SST));
+    SETQ(MPHIP_MQ_PBL, F2(MPHIP_PBL));
+    SETQ(MPHIP_MQ_PT, F2(MPHIP_PT));
+    SETQ(MPHIP_MQ_TT, F2(MPHIP_TT));
+    SETQ(MPHIP_MQ_ZT, F2(MPHIP_ZT));
+    SETQ(MPHIP_MQ_H2OT, F2(MPHIP_H2OT));
+    SETQ(MPHIP_MQ_ZG, F3(MPHIP_Z));
+    SETQ(MPHIP_MQ_P, p);
+    SETQ(MPHIP_MQ_T, t);
+    SETQ(MPHIP_MQ_RHO, rho_air(p, t));
+    SETQ(MPHIP_MQ_U, u);
+    SETQ(MPHIP_MQ_V, v);
+    SETQ(MPHIP_MQ_W, w);
+    SETQ(MPHIP_MQ_H2O, h2o);
+    SETQ(MPHIP_MQ_O3, F3(MPHIP_O3));
+    SETQ(MPHIP_MQ_LWC, F3(MPHIP_LWC));
+    SETQ(MPHIP_MQ_RWC, F3(MPHIP_RWC));
+    SETQ(MPHIP_MQ_IWC, F3(MPHIP_IWC));
+    SETQ(MPHIP_MQ_SWC, F3(MPHIP_SWC));
+    SETQ(MPHIP_MQ_CC, F3(MPHIP_CC));
+    SETQ(MPHIP_MQ_PCT, F2(MPHIP_PCT));
+    SETQ(MPHIP_MQ_PCB, F2(MPHIP_PCB));
+    SETQ(MPHIP_MQ_CL, F2(MPHIP_CL));
+    SETQ(MPHIP_MQ_PLCL, F2(MPHIP_PLCL));
+    SETQ(MPHIP_MQ_PLFC, F2(MPHIP_PLFC));
+    SETQ(MPHIP_MQ_PEL, F2(MPHIP_PEL));
+    SETQ(MPHIP_MQ_CAPE, F2(MPHIP_CAPE));
+    SETQ(MPHIP_MQ_CIN, F2(MPHIP_CIN));
+    SETQ(MPHIP_MQ_O3C, F2(MPHIP_O3C));
+    SETQ(MPHIP_MQ_VH, sqrt(u * u + v * v));
+    SETQ(MPHIP_MQ_VZ, -1e3 * kH0 / p * w);
+    SETQ(MPHIP_MQ_PSAT, psat_of(t));
+    SETQ(MPHIP_MQ_PSICE, psice_of(t));
+    SETQ(MPHIP_MQ_PW, pw_of(p, h2o));
+    SETQ(MPHIP_MQ_SH, sh_of(h2o));
+    SETQ(MPHIP_MQ_RH, pw_of(p, h2o) / psat_of(t) * 100.);      // RH, mptrac.h:1906
+    SETQ(MPHIP_MQ_RHICE, pw_of(p, h2o) / psice_of(t) * 100.);  // RHICE, mptrac.h:1936
+    SETQ(MPHIP_MQ_THETA, theta_of(p, t));
+    SETQ(MPHIP_MQ_ZETA_D, zeta_of(ps, p, t));
+    SETQ(MPHIP_MQ_TVIRT, tvirt(t, h2o));
+    SETQ(MPHIP_MQ_LAPSE, lapse_rate(t, h2o));
+    SETQ(MPHIP_MQ_PV, F3(MPHIP_PV));
+    SETQ(MPHIP_MQ_TDEW, tdew_of(p, h2o));
+    SETQ(MPHIP_MQ_TICE, tice_of(p, h2o));
+#undef F3
+#undef F2
+#undef SETQ
+  }
+}
+
+// ---------------------------------------------------------------------------
 // self-test kernels
 // ---------------------------------------------------------------------------
 

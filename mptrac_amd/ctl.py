@@ -92,7 +92,19 @@ CTL_FIELDS = [
     ("grid_ny", C.c_int, 180),
     ("grid_nz", C.c_int, 1),
     ("pad1", C.c_int, 0),
+    # module_meteo, mptrac.c:7197 and 7921-7924; qnt_met[k] = ctl->qnt_<METEO_QUANTITIES[k]>
+    ("met_dt_out", C.c_double, 0.1),
+    ("qnt_met", C.c_int * 53, (-1,) * 53),
+    ("pad2", C.c_int, 0),
 ]
+
+# quantities module_meteo fills, in the order of its SET_ATM list (mptrac.c:5091-5157) = MPHIP_MQ_*
+METEO_QUANTITIES = (
+    "ps", "ts", "zs", "us", "vs", "ess", "nss", "shf", "lsm", "sst", "pbl", "pt", "tt", "zt", "h2ot", "zg", "p",
+    "t", "rho", "u", "v", "w", "h2o", "o3", "lwc", "rwc", "iwc", "swc", "cc", "pct", "pcb", "cl", "plcl", "plfc",
+    "pel", "cape", "cin", "o3c", "vh", "vz", "psat", "psice", "pw", "sh", "rh", "rhice", "theta", "zeta_d",
+    "tvirt", "lapse", "pv", "tdew", "tice")
+assert len(METEO_QUANTITIES) == 53
 
 
 def make_ctl_struct(name):
@@ -124,7 +136,12 @@ def ctl_from_quantities(names):
     table = {"m": "qnt_m", "vmr": "qnt_vmr", "rp": "qnt_rp", "rhop": "qnt_rhop", "ens": "qnt_ens",
              "loss_rate": "qnt_loss_rate", "mloss_decay": "qnt_mloss_decay",
              "mloss_wet": "qnt_mloss_wet", "mloss_dry": "qnt_mloss_dry", "zeta": "qnt_zeta", "eta": "qnt_eta"}
+    met = [-1] * len(METEO_QUANTITIES)
     for i, n in enumerate(names):
         if n in table:
             out[table[n]] = i
+        elif n in METEO_QUANTITIES:
+            met[METEO_QUANTITIES.index(n)] = i
+    if any(v >= 0 for v in met):
+        out["qnt_met"] = tuple(met)
     return out

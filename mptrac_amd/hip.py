@@ -18,7 +18,8 @@ NQ_MAX = 16
 MOD = {
     "timesteps": 1 << 0, "position": 1 << 1, "advect": 1 << 2, "diff_turb": 1 << 3, "diff_meso": 1 << 4,
     "convection": 1 << 5, "sedi": 1 << 6, "position2": 1 << 7, "loss_zero": 1 << 8, "decay": 1 << 9,
-    "wet_depo": 1 << 10, "dry_depo": 1 << 11, "advect_init": 1 << 12, "diff_pbl": 1 << 13, "sort": 1 << 16, "mixing": 1 << 17,
+    "wet_depo": 1 << 10, "dry_depo": 1 << 11, "advect_init": 1 << 12, "diff_pbl": 1 << 13, "meteo": 1 << 14,
+    "sort": 1 << 16, "mixing": 1 << 17,
 }
 
 MphipCtl = make_ctl_struct("MphipCtl")

@@ -20,6 +20,7 @@
 static mphip_ctx *g_ctx;
 static const met_t *g_met_host[2];     /* host snapshots mirrored in device slots met0 / met1 */
 static int g_nq;                        /* ctl->nq of the last control upload */
+static int g_meteo_fields;              /* a module_meteo quantity is requested: upload the fields only it reads */
 
 #define HIP(call) {                                                     \
     if ((call) != 0)                                                    \
@@ -156,15 +157,16 @@ static const struct {
    * hot-path quantities only */
   { "ens", "-" }, { "m", "kg" }, { "vmr", "ppv" }, { "rp", "microns" }, { "rhop", "kg/m^3" },
   { "loss_rate", "s^-1" }, { "mloss_decay", "kg" }, { "mloss_wet", "kg" }, { "mloss_dry", "kg" },
-  { "idx", "-" }, { "stat", "-" }, { "zeta", "K" }, { "eta", "1" }
+  { "idx", "-" }, { "stat", "-" }, { "zeta", "K" }, { "eta", "1" },
+#define X(n, u) { #n, u },
+  MPTRAC_METEO_QNT(X)
+#undef X
 };
 
 static const char *unsupported_qnt[] = {
-  /* quantities module_meteo would fill (mptrac.c:5062-5165); not implemented */
-  "ps", "ts", "zs", "us", "vs", "pbl", "pt", "tt", "zt", "h2ot", "zg", "p", "t", "rho", "u", "v", "w",
-  "h2o", "o3", "lwc", "rwc", "iwc", "swc", "cc", "pct", "pcb", "cl", "plcl", "plfc", "pel", "cape", "cin",
-  "hno3", "oh", "vh", "vz", "rh", "rhice", "theta", "zeta_d", "tvirt", "lapse", "pv", "tdew",
-  "tice", "tsts", "tnat", NULL
+  /* quantities module_meteo takes from the chemistry climatologies (mptrac.c:5129-5140, 5158-5163);
+   * not provided */
+  "hno3", "oh", "h2o2", "ho2", "o1d", "tsts", "tnat", NULL
 };
 
 void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
@@ -173,6 +175,9 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   /* quantities, mptrac.c:6737-6971 */
   ctl->qnt_m = ctl->qnt_vmr = ctl->qnt_rp = ctl->qnt_rhop = ctl->qnt_ens = ctl->qnt_loss_rate = -1;
   ctl->qnt_mloss_decay = ctl->qnt_mloss_wet = ctl->qnt_mloss_dry = ctl->qnt_zeta = ctl->qnt_eta = -1;
+#define X(n, u) ctl->qnt_##n = -1;
+  MPTRAC_METEO_QNT(X)
+#undef X
   ctl->nq = (int) scan_ctl(filename, argc, argv, "NQ", -1, "0", NULL);
   if (ctl->nq > NQ || ctl->nq > MPHIP_NQ_MAX)
     ERRMSG("Too many quantities!");
@@ -185,7 +190,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
         sprintf(ctl->qnt_unit[iq], "%s", qnt_units[k].unit);
     for (int k = 0; unsupported_qnt[k]; k++)
       if (strcasecmp(ctl->qnt_name[iq], unsupported_qnt[k]) == 0)
-        ERRMSG("Quantity %s is filled by module_meteo, which this build does not provide!",
+        ERRMSG("Quantity %s needs the chemistry climatologies, which this build does not provide!",
                ctl->qnt_name[iq]);
     const char *n = ctl->qnt_name[iq];
     if (!strcasecmp(n, "m")) ctl->qnt_m = iq;
@@ -199,6 +204,9 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
     else if (!strcasecmp(n, "mloss_dry")) ctl->qnt_mloss_dry = iq;
     else if (!strcasecmp(n, "zeta")) ctl->qnt_zeta = iq;
     else if (!strcasecmp(n, "eta")) ctl->qnt_eta = iq;
+#define X(nm, u) else if (!strcasecmp(n, #nm)) ctl->qnt_##nm = iq;
+    MPTRAC_METEO_QNT(X)
+#undef X
   }
 
   /* coordinates, time steps, meteo input (mptrac.c:6974-7030) */
@@ -575,16 +583,16 @@ static void bin_3d(FILE *f, int write, const met_t *met, float var[EX][EY][EP], 
 
 static void met_bin_body(FILE *f, int write, met_t *met) {
   /* field order of read_met_bin / write_met_bin (mptrac.c:8990-9028, 14245-14300):
-   * 24 surface fields, 13 level fields; the ones this build does not keep are
-   * skipped on read and written as zeros */
+   * 24 surface fields, 13 level fields */
   float *help;
   ALLOC(help, float, (size_t) met->nx * (size_t) met->ny * (size_t) met->np);
-  float (*s2[24])[EY] = { met->ps, NULL, NULL, NULL, NULL, met->ess, met->nss, met->shf, NULL, NULL, met->pbl, NULL, NULL,
-    NULL, NULL, met->pct, met->pcb, met->cl, NULL, NULL, met->pel, met->cape, met->cin, NULL };
+  float (*s2[24])[EY] = { met->ps, met->ts, met->zs, met->us, met->vs, met->ess, met->nss, met->shf, met->lsm,
+    met->sst, met->pbl, met->pt, met->tt, met->zt, met->h2ot, met->pct, met->pcb, met->cl, met->plcl, met->plfc,
+    met->pel, met->cape, met->cin, met->o3c };
   for (int k = 0; k < 24; k++)
     bin_2d(f, write, met, s2[k], help);
-  float (*s3[13])[EY][EP] = { NULL, met->t, met->u, met->v, met->w, NULL, met->h2o, NULL, met->lwc, met->rwc, met->iwc,
-    met->swc, NULL };
+  float (*s3[13])[EY][EP] = { met->z, met->t, met->u, met->v, met->w, met->pv, met->h2o, met->o3, met->lwc, met->rwc,
+    met->iwc, met->swc, met->cc };
   const float lo[13] = { -1e34f, 0, -1e34f, -1e34f, -1e34f, -1e34f, 0, 0, 0, 0, 0, 0, 0 };
   const float hi[13] = { 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1 };
   for (int k = 0; k < 13; k++)
@@ -691,6 +699,15 @@ static void to_device_ctl(const ctl_t *c, mphip_ctl_t *d) {
 #undef CP
   d->qnt_zeta = c->qnt_zeta;
   d->qnt_eta = c->qnt_eta;
+  d->met_dt_out = c->met_dt_out;
+  int k_mq = 0;
+#define X(n, u) d->qnt_met[k_mq++] = c->qnt_##n;
+  MPTRAC_METEO_QNT(X)
+#undef X
+  g_meteo_fields = 0;
+  for (int k = 0; k < MPHIP_NMQ; k++)
+    if (d->qnt_met[k] >= 0)
+      g_meteo_fields = 1;
   for (int k = 0; k < 2; k++) {
     d->wet_depo_pre[k] = c->wet_depo_pre[k];
     d->wet_depo_ic_h[k] = c->wet_depo_ic_h[k];
@@ -769,6 +786,26 @@ static void upload_met(met_t *met, int slot) {
   m.f2[MPHIP_NSS] = &met->nss[0][0];
   m.f2[MPHIP_SHF] = &met->shf[0][0];
   m.f3[MPHIP_H2O] = &met->h2o[0][0][0];
+  /* module_meteo-only fields: uploaded when a quantity it fills was requested */
+  if (g_meteo_fields) {
+    m.f3[MPHIP_Z] = &met->z[0][0][0];
+    m.f3[MPHIP_PV] = &met->pv[0][0][0];
+    m.f3[MPHIP_O3] = &met->o3[0][0][0];
+    m.f3[MPHIP_CC] = &met->cc[0][0][0];
+    m.f2[MPHIP_TS] = &met->ts[0][0];
+    m.f2[MPHIP_ZS] = &met->zs[0][0];
+    m.f2[MPHIP_US] = &met->us[0][0];
+    m.f2[MPHIP_VS] = &met->vs[0][0];
+    m.f2[MPHIP_LSM] = &met->lsm[0][0];
+    m.f2[MPHIP_SST] = &met->sst[0][0];
+    m.f2[MPHIP_PT] = &met->pt[0][0];
+    m.f2[MPHIP_TT] = &met->tt[0][0];
+    m.f2[MPHIP_ZT] = &met->zt[0][0];
+    m.f2[MPHIP_H2OT] = &met->h2ot[0][0];
+    m.f2[MPHIP_PLCL] = &met->plcl[0][0];
+    m.f2[MPHIP_PLFC] = &met->plfc[0][0];
+    m.f2[MPHIP_O3C] = &met->o3c[0][0];
+  }
   HIP(mphip_update_met(g_ctx, slot, &m));
 }
 

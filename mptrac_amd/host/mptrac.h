@@ -85,6 +85,18 @@ extern "C" {
   if ((ptr = calloc((size_t) (n), sizeof(type))) == NULL)               \
     ERRMSG("Out of memory!");
 
+/* quantities module_meteo fills: X(name, unit), in the order of its SET_ATM list (mptrac.c:5091-5157) =
+ * the MPHIP_MQ_* order of include/mptrac_hip.h; units as in the SET_QNT table (mptrac.c:6853-6969) */
+#define MPTRAC_METEO_QNT(X)                                                                            \
+  X(ps, "hPa") X(ts, "K") X(zs, "km") X(us, "m/s") X(vs, "m/s") X(ess, "N/m^2") X(nss, "N/m^2")         \
+  X(shf, "W/m^2") X(lsm, "1") X(sst, "K") X(pbl, "hPa") X(pt, "hPa") X(tt, "K") X(zt, "km")             \
+  X(h2ot, "ppv") X(zg, "km") X(p, "hPa") X(t, "K") X(rho, "kg/m^3") X(u, "m/s") X(v, "m/s")             \
+  X(w, "hPa/s") X(h2o, "ppv") X(o3, "ppv") X(lwc, "kg/kg") X(rwc, "kg/kg") X(iwc, "kg/kg")              \
+  X(swc, "kg/kg") X(cc, "1") X(pct, "hPa") X(pcb, "hPa") X(cl, "kg/m^2") X(plcl, "hPa") X(plfc, "hPa")  \
+  X(pel, "hPa") X(cape, "J/kg") X(cin, "J/kg") X(o3c, "DU") X(vh, "m/s") X(vz, "m/s") X(psat, "hPa")    \
+  X(psice, "hPa") X(pw, "hPa") X(sh, "kg/kg") X(rh, "%") X(rhice, "%") X(theta, "K") X(zeta_d, "K")     \
+  X(tvirt, "K") X(lapse, "K/km") X(pv, "PVU") X(tdew, "K") X(tice, "K")
+
 /* ---- structs -------------------------------------------------------------- */
 
 /* control parameters, hot-path subset of the reference's ctl_t
@@ -95,6 +107,10 @@ typedef struct {
   char qnt_name[NQ][LEN], qnt_unit[NQ][LEN], qnt_format[NQ][LEN];
   int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens, qnt_loss_rate;
   int qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry, qnt_zeta, qnt_eta;
+  /* module_meteo outputs: qnt_ps, qnt_ts, ..., qnt_tice (mptrac.h:2518-2740) */
+#define X(n, u) int qnt_##n;
+  MPTRAC_METEO_QNT(X)
+#undef X
   /* time and meteo input */
   int direction, met_coord_type, met_type;
   double t_start, t_stop, dt_mod, dt_met, met_utm_ref_lat, met_dt_out;
@@ -170,6 +186,10 @@ typedef struct {
   double lon[EX], lat[EY], p[EP];
   float ps[EX][EY], pbl[EX][EY], cape[EX][EY], cin[EX][EY], pel[EX][EY];
   float pct[EX][EY], pcb[EX][EY], cl[EX][EY], ess[EX][EY], nss[EX][EY], shf[EX][EY];
+  /* sampled by module_meteo only */
+  float ts[EX][EY], zs[EX][EY], us[EX][EY], vs[EX][EY], lsm[EX][EY], sst[EX][EY], pt[EX][EY], tt[EX][EY];
+  float zt[EX][EY], h2ot[EX][EY], plcl[EX][EY], plfc[EX][EY], o3c[EX][EY];
+  float z[EX][EY][EP], pv[EX][EY][EP], o3[EX][EY][EP], cc[EX][EY][EP];
   float h2o[EX][EY][EP];
   float t[EX][EY][EP], u[EX][EY][EP], v[EX][EY][EP], w[EX][EY][EP];
   float lwc[EX][EY][EP], rwc[EX][EY][EP], iwc[EX][EY][EP], swc[EX][EY][EP];

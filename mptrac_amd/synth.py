@@ -13,9 +13,15 @@ import numpy as np
 P0 = 1013.25   # mptrac.h:305
 H0 = 7.0       # mptrac.h:270
 
-FIELDS_3D = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "pl", "ul", "vl", "zetal", "zeta_dotl", "h2o")
+# order = MPHIP_U ... / MPHIP_PS ... of include/mptrac_hip.h
+FIELDS_3D = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "pl", "ul", "vl", "zetal", "zeta_dotl", "h2o",
+             "z", "pv", "o3", "cc")
 FIELDS_ML = ("pl", "ul", "vl", "zetal", "zeta_dotl")     # on model levels [nx][ny][npl]
-FIELDS_2D = ("ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "ess", "nss", "shf")
+FIELDS_2D = ("ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "ess", "nss", "shf",
+             "ts", "zs", "us", "vs", "lsm", "sst", "pt", "tt", "zt", "h2ot", "plcl", "plfc", "o3c")
+# read by module_meteo only; generated on request (fields=...)
+FIELDS_METEO_ONLY = ("z", "pv", "o3", "cc", "ts", "zs", "us", "vs", "lsm", "sst", "pt", "tt", "zt", "h2ot", "plcl",
+                     "plfc", "o3c")
 
 GRIDS = {
     # name: (NX without the periodic column, NY, NP)
@@ -68,7 +74,7 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
     snapshots differ and the time interpolation is exercised."""
     nx0, ny, npl = GRIDS[grid] if isinstance(grid, str) else grid
     lon, lat, p = make_axes(nx0, ny, npl, lon0, lat_reverse)
-    want = set(FIELDS_3D + FIELDS_2D) if fields is None else set(fields)
+    want = set(FIELDS_3D + FIELDS_2D) - set(FIELDS_METEO_ONLY) if fields is None else set(fields)
     lam = np.deg2rad(lon)[:, None, None]
     phi = np.deg2rad(lat)[None, :, None]
     k = np.arange(npl, dtype=np.float64)[None, None, :]
@@ -89,6 +95,10 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
     put3("iwc", 1e-6 * np.maximum(0.0, -np.sin(lam)) * cphi * (k < npl // 3) + 0.0 * k)
     put3("swc", 0.0 * lam * phi * k)
     put3("h2o", 1e-2 * np.exp(-k * (60.0 / npl) / 2.5) * cphi * (1.0 + 0.2 * amp * np.sin(lam)))
+    put3("z", k * (60.0 / (npl - 1)) + 0.1 * amp * np.cos(lam) * cphi)
+    put3("pv", 0.5 * amp * np.sin(phi) * np.exp(k * (60.0 / npl) / 10.0) + 0.0 * lam)
+    put3("o3", 1e-8 + 8e-6 * np.exp(-((k * (60.0 / npl) - 25.0) / 8.0) ** 2) * (1.0 + 0.1 * amp * np.sin(lam) * cphi))
+    put3("cc", np.clip(0.5 * amp * np.sin(lam) * cphi, 0.0, 1.0) * (k < npl // 3))
 
     if want & set(FIELDS_ML):
         # terrain-following model levels: p = sigma_k * ps (sigma 1 -> ~2e-4), zeta = a potential-temperature-like
@@ -128,6 +138,22 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
     put2("ess", 0.15 * amp * np.cos(lam2) * np.cos(phi2))
     put2("nss", 0.05 * np.sin(2.0 * lam2) + 0.0 * phi2)
     put2("shf", 60.0 * amp * np.sin(3.0 * lam2) * np.cos(phi2) * (np.abs(np.sin(7.0 * phi2)) > 0.3))
+    # module_meteo-only surface fields; sst is undefined over land and plfc where there is no free convection
+    # (NaN, as in the reference's data: exercises the nearest-neighbour branch of intpol_met_space_2d)
+    lsm = (np.sin(3.0 * lam2) * np.cos(phi2) > 0.2).astype(np.float64)
+    put2("ts", 288.0 + 12.0 * np.cos(phi2) + amp * np.sin(lam2))
+    put2("zs", 1.5 * lsm * np.sin(lam2) ** 2 * np.cos(phi2))
+    put2("us", 6.0 * amp * np.cos(phi2) + 0.0 * lam2)
+    put2("vs", 2.0 * amp * np.sin(2.0 * lam2) * np.cos(phi2))
+    put2("lsm", lsm)
+    put2("sst", np.where(lsm > 0.5, np.nan, 290.0 + 10.0 * np.cos(phi2) + 0.5 * amp * np.cos(lam2)))
+    put2("pt", 100.0 + 180.0 * np.abs(np.sin(phi2)) + 5.0 * amp * np.sin(lam2))
+    put2("tt", 195.0 + 25.0 * np.abs(np.sin(phi2)) + 0.0 * lam2)
+    put2("zt", 17.0 - 8.0 * np.abs(np.sin(phi2)) + 0.1 * amp * np.cos(lam2))
+    put2("h2ot", 4e-6 + 2e-6 * amp * np.cos(lam2) * np.cos(phi2))
+    put2("plcl", 900.0 + 50.0 * np.sin(lam2) * np.cos(phi2))
+    put2("plfc", np.where(np.sin(2.0 * lam2) * np.cos(phi2) > 0.1, 800.0 + 60.0 * amp * np.cos(lam2), np.nan))
+    put2("o3c", 300.0 + 60.0 * np.sin(phi2) + 0.0 * lam2)
 
     # periodic column is an exact copy of column 0 (mptrac.c:11726-11769)
     for d in (f3, f2):

@@ -95,6 +95,10 @@ def lib():
                                        C.POINTER(C.c_int), _dp, _dp]
         _lib.orc_intpol_met_time_3d.argtypes = [C.POINTER(OrcMet), C.POINTER(OrcMet), C.c_int] + \
             [C.c_double] * 4 + [_dp]
+        for fn, nargs in (("orc_rh", 3), ("orc_rhice", 3), ("orc_tdew", 2), ("orc_tice", 2), ("orc_theta", 2),
+                          ("orc_zeta", 3), ("orc_lapse_rate", 2)):
+            getattr(_lib, fn).restype = C.c_double
+            getattr(_lib, fn).argtypes = [C.c_double] * nargs
         _lib.orc_intpol_met_time_2d.argtypes = [C.POINTER(OrcMet), C.POINTER(OrcMet), C.c_int] + \
             [C.c_double] * 3 + [_dp]
     return _lib
@@ -198,6 +202,8 @@ class Oracle:
             L.orc_module_wet_depo(ctl, cache, m0, m1, atm)
         elif name == "dry_depo":
             L.orc_module_dry_depo(ctl, cache, m0, m1, atm)
+        elif name == "meteo":
+            L.orc_module_meteo(ctl, m0, m1, atm)
         else:
             raise KeyError(name)
 

@@ -212,19 +212,23 @@ static void check_horizontal(const orc_met_t *m, double lon, double lat, double 
 #define A3(a, m, i, j, k) ((a)[((size_t) (i) * (size_t) (m)->ny + (size_t) (j)) * (size_t) (m)->np + (size_t) (k)])
 #define A2(a, m, i, j) ((a)[(size_t) (i) * (size_t) (m)->ny + (size_t) (j)])
 
+/* index / weight set-up of intpol_met_space_3d (init != 0), mptrac.c:2997-3021 */
+static void stencil_init_3d(const orc_met_t *m, double p, double lon, double lat, stencil_t *s) {
+  double lon2, lat2;
+  check_horizontal(m, lon, lat, &lon2, &lat2);
+  s->ip = orc_locate_irr(m->p, m->np, p);
+  s->ix = orc_locate_reg(m->lon, m->nx, lon2);
+  s->iy = orc_locate_irr(m->lat, m->ny, lat2);
+  s->wp = (m->p[s->ip + 1] - p) / (m->p[s->ip + 1] - m->p[s->ip]);
+  s->wx = (m->lon[s->ix + 1] - lon2) / (m->lon[s->ix + 1] - m->lon[s->ix]);
+  s->wy = (m->lat[s->iy + 1] - lat2) / (m->lat[s->iy + 1] - m->lat[s->iy]);
+}
+
 /* intpol_met_space_3d, mptrac.c:2985-3044 */
 static double space_3d(const orc_met_t *m, const float *a, double p, double lon, double lat,
                        stencil_t *s, int init) {
-  if (init) {
-    double lon2, lat2;
-    check_horizontal(m, lon, lat, &lon2, &lat2);
-    s->ip = orc_locate_irr(m->p, m->np, p);
-    s->ix = orc_locate_reg(m->lon, m->nx, lon2);
-    s->iy = orc_locate_irr(m->lat, m->ny, lat2);
-    s->wp = (m->p[s->ip + 1] - p) / (m->p[s->ip + 1] - m->p[s->ip]);
-    s->wx = (m->lon[s->ix + 1] - lon2) / (m->lon[s->ix + 1] - m->lon[s->ix]);
-    s->wy = (m->lat[s->iy + 1] - lat2) / (m->lat[s->iy + 1] - m->lat[s->iy]);
-  }
+  if (init)
+    stencil_init_3d(m, p, lon, lat, s);
   const int ix = s->ix, iy = s->iy, ip = s->ip;
   /* vertical first, then latitude, then longitude */
   const double c00 = s->wp * (A3(a, m, ix, iy, ip) - A3(a, m, ix, iy, ip + 1)) + A3(a, m, ix, iy, ip + 1);
@@ -1333,6 +1337,142 @@ void orc_module_sort(const orc_ctl_t *ctl, const orc_met_t *met0, orc_atm_t *atm
   free(help);
 }
 
+/* ---- module_meteo (mptrac.c:5062-5165) ---------------------------------- */
+
+#define C_LV 2501000.   /* mptrac.h:275 */
+
+static inline double pw_of(double p, double h2o) {   /* PW, mptrac.h:1859 */
+  return p * dmax(h2o, 0.1e-6) / (1. + (1. - C_EPS) * dmax(h2o, 0.1e-6));
+}
+
+static inline double psat_of(double t) {   /* PSAT, mptrac.h:1808 */
+  return 6.112 * exp(17.62 * (t - C_T0) / (243.12 + t - C_T0));
+}
+
+static inline double psice_of(double t) {   /* PSICE, mptrac.h:1832 */
+  return 6.112 * exp(22.46 * (t - C_T0) / (272.62 + t - C_T0));
+}
+
+static inline double sh_of(double h2o) {   /* SH, mptrac.h:2024 */
+  return C_EPS * dmax(h2o, 0.1e-6);
+}
+
+double orc_rh(double p, double t, double h2o) {   /* RH, mptrac.h:1906 */
+  return pw_of(p, h2o) / psat_of(t) * 100.;
+}
+
+double orc_rhice(double p, double t, double h2o) {   /* RHICE, mptrac.h:1936 */
+  return pw_of(p, h2o) / psice_of(t) * 100.;
+}
+
+double orc_tdew(double p, double h2o) {   /* TDEW, mptrac.h:2075 */
+  return C_T0 + 243.12 * log(pw_of(p, h2o) / 6.112) / (17.62 - log(pw_of(p, h2o) / 6.112));
+}
+
+double orc_tice(double p, double h2o) {   /* TICE, mptrac.h:2100 */
+  return C_T0 + 272.62 * log(pw_of(p, h2o) / 6.112) / (22.46 - log(pw_of(p, h2o) / 6.112));
+}
+
+double orc_theta(double p, double t) {   /* THETA, mptrac.h:2124 */
+  return t * pow(1000. / p, C_KAPPA);
+}
+
+double orc_zeta(double ps, double p, double t) {   /* ZETA, mptrac.h:2293 */
+  return (p / ps <= 0.3 ? 1. : sin(M_PI / 2. * (1. - p / ps) / (1. - 0.3))) * orc_theta(p, t);
+}
+
+double orc_lapse_rate(double t, double h2o) {   /* lapse_rate, mptrac.c:3324-3338 */
+  const double a = C_RA * SQ(t), r = sh_of(h2o) / (1. - sh_of(h2o));
+  return 1e3 * C_G0 * (a + C_LV * r * t) / (C_CPD * a + SQ(C_LV) * r * C_EPS);
+}
+
+/* A field the caller did not provide reads as the zero-initialised met_t array
+ * of the reference (mptrac_alloc uses calloc) and interpolates to exactly 0. */
+#define M3(f, init) ((met0->f3[f] && met1->f3[f]) ? time_3d(met0, met1, f, tm, p, lon, lat, &s, init) : 0.0)
+#define M2(f) ((met0->f2[f] && met1->f2[f]) ? time_2d(met0, met1, f, tm, lon, lat, &s, 0) : 0.0)
+#define SETQ(k, val) if (ctl->qnt_met[k] >= 0) atm->q[ctl->qnt_met[k]][ip] = (val)
+
+void orc_module_meteo(const orc_ctl_t *ctl, const orc_met_t *met0, const orc_met_t *met1,
+                      orc_atm_t *atm) {
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {   /* PARTICLE_LOOP with check_dt = 0 */
+    const double tm = atm->time[ip], p = atm->p[ip], lon = atm->lon[ip], lat = atm->lat[ip];
+    stencil_t s = STENCIL_ZERO;
+    /* INTPOL_TIME_ALL (mptrac.h:1278-1318): the first call sets indices and weights, every other one
+     * (3-D and 2-D alike) re-uses them */
+    stencil_init_3d(met0, p, lon, lat, &s);
+    const double z = M3(ORC_Z, 0);
+    const double t = M3(ORC_T, 0), u = M3(ORC_U, 0), v = M3(ORC_V, 0), w = M3(ORC_W, 0);
+    const double pv = M3(ORC_PV, 0), h2o = M3(ORC_H2O, 0), o3 = M3(ORC_O3, 0);
+    const double lwc = M3(ORC_LWC, 0), rwc = M3(ORC_RWC, 0), iwc = M3(ORC_IWC, 0), swc = M3(ORC_SWC, 0);
+    const double cc = M3(ORC_CC, 0);
+    const double ps = M2(ORC_PS), ts = M2(ORC_TS), zs = M2(ORC_ZS), us = M2(ORC_US), vs = M2(ORC_VS);
+    const double ess = M2(ORC_ESS), nss = M2(ORC_NSS), shf = M2(ORC_SHF), lsm = M2(ORC_LSM);
+    const double sst = M2(ORC_SST), pbl = M2(ORC_PBL), pt = M2(ORC_PT), tt = M2(ORC_TT), zt = M2(ORC_ZT);
+    const double h2ot = M2(ORC_H2OT), pct = M2(ORC_PCT), pcb = M2(ORC_PCB), cl = M2(ORC_CL);
+    const double plcl = M2(ORC_PLCL), plfc = M2(ORC_PLFC), pel = M2(ORC_PEL), cape = M2(ORC_CAPE);
+    const double cin = M2(ORC_CIN), o3c = M2(ORC_O3C);
+
+    SETQ(ORC_MQ_PS, ps);
+    SETQ(ORC_MQ_TS, ts);
+    SETQ(ORC_MQ_ZS, zs);
+    SETQ(ORC_MQ_US, us);
+    SETQ(ORC_MQ_VS, vs);
+    SETQ(ORC_MQ_ESS, ess);
+    SETQ(ORC_MQ_NSS, nss);
+    SETQ(ORC_MQ_SHF, shf);
+    SETQ(ORC_MQ_LSM, lsm);
+    SETQ(ORC_MQ_SST, sst);
+    SETQ(ORC_MQ_PBL, pbl);
+    SETQ(ORC_MQ_PT, pt);
+    SETQ(ORC_MQ_TT, tt);
+    SETQ(ORC_MQ_ZT, zt);
+    SETQ(ORC_MQ_H2OT, h2ot);
+    SETQ(ORC_MQ_ZG, z);
+    SETQ(ORC_MQ_P, p);
+    SETQ(ORC_MQ_T, t);
+    SETQ(ORC_MQ_RHO, rho_air(p, t));
+    SETQ(ORC_MQ_U, u);
+    SETQ(ORC_MQ_V, v);
+    SETQ(ORC_MQ_W, w);
+    SETQ(ORC_MQ_H2O, h2o);
+    SETQ(ORC_MQ_O3, o3);
+    SETQ(ORC_MQ_LWC, lwc);
+    SETQ(ORC_MQ_RWC, rwc);
+    SETQ(ORC_MQ_IWC, iwc);
+    SETQ(ORC_MQ_SWC, swc);
+    SETQ(ORC_MQ_CC, cc);
+    SETQ(ORC_MQ_PCT, pct);
+    SETQ(ORC_MQ_PCB, pcb);
+    SETQ(ORC_MQ_CL, cl);
+    SETQ(ORC_MQ_PLCL, plcl);
+    SETQ(ORC_MQ_PLFC, plfc);
+    SETQ(ORC_MQ_PEL, pel);
+    SETQ(ORC_MQ_CAPE, cape);
+    SETQ(ORC_MQ_CIN, cin);
+    SETQ(ORC_MQ_O3C, o3c);
+    SETQ(ORC_MQ_VH, sqrt(u * u + v * v));
+    SETQ(ORC_MQ_VZ, -1e3 * C_H0 / p * w);
+    SETQ(ORC_MQ_PSAT, psat_of(t));
+    SETQ(ORC_MQ_PSICE, psice_of(t));
+    SETQ(ORC_MQ_PW, pw_of(p, h2o));
+    SETQ(ORC_MQ_SH, sh_of(h2o));
+    SETQ(ORC_MQ_RH, orc_rh(p, t, h2o));
+    SETQ(ORC_MQ_RHICE, orc_rhice(p, t, h2o));
+    SETQ(ORC_MQ_THETA, orc_theta(p, t));
+    SETQ(ORC_MQ_ZETA_D, orc_zeta(ps, p, t));
+    SETQ(ORC_MQ_TVIRT, tvirt(t, h2o));
+    SETQ(ORC_MQ_LAPSE, orc_lapse_rate(t, h2o));
+    SETQ(ORC_MQ_PV, pv);
+    SETQ(ORC_MQ_TDEW, orc_tdew(p, h2o));
+    SETQ(ORC_MQ_TICE, orc_tice(p, h2o));
+  }
+}
+
+#undef M3
+#undef M2
+#undef SETQ
+
 /* ---- scheduler: mptrac_run_timestep (mptrac.c:7851-8001) ---------------- */
 
 void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
@@ -1359,6 +1499,8 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
   if (ctl->qnt_rp >= 0 && ctl->qnt_rhop >= 0)
     orc_module_sedi(ctl, cache, met0, met1, atm);
   orc_module_position(cache, met0, met1, atm);
+  if (ctl->met_dt_out > 0 && (ctl->met_dt_out < ctl->dt_mod || fmod(t, ctl->met_dt_out) == 0))
+    orc_module_meteo(ctl, met0, met1, atm);   /* mptrac.c:7921-7924 */
   /* zero the total loss rate, mptrac.c:7932-7936 */
   if (ctl->qnt_loss_rate >= 0)
     for (int ip = 0; ip < atm->np; ip++)

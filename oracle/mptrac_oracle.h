@@ -32,10 +32,22 @@ extern "C" {
 enum { ORC_U = 0, ORC_V, ORC_W, ORC_T, ORC_LWC, ORC_RWC, ORC_IWC, ORC_SWC,
        /* model-level fields, float [nx][ny][npl] (mptrac.h:3997-4012) */
        ORC_PL, ORC_UL, ORC_VL, ORC_ZETAL, ORC_ZETA_DOTL,
-       ORC_H2O, ORC_N3D };
+       ORC_H2O,
+       /* module_meteo only (INTPOL_TIME_ALL, mptrac.h:1278-1318) */
+       ORC_Z, ORC_PV, ORC_O3, ORC_CC, ORC_N3D };
 /* 2-D met fields, each float [nx][ny] */
 enum { ORC_PS = 0, ORC_PBL, ORC_CAPE, ORC_CIN, ORC_PEL, ORC_PCT, ORC_PCB, ORC_CL,
-       ORC_ESS, ORC_NSS, ORC_SHF, ORC_N2D };
+       ORC_ESS, ORC_NSS, ORC_SHF,
+       ORC_TS, ORC_ZS, ORC_US, ORC_VS, ORC_LSM, ORC_SST, ORC_PT, ORC_TT, ORC_ZT, ORC_H2OT,
+       ORC_PLCL, ORC_PLFC, ORC_O3C, ORC_N2D };
+/* quantities module_meteo sets, in the order of its SET_ATM list (mptrac.c:5091-5157) */
+enum { ORC_MQ_PS = 0, ORC_MQ_TS, ORC_MQ_ZS, ORC_MQ_US, ORC_MQ_VS, ORC_MQ_ESS, ORC_MQ_NSS, ORC_MQ_SHF,
+       ORC_MQ_LSM, ORC_MQ_SST, ORC_MQ_PBL, ORC_MQ_PT, ORC_MQ_TT, ORC_MQ_ZT, ORC_MQ_H2OT, ORC_MQ_ZG, ORC_MQ_P,
+       ORC_MQ_T, ORC_MQ_RHO, ORC_MQ_U, ORC_MQ_V, ORC_MQ_W, ORC_MQ_H2O, ORC_MQ_O3, ORC_MQ_LWC, ORC_MQ_RWC,
+       ORC_MQ_IWC, ORC_MQ_SWC, ORC_MQ_CC, ORC_MQ_PCT, ORC_MQ_PCB, ORC_MQ_CL, ORC_MQ_PLCL, ORC_MQ_PLFC,
+       ORC_MQ_PEL, ORC_MQ_CAPE, ORC_MQ_CIN, ORC_MQ_O3C, ORC_MQ_VH, ORC_MQ_VZ, ORC_MQ_PSAT, ORC_MQ_PSICE,
+       ORC_MQ_PW, ORC_MQ_SH, ORC_MQ_RH, ORC_MQ_RHICE, ORC_MQ_THETA, ORC_MQ_ZETA_D, ORC_MQ_TVIRT, ORC_MQ_LAPSE,
+       ORC_MQ_PV, ORC_MQ_TDEW, ORC_MQ_TICE, ORC_NMQ };
 
 /* Hot-path subset of ctl_t (mptrac.h:2494-3553).  Field names follow the
  * reference.  Layout is mirrored 1:1 by the Python ctypes class. */
@@ -77,6 +89,10 @@ typedef struct {
   double grid_z0, grid_z1, grid_lon0, grid_lon1, grid_lat0, grid_lat1;
   int grid_nx, grid_ny, grid_nz;
   int pad1;
+  /* module_meteo (mptrac.c:7197, 7921-7924); qnt_met[k] = ctl->qnt_<name>, -1 = not present */
+  double met_dt_out;
+  int qnt_met[ORC_NMQ];
+  int pad2;
 } orc_ctl_t;
 
 /* One meteo snapshot: compact view of met_t (mptrac.h:3844-4014). */
@@ -136,6 +152,16 @@ void orc_intpol_met_time_3d(const orc_met_t *met0, const orc_met_t *met1, int fi
 void orc_intpol_met_time_2d(const orc_met_t *met0, const orc_met_t *met1, int field,
                             double ts, double lon, double lat, double *var);
 
+/* thermodynamic macros used by module_meteo: RH, RHICE, TDEW, TICE (mptrac.h:1906, 1936, 2075, 2100),
+ * THETA, ZETA, TVIRT (mptrac.h:2124, 2293, 2199) and lapse_rate (mptrac.c:3324) */
+double orc_rh(double p, double t, double h2o);
+double orc_rhice(double p, double t, double h2o);
+double orc_tdew(double p, double h2o);
+double orc_tice(double p, double h2o);
+double orc_theta(double p, double t);
+double orc_zeta(double ps, double p, double t);
+double orc_lapse_rate(double t, double h2o);
+
 /* --- modules (mptrac.c:3598-6293) ---------------------------------------- */
 void orc_module_rng(const orc_ctl_t *ctl, orc_cache_t *cache, size_t n, int method);
 void orc_module_timesteps(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
@@ -164,6 +190,8 @@ void orc_module_wet_depo(const orc_ctl_t *ctl, const orc_cache_t *cache, const o
                          const orc_met_t *met1, orc_atm_t *atm);
 void orc_module_dry_depo(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
                          const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_meteo(const orc_ctl_t *ctl, const orc_met_t *met0, const orc_met_t *met1,
+                      orc_atm_t *atm);   /* mptrac.c:5062 */
 /* keys[np] (as the reference's double keys, exact integers) and perm[np] are
  * optional outputs (may be NULL).  Ties are ordered by original index. */
 void orc_module_sort(const orc_ctl_t *ctl, const orc_met_t *met0, orc_atm_t *atm,

@@ -3,7 +3,7 @@ import numpy as np
 
 from mptrac_amd.clim import load_clim_tropo
 from mptrac_amd.ctl import ctl_from_quantities
-from mptrac_amd.synth import synthetic_met, synthetic_particles
+from mptrac_amd.synth import FIELDS_METEO_ONLY, synthetic_met, synthetic_particles
 
 BASE = dict(advect=4, dt_mod=180.0, t_stop=3600.0, dt_met=3600.0, rng_type=1)
 
@@ -39,6 +39,15 @@ CASES = {
     # Henry-law wet deposition with SO2 pH correction
     "wet_henry": dict(BASE, wet_depo_ic_h=(1.3e-2, 2900.0), wet_depo_bc_h=(1.3e-2, 2900.0),
                       wet_depo_so2_ph=4.5, wet_depo_ic_ret_ratio=0.5, wet_depo_bc_ret_ratio=0.3),
+    # module_meteo every step (MET_DT_OUT default 0.1 < DT_MOD) on top of the stochastic modules
+    "meteo": dict(BASE, diffusion=1, turb_dz_trop=0.1, conv_cape=0.0),
+    # module_meteo only when fmod(t, MET_DT_OUT) == 0, interleaved with module_sort
+    "meteo_gated": dict(BASE, met_dt_out=1800.0, sort_dt=360.0, diffusion=1, turb_dz_trop=0.1),
+}
+
+CASE_QUANTITIES = {
+    "meteo": ("m", "rp", "rhop", "t", "u", "zg", "pv", "ps", "pt", "theta", "rh", "zeta_d", "sst", "lapse", "vh", "o3"),
+    "meteo_gated": ("m", "t", "w", "h2o", "tdew", "plfc", "cc", "rho"),
 }
 
 QUANTITIES = ("m", "rp", "rhop", "vmr", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry")
@@ -51,11 +60,13 @@ def make_case(name, n=10000, grid="C1", seed=12345, quantities=None, lon0=-180.0
     ctl = dict(CASES[name])
     ml = ctl.get("advect_vert_coord", 0) in (1, 3)
     if quantities is None:
-        quantities = QUANTITIES_ML if ml else QUANTITIES
+        quantities = CASE_QUANTITIES.get(name, QUANTITIES_ML if ml else QUANTITIES)
     if fields is None and not ml:
         fields = PRESSURE_LEVEL_FIELDS          # model-level fields only where they are used
+        if name in CASE_QUANTITIES:
+            fields = fields + FIELDS_METEO_ONLY
     ctl.update(ctl_from_quantities(quantities))
-    if name.startswith("advect") or name in ("turb", "diff", "conv_thresh", "pbl"):
+    if name.startswith("advect") or name in ("turb", "diff", "conv_thresh", "pbl", "meteo_gated"):
         # no sedimentation in these
         ctl["qnt_rp"] = ctl["qnt_rhop"] = -1
     met0 = synthetic_met(grid, 0.0, 1.0, fields=fields, lon0=lon0)
@@ -74,7 +85,23 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     if a.size == 0:
         return 0.0
+    nan = np.isnan(b)
+    if nan.any():      # undefined values (e.g. sst over land) must be undefined on both sides
+        if not np.array_equal(np.isnan(a), nan):
+            return float("inf")
+        a, b = np.where(nan, 0.0, a), np.where(nan, 0.0, b)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+
+
+def rel_err_strict(a, b, floor=1e-300):
+    """True relative error |a - b| / |b| (quantities far below 1, e.g. mixing ratios)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    nan = np.isnan(b)
+    if not np.array_equal(np.isnan(a), nan):
+        return float("inf")
+    a, b = np.where(nan, 0.0, a), np.where(nan, 0.0, b)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
 
 
 def step_times(ctl):

@@ -324,11 +324,15 @@ def test_strided_meteo_upload_matches_compact():
         mm.sx, mm.sy, mm.sx2 = EY * EP, EP, EY
         mm.npl, mm.sx_ml, mm.sy_ml = m.npl, EY * EP, EP
         for i, k in enumerate(FIELDS_3D):
+            if k not in m.f3:
+                continue
             big = np.full((EX, EY, EP), np.nan, dtype=np.float32)
             big[:m.nx, :m.ny, :(m.npl if k in FIELDS_ML else m.np)] = m.f3[k]
             keep.append(big)
             mm.f3[i] = big.ctypes.data_as(fp)
         for i, k in enumerate(FIELDS_2D):
+            if k not in m.f2:
+                continue
             big = np.full((EX, EY), np.nan, dtype=np.float32)
             big[:m.nx, :m.ny] = m.f2[k]
             keep.append(big)
@@ -353,6 +357,90 @@ def test_missing_field_is_an_error_not_a_fallback():
         s.run_timestep(180.0)
     s.close()
 
+
+
+# ---------------------------------------------------------------------------
+# module_meteo
+# ---------------------------------------------------------------------------
+
+def _row_err(a, b):
+    """Largest error of a quantity row relative to max(|b|, 1e-6 max|row|); NaN patterns must agree."""
+    nan = np.isnan(b)
+    if not np.array_equal(np.isnan(a), nan):
+        return float("inf")
+    a, b = np.where(nan, 0.0, a), np.where(nan, 0.0, b)
+    scale = np.maximum(np.abs(b), 1e-6 * max(np.max(np.abs(b)), 1e-300))
+    return float(np.max(np.abs(a - b) / scale))
+
+
+def test_module_meteo_every_quantity():
+    """All 53 quantities of module_meteo's SET_ATM list (mptrac.c:5091-5157), NQ_MAX at a time, at
+    generic and special positions (poles, date line, outside the pressure range, NaN neighbourhoods)."""
+    from mptrac_amd.ctl import METEO_QUANTITIES, ctl_from_quantities
+    from mptrac_amd.synth import FIELDS_METEO_ONLY
+    fields = cases.PRESSURE_LEVEL_FIELDS + FIELDS_METEO_ONLY
+    m0 = synthetic_met("C1", 0.0, 1.0, fields=fields)
+    m1 = synthetic_met("C1", 3600.0, 1.25, fields=fields)
+    clim = cases.load_clim_tropo()
+    n = 20000
+    for first in range(0, len(METEO_QUANTITIES), 15):
+        names = ("m",) + METEO_QUANTITIES[first:first + 15]
+        atm = synthetic_particles(n, seed=99 + first, quantities=names, time=1234.5)
+        atm["lon"][:8] = [-180.0, 179.999999, 0.0, 359.5, -359.5, 720.25, 180.0, -180.000001]
+        atm["lat"][8:16] = [90.0, -90.0, 89.9995, -89.9995, 91.0, -93.5, 45.0, -45.0]
+        atm["p"][16:20] = [0.05, 1200.0, 1013.25, 300.0]
+        atm["time"][20:24] = [0.0, 3600.0, 1800.0, 5000.0]
+        ctl = dict(cases.BASE, **ctl_from_quantities(names))
+        o = B.Oracle(ctl, clim, m0, m1, atm)
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        o.module("meteo")
+        s.module("meteo")
+        g, r = s.state(), o.state()
+        for k in ("time", "lon", "lat", "p"):
+            assert np.array_equal(g[k], r[k])
+        assert np.array_equal(g["q"][0], r["q"][0])
+        for i, name in enumerate(names[1:], start=1):
+            assert np.any(r["q"][i] != 0.0) or name in ("swc",), name
+            assert _row_err(g["q"][i], r["q"][i]) <= 1e-11, (name, _row_err(g["q"][i], r["q"][i]))
+        s.close()
+
+
+def test_module_meteo_missing_field_is_an_error():
+    from mptrac_amd.ctl import ctl_from_quantities
+    names = ("m", "t", "pv")
+    m0 = synthetic_met("tiny", 0.0, 1.0, fields=cases.PRESSURE_LEVEL_FIELDS)
+    m1 = synthetic_met("tiny", 3600.0, 1.25, fields=cases.PRESSURE_LEVEL_FIELDS)
+    atm = synthetic_particles(100, quantities=names)
+    s = hip.Simulation(dict(cases.BASE, **ctl_from_quantities(names)), cases.load_clim_tropo(), m0, m1, atm)
+    with pytest.raises(hip.MphipError, match="pv"):
+        s.module("meteo")
+    s.close()
+
+
+def test_module_meteo_in_internal_order_and_shards():
+    """Quantities land in the right external slot with the locality order on, and sharded contexts
+    reproduce the single-context bits."""
+    ctl, clim, m0, m1, atm = cases.make_case("meteo", n=6001)
+    a = hip.Simulation(ctl, clim, m0, m1, atm)
+    a.set_option("locality_sort_interval", 0)
+    b = hip.Simulation(ctl, clim, m0, m1, atm)
+    b.set_option("locality_sort_interval", 2)
+    parts = [hip.Simulation(ctl, clim, m0, m1, atm, shard=hip.shard_range(6001, r, 2)) for r in range(2)]
+    sims = [a, b] + parts
+    for sim in sims:
+        sim.timesteps_init(0.0, 0.0)
+    for t in cases.step_times(a.ctl)[:5]:
+        for sim in sims:
+            sim.run_timestep(t)
+    ga, gb = a.state(), b.state()
+    gp = [p.state() for p in parts]
+    for k in ("lon", "lat", "p"):
+        assert np.array_equal(ga[k], gb[k], equal_nan=True), k
+        assert np.array_equal(ga[k], np.concatenate([g[k] for g in gp]), equal_nan=True), k
+    assert np.array_equal(ga["q"], gb["q"], equal_nan=True)
+    assert np.array_equal(ga["q"], np.concatenate([g["q"] for g in gp], axis=1), equal_nan=True)
+    for sim in sims:
+        sim.close()
 
 # ---------------------------------------------------------------------------
 # sharding (one process per GPU in production; two contexts on one GPU here)

@@ -11,30 +11,37 @@ import cases
 import hostfiles as hf
 from mptrac_amd import build
 from mptrac_amd.clim import load_clim_tropo
-from mptrac_amd.synth import synthetic_met, synthetic_particles
+from mptrac_amd.ctl import ctl_from_quantities
+from mptrac_amd.synth import FIELDS_METEO_ONLY, synthetic_met, synthetic_particles
 from oracle import binding as B
 
 T0 = 707443200.0      # 2022-06-02 00:00 UTC, as tests/dd_test of the reference
 QUANT = ("m", "rp", "rhop")
+# with module_meteo outputs (default MET_DT_OUT 0.1: every step), as the reference's tests/trac_test sets them
+QUANT_METEO = ("m", "rp", "rhop", "t", "u", "zg", "pv", "ps", "pt", "theta", "rh", "sst")
 
 
-def _setup(tmp, n=3000, hours=2, atm_type=1, pbl=False):
+def _setup(tmp, n=3000, hours=2, atm_type=1, pbl=False, meteo=False):
     lib, trac = build.build_host()
     metbase = os.path.join(tmp, "met")
     mets = []
+    fields = cases.PRESSURE_LEVEL_FIELDS + FIELDS_METEO_ONLY if meteo else None
+    QUANT = QUANT_METEO if meteo else globals()["QUANT"]
     for k in range(hours + 1):
-        m = synthetic_met("tiny", T0 + 3600.0 * k, 1.0 + 0.1 * k)
+        m = synthetic_met("tiny", T0 + 3600.0 * k, 1.0 + 0.1 * k, fields=fields)
         hf.write_met_bin(hf.met_filename(metbase, m.time), m)
         mets.append(m)
     atm = synthetic_particles(n, time=T0, quantities=QUANT)
     if pbl:      # half of the particles inside the boundary layer
         atm["p"][::2] = 1013.25 * np.exp(-(0.02 + 0.9 * (atm["lon"][::2] + 180.0) / 360.0) / 7.0)
     (hf.write_atm_bin if atm_type == 1 else hf.write_atm_asc)(os.path.join(tmp, "atm_in"), atm)
-    keys = {"NQ": 3, "QNT_NAME[0]": "m", "QNT_NAME[1]": "rp", "QNT_NAME[2]": "rhop", "METBASE": metbase,
-            "MET_TYPE": 1, "DT_MET": 3600, "DT_MOD": 180, "ADVECT": 4, "DIFFUSION": 1, "TURB_DZ_TROP": 0.1,
+    keys = {"NQ": len(QUANT), "METBASE": metbase, "MET_TYPE": 1, "DT_MET": 3600, "DT_MOD": 180, "ADVECT": 4, "DIFFUSION": 1, "TURB_DZ_TROP": 0.1,
             "CONV_CAPE": 0, "T_STOP": T0 + 3600.0 * hours, "ATM_TYPE": atm_type, "ATM_TYPE_OUT": 1,
             "ATM_BASENAME": "atm", "ATM_DT_OUT": 3600, "GRID_BASENAME": "grid", "GRID_DT_OUT": 3600,
-            "GRID_NX": 36, "GRID_NY": 18, "MET_DT_OUT": 0}
+            "GRID_NX": 36, "GRID_NY": 18}
+    keys.update({"QNT_NAME[%d]" % i: q for i, q in enumerate(QUANT)})
+    if not meteo:
+        keys["MET_DT_OUT"] = 0
     if pbl:
         keys.update({"TURB_PBL_SCHEME": 1, "TURB_MESOZ": 0})
     hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
@@ -42,9 +49,10 @@ def _setup(tmp, n=3000, hours=2, atm_type=1, pbl=False):
     return trac, mets, atm
 
 
-def _oracle(mets, atm, hours, pbl=False):
+def _oracle(mets, atm, hours, pbl=False, meteo=False):
     ctl = dict(advect=4, dt_mod=180.0, dt_met=3600.0, diffusion=1, turb_dz_trop=0.1, conv_cape=0.0,
-               t_stop=T0 + 3600.0 * hours, nq=3, qnt_m=0, qnt_rp=1, qnt_rhop=2)
+               t_stop=T0 + 3600.0 * hours, met_dt_out=0.1 if meteo else 0.0,
+               **ctl_from_quantities(QUANT_METEO if meteo else QUANT))
     if pbl:
         ctl.update(turb_pbl_scheme=1, turb_mesoz=0.0)
     o = B.Oracle(ctl, load_clim_tropo(), mets[0], mets[1], atm)
@@ -74,10 +82,11 @@ def test_trac_refuses_to_run_without_a_device(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("atm_type,pbl", [(1, False), (0, False), (1, True)])
-def test_trac_end_to_end_matches_oracle(tmp_path, atm_type, pbl):
+@pytest.mark.parametrize("atm_type,pbl,meteo", [(1, False, False), (0, False, False), (1, True, False), (1, False, True)])
+def test_trac_end_to_end_matches_oracle(tmp_path, atm_type, pbl, meteo):
     tmp = str(tmp_path)
-    trac, mets, atm = _setup(tmp, n=3000, hours=2, atm_type=atm_type, pbl=pbl)
+    nq = len(QUANT_METEO if meteo else QUANT)
+    trac, mets, atm = _setup(tmp, n=3000, hours=2, atm_type=atm_type, pbl=pbl, meteo=meteo)
     r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT)
     out = r.stdout.decode()
@@ -85,11 +94,11 @@ def test_trac_end_to_end_matches_oracle(tmp_path, atm_type, pbl):
     if atm_type == 0:
         # ASCII input carries altitude; the driver converts with P(z) like the reference
         atm = dict(atm, p=1013.25 * np.exp(-(7.0 * np.log(1013.25 / atm["p"])) / 7.0))
-    snaps = _oracle(mets, atm, 2, pbl=pbl)
+    snaps = _oracle(mets, atm, 2, pbl=pbl, meteo=meteo)
     for hour in (0, 1, 2):
         t = T0 + 3600.0 * hour
         f = os.path.join(tmp, "atm_2022_06_02_%02d_00_00.bin" % hour)
-        got = hf.read_atm_bin(f, 3)
+        got = hf.read_atm_bin(f, nq)
         ref = snaps[t]
         tol = 1e-10 if atm_type == 1 else 1e-9     # ASCII input: repr() round trip of z -> p
         assert np.array_equal(got["time"], ref["time"])

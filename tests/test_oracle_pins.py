@@ -111,3 +111,55 @@ def test_dd_test_golden_trajectories():
             break
         t += ctl["dt_mod"]
     assert nbad == 0, (nbad, worst)
+
+
+def test_humidity_macros_match_reference_met_sample_table():
+    """tests/met_test/data.ref/sample_ei_2011_06_05_00.tab (met_sample tool): RH, RHICE, TDEW, TICE
+    recomputed from the printed p, T, H2O columns.  Inputs carry six digits, so the bar is what that
+    allows (1e-3 on the humidities, 1e-4 on the temperatures), tight enough to catch a wrong constant
+    or formula of PW / PSAT / PSICE / TDEW / TICE (mptrac.h:1808-2102)."""
+    a = np.loadtxt(os.path.join(GOLD, "ref_met_test", "sample_thermo.tab"))
+    assert a.shape == (3000, 7)
+    L = B.lib()
+    for p, t, h2o, rh, rhice, tdew, tice in a:
+        assert abs(L.orc_rh(p, t, h2o) - rh) <= 1e-3 * abs(rh)
+        assert abs(L.orc_rhice(p, t, h2o) - rhice) <= 1e-3 * abs(rhice)
+        assert abs(L.orc_tdew(p, h2o) - tdew) <= 1e-4 * tdew
+        assert abs(L.orc_tice(p, h2o) - tice) <= 1e-4 * tice
+
+
+def test_module_meteo_is_the_interpolation_plus_the_macros():
+    """orc_module_meteo against the separately pinned pieces: orc_intpol_met_time_3d/2d at the particle
+    and the scalar helpers."""
+    from mptrac_amd.ctl import ctl_from_quantities
+    from mptrac_amd.synth import FIELDS_2D, FIELDS_3D, FIELDS_METEO_ONLY
+    import cases
+    names = ("t", "h2o", "ps", "theta", "zeta_d", "rh", "tice", "lapse", "sst", "p", "pv", "vh", "u", "v")
+    fields = cases.PRESSURE_LEVEL_FIELDS + FIELDS_METEO_ONLY
+    m0 = synthetic_met("tiny", 0.0, 1.0, fields=fields)
+    m1 = synthetic_met("tiny", 3600.0, 1.3, fields=fields)
+    atm = synthetic_particles(300, quantities=names, time=900.0)
+    o = B.Oracle(dict(ctl_from_quantities(names)), load_clim_tropo(), m0, m1, atm)
+    o.module("meteo")
+    q = dict(zip(names, o.q))
+    L = o.lib
+    v = C.c_double()
+    for ip in range(o.n):
+        tm, p, lon, lat = o.time[ip], o.p[ip], o.lon[ip], o.lat[ip]
+        L.orc_intpol_met_time_3d(C.byref(o.met[0]), C.byref(o.met[1]), FIELDS_3D.index("t"), tm, p, lon, lat, C.byref(v))
+        t = v.value
+        L.orc_intpol_met_time_3d(C.byref(o.met[0]), C.byref(o.met[1]), FIELDS_3D.index("h2o"), tm, p, lon, lat, C.byref(v))
+        h2o = v.value
+        L.orc_intpol_met_time_2d(C.byref(o.met[0]), C.byref(o.met[1]), FIELDS_2D.index("ps"), tm, lon, lat, C.byref(v))
+        ps = v.value
+        L.orc_intpol_met_time_2d(C.byref(o.met[0]), C.byref(o.met[1]), FIELDS_2D.index("sst"), tm, lon, lat, C.byref(v))
+        sst = v.value
+        assert (q["t"][ip], q["h2o"][ip], q["ps"][ip], q["p"][ip]) == (t, h2o, ps, p)
+        assert q["sst"][ip] == sst or (np.isnan(sst) and np.isnan(q["sst"][ip]))
+        assert q["theta"][ip] == L.orc_theta(p, t)
+        assert q["zeta_d"][ip] == L.orc_zeta(ps, p, t)
+        assert q["rh"][ip] == L.orc_rh(p, t, h2o)
+        assert q["tice"][ip] == L.orc_tice(p, h2o)
+        assert q["lapse"][ip] == L.orc_lapse_rate(t, h2o)
+        assert q["vh"][ip] == np.sqrt(q["u"][ip] ** 2 + q["v"][ip] ** 2)
+    assert np.isnan(q["sst"]).any() and np.isfinite(q["sst"]).any()
