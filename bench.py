@@ -37,6 +37,12 @@ WORKLOADS = {
     # name: (grid, particles per GPU, control, quantities, meteo fields)
     "C3": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1),
            ("m", "rp", "rhop"), ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel")),
+    # C3 with module_meteo every step (the reference's default MET_DT_OUT 0.1) filling the quantity set of the
+    # reference's tests/trac_test (t, u, v, w, zg, pv, ps, pt); not the headline configuration (SURVEY row 22:
+    # benchmarks of the reference set MET_DT_OUT 0)
+    "C3m": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1),
+            ("m", "rp", "rhop", "t", "u", "v", "w", "zg", "pv", "ps", "pt"),
+            ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel", "z", "pv", "pt")),
     "C2": ("C2", 10 ** 6, dict(advect=4, dt_mod=180.0, diffusion=1, turb_mesox=0.0, turb_mesoz=0.0, rng_type=1),
            ("m",), ("u", "v", "w", "ps", "pbl")),
     "C1": ("C1", 10 ** 4, dict(advect=4, dt_mod=180.0, rng_type=1), ("m",), ("u", "v", "w", "ps")),
@@ -48,6 +54,7 @@ def algorithmic_bytes_per_pstep(workload, met, np_local):
     fused step must read and write once; A_met = every packed grid byte the
     step can touch, once per launch."""
     state = {"C3": 64 + 24 + 16,   # time,lon,lat,p R+W; uvwp R+W; rp,rhop R
+             "C3m": 64 + 24 + 16,  # (the step kernel's bytes; module_meteo is a separate kernel)
              "C2": 64, "C1": 64}[workload]
     wind = met.nx * met.ny * met.np * 32            # {u,v,w,t} x 2 snapshots, float
     sfc = met.nx * met.ny * 64                      # 8 surface fields x 2 snapshots
@@ -190,7 +197,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: BASELINE configs[2] -- 1e7 particles/GPU, RK4 advection + "
                                    "turbulent + mesoscale diffusion + convection + sedimentation, 721x361x137 "
-                                   "synthetic ERA5-shaped grid" if args.workload == "C3" else args.workload,
+                                   "synthetic ERA5-shaped grid" if args.workload == "C3" else
+                                   ("C3 + module_meteo every step (t, u, v, w, zg, pv, ps, pt)"
+                                    if args.workload == "C3m" else args.workload),
                        "particles_per_gpu": n_local, "particles_total": n_total,
                        "grid": [met0.nx, met0.ny, met0.np], "dt_mod": dt,
                        "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce"},

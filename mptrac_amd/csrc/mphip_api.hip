@@ -55,6 +55,7 @@ struct mphip_ctx {
   int lut_base = 0, lut_size = 0;
   size_t axes_bytes = 0;
   float *d_wind = nullptr, *d_temp = nullptr;     // packed two-snapshot grids (layouts: mphip_device.hpp)
+  f32x4 *d_mx = nullptr;                          // {z,pv,o3,cc} records (module_meteo)
   f32x4 *d_cloud = nullptr, *d_sfa = nullptr, *d_sfb = nullptr, *d_sfc = nullptr, *d_sfd = nullptr;
   float *d_h2o = nullptr;
   bool packed_dirty = true;
@@ -166,6 +167,7 @@ DevMet dev_met(const mphip_ctx *c) {
   M.wind = c->d_wind;
   M.temp = c->d_temp;
   M.cloud = c->d_cloud;
+  M.mx = c->d_mx;
   M.sfa = c->d_sfa;
   M.sfb = c->d_sfb;
   M.sfc = c->d_sfc;
@@ -291,7 +293,7 @@ int ensure_packed(mphip_ctx *ctx) {
     return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
   const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
   PackArgs a;
-  bool any_cloud = false, any_ml = false, any_pbl = false;
+  bool any_cloud = false, any_ml = false, any_pbl = false, any_mx = false;
   const MetSlot *ss[2] = { &s0, &s1 };
   for (int t = 0; t < 2; t++) {
     for (int f = 0; f < MPHIP_N3D; f++)
@@ -300,6 +302,8 @@ int ensure_packed(mphip_ctx *ctx) {
       a.f2[t][f] = ss[t]->has2[f] ? ss[t]->f2[f] : nullptr;
     for (int f = MPHIP_LWC; f <= MPHIP_SWC; f++)
       any_cloud = any_cloud || ss[t]->has3[f];
+    for (int f = MPHIP_Z; f <= MPHIP_CC; f++)
+      any_mx = any_mx || ss[t]->has3[f];
     any_ml = any_ml || ss[t]->has3[MPHIP_UL] || ss[t]->has3[MPHIP_VL] || ss[t]->has3[MPHIP_ZETA_DOTL];
     any_pbl = any_pbl || ss[t]->has3[MPHIP_H2O] || ss[t]->has2[MPHIP_ESS] || ss[t]->has2[MPHIP_NSS]
       || ss[t]->has2[MPHIP_SHF];
@@ -315,11 +319,14 @@ int ensure_packed(mphip_ctx *ctx) {
     return 1;
   if (any_cloud && !ctx->d_cloud && dev_alloc(ctx, &ctx->d_cloud, 2 * ncell))
     return 1;
+  if (any_mx && !ctx->d_mx && dev_alloc(ctx, &ctx->d_mx, 2 * ncell))
+    return 1;
   if (any_pbl && !ctx->d_sfd && (dev_alloc(ctx, &ctx->d_sfd, 2 * ncol) || dev_alloc(ctx, &ctx->d_h2o, 2 * ncell)))
     return 1;
   a.wind = ctx->d_wind;
   a.temp = ctx->d_temp;
   a.cloud = any_cloud ? ctx->d_cloud : nullptr;
+  a.mx = any_mx ? ctx->d_mx : nullptr;
   a.sfa = ctx->d_sfa;
   a.sfb = ctx->d_sfb;
   a.sfc = ctx->d_sfc;
@@ -533,12 +540,10 @@ int launch_meteo(mphip_ctx *ctx) {
   memset(&G, 0, sizeof(G));
   const MeteoDeps d = meteo_deps(c);
   for (int f = 0; f < MPHIP_N3D; f++)
-    if ((d.need3 >> f) & 1u) {
-      if (!s0.has3[f] || !s1.has3[f])
-        return fail(ctx, std::string("module_meteo: meteo field ") + n3[f] + " was not uploaded");
-      G.f3[0][f] = s0.f3[f];
-      G.f3[1][f] = s1.f3[f];
-    }
+    if (((d.need3 >> f) & 1u) && (!s0.has3[f] || !s1.has3[f]))
+      return fail(ctx, std::string("module_meteo: meteo field ") + n3[f] + " was not uploaded");
+  if (ensure_packed(ctx))
+    return 1;
   for (int f = 0; f < MPHIP_N2D; f++)
     if ((d.need2 >> f) & 1u) {
       if (!s0.has2[f] || !s1.has2[f])
@@ -551,7 +556,14 @@ int launch_meteo(mphip_ctx *ctx) {
   G.atm = dev_atm(ctx);
   G.need3 = d.need3;
   G.need2 = d.need2;
-  hipLaunchKernelGGL(meteo_kernel, dim3(grid_for(ctx->np, 256, 16384)), dim3(256), axes_lds_bytes(ctx), ctx->stream, G);
+  long long per_block = (ctx->np + ctx->step_blocks - 1) / ctx->step_blocks;
+  per_block = std::max<long long>(256, (per_block + 255) / 256 * 256);
+  int nb = (int) ((ctx->np + per_block - 1) / per_block);
+  nb = (nb + 7) & ~7;
+  G.nblocks_logical = nb;
+  G.per_block = per_block;
+  G.xcd_map = ctx->xcd_map;
+  hipLaunchKernelGGL(meteo_kernel, dim3(nb), dim3(256), axes_lds_bytes(ctx), ctx->stream, G);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -810,6 +822,7 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_wind);
   dev_free(ctx->d_temp);
   dev_free(ctx->d_cloud);
+  dev_free(ctx->d_mx);
   dev_free(ctx->d_sfa);
   dev_free(ctx->d_sfb);
   dev_free(ctx->d_sfc);
@@ -914,6 +927,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     dev_free(ctx->d_wind);
     dev_free(ctx->d_temp);
     dev_free(ctx->d_cloud);
+    dev_free(ctx->d_mx);
+    ctx->d_mx = nullptr;
     dev_free(ctx->d_sfa);
     dev_free(ctx->d_sfb);
     dev_free(ctx->d_sfc);

@@ -43,6 +43,7 @@ struct DevMet {
   const float *wind;     // [cell][6]
   const float *temp;     // [cell][2]
   const f32x4 *cloud;    // [cell][2] (optional)
+  const f32x4 *mx;       // [cell][2] {z,pv,o3,cc}0 {..}1: level fields only module_meteo reads (optional)
   const f32x4 *sfa;      // [col]
   const f32x4 *sfb;      // [col][2]
   const f32x4 *sfc;      // [col][2]
@@ -476,17 +477,22 @@ struct CloudCorners {
   f32x4 hi[2][2][2];
 };
 
-__device__ __forceinline__ void load_cloud(const DevMet &M, const Stencil &s, CloudCorners &c) {
+__device__ __forceinline__ void load_quad(const f32x4 *__restrict__ g, const DevMet &M, const Stencil &s,
+                                          CloudCorners &c) {
 #pragma unroll
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++) {
-      const f32x4 *q = M.cloud + 2 * cell_of(M, s, di, dj);
+      const f32x4 *q = g + 2 * cell_of(M, s, di, dj);
       c.lo[di][dj][0] = q[0];
       c.lo[di][dj][1] = q[1];
       c.hi[di][dj][0] = q[2];
       c.hi[di][dj][1] = q[3];
     }
+}
+
+__device__ __forceinline__ void load_cloud(const DevMet &M, const Stencil &s, CloudCorners &c) {
+  load_quad(M.cloud, M, s, c);
 }
 
 __device__ __forceinline__ double cloud_time_3d(const CloudCorners &c, const Stencil &s, double wt, int k) {
@@ -1390,27 +1396,10 @@ __device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Pa
 }
 
 // ---- module_meteo (mptrac.c:5062-5165) --------------------------------------
-// Reads the per-snapshot planar copies ([ix][iy][ip], level index fastest) the
-// context keeps of every uploaded field; a column's level pair is one 8-byte load.
+// Level fields come from the packed two-snapshot records (wind, temp, h2o,
+// cloud, mx), surface fields from the per-snapshot planar copies ([ix][iy]).
 
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 constexpr double kLv = 2501000.;   // LV, mptrac.h:275
-
-__device__ __forceinline__ double plane_space_3d(const float *__restrict__ a, const DevMet &M, const Stencil &s) {
-  const f32x2u v00 = *(const f32x2u *) (a + cell_of(M, s, 0, 0));
-  const f32x2u v01 = *(const f32x2u *) (a + cell_of(M, s, 0, 1));
-  const f32x2u v10 = *(const f32x2u *) (a + cell_of(M, s, 1, 0));
-  const f32x2u v11 = *(const f32x2u *) (a + cell_of(M, s, 1, 1));
-  return lerp3(s, v00[0], v00[1], v01[0], v01[1], v10[0], v10[1], v11[0], v11[1]);
-}
-
-// intpol_met_time_3d with init = 0 (mptrac.c:3112-3137)
-__device__ __forceinline__ double plane_time_3d(const float *__restrict__ a0, const float *__restrict__ a1,
-                                                const DevMet &M, const Stencil &s, double wt) {
-  const double v0 = plane_space_3d(a0, M, s);
-  const double v1 = plane_space_3d(a1, M, s);
-  return wt * (v0 - v1) + v1;
-}
 
 __device__ __forceinline__ double plane_space_2d(const float *__restrict__ a, const DevMet &M, const Stencil &s) {
   const size_t c0 = (size_t) s.ix * (size_t) M.ny + (size_t) s.iy, c1 = c0 + (size_t) M.ny;

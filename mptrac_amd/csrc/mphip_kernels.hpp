@@ -258,6 +258,7 @@ struct PackArgs {
   const float *f2[2][MPHIP_N2D];
   float *wind, *temp;
   f32x4 *cloud, *sfa, *sfb, *sfc, *sfd;
+  f32x4 *mx;                       // {z,pv,o3,cc}0 {..}1 (NULL: none)
   float *h2o;                      // {h2o}0 {h2o}1 (NULL: none)
   float *mlw;                      // model-level {ul,vl,zeta_dot} records (NULL: none)
   size_t ncell, ncol, ncell_ml;
@@ -280,6 +281,13 @@ __global__ void pack_kernel(PackArgs a) {
         for (int k = 0; k < 4; k++)
           v[k] = a.f3[t][MPHIP_LWC + k] ? a.f3[t][MPHIP_LWC + k][i] : 0.f;
         a.cloud[2 * i + t] = v;
+      }
+      if (a.mx) {
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          v[k] = a.f3[t][MPHIP_Z + k] ? a.f3[t][MPHIP_Z + k][i] : 0.f;
+        a.mx[2 * i + t] = v;
       }
     }
   }
@@ -630,7 +638,10 @@ __global__ void grid_accumulate_kernel(DevAtm a, const int *__restrict__ cell, i
 // ---------------------------------------------------------------------------
 // module_meteo (mptrac.c:5062-5165): sample the meteo fields at every particle
 // (no dt guard) into the requested quantities.  Only the fields a requested
-// quantity depends on are read (need3 / need2, set by the host); the values are
+// quantity depends on are read (need3 / need2, set by the host): level fields
+// from the packed two-snapshot records, so that a particle's 2 x 2 x 2 x 2 corner
+// values of up to four fields come with 16 loads and neighbouring particles of
+// the locality order share cache lines; the values are
 // those INTPOL_TIME_ALL (mptrac.h:1278-1318) produces -- one index / weight
 // set from the first 3-D call, re-used by all other 3-D and 2-D calls.
 // ---------------------------------------------------------------------------
@@ -639,12 +650,17 @@ struct MeteoArgs {
   mphip_ctl_t ctl;
   DevMet met;
   DevAtm atm;
-  const float *f3[2][MPHIP_N3D];
-  const float *f2[2][MPHIP_N2D];
+  const float *f2[2][MPHIP_N2D];   // planar surface fields of met0 / met1
   unsigned need3, need2;
+  int nblocks_logical;             // as StepParams: contiguous runs of the locality order per block
+  long long per_block;
+  int xcd_map;
 };
 
-__global__ __launch_bounds__(256) void meteo_kernel(const MeteoArgs G) {
+#ifndef MPHIP_METEO_WAVES_PER_SIMD
+#define MPHIP_METEO_WAVES_PER_SIMD 3
+#endif
+__global__ __launch_bounds__(256, MPHIP_METEO_WAVES_PER_SIMD) void meteo_kernel(const MeteoArgs G) {
   extern __shared__ double s_axes[];
   const DevMet &M = G.met;
   const DevAtm &a = G.atm;
@@ -652,19 +668,60 @@ __global__ __launch_bounds__(256) void meteo_kernel(const MeteoArgs G) {
   const Axes A = load_axes(M, s_axes);
   __syncthreads();
   const unsigned n3 = G.need3, n2 = G.need2;
-  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np; i += (long long) gridDim.x * blockDim.x) {
+  const int nb = G.nblocks_logical;
+  const int lb = G.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
+  const long long first = (long long) lb * G.per_block;
+  long long last = first + G.per_block;
+  if (last > a.np)
+    last = a.np;
+  const bool want_wind = n3 & (1u << MPHIP_U | 1u << MPHIP_V | 1u << MPHIP_W);
+  const bool want_cloud = n3 & (1u << MPHIP_LWC | 1u << MPHIP_RWC | 1u << MPHIP_IWC | 1u << MPHIP_SWC);
+  const bool want_mx = n3 & (1u << MPHIP_Z | 1u << MPHIP_PV | 1u << MPHIP_O3 | 1u << MPHIP_CC);
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
     const double tm = a.time[i], p = a.p[i], lon = a.lon[i], lat = a.lat[i];
     Stencil s = stencil_zero();
     stencil_3d(M, A, p, lon, lat, s);
     const double wt = time_weight(M, tm);
-#define F3(f) (((n3 >> (f)) & 1u) ? plane_time_3d(G.f3[0][f], G.f3[1][f], M, s, wt) : 0.0)
 #define F2(f) (((n2 >> (f)) & 1u) ? plane_time_2d(G.f2[0][f], G.f2[1][f], M, s, wt) : 0.0)
 #define SETQ(k, val)                                                                          \
   if (qm[k] >= 0)                                                                             \
     a.q[qm[k]][i] = (val)
-    const double t = F3(MPHIP_T), u = F3(MPHIP_U), v = F3(MPHIP_V), w = F3(MPHIP_W), h2o = F3(MPHIP_H2O);
-    const double ps = F2(MPHIP_PS);
-    SETQ(MPHIP_MQ_PS, ps);
+    // every group stores its quantities right after its loads (the order of the
+    // stores is immaterial; short live ranges keep the kernel at 3+ waves / SIMD)
+    if (want_wind) {
+      WindCorners c;
+      load_wind(M, s, c);
+      const double u = wind_time_3d(c, s, wt, 0);
+      const double v = wind_time_3d(c, s, wt, 1);
+      const double w = wind_time_3d(c, s, wt, 2);
+      SETQ(MPHIP_MQ_U, u);
+      SETQ(MPHIP_MQ_V, v);
+      SETQ(MPHIP_MQ_W, w);
+      SETQ(MPHIP_MQ_VH, sqrt(u * u + v * v));
+      SETQ(MPHIP_MQ_VZ, -1e3 * kH0 / p * w);
+    } else {   // the reference's zero-initialised fields
+      SETQ(MPHIP_MQ_U, 0.0);
+      SETQ(MPHIP_MQ_V, 0.0);
+      SETQ(MPHIP_MQ_W, 0.0);
+      SETQ(MPHIP_MQ_VH, 0.0);
+      SETQ(MPHIP_MQ_VZ, -1e3 * kH0 / p * 0.0);
+    }
+    if (want_cloud) {
+      CloudCorners c;
+      load_quad(M.cloud, M, s, c);
+      SETQ(MPHIP_MQ_LWC, cloud_time_3d(c, s, wt, 0));
+      SETQ(MPHIP_MQ_RWC, cloud_time_3d(c, s, wt, 1));
+      SETQ(MPHIP_MQ_IWC, cloud_time_3d(c, s, wt, 2));
+      SETQ(MPHIP_MQ_SWC, cloud_time_3d(c, s, wt, 3));
+    }
+    if (want_mx) {
+      CloudCorners c;
+      load_quad(M.mx, M, s, c);
+      SETQ(MPHIP_MQ_ZG, cloud_time_3d(c, s, wt, 0));
+      SETQ(MPHIP_MQ_PV, cloud_time_3d(c, s, wt, 1));
+      SETQ(MPHIP_MQ_O3, cloud_time_3d(c, s, wt, 2));
+      SETQ(MPHIP_MQ_CC, cloud_time_3d(c, s, wt, 3));
+    }
     SETQ(MPHIP_MQ_TS, F2(MPHIP_TS));
     SETQ(MPHIP_MQ_ZS, F2(MPHIP_ZS));
     SETQ(MPHIP_MQ_US, F2(MPHIP_US));
@@ -679,20 +736,6 @@ __global__ __launch_bounds__(256) void meteo_kernel(const MeteoArgs G) {
     SETQ(MPHIP_MQ_TT, F2(MPHIP_TT));
     SETQ(MPHIP_MQ_ZT, F2(MPHIP_ZT));
     SETQ(MPHIP_MQ_H2OT, F2(MPHIP_H2OT));
-    SETQ(MPHIP_MQ_ZG, F3(MPHIP_Z));
-    SETQ(MPHIP_MQ_P, p);
-    SETQ(MPHIP_MQ_T, t);
-    SETQ(MPHIP_MQ_RHO, rho_air(p, t));
-    SETQ(MPHIP_MQ_U, u);
-    SETQ(MPHIP_MQ_V, v);
-    SETQ(MPHIP_MQ_W, w);
-    SETQ(MPHIP_MQ_H2O, h2o);
-    SETQ(MPHIP_MQ_O3, F3(MPHIP_O3));
-    SETQ(MPHIP_MQ_LWC, F3(MPHIP_LWC));
-    SETQ(MPHIP_MQ_RWC, F3(MPHIP_RWC));
-    SETQ(MPHIP_MQ_IWC, F3(MPHIP_IWC));
-    SETQ(MPHIP_MQ_SWC, F3(MPHIP_SWC));
-    SETQ(MPHIP_MQ_CC, F3(MPHIP_CC));
     SETQ(MPHIP_MQ_PCT, F2(MPHIP_PCT));
     SETQ(MPHIP_MQ_PCB, F2(MPHIP_PCB));
     SETQ(MPHIP_MQ_CL, F2(MPHIP_CL));
@@ -702,8 +745,15 @@ __global__ __launch_bounds__(256) void meteo_kernel(const MeteoArgs G) {
     SETQ(MPHIP_MQ_CAPE, F2(MPHIP_CAPE));
     SETQ(MPHIP_MQ_CIN, F2(MPHIP_CIN));
     SETQ(MPHIP_MQ_O3C, F2(MPHIP_O3C));
-    SETQ(MPHIP_MQ_VH, sqrt(u * u + v * v));
-    SETQ(MPHIP_MQ_VZ, -1e3 * kH0 / p * w);
+    SETQ(MPHIP_MQ_P, p);
+    // temperature, water vapour, surface pressure and what derives from them
+    const double t = ((n3 >> MPHIP_T) & 1u) ? temp_time_3d(M, s, wt) : 0.0;
+    const double h2o = ((n3 >> MPHIP_H2O) & 1u) ? pair_time_3d(M.h2o, M, s, wt) : 0.0;
+    const double ps = F2(MPHIP_PS);
+    SETQ(MPHIP_MQ_PS, ps);
+    SETQ(MPHIP_MQ_T, t);
+    SETQ(MPHIP_MQ_H2O, h2o);
+    SETQ(MPHIP_MQ_RHO, rho_air(p, t));
     SETQ(MPHIP_MQ_PSAT, psat_of(t));
     SETQ(MPHIP_MQ_PSICE, psice_of(t));
     SETQ(MPHIP_MQ_PW, pw_of(p, h2o));
@@ -714,10 +764,8 @@ __global__ __launch_bounds__(256) void meteo_kernel(const MeteoArgs G) {
     SETQ(MPHIP_MQ_ZETA_D, zeta_of(ps, p, t));
     SETQ(MPHIP_MQ_TVIRT, tvirt(t, h2o));
     SETQ(MPHIP_MQ_LAPSE, lapse_rate(t, h2o));
-    SETQ(MPHIP_MQ_PV, F3(MPHIP_PV));
     SETQ(MPHIP_MQ_TDEW, tdew_of(p, h2o));
     SETQ(MPHIP_MQ_TICE, tice_of(p, h2o));
-#undef F3
 #undef F2
 #undef SETQ
   }
