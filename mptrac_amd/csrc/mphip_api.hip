@@ -75,7 +75,7 @@ struct mphip_ctx {
   // d_ext[i] is the external slot (the reference's ip) of stored particle i
   int *d_ext = nullptr, *d_ext_alt = nullptr;
   bool ext_identity = true;
-  int locality_interval = 10;         // re-sort every this many steps (0 = keep the caller's order)
+  int locality_interval = 20;         // re-sort every this many steps (0 = keep the caller's order)
   int locality_tile = 8;              // horizontal tile edge of the locality key (columns)
   int step_blocks = 4096;             // upper bound of the step kernel's grid
   int xcd_map = 1;
@@ -725,6 +725,27 @@ int run_allreduce(mphip_ctx *ctx, double *buf, size_t count) {
 }
 
 // module_mixing, mptrac.c:5169-5347
+// launch geometry of the LDS-table accumulation kernels: table entries (power of two) that fit in
+// 64 kB of LDS for nv doubles per entry, and contiguous runs of the stored order per block
+struct AccumGeom {
+  int T, nblocks;
+  long long per_block;
+  size_t lds;
+};
+
+AccumGeom accum_geom(const mphip_ctx *ctx, int nv) {
+  AccumGeom g;
+  g.T = 2048;
+  while (g.T > 16 && (size_t) g.T * (8 * (size_t) nv + 4) > 64 * 1024)
+    g.T >>= 1;
+  g.lds = (size_t) g.T * (8 * (size_t) nv + 4);
+  long long per_block = (ctx->np + 4095) / 4096;
+  per_block = std::max<long long>(256, (per_block + 255) / 256 * 256);
+  g.per_block = per_block;
+  g.nblocks = (int) std::max<long long>(1, (ctx->np + per_block - 1) / per_block);
+  return g;
+}
+
 int do_mixing(mphip_ctx *ctx, double t) {
   const mphip_ctl_t &c = ctx->ctl;
   if (!ctx->have_clim)
@@ -748,9 +769,11 @@ int do_mixing(mphip_ctx *ctx, double t) {
     if (iq < 0)
       continue;
     HIPCHK(hipMemsetAsync(ctx->d_sums, 0, 2 * ntot * sizeof(double), ctx->stream));
-    if (ctx->np)
-      hipLaunchKernelGGL(mix_accumulate_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, ctx->d_cell, a.q[iq], ens,
-                         ngrid, ntot, ctx->d_sums);
+    if (ctx->np) {
+      const AccumGeom g = accum_geom(ctx, 2);
+      hipLaunchKernelGGL(mix_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, a.q[iq],
+                         ens, ngrid, ntot, ctx->d_sums, g.T, g.per_block);
+    }
     if (run_allreduce(ctx, ctx->d_sums, 2 * ntot))
       return 1;
     if (ctx->np)
@@ -1281,8 +1304,9 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
     const int nb = grid_for(ctx->np);
     hipLaunchKernelGGL(box_index_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
                        t + 0.5 * c.dt_mod, ctx->d_cell);
-    hipLaunchKernelGGL(grid_accumulate_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, ctx->d_cell, ctx->nq, ncell,
-                       ctx->d_sums);
+    const AccumGeom g = accum_geom(ctx, 1 + 2 * ctx->nq);
+    hipLaunchKernelGGL(grid_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, ctx->nq,
+                       ncell, ctx->d_sums, g.T, g.per_block);
     HIPCHK(hipGetLastError());
   }
   if (run_allreduce(ctx, ctx->d_sums, total))

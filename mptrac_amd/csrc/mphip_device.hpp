@@ -153,10 +153,33 @@ __device__ __forceinline__ double deg2rad(double deg) {   // mptrac.h:857
   return deg * (kPi / 180.0);
 }
 
+// cos(x) for |x| <= pi/2 (a latitude in radians): the fdlibm kernels -- cosine
+// polynomial on [0, pi/4], sine polynomial of pi/2 - |x| above, both evaluated
+// and selected (no divergent branch, no argument-reduction code for the general
+// case).  Below one ulp, like the C library's cos() the reference calls.
+__device__ __forceinline__ double cos_latitude(double x) {
+  const double ax = fabs(x);
+  const bool hi = ax > 0.78539816339744830962;
+  // pi/2 = 1.57079632679489655800e+00 + 6.12323399573676603587e-17; the first difference is exact
+  const double y = hi ? (1.57079632679489655800e+00 - ax) + 6.12323399573676603587e-17 : ax;
+  const double z = y * y;
+  const double ps = y + y * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03
+    + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06
+    + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+  const double pc = 1.0 - (0.5 * z - z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03
+    + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07
+    + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))))));
+  return hi ? ps : pc;
+}
+
 __device__ __forceinline__ double dx2deg(double dx, double lat) {   // mptrac.h:904-906
   if (lat < -89.999 || lat > 89.999)
     return 0;
+#if MPHIP_EXACT_DIV
   return dx * 180. / (kPi * kRE * cos(deg2rad(lat)));
+#else
+  return dx * 180. / (kPi * kRE * cos_latitude(deg2rad(lat)));
+#endif
 }
 
 __device__ __forceinline__ double dy2deg(double dy) {   // mptrac.h:922
@@ -953,8 +976,14 @@ __device__ __forceinline__ void position(const DevMet &M, const Axes &A, Particl
 }
 
 // module_advect, pressure-level branch, mptrac.c:3612-3677
-template <int ADVECT>
-__device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particle &P) {
+// `hook(i)` runs right after the gathers of stage i were issued: work that does
+// not depend on them (the random numbers of the later modules) fills the wait.
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+template <int ADVECT, class Hook>
+__device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particle &P, Hook &hook) {
   const int ct = M.coord_type;
   const double dt = P.dt;
   double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0;
@@ -978,6 +1007,7 @@ __device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particl
     stencil_3d(M, A, x2, x0, x1, s);
     WindCorners c;
     load_wind(M, s, c);
+    hook(i);
     const double wt = time_weight(M, tm);
     u = wind_time_3d(c, s, wt, 0);
     v = wind_time_3d(c, s, wt, 1);
@@ -997,13 +1027,20 @@ __device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particl
   P.p += dt * wm;
 }
 
-__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P) {
+template <class Hook>
+__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                       Hook &hook) {
   if (ctl.advect == 4)
-    advect_n<4>(M, A, P);
+    advect_n<4>(M, A, P, hook);
   else if (ctl.advect == 2)
-    advect_n<2>(M, A, P);
+    advect_n<2>(M, A, P, hook);
   else
-    advect_n<1>(M, A, P);
+    advect_n<1>(M, A, P, hook);
+}
+
+__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P) {
+  NoHook none;
+  advect(ctl, M, A, P, none);
 }
 
 // module_advect, zeta / eta branch (mptrac.c:3681-3757); zeta is the particle's
@@ -1081,7 +1118,7 @@ __device__ __forceinline__ double kz_blend(const mphip_ctl_t &ctl, double pt, do
 
 // module_diff_turb, mptrac.c:4603-4733
 __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevClim &C,
-                                          Particle &P, uint64_t ctr, uint64_t g) {
+                                          Particle &P, uint64_t ctr, uint64_t g, const double *pre = nullptr) {
   const int ct = M.coord_type;
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
@@ -1102,7 +1139,12 @@ __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &
   const double dt_abs = fabs(P.dt);
 
   double rs0, rs1, rs2;
-  normal_triple(ctr, g, rs0, rs1, rs2);
+  if (pre) {
+    rs0 = pre[0];
+    rs1 = pre[1];
+    rs2 = pre[2];
+  } else
+    normal_triple(ctr, g, rs0, rs1, rs2);
 
   if (Kx > 0) {
     const double sigma_h = sqrt(2.0 * Kx * dt_abs);
@@ -1289,7 +1331,8 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
 
 // module_diff_meso, mptrac.c:4280-4338
 __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
-                                          float &up, float &vp, float &wp, uint64_t ctr, uint64_t g) {
+                                          float &up, float &vp, float &wp, uint64_t ctr, uint64_t g,
+                                          const double *pre = nullptr) {
   // HIP's __fadd_rn / __fmul_rn are plain operators, so contraction has to be
   // switched off here for the single-precision statistics to round like the
   // reference's separate multiply and add (the variance is a small difference
@@ -1332,7 +1375,12 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
   const double r = 1 - 2 * fabs(P.dt) / ctl.dt_met;
   const double r2 = sqrt(1 - r * r);
   double rs0, rs1, rs2;
-  normal_triple(ctr, g, rs0, rs1, rs2);
+  if (pre) {
+    rs0 = pre[0];
+    rs1 = pre[1];
+    rs2 = pre[2];
+  } else
+    normal_triple(ctr, g, rs0, rs1, rs2);
 
   if (ctl.turb_mesox > 0) {
     up = (float) (r * up + r2 * rs0 * ctl.turb_mesox * sd[0]);
@@ -1356,7 +1404,7 @@ __device__ __forceinline__ double temperature_at(const DevMet &M, const Axes &A,
 
 // module_convection, mptrac.c:4116-4170
 __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
-                                           uint64_t ctr, uint64_t g) {
+                                           uint64_t ctr, uint64_t g, const double *pre = nullptr) {
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
   SurfA c;
@@ -1382,7 +1430,7 @@ __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet 
     const double ttop = temperature_at(M, A, P.time, ptop, P.lon, P.lat);
     const double rhobot = pbot / tbot;
     const double rhotop = ptop / ttop;
-    const double rs = uniform01(ctr + g);
+    const double rs = pre ? *pre : uniform01(ctr + g);
     const double rho = rhobot + (rhotop - rhobot) * rs;
     P.p = lin(rhobot, pbot, rhotop, ptop, rho);
   }

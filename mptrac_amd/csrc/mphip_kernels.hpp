@@ -139,6 +139,41 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
 #ifndef MPHIP_STEP_WAVES_PER_SIMD
 #define MPHIP_STEP_WAVES_PER_SIMD 2
 #endif
+// 1: (experiment, no measurable gain on MI355X) the specialised instantiations evaluate the random numbers of the
+// stochastic modules between the gathers of the Runge-Kutta stages and their
+// first use (rs[] is a pure function of counter and particle index)
+#ifndef MPHIP_RNG_EARLY
+#define MPHIP_RNG_EARLY 0
+#endif
+
+// keeps a value where it was computed (the optimiser would sink the whole chain to its first use)
+__device__ __forceinline__ void pin(double &x) {
+  asm volatile("" : "+v"(x));
+}
+
+struct RngEarly {
+  unsigned mask;
+  uint64_t ctr_turb, ctr_meso, ctr_conv, g;
+  double turb[3], meso[3], conv;
+  __device__ __forceinline__ void operator()(int stage) {
+    if (stage == 0 && (mask & MPHIP_MOD_DIFF_TURB)) {
+      normal_triple(ctr_turb, g, turb[0], turb[1], turb[2]);
+      pin(turb[0]);
+      pin(turb[1]);
+      pin(turb[2]);
+    }
+    if (stage == 1 && (mask & MPHIP_MOD_DIFF_MESO)) {
+      normal_triple(ctr_meso, g, meso[0], meso[1], meso[2]);
+      pin(meso[0]);
+      pin(meso[1]);
+      pin(meso[2]);
+    }
+    if (stage == 2 && (mask & MPHIP_MOD_CONVECTION)) {
+      conv = uniform01(ctr_conv + g);
+      pin(conv);
+    }
+  }
+};
 template <unsigned CT>
 __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(const StepParams S) {
   extern __shared__ double s_axes[];
@@ -189,6 +224,15 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     // random numbers belong to the external slot (rs[3 * ip + k], mptrac.c:4645)
     const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) a.ext[i] : i));
 
+    // specialised instantiations = RK4 on pressure levels (launch_step): 4 stages, all hooks run
+    constexpr bool early = MPHIP_RNG_EARLY && CT != kMaskGeneric && (CT & MPHIP_MOD_ADVECT);
+    RngEarly pre;
+    pre.mask = mask;
+    pre.ctr_turb = S.ctr_turb;
+    pre.ctr_meso = S.ctr_meso;
+    pre.ctr_conv = S.ctr_conv;
+    pre.g = g;
+
     if (mask & MPHIP_MOD_POSITION)
       position(M, A, P);
     if (mask & MPHIP_MOD_ADVECT) {
@@ -198,11 +242,13 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
         double zeta;
         advect_ml(ctl, M, A, P, zeta);
         a.q[qnt][i] = zeta;
-      } else
+      } else if (early)
+        advect_n<4>(M, A, P, pre);
+      else
         advect(ctl, M, A, P);
     }
     if (mask & MPHIP_MOD_DIFF_TURB)
-      diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g);
+      diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr);
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_DIFF_PBL)) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
       diff_pbl(M, A, P, up, vp, wp, S.ctr_pbl, g);
@@ -212,13 +258,13 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     }
     if (mask & MPHIP_MOD_DIFF_MESO) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
-      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g);
+      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr);
       a.up[i] = up;
       a.vp[i] = vp;
       a.wp[i] = wp;
     }
     if (mask & MPHIP_MOD_CONVECTION)
-      convection(ctl, M, A, P, S.ctr_conv, g);
+      convection(ctl, M, A, P, S.ctr_conv, g, early ? &pre.conv : nullptr);
     if (mask & MPHIP_MOD_SEDI)
       sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
     if (mask & MPHIP_MOD_POSITION2)
@@ -580,20 +626,85 @@ __global__ void box_index_kernel(DevAtm a, BoxGrid G, double t0, double t1, int 
   }
 }
 
+// Block-private accumulation table in LDS.  The particles are stored in the
+// locality order and every block walks one contiguous run of it, so a block
+// sees few distinct output cells: sums are collected per cell in an LDS hash
+// table (key = cell, nv doubles per entry, LDS fp64 atomics) and only the
+// table is flushed with global atomics -- two orders of magnitude fewer of
+// them, and no long same-address queues in L2.  A particle whose cell finds no
+// free slot within kProbes tries adds to global memory directly (unsorted
+// input, very fine output grids).
+constexpr int kProbes = 8;
+
+struct LdsTable {
+  int *keys;        // [T], -1 = free
+  double *vals;     // [nv][T]
+  int T, shift, nv;
+
+  __device__ __forceinline__ void init(void *smem, int T_, int nv_) {
+    T = T_;
+    nv = nv_;
+    shift = 32 - (31 - __builtin_clz((unsigned) T_));
+    vals = (double *) smem;
+    keys = (int *) (vals + (size_t) nv_ * T_);
+    for (int i = threadIdx.x; i < T_; i += blockDim.x)
+      keys[i] = -1;
+    for (int i = threadIdx.x; i < nv_ * T_; i += blockDim.x)
+      vals[i] = 0.0;
+    __syncthreads();
+  }
+  // slot of `key`, claiming a free one if needed; -1 if the probe sequence is full
+  __device__ __forceinline__ int slot_for(int key) const {
+    unsigned h = ((unsigned) key * 2654435761u) >> shift;
+    for (int k = 0; k < kProbes; k++) {
+      const int old = atomicCAS(&keys[h], -1, key);
+      if (old == -1 || old == key)
+        return (int) h;
+      h = (h + 1) & (unsigned) (T - 1);
+    }
+    return -1;
+  }
+  __device__ __forceinline__ void add(int slot, int v, double x) const {
+    __hip_atomic_fetch_add(&vals[(size_t) v * T + slot], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  // buf[v * stride + key] += table
+  __device__ __forceinline__ void flush(double *__restrict__ buf, size_t stride) const {
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+      const int key = keys[i];
+      if (key >= 0)
+        for (int v = 0; v < nv; v++)
+          unsafeAtomicAdd(&buf[(size_t) v * stride + (size_t) key], vals[(size_t) v * T + i]);
+    }
+  }
+};
+
 // sums[0 .. ntot) += q, sums[ntot .. 2 ntot) += 1 (counts kept as doubles so
 // that one all-reduce of doubles covers both; exact below 2^53)
-__global__ void mix_accumulate_kernel(DevAtm a, const int *__restrict__ cell, const double *__restrict__ q,
-                                      const double *__restrict__ ens, int ngrid, size_t ntot,
-                                      double *__restrict__ sums) {
-  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
-       i += (long long) gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void mix_accumulate_kernel(DevAtm a, const int *__restrict__ cell,
+                                                             const double *__restrict__ q,
+                                                             const double *__restrict__ ens, int ngrid, size_t ntot,
+                                                             double *__restrict__ sums, int T, long long per_block) {
+  extern __shared__ double s_tab[];
+  LdsTable tab;
+  tab.init(s_tab, T, 2);
+  const long long first = blockIdx.x * per_block;
+  const long long last = first + per_block < a.np ? first + per_block : a.np;
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
     const int c = cell[i];
     if (c >= 0) {
       const size_t idx = (size_t) (ens ? (int) ens[i] : 0) * (size_t) ngrid + (size_t) c;
-      unsafeAtomicAdd(&sums[idx], q[i]);
-      unsafeAtomicAdd(&sums[ntot + idx], 1.0);
+      const int slot = idx < 0x7fffffffu ? tab.slot_for((int) idx) : -1;
+      if (slot >= 0) {
+        tab.add(slot, 0, q[i]);
+        tab.add(slot, 1, 1.0);
+      } else {
+        unsafeAtomicAdd(&sums[idx], q[i]);
+        unsafeAtomicAdd(&sums[ntot + idx], 1.0);
+      }
     }
   }
+  tab.flush(sums, ntot);
 }
 
 // q += (mean - q) * mixparam, mptrac.c:5324-5339
@@ -619,20 +730,35 @@ __global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a,
 }
 
 // buf[0 .. ncell) += 1, buf[(1 + iq) ncell ..] += q, buf[(1 + nq + iq) ncell ..] += q^2
-__global__ void grid_accumulate_kernel(DevAtm a, const int *__restrict__ cell, int nq, size_t ncell,
-                                       double *__restrict__ buf) {
-  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
-       i += (long long) gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void grid_accumulate_kernel(DevAtm a, const int *__restrict__ cell, int nq,
+                                                              size_t ncell, double *__restrict__ buf, int T,
+                                                              long long per_block) {
+  extern __shared__ double s_tab[];
+  LdsTable tab;
+  tab.init(s_tab, T, 1 + 2 * nq);
+  const long long first = blockIdx.x * per_block;
+  const long long last = first + per_block < a.np ? first + per_block : a.np;
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
     const int c = cell[i];
     if (c >= 0) {
-      unsafeAtomicAdd(&buf[c], 1.0);
+      const int slot = tab.slot_for(c);
+      if (slot >= 0)
+        tab.add(slot, 0, 1.0);
+      else
+        unsafeAtomicAdd(&buf[c], 1.0);
       for (int iq = 0; iq < nq; iq++) {
         const double v = 1.0 * a.q[iq][i];   // kernel weight 1 (mptrac.c:3305-3306)
-        unsafeAtomicAdd(&buf[(size_t) (1 + iq) * ncell + c], v);
-        unsafeAtomicAdd(&buf[(size_t) (1 + nq + iq) * ncell + c], v * v);
+        if (slot >= 0) {
+          tab.add(slot, 1 + iq, v);
+          tab.add(slot, 1 + nq + iq, v * v);
+        } else {
+          unsafeAtomicAdd(&buf[(size_t) (1 + iq) * ncell + c], v);
+          unsafeAtomicAdd(&buf[(size_t) (1 + nq + iq) * ncell + c], v * v);
+        }
       }
     }
   }
+  tab.flush(buf, ncell);
 }
 
 // ---------------------------------------------------------------------------
