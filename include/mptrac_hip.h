@@ -78,8 +78,12 @@ enum {
   MPHIP_MOD_ADVECT_INIT = 1 << 12, /* module_advect_init mptrac.c:3762 (not guarded by dt) */
   MPHIP_MOD_DIFF_PBL   = 1 << 13,  /* module_diff_pbl    mptrac.c:4343 (runs between diff_turb and diff_meso) */
   MPHIP_MOD_METEO      = 1 << 14,  /* module_meteo       mptrac.c:5062 (own kernel; not guarded by dt) */
+  MPHIP_MOD_ISOSURF    = 1 << 15,  /* module_isosurf     mptrac.c:4956 (not guarded by dt; between sedi and position2) */
   MPHIP_MOD_SORT       = 1 << 16,  /* module_sort        mptrac.c:5887 (own kernels) */
-  MPHIP_MOD_MIXING     = 1 << 17   /* module_mixing      mptrac.c:5169 (own kernels) */
+  MPHIP_MOD_MIXING     = 1 << 17,  /* module_mixing      mptrac.c:5169 (own kernels) */
+  MPHIP_MOD_BOUND_COND = 1 << 18,  /* module_bound_cond  mptrac.c:3789, first call (mptrac.c:7929) */
+  MPHIP_MOD_BOUND_COND2 = 1 << 19, /* module_bound_cond, second call (mptrac.c:8000) */
+  MPHIP_MOD_ISOSURF_INIT = 1 << 20 /* module_isosurf_init mptrac.c:4886, modes 1-3 (not guarded by dt) */
 };
 
 /* Hot-path subset of ctl_t (mptrac.h:2494-3553); same field names, meaning
@@ -124,6 +128,13 @@ typedef struct {
   double met_dt_out;
   int qnt_met[MPHIP_NMQ];
   int pad2;
+  /* module_isosurf (ISOSURF, mptrac.c:7208) and module_bound_cond (BOUND_*, mptrac.c:7266-7289) */
+  int isosurf;            /* 0 none, 1 pressure, 2 density, 3 potential temperature, 4 balloon time series */
+  int bound_pbl;
+  int qnt_aoa;            /* age of air: set by module_bound_cond, mixed by module_mixing */
+  int pad3;
+  double bound_mass, bound_mass_trend, bound_vmr, bound_vmr_trend;
+  double bound_lat0, bound_lat1, bound_p0, bound_p1, bound_dps, bound_dzs, bound_zetas;
 } mphip_ctl_t;
 
 /* View of one met_t snapshot (mptrac.h:3844-4014).  The arrays stay where the
@@ -188,6 +199,12 @@ int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *
  * (mptrac.h:3633); any pointer may be NULL. */
 int mphip_update_cache(mphip_ctx *ctx, const float *uvwp, const uint64_t *rng_ctr);
 int mphip_get_cache(mphip_ctx *ctx, float *uvwp, double *dt, uint64_t *rng_ctr);
+/* The isosurface part of cache_t (iso_var[np], iso_ts / iso_ps [iso_n]; mptrac.h:3620-3632), as
+ * mptrac_update_device / _host move it.  iso_var (per particle slot; filled on the device by
+ * module_isosurf_init for ISOSURF 1-3) and the balloon time series read by module_isosurf_init for
+ * ISOSURF 4 (mptrac.c:4925-4951); any pointer may be NULL. */
+int mphip_update_iso(mphip_ctx *ctx, const double *iso_var, const double *iso_ts, const double *iso_ps, int iso_n);
+int mphip_get_iso(mphip_ctx *ctx, double *iso_var);
 
 /* mptrac_run_timestep, mptrac.c:7851-8001: the reference's module order and
  * gating, fused into as few launches as the order allows. */

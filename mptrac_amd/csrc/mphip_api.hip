@@ -21,7 +21,8 @@ constexpr unsigned kAdvTurb = kAdv | MPHIP_MOD_DIFF_TURB;
 constexpr unsigned kAdvDiff = kAdvTurb | MPHIP_MOD_DIFF_MESO;
 constexpr unsigned kAdvTurbConvSedi = kAdvTurb | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kAdvDiffConvSedi = kAdvDiff | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
-constexpr unsigned kParticleBits = 0x3fffu;
+constexpr unsigned kParticleBits = 0x3fffu | MPHIP_MOD_ISOSURF | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2
+  | MPHIP_MOD_ISOSURF_INIT;
 
 struct MetSlot {
   bool valid = false;
@@ -70,6 +71,9 @@ struct mphip_ctx {
   double *d_dt = nullptr;
   double *d_dt_alt = nullptr;
   uint64_t rng_ctr = 0;
+  double *d_iso = nullptr, *d_iso_alt = nullptr;   // cache->iso_var (allocated on first use)
+  double *d_iso_ts = nullptr, *d_iso_ps = nullptr; // balloon time series (ISOSURF 4)
+  int iso_n = 0;
 
   // internal locality order: particles are stored sorted by meteo grid cell;
   // d_ext[i] is the external slot (the reference's ip) of stored particle i
@@ -156,6 +160,10 @@ DevAtm dev_atm(const mphip_ctx *c) {
   a.wp = c->d_uvwp[2];
   a.dt = c->d_dt;
   a.ext = c->ext_identity ? nullptr : c->d_ext;
+  a.iso = c->d_iso;
+  a.iso_ts = c->d_iso_ts;
+  a.iso_ps = c->d_iso_ps;
+  a.iso_n = c->iso_n;
   a.np = c->np;
   a.ip0 = c->ip0;
   a.np_total = c->np_total;
@@ -350,6 +358,17 @@ bool both_have2(const mphip_ctx *c, int f) {
   return c->slot[0].has2[f] && c->slot[1].has2[f];
 }
 
+// cache->iso_var lives on the device only while an isosurface mode needs it
+int ensure_iso(mphip_ctx *ctx) {
+  if (ctx->d_iso)
+    return 0;
+  const size_t n = (size_t) std::max<long long>(ctx->np, 1);
+  if (dev_alloc(ctx, &ctx->d_iso, n) || dev_alloc(ctx, &ctx->d_iso_alt, n))
+    return 1;
+  HIPCHK(hipMemsetAsync(ctx->d_iso, 0, n * sizeof(double), ctx->stream));   // calloc'ed cache_t
+  return 0;
+}
+
 // every field a module mask reads must have been uploaded for both snapshots
 int check_fields(mphip_ctx *ctx, unsigned mask) {
   const mphip_ctl_t &c = ctx->ctl;
@@ -412,6 +431,24 @@ int check_fields(mphip_ctx *ctx, unsigned mask) {
   if (mask & MPHIP_MOD_DRY_DEPO)
     if (need2(MPHIP_PS, "module_dry_depo"))
       return 1;
+  if (mask & (MPHIP_MOD_ISOSURF | MPHIP_MOD_ISOSURF_INIT)) {
+    if (c.isosurf < 1 || c.isosurf > 4)
+      return fail(ctx, "module_isosurf: ISOSURF must be 1 ... 4");
+    if ((c.isosurf == 2 || c.isosurf == 3) && need3(MPHIP_T, "module_isosurf"))
+      return 1;
+    if (c.isosurf == 4 && (mask & MPHIP_MOD_ISOSURF) && ctx->iso_n < 1)
+      return fail(ctx, "module_isosurf: the balloon pressure time series was not uploaded");
+    if (c.isosurf <= 3 && ensure_iso(ctx))
+      return 1;
+  }
+  if (mask & (MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2)) {
+    if ((c.bound_dps > 0 || c.bound_dzs > 0 || c.bound_zetas > 0 || c.bound_pbl) && need2(MPHIP_PS, "module_bound_cond"))
+      return 1;
+    if (c.bound_zetas > 0 && need3(MPHIP_T, "module_bound_cond"))
+      return 1;
+    if (c.bound_pbl && need2(MPHIP_PBL, "module_bound_cond"))
+      return 1;
+  }
   if ((mask & (MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DECAY)) && !ctx->have_clim)
     return fail(ctx, "climatological tropopause data were not uploaded");
   return 0;
@@ -580,6 +617,11 @@ PermArgs perm_args(mphip_ctx *ctx, bool with_cache) {
     g.in8[g.n8] = ctx->d_dt;
     g.out8[g.n8] = ctx->d_dt_alt;
     g.n8++;
+    if (ctx->d_iso) {
+      g.in8[g.n8] = ctx->d_iso;
+      g.out8[g.n8] = ctx->d_iso_alt;
+      g.n8++;
+    }
     g.n4 = 3;
     for (int k = 0; k < 3; k++) {
       g.in4[k] = ctx->d_uvwp[k];
@@ -594,6 +636,7 @@ void perm_swap(mphip_ctx *ctx, bool with_cache) {
     std::swap(ctx->d_arr[k], ctx->d_alt[k]);
   if (with_cache) {
     std::swap(ctx->d_dt, ctx->d_dt_alt);
+    std::swap(ctx->d_iso, ctx->d_iso_alt);
     for (int k = 0; k < 3; k++)
       std::swap(ctx->d_uvwp[k], ctx->d_uvwp_alt[k]);
   }
@@ -763,8 +806,8 @@ int do_mixing(mphip_ctx *ctx, double t) {
     hipLaunchKernelGGL(box_index_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
                        t + 0.5 * c.dt_mod, ctx->d_cell);
   const double *ens = (c.nens > 0 && c.qnt_ens >= 0) ? a.q[c.qnt_ens] : nullptr;
-  const int quantities[2] = { c.qnt_m, c.qnt_vmr };   // hot-path subset of mptrac.c:5223-5230
-  for (int k = 0; k < 2; k++) {
+  const int quantities[3] = { c.qnt_m, c.qnt_vmr, c.qnt_aoa };   // hot-path subset of mptrac.c:5223-5230
+  for (int k = 0; k < 3; k++) {
     const int iq = quantities[k];
     if (iq < 0)
       continue;
@@ -861,6 +904,10 @@ void mphip_destroy(mphip_ctx *ctx) {
   for (auto p : ctx->d_uvwp_alt)
     dev_free(p);
   dev_free(ctx->d_dt);
+  dev_free(ctx->d_iso);
+  dev_free(ctx->d_iso_alt);
+  dev_free(ctx->d_iso_ts);
+  dev_free(ctx->d_iso_ps);
   dev_free(ctx->d_dt_alt);
   dev_free(ctx->d_ext);
   dev_free(ctx->d_ext_alt);
@@ -1060,6 +1107,9 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
         return 1;
     if (dev_alloc(ctx, &ctx->d_cell, n))
       return 1;
+    dev_free(ctx->d_iso);
+    dev_free(ctx->d_iso_alt);
+    ctx->d_iso = ctx->d_iso_alt = nullptr;
     ctx->sorted_buf = -1;
   }
   if (!fresh && restore_external_order(ctx))   // keep cache->uvwp with its slot across a re-upload
@@ -1141,6 +1191,43 @@ int mphip_get_cache(mphip_ctx *ctx, float *uvwp, double *dt, uint64_t *rng_ctr) 
   return 0;
 }
 
+int mphip_update_iso(mphip_ctx *ctx, const double *iso_var, const double *iso_ts, const double *iso_ps, int iso_n) {
+  if (!ctx)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (iso_var && ctx->np) {
+    if (restore_external_order(ctx) || ensure_iso(ctx))
+      return 1;
+    HIPCHK(hipMemcpyAsync(ctx->d_iso, iso_var, (size_t) ctx->np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (iso_ts && iso_ps) {
+    if (iso_n < 1)
+      return fail(ctx, "Could not read any data!");   // module_isosurf_init, mptrac.c:4943-4944
+    if (dev_alloc(ctx, &ctx->d_iso_ts, (size_t) iso_n) || dev_alloc(ctx, &ctx->d_iso_ps, (size_t) iso_n))
+      return 1;
+    HIPCHK(hipMemcpyAsync(ctx->d_iso_ts, iso_ts, (size_t) iso_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_iso_ps, iso_ps, (size_t) iso_n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ctx->iso_n = iso_n;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mphip_get_iso(mphip_ctx *ctx, double *iso_var) {
+  if (!ctx)
+    return 1;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (iso_var && ctx->np) {
+    if (!ctx->d_iso)
+      return fail(ctx, "cache->iso_var is not on the device (no isosurface mode has run)");
+    if (restore_external_order(ctx))
+      return 1;
+    HIPCHK(hipMemcpyAsync(iso_var, ctx->d_iso, (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return 0;
+}
+
 int mphip_run_timestep(mphip_ctx *ctx, double t) {
   if (!ctx)
     return 1;
@@ -1151,10 +1238,16 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   const uint64_t n = (uint64_t) ctx->np_total;
   unsigned mask = MPHIP_MOD_TIMESTEPS;
 
-  // module_advect_init at the first call (mptrac.c:7863-7870)
-  if (t == c.t_start && c.advect_vert_coord == 1)
-    if (launch_step(ctx, MPHIP_MOD_ADVECT_INIT, t, 0, 0, 0))
+  // module_isosurf_init and module_advect_init at the first call (mptrac.c:7863-7870)
+  if (t == c.t_start) {
+    unsigned init = 0;
+    if (c.isosurf >= 1 && c.isosurf <= 3)
+      init |= MPHIP_MOD_ISOSURF_INIT;
+    if (c.advect_vert_coord == 1)
+      init |= MPHIP_MOD_ADVECT_INIT;
+    if (init && launch_step(ctx, init, t, 0, 0, 0))
       return 1;
+  }
 
   // module_timesteps + module_sort (mptrac.c:7877-7881).  The reference
   // permutes atm but not cache->dt, so on sort steps dt is computed per slot
@@ -1198,7 +1291,12 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   }
   if (c.qnt_rp >= 0 && c.qnt_rhop >= 0)
     mask |= MPHIP_MOD_SEDI;
+  if (c.isosurf >= 1 && c.isosurf <= 4)
+    mask |= MPHIP_MOD_ISOSURF;
   mask |= MPHIP_MOD_POSITION2;
+  const bool bound = c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1;
+  if (bound)
+    mask |= MPHIP_MOD_BOUND_COND;
   if (c.qnt_loss_rate >= 0)
     mask |= MPHIP_MOD_LOSS_ZERO;
   if (c.tdec_trop > 0 && c.tdec_strat > 0)
@@ -1208,6 +1306,8 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
     tail |= MPHIP_MOD_WET_DEPO;
   if (c.dry_depo_vdep > 0)
     tail |= MPHIP_MOD_DRY_DEPO;
+  if (bound)
+    tail |= MPHIP_MOD_BOUND_COND2;
   // module_meteo (mptrac.c:7921-7924) sits between the final module_position and the loss / decay /
   // mixing / deposition modules; those neither move particles nor touch a quantity it sets, so it
   // runs after them here (own kernel, every particle)

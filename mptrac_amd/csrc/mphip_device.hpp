@@ -72,6 +72,9 @@ struct DevAtm {
   float *up, *vp, *wp;           // cache->uvwp, kept SoA on the device
   double *dt;                    // cache->dt (only used across separate launches)
   const int *ext;                // external slot of each stored particle (NULL = identity)
+  double *iso;                   // cache->iso_var (module_isosurf; NULL = not allocated)
+  const double *iso_ts, *iso_ps; // balloon time series of ISOSURF 4
+  int iso_n;
   long long np;                  // particles owned by this context
   long long ip0;                 // global index of the first one
   long long np_total;            // particles of the whole simulation
@@ -1497,6 +1500,65 @@ __device__ __forceinline__ double zeta_of(double ps, double p, double t) {   // 
 __device__ __forceinline__ double lapse_rate(double t, double h2o) {   // lapse_rate, mptrac.c:3324-3338
   const double a = kRA * t * t, r = sh_of(h2o) / (1. - sh_of(h2o));
   return 1e3 * kG0 * (a + kLv * r * t) / (kCpd * a + kLv * kLv * r * kEps);
+}
+
+// ---- module_isosurf (mptrac.c:4886-5005) and module_bound_cond (mptrac.c:3789-3881) ----
+
+// module_isosurf_init, modes 1-3: the conserved quantity of the particle
+__device__ __forceinline__ double isosurf_value(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A,
+                                                const Particle &P) {
+  if (ctl.isosurf == 1)
+    return P.p;
+  const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
+  return ctl.isosurf == 2 ? P.p / t : theta_of(P.p, t);
+}
+
+// module_isosurf: pressure that puts the particle back on its surface
+__device__ __forceinline__ double isosurf_pressure(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A,
+                                                   const DevAtm &a, const Particle &P, double iso_var) {
+  if (ctl.isosurf == 1)
+    return iso_var;
+  if (ctl.isosurf == 2 || ctl.isosurf == 3) {
+    const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
+    return ctl.isosurf == 2 ? iso_var * t : 1000. * pow(iso_var / t, -1. / kKappa);
+  }
+  if (ctl.isosurf == 4) {
+    const int n = a.iso_n;
+    if (P.time <= a.iso_ts[0])
+      return a.iso_ps[0];
+    if (P.time >= a.iso_ts[n - 1])
+      return a.iso_ps[n - 1];
+    const int idx = locate_irr(a.iso_ts, n, P.time, a.iso_ts[(n - 1) >> 1] < a.iso_ts[((n - 1) >> 1) + 1]);
+    return lin(a.iso_ts[idx], a.iso_ps[idx], a.iso_ts[idx + 1], a.iso_ps[idx + 1], P.time);
+  }
+  return P.p;
+}
+
+// module_bound_cond: true if the particle lies in the boundary region (mptrac.c:3809-3846)
+__device__ __forceinline__ bool in_boundary_region(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A,
+                                                   const Particle &P) {
+  if (P.lat < ctl.bound_lat0 || P.lat > ctl.bound_lat1 || P.p > ctl.bound_p0 || P.p < ctl.bound_p1)
+    return false;
+  if (ctl.bound_dps > 0 || ctl.bound_dzs > 0 || ctl.bound_zetas > 0 || ctl.bound_pbl) {
+    Stencil s = stencil_zero();
+    stencil_2d(M, A, P.lon, P.lat, s);
+    SurfA c;
+    load_sfa(M, s, c);
+    const double wt = time_weight(M, P.time);
+    const double ps = sfa_time_2d(c, s, wt, 0);
+    if (ctl.bound_dps > 0 && P.p < ps - ctl.bound_dps)
+      return false;
+    if (ctl.bound_dzs > 0 && zfromp(P.p) > zfromp(ps) + ctl.bound_dzs)
+      return false;
+    if (ctl.bound_zetas > 0) {
+      const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
+      if (zeta_of(ps, P.p, t) > ctl.bound_zetas)
+        return false;
+    }
+    if (ctl.bound_pbl && P.p < sfa_time_2d(c, s, wt, 1))
+      return false;
+  }
+  return true;
 }
 
 }   // namespace mphip

@@ -31,7 +31,22 @@ struct StepParams {
 constexpr unsigned kMaskGeneric = 0xffffffffu;
 constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a later launch reads it)
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
-  | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI | MPHIP_MOD_POSITION2;
+  | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI | MPHIP_MOD_ISOSURF | MPHIP_MOD_POSITION2;
+
+// module_bound_cond, mptrac.c:3848-3879 (mass, volume mixing ratio, age of air)
+__device__ __forceinline__ void bound_cond(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
+                                           long long i, const Particle &P) {
+  if (ctl.qnt_m < 0 && ctl.qnt_vmr < 0 && ctl.qnt_aoa < 0)
+    return;
+  if (!in_boundary_region(ctl, M, A, P))
+    return;
+  if (ctl.qnt_m >= 0 && ctl.bound_mass >= 0)
+    a.q[ctl.qnt_m][i] = ctl.bound_mass + ctl.bound_mass_trend * P.time;
+  if (ctl.qnt_vmr >= 0 && ctl.bound_vmr >= 0)
+    a.q[ctl.qnt_vmr][i] = ctl.bound_vmr + ctl.bound_vmr_trend * P.time;
+  if (ctl.qnt_aoa >= 0)
+    a.q[ctl.qnt_aoa][i] = P.time;
+}
 
 // common tail of decay / wet / dry deposition (mptrac.c:4251-4260, 6279-6288, 4786-4795)
 __device__ __forceinline__ void apply_loss(const mphip_ctl_t &ctl, const DevAtm &a, long long i, double aux,
@@ -209,8 +224,12 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     P.lon = a.lon[i];
     P.lat = a.lat[i];
     P.p = a.p[i];
-    if (CT == kMaskGeneric && (mask & MPHIP_MOD_ADVECT_INIT)) {   // no dt guard (check_dt = 0)
-      a.p[i] = pressure_from_zeta(M, A, P.time, a.q[ctl.qnt_zeta][i], P.lon, P.lat);
+    if (CT == kMaskGeneric && (mask & (MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT))) {   // no dt guard (check_dt = 0)
+      P.dt = 0;
+      if (mask & MPHIP_MOD_ISOSURF_INIT)   // before module_advect_init, mptrac.c:7866-7870
+        a.iso[i] = isosurf_value(ctl, M, A, P);
+      if (mask & MPHIP_MOD_ADVECT_INIT)
+        a.p[i] = pressure_from_zeta(M, A, P.time, a.q[ctl.qnt_zeta][i], P.lon, P.lat);
       continue;
     }
     if (mask & MPHIP_MOD_TIMESTEPS) {
@@ -219,8 +238,11 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
         a.dt[i] = P.dt;
     } else
       P.dt = a.dt[i];
-    if (P.dt == 0)   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
+    if (P.dt == 0) {   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
+      if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))   // module_isosurf has check_dt = 0
+        a.p[i] = isosurf_pressure(ctl, M, A, a, P, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
       continue;
+    }
     // random numbers belong to the external slot (rs[3 * ip + k], mptrac.c:4645)
     const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) a.ext[i] : i));
 
@@ -267,6 +289,8 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       convection(ctl, M, A, P, S.ctr_conv, g, early ? &pre.conv : nullptr);
     if (mask & MPHIP_MOD_SEDI)
       sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
+    if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))
+      P.p = isosurf_pressure(ctl, M, A, a, P, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
     if (mask & MPHIP_MOD_POSITION2)
       position(M, A, P);
 
@@ -278,6 +302,8 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       a.p[i] = P.p;
     }
 
+    if (CT == kMaskGeneric && (mask & MPHIP_MOD_BOUND_COND))
+      bound_cond(ctl, M, A, a, i, P);
     if (mask & MPHIP_MOD_LOSS_ZERO)
       a.q[ctl.qnt_loss_rate][i] = 0;
     if (mask & MPHIP_MOD_DECAY) {   // module_decay, mptrac.c:4241-4261
@@ -290,6 +316,8 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       wet_depo(ctl, M, A, a, i, P);
     if (mask & MPHIP_MOD_DRY_DEPO)
       dry_depo(ctl, M, A, a, i, P);
+    if (CT == kMaskGeneric && (mask & MPHIP_MOD_BOUND_COND2))
+      bound_cond(ctl, M, A, a, i, P);
   }
 }
 
@@ -559,8 +587,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
 //                                      and the internal locality order)
 //   scatter: out[ext[i]] = in[i]      (back to the external slot order)
 struct PermArgs {
-  const double *in8[4 + MPHIP_NQ_MAX + 1];
-  double *out8[4 + MPHIP_NQ_MAX + 1];
+  const double *in8[4 + MPHIP_NQ_MAX + 2];
+  double *out8[4 + MPHIP_NQ_MAX + 2];
   const float *in4[3];
   float *out4[3];
   const int *ext_in;     // gather only: slot ids travel with the particles

@@ -96,6 +96,22 @@ CTL_FIELDS = [
     ("met_dt_out", C.c_double, 0.1),
     ("qnt_met", C.c_int * 53, (-1,) * 53),
     ("pad2", C.c_int, 0),
+    # module_isosurf (mptrac.c:7208) and module_bound_cond (mptrac.c:7266-7289)
+    ("isosurf", C.c_int, 0),
+    ("bound_pbl", C.c_int, 0),
+    ("qnt_aoa", C.c_int, -1),
+    ("pad3", C.c_int, 0),
+    ("bound_mass", C.c_double, -999.0),
+    ("bound_mass_trend", C.c_double, 0.0),
+    ("bound_vmr", C.c_double, -999.0),
+    ("bound_vmr_trend", C.c_double, 0.0),
+    ("bound_lat0", C.c_double, -999.0),
+    ("bound_lat1", C.c_double, -999.0),
+    ("bound_p0", C.c_double, -999.0),
+    ("bound_p1", C.c_double, -999.0),
+    ("bound_dps", C.c_double, -999.0),
+    ("bound_dzs", C.c_double, -999.0),
+    ("bound_zetas", C.c_double, -999.0),
 ]
 
 # quantities module_meteo fills, in the order of its SET_ATM list (mptrac.c:5091-5157) = MPHIP_MQ_*
@@ -135,7 +151,8 @@ def ctl_from_quantities(names):
     out = {"nq": len(names)}
     table = {"m": "qnt_m", "vmr": "qnt_vmr", "rp": "qnt_rp", "rhop": "qnt_rhop", "ens": "qnt_ens",
              "loss_rate": "qnt_loss_rate", "mloss_decay": "qnt_mloss_decay",
-             "mloss_wet": "qnt_mloss_wet", "mloss_dry": "qnt_mloss_dry", "zeta": "qnt_zeta", "eta": "qnt_eta"}
+             "mloss_wet": "qnt_mloss_wet", "mloss_dry": "qnt_mloss_dry", "zeta": "qnt_zeta", "eta": "qnt_eta",
+             "aoa": "qnt_aoa"}
     met = [-1] * len(METEO_QUANTITIES)
     for i, n in enumerate(names):
         if n in table:

@@ -19,7 +19,8 @@ MOD = {
     "timesteps": 1 << 0, "position": 1 << 1, "advect": 1 << 2, "diff_turb": 1 << 3, "diff_meso": 1 << 4,
     "convection": 1 << 5, "sedi": 1 << 6, "position2": 1 << 7, "loss_zero": 1 << 8, "decay": 1 << 9,
     "wet_depo": 1 << 10, "dry_depo": 1 << 11, "advect_init": 1 << 12, "diff_pbl": 1 << 13, "meteo": 1 << 14,
-    "sort": 1 << 16, "mixing": 1 << 17,
+    "isosurf": 1 << 15, "sort": 1 << 16, "mixing": 1 << 17, "bound_cond": 1 << 18, "bound_cond2": 1 << 19,
+    "isosurf_init": 1 << 20,
 }
 
 MphipCtl = make_ctl_struct("MphipCtl")
@@ -74,6 +75,8 @@ def load(build=True):
     L.mphip_get_atm.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.POINTER(_dp)]
     L.mphip_update_cache.argtypes = [C.c_void_p, _fp, C.POINTER(C.c_uint64)]
     L.mphip_get_cache.argtypes = [C.c_void_p, _fp, _dp, C.POINTER(C.c_uint64)]
+    L.mphip_update_iso.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
+    L.mphip_get_iso.argtypes = [C.c_void_p, _dp]
     L.mphip_run_timestep.argtypes = [C.c_void_p, C.c_double]
     L.mphip_module.argtypes = [C.c_void_p, C.c_uint, C.c_double]
     L.mphip_get_sort.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
@@ -216,6 +219,18 @@ class Simulation:
         s = self.get_atm()
         s["uvwp"] = self.get_cache()["uvwp"]
         return s
+
+    def set_balloon(self, ts, ps):
+        """The pressure time series module_isosurf_init reads for ISOSURF 4
+        (src/mptrac.c:4925-4951)."""
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        ps = np.ascontiguousarray(ps, dtype=np.float64)
+        self._chk(self.L.mphip_update_iso(self.h, None, _ptr(ts, _dp), _ptr(ps, _dp), len(ts)))
+
+    def get_iso(self):
+        iso = np.empty(self.n)
+        self._chk(self.L.mphip_get_iso(self.h, _ptr(iso, _dp)))
+        return iso
 
     # -- stepping -------------------------------------------------------------
     def timesteps_init(self, tmin, tmax):

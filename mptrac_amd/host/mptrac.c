@@ -20,6 +20,7 @@
 static mphip_ctx *g_ctx;
 static const met_t *g_met_host[2];     /* host snapshots mirrored in device slots met0 / met1 */
 static int g_nq;                        /* ctl->nq of the last control upload */
+static int g_isosurf;                   /* ctl->isosurf of the last control upload */
 static int g_meteo_fields;              /* a module_meteo quantity is requested: upload the fields only it reads */
 
 #define HIP(call) {                                                     \
@@ -157,7 +158,7 @@ static const struct {
    * hot-path quantities only */
   { "ens", "-" }, { "m", "kg" }, { "vmr", "ppv" }, { "rp", "microns" }, { "rhop", "kg/m^3" },
   { "loss_rate", "s^-1" }, { "mloss_decay", "kg" }, { "mloss_wet", "kg" }, { "mloss_dry", "kg" },
-  { "idx", "-" }, { "stat", "-" }, { "zeta", "K" }, { "eta", "1" },
+  { "idx", "-" }, { "stat", "-" }, { "zeta", "K" }, { "eta", "1" }, { "aoa", "s" },
 #define X(n, u) { #n, u },
   MPTRAC_METEO_QNT(X)
 #undef X
@@ -175,6 +176,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   /* quantities, mptrac.c:6737-6971 */
   ctl->qnt_m = ctl->qnt_vmr = ctl->qnt_rp = ctl->qnt_rhop = ctl->qnt_ens = ctl->qnt_loss_rate = -1;
   ctl->qnt_mloss_decay = ctl->qnt_mloss_wet = ctl->qnt_mloss_dry = ctl->qnt_zeta = ctl->qnt_eta = -1;
+  ctl->qnt_aoa = -1;
 #define X(n, u) ctl->qnt_##n = -1;
   MPTRAC_METEO_QNT(X)
 #undef X
@@ -204,6 +206,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
     else if (!strcasecmp(n, "mloss_dry")) ctl->qnt_mloss_dry = iq;
     else if (!strcasecmp(n, "zeta")) ctl->qnt_zeta = iq;
     else if (!strcasecmp(n, "eta")) ctl->qnt_eta = iq;
+    else if (!strcasecmp(n, "aoa")) ctl->qnt_aoa = iq;
 #define X(nm, u) else if (!strcasecmp(n, #nm)) ctl->qnt_##nm = iq;
     MPTRAC_METEO_QNT(X)
 #undef X
@@ -248,6 +251,21 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   ctl->conv_cape = scan_ctl(filename, argc, argv, "CONV_CAPE", -1, "-999", NULL);
   ctl->conv_cin = scan_ctl(filename, argc, argv, "CONV_CIN", -1, "-999", NULL);
   ctl->conv_dt = scan_ctl(filename, argc, argv, "CONV_DT", -1, "-999", NULL);
+  /* isosurface and boundary conditions (mptrac.c:7207-7209, 7266-7289) */
+  ctl->isosurf = (int) scan_ctl(filename, argc, argv, "ISOSURF", -1, "0", NULL);
+  scan_ctl(filename, argc, argv, "BALLOON", -1, "-", ctl->balloon);
+  ctl->bound_mass = scan_ctl(filename, argc, argv, "BOUND_MASS", -1, "-999", NULL);
+  ctl->bound_mass_trend = scan_ctl(filename, argc, argv, "BOUND_MASS_TREND", -1, "0", NULL);
+  ctl->bound_vmr = scan_ctl(filename, argc, argv, "BOUND_VMR", -1, "-999", NULL);
+  ctl->bound_vmr_trend = scan_ctl(filename, argc, argv, "BOUND_VMR_TREND", -1, "0", NULL);
+  ctl->bound_lat0 = scan_ctl(filename, argc, argv, "BOUND_LAT0", -1, "-999", NULL);
+  ctl->bound_lat1 = scan_ctl(filename, argc, argv, "BOUND_LAT1", -1, "-999", NULL);
+  ctl->bound_p0 = scan_ctl(filename, argc, argv, "BOUND_P0", -1, "-999", NULL);
+  ctl->bound_p1 = scan_ctl(filename, argc, argv, "BOUND_P1", -1, "-999", NULL);
+  ctl->bound_dps = scan_ctl(filename, argc, argv, "BOUND_DPS", -1, "-999", NULL);
+  ctl->bound_dzs = scan_ctl(filename, argc, argv, "BOUND_DZS", -1, "-999", NULL);
+  ctl->bound_zetas = scan_ctl(filename, argc, argv, "BOUND_ZETAS", -1, "-999", NULL);
+  ctl->bound_pbl = (int) scan_ctl(filename, argc, argv, "BOUND_PBL", -1, "0", NULL);
   ctl->molmass = scan_ctl(filename, argc, argv, "MOLMASS", -1, "-999", NULL);
 
   /* wet / dry deposition, decay, mixing (mptrac.c:7425-7543) */
@@ -700,6 +718,21 @@ static void to_device_ctl(const ctl_t *c, mphip_ctl_t *d) {
   d->qnt_zeta = c->qnt_zeta;
   d->qnt_eta = c->qnt_eta;
   d->met_dt_out = c->met_dt_out;
+  d->qnt_aoa = c->qnt_aoa;
+  d->isosurf = c->isosurf;
+  d->bound_pbl = c->bound_pbl;
+  d->bound_mass = c->bound_mass;
+  d->bound_mass_trend = c->bound_mass_trend;
+  d->bound_vmr = c->bound_vmr;
+  d->bound_vmr_trend = c->bound_vmr_trend;
+  d->bound_lat0 = c->bound_lat0;
+  d->bound_lat1 = c->bound_lat1;
+  d->bound_p0 = c->bound_p0;
+  d->bound_p1 = c->bound_p1;
+  d->bound_dps = c->bound_dps;
+  d->bound_dzs = c->bound_dzs;
+  d->bound_zetas = c->bound_zetas;
+  g_isosurf = c->isosurf;
   int k_mq = 0;
 #define X(n, u) d->qnt_met[k_mq++] = c->qnt_##n;
   MPTRAC_METEO_QNT(X)
@@ -832,8 +865,13 @@ void mptrac_update_device(const ctl_t *ctl, const cache_t *cache, const clim_t *
       q[iq] = atm->q[iq];
     HIP(mphip_update_atm(g_ctx, atm->np, 0, atm->np, g_nq, atm->time, atm->p, atm->lon, atm->lat, q));
   }
-  if (cache != NULL)
+  if (cache != NULL) {
     HIP(mphip_update_cache(g_ctx, &cache->uvwp[0][0], NULL));
+    if (g_isosurf >= 1 && g_isosurf <= 3)
+      HIP(mphip_update_iso(g_ctx, cache->iso_var, NULL, NULL, 0));
+    if (cache->iso_n > 0)
+      HIP(mphip_update_iso(g_ctx, NULL, cache->iso_ts, cache->iso_ps, cache->iso_n));
+  }
 }
 
 void mptrac_update_host(const ctl_t *ctl, const cache_t *cache, const clim_t *clim, met_t **met0,
@@ -855,6 +893,8 @@ void mptrac_update_host(const ctl_t *ctl, const cache_t *cache, const clim_t *cl
   if (cache != NULL) {
     cache_t *c = (cache_t *) cache;
     HIP(mphip_get_cache(g_ctx, &c->uvwp[0][0], c->dt, NULL));
+    if (g_isosurf >= 1 && g_isosurf <= 3)
+      (void) mphip_get_iso(g_ctx, c->iso_var);   /* not on the device before the first time step */
   }
 }
 
@@ -953,7 +993,6 @@ void mptrac_run_timestep(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t **met0,
                          depo_t *depo, double t, dd_t *dd) {
   /* The module order and gating of mptrac.c:7851-8001 live in the back end
    * (mphip_run_timestep); the structs stay resident on the device. */
-  (void) cache;
   (void) clim;
   (void) atm;
   (void) depo;
@@ -961,6 +1000,23 @@ void mptrac_run_timestep(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t **met0,
   need_ctx(ctl);
   map_met_slot(*met0, 0);
   map_met_slot(*met1, 1);
+  /* module_isosurf_init, ISOSURF 4: read the balloon pressure time series (mptrac.c:4925-4951);
+   * modes 1-3 are evaluated on the device */
+  if (t == ctl->t_start && ctl->isosurf == 4) {
+    LOG(1, "Read balloon pressure data: %s", ctl->balloon);
+    FILE *in;
+    if (!(in = fopen(ctl->balloon, "r")))
+      ERRMSG("Cannot open file!");
+    char line[LEN];
+    while (fgets(line, LEN, in))
+      if (sscanf(line, "%lg %lg", &(cache->iso_ts[cache->iso_n]), &(cache->iso_ps[cache->iso_n])) == 2)
+        if ((++cache->iso_n) > NP)
+          ERRMSG("Too many data points!");
+    if (cache->iso_n < 1)
+      ERRMSG("Could not read any data!");
+    fclose(in);
+    HIP(mphip_update_iso(g_ctx, NULL, cache->iso_ts, cache->iso_ps, cache->iso_n));
+  }
   HIP(mphip_run_timestep(g_ctx, t));
 }
 

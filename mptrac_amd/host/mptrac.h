@@ -106,7 +106,7 @@ typedef struct {
   int nq;
   char qnt_name[NQ][LEN], qnt_unit[NQ][LEN], qnt_format[NQ][LEN];
   int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens, qnt_loss_rate;
-  int qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry, qnt_zeta, qnt_eta;
+  int qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry, qnt_zeta, qnt_eta, qnt_aoa;
   /* module_meteo outputs: qnt_ps, qnt_ts, ..., qnt_tice (mptrac.h:2518-2740) */
 #define X(n, u) int qnt_##n;
   MPTRAC_METEO_QNT(X)
@@ -122,6 +122,11 @@ typedef struct {
   double turb_mesox, turb_mesoz, turb_pbl_trans;
   int conv_mix_pbl;
   double conv_pbl_trans, conv_cape, conv_cin, conv_dt;
+  int isosurf;
+  char balloon[LEN];
+  double bound_mass, bound_mass_trend, bound_vmr, bound_vmr_trend, bound_lat0, bound_lat1, bound_p0, bound_p1;
+  double bound_dps, bound_dzs, bound_zetas;
+  int bound_pbl;
   double tdec_trop, tdec_strat;
   int nens;
   double mixing_dt, mixing_trop, mixing_strat, mixing_z0, mixing_z1;

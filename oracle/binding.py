@@ -33,7 +33,8 @@ class OrcAtm(C.Structure):
 
 
 class OrcCache(C.Structure):
-    _fields_ = [("dt", _dp), ("rs", _dp), ("uvwp", _fp), ("rng_ctr", C.c_uint64)]
+    _fields_ = [("dt", _dp), ("rs", _dp), ("uvwp", _fp), ("rng_ctr", C.c_uint64),
+                ("iso_var", _dp), ("iso_ts", _dp), ("iso_ps", _dp), ("iso_n", C.c_int)]
 
 
 class OrcClim(C.Structure):
@@ -146,7 +147,9 @@ class Oracle:
         self.dt = np.zeros(n)
         self.rs = np.zeros(3 * n + 1)
         self.uvwp = np.zeros((n, 3), dtype=np.float32)
-        self.cache = OrcCache(_ptr(self.dt, _dp), _ptr(self.rs, _dp), _ptr(self.uvwp, _fp), rng_ctr)
+        self.iso_var = np.zeros(n)
+        self.cache = OrcCache(_ptr(self.dt, _dp), _ptr(self.rs, _dp), _ptr(self.uvwp, _fp), rng_ctr,
+                              _ptr(self.iso_var, _dp), None, None, 0)
 
     def set_met(self, slot, met):
         self._mets[slot] = met      # keep arrays alive
@@ -158,6 +161,13 @@ class Oracle:
             m.f3[i] = _ptr(met.f3[k], _fp) if k in met.f3 else None
         for i, k in enumerate(FIELDS_2D):
             m.f2[i] = _ptr(met.f2[k], _fp) if k in met.f2 else None
+
+    def set_balloon(self, ts, ps):
+        """Balloon pressure time series of ISOSURF 4 (module_isosurf_init reads it from a file)."""
+        self._iso_ts = np.ascontiguousarray(ts, dtype=np.float64)
+        self._iso_ps = np.ascontiguousarray(ps, dtype=np.float64)
+        self.cache.iso_ts, self.cache.iso_ps = _ptr(self._iso_ts, _dp), _ptr(self._iso_ps, _dp)
+        self.cache.iso_n = len(self._iso_ts)
 
     def swap_met(self, new_met1):
         """mptrac_get_met's pointer swap (mptrac.c:6488-6491) + new met1."""
@@ -204,6 +214,12 @@ class Oracle:
             L.orc_module_dry_depo(ctl, cache, m0, m1, atm)
         elif name == "meteo":
             L.orc_module_meteo(ctl, m0, m1, atm)
+        elif name == "isosurf_init":
+            L.orc_module_isosurf_init(ctl, cache, m0, m1, atm)
+        elif name == "isosurf":
+            L.orc_module_isosurf(ctl, cache, m0, m1, atm)
+        elif name in ("bound_cond", "bound_cond2"):
+            L.orc_module_bound_cond(ctl, cache, m0, m1, atm)
         else:
             raise KeyError(name)
 

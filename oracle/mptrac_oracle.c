@@ -1169,8 +1169,8 @@ void orc_module_mixing(const orc_ctl_t *ctl, const orc_clim_t *clim, orc_atm_t *
   }
   /* of the reference's quantity list (mptrac.c:5223-5230) the hot-path subset
    * carries mass and volume mixing ratio, in this order */
-  const int quantities[2] = { ctl->qnt_m, ctl->qnt_vmr };
-  for (int i = 0; i < 2; i++)
+  const int quantities[3] = { ctl->qnt_m, ctl->qnt_vmr, ctl->qnt_aoa };   /* of the list at mptrac.c:5223-5230 */
+  for (int i = 0; i < 3; i++)
     if (quantities[i] >= 0)
       mixing_one(ctl, clim, atm, ixs, iys, izs, quantities[i]);
   free(ixs);
@@ -1473,12 +1473,102 @@ void orc_module_meteo(const orc_ctl_t *ctl, const orc_met_t *met0, const orc_met
 #undef M2
 #undef SETQ
 
+/* ---- module_isosurf (mptrac.c:4886-5005) -------------------------------- */
+
+/* module_isosurf_init, modes 1-3 (mode 4 reads the balloon file on the host: the
+ * caller fills cache->iso_ts / iso_ps / iso_n) */
+void orc_module_isosurf_init(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                             const orc_met_t *met1, const orc_atm_t *atm) {
+  if (ctl->isosurf < 1 || ctl->isosurf > 3)
+    return;
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (ctl->isosurf == 1)
+      cache->iso_var[ip] = atm->p[ip];
+    else {
+      stencil_t s = STENCIL_ZERO;
+      const double t = time_3d(met0, met1, ORC_T, atm->time[ip], atm->p[ip], atm->lon[ip], atm->lat[ip], &s, 1);
+      cache->iso_var[ip] = ctl->isosurf == 2 ? atm->p[ip] / t : orc_theta(atm->p[ip], t);
+    }
+  }
+}
+
+void orc_module_isosurf(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                        const orc_met_t *met1, orc_atm_t *atm) {
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {   /* check_dt = 0 */
+    if (ctl->isosurf == 1)
+      atm->p[ip] = cache->iso_var[ip];
+    else if (ctl->isosurf == 2 || ctl->isosurf == 3) {
+      stencil_t s = STENCIL_ZERO;
+      const double t = time_3d(met0, met1, ORC_T, atm->time[ip], atm->p[ip], atm->lon[ip], atm->lat[ip], &s, 1);
+      if (ctl->isosurf == 2)
+        atm->p[ip] = cache->iso_var[ip] * t;
+      else
+        atm->p[ip] = 1000. * pow(cache->iso_var[ip] / t, -1. / C_KAPPA);
+    } else if (ctl->isosurf == 4) {
+      if (atm->time[ip] <= cache->iso_ts[0])
+        atm->p[ip] = cache->iso_ps[0];
+      else if (atm->time[ip] >= cache->iso_ts[cache->iso_n - 1])
+        atm->p[ip] = cache->iso_ps[cache->iso_n - 1];
+      else {
+        const int idx = orc_locate_irr(cache->iso_ts, cache->iso_n, atm->time[ip]);
+        atm->p[ip] = lin(cache->iso_ts[idx], cache->iso_ps[idx], cache->iso_ts[idx + 1], cache->iso_ps[idx + 1],
+                         atm->time[ip]);
+      }
+    }
+  }
+}
+
+/* ---- module_bound_cond (mptrac.c:3789-3881): mass, volume mixing ratio and age
+ * of air; the trace-gas time series belong to the chemistry part ------------- */
+
+void orc_module_bound_cond(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                           const orc_met_t *met1, orc_atm_t *atm) {
+  if (ctl->qnt_m < 0 && ctl->qnt_vmr < 0 && ctl->qnt_aoa < 0)
+    return;
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < atm->np; ip++) {
+    if (cache->dt[ip] == 0)
+      continue;
+    if (atm->lat[ip] < ctl->bound_lat0 || atm->lat[ip] > ctl->bound_lat1
+        || atm->p[ip] > ctl->bound_p0 || atm->p[ip] < ctl->bound_p1)
+      continue;
+    if (ctl->bound_dps > 0 || ctl->bound_dzs > 0 || ctl->bound_zetas > 0 || ctl->bound_pbl) {
+      stencil_t s = STENCIL_ZERO;
+      const double ps = time_2d(met0, met1, ORC_PS, atm->time[ip], atm->lon[ip], atm->lat[ip], &s, 1);
+      if (ctl->bound_dps > 0 && atm->p[ip] < ps - ctl->bound_dps)
+        continue;
+      if (ctl->bound_dzs > 0 && zfromp(atm->p[ip]) > zfromp(ps) + ctl->bound_dzs)
+        continue;
+      if (ctl->bound_zetas > 0) {
+        const double t = time_3d(met0, met1, ORC_T, atm->time[ip], atm->p[ip], atm->lon[ip], atm->lat[ip], &s, 1);
+        if (orc_zeta(ps, atm->p[ip], t) > ctl->bound_zetas)
+          continue;
+      }
+      if (ctl->bound_pbl) {
+        const double pbl = time_2d(met0, met1, ORC_PBL, atm->time[ip], atm->lon[ip], atm->lat[ip], &s, 0);
+        if (atm->p[ip] < pbl)
+          continue;
+      }
+    }
+    if (ctl->qnt_m >= 0 && ctl->bound_mass >= 0)
+      atm->q[ctl->qnt_m][ip] = ctl->bound_mass + ctl->bound_mass_trend * atm->time[ip];
+    if (ctl->qnt_vmr >= 0 && ctl->bound_vmr >= 0)
+      atm->q[ctl->qnt_vmr][ip] = ctl->bound_vmr + ctl->bound_vmr_trend * atm->time[ip];
+    if (ctl->qnt_aoa >= 0)
+      atm->q[ctl->qnt_aoa][ip] = atm->time[ip];
+  }
+}
+
 /* ---- scheduler: mptrac_run_timestep (mptrac.c:7851-8001) ---------------- */
 
 void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
                       const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm, double t) {
-  if (t == ctl->t_start)
-    orc_module_advect_init(ctl, met0, met1, atm);   /* mptrac.c:7863-7870 */
+  if (t == ctl->t_start) {   /* mptrac.c:7863-7874 */
+    orc_module_isosurf_init(ctl, cache, met0, met1, atm);
+    orc_module_advect_init(ctl, met0, met1, atm);
+  }
   orc_module_timesteps(ctl, cache, met0, atm, t);
   if (ctl->sort_dt > 0 && fmod(t, ctl->sort_dt) == 0)
     orc_module_sort(ctl, met0, atm, NULL, NULL);
@@ -1498,9 +1588,13 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
     orc_module_convection(ctl, cache, met0, met1, atm);
   if (ctl->qnt_rp >= 0 && ctl->qnt_rhop >= 0)
     orc_module_sedi(ctl, cache, met0, met1, atm);
+  if (ctl->isosurf >= 1 && ctl->isosurf <= 4)
+    orc_module_isosurf(ctl, cache, met0, met1, atm);   /* mptrac.c:7914-7916 */
   orc_module_position(cache, met0, met1, atm);
   if (ctl->met_dt_out > 0 && (ctl->met_dt_out < ctl->dt_mod || fmod(t, ctl->met_dt_out) == 0))
     orc_module_meteo(ctl, met0, met1, atm);   /* mptrac.c:7921-7924 */
+  if (ctl->bound_lat0 < ctl->bound_lat1 && ctl->bound_p0 > ctl->bound_p1)
+    orc_module_bound_cond(ctl, cache, met0, met1, atm);   /* mptrac.c:7926-7929 */
   /* zero the total loss rate, mptrac.c:7932-7936 */
   if (ctl->qnt_loss_rate >= 0)
     for (int ip = 0; ip < atm->np; ip++)
@@ -1516,6 +1610,8 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
     orc_module_wet_depo(ctl, cache, met0, met1, atm);
   if (ctl->dry_depo_vdep > 0)
     orc_module_dry_depo(ctl, cache, met0, met1, atm);
+  if (ctl->bound_lat0 < ctl->bound_lat1 && ctl->bound_p0 > ctl->bound_p1)
+    orc_module_bound_cond(ctl, cache, met0, met1, atm);   /* mptrac.c:7997-8000 */
 }
 
 /* ---- write_grid binning (mptrac.c:13815-13872) -------------------------- */

@@ -93,6 +93,13 @@ typedef struct {
   double met_dt_out;
   int qnt_met[ORC_NMQ];
   int pad2;
+  /* module_isosurf (mptrac.c:7208) and module_bound_cond (mptrac.c:7266-7289) */
+  int isosurf;            /* 0 none, 1 pressure, 2 density, 3 potential temperature, 4 balloon time series */
+  int bound_pbl;
+  int qnt_aoa;            /* age of air: set by module_bound_cond, mixed by module_mixing */
+  int pad3;
+  double bound_mass, bound_mass_trend, bound_vmr, bound_vmr_trend;
+  double bound_lat0, bound_lat1, bound_p0, bound_p1, bound_dps, bound_dzs, bound_zetas;
 } orc_ctl_t;
 
 /* One meteo snapshot: compact view of met_t (mptrac.h:3844-4014). */
@@ -121,6 +128,11 @@ typedef struct {
   double *rs;     /* [3*np + 1] */
   float *uvwp;    /* [np][3]    */
   uint64_t rng_ctr;
+  /* module_isosurf state (mptrac.h:3620-3632) */
+  double *iso_var;  /* [np] */
+  double *iso_ts;   /* [iso_n] balloon time series (ISOSURF 4) */
+  double *iso_ps;   /* [iso_n] */
+  int iso_n;
 } orc_cache_t;
 
 /* Climatological tropopause part of clim_t (mptrac.h:3785-3800). */
@@ -190,6 +202,12 @@ void orc_module_wet_depo(const orc_ctl_t *ctl, const orc_cache_t *cache, const o
                          const orc_met_t *met1, orc_atm_t *atm);
 void orc_module_dry_depo(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
                          const orc_met_t *met1, orc_atm_t *atm);
+void orc_module_isosurf_init(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
+                             const orc_met_t *met1, const orc_atm_t *atm);   /* mptrac.c:4886 (modes 1-3) */
+void orc_module_isosurf(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                        const orc_met_t *met1, orc_atm_t *atm);              /* mptrac.c:4956 */
+void orc_module_bound_cond(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
+                           const orc_met_t *met1, orc_atm_t *atm);           /* mptrac.c:3789 */
 void orc_module_meteo(const orc_ctl_t *ctl, const orc_met_t *met0, const orc_met_t *met1,
                       orc_atm_t *atm);   /* mptrac.c:5062 */
 /* keys[np] (as the reference's double keys, exact integers) and perm[np] are

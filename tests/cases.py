@@ -43,11 +43,29 @@ CASES = {
     "meteo": dict(BASE, diffusion=1, turb_dz_trop=0.1, conv_cape=0.0),
     # module_meteo only when fmod(t, MET_DT_OUT) == 0, interleaved with module_sort
     "meteo_gated": dict(BASE, met_dt_out=1800.0, sort_dt=360.0, diffusion=1, turb_dz_trop=0.1),
+    # module_isosurf: isobaric, isopycnic, isentropic and balloon-pressure trajectories
+    "isosurf_p": dict(BASE, isosurf=1, diffusion=1, turb_dz_trop=0.1),
+    "isosurf_rho": dict(BASE, isosurf=2),
+    "isosurf_theta": dict(BASE, isosurf=3, diffusion=1, turb_dz_trop=0.1, sort_dt=900.0),
+    "isosurf_balloon": dict(BASE, isosurf=4),
+    # module_bound_cond: surface layer by pressure depth / PBL / zeta, mass + vmr with trend + age of air,
+    # together with decay and mixing (which also mixes aoa)
+    "bound": dict(BASE, bound_lat0=-60.0, bound_lat1=60.0, bound_p0=1100.0, bound_p1=300.0, bound_dps=400.0,
+                  bound_mass=2.5, bound_mass_trend=1e-4, bound_vmr=3e-9, bound_vmr_trend=1e-13,
+                  tdec_trop=259200.0, tdec_strat=259200.0, diffusion=1, turb_dz_trop=0.1,
+                  mixing_trop=1e-3, mixing_strat=1e-6, mixing_dt=360.0, mixing_nx=36, mixing_ny=18, mixing_nz=20),
+    "bound_pbl_zeta": dict(BASE, bound_lat0=-90.0, bound_lat1=90.0, bound_p0=1100.0, bound_p1=100.0, bound_pbl=1,
+                           bound_zetas=330.0, bound_dzs=3.0, bound_mass=1.0, conv_cape=0.0),
 }
+
+# pressure time series a balloon would report (ISOSURF 4): 2 h, one value per 10 min
+BALLOON = ([-600.0 + 600.0 * k for k in range(13)], [80.0 - 2.5 * k + 0.3 * (k % 3) for k in range(13)])
 
 CASE_QUANTITIES = {
     "meteo": ("m", "rp", "rhop", "t", "u", "zg", "pv", "ps", "pt", "theta", "rh", "zeta_d", "sst", "lapse", "vh", "o3"),
     "meteo_gated": ("m", "t", "w", "h2o", "tdew", "plfc", "cc", "rho"),
+    "bound": ("m", "vmr", "aoa", "loss_rate", "mloss_decay"),
+    "bound_pbl_zeta": ("m", "aoa"),
 }
 
 QUANTITIES = ("m", "rp", "rhop", "vmr", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry")
@@ -63,10 +81,10 @@ def make_case(name, n=10000, grid="C1", seed=12345, quantities=None, lon0=-180.0
         quantities = CASE_QUANTITIES.get(name, QUANTITIES_ML if ml else QUANTITIES)
     if fields is None and not ml:
         fields = PRESSURE_LEVEL_FIELDS          # model-level fields only where they are used
-        if name in CASE_QUANTITIES:
+        if name.startswith("meteo"):
             fields = fields + FIELDS_METEO_ONLY
     ctl.update(ctl_from_quantities(quantities))
-    if name.startswith("advect") or name in ("turb", "diff", "conv_thresh", "pbl", "meteo_gated"):
+    if name.startswith(("advect", "isosurf", "bound")) or name in ("turb", "diff", "conv_thresh", "pbl", "meteo_gated"):
         # no sedimentation in these
         ctl["qnt_rp"] = ctl["qnt_rhop"] = -1
     met0 = synthetic_met(grid, 0.0, 1.0, fields=fields, lon0=lon0)
@@ -74,10 +92,18 @@ def make_case(name, n=10000, grid="C1", seed=12345, quantities=None, lon0=-180.0
     atm = synthetic_particles(n, seed=seed, quantities=quantities)
     if ctl.get("turb_pbl_scheme", 0):      # half of the particles inside the boundary layer
         atm["p"][::2] = 1013.25 * np.exp(-(0.02 + 0.9 * (atm["lon"][::2] + 180.0) / 360.0) / 7.0)
+    if name.startswith("isosurf"):         # some particles are released later: module_isosurf also acts on dt = 0
+        atm["time"][::7] = 540.0
     for name_q in ("zeta", "eta"):
         if name_q in quantities:     # a vertical coordinate inside the range of the synthetic zetal field
             atm["q"][list(quantities).index(name_q)] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
     return ctl, load_clim_tropo(), met0, met1, atm
+
+
+def prepare(engine):
+    """Inputs a driver hands over besides ctl / met / atm (same call on the oracle and the product)."""
+    if engine.ctl.isosurf == 4:
+        engine.set_balloon(*BALLOON)
 
 
 def rel_err(a, b):

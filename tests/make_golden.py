@@ -25,6 +25,7 @@ def run_case(name):
     ctl, clim, m0, m1, atm = cases.make_case(name, n=N)
     o = B.Oracle(ctl, clim, m0, m1, atm)
     o.timesteps_init()
+    cases.prepare(o)
     for t in cases.step_times(o.ctl):
         o.run_timestep(t)
     s = o.state()

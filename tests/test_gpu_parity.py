@@ -29,6 +29,8 @@ def _pair(name, n=10000, grid="C1", **kw):
     s = hip.Simulation(ctl, clim, m0, m1, atm)
     s.timesteps_init(atm["time"].min(), atm["time"].max())
     assert s.ctl.t_start == o.ctl.t_start and s.ctl.t_stop == o.ctl.t_stop
+    cases.prepare(o)
+    cases.prepare(s)
     return o, s
 
 
@@ -104,7 +106,9 @@ MODULE_CASES = [("position", "advect"), ("advect", "advect"), ("advect", "advect
                 ("advect", "advect_zeta"), ("advect", "advect_eta"), ("diff_pbl", "pbl"), ("diff_pbl", "pbl_meso"),
                 ("advect", "advect_euler"), ("diff_turb", "turb"), ("diff_meso", "diff"),
                 ("convection", "conv_sedi"), ("convection", "conv_thresh"), ("sedi", "conv_sedi"),
-                ("decay", "full"), ("wet_depo", "full"), ("wet_depo", "wet_henry"), ("dry_depo", "full")]
+                ("decay", "full"), ("wet_depo", "full"), ("wet_depo", "wet_henry"), ("dry_depo", "full"),
+                ("isosurf", "isosurf_rho"), ("isosurf", "isosurf_theta"), ("isosurf", "isosurf_balloon"),
+                ("bound_cond", "bound"), ("bound_cond", "bound_pbl_zeta")]
 
 
 @pytest.mark.parametrize("module,case", MODULE_CASES)

@@ -108,3 +108,38 @@ def test_trac_end_to_end_matches_oracle(tmp_path, atm_type, pbl, meteo):
         g = os.path.join(tmp, "grid_2022_06_02_%02d_00_00.tab" % hour)
         rows = [ln.split() for ln in open(g) if ln.strip() and not ln.startswith("#")]
         assert len(rows) == 36 * 18 and sum(int(r[8]) for r in rows) == 3000
+
+
+@pytest.mark.gpu
+def test_trac_balloon_isosurface_and_boundary_conditions(tmp_path):
+    """ISOSURF 4 (the driver reads the BALLOON file at the first step) and BOUND_* keys through `trac`."""
+    tmp = str(tmp_path)
+    trac, mets, atm = _setup(tmp, n=2000, hours=1)
+    ts = [T0 - 600.0 + 600.0 * k for k in range(9)]
+    ps = [300.0 - 7.5 * k + 0.4 * (k % 3) for k in range(9)]
+    with open(os.path.join(tmp, "balloon.tab"), "w") as f:
+        f.write("# time [s]  pressure [hPa]\n")
+        for a, b in zip(ts, ps):
+            f.write("%.2f %.10g\n" % (a, b))
+    extra = {"ISOSURF": 4, "BALLOON": os.path.join(tmp, "balloon.tab"), "BOUND_LAT0": -50, "BOUND_LAT1": 50,
+             "BOUND_P0": 1100, "BOUND_P1": 100, "BOUND_MASS": 4.0, "BOUND_MASS_TREND": 1e-9, "T_STOP": T0 + 3600.0}
+    with open(os.path.join(tmp, "trac.ctl"), "a") as f:
+        for k, v in extra.items():
+            f.write(f"{k} = {v}\n")
+    r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    ctl = dict(advect=4, dt_mod=180.0, dt_met=3600.0, diffusion=1, turb_dz_trop=0.1, conv_cape=0.0,
+               t_stop=T0 + 3600.0, met_dt_out=0.0, isosurf=4, bound_lat0=-50.0, bound_lat1=50.0, bound_p0=1100.0,
+               bound_p1=100.0, bound_mass=4.0, bound_mass_trend=1e-9, **ctl_from_quantities(QUANT))
+    o = B.Oracle(ctl, load_clim_tropo(), mets[0], mets[1], atm)
+    o.timesteps_init()
+    o.set_balloon(ts, ps)
+    for t in cases.step_times(o.ctl):
+        o.run_timestep(t)
+    got = hf.read_atm_bin(os.path.join(tmp, "atm_2022_06_02_01_00_00.bin"), 3)
+    ref = o.state()
+    for k in ("lon", "lat", "p"):
+        assert cases.rel_err(got[k], ref[k]) <= 1e-10, (k, cases.rel_err(got[k], ref[k]))
+    assert cases.rel_err(got["q"], ref["q"]) <= 1e-10
+    assert np.all(got["p"] == got["p"][0]) and np.any(got["q"][0] > 3.9)
