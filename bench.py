@@ -186,10 +186,12 @@ def main():
         a_per, a_state, a_met = algorithmic_bytes_per_pstep(args.workload, met0, n_local)
         bytes_per_launch = a_per * n_local
         achieved = bytes_per_launch / (kernel_ms_per_launch * 1e-3) / 1e9
-        traffic = None
+        traffic = valu_busy = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(args.workload)
+            prof = json.load(open(tfile))
+            traffic = prof.get(args.workload)
+            valu_busy = prof.get("_valu_busy_frac", {}).get(args.workload)
         out = {
             "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -207,7 +209,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "step_kernel (fused time step)", "kernel_ms": kernel_ms_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "bytes_per_particle_step": a_per},
+                         "bytes_per_particle_step": a_per,
+                         # SURVEY 8(d) caveat: the fused step is fp64-VALU-bound, not HBM-bound; share of SIMD
+                         # cycles executing VALU instructions from the committed rocprofv3 PMC profile
+                         "valu_busy_frac": valu_busy},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, ctl, clim, met0, met1, atm,

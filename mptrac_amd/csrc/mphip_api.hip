@@ -83,6 +83,7 @@ struct mphip_ctx {
   int locality_tile = 8;              // horizontal tile edge of the locality key (columns)
   int step_blocks = 4096;             // upper bound of the step kernel's grid
   int xcd_map = 1;
+  bool force_generic = false;
   int steps_since_resort = 1 << 30;
 
   // sort
@@ -494,7 +495,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     HIPCHK(hipEventRecord(e0, ctx->stream));
   }
   const bool ml_ = (ctx->ctl.advect_vert_coord == 1 || ctx->ctl.advect_vert_coord == 3);
-  const unsigned sel = (ctx->ctl.advect == 4 && !ml_ && !(mask & MPHIP_MOD_DIFF_PBL)) ? mask : kMaskGeneric;
+  const unsigned sel = (ctx->ctl.advect == 4 && !ml_ && !(mask & MPHIP_MOD_DIFF_PBL) && !ctx->force_generic)
+    ? mask : kMaskGeneric;
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
   case M:                                                                                             \
@@ -1446,6 +1448,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
   }
   if (strcmp(name, "xcd_map") == 0) {
     ctx->xcd_map = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "generic_kernel") == 0) {   // tuning aid: never pick a specialised instantiation
+    ctx->force_generic = value != 0;
     return 0;
   }
   if (strcmp(name, "locality_tile") == 0) {

@@ -77,6 +77,18 @@ if fs and ws:
         info["traffic_bytes"] = steady_f * kf + steady_w
     else:
         info["traffic_bytes"] = steady_f + steady_w
+    # fp64-VALU side of the roofline (SURVEY 8(d) caveat): share of the SIMD cycles in which a VALU
+    # instruction is executing = SQ_ACTIVE_INST_VALU [quad-cycles, summed over waves] x 4 /
+    # (1024 SIMDs x kernel cycles); kernel cycles = GRBM_GUI_ACTIVE summed over the 8 XCDs / 8
+    av, ga = one("pmc_sq2", "SQ_ACTIVE_INST_VALU"), one("pmc_grbm", "GRBM_GUI_ACTIVE")
+    iv = one("pmc_sq1", "SQ_INSTS_VALU")
+    if av and ga:
+        info["valu_busy_frac"] = max(av) * 4.0 / (1024.0 * max(ga) / 8.0)
+    if iv:
+        try:
+            info["valu_insts_per_64_particle_steps"] = max(iv) / (cfg["config"]["particles_per_gpu"] / 64.0)
+        except Exception:
+            pass
     print("== HBM traffic of step_kernel per launch ==")
     print("  " + json.dumps(info))
     json.dump(info, open(os.path.join(src, "traffic.json"), "w"))
