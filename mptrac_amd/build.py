@@ -14,7 +14,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 HIP_LIB = os.path.join(LIBDIR, "libmptrac_hip.so")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics"]
+# -disable-machine-licm: the machine-level loop-invariant code motion parks the ~60 double constants of
+# the polynomial kernels (sincosf, log, exp, cos) in VGPR pairs for the whole particle loop; without it the
+# fused step kernel needs 144 instead of 207 VGPRs and runs three waves per SIMD without scratch
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
+               "-mllvm", "-disable-machine-licm"]
 
 
 def _hipcc():

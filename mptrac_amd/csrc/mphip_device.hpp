@@ -131,6 +131,10 @@ __device__ __forceinline__ Axes load_axes(const DevMet &M, double *smem) {
 #ifndef MPHIP_EXACT_DIV
 #define MPHIP_EXACT_DIV 0
 #endif
+// 1: scheduling fences that keep independent computations from being interleaved (fewer live registers)
+#ifndef MPHIP_SCHED_FENCES
+#define MPHIP_SCHED_FENCES 0
+#endif
 
 __device__ __forceinline__ double div_const(double x, double y, double inv_y) {
 #if MPHIP_EXACT_DIV
@@ -912,6 +916,9 @@ __device__ __forceinline__ void normal_triple(uint64_t c0, uint64_t g, double &r
   const uint64_t ja = i0 - (odd ? 1 : 0);
   double ea, oa, eb, ob;
   normal_pair(c0, ja, ea, oa);
+#if MPHIP_SCHED_FENCES
+  __builtin_amdgcn_sched_barrier(0);   // one pair after the other: interleaving them doubles the temporaries
+#endif
   normal_pair(c0, ja + 2, eb, ob);
   r0 = odd ? oa : ea;
   r1 = odd ? eb : oa;
@@ -1375,6 +1382,9 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
     sd[q] = (var > 0 ? sqrtf(var) : 0.f);
   }
 
+#if MPHIP_SCHED_FENCES
+  __builtin_amdgcn_sched_barrier(0);   // the 48 corner values are dead from here on
+#endif
   const double r = 1 - 2 * fabs(P.dt) / ctl.dt_met;
   const double r2 = sqrt(1 - r * r);
   double rs0, rs1, rs2;

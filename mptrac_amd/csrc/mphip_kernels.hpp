@@ -152,13 +152,16 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
 // arrays: with cell-sorted particles each XCD's L2 then holds one region of
 // the meteo grid instead of all of it.
 #ifndef MPHIP_STEP_WAVES_PER_SIMD
-#define MPHIP_STEP_WAVES_PER_SIMD 2
+#define MPHIP_STEP_WAVES_PER_SIMD 3
 #endif
-// 1: (experiment, no measurable gain on MI355X) the specialised instantiations evaluate the random numbers of the
+// 1: the specialised instantiations evaluate the random numbers of the
 // stochastic modules between the gathers of the Runge-Kutta stages and their
 // first use (rs[] is a pure function of counter and particle index)
+#ifndef MPHIP_PARAMS_RELOAD
+#define MPHIP_PARAMS_RELOAD 1
+#endif
 #ifndef MPHIP_RNG_EARLY
-#define MPHIP_RNG_EARLY 0
+#define MPHIP_RNG_EARLY 1
 #endif
 
 // keeps a value where it was computed (the optimiser would sink the whole chain to its first use)
@@ -219,6 +222,16 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     last = a.np;
 
   for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
+#if MPHIP_PARAMS_RELOAD
+    // re-read the launch parameters from the kernarg segment in every iteration (scalar loads at
+    // the point of use) instead of keeping all of them live across the loop, which spills SGPRs
+    auto kp = (const __attribute__((address_space(4))) StepParams *) __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const StepParams &S = *(const StepParams *) kp;
+    const DevMet &M = S.met;
+    const DevAtm &a = S.atm;
+    const mphip_ctl_t &ctl = S.ctl;
+#endif
     Particle P;
     P.time = a.time[i];
     P.lon = a.lon[i];
@@ -269,8 +282,15 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       else
         advect(ctl, M, A, P);
     }
+#if MPHIP_SCHED_FENCES
+#define MODULE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MODULE_FENCE()
+#endif
+    MODULE_FENCE();
     if (mask & MPHIP_MOD_DIFF_TURB)
       diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr);
+    MODULE_FENCE();
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_DIFF_PBL)) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
       diff_pbl(M, A, P, up, vp, wp, S.ctr_pbl, g);
@@ -285,8 +305,10 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       a.vp[i] = vp;
       a.wp[i] = wp;
     }
+    MODULE_FENCE();
     if (mask & MPHIP_MOD_CONVECTION)
       convection(ctl, M, A, P, S.ctr_conv, g, early ? &pre.conv : nullptr);
+    MODULE_FENCE();
     if (mask & MPHIP_MOD_SEDI)
       sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))
