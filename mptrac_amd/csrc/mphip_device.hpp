@@ -132,6 +132,10 @@ __device__ __forceinline__ Axes load_axes(const DevMet &M, double *smem) {
 #define MPHIP_EXACT_DIV 0
 #endif
 // 1: scheduling fences that keep independent computations from being interleaved (fewer live registers)
+// 1: keep the last wind corners of a particle and reload only where its grid cell changed
+#ifndef MPHIP_WIND_CACHE
+#define MPHIP_WIND_CACHE 1
+#endif
 #ifndef MPHIP_SCHED_FENCES
 #define MPHIP_SCHED_FENCES 0
 #endif
@@ -147,6 +151,66 @@ __device__ __forceinline__ double div_const(double x, double y, double inv_y) {
 }
 
 // ---- arithmetic conventions ------------------------------------------------
+
+// Division, square root and log of the default build (MPHIP_EXACT_DIV = 0).  On gfx950 an IEEE fp64
+// division costs ~68 cycles per wave, the library sqrt ~104 and the library log ~420
+// (tools/micro/valu_latency.hip); these take ~45, ~60 and ~150 and stay within 1-2 ulp -- far inside
+// the 1e-10 parity bar.  MPHIP_EXACT_DIV = 1 restores the IEEE / library versions everywhere.
+__device__ __forceinline__ double fdiv(double a, double b) {
+#if MPHIP_EXACT_DIV
+  return a / b;
+#else
+  double r = __builtin_amdgcn_rcp(b);             // two Newton steps, then one residual correction
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+#endif
+}
+
+__device__ __forceinline__ double fsqrt(double x) {
+#if MPHIP_EXACT_DIV
+  return sqrt(x);
+#else
+  const double y = __builtin_amdgcn_rsq(x);       // coupled Newton iteration for sqrt(x) and 1/(2 sqrt(x))
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return x == 0.0 ? x : g;                        // (also keeps -0 and avoids 0 * inf)
+#endif
+}
+
+// log(u) for the Box-Muller radius, u = r / 2^64 in [0, 1]: the fdlibm algorithm (argument reduced to
+// [sqrt(1/2), sqrt(2)), s = f / (2 + f), degree-14 even polynomial); within one ulp of the C library
+// on that range (checked on the CPU).  log(0) = -inf like the library.
+__device__ __forceinline__ double log_unit(double x) {
+#if MPHIP_EXACT_DIV
+  return log(x);
+#else
+  int hx = __double2hiint(x);
+  int k = (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  const int i = (hx + 0x95f64) & 0x100000;
+  k += i >> 20;
+  const double xn = __hiloint2double(hx | (i ^ 0x3ff00000), __double2loint(x));
+  const double f = xn - 1.0;
+  const double s = fdiv(f, 2.0 + f);
+  const double dk = (double) k;
+  const double z = s * s, w = z * z;
+  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01
+    + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  const double R = t2 + t1;
+  const bool mid = ((hx - 0x6147a) | (0x6b851 - hx)) > 0;
+  const double hfsq = 0.5 * f * f;
+  const double a = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+  const double b = dk * 6.93147180369123816490e-01 - ((s * (f - R) - dk * 1.90821492927058770002e-10) - f);
+  return x == 0.0 ? -__builtin_inf() : (mid ? a : b);
+#endif
+}
 
 // FMOD, mptrac.h:1121-1122.  (int)(x / y) is 0 whenever |x| < y, so the
 // division is only executed outside that range; the result is identical.
@@ -185,7 +249,7 @@ __device__ __forceinline__ double dx2deg(double dx, double lat) {   // mptrac.h:
 #if MPHIP_EXACT_DIV
   return dx * 180. / (kPi * kRE * cos(deg2rad(lat)));
 #else
-  return dx * 180. / (kPi * kRE * cos_latitude(deg2rad(lat)));
+  return fdiv(dx * 180., kPi * kRE * cos_latitude(deg2rad(lat)));
 #endif
 }
 
@@ -210,11 +274,11 @@ __device__ __forceinline__ double zfromp(double p) {   // mptrac.h:2243
 }
 
 __device__ __forceinline__ double lin(double x0, double y0, double x1, double y1, double x) {   // mptrac.h:1351
-  return y0 + (y1 - y0) / (x1 - x0) * (x - x0);
+  return y0 + fdiv(y1 - y0, x1 - x0) * (x - x0);
 }
 
 __device__ __forceinline__ double rho_air(double p, double t) {   // mptrac.h:1961
-  return 100. * p / (kRA * t);
+  return fdiv(100. * p, kRA * t);
 }
 
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
@@ -442,6 +506,62 @@ __device__ __forceinline__ void load_wind(const DevMet &M, const Stencil &s, Win
       c.r[di][dj][1] = q[1];
       c.r[di][dj][2] = q[2];
     }
+}
+
+// The 2 x 2 x 2 x 2 wind corners a particle used last, with the cell they belong to.  A gather
+// instruction costs the vector-memory path ~40-60 cycles per wave whatever its width, and costs per
+// active lane; consecutive Runge-Kutta stages (and module_diff_meso afterwards) mostly stay in the same
+// grid cell, so only the lanes whose cell changed reload (the loads run under their exec mask).
+struct WindCache {
+  WindCorners c;
+  int ix, iy, ip;
+  bool enabled;   // compile-time constant per kernel instantiation (off in the generic one: register budget)
+};
+
+__device__ __forceinline__ void wind_cache_reset(WindCache &w, bool enabled) {
+  w.enabled = enabled && MPHIP_WIND_CACHE;
+  w.ix = w.iy = w.ip = -1;
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        w.c.r[di][dj][k] = f32x4u{ 0.f, 0.f, 0.f, 0.f };
+}
+
+// The reload is written with the load instructions as inline assembly whose destination is a
+// read-write ("+v") operand: a lane that keeps its corners keeps its registers, and the compiler sees
+// one value per register instead of a 48-register merge of "old" and "reloaded" corners (which it
+// resolved by holding both and spilling).  wind_cache_wait() closes the sequence: it waits for the
+// loads and is the point after which the corners may be read.
+__device__ __forceinline__ void load_wind_cached(const DevMet &M, const Stencil &s, WindCache &w) {
+  if (s.ix != w.ix || s.iy != w.iy || s.ip != w.ip) {
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+      for (int dj = 0; dj < 2; dj++) {
+        const float *q = M.wind + 6 * cell_of(M, s, di, dj);
+        asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                     "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %3, off offset:32"
+                     : "+v"(w.c.r[di][dj][0]), "+v"(w.c.r[di][dj][1]), "+v"(w.c.r[di][dj][2])
+                     : "v"(q)
+                     : "memory");
+      }
+    w.ix = s.ix;
+    w.iy = s.iy;
+    w.ip = s.ip;
+  }
+}
+
+__device__ __forceinline__ void wind_cache_wait(WindCache &w) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(w.c.r[0][0][0]), "+v"(w.c.r[0][0][1]), "+v"(w.c.r[0][0][2]), "+v"(w.c.r[0][1][0]),
+                 "+v"(w.c.r[0][1][1]), "+v"(w.c.r[0][1][2]), "+v"(w.c.r[1][0][0]), "+v"(w.c.r[1][0][1]),
+                 "+v"(w.c.r[1][0][2]), "+v"(w.c.r[1][1][0]), "+v"(w.c.r[1][1][1]), "+v"(w.c.r[1][1][2])
+               :
+               : "memory");
 }
 
 // value of component k (0 u, 1 v, 2 w) of snapshot t at level ip + lvl
@@ -774,7 +894,7 @@ __device__ __forceinline__ double tropo_pressure(const mphip_ctl_t &ctl, const D
 
 __device__ __forceinline__ double tropo_weight_pt(double pt, double p) {
   const double p1 = pt * 0.866877899;
-  const double p0 = pt / 0.866877899;
+  const double p0 = div_const(pt, 0.866877899, 1.0 / 0.866877899);
   if (p > p0)
     return 1;
   if (p < p1)
@@ -806,13 +926,13 @@ __device__ __forceinline__ double sedi(double p, double T, double rp, double rho
   const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * pow(T / 296.16, 1.5);
 #else
   const double tr = T * (1.0 / 296.16);   // x^1.5 = x sqrt(x): within 2 ulp of pow()
-  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * (tr * sqrt(tr));
+  const double eta = 1.8325e-5 * fdiv(416.16, T + 120.) * (tr * fsqrt(tr));
 #endif
-  const double v = sqrt(div_const(8. * kKB * T, kPi * kMAir, 1.0 / (kPi * kMAir)));
-  const double lambda = 2. * eta / (rho * v);
-  const double K = lambda / r;
-  const double G = 1. + K * (1.249 + 0.42 * exp(-0.87 / K));
-  return 2. * (r * r) * (rhop - rho) * kG0 / (9. * eta) * G;
+  const double v = fsqrt(div_const(8. * kKB * T, kPi * kMAir, 1.0 / (kPi * kMAir)));
+  const double lambda = fdiv(2. * eta, rho * v);
+  const double K = fdiv(lambda, r);
+  const double G = 1. + K * (1.249 + 0.42 * exp(fdiv(-0.87, K)));
+  return fdiv(2. * (r * r) * (rhop - rho) * kG0, 9. * eta) * G;
 }
 
 // ---- random numbers (mptrac.c:5784-5828) -----------------------------------
@@ -898,7 +1018,7 @@ __device__ __forceinline__ float libm_sincosf(float y, int which) {
 __device__ __forceinline__ void normal_pair(uint64_t c0, uint64_t j2, double &even, double &odd) {
   const double ua = uniform01(c0 + j2);
   const double ub = uniform01(c0 + j2 + 1);
-  const double r = sqrt(-2.0 * log(ua));
+  const double r = fsqrt(-2.0 * log_unit(ua));
   const double phi = 2.0 * kPi * ub;
   const float phif = (float) phi;
   even = r * libm_sincosf(phif, 1);
@@ -993,7 +1113,7 @@ struct NoHook {
 };
 
 template <int ADVECT, class Hook>
-__device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particle &P, Hook &hook) {
+__device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particle &P, Hook &hook, WindCache &wc) {
   const int ct = M.coord_type;
   const double dt = P.dt;
   double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0;
@@ -1015,9 +1135,15 @@ __device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particl
     const double tm = P.time + dts;
     Stencil s;
     stencil_3d(M, A, x2, x0, x1, s);
-    WindCorners c;
-    load_wind(M, s, c);
-    hook(i);
+    if (wc.enabled) {
+      load_wind_cached(M, s, wc);
+      hook(i);
+      wind_cache_wait(wc);
+    } else {
+      load_wind(M, s, wc.c);
+      hook(i);
+    }
+    const WindCorners &c = wc.c;
     const double wt = time_weight(M, tm);
     u = wind_time_3d(c, s, wt, 0);
     v = wind_time_3d(c, s, wt, 1);
@@ -1039,18 +1165,19 @@ __device__ __forceinline__ void advect_n(const DevMet &M, const Axes &A, Particl
 
 template <class Hook>
 __device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
-                                       Hook &hook) {
+                                       Hook &hook, WindCache &wc) {
   if (ctl.advect == 4)
-    advect_n<4>(M, A, P, hook);
+    advect_n<4>(M, A, P, hook, wc);
   else if (ctl.advect == 2)
-    advect_n<2>(M, A, P, hook);
+    advect_n<2>(M, A, P, hook, wc);
   else
-    advect_n<1>(M, A, P, hook);
+    advect_n<1>(M, A, P, hook, wc);
 }
 
-__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P) {
+__device__ __forceinline__ void advect(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                       WindCache &wc) {
   NoHook none;
-  advect(ctl, M, A, P, none);
+  advect(ctl, M, A, P, none, wc);
 }
 
 // module_advect, zeta / eta branch (mptrac.c:3681-3757); zeta is the particle's
@@ -1157,12 +1284,12 @@ __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &
     normal_triple(ctr, g, rs0, rs1, rs2);
 
   if (Kx > 0) {
-    const double sigma_h = sqrt(2.0 * Kx * dt_abs);
+    const double sigma_h = fsqrt(2.0 * Kx * dt_abs);
     P.lon += dx2coord(ct, rs0 * sigma_h, P.lat);
     P.lat += dy2coord(ct, rs1 * sigma_h);
   }
   if (Kz > 0) {
-    const double sigma_z = sqrt(2.0 * Kz * dt_abs) * 1e-3;
+    const double sigma_z = fsqrt(2.0 * Kz * dt_abs) * 1e-3;
     const double p_save = P.p;
     const double eps_km = 0.01;
     const double p_up = p_save + dz2dp(eps_km, p_save);
@@ -1342,7 +1469,7 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
 // module_diff_meso, mptrac.c:4280-4338
 __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                           float &up, float &vp, float &wp, uint64_t ctr, uint64_t g,
-                                          const double *pre = nullptr) {
+                                          const double *pre, WindCache &wc) {
   // HIP's __fadd_rn / __fmul_rn are plain operators, so contraction has to be
   // switched off here for the single-precision statistics to round like the
   // reference's separate multiply and add (the variance is a small difference
@@ -1354,8 +1481,12 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
   s.ix = locate_reg(A.lon, M.nx, P.lon);   // exact: sigma is not continuous across cells
   s.iy = locate_lat(M, A, P.lat);
   s.ip = locate_p(M, A, P.p);
-  WindCorners c;
-  load_wind(M, s, c);
+  if (wc.enabled) {
+    load_wind_cached(M, s, wc);
+    wind_cache_wait(wc);
+  } else
+    load_wind(M, s, wc.c);
+  const WindCorners &c = wc.c;
 
   // single-precision sums in the reference's order: i (lon), j (lat),
   // k (level), met0 before met1
@@ -1385,8 +1516,8 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
 #if MPHIP_SCHED_FENCES
   __builtin_amdgcn_sched_barrier(0);   // the 48 corner values are dead from here on
 #endif
-  const double r = 1 - 2 * fabs(P.dt) / ctl.dt_met;
-  const double r2 = sqrt(1 - r * r);
+  const double r = 1 - fdiv(2 * fabs(P.dt), ctl.dt_met);
+  const double r2 = fsqrt(1 - r * r);
   double rs0, rs1, rs2;
   if (pre) {
     rs0 = pre[0];
@@ -1441,8 +1572,8 @@ __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet 
   if (ptop != pbot && P.p >= ptop) {
     const double tbot = temperature_at(M, A, P.time, pbot, P.lon, P.lat);
     const double ttop = temperature_at(M, A, P.time, ptop, P.lon, P.lat);
-    const double rhobot = pbot / tbot;
-    const double rhotop = ptop / ttop;
+    const double rhobot = fdiv(pbot, tbot);
+    const double rhotop = fdiv(ptop, ttop);
     const double rs = pre ? *pre : uniform01(ctr + g);
     const double rho = rhobot + (rhotop - rhobot) * rs;
     P.p = lin(rhobot, pbot, rhotop, ptop, rho);

@@ -268,6 +268,8 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     pre.ctr_conv = S.ctr_conv;
     pre.g = g;
 
+    WindCache wc;
+    wind_cache_reset(wc, CT != kMaskGeneric);
     if (mask & MPHIP_MOD_POSITION)
       position(M, A, P);
     if (mask & MPHIP_MOD_ADVECT) {
@@ -278,9 +280,9 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
         advect_ml(ctl, M, A, P, zeta);
         a.q[qnt][i] = zeta;
       } else if (early)
-        advect_n<4>(M, A, P, pre);
+        advect_n<4>(M, A, P, pre, wc);
       else
-        advect(ctl, M, A, P);
+        advect(ctl, M, A, P, wc);
     }
 #if MPHIP_SCHED_FENCES
 #define MODULE_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     }
     if (mask & MPHIP_MOD_DIFF_MESO) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
-      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr);
+      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc);
       a.up[i] = up;
       a.vp[i] = vp;
       a.wp[i] = wp;

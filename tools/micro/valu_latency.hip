@@ -5,6 +5,25 @@
 #include <cstdio>
 #include <cstdint>
 
+__device__ __forceinline__ double fast_sqrt(double x) {   // rsq + two coupled Newton steps
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return x == 0.0 ? x : g;
+}
+
+__device__ __forceinline__ double fast_div(double a, double b) {   // rcp + two Newton steps + residual correction
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+
 template <int CH, int OP>
 __global__ void chain(double *out, long long *cycles, int n, double a, double b) {
   double x[CH];
@@ -29,6 +48,11 @@ __global__ void chain(double *out, long long *cycles, int n, double a, double b)
       if (OP == 5) x[c] = (double) (float) x[c] + b;                      // cvt f64->f32->f64 + add
       if (OP == 6) x[c] = 1.0 / x[c] + b;                                 // IEEE division sequence
       if (OP == 7) x[c] = __builtin_sqrt(x[c]) + b;
+      if (OP == 8) x[c] = log(x[c]) + 2.0;                                // ocml log
+      if (OP == 9) x[c] = exp(-x[c]) + 1.0;                               // ocml exp
+      if (OP == 10) x[c] = cos(x[c]) + 1.0;                               // ocml cos
+      if (OP == 11) x[c] = fast_sqrt(x[c]) + b;
+      if (OP == 12) x[c] = fast_div(1.0, x[c]) + b;
     }
   }
   const long long t1 = __builtin_readcyclecounter();
@@ -85,5 +109,15 @@ int main() {
   run<4, 6>("div_f64+add", 1);
   run<1, 7>("sqrt_f64+add", 1);
   run<4, 7>("sqrt_f64+add", 1);
+  run<1, 8>("log+add", 1);
+  run<4, 8>("log+add", 1);
+  run<1, 9>("exp+add", 1);
+  run<4, 9>("exp+add", 1);
+  run<1, 10>("cos+add", 1);
+  run<4, 10>("cos+add", 1);
+  run<1, 11>("fast_sqrt+add", 1);
+  run<4, 11>("fast_sqrt+add", 1);
+  run<1, 12>("fast_div+add", 1);
+  run<4, 12>("fast_div+add", 1);
   return 0;
 }
