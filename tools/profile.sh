@@ -11,12 +11,12 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
 
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
 grep "^{" "$OUT/stats.log" | tail -1 > "$OUT/bench_under_profiler.json"
 
 pmc() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "step_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "step_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
 }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
@@ -24,7 +24,7 @@ pmc write WRITE_SIZE
 # pack_kernel reads 32 B and writes 32 B per grid point, fully coalesced
 calib() {
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "pack_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "pack_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
 }
 calib calib_fetch FETCH_SIZE
 calib calib_write WRITE_SIZE

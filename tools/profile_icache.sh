@@ -11,7 +11,7 @@ rocprofv3 --list-avail 2>/dev/null | grep -oE "SQC_[A-Z0-9_]+" | sort -u | tr "\
 BENCH="python $ROOT/bench.py --steps 6 --warmup 1 --no-cpu-baseline $*"
 pmc() {
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "step_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "step_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
 }
 pmc i1 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE
 pmc i2 SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES

@@ -8,10 +8,10 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --workload C3m --steps 10 --warmup 2 --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
 grep "^{" "$OUT/stats.log" | tail -1 > "$OUT/bench_under_profiler.json"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -f csv -d "$OUT/pmc_$c" -o pmc --kernel-include-regex "meteo_kernel" -- $BENCH > "$OUT/pmc_$c.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c -f csv -d "$OUT/pmc_$c" -o pmc --kernel-include-regex "meteo_kernel" -- $BENCH > "$OUT/pmc_$c.log" 2>&1
 done
 python - "$OUT" <<'PY'
 import csv, glob, statistics, sys
