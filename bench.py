@@ -43,6 +43,14 @@ WORKLOADS = {
     "C3m": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1),
             ("m", "rp", "rhop", "t", "u", "v", "w", "zg", "pv", "ps", "pt"),
             ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel", "z", "pv", "pt")),
+    # BASELINE configs[4] / SURVEY C5: C3 + module_sort and inter-parcel mixing every step, decay, wet and dry
+    # deposition (per-GPU part; the survey's control line)
+    "C5": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1, sort_dt=180.0,
+                               mixing_trop=1e-3, mixing_strat=1e-6, mixing_dt=180.0, tdec_trop=259200.0,
+                               tdec_strat=259200.0, dry_depo_vdep=0.15, wet_depo_ic_a=1e-4, wet_depo_ic_b=0.8,
+                               wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6),
+           ("m", "rp", "rhop"), ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "lwc",
+                                 "rwc", "iwc", "swc")),
     "C2": ("C2", 10 ** 6, dict(advect=4, dt_mod=180.0, diffusion=1, turb_mesox=0.0, turb_mesoz=0.0, rng_type=1),
            ("m",), ("u", "v", "w", "ps", "pbl")),
     "C1": ("C1", 10 ** 4, dict(advect=4, dt_mod=180.0, rng_type=1), ("m",), ("u", "v", "w", "ps")),
@@ -55,6 +63,7 @@ def algorithmic_bytes_per_pstep(workload, met, np_local):
     step can touch, once per launch."""
     state = {"C3": 64 + 24 + 16,   # time,lon,lat,p R+W; uvwp R+W; rp,rhop R
              "C3m": 64 + 24 + 16,  # (the step kernel's bytes; module_meteo is a separate kernel)
+             "C5": 64 + 24 + 16 + 16,
              "C2": 64, "C1": 64}[workload]
     wind = met.nx * met.ny * met.np * 32            # {u,v,w,t} x 2 snapshots, float
     sfc = met.nx * met.ny * 64                      # 8 surface fields x 2 snapshots
@@ -201,7 +210,9 @@ def main():
                                    "turbulent + mesoscale diffusion + convection + sedimentation, 721x361x137 "
                                    "synthetic ERA5-shaped grid" if args.workload == "C3" else
                                    ("C3 + module_meteo every step (t, u, v, w, zg, pv, ps, pt)"
-                                    if args.workload == "C3m" else args.workload),
+                                    if args.workload == "C3m" else
+                                    ("C5: C3 + module_sort + mixing every step, decay, wet and dry deposition"
+                                     if args.workload == "C5" else args.workload)),
                        "particles_per_gpu": n_local, "particles_total": n_total,
                        "grid": [met0.nx, met0.ny, met0.np], "dt_mod": dt,
                        "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce"},

@@ -495,8 +495,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     HIPCHK(hipEventRecord(e0, ctx->stream));
   }
   const bool ml_ = (ctx->ctl.advect_vert_coord == 1 || ctx->ctl.advect_vert_coord == 3);
-  const unsigned sel = (ctx->ctl.advect == 4 && !ml_ && !(mask & MPHIP_MOD_DIFF_PBL) && !ctx->force_generic)
-    ? mask : kMaskGeneric;
+  const bool rare = ml_ || (mask & kRareModules);
+  const unsigned sel = ctx->force_generic ? kMaskGeneric : ((ctx->ctl.advect == 4 && !rare) ? mask : kMaskGeneric);
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
   case M:                                                                                             \
@@ -509,7 +509,10 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiffConvSedi)
 #undef STEP_CASE
   default:
-    hipLaunchKernelGGL(step_kernel<kMaskGeneric>, dim3(nb), dim3(256), lds, ctx->stream, S);
+    if (rare || ctx->force_generic)
+      hipLaunchKernelGGL(step_kernel<kMaskGeneric>, dim3(nb), dim3(256), lds, ctx->stream, S);
+    else
+      hipLaunchKernelGGL(step_kernel<kMaskGenericPL>, dim3(nb), dim3(256), lds, ctx->stream, S);
   }
   HIPCHK(hipGetLastError());
   if (ctx->prof)

@@ -28,7 +28,13 @@ struct StepParams {
   uint64_t ctr_turb, ctr_meso, ctr_conv, ctr_pbl;   // base counters of the module_rng calls
 };
 
-constexpr unsigned kMaskGeneric = 0xffffffffu;
+constexpr unsigned kMaskGeneric = 0xffffffffu;     // every module, module set taken from StepParams::mask
+// module set from StepParams::mask too, but without the code of the rarely used modules (model-level
+// advection and its init, module_diff_pbl, module_isosurf, module_bound_cond): small enough to keep
+// the wind-corner cache and three waves per SIMD
+constexpr unsigned kMaskGenericPL = 0xfffffffeu;
+constexpr unsigned kRareModules = MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT | MPHIP_MOD_ISOSURF | MPHIP_MOD_DIFF_PBL
+  | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
 constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a later launch reads it)
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI | MPHIP_MOD_ISOSURF | MPHIP_MOD_POSITION2;
@@ -195,7 +201,7 @@ struct RngEarly {
 template <unsigned CT>
 __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(const StepParams S) {
   extern __shared__ double s_axes[];
-  const unsigned mask = (CT == kMaskGeneric) ? S.mask : CT;
+  const unsigned mask = (CT == kMaskGeneric || CT == kMaskGenericPL) ? S.mask : CT;
   const DevMet &M = S.met;
   const DevAtm &a = S.atm;
   const mphip_ctl_t &ctl = S.ctl;
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) a.ext[i] : i));
 
     // specialised instantiations = RK4 on pressure levels (launch_step): 4 stages, all hooks run
-    constexpr bool early = MPHIP_RNG_EARLY && CT != kMaskGeneric && (CT & MPHIP_MOD_ADVECT);
+    constexpr bool early = MPHIP_RNG_EARLY && CT != kMaskGeneric && CT != kMaskGenericPL && (CT & MPHIP_MOD_ADVECT);
     RngEarly pre;
     pre.mask = mask;
     pre.ctr_turb = S.ctr_turb;
