@@ -984,6 +984,10 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     return fail(ctx, "bad argument");
   if (met->nx < 2 || met->ny < 2 || met->np < 2 || !met->lon || !met->lat || !met->p)
     return fail(ctx, "meteo grid dimensions out of range");
+  // index arithmetic of the kernels (cell_of / col_of): 24-bit factors, 31-bit cell index
+  if ((long long) met->nx * met->ny >= (1LL << 24) || (long long) met->nx * met->ny * std::max(met->np, met->npl) >= (1LL << 31)
+      || met->np >= (1 << 24))
+    return fail(ctx, "meteo grid too large for the device index arithmetic");
   HIPCHK(hipSetDevice(ctx->device));
   const int nml = met->npl > 0 ? met->npl : 0;
   const bool new_grid = (met->nx != ctx->nx || met->ny != ctx->ny || met->np != ctx->npl || nml != ctx->nml);

@@ -492,8 +492,17 @@ struct WindCorners {
   f32x4u r[2][2][3];   // [di][dj][piece]: 12 floats = level ip {u,v,w}0{u,v,w}1, level ip+1 {..}
 };
 
+// Index arithmetic in 24 x 24 -> 32-bit multiplies (full rate; a 64-bit integer multiply is four
+// quarter-rate ones): nx * ny < 2^24 and nx * ny * np < 2^31 are checked when the grid is uploaded.  The
+// four corners of a stencil share one base index.
+__device__ __forceinline__ unsigned col_of(const DevMet &M, const Stencil &s, int di, int dj) {
+  return __umul24((unsigned) s.ix, (unsigned) M.ny) + (unsigned) s.iy + (unsigned) di * (unsigned) M.ny + (unsigned) dj;
+}
+
 __device__ __forceinline__ size_t cell_of(const DevMet &M, const Stencil &s, int di, int dj) {
-  return ((size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj)) * (size_t) M.np + (size_t) s.ip;
+  const unsigned base = __umul24(__umul24((unsigned) s.ix, (unsigned) M.ny) + (unsigned) s.iy, (unsigned) M.np)
+    + (unsigned) s.ip;
+  return (size_t) (base + (unsigned) di * ((unsigned) M.ny * (unsigned) M.np) + (unsigned) dj * (unsigned) M.np);
 }
 
 __device__ __forceinline__ void load_wind(const DevMet &M, const Stencil &s, WindCorners &c) {
@@ -683,7 +692,7 @@ __device__ __forceinline__ void load_sfa(const DevMet &M, const Stencil &s, Surf
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++)
-      c.v[di][dj] = M.sfa[(size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj)];
+      c.v[di][dj] = M.sfa[col_of(M, s, di, dj)];
 }
 
 // f = 0: ps, f = 1: pbl
@@ -703,7 +712,7 @@ __device__ __forceinline__ void load_sfb(const f32x4 *__restrict__ g, const DevM
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++) {
-      const f32x4 *q = g + 2 * ((size_t) (s.ix + di) * (size_t) M.ny + (size_t) (s.iy + dj));
+      const f32x4 *q = g + 2 * (size_t) col_of(M, s, di, dj);
       c.v[di][dj][0] = q[0];
       c.v[di][dj][1] = q[1];
     }
@@ -1594,7 +1603,7 @@ __device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Pa
 constexpr double kLv = 2501000.;   // LV, mptrac.h:275
 
 __device__ __forceinline__ double plane_space_2d(const float *__restrict__ a, const DevMet &M, const Stencil &s) {
-  const size_t c0 = (size_t) s.ix * (size_t) M.ny + (size_t) s.iy, c1 = c0 + (size_t) M.ny;
+  const size_t c0 = col_of(M, s, 0, 0), c1 = c0 + (size_t) M.ny;
   return bilin_2d(s, a[c0], a[c0 + 1], a[c1], a[c1 + 1]);
 }
 
