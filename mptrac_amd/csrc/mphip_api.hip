@@ -56,7 +56,7 @@ struct mphip_ctx {
   int lut_base = 0, lut_size = 0;
   size_t axes_bytes = 0;
   float *d_wind = nullptr, *d_temp = nullptr;     // packed two-snapshot grids (layouts: mphip_device.hpp)
-  f32x4 *d_mx = nullptr;                          // {z,pv,o3,cc} records (module_meteo)
+  f32x4 *d_mx = nullptr, *d_mx2 = nullptr;        // level / surface pair records of module_meteo
   f32x4 *d_cloud = nullptr, *d_sfa = nullptr, *d_sfb = nullptr, *d_sfc = nullptr, *d_sfd = nullptr;
   float *d_h2o = nullptr;
   bool packed_dirty = true;
@@ -177,6 +177,7 @@ DevMet dev_met(const mphip_ctx *c) {
   M.temp = c->d_temp;
   M.cloud = c->d_cloud;
   M.mx = c->d_mx;
+  M.mx2 = c->d_mx2;
   M.sfa = c->d_sfa;
   M.sfb = c->d_sfb;
   M.sfc = c->d_sfc;
@@ -302,7 +303,7 @@ int ensure_packed(mphip_ctx *ctx) {
     return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
   const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
   PackArgs a;
-  bool any_cloud = false, any_ml = false, any_pbl = false, any_mx = false;
+  bool any_cloud = false, any_ml = false, any_pbl = false, any_mx = false, any_mx2 = false;
   const MetSlot *ss[2] = { &s0, &s1 };
   for (int t = 0; t < 2; t++) {
     for (int f = 0; f < MPHIP_N3D; f++)
@@ -313,6 +314,8 @@ int ensure_packed(mphip_ctx *ctx) {
       any_cloud = any_cloud || ss[t]->has3[f];
     for (int f = MPHIP_Z; f <= MPHIP_CC; f++)
       any_mx = any_mx || ss[t]->has3[f];
+    for (int f = MPHIP_TS; f <= MPHIP_O3C; f++)
+      any_mx2 = any_mx2 || ss[t]->has2[f];
     any_ml = any_ml || ss[t]->has3[MPHIP_UL] || ss[t]->has3[MPHIP_VL] || ss[t]->has3[MPHIP_ZETA_DOTL];
     any_pbl = any_pbl || ss[t]->has3[MPHIP_H2O] || ss[t]->has2[MPHIP_ESS] || ss[t]->has2[MPHIP_NSS]
       || ss[t]->has2[MPHIP_SHF];
@@ -330,12 +333,15 @@ int ensure_packed(mphip_ctx *ctx) {
     return 1;
   if (any_mx && !ctx->d_mx && dev_alloc(ctx, &ctx->d_mx, 2 * ncell))
     return 1;
+  if (any_mx2 && !ctx->d_mx2 && dev_alloc(ctx, &ctx->d_mx2, 7 * ncol))
+    return 1;
   if (any_pbl && !ctx->d_sfd && (dev_alloc(ctx, &ctx->d_sfd, 2 * ncol) || dev_alloc(ctx, &ctx->d_h2o, 2 * ncell)))
     return 1;
   a.wind = ctx->d_wind;
   a.temp = ctx->d_temp;
   a.cloud = any_cloud ? ctx->d_cloud : nullptr;
   a.mx = any_mx ? ctx->d_mx : nullptr;
+  a.mx2 = any_mx2 ? ctx->d_mx2 : nullptr;
   a.sfa = ctx->d_sfa;
   a.sfb = ctx->d_sfb;
   a.sfc = ctx->d_sfc;
@@ -587,12 +593,8 @@ int launch_meteo(mphip_ctx *ctx) {
   if (ensure_packed(ctx))
     return 1;
   for (int f = 0; f < MPHIP_N2D; f++)
-    if ((d.need2 >> f) & 1u) {
-      if (!s0.has2[f] || !s1.has2[f])
-        return fail(ctx, std::string("module_meteo: meteo field ") + n2[f] + " was not uploaded");
-      G.f2[0][f] = s0.f2[f];
-      G.f2[1][f] = s1.f2[f];
-    }
+    if (((d.need2 >> f) & 1u) && (!s0.has2[f] || !s1.has2[f]))
+      return fail(ctx, std::string("module_meteo: meteo field ") + n2[f] + " was not uploaded");
   G.ctl = c;
   G.met = dev_met(ctx);
   G.atm = dev_atm(ctx);
@@ -894,6 +896,7 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_temp);
   dev_free(ctx->d_cloud);
   dev_free(ctx->d_mx);
+  dev_free(ctx->d_mx2);
   dev_free(ctx->d_sfa);
   dev_free(ctx->d_sfb);
   dev_free(ctx->d_sfc);
@@ -1007,7 +1010,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     dev_free(ctx->d_temp);
     dev_free(ctx->d_cloud);
     dev_free(ctx->d_mx);
-    ctx->d_mx = nullptr;
+    dev_free(ctx->d_mx2);
+    ctx->d_mx = ctx->d_mx2 = nullptr;
     dev_free(ctx->d_sfa);
     dev_free(ctx->d_sfb);
     dev_free(ctx->d_sfc);

@@ -43,7 +43,10 @@ struct DevMet {
   const float *wind;     // [cell][6]
   const float *temp;     // [cell][2]
   const f32x4 *cloud;    // [cell][2] (optional)
-  const f32x4 *mx;       // [cell][2] {z,pv,o3,cc}0 {..}1: level fields only module_meteo reads (optional)
+  // level / surface fields only module_meteo reads, two fields x two snapshots per record {a0,b0,a1,b1}
+  // (so that a request touching one pair gathers 16 useful bytes per lane and instruction):
+  const f32x4 *mx;       // [2][cell]: {z,pv}, {o3,cc} (optional)
+  const f32x4 *mx2;      // [7][col]: {ts,zs} {us,vs} {lsm,sst} {pt,tt} {zt,h2ot} {plcl,plfc} {o3c,-} (optional)
   const f32x4 *sfa;      // [col]
   const f32x4 *sfb;      // [col][2]
   const f32x4 *sfc;      // [col][2]
@@ -687,12 +690,17 @@ struct SurfA {
   f32x4 v[2][2];   // {ps0, pbl0, ps1, pbl1}
 };
 
-__device__ __forceinline__ void load_sfa(const DevMet &M, const Stencil &s, SurfA &c) {
+__device__ __forceinline__ void load_pair_2d(const f32x4 *__restrict__ g, const DevMet &M, const Stencil &s,
+                                             SurfA &c) {
 #pragma unroll
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++)
-      c.v[di][dj] = M.sfa[col_of(M, s, di, dj)];
+      c.v[di][dj] = g[col_of(M, s, di, dj)];
+}
+
+__device__ __forceinline__ void load_sfa(const DevMet &M, const Stencil &s, SurfA &c) {
+  load_pair_2d(M.sfa, M, s, c);
 }
 
 // f = 0: ps, f = 1: pbl
@@ -700,6 +708,32 @@ __device__ __forceinline__ double sfa_time_2d(const SurfA &c, const Stencil &s, 
   const double v0 = bilin_2d(s, c.v[0][0][f], c.v[0][1][f], c.v[1][0][f], c.v[1][1][f]);
   const double v1 = bilin_2d(s, c.v[0][0][2 + f], c.v[0][1][2 + f], c.v[1][0][2 + f], c.v[1][1][2 + f]);
   return blend_time_2d(v0, v1, wt);
+}
+
+// two level fields x two snapshots per record {a0,b0,a1,b1}: a column's level pair is two loads
+struct PairCorners {
+  f32x4 lo[2][2], hi[2][2];   // level ip, level ip + 1
+};
+
+__device__ __forceinline__ void load_pair_3d(const f32x4 *__restrict__ g, const DevMet &M, const Stencil &s,
+                                             PairCorners &c) {
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++) {
+      const f32x4 *q = g + cell_of(M, s, di, dj);
+      c.lo[di][dj] = q[0];
+      c.hi[di][dj] = q[1];
+    }
+}
+
+// field f (0 / 1) of the record
+__device__ __forceinline__ double pair_field_time_3d(const PairCorners &c, const Stencil &s, double wt, int f) {
+  const double v0 = lerp3(s, c.lo[0][0][f], c.hi[0][0][f], c.lo[0][1][f], c.hi[0][1][f], c.lo[1][0][f], c.hi[1][0][f],
+                          c.lo[1][1][f], c.hi[1][1][f]);
+  const double v1 = lerp3(s, c.lo[0][0][2 + f], c.hi[0][0][2 + f], c.lo[0][1][2 + f], c.hi[0][1][2 + f],
+                          c.lo[1][0][2 + f], c.hi[1][0][2 + f], c.lo[1][1][2 + f], c.hi[1][1][2 + f]);
+  return wt * (v0 - v1) + v1;
 }
 
 // three-field surface records: {a,b,c,-}0 {a,b,c,-}1 (sfb: cape,cin,pel; sfc: pct,pcb,cl)
@@ -1597,21 +1631,9 @@ __device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Pa
 }
 
 // ---- module_meteo (mptrac.c:5062-5165) --------------------------------------
-// Level fields come from the packed two-snapshot records (wind, temp, h2o,
-// cloud, mx), surface fields from the per-snapshot planar copies ([ix][iy]).
+// Every field comes from a packed two-snapshot record (wind, temp, h2o, cloud, mx; sfa ... sfd, mx2).
 
 constexpr double kLv = 2501000.;   // LV, mptrac.h:275
-
-__device__ __forceinline__ double plane_space_2d(const float *__restrict__ a, const DevMet &M, const Stencil &s) {
-  const size_t c0 = col_of(M, s, 0, 0), c1 = c0 + (size_t) M.ny;
-  return bilin_2d(s, a[c0], a[c0 + 1], a[c1], a[c1 + 1]);
-}
-
-// intpol_met_time_2d with init = 0 (mptrac.c:3141-3170)
-__device__ __forceinline__ double plane_time_2d(const float *__restrict__ a0, const float *__restrict__ a1,
-                                                const DevMet &M, const Stencil &s, double wt) {
-  return blend_time_2d(plane_space_2d(a0, M, s), plane_space_2d(a1, M, s), wt);
-}
 
 __device__ __forceinline__ double pw_of(double p, double h2o) {   // PW, mptrac.h:1859
   return p * dmax(h2o, 0.1e-6) / (1. + (1. - kEps) * dmax(h2o, 0.1e-6));

@@ -362,7 +362,8 @@ struct PackArgs {
   const float *f2[2][MPHIP_N2D];
   float *wind, *temp;
   f32x4 *cloud, *sfa, *sfb, *sfc, *sfd;
-  f32x4 *mx;                       // {z,pv,o3,cc}0 {..}1 (NULL: none)
+  f32x4 *mx;                       // [2][cell] {z,pv}01, {o3,cc}01 (NULL: none)
+  f32x4 *mx2;                      // [7][col] surface pairs of module_meteo (NULL: none)
   float *h2o;                      // {h2o}0 {h2o}1 (NULL: none)
   float *mlw;                      // model-level {ul,vl,zeta_dot} records (NULL: none)
   size_t ncell, ncol, ncell_ml;
@@ -386,12 +387,17 @@ __global__ void pack_kernel(PackArgs a) {
           v[k] = a.f3[t][MPHIP_LWC + k] ? a.f3[t][MPHIP_LWC + k][i] : 0.f;
         a.cloud[2 * i + t] = v;
       }
-      if (a.mx) {
+    }
+    if (a.mx) {
+#pragma unroll
+      for (int pr = 0; pr < 2; pr++) {
         f32x4 v;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-          v[k] = a.f3[t][MPHIP_Z + k] ? a.f3[t][MPHIP_Z + k][i] : 0.f;
-        a.mx[2 * i + t] = v;
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int f = 0; f < 2; f++)
+            v[2 * t + f] = a.f3[t][MPHIP_Z + 2 * pr + f] ? a.f3[t][MPHIP_Z + 2 * pr + f][i] : 0.f;
+        a.mx[(size_t) pr * a.ncell + i] = v;
       }
     }
   }
@@ -430,6 +436,20 @@ __global__ void pack_kernel(PackArgs a) {
       }
     }
     a.sfa[i] = va;
+    if (a.mx2) {
+#pragma unroll
+      for (int pr = 0; pr < 7; pr++) {
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int f = 0; f < 2; f++) {
+            const int fld = MPHIP_TS + 2 * pr + f;
+            v[2 * t + f] = (fld < MPHIP_N2D && a.f2[t][fld]) ? a.f2[t][fld][i] : 0.f;
+          }
+        a.mx2[(size_t) pr * a.ncol + i] = v;
+      }
+    }
   }
 }
 
@@ -834,7 +854,6 @@ struct MeteoArgs {
   mphip_ctl_t ctl;
   DevMet met;
   DevAtm atm;
-  const float *f2[2][MPHIP_N2D];   // planar surface fields of met0 / met1
   unsigned need3, need2;
   int nblocks_logical;             // as StepParams: contiguous runs of the locality order per block
   long long per_block;
@@ -858,15 +877,14 @@ __global__ __launch_bounds__(256, MPHIP_METEO_WAVES_PER_SIMD) void meteo_kernel(
   long long last = first + G.per_block;
   if (last > a.np)
     last = a.np;
-  const bool want_wind = n3 & (1u << MPHIP_U | 1u << MPHIP_V | 1u << MPHIP_W);
-  const bool want_cloud = n3 & (1u << MPHIP_LWC | 1u << MPHIP_RWC | 1u << MPHIP_IWC | 1u << MPHIP_SWC);
-  const bool want_mx = n3 & (1u << MPHIP_Z | 1u << MPHIP_PV | 1u << MPHIP_O3 | 1u << MPHIP_CC);
+  auto bits = [](int lo, int hi) { return ((2u << hi) - 1u) & ~((1u << lo) - 1u); };   // bits lo ... hi
+  const bool want_wind = n3 & bits(MPHIP_U, MPHIP_W);
+  const bool want_cloud = n3 & bits(MPHIP_LWC, MPHIP_SWC);
   for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
     const double tm = a.time[i], p = a.p[i], lon = a.lon[i], lat = a.lat[i];
     Stencil s = stencil_zero();
     stencil_3d(M, A, p, lon, lat, s);
     const double wt = time_weight(M, tm);
-#define F2(f) (((n2 >> (f)) & 1u) ? plane_time_2d(G.f2[0][f], G.f2[1][f], M, s, wt) : 0.0)
 #define SETQ(k, val)                                                                          \
   if (qm[k] >= 0)                                                                             \
     a.q[qm[k]][i] = (val)
@@ -898,43 +916,68 @@ __global__ __launch_bounds__(256, MPHIP_METEO_WAVES_PER_SIMD) void meteo_kernel(
       SETQ(MPHIP_MQ_IWC, cloud_time_3d(c, s, wt, 2));
       SETQ(MPHIP_MQ_SWC, cloud_time_3d(c, s, wt, 3));
     }
-    if (want_mx) {
-      CloudCorners c;
-      load_quad(M.mx, M, s, c);
-      SETQ(MPHIP_MQ_ZG, cloud_time_3d(c, s, wt, 0));
-      SETQ(MPHIP_MQ_PV, cloud_time_3d(c, s, wt, 1));
-      SETQ(MPHIP_MQ_O3, cloud_time_3d(c, s, wt, 2));
-      SETQ(MPHIP_MQ_CC, cloud_time_3d(c, s, wt, 3));
+    if (n3 & bits(MPHIP_Z, MPHIP_PV)) {
+      PairCorners c;
+      load_pair_3d(M.mx, M, s, c);
+      SETQ(MPHIP_MQ_ZG, pair_field_time_3d(c, s, wt, 0));
+      SETQ(MPHIP_MQ_PV, pair_field_time_3d(c, s, wt, 1));
     }
-    SETQ(MPHIP_MQ_TS, F2(MPHIP_TS));
-    SETQ(MPHIP_MQ_ZS, F2(MPHIP_ZS));
-    SETQ(MPHIP_MQ_US, F2(MPHIP_US));
-    SETQ(MPHIP_MQ_VS, F2(MPHIP_VS));
-    SETQ(MPHIP_MQ_ESS, F2(MPHIP_ESS));
-    SETQ(MPHIP_MQ_NSS, F2(MPHIP_NSS));
-    SETQ(MPHIP_MQ_SHF, F2(MPHIP_SHF));
-    SETQ(MPHIP_MQ_LSM, F2(MPHIP_LSM));
-    SETQ(MPHIP_MQ_SST, F2(MPHIP_SST));
-    SETQ(MPHIP_MQ_PBL, F2(MPHIP_PBL));
-    SETQ(MPHIP_MQ_PT, F2(MPHIP_PT));
-    SETQ(MPHIP_MQ_TT, F2(MPHIP_TT));
-    SETQ(MPHIP_MQ_ZT, F2(MPHIP_ZT));
-    SETQ(MPHIP_MQ_H2OT, F2(MPHIP_H2OT));
-    SETQ(MPHIP_MQ_PCT, F2(MPHIP_PCT));
-    SETQ(MPHIP_MQ_PCB, F2(MPHIP_PCB));
-    SETQ(MPHIP_MQ_CL, F2(MPHIP_CL));
-    SETQ(MPHIP_MQ_PLCL, F2(MPHIP_PLCL));
-    SETQ(MPHIP_MQ_PLFC, F2(MPHIP_PLFC));
-    SETQ(MPHIP_MQ_PEL, F2(MPHIP_PEL));
-    SETQ(MPHIP_MQ_CAPE, F2(MPHIP_CAPE));
-    SETQ(MPHIP_MQ_CIN, F2(MPHIP_CIN));
-    SETQ(MPHIP_MQ_O3C, F2(MPHIP_O3C));
+    if (n3 & bits(MPHIP_O3, MPHIP_CC)) {
+      PairCorners c;
+      load_pair_3d(M.mx + (size_t) M.nx * (size_t) M.ny * (size_t) M.np, M, s, c);
+      SETQ(MPHIP_MQ_O3, pair_field_time_3d(c, s, wt, 0));
+      SETQ(MPHIP_MQ_CC, pair_field_time_3d(c, s, wt, 1));
+    }
+    // surface fields: sfa {ps,pbl}, sfb {cape,cin,pel}, sfc {pct,pcb,cl}, sfd {ess,nss,shf}, then the pairs of mx2
+    double ps = 0.0;
+    if (n2 & bits(MPHIP_PS, MPHIP_PBL)) {
+      SurfA c;
+      load_sfa(M, s, c);
+      ps = sfa_time_2d(c, s, wt, 0);
+      SETQ(MPHIP_MQ_PS, ps);
+      SETQ(MPHIP_MQ_PBL, sfa_time_2d(c, s, wt, 1));
+    }
+    if (n2 & bits(MPHIP_CAPE, MPHIP_PEL)) {
+      SurfB c;
+      load_sfb(M.sfb, M, s, c);
+      SETQ(MPHIP_MQ_CAPE, sfb_time_2d(c, s, wt, 0));
+      SETQ(MPHIP_MQ_CIN, sfb_time_2d(c, s, wt, 1));
+      SETQ(MPHIP_MQ_PEL, sfb_time_2d(c, s, wt, 2));
+    }
+    if (n2 & bits(MPHIP_PCT, MPHIP_CL)) {
+      SurfB c;
+      load_sfb(M.sfc, M, s, c);
+      SETQ(MPHIP_MQ_PCT, sfb_time_2d(c, s, wt, 0));
+      SETQ(MPHIP_MQ_PCB, sfb_time_2d(c, s, wt, 1));
+      SETQ(MPHIP_MQ_CL, sfb_time_2d(c, s, wt, 2));
+    }
+    if (n2 & bits(MPHIP_ESS, MPHIP_SHF)) {
+      SurfB c;
+      load_sfb(M.sfd, M, s, c);
+      SETQ(MPHIP_MQ_ESS, sfb_time_2d(c, s, wt, 0));
+      SETQ(MPHIP_MQ_NSS, sfb_time_2d(c, s, wt, 1));
+      SETQ(MPHIP_MQ_SHF, sfb_time_2d(c, s, wt, 2));
+    }
+#define PAIR2(pr, qa, qb)                                                                     \
+  if (n2 & bits(MPHIP_TS + 2 * (pr), MPHIP_TS + 2 * (pr) + 1)) {                              \
+    SurfA c;                                                                                  \
+    load_pair_2d(M.mx2 + (size_t) (pr) * (size_t) M.nx * (size_t) M.ny, M, s, c);             \
+    SETQ(qa, sfa_time_2d(c, s, wt, 0));                                                       \
+    if ((qb) >= 0)                                                                            \
+      SETQ((qb) >= 0 ? (qb) : 0, sfa_time_2d(c, s, wt, 1));                                   \
+  }
+    PAIR2(0, MPHIP_MQ_TS, MPHIP_MQ_ZS)
+    PAIR2(1, MPHIP_MQ_US, MPHIP_MQ_VS)
+    PAIR2(2, MPHIP_MQ_LSM, MPHIP_MQ_SST)
+    PAIR2(3, MPHIP_MQ_PT, MPHIP_MQ_TT)
+    PAIR2(4, MPHIP_MQ_ZT, MPHIP_MQ_H2OT)
+    PAIR2(5, MPHIP_MQ_PLCL, MPHIP_MQ_PLFC)
+    PAIR2(6, MPHIP_MQ_O3C, -1)
+#undef PAIR2
     SETQ(MPHIP_MQ_P, p);
     // temperature, water vapour, surface pressure and what derives from them
     const double t = ((n3 >> MPHIP_T) & 1u) ? temp_time_3d(M, s, wt) : 0.0;
     const double h2o = ((n3 >> MPHIP_H2O) & 1u) ? pair_time_3d(M.h2o, M, s, wt) : 0.0;
-    const double ps = F2(MPHIP_PS);
-    SETQ(MPHIP_MQ_PS, ps);
     SETQ(MPHIP_MQ_T, t);
     SETQ(MPHIP_MQ_H2O, h2o);
     SETQ(MPHIP_MQ_RHO, rho_air(p, t));
@@ -950,7 +993,6 @@ __global__ __launch_bounds__(256, MPHIP_METEO_WAVES_PER_SIMD) void meteo_kernel(
     SETQ(MPHIP_MQ_LAPSE, lapse_rate(t, h2o));
     SETQ(MPHIP_MQ_TDEW, tdew_of(p, h2o));
     SETQ(MPHIP_MQ_TICE, tice_of(p, h2o));
-#undef F2
 #undef SETQ
   }
 }
