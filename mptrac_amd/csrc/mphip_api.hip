@@ -612,6 +612,16 @@ int launch_meteo(mphip_ctx *ctx) {
   return 0;
 }
 
+PermGeom perm_geom(long long n) {
+  PermGeom pg;
+  long long per_block = (n + 8191) / 8192;
+  per_block = std::max<long long>(256, (per_block + 255) / 256 * 256);
+  int nb = (int) ((n + per_block - 1) / per_block);
+  pg.nblocks = std::max(8, (nb + 7) & ~7);
+  pg.per_block = per_block;
+  return pg;
+}
+
 PermArgs perm_args(mphip_ctx *ctx, bool with_cache) {
   PermArgs g;
   memset(&g, 0, sizeof(g));
@@ -703,7 +713,8 @@ int restore_external_order(mphip_ctx *ctx) {
     return 0;
   }
   PermArgs g = perm_args(ctx, true);
-  hipLaunchKernelGGL(perm_scatter_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, g, ctx->d_ext, ctx->np);
+  const PermGeom pg = perm_geom(ctx->np);
+  hipLaunchKernelGGL(perm_scatter_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_ext, ctx->np, pg);
   HIPCHK(hipGetLastError());
   perm_swap(ctx, true);
   ctx->ext_identity = true;
@@ -725,8 +736,8 @@ int locality_sort(mphip_ctx *ctx) {
   PermArgs g = perm_args(ctx, true);
   g.ext_in = ctx->ext_identity ? nullptr : ctx->d_ext;
   g.ext_out = ctx->d_ext_alt;
-  hipLaunchKernelGGL(perm_gather_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur],
-                     ctx->np);
+  const PermGeom pg = perm_geom(ctx->np);
+  hipLaunchKernelGGL(perm_gather_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], ctx->np, pg);
   HIPCHK(hipGetLastError());
   perm_swap(ctx, true);
   std::swap(ctx->d_ext, ctx->d_ext_alt);
@@ -749,7 +760,8 @@ int do_sort(mphip_ctx *ctx) {
     return 1;
   ctx->sorted_buf = cur;
   PermArgs g = perm_args(ctx, false);
-  hipLaunchKernelGGL(perm_gather_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], n);
+  const PermGeom pg = perm_geom(n);
+  hipLaunchKernelGGL(perm_gather_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], n, pg);
   HIPCHK(hipGetLastError());
   perm_swap(ctx, false);
   ctx->steps_since_resort = 0;   // the observable order is a locality order already

@@ -1079,9 +1079,6 @@ __device__ __forceinline__ void normal_triple(uint64_t c0, uint64_t g, double &r
   const uint64_t ja = i0 - (odd ? 1 : 0);
   double ea, oa, eb, ob;
   normal_pair(c0, ja, ea, oa);
-#if MPHIP_SCHED_FENCES
-  __builtin_amdgcn_sched_barrier(0);   // one pair after the other: interleaving them doubles the temporaries
-#endif
   normal_pair(c0, ja + 2, eb, ob);
   r0 = odd ? oa : ea;
   r1 = odd ? eb : oa;
@@ -1556,9 +1553,6 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
     sd[q] = (var > 0 ? sqrtf(var) : 0.f);
   }
 
-#if MPHIP_SCHED_FENCES
-  __builtin_amdgcn_sched_barrier(0);   // the 48 corner values are dead from here on
-#endif
   const double r = 1 - fdiv(2 * fabs(P.dt), ctl.dt_met);
   const double r2 = fsqrt(1 - r * r);
   double rs0, rs1, rs2;

@@ -290,15 +290,8 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       else
         advect(ctl, M, A, P, wc);
     }
-#if MPHIP_SCHED_FENCES
-#define MODULE_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define MODULE_FENCE()
-#endif
-    MODULE_FENCE();
     if (mask & MPHIP_MOD_DIFF_TURB)
       diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr);
-    MODULE_FENCE();
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_DIFF_PBL)) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
       diff_pbl(M, A, P, up, vp, wp, S.ctr_pbl, g);
@@ -313,10 +306,8 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       a.vp[i] = vp;
       a.wp[i] = wp;
     }
-    MODULE_FENCE();
     if (mask & MPHIP_MOD_CONVECTION)
       convection(ctl, M, A, P, S.ctr_conv, g, early ? &pre.conv : nullptr);
-    MODULE_FENCE();
     if (mask & MPHIP_MOD_SEDI)
       sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))
@@ -646,8 +637,24 @@ struct PermArgs {
   int n8, n4;
 };
 
-__global__ void perm_gather_kernel(PermArgs g, const int *__restrict__ perm, long long n) {
-  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+// Both kernels walk contiguous runs per workgroup, and workgroup b takes run (b % 8) * (n / 8) + b / 8:
+// the dispatcher places workgroup b on XCD b % 8, so each XCD (own L2) works on one contiguous eighth of
+// the index range and the 8-byte elements of a cache line are consumed through one L2 instead of eight.
+struct PermGeom {
+  int nblocks;            // multiple of 8
+  long long per_block;    // multiple of 256
+};
+
+__device__ __forceinline__ void perm_range(const PermGeom &pg, long long n, long long &first, long long &last) {
+  const int lb = (int) (blockIdx.x % 8) * (pg.nblocks / 8) + (int) (blockIdx.x / 8);
+  first = (long long) lb * pg.per_block;
+  last = first + pg.per_block < n ? first + pg.per_block : n;
+}
+
+__global__ void perm_gather_kernel(PermArgs g, const int *__restrict__ perm, long long n, PermGeom pg) {
+  long long first, last;
+  perm_range(pg, n, first, last);
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
     const int src = perm[i];
     for (int a = 0; a < g.n8; a++)
       g.out8[a][i] = g.in8[a][src];
@@ -658,8 +665,10 @@ __global__ void perm_gather_kernel(PermArgs g, const int *__restrict__ perm, lon
   }
 }
 
-__global__ void perm_scatter_kernel(PermArgs g, const int *__restrict__ ext, long long n) {
-  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+__global__ void perm_scatter_kernel(PermArgs g, const int *__restrict__ ext, long long n, PermGeom pg) {
+  long long first, last;
+  perm_range(pg, n, first, last);
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
     const int dst = ext[i];
     for (int a = 0; a < g.n8; a++)
       g.out8[a][dst] = g.in8[a][i];
