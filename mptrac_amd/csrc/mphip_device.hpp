@@ -134,13 +134,9 @@ __device__ __forceinline__ Axes load_axes(const DevMet &M, double *smem) {
 #ifndef MPHIP_EXACT_DIV
 #define MPHIP_EXACT_DIV 0
 #endif
-// 1: scheduling fences that keep independent computations from being interleaved (fewer live registers)
 // 1: keep the last wind corners of a particle and reload only where its grid cell changed
 #ifndef MPHIP_WIND_CACHE
 #define MPHIP_WIND_CACHE 1
-#endif
-#ifndef MPHIP_SCHED_FENCES
-#define MPHIP_SCHED_FENCES 0
 #endif
 
 __device__ __forceinline__ double div_const(double x, double y, double inv_y) {
