@@ -138,3 +138,51 @@ def test_oracle_reproduces_committed_vectors(case):
     got = make_golden.run_case(case)
     for k in ref.files:
         assert np.array_equal(got[k], ref[k], equal_nan=got[k].dtype.kind == "f"), (case, k)
+
+
+def test_oracle_isosurface_modes_conserve_their_quantity():
+    """module_isosurf (mptrac.c:4956-5005): after every step the particle is back on its surface --
+    pressure (mode 1), density p / T (mode 2), potential temperature (mode 3)."""
+    import ctypes as C
+    from mptrac_amd.synth import FIELDS_3D
+    for case, mode in (("isosurf_p", 1), ("isosurf_rho", 2), ("isosurf_theta", 3)):
+        ctl, clim, m0, m1, atm = cases.make_case(case, n=400)
+        ctl["sort_dt"] = -999.0      # (module_sort leaves cache->iso_var with the slot, not the particle)
+        o = B.Oracle(ctl, clim, m0, m1, atm)
+        o.timesteps_init()
+        p0 = o.p.copy()
+        for t in cases.step_times(o.ctl)[:6]:
+            o.run_timestep(t)
+        if mode == 1:
+            assert np.array_equal(o.p, p0)
+            continue
+        v = C.c_double()
+        for ip in range(0, o.n, 7):
+            o.lib.orc_intpol_met_time_3d(C.byref(o.met[0]), C.byref(o.met[1]), FIELDS_3D.index("t"), o.time[ip], o.p[ip],
+                                         o.lon[ip], o.lat[ip], C.byref(v))
+            now = o.p[ip] / v.value if mode == 2 else o.lib.orc_theta(o.p[ip], v.value)
+            # the temperature used to restore p was taken at the pressure before the restore: first order only
+            assert abs(now - o.iso_var[ip]) <= 5e-2 * abs(o.iso_var[ip]), (case, ip, now, o.iso_var[ip])
+
+
+def test_oracle_boundary_conditions_only_touch_the_region():
+    """module_bound_cond (mptrac.c:3789-3881) as a single call: mass / vmr with trend and age of air inside
+    the latitude-pressure window and surface layer, everything else untouched."""
+    ctl, clim, m0, m1, atm = cases.make_case("bound", n=3000)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    o.module("timesteps", 180.0)
+    q0 = o.q.copy()
+    o.module("bound_cond")
+    names = cases.CASE_QUANTITIES["bound"]
+    im, iv, ia = names.index("m"), names.index("vmr"), names.index("aoa")
+    hit = o.q[ia] != q0[ia]                      # aoa = time marks the particles that were set (time = 0 -> all 0!)
+    inside = (o.lat >= -60) & (o.lat <= 60) & (o.p <= 1100) & (o.p >= 300)
+    changed = o.q[im] != q0[im]
+    assert changed.any() and not changed[~inside].any()
+    assert np.all(o.q[im][changed] == 2.5 + 1e-4 * o.time[changed])
+    assert np.all(o.q[iv][changed] == 3e-9 + 1e-13 * o.time[changed])
+    assert not hit[~changed].any()
+    for k in range(len(names)):
+        if k not in (im, iv, ia):
+            assert np.array_equal(o.q[k], q0[k])
