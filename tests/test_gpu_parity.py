@@ -615,3 +615,27 @@ def test_sort_scales_to_1e8_keys():
 def load_clim():
     from mptrac_amd.clim import load_clim_tropo
     return load_clim_tropo()
+
+
+@pytest.mark.parametrize("lon0,lat_reverse", [(-180.0, False), (0.0, True)])
+def test_wind_cache_with_cell_changes_in_every_stage(lon0, lat_reverse):
+    """Coarse grid and a long time step: most particles change their grid cell between Runge-Kutta stages
+    (and before module_diff_meso), so the predicated corner reloads run in nearly every lane; also on a
+    0 ... 360 longitude axis with a north-to-south latitude axis (ERA5 order)."""
+    from mptrac_amd.ctl import ctl_from_quantities
+    names = ("m", "rp", "rhop")
+    ctl = dict(cases.BASE, dt_mod=1800.0, t_stop=5 * 1800.0, dt_met=10800.0, diffusion=1, turb_dz_trop=0.1,
+               conv_cape=0.0, **ctl_from_quantities(names))
+    m0 = synthetic_met("tiny", 0.0, 1.0, fields=cases.PRESSURE_LEVEL_FIELDS, lon0=lon0, lat_reverse=lat_reverse)
+    m1 = synthetic_met("tiny", 10800.0, 1.3, fields=cases.PRESSURE_LEVEL_FIELDS, lon0=lon0, lat_reverse=lat_reverse)
+    atm = synthetic_particles(20000, quantities=names, lon=(lon0, lon0 + 360.0))
+    clim = cases.load_clim_tropo()
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    for t in cases.step_times(o.ctl):
+        o.run_timestep(t)
+        s.run_timestep(t)
+    _compare(o, s)
+    s.close()
