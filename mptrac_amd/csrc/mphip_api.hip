@@ -81,7 +81,7 @@ struct mphip_ctx {
   bool ext_identity = true;
   int locality_interval = 20;         // re-sort every this many steps (0 = keep the caller's order)
   int locality_tile = 8;              // horizontal tile edge of the locality key (columns)
-  int step_blocks = 4096;             // upper bound of the step kernel's grid
+  int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;
   bool force_generic = false;
   int steps_since_resort = 1 << 30;
