@@ -1,0 +1,86 @@
+"""Randomised module combinations against the oracle (GPU): every seed draws a control set (integrator,
+stochastic modules, convection, sedimentation, sort, mixing, decay, wet / dry deposition, boundary conditions,
+isosurface mode, meteo quantities, direction, grid orientation) and runs 12 steps through
+mphip_run_timestep.  Catches interactions between modules and between the kernel instantiations that the
+named cases do not cover."""
+import numpy as np
+import pytest
+
+import cases
+from mptrac_amd import hip
+from mptrac_amd.ctl import ctl_from_quantities
+from mptrac_amd.synth import FIELDS_METEO_ONLY, synthetic_met, synthetic_particles
+from oracle import binding as B
+
+pytestmark = pytest.mark.gpu
+
+
+def draw(seed):
+    r = np.random.default_rng(seed)
+    pick = lambda *a: a[int(r.integers(len(a)))]
+    names = ["m", "vmr", "rp", "rhop", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry", "aoa"]
+    ctl = dict(advect=pick(1, 2, 4, 4), dt_mod=pick(180.0, 600.0), dt_met=7200.0, rng_type=1, direction=pick(1, 1, -1))
+    if r.random() < 0.7:
+        ctl.update(diffusion=1, turb_dz_trop=pick(0.0, 0.1), turb_dx_trop=pick(0.0, 50.0), turb_dz_pbl=pick(0.0, 0.5),
+                   turb_mesox=pick(0.0, 0.16), turb_mesoz=pick(0.0, 0.16), turb_pbl_trans=pick(0.0, 0.2))
+        if r.random() < 0.25:
+            ctl.update(turb_pbl_scheme=1, turb_mesoz=0.0)
+    if r.random() < 0.6:
+        ctl.update(conv_cape=pick(0.0, 150.0), conv_cin=pick(-999.0, 5.0), conv_mix_pbl=pick(0, 1), conv_pbl_trans=pick(0.0, 0.1),
+                   conv_dt=pick(-999.0, 360.0))
+    if r.random() < 0.4:
+        ctl.update(sort_dt=pick(360.0, 1200.0))
+    if r.random() < 0.4:
+        ctl.update(mixing_trop=1e-3, mixing_strat=1e-6, mixing_dt=pick(360.0, 1200.0), mixing_nx=36, mixing_ny=18, mixing_nz=20)
+    if r.random() < 0.5:
+        ctl.update(tdec_trop=259200.0, tdec_strat=432000.0)
+    if r.random() < 0.4:
+        ctl.update(wet_depo_ic_a=1e-4, wet_depo_ic_b=0.8, wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6)
+    if r.random() < 0.4:
+        ctl.update(dry_depo_vdep=0.15)
+    if r.random() < 0.3:
+        ctl.update(bound_lat0=-60.0, bound_lat1=60.0, bound_p0=1100.0, bound_p1=200.0, bound_mass=2.0, bound_vmr=1e-9,
+                   bound_dps=pick(-999.0, 300.0), bound_pbl=pick(0, 1))
+    if r.random() < 0.25:
+        ctl.update(isosurf=pick(1, 2, 3))
+    sedi = r.random() < 0.6
+    if r.random() < 0.4:
+        extra = list(r.choice(["t", "u", "ps", "pv", "theta", "rh", "zg", "sst", "pbl", "cape", "lwc", "h2o", "o3c", "vh"],
+                              size=4, replace=False))
+        names += extra
+        ctl.update(met_dt_out=pick(0.1, 1200.0))
+    ctl.update(ctl_from_quantities(names))
+    if not sedi:
+        ctl["qnt_rp"] = ctl["qnt_rhop"] = -1
+    n_steps = 12
+    ctl["t_stop"] = ctl["direction"] * n_steps * ctl["dt_mod"]
+    geom = dict(grid=pick("tiny", "C1"), lon0=pick(-180.0, 0.0), lat_reverse=bool(pick(0, 1)))
+    return ctl, tuple(names), geom
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_module_combination(seed):
+    ctl, names, geom = draw(seed)
+    fields = cases.PRESSURE_LEVEL_FIELDS + FIELDS_METEO_ONLY
+    t0, t1 = (0.0, 7200.0) if ctl["direction"] == 1 else (-7200.0, 0.0)
+    m0 = synthetic_met(geom["grid"], t0, 1.0, fields=fields, lon0=geom["lon0"], lat_reverse=geom["lat_reverse"])
+    m1 = synthetic_met(geom["grid"], t1, 1.25, fields=fields, lon0=geom["lon0"], lat_reverse=geom["lat_reverse"])
+    atm = synthetic_particles(6000, seed=100 + seed, quantities=names, lon=(geom["lon0"], geom["lon0"] + 360.0))
+    if ctl.get("turb_pbl_scheme", 0):
+        atm["p"][::2] = 1013.25 * np.exp(-(0.02 + 0.9 * (atm["lon"][::2] - geom["lon0"]) / 360.0) / 7.0)
+    clim = cases.load_clim_tropo()
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(atm["time"].min(), atm["time"].max())
+    for t in cases.step_times(o.ctl):
+        o.run_timestep(t)
+        s.run_timestep(t)
+    g, r = s.state(), o.state()
+    assert np.array_equal(g["time"], r["time"])
+    for k in ("lon", "lat", "p"):
+        assert cases.rel_err(g[k], r[k]) <= 1e-10, (seed, k, cases.rel_err(g[k], r[k]), ctl)
+    assert cases.rel_err(g["q"], r["q"]) <= 1e-10, (seed, cases.rel_err(g["q"], r["q"]), ctl)
+    assert cases.rel_err(g["uvwp"], r["uvwp"]) <= 1e-6
+    assert s.get_cache()["rng_ctr"] == o.cache.rng_ctr
+    s.close()
