@@ -110,7 +110,7 @@ def cpu_baseline(workload, ctl, clim, met0, met1, atm, n_sample, n_steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=15)
+    ap.add_argument("--steps", type=int, default=20)   # one meteo interval of the survey's control set (T_STOP 3600, DT_MOD 180)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
