@@ -51,6 +51,10 @@ WORKLOADS = {
                                wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6),
            ("m", "rp", "rhop"), ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "lwc",
                                  "rwc", "iwc", "swc")),
+    # C3 with model-level (zeta) advection (ADVECT_VERT_COORD 1), otherwise as C3
+    "C3z": ("C3", 10 ** 7, dict(advect=4, advect_vert_coord=1, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1),
+            ("m", "rp", "rhop", "zeta"),
+            ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel", "pl", "ul", "vl", "zetal", "zeta_dotl")),
     "C2": ("C2", 10 ** 6, dict(advect=4, dt_mod=180.0, diffusion=1, turb_mesox=0.0, turb_mesoz=0.0, rng_type=1),
            ("m",), ("u", "v", "w", "ps", "pbl")),
     "C1": ("C1", 10 ** 4, dict(advect=4, dt_mod=180.0, rng_type=1), ("m",), ("u", "v", "w", "ps")),
@@ -64,6 +68,7 @@ def algorithmic_bytes_per_pstep(workload, met, np_local):
     state = {"C3": 64 + 24 + 16,   # time,lon,lat,p R+W; uvwp R+W; rp,rhop R
              "C3m": 64 + 24 + 16,  # (the step kernel's bytes; module_meteo is a separate kernel)
              "C5": 64 + 24 + 16 + 16,
+             "C3z": 64 + 24 + 16 + 16,
              "C2": 64, "C1": 64}[workload]
     wind = met.nx * met.ny * met.np * 32            # {u,v,w,t} x 2 snapshots, float
     sfc = met.nx * met.ny * 64                      # 8 surface fields x 2 snapshots
@@ -85,6 +90,8 @@ def build_inputs(workload, rank, world, steps_total):
     n_total = n_per_gpu * world
     # every rank generates only its own index range of the global seeded set
     atm = synthetic_particles(n_per_gpu, seed=12345, quantities=quantities, first=rank * n_per_gpu)
+    if "zeta" in quantities:      # a vertical coordinate inside the range of the synthetic zetal field
+        atm["q"][list(quantities).index("zeta")] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
     return ctl, load_clim_tropo(), met0, met1, atm, n_per_gpu, n_total
 
 

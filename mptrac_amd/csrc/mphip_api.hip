@@ -50,7 +50,9 @@ struct mphip_ctx {
   int flip = 0;                       // logical slot s lives in slot[s ^ flip]
   int nx = 0, ny = 0, npl = 0, coord_type = 0;   // npl: pressure levels (met_t::np)
   int nml = 0;                                    // model levels (met_t::npl), 0 = none uploaded
-  float *d_mlw = nullptr;
+  float *d_mlw = nullptr, *d_zl2 = nullptr, *d_pl2 = nullptr;
+  int *d_ml_mono = nullptr;
+  bool ml_monotonic = false;
   std::vector<double> h_lon, h_lat, h_p;
   double *d_axes = nullptr;           // axes blob (layout: DevMet::axes)
   int lut_base = 0, lut_size = 0;
@@ -184,6 +186,9 @@ DevMet dev_met(const mphip_ctx *c) {
   M.sfd = c->d_sfd;
   M.h2o = c->d_h2o;
   M.mlw = c->d_mlw;
+  M.zl2 = c->d_zl2;
+  M.pl2 = c->d_pl2;
+  M.ml_monotonic = c->ml_monotonic ? 1 : 0;
   for (int t = 0; t < 2; t++) {
     M.zl[t] = c->slot[t ^ c->flip].f3[MPHIP_ZETAL];
     M.pll[t] = c->slot[t ^ c->flip].f3[MPHIP_PL];
@@ -322,8 +327,15 @@ int ensure_packed(mphip_ctx *ctx) {
   }
   const size_t ncell_ml = (size_t) ctx->nx * ctx->ny * ctx->nml;
   any_ml = any_ml && ncell_ml > 0;
-  if (any_ml && !ctx->d_mlw && dev_alloc(ctx, &ctx->d_mlw, 6 * ncell_ml))
+  if (any_ml && !ctx->d_mlw
+      && (dev_alloc(ctx, &ctx->d_mlw, 6 * ncell_ml) || dev_alloc(ctx, &ctx->d_zl2, 2 * ncell_ml)
+          || dev_alloc(ctx, &ctx->d_pl2, 2 * ncell_ml) || dev_alloc(ctx, &ctx->d_ml_mono, 1)))
     return 1;
+  const bool ml_heights = any_ml && s0.has3[MPHIP_ZETAL] && s1.has3[MPHIP_ZETAL] && s0.has3[MPHIP_PL] && s1.has3[MPHIP_PL];
+  if (ml_heights) {
+    const int one = 1;
+    HIPCHK(hipMemcpyAsync(ctx->d_ml_mono, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  }
   if (!ctx->d_wind && (dev_alloc(ctx, &ctx->d_wind, 6 * ncell) || dev_alloc(ctx, &ctx->d_temp, 2 * ncell)))
     return 1;
   if (!ctx->d_sfa && (dev_alloc(ctx, &ctx->d_sfa, ncol) || dev_alloc(ctx, &ctx->d_sfb, 2 * ncol)
@@ -348,11 +360,22 @@ int ensure_packed(mphip_ctx *ctx) {
   a.sfd = any_pbl ? ctx->d_sfd : nullptr;
   a.h2o = any_pbl ? ctx->d_h2o : nullptr;
   a.mlw = any_ml ? ctx->d_mlw : nullptr;
+  a.zl2 = ml_heights ? ctx->d_zl2 : nullptr;
+  a.pl2 = ml_heights ? ctx->d_pl2 : nullptr;
+  a.ml_mono = ctx->d_ml_mono;
+  a.nml = ctx->nml;
   a.ncell = ncell;
   a.ncol = ncol;
   a.ncell_ml = ncell_ml;
   hipLaunchKernelGGL(pack_kernel, dim3(grid_for((long long) ncell)), dim3(256), 0, ctx->stream, a);
   HIPCHK(hipGetLastError());
+  ctx->ml_monotonic = false;
+  if (ml_heights) {
+    int mono = 0;
+    HIPCHK(hipMemcpyAsync(&mono, ctx->d_ml_mono, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->ml_monotonic = mono != 0;
+  }
   ctx->packed_dirty = false;
   return 0;
 }
@@ -501,8 +524,10 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     HIPCHK(hipEventRecord(e0, ctx->stream));
   }
   const bool ml_ = (ctx->ctl.advect_vert_coord == 1 || ctx->ctl.advect_vert_coord == 3);
-  const bool rare = ml_ || (mask & kRareModules);
-  const unsigned sel = ctx->force_generic ? kMaskGeneric : ((ctx->ctl.advect == 4 && !rare) ? mask : kMaskGeneric);
+  // model levels: the fast path needs monotonic height columns and none of the rarely used modules
+  const bool ml_fast = ml_ && ctx->ml_monotonic && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
+  const bool rare = (ml_ && !ml_fast) || (mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u));
+  const unsigned sel = (ctx->ctl.advect == 4 && !rare && !ml_ && !ctx->force_generic) ? mask : kMaskGeneric;
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
   case M:                                                                                             \
@@ -517,6 +542,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   default:
     if (rare || ctx->force_generic)
       hipLaunchKernelGGL(step_kernel<kMaskGeneric>, dim3(nb), dim3(256), lds, ctx->stream, S);
+    else if (ml_fast)
+      hipLaunchKernelGGL(step_kernel<kMaskGenericML>, dim3(nb), dim3(256), lds, ctx->stream, S);
     else
       hipLaunchKernelGGL(step_kernel<kMaskGenericPL>, dim3(nb), dim3(256), lds, ctx->stream, S);
   }
@@ -1017,7 +1044,9 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     ctx->npl = met->np;
     ctx->nml = nml;
     dev_free(ctx->d_mlw);
-    ctx->d_mlw = nullptr;
+    dev_free(ctx->d_zl2);
+    dev_free(ctx->d_pl2);
+    ctx->d_mlw = ctx->d_zl2 = ctx->d_pl2 = nullptr;
     dev_free(ctx->d_wind);
     dev_free(ctx->d_temp);
     dev_free(ctx->d_cloud);

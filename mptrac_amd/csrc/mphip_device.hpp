@@ -55,6 +55,8 @@ struct DevMet {
   const float *mlw;      // [cellL][6] {ul,vl,zeta_dot}0 {..}1 on model levels (optional)
   const float *zl[2];    // zetal of met0 / met1, [nx][ny][npl]
   const float *pll[2];   // pl of met0 / met1
+  const float *zl2, *pl2;   // [cellL][2] {zetal0,zetal1}, {pl0,pl1}: both snapshots of a level in one load (optional)
+  int ml_monotonic;      // every zetal / pl column of both snapshots is strictly monotonic (checked when packing)
   int npl;
   // axes blob in global memory, copied to LDS by every workgroup:
   //   double lon[nx], lat[ny], p[np], 1/dlon[nx], 1/dlat[ny], 1/dp[np]; int16 p_lut[lut_size]
@@ -1279,6 +1281,247 @@ __device__ __forceinline__ double pressure_from_zeta(const DevMet &M, const Axes
   Stencil4 s;
   stencil_4d(M, A, M.zl[0], M.zl[1], time, zeta, lon, lat, s);
   return ml_field(M, M.pll[0], M.pll[1], s);
+}
+
+// ---- model-level interpolation, fast path -----------------------------------
+// Same indices and the same arithmetic as stencil_4d / ml_field above, for height fields whose columns
+// are strictly monotonic (checked on the device when the grids are packed; otherwise the kernels run the
+// path above, which reproduces the reference's bisection read by read).  For a monotonic column
+// locate_irr_float returns the unique bracketing index whatever its first guess, so the search may start
+// from the previous result; the packed pairs {h0,h1} make one 16-byte gather return levels k and k + 1 of
+// both snapshots, where the reference-shaped code issues four dword gathers.
+
+// levels k, k + 1 of both snapshots of column `col`: {h0[k], h1[k], h0[k+1], h1[k+1]}
+__device__ __forceinline__ f32x4u load_h4(const float *__restrict__ h2, size_t col, int k) {
+  return *(const f32x4u *) (h2 + 2 * (col + (size_t) k));
+}
+
+// -1: the index must decrease, +1: increase, 0: level pair (lo, hi) brackets x (bisection semantics of
+// locate_irr_float: ascending lo <= x < hi, descending lo > x >= hi)
+__device__ __forceinline__ int bracket_dir(float lo, float hi, double x) {
+  if (lo < hi)
+    return x < lo ? -1 : (x >= hi ? 1 : 0);
+  return x >= lo ? -1 : (x < hi ? 1 : 0);
+}
+
+// index of snapshot t (0 / 1) in a monotonic column by bisection over the packed pairs
+__device__ __forceinline__ int bisect_pair(const float *__restrict__ h2, size_t col, int n, double x, int t) {
+  int lo = 0, hi = n - 1;
+  const int mid0 = (hi + lo) >> 1;
+  const f32x4u m = load_h4(h2, col, mid0);
+  const bool asc = m[t] < m[2 + t];
+  while (hi > lo + 1) {
+    const int mid = (hi + lo) >> 1;
+    const float v = h2[2 * (col + (size_t) mid) + t];
+    if (asc ? (v > x) : (v <= x))
+      hi = mid;
+    else
+      lo = mid;
+  }
+  return lo;
+}
+
+// indices of both snapshots in column `col`, starting from `guess` (a few neighbouring pairs, then bisection)
+__device__ __forceinline__ void locate_pair(const float *__restrict__ h2, size_t col, int n, double x, int guess,
+                                            int &k0, int &k1) {
+  int k = guess < 0 ? 0 : (guess > n - 2 ? n - 2 : guess);
+  bool f0 = false, f1 = false;
+  k0 = k1 = k;
+#pragma unroll 1
+  for (int it = 0; it < 4 && !(f0 && f1); it++) {
+    const f32x4u v = load_h4(h2, col, k);
+    const int d0 = bracket_dir(v[0], v[2], x), d1 = bracket_dir(v[1], v[3], x);
+    // at the ends of the column the bisection returns 0 / n - 2 for values outside the profile
+    if (!f0 && (d0 == 0 || (d0 < 0 && k == 0) || (d0 > 0 && k == n - 2))) {
+      f0 = true;
+      k0 = k;
+    }
+    if (!f1 && (d1 == 0 || (d1 < 0 && k == 0) || (d1 > 0 && k == n - 2))) {
+      f1 = true;
+      k1 = k;
+    }
+    const int d = !f0 ? d0 : d1;
+    k += (f0 && f1) ? 0 : d;
+  }
+  if (!f0)
+    k0 = bisect_pair(h2, col, n, x, 0);
+  if (!f1)
+    k1 = bisect_pair(h2, col, n, x, 1);
+}
+
+__device__ __forceinline__ double level_pair_value(const Stencil4 &s, const f32x4u c00, const f32x4u c01,
+                                                   const f32x4u c10, const f32x4u c11, int l) {
+  const int e = 2 * l;   // l = 0: level k, l = 1: level k + 1
+  const double v00 = s.wt * (double) (c00[e + 1] - c00[e]) + (double) c00[e];
+  const double v01 = s.wt * (double) (c01[e + 1] - c01[e]) + (double) c01[e];
+  const double v10 = s.wt * (double) (c10[e + 1] - c10[e]) + (double) c10[e];
+  const double v11 = s.wt * (double) (c11[e + 1] - c11[e]) + (double) c11[e];
+  const double a = s.wy * (v01 - v00) + v00;
+  const double b = s.wy * (v11 - v10) + v10;
+  return s.wx * (b - a) + a;
+}
+
+// stencil_4d on a packed height field; `hint` is any earlier vertical index (e.g. of the previous stage)
+__device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, const float *__restrict__ h2, double ts,
+                                                double height, double lon, double lat, int hint, Stencil4 &s) {
+  double lon2, lat2;
+  check_horizontal(M, A, lon, lat, lon2, lat2);
+  const AxisHit hy = hit_lat(M, A, lat2);
+  s.ix = locate_lon(M, A, lon2);
+  s.iy = hy.i;
+  const int n = M.npl;
+  const size_t c00 = col_ml(M, s.ix, s.iy), c10 = col_ml(M, s.ix + 1, s.iy), c01 = col_ml(M, s.ix, s.iy + 1),
+               c11 = col_ml(M, s.ix + 1, s.iy + 1);
+  int a0, a1, b0, b1, c0, c1, d0, d1;   // locate_vert order: (ix,iy) (ix+1,iy) (ix,iy+1) (ix+1,iy+1)
+  locate_pair(h2, c00, n, height, hint, a0, a1);
+  locate_pair(h2, c10, n, height, a0, b0, b1);
+  locate_pair(h2, c01, n, height, b0, c0, c1);
+  locate_pair(h2, c11, n, height, c0, d0, d1);
+  const int kmin = min(min(min(a0, a1), min(b0, b1)), min(min(c0, c1), min(d0, d1)));
+  const int kmax = max(max(max(a0, a1), max(b0, b1)), max(max(c0, c1), max(d0, d1)));
+  s.iz = kmin;
+  s.wt = div_const(ts - M.time0, M.time1 - M.time0, M.inv_dtime);
+  s.wx = div_const(lon2 - A.lon[s.ix], A.lon[s.ix + 1] - A.lon[s.ix], A.inv_lon[s.ix]);
+  s.wy = div_const(lat2 - hy.x0, hy.x1 - hy.x0, hy.inv);
+  f32x4u q00 = load_h4(h2, c00, s.iz), q01 = load_h4(h2, c01, s.iz), q10 = load_h4(h2, c10, s.iz),
+         q11 = load_h4(h2, c11, s.iz);
+  double bot = level_pair_value(s, q00, q01, q10, q11, 0);
+  double top = level_pair_value(s, q00, q01, q10, q11, 1);
+  const float g0 = h2[0], g1 = h2[2];   // heights0[0][0][0], heights0[0][0][1]
+  while (((g0 > g1) && ((bot <= height) || (top > height)) && (bot >= height) && (s.iz < kmax))
+         || ((g0 < g1) && ((bot >= height) || (top < height)) && (bot <= height) && (s.iz < kmax))) {
+    s.iz++;
+    bot = top;
+    q00 = load_h4(h2, c00, s.iz);
+    q01 = load_h4(h2, c01, s.iz);
+    q10 = load_h4(h2, c10, s.iz);
+    q11 = load_h4(h2, c11, s.iz);
+    top = level_pair_value(s, q00, q01, q10, q11, 1);
+  }
+  s.wz = (height - bot) / (top - bot);
+}
+
+// ml_field on a packed pair array
+__device__ __forceinline__ double ml_field_fast(const DevMet &M, const float *__restrict__ a2, const Stencil4 &s) {
+  double v[2][2][2];
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++) {
+      const f32x4u q = load_h4(a2, col_ml(M, s.ix + di, s.iy + dj), s.iz);
+#pragma unroll
+      for (int l = 0; l < 2; l++)
+        v[di][dj][l] = s.wt * (double) (q[2 * l + 1] - q[2 * l]) + (double) q[2 * l];
+    }
+  return ml_combine(s, v[0][0][0], v[1][0][0], v[0][1][0], v[1][1][0], v[0][0][1], v[1][0][1], v[0][1][1],
+                    v[1][1][1]);
+}
+
+// {ul,vl,zeta_dot} corners with the cell they belong to (as WindCache)
+struct MlCache {
+  MlCorners c;
+  int ix, iy, iz;
+};
+
+__device__ __forceinline__ void ml_cache_reset(MlCache &w) {
+  w.ix = w.iy = w.iz = -1;
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        w.c.r[di][dj][k] = f32x4u{ 0.f, 0.f, 0.f, 0.f };
+}
+
+__device__ __forceinline__ void load_ml_cached(const DevMet &M, const Stencil4 &s, MlCache &w) {
+  if (s.ix != w.ix || s.iy != w.iy || s.iz != w.iz) {
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+      for (int dj = 0; dj < 2; dj++) {
+        const float *q = M.mlw + 6 * (col_ml(M, s.ix + di, s.iy + dj) + (size_t) s.iz);
+        asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                     "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %3, off offset:32"
+                     : "+v"(w.c.r[di][dj][0]), "+v"(w.c.r[di][dj][1]), "+v"(w.c.r[di][dj][2])
+                     : "v"(q)
+                     : "memory");
+      }
+    w.ix = s.ix;
+    w.iy = s.iy;
+    w.iz = s.iz;
+  }
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(w.c.r[0][0][0]), "+v"(w.c.r[0][0][1]), "+v"(w.c.r[0][0][2]), "+v"(w.c.r[0][1][0]),
+                 "+v"(w.c.r[0][1][1]), "+v"(w.c.r[0][1][2]), "+v"(w.c.r[1][0][0]), "+v"(w.c.r[1][0][1]),
+                 "+v"(w.c.r[1][0][2]), "+v"(w.c.r[1][1][0]), "+v"(w.c.r[1][1][1]), "+v"(w.c.r[1][1][2])
+               :
+               : "memory");
+}
+
+// module_advect, zeta / eta branch, on the packed height fields (same arithmetic as advect_ml_n)
+template <int ADVECT>
+__device__ __forceinline__ void advect_ml_fast_n(const DevMet &M, const Axes &A, Particle &P, double &zeta) {
+  const int ct = M.coord_type;
+  const double dt = P.dt;
+  Stencil4 s;
+  stencil_4d_fast(M, A, M.pl2, P.time, P.p, P.lon, P.lat, M.npl / 2, s);
+  zeta = ml_field_fast(M, M.zl2, s);
+  double u = 0, v = 0, wdot = 0, um = 0, vm = 0, wdotm = 0, x0 = 0, x1 = 0, x2 = 0;
+  MlCache mc;
+  ml_cache_reset(mc);
+#pragma unroll
+  for (int i = 0; i < ADVECT; i++) {
+    double dts;
+    if (i == 0) {
+      dts = 0.0;
+      x0 = P.lon;
+      x1 = P.lat;
+      x2 = zeta;
+    } else {
+      dts = (i == 3 ? 1.0 : 0.5) * dt;
+      x0 = P.lon + dx2coord(ct, dts * u, P.lat);
+      x1 = P.lat + dy2coord(ct, dts * v);
+      x2 = zeta + dts * wdot;
+    }
+    stencil_4d_fast(M, A, M.zl2, P.time + dts, x2, x0, x1, s.iz, s);
+    load_ml_cached(M, s, mc);
+    u = ml_packed(mc.c, s, 0);
+    v = ml_packed(mc.c, s, 1);
+    wdot = ml_packed(mc.c, s, 2);
+    double k = 1.0;
+    if (ADVECT == 2)
+      k = (i == 0 ? 0.0 : 1.0);
+    else if (ADVECT == 4)
+      k = (i == 0 || i == 3 ? 1.0 / 6.0 : 2.0 / 6.0);
+    um += k * u;
+    vm += k * v;
+    wdotm += k * wdot;
+  }
+  P.time += dt;
+  P.lon += dx2coord(ct, dt * um, (ADVECT == 2 ? x1 : P.lat));
+  P.lat += dy2coord(ct, dt * vm);
+  zeta += dt * wdotm;
+  stencil_4d_fast(M, A, M.zl2, P.time, zeta, P.lon, P.lat, s.iz, s);
+  P.p = ml_field_fast(M, M.pl2, s);
+}
+
+__device__ __forceinline__ void advect_ml_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                               double &zeta) {
+  if (ctl.advect == 4)
+    advect_ml_fast_n<4>(M, A, P, zeta);
+  else if (ctl.advect == 2)
+    advect_ml_fast_n<2>(M, A, P, zeta);
+  else
+    advect_ml_fast_n<1>(M, A, P, zeta);
+}
+
+__device__ __forceinline__ double pressure_from_zeta_fast(const DevMet &M, const Axes &A, double time, double zeta,
+                                                          double lon, double lat) {
+  Stencil4 s;
+  stencil_4d_fast(M, A, M.zl2, time, zeta, lon, lat, M.npl / 2, s);
+  return ml_field_fast(M, M.pl2, s);
 }
 
 // the Kz blend evaluated at a displaced pressure, mptrac.c:4669-4688

@@ -33,6 +33,11 @@ constexpr unsigned kMaskGeneric = 0xffffffffu;     // every module, module set t
 // advection and its init, module_diff_pbl, module_isosurf, module_bound_cond): small enough to keep
 // the wind-corner cache and three waves per SIMD
 constexpr unsigned kMaskGenericPL = 0xfffffffeu;
+// as kMaskGenericPL, with model-level (zeta / eta) advection on the packed height fields instead of the
+// pressure-level integrator (needs monotonic height columns: DevMet::ml_monotonic)
+constexpr unsigned kMaskGenericML = 0xfffffffdu;
+template <unsigned CT>
+constexpr bool kRuntimeMask = (CT == kMaskGeneric || CT == kMaskGenericPL || CT == kMaskGenericML);
 constexpr unsigned kRareModules = MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT | MPHIP_MOD_ISOSURF | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
 constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a later launch reads it)
@@ -201,7 +206,7 @@ struct RngEarly {
 template <unsigned CT>
 __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(const StepParams S) {
   extern __shared__ double s_axes[];
-  const unsigned mask = (CT == kMaskGeneric || CT == kMaskGenericPL) ? S.mask : CT;
+  const unsigned mask = kRuntimeMask<CT> ? S.mask : CT;
   const DevMet &M = S.met;
   const DevAtm &a = S.atm;
   const mphip_ctl_t &ctl = S.ctl;
@@ -251,6 +256,10 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
         a.p[i] = pressure_from_zeta(M, A, P.time, a.q[ctl.qnt_zeta][i], P.lon, P.lat);
       continue;
     }
+    if (CT == kMaskGenericML && (mask & MPHIP_MOD_ADVECT_INIT)) {
+      a.p[i] = pressure_from_zeta_fast(M, A, P.time, a.q[ctl.qnt_zeta][i], P.lon, P.lat);
+      continue;
+    }
     if (mask & MPHIP_MOD_TIMESTEPS) {
       P.dt = timestep_of(ctl, M, A, P.time, P.lon, P.lat, S.t);
       if (mask & kStoreDt)
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) a.ext[i] : i));
 
     // specialised instantiations = RK4 on pressure levels (launch_step): 4 stages, all hooks run
-    constexpr bool early = MPHIP_RNG_EARLY && CT != kMaskGeneric && CT != kMaskGenericPL && (CT & MPHIP_MOD_ADVECT);
+    constexpr bool early = MPHIP_RNG_EARLY && !kRuntimeMask<CT> && (CT & MPHIP_MOD_ADVECT);
     RngEarly pre;
     pre.mask = mask;
     pre.ctr_turb = S.ctr_turb;
@@ -284,6 +293,11 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
         const int qnt = ctl.advect_vert_coord == 1 ? ctl.qnt_zeta : ctl.qnt_eta;
         double zeta;
         advect_ml(ctl, M, A, P, zeta);
+        a.q[qnt][i] = zeta;
+      } else if (CT == kMaskGenericML) {
+        const int qnt = ctl.advect_vert_coord == 1 ? ctl.qnt_zeta : ctl.qnt_eta;
+        double zeta;
+        advect_ml_fast(ctl, M, A, P, zeta);
         a.q[qnt][i] = zeta;
       } else if (early)
         advect_n<4>(M, A, P, pre, wc);
@@ -357,6 +371,9 @@ struct PackArgs {
   f32x4 *mx2;                      // [7][col] surface pairs of module_meteo (NULL: none)
   float *h2o;                      // {h2o}0 {h2o}1 (NULL: none)
   float *mlw;                      // model-level {ul,vl,zeta_dot} records (NULL: none)
+  float *zl2, *pl2;                // model-level {zetal0,zetal1}, {pl0,pl1} pairs (NULL: none)
+  int *ml_mono;                    // cleared to 0 by a thread that finds a non-monotonic height column
+  int nml;                         // model levels
   size_t ncell, ncol, ncell_ml;
 };
 
@@ -400,6 +417,29 @@ __global__ void pack_kernel(PackArgs a) {
         a.mlw[6 * i + 3 * t + 1] = a.f3[t][MPHIP_VL] ? a.f3[t][MPHIP_VL][i] : 0.f;
         a.mlw[6 * i + 3 * t + 2] = a.f3[t][MPHIP_ZETA_DOTL] ? a.f3[t][MPHIP_ZETA_DOTL][i] : 0.f;
       }
+  if (a.zl2) {
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < a.ncell_ml; i += stride)
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        a.zl2[2 * i + t] = a.f3[t][MPHIP_ZETAL] ? a.f3[t][MPHIP_ZETAL][i] : 0.f;
+        a.pl2[2 * i + t] = a.f3[t][MPHIP_PL] ? a.f3[t][MPHIP_PL][i] : 0.f;
+      }
+    // strict monotonicity of every height column (the fast model-level path relies on it)
+    const size_t ncol_ml = a.ncell_ml / (size_t) a.nml;
+    for (size_t c = blockIdx.x * (size_t) blockDim.x + threadIdx.x; c < 4 * ncol_ml; c += stride) {
+      const int which = (int) (c / ncol_ml);        // 0, 1: zetal of met0 / met1; 2, 3: pl
+      const float *h = a.f3[which & 1][which < 2 ? MPHIP_ZETAL : MPHIP_PL];
+      if (!h)
+        continue;
+      h += (c % ncol_ml) * (size_t) a.nml;
+      const bool asc = h[0] < h[1];
+      bool ok = true;
+      for (int k = 0; k + 1 < a.nml; k++)
+        ok = ok && (asc ? h[k] < h[k + 1] : h[k] > h[k + 1]);
+      if (!ok)
+        *a.ml_mono = 0;
+    }
+  }
   for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < a.ncol; i += stride) {
     f32x4 va;
 #pragma unroll

@@ -639,3 +639,22 @@ def test_wind_cache_with_cell_changes_in_every_stage(lon0, lat_reverse):
         s.run_timestep(t)
     _compare(o, s)
     s.close()
+
+
+def test_model_levels_with_a_non_monotonic_height_column():
+    """The packed model-level path needs strictly monotonic zetal / pl columns; a single column that is not
+    (zeta can fold near the surface in real data) sends the launch to the instantiation that repeats the
+    reference's bisection read by read -- same bits as the oracle either way."""
+    ctl, clim, m0, m1, atm = cases.make_case("zeta_full", n=4000)
+    for m in (m0, m1):
+        z = m.f3["zetal"]
+        z[100:140, 60:120, 3] = z[100:140, 60:120, 1] - 0.5      # a fold in the lowest levels of a patch
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    for t in cases.step_times(o.ctl)[:8]:
+        o.run_timestep(t)
+        s.run_timestep(t)
+    _compare(o, s)
+    s.close()
