@@ -74,6 +74,7 @@ struct mphip_ctx {
   double *d_dt_alt = nullptr;
   uint64_t rng_ctr = 0;
   double *d_iso = nullptr, *d_iso_alt = nullptr;   // cache->iso_var (allocated on first use)
+  int *d_kz = nullptr, *d_kz_alt = nullptr;        // model-level search hint per particle (allocated on first use)
   double *d_iso_ts = nullptr, *d_iso_ps = nullptr; // balloon time series (ISOSURF 4)
   int iso_n = 0;
 
@@ -164,6 +165,7 @@ DevAtm dev_atm(const mphip_ctx *c) {
   a.dt = c->d_dt;
   a.ext = c->ext_identity ? nullptr : c->d_ext;
   a.iso = c->d_iso;
+  a.kz = c->d_kz;
   a.iso_ts = c->d_iso_ts;
   a.iso_ps = c->d_iso_ps;
   a.iso_n = c->iso_n;
@@ -490,6 +492,14 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     return 0;
   if (ensure_packed(ctx) || check_fields(ctx, mask))
     return 1;
+  if ((ctx->ctl.advect_vert_coord == 1 || ctx->ctl.advect_vert_coord == 3) && !ctx->d_kz) {
+    const size_t n = (size_t) std::max<long long>(ctx->np, 1);
+    if (dev_alloc(ctx, &ctx->d_kz, n) || dev_alloc(ctx, &ctx->d_kz_alt, n))
+      return 1;
+    std::vector<int> mid(n, std::max(ctx->nml / 2, 0));     // any level: the hint only shortens the search
+    HIPCHK(hipMemcpyAsync(ctx->d_kz, mid.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   StepParams S;
   S.ctl = ctx->ctl;
   S.met = dev_met(ctx);
@@ -671,6 +681,11 @@ PermArgs perm_args(mphip_ctx *ctx, bool with_cache) {
       g.in4[k] = ctx->d_uvwp[k];
       g.out4[k] = ctx->d_uvwp_alt[k];
     }
+    if (ctx->d_kz) {
+      g.in4[3] = (const float *) ctx->d_kz;
+      g.out4[3] = (float *) ctx->d_kz_alt;
+      g.n4 = 4;
+    }
   }
   return g;
 }
@@ -681,6 +696,7 @@ void perm_swap(mphip_ctx *ctx, bool with_cache) {
   if (with_cache) {
     std::swap(ctx->d_dt, ctx->d_dt_alt);
     std::swap(ctx->d_iso, ctx->d_iso_alt);
+    std::swap(ctx->d_kz, ctx->d_kz_alt);
     for (int k = 0; k < 3; k++)
       std::swap(ctx->d_uvwp[k], ctx->d_uvwp_alt[k]);
   }
@@ -953,6 +969,8 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_dt);
   dev_free(ctx->d_iso);
   dev_free(ctx->d_iso_alt);
+  dev_free(ctx->d_kz);
+  dev_free(ctx->d_kz_alt);
   dev_free(ctx->d_iso_ts);
   dev_free(ctx->d_iso_ps);
   dev_free(ctx->d_dt_alt);
@@ -1164,6 +1182,9 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
     dev_free(ctx->d_iso);
     dev_free(ctx->d_iso_alt);
     ctx->d_iso = ctx->d_iso_alt = nullptr;
+    dev_free(ctx->d_kz);
+    dev_free(ctx->d_kz_alt);
+    ctx->d_kz = ctx->d_kz_alt = nullptr;
     ctx->sorted_buf = -1;
   }
   if (!fresh && restore_external_order(ctx))   // keep cache->uvwp with its slot across a re-upload

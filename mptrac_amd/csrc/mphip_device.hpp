@@ -78,6 +78,7 @@ struct DevAtm {
   double *dt;                    // cache->dt (only used across separate launches)
   const int *ext;                // external slot of each stored particle (NULL = identity)
   double *iso;                   // cache->iso_var (module_isosurf; NULL = not allocated)
+  int *kz;                       // model levels: vertical index of the last step (search hint only; NULL = none)
   const double *iso_ts, *iso_ps; // balloon time series of ISOSURF 4
   int iso_n;
   long long np;                  // particles owned by this context
@@ -1321,9 +1322,10 @@ __device__ __forceinline__ int bisect_pair(const float *__restrict__ h2, size_t 
   return lo;
 }
 
-// indices of both snapshots in column `col`, starting from `guess` (a few neighbouring pairs, then bisection)
+// indices of both snapshots in column `col`, starting from `guess` (a few neighbouring pairs, then
+// bisection); v0 returns the pair record at k0 (the caller usually needs exactly that one again)
 __device__ __forceinline__ void locate_pair(const float *__restrict__ h2, size_t col, int n, double x, int guess,
-                                            int &k0, int &k1) {
+                                            int &k0, int &k1, f32x4u &v0) {
   int k = guess < 0 ? 0 : (guess > n - 2 ? n - 2 : guess);
   bool f0 = false, f1 = false;
   k0 = k1 = k;
@@ -1335,6 +1337,7 @@ __device__ __forceinline__ void locate_pair(const float *__restrict__ h2, size_t
     if (!f0 && (d0 == 0 || (d0 < 0 && k == 0) || (d0 > 0 && k == n - 2))) {
       f0 = true;
       k0 = k;
+      v0 = v;
     }
     if (!f1 && (d1 == 0 || (d1 < 0 && k == 0) || (d1 > 0 && k == n - 2))) {
       f1 = true;
@@ -1343,8 +1346,10 @@ __device__ __forceinline__ void locate_pair(const float *__restrict__ h2, size_t
     const int d = !f0 ? d0 : d1;
     k += (f0 && f1) ? 0 : d;
   }
-  if (!f0)
+  if (!f0) {
     k0 = bisect_pair(h2, col, n, x, 0);
+    v0 = load_h4(h2, col, k0);
+  }
   if (!f1)
     k1 = bisect_pair(h2, col, n, x, 1);
 }
@@ -1373,18 +1378,26 @@ __device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, 
   const size_t c00 = col_ml(M, s.ix, s.iy), c10 = col_ml(M, s.ix + 1, s.iy), c01 = col_ml(M, s.ix, s.iy + 1),
                c11 = col_ml(M, s.ix + 1, s.iy + 1);
   int a0, a1, b0, b1, c0, c1, d0, d1;   // locate_vert order: (ix,iy) (ix+1,iy) (ix,iy+1) (ix+1,iy+1)
-  locate_pair(h2, c00, n, height, hint, a0, a1);
-  locate_pair(h2, c10, n, height, a0, b0, b1);
-  locate_pair(h2, c01, n, height, b0, c0, c1);
-  locate_pair(h2, c11, n, height, c0, d0, d1);
+  f32x4u q00, q10, q01, q11;
+  locate_pair(h2, c00, n, height, hint, a0, a1, q00);
+  locate_pair(h2, c10, n, height, a0, b0, b1, q10);
+  locate_pair(h2, c01, n, height, b0, c0, c1, q01);
+  locate_pair(h2, c11, n, height, c0, d0, d1, q11);
   const int kmin = min(min(min(a0, a1), min(b0, b1)), min(min(c0, c1), min(d0, d1)));
   const int kmax = max(max(max(a0, a1), max(b0, b1)), max(max(c0, c1), max(d0, d1)));
   s.iz = kmin;
   s.wt = div_const(ts - M.time0, M.time1 - M.time0, M.inv_dtime);
   s.wx = div_const(lon2 - A.lon[s.ix], A.lon[s.ix + 1] - A.lon[s.ix], A.inv_lon[s.ix]);
   s.wy = div_const(lat2 - hy.x0, hy.x1 - hy.x0, hy.inv);
-  f32x4u q00 = load_h4(h2, c00, s.iz), q01 = load_h4(h2, c01, s.iz), q10 = load_h4(h2, c10, s.iz),
-         q11 = load_h4(h2, c11, s.iz);
+  // the records at the lowest index: already there for the columns whose snapshot-0 index is that one
+  if (a0 != s.iz)
+    q00 = load_h4(h2, c00, s.iz);
+  if (b0 != s.iz)
+    q10 = load_h4(h2, c10, s.iz);
+  if (c0 != s.iz)
+    q01 = load_h4(h2, c01, s.iz);
+  if (d0 != s.iz)
+    q11 = load_h4(h2, c11, s.iz);
   double bot = level_pair_value(s, q00, q01, q10, q11, 0);
   double top = level_pair_value(s, q00, q01, q10, q11, 1);
   const float g0 = h2[0], g1 = h2[2];   // heights0[0][0][0], heights0[0][0][1]
@@ -1462,11 +1475,11 @@ __device__ __forceinline__ void load_ml_cached(const DevMet &M, const Stencil4 &
 
 // module_advect, zeta / eta branch, on the packed height fields (same arithmetic as advect_ml_n)
 template <int ADVECT>
-__device__ __forceinline__ void advect_ml_fast_n(const DevMet &M, const Axes &A, Particle &P, double &zeta) {
+__device__ __forceinline__ void advect_ml_fast_n(const DevMet &M, const Axes &A, Particle &P, double &zeta, int &kz) {
   const int ct = M.coord_type;
   const double dt = P.dt;
   Stencil4 s;
-  stencil_4d_fast(M, A, M.pl2, P.time, P.p, P.lon, P.lat, M.npl / 2, s);
+  stencil_4d_fast(M, A, M.pl2, P.time, P.p, P.lon, P.lat, kz, s);
   zeta = ml_field_fast(M, M.zl2, s);
   double u = 0, v = 0, wdot = 0, um = 0, vm = 0, wdotm = 0, x0 = 0, x1 = 0, x2 = 0;
   MlCache mc;
@@ -1505,16 +1518,17 @@ __device__ __forceinline__ void advect_ml_fast_n(const DevMet &M, const Axes &A,
   zeta += dt * wdotm;
   stencil_4d_fast(M, A, M.zl2, P.time, zeta, P.lon, P.lat, s.iz, s);
   P.p = ml_field_fast(M, M.pl2, s);
+  kz = s.iz;
 }
 
 __device__ __forceinline__ void advect_ml_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
-                                               double &zeta) {
+                                               double &zeta, int &kz) {
   if (ctl.advect == 4)
-    advect_ml_fast_n<4>(M, A, P, zeta);
+    advect_ml_fast_n<4>(M, A, P, zeta, kz);
   else if (ctl.advect == 2)
-    advect_ml_fast_n<2>(M, A, P, zeta);
+    advect_ml_fast_n<2>(M, A, P, zeta, kz);
   else
-    advect_ml_fast_n<1>(M, A, P, zeta);
+    advect_ml_fast_n<1>(M, A, P, zeta, kz);
 }
 
 __device__ __forceinline__ double pressure_from_zeta_fast(const DevMet &M, const Axes &A, double time, double zeta,

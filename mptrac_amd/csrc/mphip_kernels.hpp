@@ -297,7 +297,9 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       } else if (CT == kMaskGenericML) {
         const int qnt = ctl.advect_vert_coord == 1 ? ctl.qnt_zeta : ctl.qnt_eta;
         double zeta;
-        advect_ml_fast(ctl, M, A, P, zeta);
+        int kz = a.kz[i];     // vertical index of the last step: first guess of this step's searches
+        advect_ml_fast(ctl, M, A, P, zeta, kz);
+        a.kz[i] = kz;
         a.q[qnt][i] = zeta;
       } else if (early)
         advect_n<4>(M, A, P, pre, wc);
@@ -670,8 +672,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
 struct PermArgs {
   const double *in8[4 + MPHIP_NQ_MAX + 2];
   double *out8[4 + MPHIP_NQ_MAX + 2];
-  const float *in4[3];
-  float *out4[3];
+  const float *in4[4];   // uvwp + the model-level index hint (an int array moved as 4-byte words)
+  float *out4[4];
   const int *ext_in;     // gather only: slot ids travel with the particles
   int *ext_out;          // (ext_in == NULL means identity)
   int n8, n4;
