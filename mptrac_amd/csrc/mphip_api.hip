@@ -703,7 +703,7 @@ void perm_swap(mphip_ctx *ctx, bool with_cache) {
 }
 
 // keys + stable LSD radix sort of (key, index); returns the buffer holding the result
-int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf) {
+int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep_t = nullptr) {
   const long long n = ctx->np;
   const int ntiles = (int) ((n + kSortTile - 1) / kSortTile);
   const size_t m = (size_t) kRadix * ntiles;
@@ -718,8 +718,9 @@ int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf) {
   uint32_t *d_chunks = ctx->d_counts + m;
   const DevMet M = dev_met(ctx);
   const DevAtm a = dev_atm(ctx);
+  TimestepArgs ts = { (double) ctx->ctl.direction, ctx->ctl.t_start, ctx->ctl.t_stop, timestep_t ? *timestep_t : 0.0 };
   hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
-                     ctx->d_keys[0], ctx->d_vals[0]);
+                     ctx->d_keys[0], ctx->d_vals[0], ts, timestep_t ? ctx->d_dt : nullptr);
   // number of 8-bit digits that can be non-zero
   unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
   if (tile > 0) {
@@ -792,14 +793,14 @@ int locality_sort(mphip_ctx *ctx) {
 // module_sort, mptrac.c:5887-5957: observable re-ordering of atm (time, p, lon,
 // lat, q[*]); cache->uvwp and cache->dt stay with their slots as in the
 // reference.
-int do_sort(mphip_ctx *ctx) {
+int do_sort(mphip_ctx *ctx, const double *timestep_t = nullptr) {
   const long long n = ctx->np;
   if (n == 0)
     return 0;
   if (ensure_packed(ctx) || restore_external_order(ctx))
     return 1;
   int cur = 0;
-  if (sort_pairs(ctx, 0, &cur))
+  if (sort_pairs(ctx, 0, &cur, timestep_t))   // with timestep_t: module_timesteps in the key kernel
     return 1;
   ctx->sorted_buf = cur;
   PermArgs g = perm_args(ctx, false);
@@ -841,7 +842,7 @@ struct AccumGeom {
 AccumGeom accum_geom(const mphip_ctx *ctx, int nv) {
   AccumGeom g;
   g.T = 2048;
-  while (g.T > 16 && (size_t) g.T * (8 * (size_t) nv + 4) > 64 * 1024)
+  while (g.T > 64 && (size_t) g.T * (8 * (size_t) nv + 4) > 64 * 1024)
     g.T >>= 1;
   g.lds = (size_t) g.T * (8 * (size_t) nv + 4);
   long long per_block = (ctx->np + 4095) / 4096;
@@ -1328,7 +1329,7 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   // permutes atm but not cache->dt, so on sort steps dt is computed per slot
   // before the sort and read back per slot afterwards.
   if (c.sort_dt > 0 && fmod(t, c.sort_dt) == 0) {
-    if (restore_external_order(ctx) || launch_step(ctx, MPHIP_MOD_TIMESTEPS | kStoreDt, t, 0, 0, 0) || do_sort(ctx))
+    if (restore_external_order(ctx) || do_sort(ctx, &t))
       return 1;
     mask = 0;
   } else if (ctx->locality_interval > 0 && ctx->steps_since_resort >= ctx->locality_interval) {

@@ -499,8 +499,14 @@ __global__ void pack_kernel(PackArgs a) {
 // level-dependent branches (convection below the equilibrium level, vertical
 // diffusion above the tropopause, surface reflection) then go one way per
 // wavefront.
+// With a TimestepArgs the kernel is module_timesteps as well (sort steps of
+// mphip_run_timestep: dt is computed per slot before the sort, mptrac.c:7877-7881).
+struct TimestepArgs {
+  double direction, t_start, t_stop, t;
+};
+
 __global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, uint32_t *__restrict__ keys,
-                                int *__restrict__ idx) {
+                                int *__restrict__ idx, const TimestepArgs ts, double *__restrict__ dt_out) {
   const int wrapped = tile > 0;
   const int nty = tile > 0 ? (M.ny + tile - 1) / tile : 0;
   extern __shared__ double s_axes[];
@@ -509,6 +515,16 @@ __global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, uint32_t *__restri
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
        i += (long long) gridDim.x * blockDim.x) {
     double lon = a.lon[i], lat = a.lat[i];
+    if (dt_out) {   // module_timesteps, mptrac.c:6016-6041
+      const double time = a.time[i];
+      double dt = 0.0;
+      if (ts.direction * (time - ts.t_start) >= 0 && ts.direction * (time - ts.t_stop) <= 0
+          && ts.direction * (time - ts.t) < 0)
+        dt = ts.t - time;
+      if (M.local && (lon <= A.lon[0] || lon >= A.lon[M.nx - 1] || lat <= M.latmin || lat >= M.latmax))
+        dt = 0.0;
+      dt_out[i] = dt;
+    }
     if (wrapped) {
       double lon2, lat2;
       check_horizontal(M, A, lon, lat, lon2, lat2);
@@ -611,32 +627,51 @@ __global__ __launch_bounds__(kScanThreads) void sort_scan_chunks_kernel(uint32_t
     chunk_sums[threadIdx.x] = off;
 }
 
-// stable scatter of one digit pass
+// Stable scatter of one digit pass.  A workgroup ranks its whole tile first,
+// re-orders it by digit in LDS and only then writes: the keys of one digit
+// leave as one contiguous run (kSortTile / kRadix = 16 pairs on average, whole
+// 64-byte segments) instead of 4-byte stores to 256 different places per round.
+//   ranking: wave w owns keys [1024 w, 1024 (w + 1)) of the tile and walks them
+//   in rounds of 64 -- (wave, round, lane) is the input order, so ranks are
+//   stable; the lanes of a round that hold the same digit are found with eight
+//   ballots, and a per-wave counter row in LDS carries the running count from
+//   round to round (no workgroup barrier inside the loop).
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32_t *__restrict__ keys_in,
                                                                     const int *__restrict__ vals_in,
                                                                     uint32_t *__restrict__ keys_out,
                                                                     int *__restrict__ vals_out, long long n, int shift,
                                                                     int ntiles, const uint32_t *__restrict__ offsets,
                                                                     const uint32_t *__restrict__ chunk_offsets) {
-  __shared__ uint32_t running[kRadix];      // next free slot per digit
-  __shared__ uint32_t wcnt[4][kRadix];      // per-wave counts of the current round
+  constexpr int kWaves = kSortThreads / 64;
+  constexpr int kPerWave = kSortTile / kWaves;
+  __shared__ uint32_t s_key[kSortTile];
+  __shared__ int s_val[kSortTile];
+  __shared__ uint32_t s_cnt[kWaves][kRadix];   // per-wave digit counts, then exclusive prefix over the waves
+  __shared__ uint32_t s_dbase[kRadix];         // first tile-local position of a digit
+  __shared__ uint32_t s_gdelta[kRadix];        // global position - tile-local position
+  __shared__ uint32_t s_wsum[kWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    const size_t slot = (size_t) threadIdx.x * ntiles + blockIdx.x;
-    running[threadIdx.x] = offsets[slot] + chunk_offsets[slot / kScanChunk];
-  }
 #pragma unroll
-  for (int w = 0; w < 4; w++)
-    wcnt[w][threadIdx.x] = 0;
+  for (int w = 0; w < kWaves; w++)
+    s_cnt[w][threadIdx.x] = 0;
   __syncthreads();
-  const long long base = (long long) blockIdx.x * kSortTile;
+
+  const long long base = (long long) blockIdx.x * kSortTile + (long long) wave * kPerWave + lane;
+  uint32_t key[kSortRounds];
+  int val[kSortRounds];
+  uint32_t off[kSortRounds];
+#pragma unroll
   for (int r = 0; r < kSortRounds; r++) {
-    const long long i = base + r * kSortThreads + threadIdx.x;
+    const long long i = base + r * 64;
     const bool valid = i < n;
-    const uint32_t key = valid ? keys_in[i] : 0xffffffffu;
-    const int val = valid ? vals_in[i] : 0;
-    const uint32_t d = (key >> shift) & (kRadix - 1);
-    // lanes of this wave holding the same digit
+    key[r] = valid ? keys_in[i] : 0xffffffffu;
+    val[r] = valid ? vals_in[i] : 0;
+  }
+  volatile uint32_t *cnt = s_cnt[wave];
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    const bool valid = base + r * 64 < n;
+    const uint32_t d = (key[r] >> shift) & (kRadix - 1);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
@@ -644,24 +679,53 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
       peers &= ((d >> b) & 1) ? bal : ~bal;
     }
     const unsigned long long below = peers & ((1ull << lane) - 1ull);
-    const uint32_t rank_in_wave = __popcll(below);
+    const uint32_t prev = cnt[d];              // every lane of the wave reads before the leaders write
+    off[r] = prev + __popcll(below);
     if (valid && below == 0)
-      wcnt[wave][d] = __popcll(peers);
-    __syncthreads();
-    uint32_t pos = running[d] + rank_in_wave;
-    for (int w = 0; w < wave; w++)
-      pos += wcnt[w][d];
-    if (valid) {
-      keys_out[pos] = key;
-      vals_out[pos] = val;
+      cnt[d] = prev + __popcll(peers);
+  }
+  __syncthreads();
+
+  // thread = digit: prefix over the waves, then over the digits
+  {
+    const int d = threadIdx.x;
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+      const uint32_t c = s_cnt[w][d];
+      s_cnt[w][d] = tot;
+      tot += c;
     }
-    __syncthreads();
-    {
-      const int dd = threadIdx.x;
-      running[dd] += wcnt[0][dd] + wcnt[1][dd] + wcnt[2][dd] + wcnt[3][dd];
-      wcnt[0][dd] = wcnt[1][dd] = wcnt[2][dd] = wcnt[3][dd] = 0;
+    uint32_t all;
+    const uint32_t dbase = block_exclusive_scan(tot, s_wsum, &all);
+    const size_t slot = (size_t) d * ntiles + blockIdx.x;
+    s_dbase[d] = dbase;
+    s_gdelta[d] = offsets[slot] + chunk_offsets[slot / kScanChunk] - dbase;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int r = 0; r < kSortRounds; r++) {
+    if (base + r * 64 < n) {
+      const uint32_t d = (key[r] >> shift) & (kRadix - 1);
+      const uint32_t pos = s_dbase[d] + s_cnt[wave][d] + off[r];
+      s_key[pos] = key[r];
+      s_val[pos] = val[r];
     }
-    __syncthreads();
+  }
+  __syncthreads();
+
+  const long long left = n - (long long) blockIdx.x * kSortTile;
+  const int count = left < kSortTile ? (int) left : kSortTile;
+#pragma unroll 4
+  for (int j = 0; j < kSortRounds; j++) {
+    const int L = j * kSortThreads + threadIdx.x;
+    if (L < count) {
+      const uint32_t k = s_key[L];
+      const uint32_t pos = (uint32_t) L + s_gdelta[(k >> shift) & (kRadix - 1)];
+      keys_out[pos] = k;
+      vals_out[pos] = s_val[L];
+    }
   }
 }
 
@@ -763,6 +827,9 @@ __global__ void box_index_kernel(DevAtm a, BoxGrid G, double t0, double t1, int 
 // them, and no long same-address queues in L2.  A particle whose cell finds no
 // free slot within kProbes tries adds to global memory directly (unsorted
 // input, very fine output grids).
+#ifndef MPHIP_TABLE_GROUP_LOG2
+#define MPHIP_TABLE_GROUP_LOG2 4
+#endif
 constexpr int kProbes = 8;
 
 struct LdsTable {
@@ -782,14 +849,18 @@ struct LdsTable {
       vals[i] = 0.0;
     __syncthreads();
   }
-  // slot of `key`, claiming a free one if needed; -1 if the probe sequence is full
+  // slot of `key`, claiming a free one if needed; -1 if the probe sequence is full.
+  // 2^G consecutive cells (one 128-byte line of the output array) hash to 2^G consecutive
+  // slots, so that the flush sends the atomics of a line from neighbouring lanes: with a
+  // hash per cell the flush of module_mixing took 300 of the kernel's 360 us, now 45.
   __device__ __forceinline__ int slot_for(int key) const {
-    unsigned h = ((unsigned) key * 2654435761u) >> shift;
+    constexpr int G = MPHIP_TABLE_GROUP_LOG2;
+    unsigned h = ((((unsigned) key >> G) * 2654435761u) >> (shift + G)) << G | ((unsigned) key & ((1u << G) - 1u));
     for (int k = 0; k < kProbes; k++) {
       const int old = atomicCAS(&keys[h], -1, key);
       if (old == -1 || old == key)
         return (int) h;
-      h = (h + 1) & (unsigned) (T - 1);
+      h = (h + (1u << G)) & (unsigned) (T - 1);
     }
     return -1;
   }
