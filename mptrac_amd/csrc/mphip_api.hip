@@ -21,6 +21,7 @@ constexpr unsigned kAdvTurb = kAdv | MPHIP_MOD_DIFF_TURB;
 constexpr unsigned kAdvDiff = kAdvTurb | MPHIP_MOD_DIFF_MESO;
 constexpr unsigned kAdvTurbConvSedi = kAdvTurb | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kAdvDiffConvSedi = kAdvDiff | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
+constexpr unsigned kAdvDiffConvSediDecay = kAdvDiffConvSedi | MPHIP_MOD_DECAY;
 constexpr unsigned kParticleBits = 0x3fffu | MPHIP_MOD_ISOSURF | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2
   | MPHIP_MOD_ISOSURF_INIT;
 
@@ -537,7 +538,9 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // model levels: the fast path needs monotonic height columns and none of the rarely used modules
   const bool ml_fast = ml_ && ctx->ml_monotonic && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
   const bool rare = (ml_ && !ml_fast) || (mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u));
-  const unsigned sel = (ctx->ctl.advect == 4 && !rare && !ml_ && !ctx->force_generic) ? mask : kMaskGeneric;
+  // the specialised instantiations take module_timesteps / the dt store from the run-time mask
+  const unsigned sel = (ctx->ctl.advect == 4 && !rare && !ml_ && !ctx->force_generic)
+    ? ((mask | MPHIP_MOD_TIMESTEPS) & ~kStoreDt) : kMaskGeneric;
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
   case M:                                                                                             \
@@ -548,6 +551,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiff)
     STEP_CASE(kAdvTurbConvSedi)
     STEP_CASE(kAdvDiffConvSedi)
+    STEP_CASE(kAdvDiffConvSediDecay)
 #undef STEP_CASE
   default:
     if (rare || ctx->force_generic)

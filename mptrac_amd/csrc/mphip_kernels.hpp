@@ -260,9 +260,11 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       a.p[i] = pressure_from_zeta_fast(M, A, P.time, a.q[ctl.qnt_zeta][i], P.lon, P.lat);
       continue;
     }
-    if (mask & MPHIP_MOD_TIMESTEPS) {
+    // module_timesteps and the store of cache->dt are run-time choices in every instantiation
+    // (sort steps compute dt before the sort; launches split around module_mixing share it)
+    if (S.mask & MPHIP_MOD_TIMESTEPS) {
       P.dt = timestep_of(ctl, M, A, P.time, P.lon, P.lat, S.t);
-      if (mask & kStoreDt)
+      if (S.mask & kStoreDt)
         a.dt[i] = P.dt;
     } else
       P.dt = a.dt[i];
