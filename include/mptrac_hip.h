@@ -183,6 +183,22 @@ int mphip_update_clim(mphip_ctx *ctx, int ntime, int nlat, const double *tropo_t
 int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met);
 /* the met0/met1 pointer swap in mptrac_get_met, mptrac.c:6488-6491 */
 int mphip_swap_met(mphip_ctx *ctx);
+/* The same hand-over of mptrac_get_met (read the next file into the old met0
+ * buffer, swap, mptrac.c:6479-6503) with the upload taken off the stepping
+ * path: mphip_prefetch_met() starts the host-to-device copies of the NEXT
+ * snapshot into a third staging slot on a copy stream and returns at once
+ * (the caller's arrays are page-locked on first use, option "pin_host_met";
+ * they must stay untouched until the commit); time steps keep running on
+ * met0 / met1 meanwhile.  mphip_commit_met() makes old met1 the new met0 and
+ * the prefetched snapshot the new met1: the next kernel waits for the copy on
+ * the device, the host does not block.  mphip_prefetch_done() = 1 once the
+ * copies have finished.  Same grid dimensions as the resident snapshots
+ * ("Meteo grid dimensions do not match!" otherwise, mptrac.c:6543-6546). */
+int mphip_prefetch_met(mphip_ctx *ctx, const mphip_met_t *met);
+int mphip_commit_met(mphip_ctx *ctx);
+int mphip_prefetch_done(mphip_ctx *ctx);
+/* drop a prefetched snapshot that will not be used (waits for its copies) */
+int mphip_discard_prefetch(mphip_ctx *ctx);
 
 /* mptrac_update_device(..., atm), mptrac.c:8050-8055.  This process owns the
  * particles [ip0, ip0 + np) of a simulation with np_total particles; random

@@ -87,7 +87,7 @@ def build_host(force=False, verbose=False, dims=None):
     defs.append('-DMPTRAC_AMD_DATA_DIR="%s"' % os.path.join(HERE, "data"))
     common = ["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-W", "-Wno-format-security", "-fPIC", "-mcmodel=medium",
               *defs]
-    rpath = ["-L" + LIBDIR, "-lmptrac_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    rpath = ["-L" + LIBDIR, "-lmptrac_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread"]
     cmds = [common + ["-shared", "-o", HOST_LIB, os.path.join(HOST_DIR, "mptrac.c")] + rpath,
             common + ["-o", TRAC_BIN, os.path.join(HOST_DIR, "trac.c"), os.path.join(HOST_DIR, "mptrac.c")] + rpath]
     for cmd in cmds:

@@ -49,6 +49,13 @@ struct mphip_ctx {
   // meteo
   MetSlot slot[2];
   int flip = 0;                       // logical slot s lives in slot[s ^ flip]
+  MetSlot next;                       // snapshot being uploaded ahead of time (mphip_prefetch_met)
+  bool next_pending = false;
+  hipStream_t copy_stream = nullptr;  // uploads of `next` run here, beside the kernels on `stream`
+  hipEvent_t next_ready = nullptr;
+  hipEvent_t main_mark = nullptr;     // copies into `next` start after the kernels queued so far (they may read its arrays)
+  bool pin_host_met = true;           // page-lock the caller's meteo arrays on first prefetch (async H2D needs it)
+  std::vector<std::pair<void *, size_t>> pinned;
   int nx = 0, ny = 0, npl = 0, coord_type = 0;   // npl: pressure levels (met_t::np)
   int nml = 0;                                    // model levels (met_t::npl), 0 = none uploaded
   float *d_mlw = nullptr, *d_zl2 = nullptr, *d_pl2 = nullptr;
@@ -894,6 +901,55 @@ int do_mixing(mphip_ctx *ctx, double t) {
   return 0;
 }
 
+// host -> device copies of one snapshot's fields into the staging arrays of slot S (asynchronous on `stream`)
+int upload_fields(mphip_ctx *ctx, MetSlot &S, const mphip_met_t *met, bool new_grid, hipStream_t stream) {
+  const int nml = met->npl > 0 ? met->npl : 0;
+  const size_t ncell = (size_t) met->nx * met->ny * met->np, ncol = (size_t) met->nx * met->ny;
+  for (int f = 0; f < MPHIP_N3D; f++) {
+    const bool is_ml = f >= MPHIP_PL && f <= MPHIP_ZETA_DOTL;
+    const long long nlev = is_ml ? nml : met->np;
+    const long long sx = is_ml ? met->sx_ml : met->sx, sy = is_ml ? met->sy_ml : met->sy;
+    S.has3[f] = met->f3[f] != nullptr && nlev > 0;
+    if (!S.has3[f])
+      continue;
+    const size_t n3 = (size_t) met->nx * met->ny * (size_t) nlev;
+    if (new_grid || !S.f3[f])
+      if (dev_alloc(ctx, &S.f3[f], n3))
+        return 1;
+    if (sy == nlev && sx == (long long) met->ny * nlev) {
+      HIPCHK(hipMemcpyAsync(S.f3[f], met->f3[f], n3 * sizeof(float), hipMemcpyHostToDevice, stream));
+    } else {
+      if (sy < nlev || sx < sy * met->ny || sx % sy != 0)
+        return fail(ctx, "unsupported 3-D meteo strides");
+      hipMemcpy3DParms p;
+      memset(&p, 0, sizeof(p));
+      p.srcPtr = make_hipPitchedPtr((void *) met->f3[f], (size_t) sy * sizeof(float), (size_t) nlev,
+                                    (size_t) (sx / sy));
+      p.dstPtr = make_hipPitchedPtr(S.f3[f], (size_t) nlev * sizeof(float), (size_t) nlev, (size_t) met->ny);
+      p.extent = make_hipExtent((size_t) nlev * sizeof(float), (size_t) met->ny, (size_t) met->nx);
+      p.kind = hipMemcpyHostToDevice;
+      HIPCHK(hipMemcpy3DAsync(&p, stream));
+    }
+  }
+  for (int f = 0; f < MPHIP_N2D; f++) {
+    S.has2[f] = met->f2[f] != nullptr;
+    if (!S.has2[f])
+      continue;
+    if (new_grid || !S.f2[f])
+      if (dev_alloc(ctx, &S.f2[f], ncol))
+        return 1;
+    if (met->sx2 == met->ny) {
+      HIPCHK(hipMemcpyAsync(S.f2[f], met->f2[f], ncol * sizeof(float), hipMemcpyHostToDevice, stream));
+    } else {
+      if (met->sx2 < met->ny)
+        return fail(ctx, "unsupported 2-D meteo stride");
+      HIPCHK(hipMemcpy2DAsync(S.f2[f], (size_t) met->ny * sizeof(float), met->f2[f], (size_t) met->sx2 * sizeof(float),
+                              (size_t) met->ny * sizeof(float), (size_t) met->nx, hipMemcpyHostToDevice, stream));
+    }
+  }
+  return 0;
+}
+
 }   // namespace
 
 // ---------------------------------------------------------------------------
@@ -944,10 +1000,20 @@ void mphip_destroy(mphip_ctx *ctx) {
     return;
   (void) hipSetDevice(ctx->device);
   (void) hipStreamSynchronize(ctx->stream);
-  for (auto &s : ctx->slot) {
-    for (auto p : s.f3)
+  if (ctx->copy_stream) {
+    (void) hipStreamSynchronize(ctx->copy_stream);
+    (void) hipStreamDestroy(ctx->copy_stream);
+  }
+  if (ctx->next_ready)
+    (void) hipEventDestroy(ctx->next_ready);
+  if (ctx->main_mark)
+    (void) hipEventDestroy(ctx->main_mark);
+  for (auto &r : ctx->pinned)
+    (void) hipHostUnregister(r.first);
+  for (MetSlot *s : { &ctx->slot[0], &ctx->slot[1], &ctx->next }) {
+    for (auto p : s->f3)
       dev_free(p);
-    for (auto p : s.f2)
+    for (auto p : s->f2)
       dev_free(p);
   }
   dev_free(ctx->d_clim);
@@ -963,6 +1029,9 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_sfd);
   dev_free(ctx->d_h2o);
   dev_free(ctx->d_mlw);
+  dev_free(ctx->d_zl2);
+  dev_free(ctx->d_pl2);
+  dev_free(ctx->d_ml_mono);
   for (auto p : ctx->d_arr)
     dev_free(p);
   for (auto p : ctx->d_alt)
@@ -1066,6 +1135,18 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     ctx->ny = met->ny;
     ctx->npl = met->np;
     ctx->nml = nml;
+    if (ctx->copy_stream)
+      HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+    for (auto &q : ctx->next.f3) {
+      dev_free(q);
+      q = nullptr;
+    }
+    for (auto &q : ctx->next.f2) {
+      dev_free(q);
+      q = nullptr;
+    }
+    ctx->next.valid = false;
+    ctx->next_pending = false;
     dev_free(ctx->d_mlw);
     dev_free(ctx->d_zl2);
     dev_free(ctx->d_pl2);
@@ -1094,49 +1175,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
       return 1;
   }
   MetSlot &S = ctx->slot[slot ^ ctx->flip];
-  const size_t ncell = (size_t) met->nx * met->ny * met->np, ncol = (size_t) met->nx * met->ny;
-  for (int f = 0; f < MPHIP_N3D; f++) {
-    const bool is_ml = f >= MPHIP_PL && f <= MPHIP_ZETA_DOTL;
-    const long long nlev = is_ml ? nml : met->np;
-    const long long sx = is_ml ? met->sx_ml : met->sx, sy = is_ml ? met->sy_ml : met->sy;
-    S.has3[f] = met->f3[f] != nullptr && nlev > 0;
-    if (!S.has3[f])
-      continue;
-    const size_t n3 = (size_t) met->nx * met->ny * (size_t) nlev;
-    if (new_grid || !S.f3[f])
-      if (dev_alloc(ctx, &S.f3[f], n3))
-        return 1;
-    if (sy == nlev && sx == (long long) met->ny * nlev) {
-      HIPCHK(hipMemcpyAsync(S.f3[f], met->f3[f], n3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    } else {
-      if (sy < nlev || sx < sy * met->ny || sx % sy != 0)
-        return fail(ctx, "unsupported 3-D meteo strides");
-      hipMemcpy3DParms p;
-      memset(&p, 0, sizeof(p));
-      p.srcPtr = make_hipPitchedPtr((void *) met->f3[f], (size_t) sy * sizeof(float), (size_t) nlev,
-                                    (size_t) (sx / sy));
-      p.dstPtr = make_hipPitchedPtr(S.f3[f], (size_t) nlev * sizeof(float), (size_t) nlev, (size_t) met->ny);
-      p.extent = make_hipExtent((size_t) nlev * sizeof(float), (size_t) met->ny, (size_t) met->nx);
-      p.kind = hipMemcpyHostToDevice;
-      HIPCHK(hipMemcpy3DAsync(&p, ctx->stream));
-    }
-  }
-  for (int f = 0; f < MPHIP_N2D; f++) {
-    S.has2[f] = met->f2[f] != nullptr;
-    if (!S.has2[f])
-      continue;
-    if (new_grid || !S.f2[f])
-      if (dev_alloc(ctx, &S.f2[f], ncol))
-        return 1;
-    if (met->sx2 == met->ny) {
-      HIPCHK(hipMemcpyAsync(S.f2[f], met->f2[f], ncol * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    } else {
-      if (met->sx2 < met->ny)
-        return fail(ctx, "unsupported 2-D meteo stride");
-      HIPCHK(hipMemcpy2DAsync(S.f2[f], (size_t) met->ny * sizeof(float), met->f2[f], (size_t) met->sx2 * sizeof(float),
-                              (size_t) met->ny * sizeof(float), (size_t) met->nx, hipMemcpyHostToDevice, ctx->stream));
-    }
-  }
+  if (upload_fields(ctx, S, met, new_grid, ctx->stream))
+    return 1;
   HIPCHK(hipStreamSynchronize(ctx->stream));   // the host arrays may be reused by the caller
   S.time = met->time;
   S.valid = true;
@@ -1150,6 +1190,93 @@ int mphip_swap_met(mphip_ctx *ctx) {
   ctx->flip ^= 1;
   ctx->packed_dirty = true;
   return 0;
+}
+
+// Page-lock a caller array once (the reference re-uses its two met_t buffers for the whole run), so
+// that the copies of mphip_prefetch_met really are asynchronous.  Failure is not an error: the copy
+// then goes through the runtime's staging buffers.
+static void pin_host_range(mphip_ctx *ctx, const void *ptr, size_t bytes) {
+  if (!ctx->pin_host_met || !ptr || !bytes)
+    return;
+  for (auto &r : ctx->pinned)
+    if (r.first == ptr && r.second >= bytes)
+      return;
+  if (hipHostRegister((void *) ptr, bytes, hipHostRegisterDefault) == hipSuccess)
+    ctx->pinned.emplace_back((void *) ptr, bytes);
+  else
+    (void) hipGetLastError();
+}
+
+int mphip_prefetch_met(mphip_ctx *ctx, const mphip_met_t *met) {
+  if (!ctx || !met)
+    return fail(ctx, "bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nml = met->npl > 0 ? met->npl : 0;
+  if (!ctx->slot[0].valid || !ctx->slot[1].valid)
+    return fail(ctx, "mphip_prefetch_met needs both snapshots on the device (mphip_update_met first)");
+  if (met->nx != ctx->nx || met->ny != ctx->ny || met->np != ctx->npl || nml != ctx->nml)
+    return fail(ctx, "Meteo grid dimensions do not match!");   // mptrac.c:6543-6546
+  if (ctx->next_pending)
+    return fail(ctx, "a prefetched snapshot is waiting for mphip_commit_met");
+  if (!ctx->copy_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->next_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming));
+  }
+  for (int f = 0; f < MPHIP_N3D; f++) {
+    const bool is_ml = f >= MPHIP_PL && f <= MPHIP_ZETA_DOTL;
+    const long long nlev = is_ml ? nml : met->np;
+    const long long sx = is_ml ? met->sx_ml : met->sx;
+    if (met->f3[f] && nlev > 0)
+      pin_host_range(ctx, met->f3[f], (size_t) met->nx * (size_t) sx * sizeof(float));
+  }
+  for (int f = 0; f < MPHIP_N2D; f++)
+    if (met->f2[f])
+      pin_host_range(ctx, met->f2[f], (size_t) met->nx * (size_t) met->sx2 * sizeof(float));
+  // the staging arrays of `next` were met0 until the last commit: kernels queued before it may still read them
+  HIPCHK(hipEventRecord(ctx->main_mark, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->main_mark, 0));
+  if (upload_fields(ctx, ctx->next, met, false, ctx->copy_stream))
+    return 1;
+  HIPCHK(hipEventRecord(ctx->next_ready, ctx->copy_stream));
+  ctx->next.time = met->time;
+  ctx->next.valid = true;
+  ctx->next_pending = true;
+  return 0;
+}
+
+int mphip_commit_met(mphip_ctx *ctx) {
+  if (!ctx)
+    return 1;
+  if (!ctx->next_pending)
+    return fail(ctx, "no prefetched snapshot to commit");
+  HIPCHK(hipSetDevice(ctx->device));
+  // kernels launched from here on wait for the upload; the host does not
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->next_ready, 0));
+  std::swap(ctx->slot[0 ^ ctx->flip], ctx->next);   // the old met0 arrays become the next staging slot
+  ctx->flip ^= 1;                                    // old met1 -> met0, prefetched -> met1
+  ctx->next.valid = false;
+  ctx->next_pending = false;
+  ctx->packed_dirty = true;
+  return 0;
+}
+
+int mphip_discard_prefetch(mphip_ctx *ctx) {
+  if (!ctx)
+    return 1;
+  if (!ctx->next_pending)
+    return 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+  ctx->next.valid = false;
+  ctx->next_pending = false;
+  return 0;
+}
+
+int mphip_prefetch_done(mphip_ctx *ctx) {
+  if (!ctx || !ctx->next_pending)
+    return 1;
+  return hipEventQuery(ctx->next_ready) == hipSuccess ? 1 : 0;
 }
 
 int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_total, int nq, const double *time,
@@ -1522,6 +1649,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (value < 8 || value > 1048576)
       return fail(ctx, "step_blocks must be in 8 ... 1048576");
     ctx->step_blocks = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "pin_host_met") == 0) {   // page-lock the arrays handed to mphip_prefetch_met
+    ctx->pin_host_met = value != 0;
     return 0;
   }
   if (strcmp(name, "xcd_map") == 0) {

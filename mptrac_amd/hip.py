@@ -70,6 +70,10 @@ def load(build=True):
     L.mphip_update_clim.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
     L.mphip_update_met.argtypes = [C.c_void_p, C.c_int, C.POINTER(MphipMet)]
     L.mphip_swap_met.argtypes = [C.c_void_p]
+    L.mphip_prefetch_met.argtypes = [C.c_void_p, C.POINTER(MphipMet)]
+    L.mphip_commit_met.argtypes = [C.c_void_p]
+    L.mphip_prefetch_done.argtypes = [C.c_void_p]
+    L.mphip_discard_prefetch.argtypes = [C.c_void_p]
     L.mphip_update_atm.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int,
                                    _dp, _dp, _dp, _dp, C.POINTER(_dp)]
     L.mphip_get_atm.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.POINTER(_dp)]
@@ -162,7 +166,7 @@ class Simulation:
     def update_ctl(self):
         self._chk(self.L.mphip_update_ctl(self.h, C.byref(self.ctl)))
 
-    def set_met(self, slot, met):
+    def _met_struct(self, met):
         m = MphipMet()
         m.time, m.coord_type, m.nx, m.ny, m.np = met.time, met.coord_type, met.nx, met.ny, met.np
         m.lon, m.lat, m.p = _ptr(met.lon, _dp), _ptr(met.lat, _dp), _ptr(met.p, _dp)
@@ -173,6 +177,10 @@ class Simulation:
             m.f3[i] = _ptr(met.f3[k], _fp) if k in met.f3 else None
         for i, k in enumerate(FIELDS_2D):
             m.f2[i] = _ptr(met.f2[k], _fp) if k in met.f2 else None
+        return m
+
+    def set_met(self, slot, met):
+        m = self._met_struct(met)
         self._chk(self.L.mphip_update_met(self.h, slot, C.byref(m)))
         self._mets[slot] = met
 
@@ -182,6 +190,27 @@ class Simulation:
         self._chk(self.L.mphip_swap_met(self.h))
         self._mets[0] = self._mets[1]
         self.set_met(1, new_met1)
+
+    def prefetch_met(self, next_met):
+        """Start the upload of the snapshot after met1 beside the time steps
+        (copy stream); its arrays must stay untouched until commit_met()."""
+        m = self._met_struct(next_met)
+        self._chk(self.L.mphip_prefetch_met(self.h, C.byref(m)))
+        self._next_met = next_met
+
+    def commit_met(self):
+        """met1 -> met0, prefetched snapshot -> met1 (no host wait)."""
+        self._chk(self.L.mphip_commit_met(self.h))
+        self._mets[0] = self._mets[1]
+        self._mets[1] = self._next_met
+        self._next_met = None
+
+    def discard_prefetch(self):
+        self._chk(self.L.mphip_discard_prefetch(self.h))
+        self._next_met = None
+
+    def prefetch_done(self):
+        return bool(self.L.mphip_prefetch_done(self.h))
 
     def update_atm(self, atm):
         sl = slice(0, self.n) if self.atm_is_local else slice(self.lo, self.hi)

@@ -10,6 +10,7 @@
 #define _GNU_SOURCE
 #include "mptrac.h"
 
+#include <pthread.h>
 #include <strings.h>
 #include <time.h>
 
@@ -19,6 +20,16 @@
  * either (file-static RNG state, mptrac.c:32-40) */
 static mphip_ctx *g_ctx;
 static const met_t *g_met_host[2];     /* host snapshots mirrored in device slots met0 / met1 */
+/* meteo read-ahead (HIP_MET_PREFETCH), see start_read_ahead() */
+static struct {
+  met_t *met;              /* the spare buffer */
+  pthread_t thread;
+  int active;              /* a reader thread is running or waits to be joined */
+  int ok;                  /* file read and upload started */
+  ctl_t *ctl;
+  clim_t *clim;
+  char filename[LEN];
+} g_ahead;
 static int g_nq;                        /* ctl->nq of the last control upload */
 static int g_isosurf;                   /* ctl->isosurf of the last control upload */
 static int g_meteo_fields;              /* a module_meteo quantity is requested: upload the fields only it reads */
@@ -132,10 +143,16 @@ void mptrac_alloc(ctl_t **ctl, cache_t **cache, clim_t **clim, met_t **met0, met
 
 void mptrac_free(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t *met0, met_t *met1, atm_t *atm,
                  depo_t *depo, dd_t *dd) {
+  if (g_ahead.active) {
+    pthread_join(g_ahead.thread, NULL);
+    g_ahead.active = 0;
+  }
   if (g_ctx) {
     mphip_destroy(g_ctx);
     g_ctx = NULL;
   }
+  free(g_ahead.met);
+  g_ahead.met = NULL;
   g_met_host[0] = g_met_host[1] = NULL;
   free(ctl);
   free(cache);
@@ -340,6 +357,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   /* back-end options */
   ctl->hip_device = (int) scan_ctl(filename, argc, argv, "HIP_DEVICE", -1, "0", NULL);
   ctl->hip_locality_interval = (int) scan_ctl(filename, argc, argv, "HIP_LOCALITY_SORT_INTERVAL", -1, "20", NULL);
+  ctl->hip_met_prefetch = (int) scan_ctl(filename, argc, argv, "HIP_MET_PREFETCH", -1, "0", NULL);
 
   /* what the device does not implement must not be requested silently */
   if (ctl->rng_type != 1)
@@ -774,8 +792,7 @@ static void map_met_slot(const met_t *host, int slot) {
   g_met_host[slot] = host;
 }
 
-static void upload_met(met_t *met, int slot) {
-  map_met_slot(met, slot);
+static void describe_met(met_t *met, mphip_met_t *out) {
   mphip_met_t m;
   memset(&m, 0, sizeof(m));
   m.time = met->time;
@@ -839,7 +856,84 @@ static void upload_met(met_t *met, int slot) {
     m.f2[MPHIP_PLFC] = &met->plfc[0][0];
     m.f2[MPHIP_O3C] = &met->o3c[0][0];
   }
+  *out = m;
+}
+
+static void upload_met(met_t *met, int slot) {
+  map_met_slot(met, slot);
+  mphip_met_t m;
+  describe_met(met, &m);
   HIP(mphip_update_met(g_ctx, slot, &m));
+}
+
+/* Read-ahead of the next meteo file (HIP_MET_PREFETCH 1, forward runs): while
+ * the time steps of the current interval run, a reader thread loads the file
+ * after met1 into a third met_t and starts its upload on the back end's copy
+ * stream (mphip_prefetch_met); at the hand-over mptrac_get_met rotates the
+ * three host pointers and commits instead of reading and uploading on the
+ * stepping path.  Costs one more met_t of host memory, hence off by default. */
+
+static void *read_ahead_main(void *arg) {
+  (void) arg;
+  g_ahead.ok = 0;
+  FILE *probe = fopen(g_ahead.filename, "r");   /* past the last file of the run: nothing to do */
+  if (!probe)
+    return NULL;
+  fclose(probe);
+  if (!mptrac_read_met(g_ahead.filename, g_ahead.ctl, g_ahead.clim, g_ahead.met, NULL))
+    return NULL;
+  mphip_met_t m;
+  describe_met(g_ahead.met, &m);
+  if (mphip_prefetch_met(g_ctx, &m) != 0) {
+    WARN("Meteo read-ahead: %s", mphip_last_error(g_ctx));
+    return NULL;
+  }
+  g_ahead.ok = 1;
+  return NULL;
+}
+
+static void start_read_ahead(ctl_t *ctl, clim_t *clim, const met_t *met1) {
+  if (!ctl->hip_met_prefetch || ctl->direction != 1 || g_ahead.active)
+    return;
+  if (!g_ahead.met)
+    ALLOC(g_ahead.met, met_t, 1);
+  g_ahead.ctl = ctl;
+  g_ahead.clim = clim;
+  get_met_filename(ctl, met1->time + 1, 1, g_ahead.filename);
+  if (pthread_create(&g_ahead.thread, NULL, read_ahead_main, NULL) == 0)
+    g_ahead.active = 1;
+}
+
+static void cancel_read_ahead(void) {
+  if (!g_ahead.active)
+    return;
+  pthread_join(g_ahead.thread, NULL);
+  g_ahead.active = 0;
+  if (g_ahead.ok)
+    HIP(mphip_discard_prefetch(g_ctx));
+}
+
+/* 1: the prefetched snapshot is the one `filename` names and now is *met1 */
+static int take_read_ahead(const char *filename, met_t **met0, met_t **met1) {
+  if (!g_ahead.active)
+    return 0;
+  pthread_join(g_ahead.thread, NULL);
+  g_ahead.active = 0;
+  if (!g_ahead.ok)
+    return 0;
+  if (strcmp(filename, g_ahead.filename) != 0) {   /* not the file this hand-over needs */
+    HIP(mphip_discard_prefetch(g_ctx));
+    return 0;
+  }
+  met_t *old0 = *met0;
+  *met0 = *met1;
+  *met1 = g_ahead.met;
+  g_ahead.met = old0;
+  HIP(mphip_commit_met(g_ctx));
+  LOG(1, "Meteo data from the read-ahead: %s", filename);
+  g_met_host[0] = *met0;
+  g_met_host[1] = *met1;
+  return 1;
 }
 
 void mptrac_update_device(const ctl_t *ctl, const cache_t *cache, const clim_t *clim, met_t **met0,
@@ -944,6 +1038,7 @@ void mptrac_get_met(ctl_t *ctl, clim_t *clim, const double t, met_t **met0, met_
 
   if (t == ctl->t_start || !init) {
     init = 1;
+    cancel_read_ahead();
     get_met_filename(ctl, t + (ctl->direction == -1 ? -1 : 0), -1, filename);
     if (!mptrac_read_met(filename, ctl, clim, *met0, dd))
       ERRMSG("Cannot open file!");
@@ -951,16 +1046,20 @@ void mptrac_get_met(ctl_t *ctl, clim_t *clim, const double t, met_t **met0, met_
     if (!mptrac_read_met(filename, ctl, clim, *met1, dd))
       ERRMSG("Cannot open file!");
     mptrac_update_device(NULL, NULL, NULL, met0, met1, NULL);
+    start_read_ahead(ctl, clim, *met1);
   }
   if (t > (*met1)->time) {
-    mets = *met1;
-    *met1 = *met0;
-    *met0 = mets;
     get_met_filename(ctl, t, 1, filename);
-    if (!mptrac_read_met(filename, ctl, clim, *met1, dd))
-      ERRMSG("Cannot open file!");
-    map_met_slot(*met0, 0);   /* device slots follow the pointer swap */
-    mptrac_update_device(NULL, NULL, NULL, NULL, met1, NULL);
+    if (!take_read_ahead(filename, met0, met1)) {
+      mets = *met1;
+      *met1 = *met0;
+      *met0 = mets;
+      if (!mptrac_read_met(filename, ctl, clim, *met1, dd))
+        ERRMSG("Cannot open file!");
+      map_met_slot(*met0, 0);   /* device slots follow the pointer swap */
+      mptrac_update_device(NULL, NULL, NULL, NULL, met1, NULL);
+    }
+    start_read_ahead(ctl, clim, *met1);
   }
   if (t < (*met0)->time) {
     mets = *met1;

@@ -149,6 +149,7 @@ typedef struct {
   /* back-end options (no reference counterpart) */
   int hip_device;
   int hip_locality_interval;
+  int hip_met_prefetch;   /* HIP_MET_PREFETCH: read and upload the next meteo file beside the time steps */
 } ctl_t;
 
 /* air parcels, as the reference (mptrac.h:3563-3583) */

@@ -185,6 +185,42 @@ def test_met_swap_over_two_intervals():
     s.close()
 
 
+@pytest.mark.parametrize("case", ["diff", "full", "zeta_full", "bound_pbl_zeta"])
+def test_met_prefetch_and_commit_equal_the_synchronous_swap(case):
+    """mphip_prefetch_met / mphip_commit_met (upload of the next snapshot on a copy stream beside the
+    time steps) against the oracle's pointer swap over 3 h with 4 snapshots: the prefetch is issued right
+    after each hand-over, the staging arrays rotate twice."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=3000)
+    ctl["t_stop"] = 10800.0
+    fields = tuple(m0.f3) + tuple(m0.f2)
+    m2 = synthetic_met("C1", 7200.0, 0.8, fields=fields)
+    m3 = synthetic_met("C1", 10800.0, 1.1, fields=fields)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    cases.prepare(o)
+    cases.prepare(s)
+    with pytest.raises(RuntimeError):
+        s.commit_met()                     # nothing prefetched yet
+    s.prefetch_met(m2)
+    with pytest.raises(RuntimeError):
+        s.prefetch_met(m3)                 # one snapshot at a time
+    upcoming = [(3600.0, m2, m3), (7200.0, m3, None)]
+    for t in cases.step_times(o.ctl):
+        if upcoming and t > upcoming[0][0]:
+            _, new1, after = upcoming.pop(0)
+            o.swap_met(new1)
+            s.commit_met()
+            if after is not None:
+                s.prefetch_met(after)
+        o.run_timestep(t)
+        s.run_timestep(t)
+    assert not upcoming
+    _compare(o, s)
+    s.close()
+
+
 def test_backward_trajectories():
     ctl, clim, m0, m1, atm = cases.make_case("turb", n=2000)
     ctl.update(direction=-1, t_stop=0.0)

@@ -21,7 +21,7 @@ QUANT = ("m", "rp", "rhop")
 QUANT_METEO = ("m", "rp", "rhop", "t", "u", "zg", "pv", "ps", "pt", "theta", "rh", "sst")
 
 
-def _setup(tmp, n=3000, hours=2, atm_type=1, pbl=False, meteo=False):
+def _setup(tmp, n=3000, hours=2, atm_type=1, pbl=False, meteo=False, extra=None):
     lib, trac = build.build_host()
     metbase = os.path.join(tmp, "met")
     mets = []
@@ -44,6 +44,7 @@ def _setup(tmp, n=3000, hours=2, atm_type=1, pbl=False, meteo=False):
         keys["MET_DT_OUT"] = 0
     if pbl:
         keys.update({"TURB_PBL_SCHEME": 1, "TURB_MESOZ": 0})
+    keys.update(extra or {})
     hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
     open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
     return trac, mets, atm
@@ -108,6 +109,27 @@ def test_trac_end_to_end_matches_oracle(tmp_path, atm_type, pbl, meteo):
         g = os.path.join(tmp, "grid_2022_06_02_%02d_00_00.tab" % hour)
         rows = [ln.split() for ln in open(g) if ln.strip() and not ln.startswith("#")]
         assert len(rows) == 36 * 18 and sum(int(r[8]) for r in rows) == 3000
+
+
+@pytest.mark.gpu
+def test_trac_with_meteo_read_ahead(tmp_path):
+    """HIP_MET_PREFETCH 1: the next meteo file is read by a thread and uploaded on the copy stream while
+    the interval's time steps run; results as without it (3 h, 4 files, two hand-overs from the read-ahead)."""
+    tmp = str(tmp_path)
+    trac, mets, atm = _setup(tmp, n=3000, hours=3, extra={"HIP_MET_PREFETCH": 1})
+    r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert out.count("Meteo data from the read-ahead") == 2, out[-3000:]
+    snaps = _oracle(mets, atm, 3)
+    for hour in (1, 2, 3):
+        got = hf.read_atm_bin(os.path.join(tmp, "atm_2022_06_02_%02d_00_00.bin" % hour), len(QUANT))
+        ref = snaps[T0 + 3600.0 * hour]
+        assert np.array_equal(got["time"], ref["time"])
+        for k in ("lon", "lat", "p"):
+            assert cases.rel_err(got[k], ref[k]) <= 1e-10, (hour, k, cases.rel_err(got[k], ref[k]))
+        assert cases.rel_err(got["q"], ref["q"]) <= 1e-10
 
 
 @pytest.mark.gpu
