@@ -55,6 +55,7 @@ struct mphip_ctx {
   hipEvent_t next_ready = nullptr;
   hipEvent_t main_mark = nullptr;     // copies into `next` start after the kernels queued so far (they may read its arrays)
   bool pin_host_met = true;           // page-lock the caller's meteo arrays on first prefetch (async H2D needs it)
+  bool pin_host_atm = false;          // page-lock the caller's particle arrays (persistent atm_t of a C caller only)
   std::vector<std::pair<void *, size_t>> pinned;
   int nx = 0, ny = 0, npl = 0, coord_type = 0;   // npl: pressure levels (met_t::np)
   int nml = 0;                                    // model levels (met_t::npl), 0 = none uploaded
@@ -1195,8 +1196,8 @@ int mphip_swap_met(mphip_ctx *ctx) {
 // Page-lock a caller array once (the reference re-uses its two met_t buffers for the whole run), so
 // that the copies of mphip_prefetch_met really are asynchronous.  Failure is not an error: the copy
 // then goes through the runtime's staging buffers.
-static void pin_host_range(mphip_ctx *ctx, const void *ptr, size_t bytes) {
-  if (!ctx->pin_host_met || !ptr || !bytes)
+static void pin_host_range(mphip_ctx *ctx, const void *ptr, size_t bytes, bool enabled) {
+  if (!enabled || !ptr || !bytes)
     return;
   for (auto &r : ctx->pinned)
     if (r.first == ptr && r.second >= bytes)
@@ -1228,11 +1229,11 @@ int mphip_prefetch_met(mphip_ctx *ctx, const mphip_met_t *met) {
     const long long nlev = is_ml ? nml : met->np;
     const long long sx = is_ml ? met->sx_ml : met->sx;
     if (met->f3[f] && nlev > 0)
-      pin_host_range(ctx, met->f3[f], (size_t) met->nx * (size_t) sx * sizeof(float));
+      pin_host_range(ctx, met->f3[f], (size_t) met->nx * (size_t) sx * sizeof(float), ctx->pin_host_met);
   }
   for (int f = 0; f < MPHIP_N2D; f++)
     if (met->f2[f])
-      pin_host_range(ctx, met->f2[f], (size_t) met->nx * (size_t) met->sx2 * sizeof(float));
+      pin_host_range(ctx, met->f2[f], (size_t) met->nx * (size_t) met->sx2 * sizeof(float), ctx->pin_host_met);
   // the staging arrays of `next` were met0 until the last commit: kernels queued before it may still read them
   HIPCHK(hipEventRecord(ctx->main_mark, ctx->stream));
   HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->main_mark, 0));
@@ -1329,6 +1330,10 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
   ctx->np_total = np_total;
   const double *src[4] = { time, p, lon, lat };
   for (int k = 0; k < 4 && np; k++)
+    pin_host_range(ctx, src[k], (size_t) np * sizeof(double), ctx->pin_host_atm);
+  for (int iq = 0; iq < nq && np; iq++)
+    pin_host_range(ctx, q[iq], (size_t) np * sizeof(double), ctx->pin_host_atm);
+  for (int k = 0; k < 4 && np; k++)
     HIPCHK(hipMemcpyAsync(ctx->d_arr[k], src[k], (size_t) np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   for (int iq = 0; iq < nq && np; iq++) {
     if (!q[iq])
@@ -1346,6 +1351,10 @@ int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *
   if (restore_external_order(ctx))
     return 1;
   double *dst[4] = { time, p, lon, lat };
+  for (int k = 0; k < 4 && ctx->np; k++)
+    pin_host_range(ctx, dst[k], (size_t) ctx->np * sizeof(double), ctx->pin_host_atm);
+  for (int iq = 0; iq < ctx->nq && q && ctx->np; iq++)
+    pin_host_range(ctx, q[iq], (size_t) ctx->np * sizeof(double), ctx->pin_host_atm);
   for (int k = 0; k < 4; k++)
     if (dst[k] && ctx->np)
       HIPCHK(hipMemcpyAsync(dst[k], ctx->d_arr[k], (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1649,6 +1658,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (value < 8 || value > 1048576)
       return fail(ctx, "step_blocks must be in 8 ... 1048576");
     ctx->step_blocks = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "pin_host_atm") == 0) {   // page-lock the arrays handed to mphip_update_atm / mphip_get_atm
+    ctx->pin_host_atm = value != 0;
     return 0;
   }
   if (strcmp(name, "pin_host_met") == 0) {   // page-lock the arrays handed to mphip_prefetch_met

@@ -226,9 +226,13 @@ class Simulation:
                                           *[_ptr(a, _dp) for a in arrs], qp))
 
     # -- mptrac_update_host ---------------------------------------------------
-    def get_atm(self):
-        out = {k: np.empty(self.n) for k in ("time", "p", "lon", "lat")}
-        q = np.empty((self.nq, self.n))
+    def get_atm(self, out=None):
+        """Particle arrays in the caller's order; `out` = a dict returned earlier, to download into the
+        same host arrays again (what a C caller's persistent atm_t does)."""
+        if out is None:
+            out = {k: np.empty(self.n) for k in ("time", "p", "lon", "lat")}
+            out["q"] = np.empty((self.nq, self.n))
+        q = out["q"]
         qp = (_dp * NQ_MAX)()
         for iq in range(self.nq):
             qp[iq] = _ptr(q[iq], _dp)

@@ -773,6 +773,8 @@ static void need_ctx(const ctl_t *ctl) {
     ERRMSG("Cannot initialise the HIP device (this build has no CPU path)!");
   if (ctl)
     HIP(mphip_set_option(g_ctx, "locality_sort_interval", ctl->hip_locality_interval));
+  /* atm_t lives from mptrac_alloc to mptrac_free: page-lock its arrays for the particle transfers */
+  HIP(mphip_set_option(g_ctx, "pin_host_atm", 1));
 }
 
 /* Device copies of the meteo snapshots are keyed on the host addresses, as

@@ -27,5 +27,17 @@ print(f"update_atm: {n_local * 8 * (4 + len(atm['q'])) / 1e6:.0f} MB in {dt * 1e
 t0 = time.perf_counter()
 g = s.get_atm()
 dt = time.perf_counter() - t0
-print(f"get_atm:    {dt * 1e3:.1f} ms")
+print(f"get_atm:    {dt * 1e3:.1f} ms (pageable host arrays)")
+# a C caller's atm_t is persistent: its arrays are page-locked on first use (option pin_host_atm)
+s.set_option("pin_host_atm", 1)
+for rep in range(3):
+    t0 = time.perf_counter()
+    s.get_atm(out=g)
+    dt = time.perf_counter() - t0
+    print(f"get_atm:    {dt * 1e3:.1f} ms (page-locked{', first call registers' if rep == 0 else ''})")
+t0 = time.perf_counter()
+s.update_atm(g)
+s.synchronize()
+dt = time.perf_counter() - t0
+print(f"update_atm: {dt * 1e3:.1f} ms (page-locked)")
 s.close()
