@@ -40,6 +40,8 @@ def run(mode):
         s.run_timestep(k * dt)
         spare[0].time = 3600.0 * 2
         s.prefetch_met(spare[0])
+        while not s.prefetch_done():      # steady state: this upload ran beside the previous interval's steps
+            time.sleep(0.001)
     s.synchronize()
     host_ms = []
     t0 = time.perf_counter()
