@@ -72,19 +72,21 @@ def algorithmic_bytes_per_pstep(workload, met, np_local):
              "C2": 64, "C1": 64}[workload]
     wind = met.nx * met.ny * met.np * 32            # {u,v,w,t} x 2 snapshots, float
     sfc = met.nx * met.ny * 64                      # 8 surface fields x 2 snapshots
-    # few particles on a large grid cannot touch every grid byte: the grid term is capped by the
-    # bytes the particles' own gathers add up to with no cache credit (secondary figure:
-    # RK4 advection 768 B, turbulent 64, mesoscale 192, convection 160, sedimentation 64 per particle-step)
-    gathered = {"C1": 768, "C2": 832}.get(workload, 1248) * float(np_local)
+    # few particles on a large grid cannot touch every grid byte: the grid term is capped by the bytes of
+    # the distinct records one particle's stencils cover (8 corners x 32 B {u,v,w,t} x 2 snapshots, 4 columns
+    # x 64 B surface fields; the Runge-Kutta stages and the other modules re-use them)
+    gathered = {"C1": 256, "C2": 512}.get(workload, 512) * float(np_local)
     met_bytes = min(float(wind + sfc), gathered)
     return state + met_bytes / float(np_local), state, met_bytes
 
 
-def build_inputs(workload, rank, world, steps_total):
+def build_inputs(workload, rank, world, steps_total, particles=None):
     from mptrac_amd.clim import load_clim_tropo
     from mptrac_amd.ctl import ctl_from_quantities
     from mptrac_amd.synth import synthetic_met, synthetic_particles
     grid, n_per_gpu, ctl, quantities, fields = WORKLOADS[workload]
+    if particles:
+        n_per_gpu = int(particles)
     ctl = dict(ctl)
     ctl.update(ctl_from_quantities(quantities))
     # one meteo interval long enough for all steps (synthetic: no file boundary)
@@ -125,6 +127,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)   # one meteo interval of the survey's control set (T_STOP 3600, DT_MOD 180)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--particles", type=float, default=0,
+                    help="particles per GPU instead of the workload's own count (density sweeps; the bench line says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -152,7 +156,7 @@ def main():
     from mptrac_amd import hip
 
     steps_total = args.warmup + args.steps + 1
-    ctl, clim, met0, met1, atm, n_local, n_total = build_inputs(args.workload, rank, world, steps_total)
+    ctl, clim, met0, met1, atm, n_local, n_total = build_inputs(args.workload, rank, world, steps_total, particles=args.particles)
     sim = hip.Simulation(ctl, clim, met0, met1, atm, device=local_rank,
                          shard=(rank * n_local, (rank + 1) * n_local), n_total=n_total)
     if use_dist:
@@ -216,6 +220,8 @@ def main():
             prof = json.load(open(tfile))
             traffic = prof.get(args.workload)
             valu_busy = prof.get("_valu_busy_frac", {}).get(args.workload)
+        if args.particles:      # the committed PMC profile belongs to the workload's own particle count
+            traffic = valu_busy = None
         out = {
             "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -229,6 +235,7 @@ def main():
                                     ("C5: C3 + module_sort + mixing every step, decay, wet and dry deposition"
                                      if args.workload == "C5" else args.workload)),
                        "particles_per_gpu": n_local, "particles_total": n_total,
+                       **({"particles_override": True} if args.particles else {}),
                        "grid": [met0.nx, met0.ny, met0.np], "dt_mod": dt,
                        "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
