@@ -1348,8 +1348,16 @@ int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *
   if (!ctx)
     return 1;
   HIPCHK(hipSetDevice(ctx->device));
-  if (restore_external_order(ctx))
-    return 1;
+  // The caller's order is produced in the alternate buffers (free between two sorts); the resident
+  // arrays keep their internal order, so an output costs one scatter pass and no re-sort.
+  double *const *srcs = ctx->d_arr;
+  if (!ctx->ext_identity && ctx->np) {
+    PermArgs g = perm_args(ctx, false);
+    const PermGeom pg = perm_geom(ctx->np);
+    hipLaunchKernelGGL(perm_scatter_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_ext, ctx->np, pg);
+    HIPCHK(hipGetLastError());
+    srcs = ctx->d_alt;
+  }
   double *dst[4] = { time, p, lon, lat };
   for (int k = 0; k < 4 && ctx->np; k++)
     pin_host_range(ctx, dst[k], (size_t) ctx->np * sizeof(double), ctx->pin_host_atm);
@@ -1357,10 +1365,10 @@ int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *
     pin_host_range(ctx, q[iq], (size_t) ctx->np * sizeof(double), ctx->pin_host_atm);
   for (int k = 0; k < 4; k++)
     if (dst[k] && ctx->np)
-      HIPCHK(hipMemcpyAsync(dst[k], ctx->d_arr[k], (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(dst[k], srcs[k], (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   for (int iq = 0; iq < ctx->nq; iq++)
     if (q && q[iq] && ctx->np)
-      HIPCHK(hipMemcpyAsync(q[iq], ctx->d_arr[4 + iq], (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost,
+      HIPCHK(hipMemcpyAsync(q[iq], srcs[4 + iq], (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost,
                             ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;

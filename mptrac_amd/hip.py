@@ -126,6 +126,7 @@ class Simulation:
         self.ctl = fill_ctl(MphipCtl(), **ctl_kw)
         self._cb = None
         self._mets = [None, None]
+        self._next_met = None
         time, lat, tropo = clim
         tropo = np.ascontiguousarray(tropo, dtype=np.float64)
         self._chk(self.L.mphip_update_clim(self.h, len(time), len(lat),
