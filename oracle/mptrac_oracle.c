@@ -6,6 +6,11 @@
  * (paths relative to the reference repo, mptrac.c = src/mptrac.c,
  * mptrac.h = src/mptrac.h).
  *
+ * Pinned (tests/test_oracle_pins.py) against the reference's own golden files: sedi.tab, the dd_test
+ * trajectories, the met_sample humidity table, the survey's known-answer values, and a whole stochastic
+ * run -- tests/coord_test, reproduced in every printed digit.  oracle/README.md lists what each pin fixes
+ * and which modules no reference artefact reaches.
+ *
  * Build: gcc -O3 -ffp-contract=off -fopenmp (oracle/Makefile).  Contraction is
  * switched off so that the arithmetic is the reference's gcc/x86-64 arithmetic
  * (no FMA), operation by operation.

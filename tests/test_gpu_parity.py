@@ -612,6 +612,28 @@ def test_cartesian_coordinates():
     s.close()
 
 
+def test_reference_coord_test_golden_on_the_device():
+    """The reference's own tests/coord_test golden files (see ref_coord.py and the oracle pin of the same
+    name) against the HIP back end: every printed digit of the four golden particle files, and the oracle
+    within the usual bar."""
+    import ref_coord as R
+    from mptrac_amd.ctl import ctl_from_quantities
+    mets = [R.load_met(h) for h in range(3)]
+    ctl = dict(R.CTL, **ctl_from_quantities(R.QUANTITIES))
+    from mptrac_amd.clim import load_clim_tropo
+    clim = load_clim_tropo()
+    s = hip.Simulation(ctl, clim, mets[0], mets[1], R.initial_particles())
+    s.timesteps_init(R.T0, R.T0)
+    worst = R.run_against_golden(s, mets)
+    assert worst["x"] <= R.TOL_XY and worst["y"] <= R.TOL_XY, worst
+    assert worst["z"] <= R.TOL_REL and worst["q"] <= R.TOL_REL, worst
+    o = B.Oracle(ctl, clim, mets[0], mets[1], R.initial_particles())
+    o.timesteps_init()
+    R.run_against_golden(o, mets)
+    _compare(o, s)
+    s.close()
+
+
 def test_full_size_stochastic_parity_1e6():
     """10^6 particles on the 137-level grid with every stochastic module on
     (random numbers depend on the global particle index, so the oracle runs the

@@ -163,3 +163,19 @@ def test_module_meteo_is_the_interpolation_plus_the_macros():
         assert q["lapse"][ip] == L.orc_lapse_rate(t, h2o)
         assert q["vh"][ip] == np.sqrt(q["u"][ip] ** 2 + q["v"][ip] ** 2)
     assert np.isnan(q["sst"]).any() and np.isfinite(q["sst"]).any()
+
+
+def test_coord_test_golden_of_the_reference():
+    """The reference's tests/coord_test end to end: its netCDF meteo files (UTM grid), 1000 parcels, two hours of
+    midpoint advection + turbulent + mesoscale diffusion (Squares generator, single-precision sine / cosine),
+    the meteo hand-over after one hour and module_meteo's t, u, v, w -- the oracle reproduces every printed digit
+    of the reference's own golden particle files."""
+    import ref_coord as R
+    from mptrac_amd.ctl import ctl_from_quantities
+    mets = [R.load_met(h) for h in range(3)]
+    ctl = dict(R.CTL, **ctl_from_quantities(R.QUANTITIES))
+    o = B.Oracle(ctl, load_clim_tropo(), mets[0], mets[1], R.initial_particles())
+    o.timesteps_init()
+    worst = R.run_against_golden(o, mets)
+    assert worst["x"] <= R.TOL_XY and worst["y"] <= R.TOL_XY, worst
+    assert worst["z"] <= R.TOL_REL and worst["q"] <= R.TOL_REL, worst
