@@ -614,7 +614,7 @@ def test_cartesian_coordinates():
 
 def test_reference_coord_test_golden_on_the_device():
     """The reference's own tests/coord_test golden files (see ref_coord.py and the oracle pin of the same
-    name) against the HIP back end: every printed digit of the four golden particle files, and the oracle
+    name) against the HIP back end: every printed digit of the thirteen golden particle files, and the oracle
     within the usual bar."""
     import ref_coord as R
     from mptrac_amd.ctl import ctl_from_quantities

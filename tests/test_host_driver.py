@@ -133,6 +133,43 @@ def test_trac_with_meteo_read_ahead(tmp_path):
 
 
 @pytest.mark.gpu
+def test_trac_writes_the_reference_coord_test_files_byte_for_byte(tmp_path):
+    """The reference's tests/coord_test through the drop-in `trac` driver on the GPU: the control file and
+    command line of the reference's run.sh (its netCDF meteo files handed over as MET_TYPE 1 binaries, the
+    format this host layer reads), its input particle file, and the thirteen golden output files compared as
+    text -- identical bytes."""
+    import shutil
+    import ref_coord as R
+    tmp = str(tmp_path)
+    _, trac = build.build_host()
+    metbase = os.path.join(tmp, "era5_utm32")
+    for h in range(3):
+        m = R.load_met(h)
+        hf.write_met_bin(hf.met_filename(metbase, m.time), m)
+    # the particle file the reference's tools wrote carries the same text as its first output
+    shutil.copy(os.path.join(R.HERE, R.OUTPUTS[0]), os.path.join(tmp, "atm_split.tab"))
+    keys = {"NQ": 4, "QNT_NAME[0]": "t", "QNT_NAME[1]": "u", "QNT_NAME[2]": "v", "QNT_NAME[3]": "w",
+            "METBASE": metbase, "MET_TYPE": 1, "TRACER_CHEM": 0, "DIFFUSION": 1, "DT_MET": 3600.0,
+            "T_STOP": R.T0 + 7200.0}
+    hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
+    open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
+    r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_split.tab", "ATM_BASENAME", "atm",
+                        "MET_CAPE", "0", "DT_MOD", "600", "ATM_DT_OUT", "600", "MET_COORD_TYPE", "1",
+                        "MET_UTM_REF_LON", "11.5692782", "MET_UTM_REF_LAT", "48.1507476"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    for name in R.OUTPUTS.values():
+        got = open(os.path.join(tmp, name)).read()
+        ref = open(os.path.join(R.HERE, name)).read()
+        if got != ref:
+            gl, rl = got.splitlines(), ref.splitlines()
+            bad = [i for i in range(min(len(gl), len(rl))) if gl[i] != rl[i]]
+            raise AssertionError("%s: %d of %d lines differ, first: %r vs %r" % (
+                name, len(bad) + abs(len(gl) - len(rl)), len(rl), gl[bad[0]] if bad else None, rl[bad[0]] if bad else None))
+
+
+@pytest.mark.gpu
 def test_trac_balloon_isosurface_and_boundary_conditions(tmp_path):
     """ISOSURF 4 (the driver reads the BALLOON file at the first step) and BOUND_* keys through `trac`."""
     tmp = str(tmp_path)
