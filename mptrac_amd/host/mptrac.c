@@ -203,6 +203,8 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   for (int iq = 0; iq < ctl->nq; iq++) {
     scan_ctl(filename, argc, argv, "QNT_NAME", iq, "", ctl->qnt_name[iq]);
     scan_ctl(filename, argc, argv, "QNT_FORMAT", iq, "%g", ctl->qnt_format[iq]);
+    if (strcasecmp(ctl->qnt_name[iq], "aoa") == 0)   /* mptrac.c:6852-6853 */
+      sprintf(ctl->qnt_format[iq], "%%.2f");
     sprintf(ctl->qnt_unit[iq], "-");
     for (size_t k = 0; k < sizeof(qnt_units) / sizeof(qnt_units[0]); k++)
       if (strcasecmp(ctl->qnt_name[iq], qnt_units[k].name) == 0)
@@ -1125,15 +1127,75 @@ void mptrac_run_timestep(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t **met0,
 /* output                                                                     */
 /* -------------------------------------------------------------------------- */
 
+/* Temperature at an output cell centre for the implicit volume mixing ratio of
+ * write_grid: intpol_met_time_3d(..., init = 1) of the reference
+ * (mptrac.c:3112-3137) = intpol_met_space_3d on both snapshots with met0's
+ * indices and weights (mptrac.c:2985-3044; intpol_check_lon_lat 2755-2778,
+ * locate_irr 3495-3521, locate_reg 3559-3574).  One call per output cell and
+ * output time, on the host like the reference; particles are never
+ * interpolated here. */
+static int grid_locate_irr(const double *xx, const int n, const double x) {
+  int ilo = 0, ihi = n - 1, i = (ihi + ilo) >> 1;
+  if (xx[i] < xx[i + 1])
+    while (ihi > ilo + 1) {
+      i = (ihi + ilo) >> 1;
+      if (xx[i] > x)
+        ihi = i;
+      else
+        ilo = i;
+  } else
+    while (ihi > ilo + 1) {
+      i = (ihi + ilo) >> 1;
+      if (xx[i] <= x)
+        ihi = i;
+      else
+        ilo = i;
+    }
+  return ilo;
+}
+
+static double grid_temperature(const met_t *met0, const met_t *met1, const double ts, const double p,
+                               const double lon, const double lat) {
+  double lon2 = FMOD(lon, 360.);
+  if (lon2 < met0->lon[0])
+    lon2 += 360;
+  else if (lon2 > met0->lon[met0->nx - 1])
+    lon2 -= 360;
+  double lat2 = lat;
+  if (met0->lat[0] < met0->lat[met0->ny - 1])
+    lat2 = fmin(fmax(lat, met0->lat[0]), met0->lat[met0->ny - 1]);
+  else
+    lat2 = fmin(fmax(lat, met0->lat[met0->ny - 1]), met0->lat[0]);
+  const int ip = grid_locate_irr(met0->p, met0->np, p);
+  int ix = (int) ((lon2 - met0->lon[0]) / (met0->lon[1] - met0->lon[0]));
+  ix = ix < 0 ? 0 : (ix > met0->nx - 2 ? met0->nx - 2 : ix);
+  const int iy = grid_locate_irr(met0->lat, met0->ny, lat2);
+  const double wp = (met0->p[ip + 1] - p) / (met0->p[ip + 1] - met0->p[ip]);
+  const double wx = (met0->lon[ix + 1] - lon2) / (met0->lon[ix + 1] - met0->lon[ix]);
+  const double wy = (met0->lat[iy + 1] - lat2) / (met0->lat[iy + 1] - met0->lat[iy]);
+  double v[2];
+  const met_t *mm[2] = { met0, met1 };
+  for (int k = 0; k < 2; k++) {
+    const met_t *m = mm[k];
+    double a00 = wp * (m->t[ix][iy][ip] - m->t[ix][iy][ip + 1]) + m->t[ix][iy][ip + 1];
+    const double a01 = wp * (m->t[ix][iy + 1][ip] - m->t[ix][iy + 1][ip + 1]) + m->t[ix][iy + 1][ip + 1];
+    double a10 = wp * (m->t[ix + 1][iy][ip] - m->t[ix + 1][iy][ip + 1]) + m->t[ix + 1][iy][ip + 1];
+    const double a11 = wp * (m->t[ix + 1][iy + 1][ip] - m->t[ix + 1][iy + 1][ip + 1]) + m->t[ix + 1][iy + 1][ip + 1];
+    a00 = wy * (a00 - a01) + a01;
+    a10 = wy * (a10 - a11) + a11;
+    v[k] = wx * (a00 - a10) + a10;
+  }
+  const double wt = (met1->time - ts) / (met1->time - met0->time);
+  return wt * (v[0] - v[1]) + v[1];
+}
+
 void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1, const atm_t *atm,
                 const double t) {
   /* Binning and sums on the device (mphip_grid_sums; mptrac.c:13815-13872),
-   * post-processing and ASCII layout as mptrac.c:13875-13918, 13954-14056.
-   * The implicit volume mixing ratio needs the gridded temperature, which the
-   * reference interpolates on the host; it is written as NaN unless MOLMASS is
-   * unset (then the reference writes NaN as well). */
-  (void) met0;
-  (void) met1;
+   * post-processing and ASCII layout as mptrac.c:13875-13918, 13954-14056;
+   * the implicit volume mixing ratio (MOLMASS set, mass quantity present) uses
+   * the temperature at the cell centre, interpolated on the host as in the
+   * reference. */
   (void) atm;
   if (ctl->met_coord_type != 0)
     ERRMSG("Only lat/lon grid supported");
@@ -1172,9 +1234,17 @@ void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1
       for (int iz = 0; iz < ctl->grid_nz; iz++) {
         const size_t idx = (size_t) ARRAY_3D(ix, iy, ctl->grid_ny, iz, ctl->grid_nz);
         const double cd = ctl->qnt_m >= 0 ? mean[(size_t) ctl->qnt_m * ncell + idx] / (1e6 * area) : NAN;
-        const double vmr_impl = NAN;
-        if (ctl->grid_sparse)
-          continue;   /* sparse output is keyed on vmr_impl > 0 in the reference */
+        double vmr_impl = NAN;   /* mptrac.c:13885-13900 */
+        if (ctl->qnt_m >= 0 && ctl->molmass > 0 && met0 != NULL && met1 != NULL) {
+          vmr_impl = 0;
+          if (mean[(size_t) ctl->qnt_m * ncell + idx] > 0) {
+            const double press = P(ctl->grid_z0 + dz * (iz + 0.5));
+            const double temp = grid_temperature(met0, met1, t, press, ctl->grid_lon0 + dlon * (ix + 0.5), lat);
+            vmr_impl = MA / ctl->molmass * cd / (100. * press / (RA * temp) * dz * 1e3);
+          }
+        }
+        if (ctl->grid_sparse && !(vmr_impl > 0))   /* sparse output keeps cells with vmr_impl > 0 only */
+          continue;
         fprintf(out, "%.2f %g %g %g %g %g %g %g %d", t, ctl->grid_z0 + dz * (iz + 0.5),
                 ctl->grid_lon0 + dlon * (ix + 0.5), lat, area, dz, cd, vmr_impl, np[idx]);
         for (int iq = 0; iq < ctl->nq; iq++) {

@@ -58,6 +58,14 @@ extern "C" {
 #ifndef RE
 #define RE 6367.421
 #endif
+#ifndef MA
+#define MA 28.9644            /* molar mass of dry air [g/mol], mptrac.h:297 */
+#endif
+#ifndef RI
+#define RI 8.3144598          /* ideal gas constant [J/(mol K)], mptrac.h:322 */
+#endif
+#define RA (1e3 * RI / MA)    /* specific gas constant of dry air, mptrac.h:317 */
+#define FMOD(x, y) ((x) - (int) ((x) / (y)) * (y))   /* mptrac.h:1121 */
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif

@@ -169,6 +169,73 @@ def test_trac_writes_the_reference_coord_test_files_byte_for_byte(tmp_path):
                 name, len(bad) + abs(len(gl) - len(rl)), len(rl), gl[bad[0]] if bad else None, rl[bad[0]] if bad else None))
 
 
+def _atm_test_run(tmp, extra_args=()):
+    """`trac` on the particle file of the reference's tests/atm_test (10000 parcels: aoa, m, vmr); the outputs at t = 0 are written
+    after the first call of the time step, which moves nothing (dt = 0)."""
+    import shutil
+    _, trac = build.build_host()
+    metbase = os.path.join(tmp, "met")
+    for k in range(2):
+        m = synthetic_met("tiny", 3600.0 * k, 1.0 + 0.1 * k)
+        hf.write_met_bin(hf.met_filename(metbase, m.time), m)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_atm_test")
+    shutil.copy(os.path.join(gold, "atm_2000_01_01_00_00_00.tab"), os.path.join(tmp, "atm_in.tab"))
+    keys = {"NQ": 3, "QNT_NAME[0]": "aoa", "QNT_NAME[1]": "m", "QNT_NAME[2]": "vmr", "METBASE": metbase, "MET_TYPE": 1,
+            "DT_MET": 3600, "DT_MOD": 180, "T_STOP": 180, "MET_DT_OUT": 0, "ATM_BASENAME": "atm",
+            "ATM_DT_OUT": 86400, "GRID_BASENAME": "grid", "GRID_DT_OUT": 86400, "GRID_NX": 72, "GRID_NY": 36}
+    hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
+    open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
+    r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in.tab", *extra_args],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    return gold
+
+
+@pytest.mark.gpu
+def test_trac_grid_and_particle_files_equal_the_reference_atm_test_goldens(tmp_path):
+    """Gridded output (binning on the device, post-processing and text layout on the host) and the ASCII
+    particle reader / writer against the reference's tests/atm_test: the `atm2grid` golden
+    (72 x 36 cells, column density, particle counts, means of aoa / m / vmr) and the particle file itself,
+    byte for byte."""
+    tmp = str(tmp_path)
+    gold = _atm_test_run(tmp)
+    for name in ("grid_2000_01_01_00_00_00.tab", "atm_2000_01_01_00_00_00.tab"):
+        got, ref = open(os.path.join(tmp, name)).read(), open(os.path.join(gold, name)).read()
+        if got != ref:
+            gl, rl = got.splitlines(), ref.splitlines()
+            bad = [i for i in range(min(len(gl), len(rl))) if gl[i] != rl[i]]
+            raise AssertionError("%s: %d lines differ, first: %r vs %r" % (name, len(bad), gl[bad[0]], rl[bad[0]]))
+
+
+@pytest.mark.gpu
+def test_trac_grid_implicit_volume_mixing_ratio(tmp_path):
+    """MOLMASS set: column 8 of the grid file = MA / MOLMASS * column density / (rho(p, T) * dz), T interpolated
+    to the cell centre from the two snapshots (mptrac.c:13885-13900)."""
+    tmp = str(tmp_path)
+    _atm_test_run(tmp, ("MOLMASS", "64.066"))
+    rows = np.array([[float(c) for c in ln.split()] for ln in open(os.path.join(tmp, "grid_2000_01_01_00_00_00.tab"))
+                     if ln.strip() and not ln.startswith("#")])
+    m0 = synthetic_met("tiny", 0.0, 1.0)
+    lon, lat, cd, vmr, cnt = rows[:, 2], rows[:, 3], rows[:, 6], rows[:, 7], rows[:, 8]
+    press = 1013.25 * np.exp(-40.0 / 7.0)
+    ip = np.searchsorted(-m0.p, -press) - 1
+    wp = (m0.p[ip + 1] - press) / (m0.p[ip + 1] - m0.p[ip])
+    temp = np.empty(len(rows))
+    for i in range(len(rows)):
+        ix = min(int((lon[i] - m0.lon[0]) / (m0.lon[1] - m0.lon[0])), m0.nx - 2)
+        iy = min(max(np.searchsorted(m0.lat, lat[i]) - 1, 0), m0.ny - 2)
+        wx = (m0.lon[ix + 1] - lon[i]) / (m0.lon[ix + 1] - m0.lon[ix])
+        wy = (m0.lat[iy + 1] - lat[i]) / (m0.lat[iy + 1] - m0.lat[iy])
+        T = m0.f3["t"].astype(np.float64)
+        col = lambda a, b: wp * (T[a, b, ip] - T[a, b, ip + 1]) + T[a, b, ip + 1]
+        a0 = wy * (col(ix, iy) - col(ix, iy + 1)) + col(ix, iy + 1)
+        a1 = wy * (col(ix + 1, iy) - col(ix + 1, iy + 1)) + col(ix + 1, iy + 1)
+        temp[i] = wx * (a0 - a1) + a1          # t = met0.time: the time weight is 1
+    expect = np.where(cnt > 0, 28.9644 / 64.066 * cd / (100.0 * press / (1e3 * 8.3144598 / 28.9644 * temp) * 90.0 * 1e3), 0.0)
+    assert cnt.sum() == 10000 and (vmr[cnt == 0] == 0).all()
+    assert np.allclose(vmr, expect, rtol=2e-5, atol=0)       # six printed digits of cd and vmr
+
+
 @pytest.mark.gpu
 def test_trac_balloon_isosurface_and_boundary_conditions(tmp_path):
     """ISOSURF 4 (the driver reads the BALLOON file at the first step) and BOUND_* keys through `trac`."""
