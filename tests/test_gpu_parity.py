@@ -612,6 +612,42 @@ def test_cartesian_coordinates():
     s.close()
 
 
+def test_reference_dd_test_golden_on_the_device():
+    """The reference's tests/dd_test goldens (144 parcels, six hours of midpoint advection through the
+    wind tool's solid-body rotation + decay bookkeeping, seven hourly files) against the HIP back end: every
+    printed digit of longitude, latitude and altitude -- the device twin of
+    test_oracle_pins.py::test_dd_test_golden_trajectories."""
+    import refcases
+    from mptrac_amd.clim import load_clim_tropo
+    ctl, atm, t0, gold = refcases.dd_test_case()
+    mets = [refcases.wind_tool_met(t0 + 3600.0 * i) for i in range(8)]
+    s = hip.Simulation(ctl, load_clim_tropo(), mets[0], mets[1], atm)
+    s.timesteps_init(t0, t0)
+    assert s.ctl.t_start == t0
+    imet, t, checked = 0, t0, 0
+    while True:
+        if t > mets[imet + 1].time:
+            imet += 1
+            s.swap_met(mets[imet + 1])
+        s.run_timestep(t)
+        hours = (t - t0) / 3600.0
+        if hours == int(hours):
+            g, st = gold[int(hours)], s.state()
+            idx = st["q"][0].astype(int)
+            order = np.argsort(idx)
+            assert np.array_equal(idx[order], g[:, 4].astype(int))
+            z = 7.0 * np.log(1013.25 / st["p"][order])
+            for col, arr in ((1, z), (2, st["lon"][order]), (3, st["lat"][order])):
+                assert all(refcases.fmt_g(a) == b for a, b in zip(arr, g[:, col])), (hours, col)
+            assert np.all(st["time"] == t)
+            checked += 1
+        if t >= ctl["t_stop"]:
+            break
+        t += ctl["dt_mod"]
+    assert checked == 7
+    s.close()
+
+
 def test_reference_coord_test_golden_on_the_device():
     """The reference's own tests/coord_test golden files (see ref_coord.py and the oracle pin of the same
     name) against the HIP back end: every printed digit of the thirteen golden particle files, and the oracle
