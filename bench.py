@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--particles", type=float, default=0,
                     help="particles per GPU instead of the workload's own count (density sweeps; the bench line says so)")
+    ap.add_argument("--eager-meteo", action="store_true",
+                    help="workload C3m: launch module_meteo inside every time step instead of before each output")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -162,6 +164,8 @@ def main():
     if use_dist:
         from mptrac_amd import dist as mdist
         sim.set_allreduce(mdist.make_allreduce_hook("cuda"))
+    if args.eager_meteo:
+        sim.set_option("lazy_meteo", 0)
     sim.timesteps_init(0.0, 0.0)
     dt = sim.ctl.dt_mod
 
@@ -230,7 +234,10 @@ def main():
             "config": {"workload": f"{args.workload}: BASELINE configs[2] -- 1e7 particles/GPU, RK4 advection + "
                                    "turbulent + mesoscale diffusion + convection + sedimentation, 721x361x137 "
                                    "synthetic ERA5-shaped grid" if args.workload == "C3" else
-                                   ("C3 + module_meteo every step (t, u, v, w, zg, pv, ps, pt)"
+                                   ("C3 + module_meteo every step (t, u, v, w, zg, pv, ps, pt); "
+                                    + ("launched in every step" if args.eager_meteo else
+                                       "scheduled every step, launched when its result can be seen -- here once, "
+                                       "before the gridded output (lazy_meteo)")
                                     if args.workload == "C3m" else
                                     ("C5: C3 + module_sort + mixing every step, decay, wet and dry deposition"
                                      if args.workload == "C5" else args.workload)),

@@ -250,7 +250,17 @@ int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
  *   "locality_tile" (default 8): edge, in grid columns, of the horizontal tiles of
  *   that order (tile, then level, then column within the tile).
  *   "step_blocks" (default 8192): upper bound of the step kernel's grid;
- *   "xcd_map" (default 1): give each XCD one contiguous eighth of the particles. */
+ *   "xcd_map" (default 1): give each XCD one contiguous eighth of the particles;
+ *   "lazy_meteo" (default 1): module_meteo (mptrac.c:7921-7924) writes quantities
+ *   no module reads, so the launch a time step schedules is held back until
+ *   its result can be seen -- mphip_get_atm, mphip_grid_sums, mphip_module --
+ *   or its inputs change (meteo / control uploads), and is dropped when the
+ *   next time step would overwrite it unseen; a time step that does not run
+ *   module_meteo evaluates a pending one first, before the particles move.
+ *   Downloads are bit-identical either way.  0 = launch it inside every step;
+ *   "pin_host_met" (default 1), "pin_host_atm" (default 0): page-lock the caller's
+ *   arrays handed to mphip_prefetch_met / mphip_update_atm + mphip_get_atm;
+ *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel. */
 int mphip_set_option(mphip_ctx *ctx, const char *name, double value);
 int mphip_synchronize(mphip_ctx *ctx);
 

@@ -54,6 +54,11 @@ struct mphip_ctx {
   hipStream_t copy_stream = nullptr;  // uploads of `next` run here, beside the kernels on `stream`
   hipEvent_t next_ready = nullptr;
   hipEvent_t main_mark = nullptr;     // copies into `next` start after the kernels queued so far (they may read its arrays)
+  // module_meteo only writes quantities nothing on the device reads: its launch is deferred until someone
+  // can see the result (a download, gridded output, a single-module call) or its inputs change; a pending
+  // launch that the next time step would overwrite unseen is dropped
+  bool lazy_meteo = true;
+  bool meteo_pending = false;
   bool pin_host_met = true;           // page-lock the caller's meteo arrays on first prefetch (async H2D needs it)
   bool pin_host_atm = false;          // page-lock the caller's particle arrays (persistent atm_t of a C caller only)
   std::vector<std::pair<void *, size_t>> pinned;
@@ -618,10 +623,11 @@ bool meteo_requested(const mphip_ctl_t &c) {
   return false;
 }
 
-int launch_meteo(mphip_ctx *ctx) {
+// checks of a module_meteo call (quantity indices, uploaded fields); 0 = fine
+int check_meteo(mphip_ctx *ctx) {
   const mphip_ctl_t &c = ctx->ctl;
   if (ctx->np == 0 || !meteo_requested(c))
-    return 0;   // nothing to set: every SET_ATM of the reference is a no-op
+    return 0;
   for (int k = 0; k < MPHIP_NMQ; k++)
     if (c.qnt_met[k] >= c.nq)
       return fail(ctx, "module_meteo: quantity index out of range");
@@ -633,17 +639,25 @@ int launch_meteo(mphip_ctx *ctx) {
   static const char *const n2[MPHIP_N2D] = { "ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "ess", "nss", "shf",
                                              "ts", "zs", "us", "vs", "lsm", "sst", "pt", "tt", "zt", "h2ot", "plcl",
                                              "plfc", "o3c" };
-  MeteoArgs G;
-  memset(&G, 0, sizeof(G));
   const MeteoDeps d = meteo_deps(c);
   for (int f = 0; f < MPHIP_N3D; f++)
     if (((d.need3 >> f) & 1u) && (!s0.has3[f] || !s1.has3[f]))
       return fail(ctx, std::string("module_meteo: meteo field ") + n3[f] + " was not uploaded");
-  if (ensure_packed(ctx))
-    return 1;
   for (int f = 0; f < MPHIP_N2D; f++)
     if (((d.need2 >> f) & 1u) && (!s0.has2[f] || !s1.has2[f]))
       return fail(ctx, std::string("module_meteo: meteo field ") + n2[f] + " was not uploaded");
+  return 0;
+}
+
+int launch_meteo(mphip_ctx *ctx) {
+  const mphip_ctl_t &c = ctx->ctl;
+  if (ctx->np == 0 || !meteo_requested(c))
+    return 0;   // nothing to set: every SET_ATM of the reference is a no-op
+  if (check_meteo(ctx) || ensure_packed(ctx))
+    return 1;
+  MeteoArgs G;
+  memset(&G, 0, sizeof(G));
+  const MeteoDeps d = meteo_deps(c);
   G.ctl = c;
   G.met = dev_met(ctx);
   G.atm = dev_atm(ctx);
@@ -659,6 +673,23 @@ int launch_meteo(mphip_ctx *ctx) {
   hipLaunchKernelGGL(meteo_kernel, dim3(nb), dim3(256), axes_lds_bytes(ctx), ctx->stream, G);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+// module_meteo of mphip_run_timestep: checked now, run when its result can be seen (lazy_meteo)
+int schedule_meteo(mphip_ctx *ctx) {
+  if (!ctx->lazy_meteo)
+    return launch_meteo(ctx);
+  if (check_meteo(ctx))
+    return 1;
+  ctx->meteo_pending = true;
+  return 0;
+}
+
+int flush_meteo(mphip_ctx *ctx) {
+  if (!ctx->meteo_pending)
+    return 0;
+  ctx->meteo_pending = false;
+  return launch_meteo(ctx);
 }
 
 PermGeom perm_geom(long long n) {
@@ -1079,6 +1110,8 @@ int mphip_update_ctl(mphip_ctx *ctx, const mphip_ctl_t *ctl) {
     return fail(ctx, "Set ADVECT_VERT_COORD to 0, 1, 2, or 3!");
   if (!(ctl->advect == 0 || ctl->advect == 1 || ctl->advect == 2 || ctl->advect == 4))
     return fail(ctx, "Set ADVECT to 1, 2, or 4!");
+  if (ctx->have_ctl && flush_meteo(ctx))   // a deferred module_meteo belongs to the old parameters
+    return 1;
   ctx->ctl = *ctl;
   ctx->have_ctl = true;
   return 0;
@@ -1124,6 +1157,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
       || met->np >= (1 << 24))
     return fail(ctx, "meteo grid too large for the device index arithmetic");
   HIPCHK(hipSetDevice(ctx->device));
+  if (flush_meteo(ctx))   // a deferred module_meteo samples the snapshots it was scheduled with
+    return 1;
   const int nml = met->npl > 0 ? met->npl : 0;
   const bool new_grid = (met->nx != ctx->nx || met->ny != ctx->ny || met->np != ctx->npl || nml != ctx->nml);
   if (new_grid) {
@@ -1187,6 +1222,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
 
 int mphip_swap_met(mphip_ctx *ctx) {
   if (!ctx)
+    return 1;
+  if (flush_meteo(ctx))
     return 1;
   ctx->flip ^= 1;
   ctx->packed_dirty = true;
@@ -1252,6 +1289,8 @@ int mphip_commit_met(mphip_ctx *ctx) {
   if (!ctx->next_pending)
     return fail(ctx, "no prefetched snapshot to commit");
   HIPCHK(hipSetDevice(ctx->device));
+  if (flush_meteo(ctx))
+    return 1;
   // kernels launched from here on wait for the upload; the host does not
   HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->next_ready, 0));
   std::swap(ctx->slot[0 ^ ctx->flip], ctx->next);   // the old met0 arrays become the next staging slot
@@ -1320,6 +1359,7 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
     ctx->d_kz = ctx->d_kz_alt = nullptr;
     ctx->sorted_buf = -1;
   }
+  ctx->meteo_pending = false;   // the uploaded quantity arrays replace whatever module_meteo would have written
   if (!fresh && restore_external_order(ctx))   // keep cache->uvwp with its slot across a re-upload
     return 1;
   ctx->ext_identity = true;
@@ -1348,6 +1388,8 @@ int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *
   if (!ctx)
     return 1;
   HIPCHK(hipSetDevice(ctx->device));
+  if (flush_meteo(ctx))
+    return 1;
   // The caller's order is produced in the alternate buffers (free between two sorts); the resident
   // arrays keep their internal order, so an output costs one scatter pass and no re-sort.
   double *const *srcs = ctx->d_arr;
@@ -1461,6 +1503,15 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   const mphip_ctl_t &c = ctx->ctl;
   const uint64_t n = (uint64_t) ctx->np_total;
   unsigned mask = MPHIP_MOD_TIMESTEPS;
+  // a deferred module_meteo of the previous step: dropped if this step runs module_meteo again (nobody
+  // saw its values), evaluated now -- before the particles move -- otherwise
+  {
+    const bool again = c.met_dt_out > 0 && (c.met_dt_out < c.dt_mod || fmod(t, c.met_dt_out) == 0);
+    if (again)
+      ctx->meteo_pending = false;
+    else if (flush_meteo(ctx))
+      return 1;
+  }
 
   // module_isosurf_init and module_advect_init at the first call (mptrac.c:7863-7870)
   if (t == c.t_start) {
@@ -1540,7 +1591,7 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   if (!mixing_now) {
     if (launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
       return 1;
-    return meteo_now ? launch_meteo(ctx) : 0;
+    return meteo_now ? schedule_meteo(ctx) : 0;
   }
   if (tail && (mask & MPHIP_MOD_TIMESTEPS))
     mask |= kStoreDt;
@@ -1548,7 +1599,7 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
     return 1;
   if (tail && launch_step(ctx, tail, t, 0, 0, 0))
     return 1;
-  return meteo_now ? launch_meteo(ctx) : 0;
+  return meteo_now ? schedule_meteo(ctx) : 0;
 }
 
 int mphip_module(mphip_ctx *ctx, unsigned modules, double t) {
@@ -1557,6 +1608,8 @@ int mphip_module(mphip_ctx *ctx, unsigned modules, double t) {
   if (!ctx->have_ctl)
     return fail(ctx, "control parameters were not uploaded");
   HIPCHK(hipSetDevice(ctx->device));
+  if (flush_meteo(ctx))
+    return 1;
   if (modules == MPHIP_MOD_SORT)
     return do_sort(ctx);
   if (modules == MPHIP_MOD_MIXING)
@@ -1615,6 +1668,8 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
   if (!ctx->have_ctl)
     return fail(ctx, "control parameters were not uploaded");
   HIPCHK(hipSetDevice(ctx->device));
+  if (flush_meteo(ctx))
+    return 1;
   const mphip_ctl_t &c = ctx->ctl;
   const size_t ncell = (size_t) c.grid_nx * c.grid_ny * c.grid_nz;
   const size_t total = ncell * (size_t) (1 + 2 * ctx->nq);
@@ -1666,6 +1721,12 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (value < 8 || value > 1048576)
       return fail(ctx, "step_blocks must be in 8 ... 1048576");
     ctx->step_blocks = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "lazy_meteo") == 0) {   // 0: run module_meteo inside every time step that schedules it
+    if (value == 0 && flush_meteo(ctx))
+      return 1;
+    ctx->lazy_meteo = value != 0;
     return 0;
   }
   if (strcmp(name, "pin_host_atm") == 0) {   // page-lock the arrays handed to mphip_update_atm / mphip_get_atm

@@ -445,6 +445,42 @@ def test_module_meteo_every_quantity():
         s.close()
 
 
+@pytest.mark.parametrize("case", ["meteo", "meteo_gated"])
+def test_deferred_module_meteo_is_not_observable(case):
+    """module_meteo of a time step is launched only when its result can be seen (option lazy_meteo, on by
+    default): with downloads, a gridded output, a meteo hand-over and module_sort in between, every download
+    carries the bits of the run that launches it inside each step.  `meteo_gated` (MET_DT_OUT 1800 > DT_MOD)
+    has steps without module_meteo, before which a pending launch must be evaluated."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=3000)
+    ctl["t_stop"] = 7200.0
+    m2 = synthetic_met("C1", 7200.0, 0.8, fields=tuple(m0.f3) + tuple(m0.f2))
+    runs = []
+    for lazy in (0, 1):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("lazy_meteo", lazy)
+        s.timesteps_init(0.0, 0.0)
+        seen, swapped = [], False
+        for k, t in enumerate(cases.step_times(s.ctl)):
+            if t > 3600.0 and not swapped:
+                s.swap_met(m2)
+                swapped = True
+            s.run_timestep(t)
+            if k in (0, 3, 4, 11, 25):
+                seen.append(s.state())
+            if k == 17:
+                seen.append(s.grid_sums(t))
+        seen.append(s.state())
+        runs.append(seen)
+        s.close()
+    for a, b in zip(*runs):
+        if isinstance(a, dict):
+            for key in ("time", "lon", "lat", "p", "q"):
+                assert np.array_equal(a[key], b[key], equal_nan=True), key
+        else:
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y, equal_nan=True)
+
+
 def test_module_meteo_missing_field_is_an_error():
     from mptrac_amd.ctl import ctl_from_quantities
     names = ("m", "t", "pv")
