@@ -241,7 +241,7 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
 int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
 
 /* Tuning knobs without a reference counterpart.
- *   "locality_sort_interval" (default 20): the device keeps the particles stored
+ *   "locality_sort_interval" (default 60): the device keeps the particles stored
  *   in meteo-grid-cell order and re-sorts every this many time steps so that
  *   the gathers of neighbouring particles share cache lines.  The order is
  *   internal: random numbers follow the external slot index and every download

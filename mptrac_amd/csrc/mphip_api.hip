@@ -96,7 +96,7 @@ struct mphip_ctx {
   // d_ext[i] is the external slot (the reference's ip) of stored particle i
   int *d_ext = nullptr, *d_ext_alt = nullptr;
   bool ext_identity = true;
-  int locality_interval = 20;         // re-sort every this many steps (0 = keep the caller's order)
+  int locality_interval = 60;         // re-sort every this many steps (0 = keep the caller's order)
   int locality_tile = 8;              // horizontal tile edge of the locality key (columns)
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;

@@ -358,7 +358,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
 
   /* back-end options */
   ctl->hip_device = (int) scan_ctl(filename, argc, argv, "HIP_DEVICE", -1, "0", NULL);
-  ctl->hip_locality_interval = (int) scan_ctl(filename, argc, argv, "HIP_LOCALITY_SORT_INTERVAL", -1, "20", NULL);
+  ctl->hip_locality_interval = (int) scan_ctl(filename, argc, argv, "HIP_LOCALITY_SORT_INTERVAL", -1, "60", NULL);
   ctl->hip_met_prefetch = (int) scan_ctl(filename, argc, argv, "HIP_MET_PREFETCH", -1, "0", NULL);
 
   /* what the device does not implement must not be requested silently */
