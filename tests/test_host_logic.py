@@ -186,3 +186,31 @@ def test_oracle_boundary_conditions_only_touch_the_region():
     for k in range(len(names)):
         if k not in (im, iv, ia):
             assert np.array_equal(o.q[k], q0[k])
+
+
+def test_host_layer_calendar_functions_match_the_reference_time_table():
+    """time2jsec / jsec2time of the host layer (they name the meteo and output files) against the reference's
+    tests/tools_test/data.ref/time.tab: 135 dates between 1900 and 2100, incl. hour 24 and day 31 of short
+    months (tests/tools_test/run.sh:13-25); the day-of-year lines of the table belong to tools outside this
+    repository's scope and are skipped."""
+    import ctypes as C
+    from mptrac_amd import build
+    lib, _ = build.build_host()
+    L = C.CDLL(lib)
+    L.time2jsec.argtypes = [C.c_int] * 6 + [C.c_double, C.POINTER(C.c_double)]
+    L.jsec2time.argtypes = [C.c_double] + [C.POINTER(C.c_int)] * 6 + [C.POINTER(C.c_double)]
+    lines = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tools_test", "time.tab")).read().splitlines()
+    k = 0
+    for year in (1900, 1980, 2000, 2020, 2100):
+        for mon in (1, 7, 12):
+            for day in (1, 15, 31):
+                for hour in (0, 12, 24):
+                    t = C.c_double()
+                    L.time2jsec(year, mon, day, hour, 0, 0, 0.0, C.byref(t))
+                    v = [C.c_int() for _ in range(6)]
+                    r = C.c_double()
+                    L.jsec2time(t.value, *[C.byref(x) for x in v], C.byref(r))
+                    got = "%d %d %d %d %d %d %g = %.2f" % (*[x.value for x in v], r.value, t.value)
+                    assert got == lines[k], (got, lines[k])
+                    k += 2
+    assert k == len(lines) == 270
