@@ -192,7 +192,10 @@ int mphip_swap_met(mphip_ctx *ctx);
  * met0 / met1 meanwhile.  mphip_commit_met() makes old met1 the new met0 and
  * the prefetched snapshot the new met1: the next kernel waits for the copy on
  * the device, the host does not block.  mphip_prefetch_done() = 1 once the
- * copies have finished.  Same grid dimensions as the resident snapshots
+ * copies have finished.  mphip_prefetch_met() is the one entry point that may
+ * be called from a second thread (a file reader) while another thread steps;
+ * everything else, the commit included, belongs to the stepping thread (the
+ * reference's interface is not re-entrant either).  Same grid dimensions as the resident snapshots
  * ("Meteo grid dimensions do not match!" otherwise, mptrac.c:6543-6546). */
 int mphip_prefetch_met(mphip_ctx *ctx, const mphip_met_t *met);
 int mphip_commit_met(mphip_ctx *ctx);

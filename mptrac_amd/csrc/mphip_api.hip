@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "mphip_kernels.hpp"
@@ -62,6 +63,7 @@ struct mphip_ctx {
   bool pin_host_met = true;           // page-lock the caller's meteo arrays on first prefetch (async H2D needs it)
   bool pin_host_atm = false;          // page-lock the caller's particle arrays (persistent atm_t of a C caller only)
   std::vector<std::pair<void *, size_t>> pinned;
+  std::mutex pinned_lock;             // mphip_prefetch_met may run on a reader thread beside the stepping thread
   int nx = 0, ny = 0, npl = 0, coord_type = 0;   // npl: pressure levels (met_t::np)
   int nml = 0;                                    // model levels (met_t::npl), 0 = none uploaded
   float *d_mlw = nullptr, *d_zl2 = nullptr, *d_pl2 = nullptr;
@@ -1236,6 +1238,7 @@ int mphip_swap_met(mphip_ctx *ctx) {
 static void pin_host_range(mphip_ctx *ctx, const void *ptr, size_t bytes, bool enabled) {
   if (!enabled || !ptr || !bytes)
     return;
+  std::lock_guard<std::mutex> guard(ctx->pinned_lock);
   for (auto &r : ctx->pinned)
     if (r.first == ptr && r.second >= bytes)
       return;
