@@ -1023,16 +1023,18 @@ struct SinCosTab {
   double c0, c1, c2, c3, c4, s1, s2, s3;
 };
 
-__device__ __forceinline__ float sincosf_poly(double x, double x2, double csign, int n) {
-  // csign = +1 -> table 0, -1 -> table 1 (cosine polynomial negated)
-  if ((n & 1) == 0) {
+// both polynomials of the reduced argument: sp = sine polynomial of x, cp = cosine polynomial with the
+// sign csign folded into its coefficients (as the library's two tables)
+__device__ __forceinline__ void sincosf_polys(double x, double x2, double csign, float &sp, float &cp) {
+  {
     const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
     const double x3 = x * x2;
     const double s1 = s2c + x2 * s3c;
     const double x7 = x3 * x2;
     const double s = x + x3 * s1c;
-    return (float) (s + x7 * s1);
-  } else {
+    sp = (float) (s + x7 * s1);
+  }
+  {
     const double c0 = csign * 0x1p0, c1c = csign * -0x1.ffffffd0c621cp-2, c2c = csign * 0x1.55553e1068f19p-5;
     const double c3c = csign * -0x1.6c087e89a359dp-10, c4c = csign * 0x1.99343027bf8c3p-16;
     const double x4 = x2 * x2;
@@ -1040,7 +1042,7 @@ __device__ __forceinline__ float sincosf_poly(double x, double x2, double csign,
     const double c1 = c0 + x2 * c1c;
     const double x6 = x4 * x2;
     const double c = c1 + x4 * c2c;
-    return (float) (c + x6 * c2);
+    cp = (float) (c + x6 * c2);
   }
 }
 
@@ -1048,12 +1050,14 @@ __device__ __forceinline__ uint32_t abstop12(float x) {
   return (__float_as_uint(x) >> 20) & 0x7ff;
 }
 
-// which = 0: sinf(y), which = 1: cosf(y), for 0 <= y < 120.  glibc branches to
-// shorter paths for |y| < pi/4 and |y| < 2^-12; the general path below returns
-// the same bits there (n = 0, x - 0 * hpi = x, and the polynomial rounds to y
-// resp. 1.0f), so it is used for every lane -- one eighth of the Box-Muller
-// angles would otherwise diverge.
-__device__ __forceinline__ float libm_sincosf(float y, int which) {
+// sinf(y) and cosf(y) for 0 <= y < 120.  glibc branches to shorter paths for |y| < pi/4 and |y| < 2^-12;
+// the general path below returns the same bits there (n = 0, x - 0 * hpi = x, and the polynomial rounds
+// to y resp. 1.0f), so it is used for every lane -- one eighth of the Box-Muller angles would otherwise
+// diverge.  The library evaluates one polynomial per function, chosen by the parity of the quadrant n:
+// sine -> (n even ? sine : cosine polynomial), cosine the other way round, same reduced argument and signs
+// for both; here each polynomial is evaluated once and the two results are assigned by that parity
+// (a branch on n would run both sides in every wavefront, twice).
+__device__ __forceinline__ void libm_sincosf_both(float y, float &sinv, float &cosv) {
   double x = (double) y;
   const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
   const double r = x * hpi_inv;
@@ -1062,7 +1066,18 @@ __device__ __forceinline__ float libm_sincosf(float y, int which) {
   const int q = n & 3;
   const double sgn = (q == 1 || q == 2) ? -1.0 : 1.0;
   const double csign = (n & 2) ? -1.0 : 1.0;
-  return sincosf_poly(x * sgn, x * x, csign, n ^ which);
+  float sp, cp;
+  sincosf_polys(x * sgn, x * x, csign, sp, cp);
+  const bool even = (n & 1) == 0;
+  sinv = even ? sp : cp;
+  cosv = even ? cp : sp;
+}
+
+// which = 0: sinf(y), which = 1: cosf(y)
+__device__ __forceinline__ float libm_sincosf(float y, int which) {
+  float sv, cv;
+  libm_sincosf_both(y, sv, cv);
+  return which ? cv : sv;
 }
 
 // Element i of the array module_rng(..., method = 1) would have produced for
@@ -1075,8 +1090,10 @@ __device__ __forceinline__ void normal_pair_from(uint64_t y, double &even, doubl
   const double r = fsqrt(-2.0 * log_unit(ua));
   const double phi = 2.0 * kPi * ub;
   const float phif = (float) phi;
-  even = r * libm_sincosf(phif, 1);
-  odd = r * libm_sincosf(phif, 0);
+  float sv, cv;
+  libm_sincosf_both(phif, sv, cv);
+  even = r * cv;
+  odd = r * sv;
 }
 
 __device__ __forceinline__ void normal_pair(uint64_t c0, uint64_t j2, double &even, double &odd) {
