@@ -132,8 +132,8 @@ def main():
     ap.add_argument("--eager-meteo", action="store_true",
                     help="workload C3m: launch module_meteo inside every time step instead of before each output")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=10 ** 6)
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-sample", type=int, default=2 * 10 ** 6)     # x 20 steps: about 10 s on 16 host cores
+    ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--use-torch", action="store_true", help="go through torch.distributed even at N = 1")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="(diagnostic) do not bracket the step kernel with HIP events; roofline is then not reported")
