@@ -156,6 +156,11 @@ def main():
         dist = mdist.init_process_group("nccl")
 
     from mptrac_amd import hip
+    if use_dist:
+        # should the in-tree library look stale on this box, one rank rebuilds it and the others wait
+        if local_rank == 0:
+            hip.load()
+        dist.barrier()
 
     steps_total = args.warmup + args.steps + 1
     ctl, clim, met0, met1, atm, n_local, n_total = build_inputs(args.workload, rank, world, steps_total, particles=args.particles)
