@@ -5,8 +5,11 @@ mirror of the reference's high-level interface (``mptrac_alloc`` ...
 There is no CPU fallback: if the HIP library or a device is missing, creating
 a ``Simulation`` raises.
 """
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 import numpy as np
 
@@ -43,6 +46,18 @@ _lib = None
 
 class MphipError(RuntimeError):
     pass
+
+
+_LIVE = weakref.WeakSet()     # contexts not closed yet: closed at exit while the HIP runtime is still up
+
+
+@atexit.register
+def _close_live_contexts():
+    for sim in list(_LIVE):
+        try:
+            sim.close()
+        except Exception:
+            pass
 
 
 def lib_path():
@@ -125,6 +140,7 @@ class Simulation:
             raise MphipError(f"mphip_create failed with code {rc} (no usable HIP device?)")
         self.ctl = fill_ctl(MphipCtl(), **ctl_kw)
         self._cb = None
+        _LIVE.add(self)
         self._mets = [None, None]
         self._next_met = None
         time, lat, tropo = clim
@@ -153,11 +169,16 @@ class Simulation:
             raise MphipError(self.L.mphip_last_error(self.h).decode())
 
     def close(self):
+        _LIVE.discard(self)
         if self.h:
             self.L.mphip_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
+        # not at interpreter shutdown: the HIP runtime may already be gone then (the atexit hook below
+        # has closed every live context before that)
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
