@@ -38,6 +38,7 @@ enum { MPHIP_U = 0, MPHIP_V, MPHIP_W, MPHIP_T, MPHIP_LWC, MPHIP_RWC, MPHIP_IWC, 
        MPHIP_H2O,   /* water vapour on pressure levels (module_diff_pbl, module_meteo) */
        /* read by module_meteo only (INTPOL_TIME_ALL, mptrac.h:1278-1318) */
        MPHIP_Z, MPHIP_PV, MPHIP_O3, MPHIP_CC,
+       MPHIP_WL,    /* vertical velocity on model levels (met_t wl), float [ix][iy][npl]: ADVECT_VERT_COORD 2 */
        MPHIP_N3D };
 /* 2-D meteo fields (met_t, mptrac.h:3886-3958), float [ix][iy] */
 enum { MPHIP_PS = 0, MPHIP_PBL, MPHIP_CAPE, MPHIP_CIN, MPHIP_PEL, MPHIP_PCT, MPHIP_PCB, MPHIP_CL,
@@ -100,7 +101,7 @@ typedef struct {
   int qnt_zeta, qnt_eta;
   int nens;
   int advect;
-  int advect_vert_coord;
+  int advect_vert_coord;   /* 0 pressure levels, 1 zeta, 2 pressure with model-level winds (pl, ul, vl, wl), 3 eta (mptrac.c:3609-3757) */
   int rng_type;
   int diffusion;
   int turb_pbl_scheme;

@@ -339,7 +339,8 @@ int ensure_packed(mphip_ctx *ctx) {
       any_mx = any_mx || ss[t]->has3[f];
     for (int f = MPHIP_TS; f <= MPHIP_O3C; f++)
       any_mx2 = any_mx2 || ss[t]->has2[f];
-    any_ml = any_ml || ss[t]->has3[MPHIP_UL] || ss[t]->has3[MPHIP_VL] || ss[t]->has3[MPHIP_ZETA_DOTL];
+    any_ml = any_ml || ss[t]->has3[MPHIP_UL] || ss[t]->has3[MPHIP_VL] || ss[t]->has3[MPHIP_ZETA_DOTL]
+      || ss[t]->has3[MPHIP_WL];
     any_pbl = any_pbl || ss[t]->has3[MPHIP_H2O] || ss[t]->has2[MPHIP_ESS] || ss[t]->has2[MPHIP_NSS]
       || ss[t]->has2[MPHIP_SHF];
   }
@@ -349,7 +350,10 @@ int ensure_packed(mphip_ctx *ctx) {
       && (dev_alloc(ctx, &ctx->d_mlw, 6 * ncell_ml) || dev_alloc(ctx, &ctx->d_zl2, 2 * ncell_ml)
           || dev_alloc(ctx, &ctx->d_pl2, 2 * ncell_ml) || dev_alloc(ctx, &ctx->d_ml_mono, 1)))
     return 1;
-  const bool ml_heights = any_ml && s0.has3[MPHIP_ZETAL] && s1.has3[MPHIP_ZETAL] && s0.has3[MPHIP_PL] && s1.has3[MPHIP_PL];
+  // packed height pairs: {zetal}, {pl}; ADVECT_VERT_COORD 2 searches in pl only
+  const bool coord2 = ctx->have_ctl && ctx->ctl.advect_vert_coord == 2;
+  const bool ml_heights = any_ml && s0.has3[MPHIP_PL] && s1.has3[MPHIP_PL]
+    && (coord2 || (s0.has3[MPHIP_ZETAL] && s1.has3[MPHIP_ZETAL]));
   if (ml_heights) {
     const int one = 1;
     HIPCHK(hipMemcpyAsync(ctx->d_ml_mono, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -378,6 +382,7 @@ int ensure_packed(mphip_ctx *ctx) {
   a.sfd = any_pbl ? ctx->d_sfd : nullptr;
   a.h2o = any_pbl ? ctx->d_h2o : nullptr;
   a.mlw = any_ml ? ctx->d_mlw : nullptr;
+  a.mlw_third = coord2 ? MPHIP_WL : MPHIP_ZETA_DOTL;
   a.zl2 = ml_heights ? ctx->d_zl2 : nullptr;
   a.pl2 = ml_heights ? ctx->d_pl2 : nullptr;
   a.ml_mono = ctx->d_ml_mono;
@@ -430,7 +435,11 @@ int check_fields(mphip_ctx *ctx, unsigned mask) {
     if (need2(MPHIP_PS, "module_position"))
       return 1;
   const bool model_levels = (c.advect_vert_coord == 1 || c.advect_vert_coord == 3);
-  if ((mask & MPHIP_MOD_DIFF_MESO) || ((mask & MPHIP_MOD_ADVECT) && !model_levels))
+  if ((mask & MPHIP_MOD_ADVECT) && c.advect_vert_coord == 2)
+    if (need3(MPHIP_PL, "module_advect") || need3(MPHIP_UL, "module_advect") || need3(MPHIP_VL, "module_advect")
+        || need3(MPHIP_WL, "module_advect") || ctx->nml < 2)
+      return 1;
+  if ((mask & MPHIP_MOD_DIFF_MESO) || ((mask & MPHIP_MOD_ADVECT) && c.advect_vert_coord == 0))
     if (need3(MPHIP_U, "module_advect") || need3(MPHIP_V, "module_advect") || need3(MPHIP_W, "module_advect"))
       return 1;
   if (((mask & MPHIP_MOD_ADVECT) && model_levels) || (mask & MPHIP_MOD_ADVECT_INIT)) {
@@ -508,7 +517,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     return 0;
   if (ensure_packed(ctx) || check_fields(ctx, mask))
     return 1;
-  if ((ctx->ctl.advect_vert_coord == 1 || ctx->ctl.advect_vert_coord == 3) && !ctx->d_kz) {
+  if (ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3 && !ctx->d_kz) {
     const size_t n = (size_t) std::max<long long>(ctx->np, 1);
     if (dev_alloc(ctx, &ctx->d_kz, n) || dev_alloc(ctx, &ctx->d_kz_alt, n))
       return 1;
@@ -549,7 +558,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     e1 = ctx->ev[ctx->ev_used++];
     HIPCHK(hipEventRecord(e0, ctx->stream));
   }
-  const bool ml_ = (ctx->ctl.advect_vert_coord == 1 || ctx->ctl.advect_vert_coord == 3);
+  const bool ml_ = ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3;   // winds from the model levels
   // model levels: the fast path needs monotonic height columns and none of the rarely used modules
   const bool ml_fast = ml_ && ctx->ml_monotonic && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
   const bool rare = (ml_ && !ml_fast) || (mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u));
@@ -637,7 +646,7 @@ int check_meteo(mphip_ctx *ctx) {
   if (!s0.valid || !s1.valid)
     return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
   static const char *const n3[MPHIP_N3D] = { "u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "pl", "ul", "vl", "zetal",
-                                             "zeta_dotl", "h2o", "z", "pv", "o3", "cc" };
+                                             "zeta_dotl", "h2o", "z", "pv", "o3", "cc", "wl" };
   static const char *const n2[MPHIP_N2D] = { "ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "ess", "nss", "shf",
                                              "ts", "zs", "us", "vs", "lsm", "sst", "pt", "tt", "zt", "h2ot", "plcl",
                                              "plfc", "o3c" };
@@ -940,7 +949,7 @@ int upload_fields(mphip_ctx *ctx, MetSlot &S, const mphip_met_t *met, bool new_g
   const int nml = met->npl > 0 ? met->npl : 0;
   const size_t ncell = (size_t) met->nx * met->ny * met->np, ncol = (size_t) met->nx * met->ny;
   for (int f = 0; f < MPHIP_N3D; f++) {
-    const bool is_ml = f >= MPHIP_PL && f <= MPHIP_ZETA_DOTL;
+    const bool is_ml = (f >= MPHIP_PL && f <= MPHIP_ZETA_DOTL) || f == MPHIP_WL;
     const long long nlev = is_ml ? nml : met->np;
     const long long sx = is_ml ? met->sx_ml : met->sx, sy = is_ml ? met->sy_ml : met->sy;
     S.has3[f] = met->f3[f] != nullptr && nlev > 0;
@@ -1114,6 +1123,8 @@ int mphip_update_ctl(mphip_ctx *ctx, const mphip_ctl_t *ctl) {
     return fail(ctx, "Set ADVECT to 1, 2, or 4!");
   if (ctx->have_ctl && flush_meteo(ctx))   // a deferred module_meteo belongs to the old parameters
     return 1;
+  if (!ctx->have_ctl || ctx->ctl.advect_vert_coord != ctl->advect_vert_coord)
+    ctx->packed_dirty = true;               // the model-level wind records carry zeta_dot or omega
   ctx->ctl = *ctl;
   ctx->have_ctl = true;
   return 0;
@@ -1265,7 +1276,7 @@ int mphip_prefetch_met(mphip_ctx *ctx, const mphip_met_t *met) {
     HIPCHK(hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming));
   }
   for (int f = 0; f < MPHIP_N3D; f++) {
-    const bool is_ml = f >= MPHIP_PL && f <= MPHIP_ZETA_DOTL;
+    const bool is_ml = (f >= MPHIP_PL && f <= MPHIP_ZETA_DOTL) || f == MPHIP_WL;
     const long long nlev = is_ml ? nml : met->np;
     const long long sx = is_ml ? met->sx_ml : met->sx;
     if (met->f3[f] && nlev > 0)

@@ -1310,6 +1310,59 @@ __device__ __forceinline__ void advect_ml(const mphip_ctl_t &ctl, const DevMet &
     advect_ml_n<1>(M, A, P, zeta);
 }
 
+// module_advect with ADVECT_VERT_COORD 2 (mptrac.c:3609-3678, branch 3649-3659): the pressure-level
+// integrator with u, v, omega interpolated from the model levels -- intpol_met_4d_zeta with the pressure
+// field pl as the height variable, first call initialises the stencil, the two others re-use it
+template <int ADVECT>
+__device__ __forceinline__ void advect_mlp_n(const DevMet &M, const Axes &A, Particle &P) {
+  const int ct = M.coord_type;
+  const double dt = P.dt;
+  Stencil4 s;
+  double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0, x0 = 0, x1 = 0, x2 = 0;
+#pragma unroll
+  for (int i = 0; i < ADVECT; i++) {
+    double dts;
+    if (i == 0) {
+      dts = 0.0;
+      x0 = P.lon;
+      x1 = P.lat;
+      x2 = P.p;
+    } else {
+      dts = (i == 3 ? 1.0 : 0.5) * dt;
+      x0 = P.lon + dx2coord(ct, dts * u, P.lat);
+      x1 = P.lat + dy2coord(ct, dts * v);
+      x2 = P.p + dts * w;
+    }
+    stencil_4d(M, A, M.pll[0], M.pll[1], P.time + dts, x2, x0, x1, s);
+    MlCorners c;
+    load_ml(M, s, c);
+    u = ml_packed(c, s, 0);
+    v = ml_packed(c, s, 1);
+    w = ml_packed(c, s, 2);
+    double k = 1.0;
+    if (ADVECT == 2)
+      k = (i == 0 ? 0.0 : 1.0);
+    else if (ADVECT == 4)
+      k = (i == 0 || i == 3 ? 1.0 / 6.0 : 2.0 / 6.0);
+    um += k * u;
+    vm += k * v;
+    wm += k * w;
+  }
+  P.time += dt;
+  P.lon += dx2coord(ct, dt * um, (ADVECT == 2 ? x1 : P.lat));
+  P.lat += dy2coord(ct, dt * vm);
+  P.p += dt * wm;
+}
+
+__device__ __forceinline__ void advect_mlp(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P) {
+  if (ctl.advect == 4)
+    advect_mlp_n<4>(M, A, P);
+  else if (ctl.advect == 2)
+    advect_mlp_n<2>(M, A, P);
+  else
+    advect_mlp_n<1>(M, A, P);
+}
+
 // module_advect_init, mptrac.c:3777-3784: pressure consistent with zeta
 __device__ __forceinline__ double pressure_from_zeta(const DevMet &M, const Axes &A, double time, double zeta,
                                                      double lon, double lat) {
@@ -1563,6 +1616,61 @@ __device__ __forceinline__ void advect_ml_fast(const mphip_ctl_t &ctl, const Dev
     advect_ml_fast_n<2>(M, A, P, zeta, kz);
   else
     advect_ml_fast_n<1>(M, A, P, zeta, kz);
+}
+
+// ADVECT_VERT_COORD 2 on the packed pressure field (monotonic columns), as advect_mlp_n
+template <int ADVECT>
+__device__ __forceinline__ void advect_mlp_fast_n(const DevMet &M, const Axes &A, Particle &P, int &kz) {
+  const int ct = M.coord_type;
+  const double dt = P.dt;
+  Stencil4 s;
+  s.iz = kz;
+  double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0, x0 = 0, x1 = 0, x2 = 0;
+  MlCache mc;
+  ml_cache_reset(mc);
+#pragma unroll
+  for (int i = 0; i < ADVECT; i++) {
+    double dts;
+    if (i == 0) {
+      dts = 0.0;
+      x0 = P.lon;
+      x1 = P.lat;
+      x2 = P.p;
+    } else {
+      dts = (i == 3 ? 1.0 : 0.5) * dt;
+      x0 = P.lon + dx2coord(ct, dts * u, P.lat);
+      x1 = P.lat + dy2coord(ct, dts * v);
+      x2 = P.p + dts * w;
+    }
+    stencil_4d_fast(M, A, M.pl2, P.time + dts, x2, x0, x1, s.iz, s);
+    load_ml_cached(M, s, mc);
+    u = ml_packed(mc.c, s, 0);
+    v = ml_packed(mc.c, s, 1);
+    w = ml_packed(mc.c, s, 2);
+    double k = 1.0;
+    if (ADVECT == 2)
+      k = (i == 0 ? 0.0 : 1.0);
+    else if (ADVECT == 4)
+      k = (i == 0 || i == 3 ? 1.0 / 6.0 : 2.0 / 6.0);
+    um += k * u;
+    vm += k * v;
+    wm += k * w;
+  }
+  P.time += dt;
+  P.lon += dx2coord(ct, dt * um, (ADVECT == 2 ? x1 : P.lat));
+  P.lat += dy2coord(ct, dt * vm);
+  P.p += dt * wm;
+  kz = s.iz;
+}
+
+__device__ __forceinline__ void advect_mlp_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                                int &kz) {
+  if (ctl.advect == 4)
+    advect_mlp_fast_n<4>(M, A, P, kz);
+  else if (ctl.advect == 2)
+    advect_mlp_fast_n<2>(M, A, P, kz);
+  else
+    advect_mlp_fast_n<1>(M, A, P, kz);
 }
 
 __device__ __forceinline__ double pressure_from_zeta_fast(const DevMet &M, const Axes &A, double time, double zeta,

@@ -291,7 +291,13 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
       position(M, A, P);
     if (mask & MPHIP_MOD_ADVECT) {
       // model-level advection (ADVECT_VERT_COORD 1 / 3) runs in the generic instantiation only
-      if (CT == kMaskGeneric && (ctl.advect_vert_coord == 1 || ctl.advect_vert_coord == 3)) {
+      if (CT == kMaskGeneric && ctl.advect_vert_coord == 2) {
+        advect_mlp(ctl, M, A, P);      // pressure advection, winds from the model levels
+      } else if (CT == kMaskGenericML && ctl.advect_vert_coord == 2) {
+        int kz = a.kz[i];
+        advect_mlp_fast(ctl, M, A, P, kz);
+        a.kz[i] = kz;
+      } else if (CT == kMaskGeneric && (ctl.advect_vert_coord == 1 || ctl.advect_vert_coord == 3)) {
         const int qnt = ctl.advect_vert_coord == 1 ? ctl.qnt_zeta : ctl.qnt_eta;
         double zeta;
         advect_ml(ctl, M, A, P, zeta);
@@ -375,6 +381,7 @@ struct PackArgs {
   f32x4 *mx2;                      // [7][col] surface pairs of module_meteo (NULL: none)
   float *h2o;                      // {h2o}0 {h2o}1 (NULL: none)
   float *mlw;                      // model-level {ul,vl,zeta_dot} records (NULL: none)
+  int mlw_third;                   // MPHIP_ZETA_DOTL, or MPHIP_WL for ADVECT_VERT_COORD 2 ({ul,vl,wl})
   float *zl2, *pl2;                // model-level {zetal0,zetal1}, {pl0,pl1} pairs (NULL: none)
   int *ml_mono;                    // cleared to 0 by a thread that finds a non-monotonic height column
   int nml;                         // model levels
@@ -419,7 +426,7 @@ __global__ void pack_kernel(PackArgs a) {
       for (int t = 0; t < 2; t++) {
         a.mlw[6 * i + 3 * t + 0] = a.f3[t][MPHIP_UL] ? a.f3[t][MPHIP_UL][i] : 0.f;
         a.mlw[6 * i + 3 * t + 1] = a.f3[t][MPHIP_VL] ? a.f3[t][MPHIP_VL][i] : 0.f;
-        a.mlw[6 * i + 3 * t + 2] = a.f3[t][MPHIP_ZETA_DOTL] ? a.f3[t][MPHIP_ZETA_DOTL][i] : 0.f;
+        a.mlw[6 * i + 3 * t + 2] = a.f3[t][a.mlw_third] ? a.f3[t][a.mlw_third][i] : 0.f;
       }
   if (a.zl2) {
     for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < a.ncell_ml; i += stride)

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import build as _build
 from .ctl import fill_ctl, make_ctl_struct
-from .synth import FIELDS_2D, FIELDS_3D
+from .synth import FIELDS_2D, FIELDS_3D, FIELDS_ML
 
 NQ_MAX = 16
 MOD = {
@@ -193,7 +193,7 @@ class Simulation:
         m.time, m.coord_type, m.nx, m.ny, m.np = met.time, met.coord_type, met.nx, met.ny, met.np
         m.lon, m.lat, m.p = _ptr(met.lon, _dp), _ptr(met.lat, _dp), _ptr(met.p, _dp)
         m.sx, m.sy, m.sx2 = met.ny * met.np, met.np, met.ny
-        m.npl = met.npl if any(k in met.f3 for k in ("pl", "ul", "vl", "zetal", "zeta_dotl")) else 0
+        m.npl = met.npl if any(k in met.f3 for k in FIELDS_ML) else 0
         m.sx_ml, m.sy_ml = met.ny * met.npl, met.npl
         for i, k in enumerate(FIELDS_3D):
             m.f3[i] = _ptr(met.f3[k], _fp) if k in met.f3 else None

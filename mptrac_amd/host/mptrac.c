@@ -370,6 +370,14 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
     ERRMSG("Please add zeta to your quantities for diabatic calculations!");   /* mptrac.c:6992 */
   if (ctl->advect_vert_coord == 3 && ctl->qnt_eta < 0)
     ERRMSG("Please add eta to your quantities for etadot calculations!");      /* mptrac.c:6994 */
+  /* MET_TYPE 1 files carry pressure-level fields only (mptrac.c:8887-9043); the model-level options of
+   * the back end are reached through the C ABI (mphip_update_met with pl, ul, vl, wl, zetal, zeta_dotl) */
+  if (ctl->advect_vert_coord == 2)
+    ERRMSG("Using ADVECT_VERT_COORD = 2 requires meteo data on model levels!");            /* mptrac.c:7002 */
+  if (ctl->advect_vert_coord == 1)
+    ERRMSG("Please use meteo files in netcdf format for diabatic calculations.");           /* mptrac.c:7031 */
+  if (ctl->advect_vert_coord == 3)
+    ERRMSG("Please use meteo files in netcdf format for etadot calculations.");             /* mptrac.c:7034 */
 }
 
 /* -------------------------------------------------------------------------- */

@@ -15,8 +15,8 @@ H0 = 7.0       # mptrac.h:270
 
 # order = MPHIP_U ... / MPHIP_PS ... of include/mptrac_hip.h
 FIELDS_3D = ("u", "v", "w", "t", "lwc", "rwc", "iwc", "swc", "pl", "ul", "vl", "zetal", "zeta_dotl", "h2o",
-             "z", "pv", "o3", "cc")
-FIELDS_ML = ("pl", "ul", "vl", "zetal", "zeta_dotl")     # on model levels [nx][ny][npl]
+             "z", "pv", "o3", "cc", "wl")
+FIELDS_ML = ("pl", "ul", "vl", "zetal", "zeta_dotl", "wl")     # on model levels [nx][ny][npl]
 FIELDS_2D = ("ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "ess", "nss", "shf",
              "ts", "zs", "us", "vs", "lsm", "sst", "pt", "tt", "zt", "h2ot", "plcl", "plfc", "o3c")
 # read by module_meteo only; generated on request (fields=...)
@@ -113,7 +113,8 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
         ml = {"pl": pl, "zetal": zeta,
               "ul": 25.0 * amp * cphi * (1.0 + 0.2 * np.sin(0.2 * kk)) + 0.0 * lam,
               "vl": 4.0 * amp * np.sin(2.0 * lam) * cphi + 0.0 * kk,
-              "zeta_dotl": 2e-3 * amp * np.sin(lam) * cphi * np.sin(np.pi * kk / (npl_ml - 1))}
+              "zeta_dotl": 2e-3 * amp * np.sin(lam) * cphi * np.sin(np.pi * kk / (npl_ml - 1)),
+              "wl": 1.5e-3 * amp * np.sin(lam) * cphi * np.sin(np.pi * kk / (npl_ml - 1)) * (pl / 1000.0)}
         for name, expr in ml.items():
             if name in want:
                 f3[name] = np.broadcast_to(expr, shape_ml).astype(np.float32)

@@ -508,8 +508,16 @@ void orc_module_position(const orc_cache_t *cache, const orc_met_t *met0, const 
 
 /* ---- module_advect, pressure-level branch (mptrac.c:3609-3678) ---------- */
 
+/* indices/weights of intpol_met_4d_zeta: ci[3], cw[4] */
+typedef struct {
+  int ix, iy, iz;
+  double wx, wy, wz, wt;
+} stencil4_t;
+
 static void advect_model_levels(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
                                 const orc_met_t *met1, orc_atm_t *atm);
+static double intpol_4d_zeta(const orc_met_t *m0, int fh, int fa, const orc_met_t *m1, double ts, double height,
+                             double lon, double lat, stencil4_t *s, int init);
 
 void orc_module_advect(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
                        const orc_met_t *met1, orc_atm_t *atm) {
@@ -524,6 +532,7 @@ void orc_module_advect(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc
       continue;
     const double dt = cache->dt[ip];
     stencil_t s = STENCIL_ZERO;
+    stencil4_t s4 = { 0, 0, 0, 0, 0, 0, 0 };
     double u[4], v[4], w[4], um = 0, vm = 0, wm = 0;
     double x0 = 0, x1 = 0, x2 = 0;
     for (int i = 0; i < ctl->advect; i++) {
@@ -540,9 +549,15 @@ void orc_module_advect(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc
         x2 = atm->p[ip] + dts * w[i - 1];
       }
       const double tm = atm->time[ip] + dts;
-      u[i] = time_3d(met0, met1, ORC_U, tm, x2, x0, x1, &s, 1);
-      v[i] = time_3d(met0, met1, ORC_V, tm, x2, x0, x1, &s, 0);
-      w[i] = time_3d(met0, met1, ORC_W, tm, x2, x0, x1, &s, 0);
+      if (ctl->advect_vert_coord == 0) {
+        u[i] = time_3d(met0, met1, ORC_U, tm, x2, x0, x1, &s, 1);
+        v[i] = time_3d(met0, met1, ORC_V, tm, x2, x0, x1, &s, 0);
+        w[i] = time_3d(met0, met1, ORC_W, tm, x2, x0, x1, &s, 0);
+      } else {   /* ADVECT_VERT_COORD 2: winds from the model levels, pressure as the height variable (mptrac.c:3649-3659) */
+        u[i] = intpol_4d_zeta(met0, ORC_PL, ORC_UL, met1, tm, x2, x0, x1, &s4, 1);
+        v[i] = intpol_4d_zeta(met0, ORC_PL, ORC_VL, met1, tm, x2, x0, x1, &s4, 0);
+        w[i] = intpol_4d_zeta(met0, ORC_PL, ORC_WL, met1, tm, x2, x0, x1, &s4, 0);
+      }
       double k = 1.0;
       if (ctl->advect == 2)
         k = (i == 0 ? 0.0 : 1.0);
@@ -589,12 +604,6 @@ static int locate_irr_float(const float *xx, int n, double x, int ig) {
   }
   return lo;
 }
-
-/* indices/weights of intpol_met_4d_zeta: ci[3], cw[4] */
-typedef struct {
-  int ix, iy, iz;
-  double wx, wy, wz, wt;
-} stencil4_t;
 
 /* time-then-horizontal interpolation of the height field at level k */
 static double height_at(const orc_met_t *m0, const float *h0, const float *h1, const stencil4_t *s, int k) {

@@ -34,7 +34,9 @@ enum { ORC_U = 0, ORC_V, ORC_W, ORC_T, ORC_LWC, ORC_RWC, ORC_IWC, ORC_SWC,
        ORC_PL, ORC_UL, ORC_VL, ORC_ZETAL, ORC_ZETA_DOTL,
        ORC_H2O,
        /* module_meteo only (INTPOL_TIME_ALL, mptrac.h:1278-1318) */
-       ORC_Z, ORC_PV, ORC_O3, ORC_CC, ORC_N3D };
+       ORC_Z, ORC_PV, ORC_O3, ORC_CC,
+       ORC_WL,      /* vertical velocity on model levels, float [nx][ny][npl] (ADVECT_VERT_COORD 2) */
+       ORC_N3D };
 /* 2-D met fields, each float [nx][ny] */
 enum { ORC_PS = 0, ORC_PBL, ORC_CAPE, ORC_CIN, ORC_PEL, ORC_PCT, ORC_PCB, ORC_CL,
        ORC_ESS, ORC_NSS, ORC_SHF,

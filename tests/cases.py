@@ -36,6 +36,10 @@ CASES = {
     "advect_zeta_midpoint": dict(BASE, advect=2, advect_vert_coord=1),
     "advect_eta": dict(BASE, advect_vert_coord=3),
     "zeta_full": dict(BASE, advect_vert_coord=1, diffusion=1, turb_dz_trop=0.1, conv_cape=0.0),
+    # ADVECT_VERT_COORD 2: pressure advection with u, v, omega interpolated from the model levels (mptrac.c:3649-3659)
+    "advect_mlp": dict(BASE, advect_vert_coord=2),
+    "advect_mlp_midpoint": dict(BASE, advect=2, advect_vert_coord=2),
+    "mlp_full": dict(BASE, advect_vert_coord=2, diffusion=1, turb_dz_trop=0.1, conv_cape=0.0),
     # Henry-law wet deposition with SO2 pH correction
     "wet_henry": dict(BASE, wet_depo_ic_h=(1.3e-2, 2900.0), wet_depo_bc_h=(1.3e-2, 2900.0),
                       wet_depo_so2_ph=4.5, wet_depo_ic_ret_ratio=0.5, wet_depo_bc_ret_ratio=0.3),
@@ -79,6 +83,7 @@ def make_case(name, n=10000, grid="C1", seed=12345, quantities=None, lon0=-180.0
     ml = ctl.get("advect_vert_coord", 0) in (1, 3)
     if quantities is None:
         quantities = CASE_QUANTITIES.get(name, QUANTITIES_ML if ml else QUANTITIES)
+    ml = ml or ctl.get("advect_vert_coord", 0) == 2      # model-level fields are generated
     if fields is None and not ml:
         fields = PRESSURE_LEVEL_FIELDS          # model-level fields only where they are used
         if name.startswith("meteo"):

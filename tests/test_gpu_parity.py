@@ -103,7 +103,8 @@ def test_rng_stream_matches_module_rng(ctr, n):
 # ---------------------------------------------------------------------------
 
 MODULE_CASES = [("position", "advect"), ("advect", "advect"), ("advect", "advect_midpoint"),
-                ("advect", "advect_zeta"), ("advect", "advect_eta"), ("diff_pbl", "pbl"), ("diff_pbl", "pbl_meso"),
+                ("advect", "advect_zeta"), ("advect", "advect_eta"), ("advect", "advect_mlp"),
+                ("advect", "advect_mlp_midpoint"), ("diff_pbl", "pbl"), ("diff_pbl", "pbl_meso"),
                 ("advect", "advect_euler"), ("diff_turb", "turb"), ("diff_meso", "diff"),
                 ("convection", "conv_sedi"), ("convection", "conv_thresh"), ("sedi", "conv_sedi"),
                 ("decay", "full"), ("wet_depo", "full"), ("wet_depo", "wet_henry"), ("dry_depo", "full"),
@@ -774,13 +775,14 @@ def test_wind_cache_with_cell_changes_in_every_stage(lon0, lat_reverse):
     s.close()
 
 
-def test_model_levels_with_a_non_monotonic_height_column():
+@pytest.mark.parametrize("case,field", [("zeta_full", "zetal"), ("mlp_full", "pl")])
+def test_model_levels_with_a_non_monotonic_height_column(case, field):
     """The packed model-level path needs strictly monotonic zetal / pl columns; a single column that is not
     (zeta can fold near the surface in real data) sends the launch to the instantiation that repeats the
     reference's bisection read by read -- same bits as the oracle either way."""
-    ctl, clim, m0, m1, atm = cases.make_case("zeta_full", n=4000)
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=4000)
     for m in (m0, m1):
-        z = m.f3["zetal"]
+        z = m.f3[field]
         z[100:140, 60:120, 3] = z[100:140, 60:120, 1] - 0.5      # a fold in the lowest levels of a patch
     o = B.Oracle(ctl, clim, m0, m1, atm)
     o.timesteps_init()
