@@ -361,7 +361,24 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   ctl->hip_locality_interval = (int) scan_ctl(filename, argc, argv, "HIP_LOCALITY_SORT_INTERVAL", -1, "60", NULL);
   ctl->hip_met_prefetch = (int) scan_ctl(filename, argc, argv, "HIP_MET_PREFETCH", -1, "0", NULL);
 
-  /* what the device does not implement must not be requested silently */
+  /* what this host layer / the device do not implement must not be requested silently: the reference's
+   * other output writers (mptrac.c:7574-7713), chemistry and radioactive decay switches (7386-7411),
+   * kernel-weighted and netCDF gridded output, domain decomposition */
+  {
+    static const char *const names[] = { "DEPO_BASENAME", "CSI_BASENAME", "ENS_BASENAME", "PROF_BASENAME",
+      "SAMPLE_BASENAME", "STAT_BASENAME", "VTK_BASENAME", "GRID_KERNEL", "ATM_GPFILE", "GRID_GPFILE", NULL };
+    char val[LEN];
+    for (int k = 0; names[k]; k++) {
+      scan_ctl(filename, argc, argv, names[k], -1, "-", val);
+      if (val[0] != '-')
+        ERRMSG("%s is not implemented in this host layer!", names[k]);
+    }
+    static const char *const switches[] = { "OH_CHEM_REACTION", "H2O2_CHEM_REACTION", "KPP_CHEM", "TRACER_CHEM",
+      "RADIO_DECAY", "GRID_TYPE", "DD", NULL };
+    for (int k = 0; switches[k]; k++)
+      if ((int) scan_ctl(filename, argc, argv, switches[k], -1, "0", NULL) != 0)
+        ERRMSG("%s is not implemented in this host layer!", switches[k]);
+  }
   if (ctl->rng_type != 1)
     ERRMSG("This build implements RNG_TYPE 1 (Squares) only!");
   if (ctl->advect_vert_coord < 0 || ctl->advect_vert_coord > 3)

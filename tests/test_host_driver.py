@@ -82,6 +82,22 @@ def test_trac_refuses_to_run_without_a_device(tmp_path):
     assert r.returncode != 0 and "HIP device" in out, out[-2000:]
 
 
+@pytest.mark.parametrize("args,msg", [(("CSI_BASENAME", "csi"), "CSI_BASENAME is not implemented"),
+                                      (("TRACER_CHEM", "1"), "TRACER_CHEM is not implemented"),
+                                      (("GRID_TYPE", "1"), "GRID_TYPE is not implemented"),
+                                      (("ADVECT_VERT_COORD", "2"), "requires meteo data on model levels"),
+                                      (("RNG_TYPE", "0"), "RNG_TYPE 1"),
+                                      (("QNT_NAME[2]", "tnat"), "tnat")])
+def test_trac_rejects_what_it_does_not_implement(tmp_path, args, msg):
+    """Control keys of the reference this host layer has no code for stop the run with a message instead of
+    being ignored (the reference ignores unknown keys, so a silent drop would look like a normal run)."""
+    trac, mets, atm = _setup(str(tmp_path), n=10, hours=1)
+    r = subprocess.run([trac, os.path.join(str(tmp_path), "dirlist"), "trac.ctl", "atm_in", *args],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode != 0 and msg in out, out[-1500:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("atm_type,pbl,meteo", [(1, False, False), (0, False, False), (1, True, False), (1, False, True)])
 def test_trac_end_to_end_matches_oracle(tmp_path, atm_type, pbl, meteo):
