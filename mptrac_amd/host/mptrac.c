@@ -184,7 +184,12 @@ static const struct {
 static const char *unsupported_qnt[] = {
   /* quantities module_meteo takes from the chemistry climatologies (mptrac.c:5129-5140, 5158-5163);
    * not provided */
-  "hno3", "oh", "h2o2", "ho2", "o1d", "tsts", "tnat", NULL
+  "hno3", "oh", "h2o2", "ho2", "o1d", "tsts", "tnat",
+  /* quantities only the chemistry, radioactive-decay and domain-decomposition code of the reference fills or
+   * mixes (SET_QNT table, mptrac.c:6905-6969): they would be carried along unchanged here */
+  "mloss_oh", "mloss_h2o2", "mloss_kpp", "Cx", "Ch2o", "Co3", "Cco", "Coh", "Ch", "Cho2", "Ch2o2", "Co1d", "Co3p",
+  "Cccl4", "Cccl3f", "Cccl2f2", "Cn2o", "Csf6", "Arn222", "Apb210", "Abe7", "Acs137", "Ai131", "Axe133",
+  "current_subdomain", "target_subdomain", NULL
 };
 
 void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
@@ -211,8 +216,8 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
         sprintf(ctl->qnt_unit[iq], "%s", qnt_units[k].unit);
     for (int k = 0; unsupported_qnt[k]; k++)
       if (strcasecmp(ctl->qnt_name[iq], unsupported_qnt[k]) == 0)
-        ERRMSG("Quantity %s needs the chemistry climatologies, which this build does not provide!",
-               ctl->qnt_name[iq]);
+        ERRMSG("Quantity %s is filled by the chemistry / climatology / decomposition code of the reference, "
+               "which this build does not provide!", ctl->qnt_name[iq]);
     const char *n = ctl->qnt_name[iq];
     if (!strcasecmp(n, "m")) ctl->qnt_m = iq;
     else if (!strcasecmp(n, "vmr")) ctl->qnt_vmr = iq;
