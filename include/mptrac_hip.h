@@ -262,6 +262,9 @@ int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
  *   next time step would overwrite it unseen; a time step that does not run
  *   module_meteo evaluates a pending one first, before the particles move.
  *   Downloads are bit-identical either way.  0 = launch it inside every step;
+ *   "fuse_sort" (default 1): inside mphip_run_timestep the gather of time, p,
+ *   lon, lat that module_sort ends with (mptrac.c:5944-5949) happens in the step
+ *   launch that follows; 0 = every array is re-ordered in module_sort's own pass;
  *   "pin_host_met" (default 1), "pin_host_atm" (default 0): page-lock the caller's
  *   arrays handed to mphip_prefetch_met / mphip_update_atm + mphip_get_atm;
  *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel. */

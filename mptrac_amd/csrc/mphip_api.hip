@@ -58,6 +58,8 @@ struct mphip_ctx {
   // module_meteo only writes quantities nothing on the device reads: its launch is deferred until someone
   // can see the result (a download, gridded output, a single-module call) or its inputs change; a pending
   // launch that the next time step would overwrite unseen is dropped
+  bool fuse_sort = true;              // module_sort's gather of time, p, lon, lat inside the following step launch
+  const int *fused_perm = nullptr;    // set by do_sort, consumed by the next launch_step
   bool lazy_meteo = true;
   bool meteo_pending = false;
   bool pin_host_met = true;           // page-lock the caller's meteo arrays on first prefetch (async H2D needs it)
@@ -185,6 +187,11 @@ DevAtm dev_atm(const mphip_ctx *c) {
   a.iso_ts = c->d_iso_ts;
   a.iso_ps = c->d_iso_ps;
   a.iso_n = c->iso_n;
+  a.perm = c->fused_perm;
+  a.s_time = c->d_alt[0];
+  a.s_p = c->d_alt[1];
+  a.s_lon = c->d_alt[2];
+  a.s_lat = c->d_alt[3];
   a.np = c->np;
   a.ip0 = c->ip0;
   a.np_total = c->np_total;
@@ -586,6 +593,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
       hipLaunchKernelGGL(step_kernel<kMaskGenericPL>, dim3(nb), dim3(256), lds, ctx->stream, S);
   }
   HIPCHK(hipGetLastError());
+  ctx->fused_perm = nullptr;   // module_sort's gather, if one was pending, has happened in this launch
   if (ctx->prof)
     HIPCHK(hipEventRecord(e1, ctx->stream));
   return 0;
@@ -857,11 +865,30 @@ int do_sort(mphip_ctx *ctx, const double *timestep_t = nullptr) {
   if (sort_pairs(ctx, 0, &cur, timestep_t))   // with timestep_t: module_timesteps in the key kernel
     return 1;
   ctx->sorted_buf = cur;
-  PermArgs g = perm_args(ctx, false);
   const PermGeom pg = perm_geom(n);
-  hipLaunchKernelGGL(perm_gather_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], n, pg);
-  HIPCHK(hipGetLastError());
-  perm_swap(ctx, false);
+  if (timestep_t && ctx->fuse_sort) {
+    // inside mphip_run_timestep the step launch that follows reads time, p, lon, lat through the
+    // permutation and writes them in the new order (DevAtm::perm); only the quantity arrays move here
+    PermArgs g;
+    memset(&g, 0, sizeof(g));
+    g.n8 = ctx->nq;
+    for (int k = 0; k < ctx->nq; k++) {
+      g.in8[k] = ctx->d_arr[4 + k];
+      g.out8[k] = ctx->d_alt[4 + k];
+    }
+    if (ctx->nq > 0) {
+      hipLaunchKernelGGL(perm_gather_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], n, pg);
+      HIPCHK(hipGetLastError());
+    }
+    for (int k = 0; k < 4 + ctx->nq; k++)
+      std::swap(ctx->d_arr[k], ctx->d_alt[k]);   // d_alt[0..3] now hold the pre-sort time, p, lon, lat
+    ctx->fused_perm = ctx->d_vals[cur];
+  } else {
+    PermArgs g = perm_args(ctx, false);
+    hipLaunchKernelGGL(perm_gather_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], n, pg);
+    HIPCHK(hipGetLastError());
+    perm_swap(ctx, false);
+  }
   ctx->steps_since_resort = 0;   // the observable order is a locality order already
   return 0;
 }
@@ -1735,6 +1762,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (value < 8 || value > 1048576)
       return fail(ctx, "step_blocks must be in 8 ... 1048576");
     ctx->step_blocks = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "fuse_sort") == 0) {    // 0: module_sort re-orders every array in its own pass
+    ctx->fuse_sort = value != 0;
     return 0;
   }
   if (strcmp(name, "lazy_meteo") == 0) {   // 0: run module_meteo inside every time step that schedules it

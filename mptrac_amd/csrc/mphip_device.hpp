@@ -81,6 +81,10 @@ struct DevAtm {
   int *kz;                       // model levels: vertical index of the last step (search hint only; NULL = none)
   const double *iso_ts, *iso_ps; // balloon time series of ISOSURF 4
   int iso_n;
+  // module_sort fused into the following step launch: particle i of the new order is read from slot perm[i]
+  // of the arrays below and written to slot i of time / p / lon / lat (NULL = read where it is written)
+  const int *perm;
+  const double *s_time, *s_p, *s_lon, *s_lat;
   long long np;                  // particles owned by this context
   long long ip0;                 // global index of the first one
   long long np_total;            // particles of the whole simulation

@@ -244,10 +244,19 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     const mphip_ctl_t &ctl = S.ctl;
 #endif
     Particle P;
-    P.time = a.time[i];
-    P.lon = a.lon[i];
-    P.lat = a.lat[i];
-    P.p = a.p[i];
+    const bool fused_sort = a.perm != nullptr;
+    if (fused_sort) {   // the gather of module_sort_help (mptrac.c:5944-5949) for time, p, lon, lat
+      const long long src = a.perm[i];
+      P.time = a.s_time[src];
+      P.lon = a.s_lon[src];
+      P.lat = a.s_lat[src];
+      P.p = a.s_p[src];
+    } else {
+      P.time = a.time[i];
+      P.lon = a.lon[i];
+      P.lat = a.lat[i];
+      P.p = a.p[i];
+    }
     if (CT == kMaskGeneric && (mask & (MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT))) {   // no dt guard (check_dt = 0)
       P.dt = 0;
       if (mask & MPHIP_MOD_ISOSURF_INIT)   // before module_advect_init, mptrac.c:7866-7870
@@ -269,6 +278,12 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     } else
       P.dt = a.dt[i];
     if (P.dt == 0) {   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
+      if (fused_sort) {
+        a.time[i] = P.time;
+        a.lon[i] = P.lon;
+        a.lat[i] = P.lat;
+        a.p[i] = P.p;
+      }
       if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))   // module_isosurf has check_dt = 0
         a.p[i] = isosurf_pressure(ctl, M, A, a, P, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
       continue;
@@ -339,9 +354,9 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     if (mask & MPHIP_MOD_POSITION2)
       position(M, A, P);
 
-    if (mask & MPHIP_MOD_ADVECT)
+    if ((mask & MPHIP_MOD_ADVECT) || fused_sort)
       a.time[i] = P.time;
-    if (mask & kMovers) {
+    if ((mask & kMovers) || fused_sort) {
       a.lon[i] = P.lon;
       a.lat[i] = P.lat;
       a.p[i] = P.p;
