@@ -188,8 +188,9 @@ int mphip_swap_met(mphip_ctx *ctx);
  * buffer, swap, mptrac.c:6479-6503) with the upload taken off the stepping
  * path: mphip_prefetch_met() starts the host-to-device copies of the NEXT
  * snapshot into a third staging slot on a copy stream and returns at once
- * (the caller's arrays are page-locked on first use, option "pin_host_met";
- * they must stay untouched until the commit); time steps keep running on
+ * (an uploader thread of the library issues the copies, which keep their
+ * calling thread busy for ordinary host memory; the caller's arrays must
+ * stay untouched until the commit); time steps keep running on
  * met0 / met1 meanwhile.  mphip_commit_met() makes old met1 the new met0 and
  * the prefetched snapshot the new met1: the next kernel waits for the copy on
  * the device, the host does not block.  mphip_prefetch_done() = 1 once the
@@ -251,7 +252,7 @@ int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
  *   internal: random numbers follow the external slot index and every download
  *   returns the caller's order, so results do not depend on the value.
  *   0 switches it off.
- *   "locality_tile" (default 8): edge, in grid columns, of the horizontal tiles of
+ *   "locality_tile" (default 0 = 4, or 8 with model-level winds): edge, in grid columns, of the horizontal tiles of
  *   that order (tile, then level, then column within the tile).
  *   "step_blocks" (default 8192): upper bound of the step kernel's grid;
  *   "xcd_map" (default 1): give each XCD one contiguous eighth of the particles;
@@ -265,8 +266,9 @@ int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
  *   "fuse_sort" (default 1): inside mphip_run_timestep the gather of time, p,
  *   lon, lat that module_sort ends with (mptrac.c:5944-5949) happens in the step
  *   launch that follows; 0 = every array is re-ordered in module_sort's own pass;
- *   "pin_host_met" (default 1), "pin_host_atm" (default 0): page-lock the caller's
- *   arrays handed to mphip_prefetch_met / mphip_update_atm + mphip_get_atm;
+ *   "pin_host_atm" (default 0): page-lock the caller's particle arrays handed to
+ *   mphip_update_atm / mphip_get_atm with one registration spanning them (for
+ *   a persistent atm_t whose arrays lie in one allocation);
  *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel. */
 int mphip_set_option(mphip_ctx *ctx, const char *name, double value);
 int mphip_synchronize(mphip_ctx *ctx);

@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "mphip_kernels.hpp"
@@ -62,10 +64,15 @@ struct mphip_ctx {
   const int *fused_perm = nullptr;    // set by do_sort, consumed by the next launch_step
   bool lazy_meteo = true;
   bool meteo_pending = false;
-  bool pin_host_met = true;           // page-lock the caller's meteo arrays on first prefetch (async H2D needs it)
   bool pin_host_atm = false;          // page-lock the caller's particle arrays (persistent atm_t of a C caller only)
-  std::vector<std::pair<void *, size_t>> pinned;
-  std::mutex pinned_lock;             // mphip_prefetch_met may run on a reader thread beside the stepping thread
+  // One page-locked span of caller memory (option pin_host_atm: the particle arrays of a persistent atm_t,
+  // which lie next to each other in one allocation); released by mphip_destroy.
+  std::vector<std::pair<uintptr_t, uintptr_t>> pinned;
+  std::mutex pinned_lock;
+  std::thread uploader;               // mphip_prefetch_met: issues the (blocking, pageable) copies beside the stepping thread
+  int uploader_rc = 0;
+  std::atomic<bool> uploader_done{ false };
+  std::string uploader_err;
   int nx = 0, ny = 0, npl = 0, coord_type = 0;   // npl: pressure levels (met_t::np)
   int nml = 0;                                    // model levels (met_t::npl), 0 = none uploaded
   float *d_mlw = nullptr, *d_zl2 = nullptr, *d_pl2 = nullptr;
@@ -101,7 +108,7 @@ struct mphip_ctx {
   int *d_ext = nullptr, *d_ext_alt = nullptr;
   bool ext_identity = true;
   int locality_interval = 60;         // re-sort every this many steps (0 = keep the caller's order)
-  int locality_tile = 8;              // horizontal tile edge of the locality key (columns)
+  int locality_tile = 0;              // horizontal tile edge of the locality key (columns); 0 = 4, or 8 with model-level winds
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;
   bool force_generic = false;
@@ -837,7 +844,10 @@ int locality_sort(mphip_ctx *ctx) {
   if (ensure_packed(ctx))
     return 1;
   int cur = 0;
-  if (sort_pairs(ctx, ctx->locality_tile, &cur))
+  // measured (tools/gpu_ablate.py tiles): 4 x 4 columns for the pressure-level kernels, 8 x 8 for the model-level ones
+  const bool ml_winds = ctx->have_ctl && ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3;
+  const int tile = ctx->locality_tile > 0 ? ctx->locality_tile : (ml_winds ? 8 : 4);
+  if (sort_pairs(ctx, tile, &cur))
     return 1;
   PermArgs g = perm_args(ctx, true);
   g.ext_in = ctx->ext_identity ? nullptr : ctx->d_ext;
@@ -971,6 +981,14 @@ int do_mixing(mphip_ctx *ctx, double t) {
   return 0;
 }
 
+void unpin_all(mphip_ctx *ctx, std::vector<std::pair<uintptr_t, uintptr_t>> &list) {
+  std::lock_guard<std::mutex> guard(ctx->pinned_lock);
+  for (auto &r : list)
+    if (hipHostUnregister((void *) r.first) != hipSuccess)
+      (void) hipGetLastError();
+  list.clear();
+}
+
 // host -> device copies of one snapshot's fields into the staging arrays of slot S (asynchronous on `stream`)
 int upload_fields(mphip_ctx *ctx, MetSlot &S, const mphip_met_t *met, bool new_grid, hipStream_t stream) {
   const int nml = met->npl > 0 ? met->npl : 0;
@@ -1070,6 +1088,8 @@ void mphip_destroy(mphip_ctx *ctx) {
     return;
   (void) hipSetDevice(ctx->device);
   (void) hipStreamSynchronize(ctx->stream);
+  if (ctx->uploader.joinable())
+    ctx->uploader.join();
   if (ctx->copy_stream) {
     (void) hipStreamSynchronize(ctx->copy_stream);
     (void) hipStreamDestroy(ctx->copy_stream);
@@ -1078,8 +1098,7 @@ void mphip_destroy(mphip_ctx *ctx) {
     (void) hipEventDestroy(ctx->next_ready);
   if (ctx->main_mark)
     (void) hipEventDestroy(ctx->main_mark);
-  for (auto &r : ctx->pinned)
-    (void) hipHostUnregister(r.first);
+  unpin_all(ctx, ctx->pinned);
   for (MetSlot *s : { &ctx->slot[0], &ctx->slot[1], &ctx->next }) {
     for (auto p : s->f3)
       dev_free(p);
@@ -1211,6 +1230,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     ctx->ny = met->ny;
     ctx->npl = met->np;
     ctx->nml = nml;
+    if (ctx->uploader.joinable())
+      ctx->uploader.join();
     if (ctx->copy_stream)
       HIPCHK(hipStreamSynchronize(ctx->copy_stream));
     for (auto &q : ctx->next.f3) {
@@ -1270,18 +1291,31 @@ int mphip_swap_met(mphip_ctx *ctx) {
   return 0;
 }
 
-// Page-lock a caller array once (the reference re-uses its two met_t buffers for the whole run), so
-// that the copies of mphip_prefetch_met really are asynchronous.  Failure is not an error: the copy
-// then goes through the runtime's staging buffers.
-static void pin_host_range(mphip_ctx *ctx, const void *ptr, size_t bytes, bool enabled) {
-  if (!enabled || !ptr || !bytes)
+// Page-lock the caller's particle arrays (option pin_host_atm) with ONE registration spanning all of them:
+// a copy must lie inside a single registration, and neighbouring arrays of one allocation share pages, so
+// per-array registrations are not an option.  Only done when the arrays lie close together (the members of
+// an atm_t); failure is not an error -- the copies then go through the runtime's staging buffers.
+static void pin_host_span(mphip_ctx *ctx, const void *const *ptrs, int n, size_t bytes_each) {
+  if (!ctx->pin_host_atm || !bytes_each)
     return;
+  uintptr_t lo = ~(uintptr_t) 0, hi = 0;
+  size_t total = 0;
+  for (int k = 0; k < n; k++)
+    if (ptrs[k]) {
+      lo = std::min(lo, (uintptr_t) ptrs[k]);
+      hi = std::max(hi, (uintptr_t) ptrs[k] + bytes_each);
+      total += bytes_each;
+    }
+  if (!total || hi - lo > total + total / 2 + (1u << 20))
+    return;   // scattered arrays
   std::lock_guard<std::mutex> guard(ctx->pinned_lock);
   for (auto &r : ctx->pinned)
-    if (r.first == ptr && r.second >= bytes)
+    if (lo >= r.first && hi <= r.second)
       return;
-  if (hipHostRegister((void *) ptr, bytes, hipHostRegisterDefault) == hipSuccess)
-    ctx->pinned.emplace_back((void *) ptr, bytes);
+    else if (lo < r.second && hi > r.first)
+      return;   // partly covered by an earlier span: leave it alone
+  if (hipHostRegister((void *) lo, hi - lo, hipHostRegisterDefault) == hipSuccess)
+    ctx->pinned.emplace_back(lo, hi);
   else
     (void) hipGetLastError();
 }
@@ -1302,25 +1336,40 @@ int mphip_prefetch_met(mphip_ctx *ctx, const mphip_met_t *met) {
     HIPCHK(hipEventCreateWithFlags(&ctx->next_ready, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->main_mark, hipEventDisableTiming));
   }
-  for (int f = 0; f < MPHIP_N3D; f++) {
-    const bool is_ml = (f >= MPHIP_PL && f <= MPHIP_ZETA_DOTL) || f == MPHIP_WL;
-    const long long nlev = is_ml ? nml : met->np;
-    const long long sx = is_ml ? met->sx_ml : met->sx;
-    if (met->f3[f] && nlev > 0)
-      pin_host_range(ctx, met->f3[f], (size_t) met->nx * (size_t) sx * sizeof(float), ctx->pin_host_met);
-  }
-  for (int f = 0; f < MPHIP_N2D; f++)
-    if (met->f2[f])
-      pin_host_range(ctx, met->f2[f], (size_t) met->nx * (size_t) met->sx2 * sizeof(float), ctx->pin_host_met);
   // the staging arrays of `next` were met0 until the last commit: kernels queued before it may still read them
   HIPCHK(hipEventRecord(ctx->main_mark, ctx->stream));
   HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->main_mark, 0));
-  if (upload_fields(ctx, ctx->next, met, false, ctx->copy_stream))
-    return 1;
-  HIPCHK(hipEventRecord(ctx->next_ready, ctx->copy_stream));
-  ctx->next.time = met->time;
-  ctx->next.valid = true;
+  // Copies from ordinary (pageable) host memory keep the calling thread busy until they are done, and
+  // page-locking arrays the caller owns is fragile (a copy has to lie inside one registration, arrays of
+  // one allocation share pages, the caller may free them): an uploader thread of the library issues them
+  // instead.  mphip_commit_met / mphip_discard_prefetch join it.
+  const mphip_met_t desc = *met;
+  ctx->uploader_rc = 0;
+  ctx->uploader_done = false;
+  ctx->uploader_err.clear();
   ctx->next_pending = true;
+  ctx->next.time = met->time;
+  ctx->uploader = std::thread([ctx, desc]() {
+    int rc = hipSetDevice(ctx->device) == hipSuccess ? 0 : 1;
+    if (!rc)
+      rc = upload_fields(ctx, ctx->next, &desc, false, ctx->copy_stream);
+    if (!rc && hipEventRecord(ctx->next_ready, ctx->copy_stream) != hipSuccess)
+      rc = 1;
+    ctx->uploader_rc = rc;
+    ctx->uploader_done = true;
+  });
+  return 0;
+}
+
+// waits for the uploader thread; 0 = the snapshot is on its way (next_ready recorded)
+static int join_uploader(mphip_ctx *ctx) {
+  if (ctx->uploader.joinable())
+    ctx->uploader.join();
+  if (ctx->uploader_rc) {
+    ctx->next_pending = false;
+    ctx->next.valid = false;
+    return fail(ctx, "upload of the prefetched meteo snapshot failed: " + ctx->err);
+  }
   return 0;
 }
 
@@ -1330,10 +1379,11 @@ int mphip_commit_met(mphip_ctx *ctx) {
   if (!ctx->next_pending)
     return fail(ctx, "no prefetched snapshot to commit");
   HIPCHK(hipSetDevice(ctx->device));
-  if (flush_meteo(ctx))
+  if (join_uploader(ctx) || flush_meteo(ctx))
     return 1;
   // kernels launched from here on wait for the upload; the host does not
   HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->next_ready, 0));
+  ctx->next.valid = true;
   std::swap(ctx->slot[0 ^ ctx->flip], ctx->next);   // the old met0 arrays become the next staging slot
   ctx->flip ^= 1;                                    // old met1 -> met0, prefetched -> met1
   ctx->next.valid = false;
@@ -1348,6 +1398,7 @@ int mphip_discard_prefetch(mphip_ctx *ctx) {
   if (!ctx->next_pending)
     return 0;
   HIPCHK(hipSetDevice(ctx->device));
+  (void) join_uploader(ctx);
   HIPCHK(hipStreamSynchronize(ctx->copy_stream));
   ctx->next.valid = false;
   ctx->next_pending = false;
@@ -1357,7 +1408,8 @@ int mphip_discard_prefetch(mphip_ctx *ctx) {
 int mphip_prefetch_done(mphip_ctx *ctx) {
   if (!ctx || !ctx->next_pending)
     return 1;
-  return hipEventQuery(ctx->next_ready) == hipSuccess ? 1 : 0;
+  // the uploader thread has handed its last copy to the copy stream and that copy has finished
+  return ctx->uploader_done && hipEventQuery(ctx->next_ready) == hipSuccess ? 1 : 0;
 }
 
 int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_total, int nq, const double *time,
@@ -1410,10 +1462,12 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
   ctx->ip0 = ip0;
   ctx->np_total = np_total;
   const double *src[4] = { time, p, lon, lat };
-  for (int k = 0; k < 4 && np; k++)
-    pin_host_range(ctx, src[k], (size_t) np * sizeof(double), ctx->pin_host_atm);
-  for (int iq = 0; iq < nq && np; iq++)
-    pin_host_range(ctx, q[iq], (size_t) np * sizeof(double), ctx->pin_host_atm);
+  if (np) {
+    const void *all[4 + MPHIP_NQ_MAX] = { time, p, lon, lat };
+    for (int iq = 0; iq < nq; iq++)
+      all[4 + iq] = q[iq];
+    pin_host_span(ctx, all, 4 + nq, (size_t) np * sizeof(double));
+  }
   for (int k = 0; k < 4 && np; k++)
     HIPCHK(hipMemcpyAsync(ctx->d_arr[k], src[k], (size_t) np * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   for (int iq = 0; iq < nq && np; iq++) {
@@ -1442,10 +1496,12 @@ int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *
     srcs = ctx->d_alt;
   }
   double *dst[4] = { time, p, lon, lat };
-  for (int k = 0; k < 4 && ctx->np; k++)
-    pin_host_range(ctx, dst[k], (size_t) ctx->np * sizeof(double), ctx->pin_host_atm);
-  for (int iq = 0; iq < ctx->nq && q && ctx->np; iq++)
-    pin_host_range(ctx, q[iq], (size_t) ctx->np * sizeof(double), ctx->pin_host_atm);
+  if (ctx->np) {
+    const void *all[4 + MPHIP_NQ_MAX] = { time, p, lon, lat };
+    for (int iq = 0; iq < ctx->nq; iq++)
+      all[4 + iq] = q ? q[iq] : nullptr;
+    pin_host_span(ctx, all, 4 + ctx->nq, (size_t) ctx->np * sizeof(double));
+  }
   for (int k = 0; k < 4; k++)
     if (dst[k] && ctx->np)
       HIPCHK(hipMemcpyAsync(dst[k], srcs[k], (size_t) ctx->np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1778,10 +1834,6 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     ctx->pin_host_atm = value != 0;
     return 0;
   }
-  if (strcmp(name, "pin_host_met") == 0) {   // page-lock the arrays handed to mphip_prefetch_met
-    ctx->pin_host_met = value != 0;
-    return 0;
-  }
   if (strcmp(name, "xcd_map") == 0) {
     ctx->xcd_map = value != 0;
     return 0;
@@ -1791,8 +1843,8 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     return 0;
   }
   if (strcmp(name, "locality_tile") == 0) {
-    if (value < 1 || value > 64)
-      return fail(ctx, "locality_tile must be in 1 ... 64");
+    if (value < 0 || value > 64)
+      return fail(ctx, "locality_tile must be in 0 ... 64");
     ctx->locality_tile = (int) value;
     ctx->steps_since_resort = 1 << 30;
     return 0;
