@@ -1,6 +1,6 @@
 """Randomised module combinations against the oracle (GPU): every seed draws a control set (integrator,
 stochastic modules, convection, sedimentation, sort, mixing, decay, wet / dry deposition, boundary conditions,
-isosurface mode, meteo quantities, direction, grid orientation) and runs 12 steps through
+isosurface mode, meteo quantities, direction, grid orientation, vertical coordinate of the advection) and runs 12 steps through
 mphip_run_timestep.  Catches interactions between modules and between the kernel instantiations that the
 named cases do not cover."""
 import numpy as np
@@ -9,7 +9,7 @@ import pytest
 import cases
 from mptrac_amd import hip
 from mptrac_amd.ctl import ctl_from_quantities
-from mptrac_amd.synth import FIELDS_METEO_ONLY, synthetic_met, synthetic_particles
+from mptrac_amd.synth import FIELDS_METEO_ONLY, FIELDS_ML, synthetic_met, synthetic_particles
 from oracle import binding as B
 
 pytestmark = pytest.mark.gpu
@@ -49,7 +49,11 @@ def draw(seed):
                               size=4, replace=False))
         names += extra
         ctl.update(met_dt_out=pick(0.1, 1200.0))
-    ctl.update(ctl_from_quantities(names))
+    vert = pick(0, 0, 0, 1, 2, 3)         # winds from the model levels: zeta, pressure, eta coordinate
+    if vert:
+        names += ["zeta", "eta"]
+        ctl.pop("isosurf", None)
+    ctl.update(ctl_from_quantities(names), advect_vert_coord=vert)
     if not sedi:
         ctl["qnt_rp"] = ctl["qnt_rhop"] = -1
     n_steps = 12
@@ -62,10 +66,16 @@ def draw(seed):
 def test_random_module_combination(seed):
     ctl, names, geom = draw(seed)
     fields = cases.PRESSURE_LEVEL_FIELDS + FIELDS_METEO_ONLY
+    if ctl["advect_vert_coord"]:
+        fields = fields + FIELDS_ML
+        geom["lat_reverse"] = False
     t0, t1 = (0.0, 7200.0) if ctl["direction"] == 1 else (-7200.0, 0.0)
     m0 = synthetic_met(geom["grid"], t0, 1.0, fields=fields, lon0=geom["lon0"], lat_reverse=geom["lat_reverse"])
     m1 = synthetic_met(geom["grid"], t1, 1.25, fields=fields, lon0=geom["lon0"], lat_reverse=geom["lat_reverse"])
     atm = synthetic_particles(6000, seed=100 + seed, quantities=names, lon=(geom["lon0"], geom["lon0"] + 360.0))
+    for nq in ("zeta", "eta"):
+        if nq in names:      # a vertical coordinate inside the range of the synthetic zetal field
+            atm["q"][list(names).index(nq)] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
     if ctl.get("turb_pbl_scheme", 0):
         atm["p"][::2] = 1013.25 * np.exp(-(0.02 + 0.9 * (atm["lon"][::2] - geom["lon0"]) / 360.0) / 7.0)
     clim = cases.load_clim_tropo()
