@@ -85,6 +85,7 @@ struct mphip_ctx {
   float *d_wind = nullptr, *d_temp = nullptr;     // packed two-snapshot grids (layouts: mphip_device.hpp)
   f32x4 *d_mx = nullptr, *d_mx2 = nullptr;        // level / surface pair records of module_meteo
   f32x4 *d_cloud = nullptr, *d_sfa = nullptr, *d_sfb = nullptr, *d_sfc = nullptr, *d_sfd = nullptr;
+  f32x4 *d_cp2 = nullptr;                         // {cape,pel} pair records (module_convection)
   float *d_h2o = nullptr;
   bool packed_dirty = true;
 
@@ -214,6 +215,7 @@ DevMet dev_met(const mphip_ctx *c) {
   M.mx2 = c->d_mx2;
   M.sfa = c->d_sfa;
   M.sfb = c->d_sfb;
+  M.cp2 = c->d_cp2;
   M.sfc = c->d_sfc;
   M.sfd = c->d_sfd;
   M.h2o = c->d_h2o;
@@ -374,6 +376,8 @@ int ensure_packed(mphip_ctx *ctx) {
   }
   if (!ctx->d_wind && (dev_alloc(ctx, &ctx->d_wind, 6 * ncell) || dev_alloc(ctx, &ctx->d_temp, 2 * ncell)))
     return 1;
+  if (!ctx->d_cp2 && dev_alloc(ctx, &ctx->d_cp2, ncol))
+    return 1;
   if (!ctx->d_sfa && (dev_alloc(ctx, &ctx->d_sfa, ncol) || dev_alloc(ctx, &ctx->d_sfb, 2 * ncol)
                       || dev_alloc(ctx, &ctx->d_sfc, 2 * ncol)))
     return 1;
@@ -392,6 +396,7 @@ int ensure_packed(mphip_ctx *ctx) {
   a.mx2 = any_mx2 ? ctx->d_mx2 : nullptr;
   a.sfa = ctx->d_sfa;
   a.sfb = ctx->d_sfb;
+  a.cp2 = ctx->d_cp2;
   a.sfc = ctx->d_sfc;
   a.sfd = any_pbl ? ctx->d_sfd : nullptr;
   a.h2o = any_pbl ? ctx->d_h2o : nullptr;
@@ -1114,6 +1119,7 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_mx2);
   dev_free(ctx->d_sfa);
   dev_free(ctx->d_sfb);
+  dev_free(ctx->d_cp2);
   dev_free(ctx->d_sfc);
   dev_free(ctx->d_sfd);
   dev_free(ctx->d_h2o);
@@ -1256,6 +1262,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     ctx->d_mx = ctx->d_mx2 = nullptr;
     dev_free(ctx->d_sfa);
     dev_free(ctx->d_sfb);
+    dev_free(ctx->d_cp2);
+    ctx->d_cp2 = nullptr;
     dev_free(ctx->d_sfc);
     dev_free(ctx->d_sfd);
     dev_free(ctx->d_h2o);

@@ -49,6 +49,7 @@ struct DevMet {
   const f32x4 *mx2;      // [7][col]: {ts,zs} {us,vs} {lsm,sst} {pt,tt} {zt,h2ot} {plcl,plfc} {o3c,-} (optional)
   const f32x4 *sfa;      // [col]
   const f32x4 *sfb;      // [col][2]
+  const f32x4 *cp2;      // [col] {cape,pel}0 {cape,pel}1: what module_convection reads when CONV_CIN is off
   const f32x4 *sfc;      // [col][2]
   const f32x4 *sfd;      // [col][2] {ess,nss,shf,-}0 {..}1 (optional)
   const float *h2o;      // [cell][2] {h2o}0 {h2o}1 (optional)
@@ -1997,13 +1998,22 @@ __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet 
     ptop = pbl - ctl.conv_pbl_trans * (ps - pbl);
   }
   if (ctl.conv_cape >= 0) {
-    SurfB b;
-    load_sfb(M.sfb, M, s, b);
-    const double cape = sfb_time_2d(b, s, wt, 0);
-    const double cin = sfb_time_2d(b, s, wt, 1);
-    const double pel = sfb_time_2d(b, s, wt, 2);
-    if (isfinite(cape) && cape >= ctl.conv_cape && (ctl.conv_cin <= 0 || (isfinite(cin) && cin >= ctl.conv_cin)))
-      ptop = dmin(ptop, pel);
+    if (ctl.conv_cin <= 0) {   // CIN is not consulted: one 16-byte pair record per corner instead of two loads
+      SurfA b;
+      load_pair_2d(M.cp2, M, s, b);
+      const double cape = sfa_time_2d(b, s, wt, 0);
+      const double pel = sfa_time_2d(b, s, wt, 1);
+      if (isfinite(cape) && cape >= ctl.conv_cape)
+        ptop = dmin(ptop, pel);
+    } else {
+      SurfB b;
+      load_sfb(M.sfb, M, s, b);
+      const double cape = sfb_time_2d(b, s, wt, 0);
+      const double cin = sfb_time_2d(b, s, wt, 1);
+      const double pel = sfb_time_2d(b, s, wt, 2);
+      if (isfinite(cape) && cape >= ctl.conv_cape && isfinite(cin) && cin >= ctl.conv_cin)
+        ptop = dmin(ptop, pel);
+    }
   }
   if (ptop != pbot && P.p >= ptop) {
     const double tbot = temperature_at(M, A, P.time, pbot, P.lon, P.lat);

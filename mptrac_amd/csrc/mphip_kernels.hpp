@@ -392,6 +392,7 @@ struct PackArgs {
   const float *f2[2][MPHIP_N2D];
   float *wind, *temp;
   f32x4 *cloud, *sfa, *sfb, *sfc, *sfd;
+  f32x4 *cp2;                      // {cape,pel}0 {cape,pel}1 per column
   f32x4 *mx;                       // [2][cell] {z,pv}01, {o3,cc}01 (NULL: none)
   f32x4 *mx2;                      // [7][col] surface pairs of module_meteo (NULL: none)
   float *h2o;                      // {h2o}0 {h2o}1 (NULL: none)
@@ -467,7 +468,7 @@ __global__ void pack_kernel(PackArgs a) {
     }
   }
   for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < a.ncol; i += stride) {
-    f32x4 va;
+    f32x4 va, vp;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       va[2 * t] = a.f2[t][MPHIP_PS] ? a.f2[t][MPHIP_PS][i] : 0.f;
@@ -482,6 +483,8 @@ __global__ void pack_kernel(PackArgs a) {
       vc[2] = a.f2[t][MPHIP_CL] ? a.f2[t][MPHIP_CL][i] : 0.f;
       vc[3] = 0.f;
       a.sfb[2 * i + t] = vb;
+      vp[2 * t] = vb[0];
+      vp[2 * t + 1] = vb[2];
       a.sfc[2 * i + t] = vc;
       if (a.sfd) {
         f32x4 vd;
@@ -493,6 +496,7 @@ __global__ void pack_kernel(PackArgs a) {
       }
     }
     a.sfa[i] = va;
+    a.cp2[i] = vp;
     if (a.mx2) {
 #pragma unroll
       for (int pr = 0; pr < 7; pr++) {
