@@ -285,6 +285,10 @@ int mphip_profile_end(mphip_ctx *ctx, long long *launches, double *kernel_ms);
 int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, float *cos_out,
                        float *sin_out);
 int mphip_test_rng(mphip_ctx *ctx, uint64_t ctr, long long n, int method, double *out);
+/* Profiling aid: run building block `piece` of the step kernel (stencil set-up, one Runge-Kutta stage's
+ * interpolation, the random-number triple, ...; list in mphip_kernels.hpp:piece_kernel) `reps` times per
+ * resident particle; tools/piece_cost.py reads the instruction counters of these launches. */
+int mphip_test_piece(mphip_ctx *ctx, int piece, int reps, double *checksum);
 #ifdef __cplusplus
 }
 #endif

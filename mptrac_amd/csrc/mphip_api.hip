@@ -35,6 +35,7 @@ struct MetSlot {
   float *f2[MPHIP_N2D] = {};
   bool has3[MPHIP_N3D] = {};
   bool has2[MPHIP_N2D] = {};
+  float ps11 = 0.f;                   // ps at grid node [1][1] (module_position reflects there)
 };
 
 }   // namespace
@@ -252,6 +253,16 @@ DevMet dev_met(const mphip_ctx *c) {
   const int my = (c->ny - 1) >> 1, mp = (c->npl - 1) >> 1;
   M.lat_ascending = c->h_lat[my] < c->h_lat[my + 1];
   M.p_ascending = c->h_p[mp] < c->h_p[mp + 1];
+  M.lon_first = c->h_lon[0];
+  M.lon_last = c->h_lon[c->nx - 1];
+  M.inv_dlon0 = 1.0 / (c->h_lon[1] - c->h_lon[0]);
+  M.lat_search_max = std::nextafter(latmax, -HUGE_VAL);
+  M.p_min = *std::min_element(c->h_p.begin(), c->h_p.end());
+  M.p_search_max = std::nextafter(*std::max_element(c->h_p.begin(), c->h_p.end()), -HUGE_VAL);
+  M.p_cmp_off = M.p_ascending ? 1 : 0;
+  M.p_step = M.p_ascending ? 1 : -1;
+  M.ps11[0] = c->slot[0 ^ c->flip].ps11;
+  M.ps11[1] = c->slot[1 ^ c->flip].ps11;
   return M;
 }
 
@@ -582,7 +593,9 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   const bool ml_fast = ml_ && ctx->ml_monotonic && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
   const bool rare = (ml_ && !ml_fast) || (mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u));
   // the specialised instantiations take module_timesteps / the dt store from the run-time mask
-  const unsigned sel = (ctx->ctl.advect == 4 && !rare && !ml_ && !ctx->force_generic)
+  // ... and run the lean code: lat/lon grid with a pressure look-up table
+  const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV;
+  const unsigned sel = (ctx->ctl.advect == 4 && !rare && !ml_ && !ctx->force_generic && lean_ok)
     ? ((mask | MPHIP_MOD_TIMESTEPS) & ~kStoreDt) : kMaskGeneric;
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
@@ -1024,6 +1037,7 @@ int upload_fields(mphip_ctx *ctx, MetSlot &S, const mphip_met_t *met, bool new_g
       HIPCHK(hipMemcpy3DAsync(&p, stream));
     }
   }
+  S.ps11 = met->f2[MPHIP_PS] ? met->f2[MPHIP_PS][(size_t) met->sx2 + 1] : 0.f;
   for (int f = 0; f < MPHIP_N2D; f++) {
     S.has2[f] = met->f2[f] != nullptr;
     if (!S.has2[f])
@@ -1909,6 +1923,62 @@ int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, floa
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipFree(dc));
   HIPCHK(hipFree(ds));
+  return 0;
+}
+
+int mphip_test_piece(mphip_ctx *ctx, int piece, int reps, double *checksum) {
+  if (!ctx || !ctx->have_ctl || ctx->np == 0)
+    return fail(ctx, "mphip_test_piece needs control parameters and particles");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ensure_packed(ctx))
+    return 1;
+  if (!ctx->have_clim)
+    return fail(ctx, "climatological tropopause data were not uploaded");
+  StepParams S;
+  S.ctl = ctx->ctl;
+  S.met = dev_met(ctx);
+  S.atm = dev_atm(ctx);
+  S.clim = ctx->d_clim;
+  S.t = 0;
+  S.mask = 0;
+  long long per_block = (ctx->np + ctx->step_blocks - 1) / ctx->step_blocks;
+  per_block = std::max<long long>(256, (per_block + 255) / 256 * 256);
+  int nb = (int) ((ctx->np + per_block - 1) / per_block);
+  nb = (nb + 7) & ~7;
+  S.nblocks_logical = nb;
+  S.per_block = per_block;
+  S.xcd_map = ctx->xcd_map;
+  S.ctr_turb = 1000;
+  S.ctr_meso = 5000;
+  S.ctr_conv = 9000;
+  S.ctr_pbl = 0;
+  double *d = nullptr;
+  HIPCHK(hipMalloc((void **) &d, (size_t) ctx->np * sizeof(double)));
+  const size_t lds = axes_lds_bytes(ctx) + sizeof(DevClim);
+  switch (piece) {
+#define PIECE_CASE(K)                                                                                  \
+  case K:                                                                                              \
+    hipLaunchKernelGGL(piece_kernel<K>, dim3(nb), dim3(256), lds, ctx->stream, S, reps, d);            \
+    break;
+    PIECE_CASE(0) PIECE_CASE(1) PIECE_CASE(2) PIECE_CASE(3) PIECE_CASE(4) PIECE_CASE(5) PIECE_CASE(6) PIECE_CASE(7)
+    PIECE_CASE(8) PIECE_CASE(9) PIECE_CASE(10) PIECE_CASE(11) PIECE_CASE(12) PIECE_CASE(13) PIECE_CASE(14)
+    PIECE_CASE(15)
+#undef PIECE_CASE
+  default:
+    (void) hipFree(d);
+    return fail(ctx, "unknown piece");
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (checksum) {
+    std::vector<double> h((size_t) std::min<long long>(ctx->np, 1024));
+    HIPCHK(hipMemcpy(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double sum = 0;
+    for (double v : h)
+      sum += v;
+    *checksum = sum;
+  }
+  HIPCHK(hipFree(d));
   return 0;
 }
 

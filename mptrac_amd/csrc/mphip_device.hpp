@@ -40,7 +40,7 @@ constexpr double kEps = 18.01528 / kMA, kKappa = 0.286, kCpd = 1003.5, kKarman =
 // Both bracketing snapshots packed per grid point (record layouts: see the
 // interpolation section)
 struct DevMet {
-  const float *wind;     // [cell][6]
+  const float *wind;     // [cell][6] {u0,v0,u1,v1,w0,w1}
   const float *temp;     // [cell][2]
   const f32x4 *cloud;    // [cell][2] (optional)
   // level / surface fields only module_meteo reads, two fields x two snapshots per record {a0,b0,a1,b1}
@@ -70,6 +70,13 @@ struct DevMet {
   double latmin, latmax;         // module_timesteps, mptrac.c:6009-6010
   int local;                     // mptrac.c:6012-6013
   int lat_ascending, p_ascending;
+  // wave-uniform scalars of the lean stencil set-up (specialised kernels, lat/lon grids with a pressure table)
+  double lon_first, lon_last;    // lon[0], lon[nx - 1]
+  double inv_dlon0;              // 1 / (lon[1] - lon[0])
+  double lat_search_max;         // largest double below latmax: the search value of a latitude on the last node
+  double p_min, p_search_max;    // smallest node of the pressure axis, largest double below its largest node
+  int p_cmp_off, p_step;         // ascending axis: 1, +1; descending: 0, -1 (the node that decides table index vs neighbour)
+  float ps11[2];                 // ps of met0 / met1 at grid node [1][1] (module_position, quirk Q1)
 };
 
 struct DevAtm {
@@ -487,7 +494,8 @@ __device__ __forceinline__ void stencil_2d(const DevMet &M, const Axes &A, doubl
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // Packed grids (both snapshots in one record, level index fastest):
-//   wind [cell][6]  {u,v,w}0 {u,v,w}1      a column's level pair = 48 B = 3 x 16 B
+//   wind [cell][6]  {u0,v0,u1,v1,w0,w1}    a column's level pair = 48 B = 3 x 16 B; the (u,v) of one snapshot are an
+//                                          aligned register pair after the loads (packed two-float arithmetic)
 //   temp [cell][2]  {t}0 {t}1              a column's level pair = 16 B = 1 load
 //   cloud[cell][8]  {lwc,rwc,iwc,swc}0 {..}1   level pair = 64 B (wet deposition only)
 //   sfa  [col][4]   {ps,pbl}0 {ps,pbl}1    one load per corner
@@ -496,7 +504,7 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 // so a wind stencil is 12 loads, a temperature stencil 4, a {ps,pbl} stencil 4.
 
 struct WindCorners {
-  f32x4u r[2][2][3];   // [di][dj][piece]: 12 floats = level ip {u,v,w}0{u,v,w}1, level ip+1 {..}
+  f32x4u r[2][2][3];   // [di][dj][piece]: 12 floats = level ip {u0,v0,u1,v1,w0,w1}, level ip+1 {..}
 };
 
 // Index arithmetic in 24 x 24 -> 32-bit multiplies (full rate; a 64-bit integer multiply is four
@@ -537,13 +545,15 @@ struct WindCache {
 __device__ __forceinline__ void wind_cache_reset(WindCache &w, bool enabled) {
   w.enabled = enabled && MPHIP_WIND_CACHE;
   w.ix = w.iy = w.ip = -1;
+  // the corners have no value yet (every lane loads them at the first stencil: no cell is -1); an empty
+  // asm gives the registers a definition without the 48 moves a zero fill costs per particle
 #pragma unroll
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++)
 #pragma unroll
       for (int k = 0; k < 3; k++)
-        w.c.r[di][dj][k] = f32x4u{ 0.f, 0.f, 0.f, 0.f };
+        asm volatile("" : "=v"(w.c.r[di][dj][k]));
 }
 
 // The reload is written with the load instructions as inline assembly whose destination is a
@@ -582,7 +592,7 @@ __device__ __forceinline__ void wind_cache_wait(WindCache &w) {
 
 // value of component k (0 u, 1 v, 2 w) of snapshot t at level ip + lvl
 __device__ __forceinline__ float wind_elem(const WindCorners &c, int di, int dj, int lvl, int t, int k) {
-  const int e = 6 * lvl + 3 * t + k;
+  const int e = 6 * lvl + (k < 2 ? 2 * t + k : 4 + t);   // record layout {u0,v0,u1,v1,w0,w1}
   return c.r[di][dj][e >> 2][e & 3];
 }
 
@@ -2134,6 +2144,548 @@ __device__ __forceinline__ bool in_boundary_region(const mphip_ctl_t &ctl, const
       return false;
   }
   return true;
+}
+
+// =============================================================================
+// Lean versions for the specialised kernels (RK4 on pressure levels, lat/lon grid with a pressure look-up
+// table -- launch_step checks that; everything else runs the general code above).  Same values as the
+// general functions: every stencil is set up in straight-line code from a first guess and checked as a
+// whole; a lane whose check fails (a coordinate exactly on a grid line, |lon| >= 360, two axis nodes in
+// one table bin, NaN) recomputes it with the general function, so there is one rarely taken branch per
+// stencil instead of one per search step and per special case.  On gfx950 every VALU instruction -- a
+// move, a compare, an fp64 fma -- occupies the SIMD for the same four cycles, so what these versions save
+// is instruction count: one-instruction min / max / med3 (the C ternaries compile to compare + two
+// selects), axis end values from the kernel arguments instead of LDS, no per-axis direction branches.
+// =============================================================================
+
+__device__ __forceinline__ double vmin(double a, double b) {   // v_min_f64 without the canonicalising copies
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// the same with a wave-uniform second operand (kernel argument): stays in its SGPR pair
+__device__ __forceinline__ double vmin_s(double a, double s) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));
+  return r;
+}
+
+__device__ __forceinline__ double vmax_s(double a, double s) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));
+  return r;
+}
+
+// min(max(x, 0), hi) with a wave-uniform hi >= 0
+__device__ __forceinline__ int clamp0_s(int x, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+  return r;
+}
+
+// x * y + c with a literal constant c: the constant goes into an SGPR pair (two scalar moves beside the
+// vector pipe) -- left to itself the compiler often builds it in a VGPR pair with two v_mov per Horner step
+__device__ __forceinline__ double fma_k(double x, double y, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "s"(c));
+  return r;
+}
+
+// 1 / b to an ulp or two (rcp + two Newton steps)
+__device__ __forceinline__ double frcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+}
+
+// cos_latitude with the polynomial constants in SGPRs
+__device__ __forceinline__ double cos_latitude_k(double x) {
+  const double ax = fabs(x);
+  const bool hi = ax > 0.78539816339744830962;
+  const double y = hi ? (1.57079632679489655800e+00 - ax) + 6.12323399573676603587e-17 : ax;
+  const double z = y * y;
+  double a = fma_k(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  a = fma_k(z, a, 2.75573137070700676789e-06);
+  a = fma_k(z, a, -1.98412698298579493134e-04);
+  a = fma_k(z, a, 8.33333333332248946124e-03);
+  a = fma_k(z, a, -1.66666666666666324348e-01);
+  const double ps = y + y * z * a;
+  double b = fma_k(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  b = fma_k(z, b, -2.75573143513906633035e-07);
+  b = fma_k(z, b, 2.48015872894767294178e-05);
+  b = fma_k(z, b, -1.38888888888741095749e-03);
+  b = fma_k(z, b, 4.16666666666666019037e-02);
+  const double pc = 1.0 - (0.5 * z - z * z * b);
+  return hi ? ps : pc;
+}
+
+// Metre -> degree factors of one latitude: DX2DEG(dx, lat) = dx * kx, DY2DEG(dy) = dy * ky with dx, dy in
+// metres (mptrac.h:904-906, 922; the / 1000 of DX2COORD folded in).  One cosine and one reciprocal serve
+// every conversion at that latitude (the four of a Runge-Kutta step use the same one, mptrac.c:3628, 3672).
+struct DegPerMetre {
+  double kx;
+};
+
+__device__ __forceinline__ DegPerMetre deg_per_metre(double lat) {
+  DegPerMetre d;
+  const double c = kPi * kRE * cos_latitude_k(deg2rad(lat));
+  d.kx = (lat < -89.999 || lat > 89.999) ? 0.0 : frcp(c);
+  return d;
+}
+
+__device__ __forceinline__ double dx2deg_k(const DegPerMetre &d, double dx_metres) {
+  return ((dx_metres * 1e-3) * 180.) * d.kx;
+}
+
+__device__ __forceinline__ double dy2deg_k(double dy_metres) {
+  return ((dy_metres * 1e-3) * 180.) * (1.0 / (kPi * kRE));
+}
+
+// ---- stencil set-up ---------------------------------------------------------
+
+// longitude part of intpol_check_lon_lat + locate_reg + weight (mptrac.c:2762-2770, 3004-3018); false if the
+// longitude needs FMOD (|lon| >= 360)
+__device__ __forceinline__ bool lon_fast(const DevMet &M, const Axes &A, double lon, int &ix, double &wx) {
+  double lon2 = lon + (lon < M.lon_first ? 360.0 : (lon > M.lon_last ? -360.0 : 0.0));
+  ix = clamp0_s((int) ((lon2 - M.lon_first) * M.inv_dlon0), M.nx - 2);
+  const double lx1 = A.lon[ix + 1], linv = A.inv_lon[ix];
+  wx = (lx1 - lon2) * linv;
+  return fabs(lon) < 360.0;
+}
+
+// index of the latitude interval (locate_irr semantics on either axis direction) for a latitude inside
+// the axis range, with the interval's far node and reciprocal width; false if the guess was not it
+__device__ __forceinline__ bool lat_fast(const DevMet &M, const Axes &A, double lat2, int &iy, double &y1,
+                                         double &yinv) {
+  const double lat_s = vmin_s(lat2, M.lat_search_max);   // a latitude on the last node belongs to the last interval
+  iy = clamp0_s((int) ((lat2 - M.lat_x0) * M.lat_inv_dx), M.ny - 2);
+  const double y0 = A.lat[iy];
+  y1 = A.lat[iy + 1];
+  yinv = A.inv_lat[iy];
+  return (vmin(y0, y1) <= lat_s) & (lat_s < vmax(y0, y1));
+}
+
+// the same for a pressure (any value: outside the axis the end intervals, as the bisection returns them)
+__device__ __forceinline__ bool p_fast(const DevMet &M, const Axes &A, double p, int &ip, double &p1, double &pinv) {
+  const double ps = vmin_s(vmax_s(p, M.p_min), M.p_search_max);
+  const int g = (int) A.p_lut[(__double2hiint(ps) >> 13) - M.lut_base];   // index of the table bin's lower edge
+  // the bin may hold an axis node between its edge and p: then the neighbouring interval is the one
+  const double node = A.p[g + M.p_cmp_off];
+  ip = g + (ps >= node ? M.p_step : 0);
+  const double p0 = A.p[ip];
+  p1 = A.p[ip + 1];
+  pinv = A.inv_p[ip];
+  return (vmin(p0, p1) <= ps) & (ps < vmax(p0, p1)) & (p == p);   // (a NaN takes the general path: index n - 2)
+}
+
+// horizontal part of a stencil: indices and weights of intpol_met_space_2d / _3d (mptrac.c:2997-3021,
+// 3059-3081); on return s.ix, s.iy, s.wx, s.wy are set (s.ip, s.wp untouched)
+__device__ __forceinline__ void horiz_fast(const DevMet &M, const Axes &A, double lon, double lat, Stencil &s) {
+  const double lat2 = vmin_s(vmax_s(lat, M.latmin), M.latmax);
+  double y1, yinv;
+  bool ok = lon_fast(M, A, lon, s.ix, s.wx);
+  ok &= lat_fast(M, A, lat2, s.iy, y1, yinv);
+  s.wy = (y1 - lat2) * yinv;
+  if (!ok) {
+    Stencil g = stencil_zero();
+    stencil_2d(M, A, lon, lat, g);
+    s.ix = g.ix;
+    s.iy = g.iy;
+    s.wx = g.wx;
+    s.wy = g.wy;
+  }
+}
+
+// vertical part: s.ip, s.wp
+__device__ __forceinline__ void vert_fast(const DevMet &M, const Axes &A, double p, Stencil &s) {
+  double p1, pinv;
+  const bool ok = p_fast(M, A, p, s.ip, p1, pinv);
+  s.wp = (p1 - p) * pinv;
+  if (!ok) {
+    const AxisHit hp = hit_p(M, A, p);
+    s.ip = hp.i;
+    s.wp = div_const(hp.x1 - p, hp.x1 - hp.x0, hp.inv);
+  }
+}
+
+__device__ __forceinline__ void stencil_3d_fast(const DevMet &M, const Axes &A, double p, double lon, double lat,
+                                                Stencil &s) {
+  const double lat2 = vmin_s(vmax_s(lat, M.latmin), M.latmax);
+  double y1, yinv, p1, pinv;
+  bool ok = lon_fast(M, A, lon, s.ix, s.wx);
+  ok &= lat_fast(M, A, lat2, s.iy, y1, yinv);
+  ok &= p_fast(M, A, p, s.ip, p1, pinv);
+  s.wy = (y1 - lat2) * yinv;
+  s.wp = (p1 - p) * pinv;
+  if (!ok)
+    stencil_3d(M, A, p, lon, lat, s);
+}
+
+// raw indices of module_diff_meso / module_sort (mptrac.c:4283-4285, 5913-5917): locate_reg on the
+// un-wrapped longitude with the reference's division -- the product with the reciprocal spacing decides
+// unless it lands within 1e-9 of a whole number --, locate_irr on latitude and pressure
+__device__ __forceinline__ void raw_cell_fast(const DevMet &M, const Axes &A, double lon, double lat, double p,
+                                              Stencil &s) {
+  const double q = (lon - M.lon_first) * M.inv_dlon0;
+  const int i = (int) q;
+  const double f = q - (double) i;
+  bool ok = (q < -1e-9) | ((f > 1e-9) & (f < 1.0 - 1e-9));
+  s.ix = clamp0_s(i, M.nx - 2);
+  double y1, yinv, p1, pinv;
+  ok &= lat_fast(M, A, vmin_s(vmax_s(lat, M.latmin), M.latmax), s.iy, y1, yinv);
+  ok &= p_fast(M, A, p, s.ip, p1, pinv);
+  if (!ok) {
+    s.ix = locate_reg(A.lon, M.nx, lon);
+    s.iy = locate_lat(M, A, lat);
+    s.ip = locate_p(M, A, p);
+  }
+}
+
+// ---- interpolation ----------------------------------------------------------
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Wind records of the lean kernels: {u0,v0,u1,v1,w0,w1} per level (snapshots 0 / 1), so that a level pair
+// is twelve floats whose (u,v) pairs of one snapshot sit in an aligned register pair -- the single-
+// precision corner differences of intpol_met_space_3d and the sums of module_diff_meso then run as packed
+// two-float instructions.  Element e of a corner: 6 * level + {0,1,4: u,v,w of met0; 2,3,5: of met1}.
+__device__ __forceinline__ int wind_e(int lvl, int t, int k) {
+  return 6 * lvl + (k < 2 ? 2 * t + k : 4 + t);
+}
+
+__device__ __forceinline__ float wind_at(const WindCorners &c, int di, int dj, int e) {
+  return c.r[di][dj][e >> 2][e & 3];
+}
+
+// u, v, w at the stencil: intpol_met_time_3d of the three components (mptrac.c:3023-3043, 3112-3137) with
+// the corner differences (level ip minus level ip + 1, in single precision as the reference's float - float)
+// formed two at a time
+__device__ __forceinline__ void wind_uvw_fast(const WindCorners &c, const Stencil &s, double wt, double &u, double &v,
+                                              double &w) {
+  double col[2][2][6];   // [di][dj][element]: wp * (lo - hi) + hi
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++) {
+      const f32x4u r0 = c.r[di][dj][0], r1 = c.r[di][dj][1], r2 = c.r[di][dj][2];
+      // level ip: r0[0..3], r1[0..1]; level ip + 1: r1[2..3], r2[0..3]
+      const f32x2 d01 = __builtin_shufflevector(r0, r0, 0, 1) - __builtin_shufflevector(r1, r1, 2, 3);
+      const f32x2 d23 = __builtin_shufflevector(r0, r0, 2, 3) - __builtin_shufflevector(r2, r2, 0, 1);
+      const f32x2 d45 = __builtin_shufflevector(r1, r1, 0, 1) - __builtin_shufflevector(r2, r2, 2, 3);
+      const float d[6] = { d01[0], d01[1], d23[0], d23[1], d45[0], d45[1] };
+      const float h[6] = { r1[2], r1[3], r2[0], r2[1], r2[2], r2[3] };
+#pragma unroll
+      for (int e = 0; e < 6; e++)
+        col[di][dj][e] = s.wp * (double) d[e] + (double) h[e];
+    }
+  double val[6];
+#pragma unroll
+  for (int e = 0; e < 6; e++) {
+    const double r0 = s.wy * (col[0][0][e] - col[0][1][e]) + col[0][1][e];
+    const double r1 = s.wy * (col[1][0][e] - col[1][1][e]) + col[1][1][e];
+    val[e] = s.wx * (r0 - r1) + r1;
+  }
+  u = wt * (val[0] - val[2]) + val[2];
+  v = wt * (val[1] - val[3]) + val[3];
+  w = wt * (val[4] - val[5]) + val[5];
+}
+
+// field f (0 / 1) of a {a0,b0,a1,b1} surface record at the stencil: intpol_met_space_2d at both snapshots
+// and intpol_met_time_2d (mptrac.c:3083-3107, 3155-3169).  A corner that is not finite makes the plain
+// result not finite (inf - inf, 0 * inf, inf + x), and only then do the nearest-neighbour rules apply, so
+// one test of the result replaces the ten tests of the inputs.
+__device__ __forceinline__ double pair_time_2d_fast(const SurfA &c, const Stencil &s, double wt, int f) {
+  double v[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const double c00 = c.v[0][0][2 * t + f], c01 = c.v[0][1][2 * t + f], c10 = c.v[1][0][2 * t + f],
+                 c11 = c.v[1][1][2 * t + f];
+    const double r0 = s.wy * (c00 - c01) + c01;
+    const double r1 = s.wy * (c10 - c11) + c11;
+    v[t] = s.wx * (r0 - r1) + r1;
+  }
+  double r = wt * (v[0] - v[1]) + v[1];
+  if (!isfinite(r))
+    r = sfa_time_2d(c, s, wt, f);
+  return r;
+}
+
+// temperature at a stencil: as pair_time_3d, corner differences two at a time
+__device__ __forceinline__ double temp_fast(const DevMet &M, const Stencil &s, double wt) {
+  double col[2][2][2];
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++) {
+      const f32x4u q = *(const f32x4u *) (M.temp + 2 * cell_of(M, s, di, dj));   // {t0,t1} at ip, {t0,t1} at ip + 1
+      const f32x2 d = __builtin_shufflevector(q, q, 0, 1) - __builtin_shufflevector(q, q, 2, 3);
+      col[di][dj][0] = s.wp * (double) d[0] + (double) q[2];
+      col[di][dj][1] = s.wp * (double) d[1] + (double) q[3];
+    }
+  double val[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const double r0 = s.wy * (col[0][0][t] - col[0][1][t]) + col[0][1][t];
+    const double r1 = s.wy * (col[1][0][t] - col[1][1][t]) + col[1][1][t];
+    val[t] = s.wx * (r0 - r1) + r1;
+  }
+  return wt * (val[0] - val[1]) + val[1];
+}
+
+// ---- modules ----------------------------------------------------------------
+
+// module_position (mptrac.c:5445-5488) on a lat/lon grid; the surface pressure it reflects at is the one of
+// grid node [1][1] (quirk Q1): with zero weights intpol_met_space_2d returns that corner whatever the others are
+__device__ __forceinline__ void position_fast(const DevMet &M, const Axes &A, Particle &P) {
+  double lon = fmod_trunc(P.lon, 360.);
+  double lat = fmod_trunc(P.lat, 360.);
+  while (lat < -90 || lat > 90) {
+    if (lat > 90) {
+      lat = 180 - lat;
+      lon += 180;
+    }
+    if (lat < -90) {
+      lat = -180 - lat;
+      lon += 180;
+    }
+  }
+  while (lon < -180)
+    lon += 360;
+  while (lon >= 180)
+    lon -= 360;
+  P.lon = lon;
+  P.lat = lat;
+  const double ptop = A.p[M.np - 1];
+  if (P.p < ptop) {
+    P.p = ptop * ptop / P.p;
+  } else if (P.p > 300.) {
+    const double ps = blend_time_2d((double) M.ps11[0], (double) M.ps11[1], time_weight(M, P.time));
+    if (P.p > ps)
+      P.p = ps * ps / P.p;
+  }
+}
+
+// module_advect, RK4 on pressure levels (mptrac.c:3612-3677); `hook(i)` runs behind the gathers of stage i
+template <class Hook>
+__device__ __forceinline__ void advect_rk4_fast(const DevMet &M, const Axes &A, Particle &P, Hook &hook, WindCache &wc) {
+  const double dt = P.dt;
+  const DegPerMetre dm = deg_per_metre(P.lat);   // every stage converts at the latitude the step starts from
+  double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double dts = 0.0, x0 = P.lon, x1 = P.lat, x2 = P.p;
+    if (i > 0) {
+      dts = (i == 3 ? 1.0 : 0.5) * dt;
+      x0 = P.lon + dx2deg_k(dm, dts * u);
+      x1 = P.lat + dy2deg_k(dts * v);
+      x2 = P.p + dts * w;
+    }
+    Stencil s;
+    stencil_3d_fast(M, A, x2, x0, x1, s);
+    load_wind_cached(M, s, wc);
+    hook(i);
+    wind_cache_wait(wc);
+    wind_uvw_fast(wc.c, s, time_weight(M, P.time + dts), u, v, w);
+    const double k = (i == 0 || i == 3) ? 1.0 / 6.0 : 2.0 / 6.0;
+    um += k * u;
+    vm += k * v;
+    wm += k * w;
+  }
+  P.time += dt;
+  P.lon += dx2deg_k(dm, dt * um);
+  P.lat += dy2deg_k(dt * vm);
+  P.p += dt * wm;
+}
+
+// module_diff_turb (mptrac.c:4603-4733)
+__device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevClim &C,
+                                               Particle &P, uint64_t ctr, uint64_t g, const double *pre) {
+  Stencil s = stencil_zero();
+  horiz_fast(M, A, P.lon, P.lat, s);
+  SurfA c;
+  load_sfa(M, s, c);
+  const double wt = time_weight(M, P.time);
+  const double pbl = pair_time_2d_fast(c, s, wt, 1);
+  if (ctl.turb_pbl_scheme > 0 && P.p >= pbl)
+    return;
+  const double ps = pair_time_2d_fast(c, s, wt, 0);
+  const double ptop = A.p[M.np - 1];
+
+  const double wpbl = pbl_weight(ctl, P.p, pbl, ps);
+  const double wtrop = tropo_weight(ctl, C, P.time, P.lat, P.p) * (1.0 - wpbl);
+  const double wstrat = 1.0 - wpbl - wtrop;
+  const double Kx = wpbl * ctl.turb_dx_pbl + wtrop * ctl.turb_dx_trop + wstrat * ctl.turb_dx_strat;
+  const double Kz = wpbl * ctl.turb_dz_pbl + wtrop * ctl.turb_dz_trop + wstrat * ctl.turb_dz_strat;
+  const double dt_abs = fabs(P.dt);
+
+  double rs0, rs1, rs2;
+  if (pre) {
+    rs0 = pre[0];
+    rs1 = pre[1];
+    rs2 = pre[2];
+  } else
+    normal_triple(ctr, g, rs0, rs1, rs2);
+
+  if (Kx > 0) {
+    const double sigma_h = fsqrt(2.0 * Kx * dt_abs);
+    const DegPerMetre dm = deg_per_metre(P.lat);
+    P.lon += dx2deg_k(dm, rs0 * sigma_h);
+    P.lat += dy2deg_k(rs1 * sigma_h);
+  }
+  if (Kz > 0) {
+    const double sigma_z = fsqrt(2.0 * Kz * dt_abs) * 1e-3;
+    const double p_save = P.p;
+    const double eps_km = 0.01;
+    const double p_up = p_save + dz2dp(eps_km, p_save);
+    const double p_dn = p_save + dz2dp(-eps_km, p_save);
+    const double pt = tropo_pressure(ctl, C, P.time, P.lat);   // latitude already displaced above
+    const double Kz_up = kz_blend(ctl, pt, vmax(ptop, vmin(ps, p_up)), pbl, ps);
+    const double Kz_dn = kz_blend(ctl, pt, vmax(ptop, vmin(ps, p_dn)), pbl, ps);
+    const double dKz_dz = (Kz_up - Kz_dn) * (1.0 / (2.0 * eps_km * 1e3));
+    const double dlnrho_dz = -1.0 / (1e3 * kH0);
+    const double w_drift = dKz_dz + Kz * dlnrho_dz;
+    const double dz_drift = w_drift * dt_abs * 1e-3;
+    const double dz_tot = rs2 * sigma_z + dz_drift;
+    double ptrial = p_save + dz2dp(dz_tot, p_save);
+    for (int iter = 0; iter < 10; iter++) {
+      if (ptrial > ps)
+        ptrial = ps * ps / ptrial;
+      else if (ptrial < ptop)
+        ptrial = ptop * ptop / ptrial;
+      else
+        break;
+    }
+    P.p = dmax(ptop, dmin(ps, ptrial));
+  }
+}
+
+// module_diff_meso (mptrac.c:4280-4338) on the {u0,v0,u1,v1,w0,w1} records
+__device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                               float &up, float &vp, float &wp, uint64_t ctr, uint64_t g,
+                                               const double *pre, WindCache &wc) {
+#pragma clang fp contract(off)
+  Stencil s;
+  raw_cell_fast(M, A, P.lon, P.lat, P.p, s);
+  load_wind_cached(M, s, wc);
+  wind_cache_wait(wc);
+  const WindCorners &c = wc.c;
+
+  // single-precision sums in the reference's order -- i (lon), j (lat), k (level), met0 before met1 --,
+  // u and v side by side in one packed accumulator
+  f32x2 mean_uv = { 0.f, 0.f }, sig_uv = { 0.f, 0.f };
+  float mean_w = 0.f, sig_w = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const f32x4u r0 = c.r[i][j][0], r1 = c.r[i][j][1], r2 = c.r[i][j][2];
+      // level ip: uv0 = r0[0,1], uv1 = r0[2,3], w0 w1 = r1[0,1]; level ip + 1: uv0 = r1[2,3], uv1 = r2[0,1], w0 w1 = r2[2,3]
+      const f32x2 uv[2][2] = { { __builtin_shufflevector(r0, r0, 0, 1), __builtin_shufflevector(r0, r0, 2, 3) },
+                               { __builtin_shufflevector(r1, r1, 2, 3), __builtin_shufflevector(r2, r2, 0, 1) } };
+      const float ww[2][2] = { { r1[0], r1[1] }, { r2[2], r2[3] } };
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          mean_uv = mean_uv + uv[k][t];
+          sig_uv = sig_uv + uv[k][t] * uv[k][t];
+          mean_w = mean_w + ww[k][t];
+          sig_w = sig_w + ww[k][t] * ww[k][t];
+        }
+    }
+  const float mean[3] = { mean_uv[0], mean_uv[1], mean_w }, sig[3] = { sig_uv[0], sig_uv[1], sig_w };
+  float sd[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const float m16 = mean[q] / 16.f;
+    const float var = sig[q] / 16.f - m16 * m16;
+    sd[q] = (var > 0 ? sqrtf(var) : 0.f);
+  }
+
+  const double r = 1 - fdiv(2 * fabs(P.dt), ctl.dt_met);
+  const double r2 = fsqrt(1 - r * r);
+  double rs0, rs1, rs2;
+  if (pre) {
+    rs0 = pre[0];
+    rs1 = pre[1];
+    rs2 = pre[2];
+  } else
+    normal_triple(ctr, g, rs0, rs1, rs2);
+
+  if (ctl.turb_mesox > 0) {
+    up = (float) (r * up + r2 * rs0 * ctl.turb_mesox * sd[0]);
+    const DegPerMetre dm = deg_per_metre(P.lat);
+    P.lon += dx2deg_k(dm, up * P.dt);
+    vp = (float) (r * vp + r2 * rs1 * ctl.turb_mesox * sd[1]);
+    P.lat += dy2deg_k(vp * P.dt);
+  }
+  if (ctl.turb_mesoz > 0) {
+    wp = (float) (r * wp + r2 * rs2 * ctl.turb_mesoz * sd[2]);
+    P.p += wp * P.dt;
+  }
+}
+
+// module_convection (mptrac.c:4116-4170) and module_sedi (mptrac.c:5869-5882): both work at the horizontal
+// position module_diff_meso left, so one horizontal stencil serves the surface fields and the three
+// temperature columns
+__device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
+                                               unsigned mask, uint64_t ctr, uint64_t g, const double *pre, double rp,
+                                               double rhop) {
+  Stencil s = stencil_zero();
+  horiz_fast(M, A, P.lon, P.lat, s);
+  const double wt = time_weight(M, P.time);
+  if (mask & MPHIP_MOD_CONVECTION) {
+    SurfA c;
+    load_sfa(M, s, c);
+    const double ps = pair_time_2d_fast(c, s, wt, 0);
+    double pbot = ps, ptop = ps;
+    if (ctl.conv_mix_pbl) {
+      const double pbl = pair_time_2d_fast(c, s, wt, 1);
+      ptop = pbl - ctl.conv_pbl_trans * (ps - pbl);
+    }
+    if (ctl.conv_cape >= 0) {
+      if (ctl.conv_cin <= 0) {
+        SurfA b;
+        load_pair_2d(M.cp2, M, s, b);
+        const double cape = pair_time_2d_fast(b, s, wt, 0);
+        const double pel = pair_time_2d_fast(b, s, wt, 1);
+        if (isfinite(cape) && cape >= ctl.conv_cape)
+          ptop = dmin(ptop, pel);
+      } else {
+        SurfB b;
+        load_sfb(M.sfb, M, s, b);
+        const double cape = sfb_time_2d(b, s, wt, 0);
+        const double cin = sfb_time_2d(b, s, wt, 1);
+        const double pel = sfb_time_2d(b, s, wt, 2);
+        if (isfinite(cape) && cape >= ctl.conv_cape && isfinite(cin) && cin >= ctl.conv_cin)
+          ptop = dmin(ptop, pel);
+      }
+    }
+    if (ptop != pbot && P.p >= ptop) {
+      vert_fast(M, A, pbot, s);
+      const double tbot = temp_fast(M, s, wt);
+      vert_fast(M, A, ptop, s);
+      const double ttop = temp_fast(M, s, wt);
+      const double rhobot = fdiv(pbot, tbot);
+      const double rhotop = fdiv(ptop, ttop);
+      const double rs = pre ? *pre : uniform01(ctr + g);
+      const double rho = rhobot + (rhotop - rhobot) * rs;
+      P.p = lin(rhobot, pbot, rhotop, ptop, rho);
+    }
+  }
+  if (mask & MPHIP_MOD_SEDI) {
+    vert_fast(M, A, P.p, s);
+    const double t = temp_fast(M, s, wt);
+    const double v_s = sedi(P.p, t, rp, rhop);
+    P.p += dz2dp(v_s * P.dt * 1e-3, P.p);
+  }
 }
 
 }   // namespace mphip

@@ -300,10 +300,16 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     pre.ctr_conv = S.ctr_conv;
     pre.g = g;
 
+    // the specialised instantiations run the lean versions (lat/lon grid, pressure table: launch_step)
+    constexpr bool lean = !kRuntimeMask<CT>;
     WindCache wc;
     wind_cache_reset(wc, CT != kMaskGeneric);
-    if (mask & MPHIP_MOD_POSITION)
-      position(M, A, P);
+    if (mask & MPHIP_MOD_POSITION) {
+      if (lean)
+        position_fast(M, A, P);
+      else
+        position(M, A, P);
+    }
     if (mask & MPHIP_MOD_ADVECT) {
       // model-level advection (ADVECT_VERT_COORD 1 / 3) runs in the generic instantiation only
       if (CT == kMaskGeneric && ctl.advect_vert_coord == 2) {
@@ -324,13 +330,20 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
         advect_ml_fast(ctl, M, A, P, zeta, kz);
         a.kz[i] = kz;
         a.q[qnt][i] = zeta;
-      } else if (early)
-        advect_n<4>(M, A, P, pre, wc);
-      else
+      } else if (lean && early)
+        advect_rk4_fast(M, A, P, pre, wc);
+      else if (lean) {
+        NoHook none;
+        advect_rk4_fast(M, A, P, none, wc);
+      } else
         advect(ctl, M, A, P, wc);
     }
-    if (mask & MPHIP_MOD_DIFF_TURB)
-      diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr);
+    if (mask & MPHIP_MOD_DIFF_TURB) {
+      if (lean)
+        diff_turb_fast(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr);
+      else
+        diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr);
+    }
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_DIFF_PBL)) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
       diff_pbl(M, A, P, up, vp, wp, S.ctr_pbl, g);
@@ -340,19 +353,34 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     }
     if (mask & MPHIP_MOD_DIFF_MESO) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
-      diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc);
+      if (lean)
+        diff_meso_fast(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc);
+      else
+        diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc);
       a.up[i] = up;
       a.vp[i] = vp;
       a.wp[i] = wp;
     }
-    if (mask & MPHIP_MOD_CONVECTION)
-      convection(ctl, M, A, P, S.ctr_conv, g, early ? &pre.conv : nullptr);
-    if (mask & MPHIP_MOD_SEDI)
-      sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
+    if (lean) {
+      if (mask & (MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI)) {
+        const bool sedi_on = (mask & MPHIP_MOD_SEDI) != 0;
+        conv_sedi_fast(ctl, M, A, P, mask, S.ctr_conv, g, early ? &pre.conv : nullptr,
+                       sedi_on ? a.q[ctl.qnt_rp][i] : 0.0, sedi_on ? a.q[ctl.qnt_rhop][i] : 0.0);
+      }
+    } else {
+      if (mask & MPHIP_MOD_CONVECTION)
+        convection(ctl, M, A, P, S.ctr_conv, g, early ? &pre.conv : nullptr);
+      if (mask & MPHIP_MOD_SEDI)
+        sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
+    }
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))
       P.p = isosurf_pressure(ctl, M, A, a, P, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
-    if (mask & MPHIP_MOD_POSITION2)
-      position(M, A, P);
+    if (mask & MPHIP_MOD_POSITION2) {
+      if (lean)
+        position_fast(M, A, P);
+      else
+        position(M, A, P);
+    }
 
     if ((mask & MPHIP_MOD_ADVECT) || fused_sort)
       a.time[i] = P.time;
@@ -411,7 +439,7 @@ __global__ void pack_kernel(PackArgs a) {
     for (int t = 0; t < 2; t++) {
 #pragma unroll
       for (int k = 0; k < 3; k++)
-        a.wind[6 * i + 3 * t + k] = a.f3[t][MPHIP_U + k] ? a.f3[t][MPHIP_U + k][i] : 0.f;
+        a.wind[6 * i + (k < 2 ? 2 * t + k : 4 + t)] = a.f3[t][MPHIP_U + k] ? a.f3[t][MPHIP_U + k][i] : 0.f;   // {u0,v0,u1,v1,w0,w1}
       a.temp[2 * i + t] = a.f3[t][MPHIP_T] ? a.f3[t][MPHIP_T][i] : 0.f;
       if (a.h2o)
         a.h2o[2 * i + t] = a.f3[t][MPHIP_H2O] ? a.f3[t][MPHIP_H2O][i] : 0.f;
@@ -1156,6 +1184,127 @@ __global__ void test_sincosf_kernel(uint32_t first, uint32_t count, float *__res
     const float x = __uint_as_float(first + i);
     c[i] = libm_sincosf(x, 1);
     s[i] = libm_sincosf(x, 0);
+  }
+}
+
+// Cost of the building blocks of the step kernel on the resident particles and grids (profiling aid:
+// tools/piece_cost.py runs every PIECE under rocprofv3 --pmc and subtracts piece 0).  Each thread loads
+// its particle like the step kernel, runs the piece `reps` times on slightly different inputs and adds
+// the result to out[i] so that nothing is optimised away.
+template <int PIECE>
+__global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(const StepParams S, int reps,
+                                                                               double *__restrict__ out) {
+  extern __shared__ double s_axes[];
+  const DevMet &M = S.met;
+  const DevAtm &a = S.atm;
+  const mphip_ctl_t &ctl = S.ctl;
+  const Axes A = load_axes(M, s_axes);
+  double *dst = s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8;
+  const double *src = (const double *) S.clim;
+  for (int i = threadIdx.x; i < (int) (sizeof(DevClim) / sizeof(double)); i += blockDim.x)
+    dst[i] = src[i];
+  const DevClim &clim = *(const DevClim *) dst;
+  __syncthreads();
+  const int nb = S.nblocks_logical;
+  const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
+  const long long first = (long long) lb * S.per_block;
+  long long last = first + S.per_block;
+  if (last > a.np)
+    last = a.np;
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
+    Particle P;
+    P.time = a.time[i];
+    P.lon = a.lon[i];
+    P.lat = a.lat[i];
+    P.p = a.p[i];
+    P.dt = 180.0;
+    const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) a.ext[i] : i));
+    double acc = 0.0;
+    for (int r = 0; r < reps; r++) {
+      const double lon = P.lon + 1e-3 * r, lat = P.lat - 1e-3 * r, p = P.p * (1.0 + 1e-4 * r);
+      if (PIECE == 1) {
+        Stencil s;
+        stencil_3d(M, A, p, lon, lat, s);
+        acc += s.wp + s.wx + s.wy + (double) (s.ip + s.ix + s.iy);
+      } else if (PIECE == 2) {
+        Stencil s = stencil_zero();
+        stencil_2d(M, A, lon, lat, s);
+        acc += s.wx + s.wy + (double) (s.ix + s.iy);
+      } else if (PIECE == 3) {   // one Runge-Kutta stage's interpolation: stencil + 12 loads + 3 components
+        Stencil s;
+        stencil_3d(M, A, p, lon, lat, s);
+        WindCorners c;
+        load_wind(M, s, c);
+        const double wt = time_weight(M, P.time + r);
+        acc += wind_time_3d(c, s, wt, 0) + wind_time_3d(c, s, wt, 1) + wind_time_3d(c, s, wt, 2);
+      } else if (PIECE == 4) {
+        double r0, r1, r2;
+        normal_triple(S.ctr_turb + (uint64_t) r, g, r0, r1, r2);
+        acc += r0 + r1 + r2;
+      } else if (PIECE == 5) {
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        position(M, A, Q);
+        acc += Q.lon + Q.lat + Q.p;
+      } else if (PIECE == 6) {   // {ps, pbl} at the particle: what module_diff_turb / module_convection start with
+        Stencil s = stencil_zero();
+        stencil_2d(M, A, lon, lat, s);
+        SurfA c;
+        load_sfa(M, s, c);
+        const double wt = time_weight(M, P.time + r);
+        acc += sfa_time_2d(c, s, wt, 0) + sfa_time_2d(c, s, wt, 1);
+      } else if (PIECE == 7) {
+        acc += temperature_at(M, A, P.time + r, p, lon, lat);
+      } else if (PIECE == 8) {
+        acc += dx2coord(0, 100.0 + r, lat) + dy2coord(0, 50.0 + r);
+      } else if (PIECE == 9) {
+        acc += tropo_weight(ctl, clim, P.time + r, lat, p);
+      } else if (PIECE == 10) {
+        acc += sedi(p, 220.0 + r, 1.0, 1000.0);
+      } else if (PIECE == 11) {
+        acc += uniform01(S.ctr_conv + g + (uint64_t) r);
+      } else if (PIECE == 12) {   // module_diff_turb as a whole
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        diff_turb(ctl, M, A, clim, Q, S.ctr_turb + (uint64_t) r, g);
+        acc += Q.lon + Q.lat + Q.p;
+      } else if (PIECE == 13) {   // module_convection + module_sedi
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        convection(ctl, M, A, Q, S.ctr_conv + (uint64_t) r, g);
+        sedimentation(M, A, Q, 1.0, 1000.0);
+        acc += Q.p;
+      } else if (PIECE == 14) {   // module_diff_meso without the particle-array traffic
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        float up = 0.1f * r, vp = 0.2f, wp = 1e-4f;
+        WindCache wc;
+        wind_cache_reset(wc, false);
+        diff_meso(ctl, M, A, Q, up, vp, wp, S.ctr_meso + (uint64_t) r, g, nullptr, wc);
+        acc += Q.lon + Q.lat + Q.p + (double) (up + vp + wp);
+      } else if (PIECE == 15) {   // module_advect (RK4) without the wind-corner cache
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        WindCache wc;
+        wind_cache_reset(wc, false);
+        NoHook none;
+        advect_n<4>(M, A, Q, none, wc);
+        acc += Q.lon + Q.lat + Q.p;
+      } else {
+        acc += lon + lat + p;
+      }
+    }
+    out[i] = acc;
   }
 }
 

@@ -107,6 +107,7 @@ def load(build=True):
     L.mphip_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), _dp]
     L.mphip_test_sincosf.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _fp, _fp]
     L.mphip_test_rng.argtypes = [C.c_void_p, C.c_uint64, C.c_longlong, C.c_int, _dp]
+    L.mphip_test_piece.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
     if L.mphip_sizeof_ctl() != C.sizeof(MphipCtl):
         raise MphipError("mphip_ctl_t layout mismatch between header and Python mirror")
     if L.mphip_sizeof_met() != C.sizeof(MphipMet):
@@ -361,6 +362,12 @@ class Simulation:
         s = np.empty(count, dtype=np.float32)
         self._chk(self.L.mphip_test_sincosf(self.h, first_bits, count, _ptr(c, _fp), _ptr(s, _fp)))
         return c, s
+
+    def test_piece(self, piece, reps=1):
+        """Profiling aid (tools/piece_cost.py): run one building block of the step kernel per particle."""
+        chk = C.c_double(0.0)
+        self._chk(self.L.mphip_test_piece(self.h, int(piece), int(reps), C.byref(chk)))
+        return chk.value
 
     def test_rng(self, ctr, n, method):
         out = np.empty(n)

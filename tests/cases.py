@@ -135,6 +135,35 @@ def rel_err_strict(a, b, floor=1e-300):
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
 
 
+def q_rows_err(ctl, a, b, floor=1e-3):
+    """Largest error over the quantity rows, each row on ITS OWN scale:
+    |a - b| / max(|b|, floor * max|row|).  rel_err() floors the denominator at
+    1, which for rows far below 1 (vmr ~ 3e-9, loss_rate ~ 4e-6, mloss_*) is
+    an absolute bar and checks nothing.  The mloss_* rows accumulate
+    m * (1 - aux) -- a difference of numbers near 1 -- so their natural scale is
+    the mass row's.  Returns (error, row index of the worst row)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    worst, where = 0.0, -1
+    qm = getattr(ctl, "qnt_m", -1)
+    mloss = {getattr(ctl, k, -1) for k in ("qnt_mloss_wet", "qnt_mloss_dry", "qnt_mloss_decay")}
+    for iq in range(b.shape[0]):
+        nan = np.isnan(b[iq])
+        if not np.array_equal(np.isnan(a[iq]), nan):
+            return float("inf"), iq
+        x, y = np.where(nan, 0.0, a[iq]), np.where(nan, 0.0, b[iq])
+        top = float(np.max(np.abs(y))) if y.size else 0.0
+        if iq in mloss and qm >= 0 and b[qm].size:
+            top = max(top, float(np.nanmax(np.abs(b[qm]))))
+        if top == 0.0:
+            err = 0.0 if np.array_equal(x, y) else float("inf")
+        else:
+            err = float(np.max(np.abs(x - y) / np.maximum(np.abs(y), floor * top))) if y.size else 0.0
+        if err > worst:
+            worst, where = err, iq
+    return worst, where
+
+
 def step_times(ctl):
     """The driver's time loop (src/trac.c:131-137)."""
     t = ctl.t_start

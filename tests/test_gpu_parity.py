@@ -40,7 +40,9 @@ def _compare(o, s, tol=TOL):
     for k in ("lon", "lat", "p"):
         assert cases.rel_err(g[k], r[k]) <= tol, (k, cases.rel_err(g[k], r[k]))
     if r["q"].size:
-        assert cases.rel_err(g["q"], r["q"]) <= tol, cases.rel_err(g["q"], r["q"])
+        # every quantity row on its own scale (vmr ~ 3e-9, loss_rate ~ 4e-6 ... are far below 1)
+        err, row = cases.q_rows_err(o.ctl, g["q"], r["q"])
+        assert err <= tol, ("q", row, err)
     assert cases.rel_err(g["uvwp"], r["uvwp"]) <= TOL_UVWP
     assert s.get_cache()["rng_ctr"] == o.cache.rng_ctr
 
@@ -791,5 +793,132 @@ def test_model_levels_with_a_non_monotonic_height_column(case, field):
     for t in cases.step_times(o.ctl)[:8]:
         o.run_timestep(t)
         s.run_timestep(t)
+    _compare(o, s)
+    s.close()
+
+
+# ---------------------------------------------------------------------------
+# the BASELINE configurations on their own grids / default mixing grid / ensembles / long run
+# ---------------------------------------------------------------------------
+
+def test_c3_grid_stochastic_parity():
+    """BASELINE configs[2] on ITS OWN grid (0.5 deg, 721 x 361 x 137 -- the grid bench.py runs): 2 x 10^5
+    particles, RK4 + turbulent + mesoscale diffusion + convection + sedimentation, six steps against the
+    multi-threaded oracle.  Exercises the 137-level pressure table and the 24-bit index arithmetic at the
+    extents the headline number is quoted on."""
+    n = 200000
+    ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=n, grid="C3",
+                                             fields=("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel"),
+                                             quantities=("m", "rp", "rhop"))
+    assert (m0.nx, m0.ny, m0.np) == (721, 361, 137)
+    B.lib().orc_set_num_threads(B.usable_cores())
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    for t in cases.step_times(o.ctl)[:7]:
+        o.run_timestep(t)
+        s.run_timestep(t)
+    _compare(o, s)
+    s.close()
+
+
+def _crowded(n, names, seed=5):
+    """Particles inside a 20 deg x 10 deg x 5 km box: ~100 per cell of the default 1 deg x 1 deg x 1 km mixing grid."""
+    atm = synthetic_particles(n, seed=seed, quantities=names, lon=(0.0, 20.0), lat=(0.0, 10.0), z=(5.0, 10.0))
+    if "vmr" in names:
+        atm["q"][list(names).index("vmr")] = 1e-9 * (1.0 + atm["lat"] / 10.0)
+    return atm
+
+
+def test_default_mixing_grid_360x180x90():
+    """module_mixing on the reference's DEFAULT grid (MIXING_NX/NY/NZ 360 x 180 x 90 = 5.8 x 10^6 cells,
+    mptrac.c:7631-7648) -- BASELINE configs[4] leaves it at that -- with module_sort, decay and deposition, ten steps."""
+    from mptrac_amd.ctl import ctl_from_quantities
+    names = cases.QUANTITIES + ("aoa",)
+    ctl = {k: v for k, v in cases.CASES["full"].items() if k not in ("mixing_nx", "mixing_ny", "mixing_nz")}
+    ctl.update(mixing_dt=180.0, sort_dt=540.0, **ctl_from_quantities(names))
+    m0 = synthetic_met("C1", 0.0, 1.0, fields=cases.PRESSURE_LEVEL_FIELDS)
+    m1 = synthetic_met("C1", 3600.0, 1.25, fields=cases.PRESSURE_LEVEL_FIELDS)
+    atm = _crowded(100000, names)
+    clim = cases.load_clim_tropo()
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    assert (s.ctl.mixing_nx, s.ctl.mixing_ny, s.ctl.mixing_nz) == (360, 180, 90)
+    for t in cases.step_times(o.ctl)[:11]:
+        o.run_timestep(t)
+        s.run_timestep(t)
+    im = names.index("m")
+    assert np.abs(o.state()["q"][im] - atm["q"][im]).max() > 1e-4       # mixing moved the masses
+    _compare(o, s)
+    s.close()
+
+
+@pytest.mark.parametrize("nens", [4, 1])
+def test_ensemble_mixing(nens):
+    """NENS > 0: every ensemble member mixes inside its own copy of the grid (index ens * ngrid + cell,
+    mptrac.c:5291-5294, 5305-5316), member id from the quantity `ens`."""
+    from mptrac_amd.ctl import ctl_from_quantities
+    names = ("m", "vmr", "ens", "aoa")
+    ctl = dict(cases.BASE, diffusion=1, turb_dz_trop=0.1, mixing_trop=1e-2, mixing_strat=1e-4, mixing_dt=180.0,
+               mixing_nx=72, mixing_ny=36, mixing_nz=30, nens=nens, **ctl_from_quantities(names))
+    m0 = synthetic_met("C1", 0.0, 1.0, fields=cases.PRESSURE_LEVEL_FIELDS)
+    m1 = synthetic_met("C1", 3600.0, 1.25, fields=cases.PRESSURE_LEVEL_FIELDS)
+    atm = _crowded(40000, names, seed=11)
+    ie = names.index("ens")
+    atm["q"][ie] = (np.arange(40000) * 7 % nens).astype(np.float64)
+    atm["q"][names.index("m")] += atm["q"][ie]          # members differ: mixing across them would show
+    clim = cases.load_clim_tropo()
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    for t in cases.step_times(o.ctl)[:8]:
+        o.run_timestep(t)
+        s.run_timestep(t)
+    r = o.state()
+    assert np.array_equal(r["q"][ie], atm["q"][ie])
+    assert np.abs(r["q"][0] - atm["q"][0]).max() > 1e-3
+    _compare(o, s)
+    s.close()
+
+
+def test_long_run_400_steps_with_prefetched_handovers():
+    """Drift check (was tools/gpu_soak.py): 2 x 10^4 particles, every module of the `full` case with
+    module_meteo, module_sort every 10 and mixing every 5 steps, 400 time steps over 20 h, three meteo hand-overs
+    through mphip_prefetch_met / mphip_commit_met, downloads on the way."""
+    from mptrac_amd.ctl import ctl_from_quantities
+    from mptrac_amd.synth import FIELDS_METEO_ONLY
+    names = ("m", "vmr", "rp", "rhop", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry", "aoa", "t", "u", "ps", "theta")
+    ctl = dict(cases.CASES["full"])
+    ctl.update(ctl_from_quantities(names))
+    ctl.update(t_stop=4 * 18000.0, dt_met=18000.0, met_dt_out=0.1, sort_dt=1800.0, mixing_dt=900.0)
+    fields = tuple(cases.PRESSURE_LEVEL_FIELDS) + tuple(FIELDS_METEO_ONLY)
+    mets = [synthetic_met("C1", 18000.0 * k, 1.0 + 0.1 * k, fields=fields) for k in range(6)]
+    atm = synthetic_particles(20000, seed=7, quantities=names)
+    clim = cases.load_clim_tropo()
+    B.lib().orc_set_num_threads(B.usable_cores())
+    o = B.Oracle(ctl, clim, mets[0], mets[1], atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, mets[0], mets[1], atm)
+    s.timesteps_init(0.0, 0.0)
+    s.prefetch_met(mets[2])
+    imet = 0
+    times = cases.step_times(o.ctl)
+    assert len(times) == 401
+    for k, t in enumerate(times):
+        if t > mets[imet + 1].time:
+            imet += 1
+            o.swap_met(mets[imet + 1])
+            s.commit_met()
+            if imet + 2 < len(mets):
+                s.prefetch_met(mets[imet + 2])
+        o.run_timestep(t)
+        s.run_timestep(t)
+        if k % 97 == 0:
+            _compare(o, s)
+    assert imet == 3
     _compare(o, s)
     s.close()
