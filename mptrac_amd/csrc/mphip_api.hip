@@ -49,6 +49,7 @@ struct mphip_ctx {
   bool have_ctl = false;
   DevClim *d_clim = nullptr;
   bool have_clim = false;
+  double *d_logtab = nullptr;         // table of the lean kernels' logarithm (mphip_logtab.hpp)
 
   // meteo
   MetSlot slot[2];
@@ -114,6 +115,7 @@ struct mphip_ctx {
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;
   bool force_generic = false;
+  bool test_lean = false;             // mphip_test_sincosf evaluates the lean kernels' version
   int steps_since_resort = 1 << 30;
 
   // sort
@@ -263,6 +265,7 @@ DevMet dev_met(const mphip_ctx *c) {
   M.p_step = M.p_ascending ? 1 : -1;
   M.ps11[0] = c->slot[0 ^ c->flip].ps11;
   M.ps11[1] = c->slot[1 ^ c->flip].ps11;
+  M.logtab = c->d_logtab;
   return M;
 }
 
@@ -574,7 +577,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   S.ctr_meso = ctr_meso;
   S.ctr_conv = ctr_conv;
   S.ctr_pbl = ctr_pbl;
-  const size_t lds = axes_lds_bytes(ctx) + sizeof(DevClim);
+  const size_t lds = axes_lds_bytes(ctx) + sizeof(DevClim) + sizeof(kLogTabHost);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof) {
     if (ctx->ev_used + 2 > ctx->ev.size()) {
@@ -594,7 +597,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   const bool rare = (ml_ && !ml_fast) || (mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u));
   // the specialised instantiations take module_timesteps / the dt store from the run-time mask
   // ... and run the lean code: lat/lon grid with a pressure look-up table
-  const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV;
+  const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
+    && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // 32-bit byte offsets into the packed grids
   const unsigned sel = (ctx->ctl.advect == 4 && !rare && !ml_ && !ctx->force_generic && lean_ok)
     ? ((mask | MPHIP_MOD_TIMESTEPS) & ~kStoreDt) : kMaskGeneric;
   switch (sel) {
@@ -1098,6 +1102,12 @@ int mphip_create(mphip_ctx **out, int device) {
     return 4;
   }
   memset(&ctx->ctl, 0, sizeof(ctx->ctl));
+  if (hipMalloc((void **) &ctx->d_logtab, sizeof(kLogTabHost)) != hipSuccess
+      || hipMemcpy(ctx->d_logtab, kLogTabHost, sizeof(kLogTabHost), hipMemcpyHostToDevice) != hipSuccess) {
+    fprintf(stderr, "mptrac_hip: cannot initialise device %d\n", device);
+    delete ctx;
+    return 4;
+  }
   *out = ctx;
   return 0;
 }
@@ -1125,6 +1135,7 @@ void mphip_destroy(mphip_ctx *ctx) {
       dev_free(p);
   }
   dev_free(ctx->d_clim);
+  dev_free(ctx->d_logtab);
   dev_free(ctx->d_axes);
   dev_free(ctx->d_wind);
   dev_free(ctx->d_temp);
@@ -1864,6 +1875,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     ctx->force_generic = value != 0;
     return 0;
   }
+  if (strcmp(name, "test_lean") == 0) {   // self tests: evaluate the lean kernels' sine / cosine
+    ctx->test_lean = value != 0;
+    return 0;
+  }
   if (strcmp(name, "locality_tile") == 0) {
     if (value < 0 || value > 64)
       return fail(ctx, "locality_tile must be in 0 ... 64");
@@ -1917,7 +1932,8 @@ int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, floa
   float *dc = nullptr, *ds = nullptr;
   HIPCHK(hipMalloc((void **) &dc, (size_t) count * sizeof(float)));
   HIPCHK(hipMalloc((void **) &ds, (size_t) count * sizeof(float)));
-  hipLaunchKernelGGL(test_sincosf_kernel, dim3(grid_for(count)), dim3(256), 0, ctx->stream, bits_first, count, dc, ds);
+  hipLaunchKernelGGL(test_sincosf_kernel, dim3(grid_for(count)), dim3(256), 0, ctx->stream, bits_first, count, dc, ds,
+                     ctx->test_lean ? 1 : 0);
   HIPCHK(hipMemcpyAsync(cos_out, dc, (size_t) count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(sin_out, ds, (size_t) count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1954,7 +1970,7 @@ int mphip_test_piece(mphip_ctx *ctx, int piece, int reps, double *checksum) {
   S.ctr_pbl = 0;
   double *d = nullptr;
   HIPCHK(hipMalloc((void **) &d, (size_t) ctx->np * sizeof(double)));
-  const size_t lds = axes_lds_bytes(ctx) + sizeof(DevClim);
+  const size_t lds = axes_lds_bytes(ctx) + sizeof(DevClim) + sizeof(kLogTabHost);
   switch (piece) {
 #define PIECE_CASE(K)                                                                                  \
   case K:                                                                                              \
@@ -1962,7 +1978,9 @@ int mphip_test_piece(mphip_ctx *ctx, int piece, int reps, double *checksum) {
     break;
     PIECE_CASE(0) PIECE_CASE(1) PIECE_CASE(2) PIECE_CASE(3) PIECE_CASE(4) PIECE_CASE(5) PIECE_CASE(6) PIECE_CASE(7)
     PIECE_CASE(8) PIECE_CASE(9) PIECE_CASE(10) PIECE_CASE(11) PIECE_CASE(12) PIECE_CASE(13) PIECE_CASE(14)
-    PIECE_CASE(15)
+    PIECE_CASE(15) PIECE_CASE(16) PIECE_CASE(17) PIECE_CASE(18) PIECE_CASE(19) PIECE_CASE(20) PIECE_CASE(21)
+    PIECE_CASE(22) PIECE_CASE(23) PIECE_CASE(24) PIECE_CASE(25) PIECE_CASE(26) PIECE_CASE(27) PIECE_CASE(28)
+    PIECE_CASE(29) PIECE_CASE(30)
 #undef PIECE_CASE
   default:
     (void) hipFree(d);
@@ -1989,7 +2007,7 @@ int mphip_test_rng(mphip_ctx *ctx, uint64_t ctr, long long n, int method, double
   double *d = nullptr;
   HIPCHK(hipMalloc((void **) &d, (size_t) std::max<long long>(n, 1) * sizeof(double)));
   hipLaunchKernelGGL(test_rng_kernel, dim3(grid_for(std::max<long long>(n, 1))), dim3(256), 0, ctx->stream, ctr, n,
-                     method, d);
+                     method, d, ctx->d_logtab);
   HIPCHK(hipMemcpyAsync(out, d, (size_t) n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipFree(d));

@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "../../include/mptrac_hip.h"
+#include "mphip_logtab.hpp"
 
 namespace mphip {
 
@@ -77,6 +78,7 @@ struct DevMet {
   double p_min, p_search_max;    // smallest node of the pressure axis, largest double below its largest node
   int p_cmp_off, p_step;         // ascending axis: 1, +1; descending: 0, -1 (the node that decides table index vs neighbour)
   float ps11[2];                 // ps of met0 / met1 at grid node [1][1] (module_position, quirk Q1)
+  const double *logtab;          // table of log_tab() (kLogTabN x 3 doubles), copied to LDS by the step kernel
 };
 
 struct DevAtm {
@@ -2211,13 +2213,13 @@ __device__ __forceinline__ double cos_latitude_k(double x) {
   const bool hi = ax > 0.78539816339744830962;
   const double y = hi ? (1.57079632679489655800e+00 - ax) + 6.12323399573676603587e-17 : ax;
   const double z = y * y;
-  double a = fma_k(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  double a = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
   a = fma_k(z, a, 2.75573137070700676789e-06);
   a = fma_k(z, a, -1.98412698298579493134e-04);
   a = fma_k(z, a, 8.33333333332248946124e-03);
   a = fma_k(z, a, -1.66666666666666324348e-01);
   const double ps = y + y * z * a;
-  double b = fma_k(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  double b = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
   b = fma_k(z, b, -2.75573143513906633035e-07);
   b = fma_k(z, b, 2.48015872894767294178e-05);
   b = fma_k(z, b, -1.38888888888741095749e-03);
@@ -2246,6 +2248,91 @@ __device__ __forceinline__ double dx2deg_k(const DegPerMetre &d, double dx_metre
 
 __device__ __forceinline__ double dy2deg_k(double dy_metres) {
   return ((dy_metres * 1e-3) * 180.) * (1.0 / (kPi * kRE));
+}
+
+// ---- random numbers -----------------------------------------------------------
+
+// log(X 2^-64) for X = (double) of a non-zero 64-bit integer: table-driven (tools/gen_log_table.py; table in
+// LDS), no division, ~27 instructions against ~58 of log_unit(); within 1.4 ulp of the exact logarithm (CPU
+// check of the same arithmetic over 2 x 10^7 arguments) where log_unit() / the C library are within 1 / 0.5
+__device__ __forceinline__ double log_tab(const double *__restrict__ tab, double X) {
+  const int hx = __double2hiint(X);
+  const int t = hx - 0x3fe60000;                       // x = 2^k z, z in [0.6875, 1.375)
+  const int i = (t >> 13) & (kLogTabN - 1);
+  const int k = t >> 20;
+  const double z = __hiloint2double(hx - (t & (int) 0xfff00000), __double2loint(X));
+  const double *e = tab + 3 * i;
+  const double invc = e[0], lh = e[1], ll = e[2];
+  const double r = __builtin_fma(z, invc, -1.0);     // |r| <= 2^-7, one rounding
+  const double kd = (double) (k - 64);
+  double p = r * (1.0 / 7) - 1.0 / 6;                  // (one SGPR constant per instruction on gfx950)
+  p = fma_k(r, p, 1.0 / 5);
+  p = fma_k(r, p, -1.0 / 4);
+  p = fma_k(r, p, 1.0 / 3);
+  p = fma_k(r, p, -1.0 / 2);
+  const double w = __builtin_fma(kd, kLn2Hi, lh);     // k ln2_hi is exact (trailing zeros)
+  const double hi = w + r;
+  const double lo = ((w - hi) + r) + __builtin_fma(kd, kLn2Lo, ll);
+  return __builtin_fma(r * r, p, lo) + hi;
+}
+
+// (double) r of a 64-bit integer in three instructions (both halves convert exactly, the fma rounds once)
+__device__ __forceinline__ double u64_to_double(uint64_t r) {
+  return __builtin_fma((double) (uint32_t) (r >> 32), 0x1p32, (double) (uint32_t) r);
+}
+
+// libm_sincosf_both with the sign of the cosine polynomial applied to its rounded result instead of to its
+// five coefficients (rounding commutes with negation: same bits)
+__device__ __forceinline__ void sincosf_lean(float y, float &sinv, float &cosv) {
+  double x = (double) y;
+  const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+  const int n = ((int32_t) (x * hpi_inv) + 0x800000) >> 24;
+  x = x - n * hpi;
+  const double xs = __hiloint2double(__double2hiint(x) ^ (((n + 1) & 2) << 30), __double2loint(x));   // quadrants 1, 2: -x
+  const double x2 = x * x;
+  float sp, cp;
+  {
+    const double x3 = xs * x2;
+    const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+    const double x7 = x3 * x2;
+    const double sn = __builtin_fma(x3, -0x1.555545995a603p-3, xs);
+    sp = (float) __builtin_fma(x7, s1, sn);
+  }
+  {
+    const double x4 = x2 * x2;
+    const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+    const double c1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 0x1p0);
+    const double x6 = x4 * x2;
+    const double c = __builtin_fma(x4, 0x1.55553e1068f19p-5, c1);
+    cp = __uint_as_float(__float_as_uint((float) __builtin_fma(x6, c2, c)) ^ ((uint32_t) (n & 2) << 30));
+  }
+  const bool even = (n & 1) == 0;
+  sinv = even ? sp : cp;
+  cosv = even ? cp : sp;
+}
+
+// normal_pair_from / normal_triple on these (same values up to the last place of the logarithm)
+__device__ __forceinline__ void normal_pair_lean(const double *__restrict__ ltab, uint64_t y, double &even, double &odd) {
+  const uint64_t ra = squares_from(y), rb = squares_from(y + kSquaresKey);
+  const double r = fsqrt(-2.0 * (ra == 0 ? -__builtin_inf() : log_tab(ltab, u64_to_double(ra))));
+  const float phif = (float) (u64_to_double(rb) * (2.0 * kPi * 0x1p-64));   // 2 pi u, u = r 2^-64 (exact scaling)
+  float sv, cv;
+  sincosf_lean(phif, sv, cv);
+  even = r * cv;
+  odd = r * sv;
+}
+
+__device__ __forceinline__ void normal_triple_lean(const double *__restrict__ ltab, uint64_t c0, uint64_t g, double &r0,
+                                                   double &r1, double &r2) {
+  const uint64_t i0 = 3 * g;
+  const bool odd = (i0 & 1) != 0;
+  const uint64_t y = (c0 + (i0 & ~1ull)) * kSquaresKey;
+  double ea, oa, eb, ob;
+  normal_pair_lean(ltab, y, ea, oa);
+  normal_pair_lean(ltab, y + 2 * kSquaresKey, eb, ob);
+  r0 = odd ? oa : ea;
+  r1 = odd ? eb : oa;
+  r2 = odd ? ob : eb;
 }
 
 // ---- stencil set-up ---------------------------------------------------------
@@ -2350,7 +2437,52 @@ __device__ __forceinline__ void raw_cell_fast(const DevMet &M, const Axes &A, do
 
 // ---- interpolation ----------------------------------------------------------
 
+// Gathers of the lean kernels address their records as (wave-uniform base in an SGPR pair) + (32-bit byte
+// offset per lane): one VGPR and one 32-bit multiply per address instead of a 64-bit multiply-add into a
+// register pair (launch_step checks that every packed grid is smaller than 4 GB)
+__device__ __forceinline__ unsigned cell32(const DevMet &M, const Stencil &s, int di, int dj) {
+  const unsigned base = __umul24(__umul24((unsigned) s.ix, (unsigned) M.ny) + (unsigned) s.iy, (unsigned) M.np)
+    + (unsigned) s.ip;
+  return base + (unsigned) di * ((unsigned) M.ny * (unsigned) M.np) + (unsigned) dj * (unsigned) M.np;
+}
+
+template <class T>
+__device__ __forceinline__ T load_at(const void *base, unsigned byte_offset) {
+  return *(const T *) ((const char *) base + byte_offset);
+}
+
+__device__ __forceinline__ void load_wind_cached32(const DevMet &M, const Stencil &s, WindCache &w) {
+  if (s.ix != w.ix || s.iy != w.iy || s.ip != w.ip) {
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+      for (int dj = 0; dj < 2; dj++) {
+        const unsigned off = 24u * cell32(M, s, di, dj);
+        asm volatile("global_load_dwordx4 %0, %3, %4\n\t"
+                     "global_load_dwordx4 %1, %3, %4 offset:16\n\t"
+                     "global_load_dwordx4 %2, %3, %4 offset:32"
+                     : "+v"(w.c.r[di][dj][0]), "+v"(w.c.r[di][dj][1]), "+v"(w.c.r[di][dj][2])
+                     : "v"(off), "s"(M.wind)
+                     : "memory");
+      }
+    w.ix = s.ix;
+    w.iy = s.iy;
+    w.ip = s.ip;
+  }
+}
+
+__device__ __forceinline__ void load_pair_2d32(const f32x4 *__restrict__ g, const DevMet &M, const Stencil &s, SurfA &c) {
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++)
+      c.v[di][dj] = load_at<f32x4>(g, 16u * col_of(M, s, di, dj));
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef MPHIP_WIND_SERIAL
+#define MPHIP_WIND_SERIAL 1
+#endif
 
 // Wind records of the lean kernels: {u0,v0,u1,v1,w0,w1} per level (snapshots 0 / 1), so that a level pair
 // is twelve floats whose (u,v) pairs of one snapshot sit in an aligned register pair -- the single-
@@ -2369,28 +2501,35 @@ __device__ __forceinline__ float wind_at(const WindCorners &c, int di, int dj, i
 // formed two at a time
 __device__ __forceinline__ void wind_uvw_fast(const WindCorners &c, const Stencil &s, double wt, double &u, double &v,
                                               double &w) {
-  double col[2][2][6];   // [di][dj][element]: wp * (lo - hi) + hi
-#pragma unroll
-  for (int di = 0; di < 2; di++)
-#pragma unroll
-    for (int dj = 0; dj < 2; dj++) {
-      const f32x4u r0 = c.r[di][dj][0], r1 = c.r[di][dj][1], r2 = c.r[di][dj][2];
-      // level ip: r0[0..3], r1[0..1]; level ip + 1: r1[2..3], r2[0..3]
-      const f32x2 d01 = __builtin_shufflevector(r0, r0, 0, 1) - __builtin_shufflevector(r1, r1, 2, 3);
-      const f32x2 d23 = __builtin_shufflevector(r0, r0, 2, 3) - __builtin_shufflevector(r2, r2, 0, 1);
-      const f32x2 d45 = __builtin_shufflevector(r1, r1, 0, 1) - __builtin_shufflevector(r2, r2, 2, 3);
-      const float d[6] = { d01[0], d01[1], d23[0], d23[1], d45[0], d45[1] };
-      const float h[6] = { r1[2], r1[3], r2[0], r2[1], r2[2], r2[3] };
-#pragma unroll
-      for (int e = 0; e < 6; e++)
-        col[di][dj][e] = s.wp * (double) d[e] + (double) h[e];
-    }
   double val[6];
+  // one register pair of elements at a time (u0 v0 | u1 v1 | w0 w1): with MPHIP_WIND_SERIAL the scheduler may
+  // not start the next pair before this one is reduced to its two values -- 16 instead of 48 live registers
 #pragma unroll
-  for (int e = 0; e < 6; e++) {
-    const double r0 = s.wy * (col[0][0][e] - col[0][1][e]) + col[0][1][e];
-    const double r1 = s.wy * (col[1][0][e] - col[1][1][e]) + col[1][1][e];
-    val[e] = s.wx * (r0 - r1) + r1;
+  for (int pr = 0; pr < 3; pr++) {
+    double col[2][2][2];   // [di][dj][element of the pair]: wp * (lo - hi) + hi
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+      for (int dj = 0; dj < 2; dj++) {
+        const f32x4u r0 = c.r[di][dj][0], r1 = c.r[di][dj][1], r2 = c.r[di][dj][2];
+        // level ip: r0[0..3], r1[0..1]; level ip + 1: r1[2..3], r2[0..3]
+        const f32x2 lo = pr == 0 ? __builtin_shufflevector(r0, r0, 0, 1)
+          : (pr == 1 ? __builtin_shufflevector(r0, r0, 2, 3) : __builtin_shufflevector(r1, r1, 0, 1));
+        const f32x2 hi = pr == 0 ? __builtin_shufflevector(r1, r1, 2, 3)
+          : (pr == 1 ? __builtin_shufflevector(r2, r2, 0, 1) : __builtin_shufflevector(r2, r2, 2, 3));
+        const f32x2 d = lo - hi;
+        col[di][dj][0] = s.wp * (double) d[0] + (double) hi[0];
+        col[di][dj][1] = s.wp * (double) d[1] + (double) hi[1];
+      }
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const double r0 = s.wy * (col[0][0][e] - col[0][1][e]) + col[0][1][e];
+      const double r1 = s.wy * (col[1][0][e] - col[1][1][e]) + col[1][1][e];
+      val[2 * pr + e] = s.wx * (r0 - r1) + r1;
+    }
+#if MPHIP_WIND_SERIAL
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
   u = wt * (val[0] - val[2]) + val[2];
   v = wt * (val[1] - val[3]) + val[3];
@@ -2424,7 +2563,7 @@ __device__ __forceinline__ double temp_fast(const DevMet &M, const Stencil &s, d
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++) {
-      const f32x4u q = *(const f32x4u *) (M.temp + 2 * cell_of(M, s, di, dj));   // {t0,t1} at ip, {t0,t1} at ip + 1
+      const f32x4u q = load_at<f32x4u>(M.temp, 8u * cell32(M, s, di, dj));   // {t0,t1} at ip, {t0,t1} at ip + 1
       const f32x2 d = __builtin_shufflevector(q, q, 0, 1) - __builtin_shufflevector(q, q, 2, 3);
       col[di][dj][0] = s.wp * (double) d[0] + (double) q[2];
       col[di][dj][1] = s.wp * (double) d[1] + (double) q[3];
@@ -2489,7 +2628,7 @@ __device__ __forceinline__ void advect_rk4_fast(const DevMet &M, const Axes &A, 
     }
     Stencil s;
     stencil_3d_fast(M, A, x2, x0, x1, s);
-    load_wind_cached(M, s, wc);
+    load_wind_cached32(M, s, wc);
     hook(i);
     wind_cache_wait(wc);
     wind_uvw_fast(wc.c, s, time_weight(M, P.time + dts), u, v, w);
@@ -2506,11 +2645,12 @@ __device__ __forceinline__ void advect_rk4_fast(const DevMet &M, const Axes &A, 
 
 // module_diff_turb (mptrac.c:4603-4733)
 __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevClim &C,
-                                               Particle &P, uint64_t ctr, uint64_t g, const double *pre) {
+                                               Particle &P, uint64_t ctr, uint64_t g, const double *pre,
+                                               const double *ltab) {
   Stencil s = stencil_zero();
   horiz_fast(M, A, P.lon, P.lat, s);
   SurfA c;
-  load_sfa(M, s, c);
+  load_pair_2d32(M.sfa, M, s, c);
   const double wt = time_weight(M, P.time);
   const double pbl = pair_time_2d_fast(c, s, wt, 1);
   if (ctl.turb_pbl_scheme > 0 && P.p >= pbl)
@@ -2531,7 +2671,7 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
     rs1 = pre[1];
     rs2 = pre[2];
   } else
-    normal_triple(ctr, g, rs0, rs1, rs2);
+    normal_triple_lean(ltab, ctr, g, rs0, rs1, rs2);
 
   if (Kx > 0) {
     const double sigma_h = fsqrt(2.0 * Kx * dt_abs);
@@ -2569,11 +2709,11 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
 // module_diff_meso (mptrac.c:4280-4338) on the {u0,v0,u1,v1,w0,w1} records
 __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                                float &up, float &vp, float &wp, uint64_t ctr, uint64_t g,
-                                               const double *pre, WindCache &wc) {
+                                               const double *pre, WindCache &wc, const double *ltab) {
 #pragma clang fp contract(off)
   Stencil s;
   raw_cell_fast(M, A, P.lon, P.lat, P.p, s);
-  load_wind_cached(M, s, wc);
+  load_wind_cached32(M, s, wc);
   wind_cache_wait(wc);
   const WindCorners &c = wc.c;
 
@@ -2617,7 +2757,7 @@ __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const Dev
     rs1 = pre[1];
     rs2 = pre[2];
   } else
-    normal_triple(ctr, g, rs0, rs1, rs2);
+    normal_triple_lean(ltab, ctr, g, rs0, rs1, rs2);
 
   if (ctl.turb_mesox > 0) {
     up = (float) (r * up + r2 * rs0 * ctl.turb_mesox * sd[0]);
@@ -2643,7 +2783,7 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
   const double wt = time_weight(M, P.time);
   if (mask & MPHIP_MOD_CONVECTION) {
     SurfA c;
-    load_sfa(M, s, c);
+    load_pair_2d32(M.sfa, M, s, c);
     const double ps = pair_time_2d_fast(c, s, wt, 0);
     double pbot = ps, ptop = ps;
     if (ctl.conv_mix_pbl) {
@@ -2653,7 +2793,7 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
     if (ctl.conv_cape >= 0) {
       if (ctl.conv_cin <= 0) {
         SurfA b;
-        load_pair_2d(M.cp2, M, s, b);
+        load_pair_2d32(M.cp2, M, s, b);
         const double cape = pair_time_2d_fast(b, s, wt, 0);
         const double pel = pair_time_2d_fast(b, s, wt, 1);
         if (isfinite(cape) && cape >= ctl.conv_cape)

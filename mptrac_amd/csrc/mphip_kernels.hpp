@@ -162,8 +162,14 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
 // places workgroup b on XCD b % 8) walks one contiguous eighth of the particle
 // arrays: with cell-sorted particles each XCD's L2 then holds one region of
 // the meteo grid instead of all of it.
+// Waves per SIMD the register allocation aims at: 4 for the lean instantiations (128 VGPRs without scratch --
+// reached by reducing the wind interpolation one element pair at a time, MPHIP_WIND_SERIAL, and by drawing
+// the random numbers where they are used, MPHIP_RNG_EARLY 0), 3 for the general ones
 #ifndef MPHIP_STEP_WAVES_PER_SIMD
 #define MPHIP_STEP_WAVES_PER_SIMD 3
+#endif
+#ifndef MPHIP_LEAN_WAVES_PER_SIMD
+#define MPHIP_LEAN_WAVES_PER_SIMD 4
 #endif
 // 1: the specialised instantiations evaluate the random numbers of the
 // stochastic modules between the gathers of the Runge-Kutta stages and their
@@ -172,7 +178,7 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
 #define MPHIP_PARAMS_RELOAD 1
 #endif
 #ifndef MPHIP_RNG_EARLY
-#define MPHIP_RNG_EARLY 1
+#define MPHIP_RNG_EARLY 0
 #endif
 
 // keeps a value where it was computed (the optimiser would sink the whole chain to its first use)
@@ -180,19 +186,59 @@ __device__ __forceinline__ void pin(double &x) {
   asm volatile("" : "+v"(x));
 }
 
+// 1: one Box-Muller pair behind the gathers of every Runge-Kutta stage (turb A, turb B, meso A, meso B + the
+// convection uniform) instead of a whole triple behind stages 0 and 1: every wait of the integrator has
+// independent arithmetic to cover it
+#ifndef MPHIP_RNG_BALANCED
+#define MPHIP_RNG_BALANCED 1
+#endif
+
 struct RngEarly {
   unsigned mask;
   uint64_t ctr_turb, ctr_meso, ctr_conv, g;
+  const double *ltab;
   double turb[3], meso[3], conv;
+  double e, o;   // first pair of the triple under construction
+  // pair `which` (0, 1) of the triple rs[3g .. 3g + 2] of a module_rng call with base counter c0; the second
+  // pair completes out[0 .. 2] (selection as normal_triple)
+  __device__ __forceinline__ void pair_of(uint64_t c0, int which, double *out) {
+    const uint64_t i0 = 3 * g;
+    const uint64_t y = (c0 + (i0 & ~1ull)) * kSquaresKey;
+    if (which == 0) {
+      normal_pair_lean(ltab, y, e, o);
+      pin(e);
+      pin(o);
+    } else {
+      double eb, ob;
+      normal_pair_lean(ltab, y + 2 * kSquaresKey, eb, ob);
+      const bool odd = (i0 & 1) != 0;
+      out[0] = odd ? o : e;
+      out[1] = odd ? eb : o;
+      out[2] = odd ? ob : eb;
+      pin(out[0]);
+      pin(out[1]);
+      pin(out[2]);
+    }
+  }
   __device__ __forceinline__ void operator()(int stage) {
+#if MPHIP_RNG_BALANCED
+    if (stage < 2 && (mask & MPHIP_MOD_DIFF_TURB))
+      pair_of(ctr_turb, stage, turb);
+    if (stage >= 2 && (mask & MPHIP_MOD_DIFF_MESO))
+      pair_of(ctr_meso, stage - 2, meso);
+    if (stage == 3 && (mask & MPHIP_MOD_CONVECTION)) {
+      conv = uniform01(ctr_conv + g);
+      pin(conv);
+    }
+#else
     if (stage == 0 && (mask & MPHIP_MOD_DIFF_TURB)) {
-      normal_triple(ctr_turb, g, turb[0], turb[1], turb[2]);
+      normal_triple_lean(ltab, ctr_turb, g, turb[0], turb[1], turb[2]);
       pin(turb[0]);
       pin(turb[1]);
       pin(turb[2]);
     }
     if (stage == 1 && (mask & MPHIP_MOD_DIFF_MESO)) {
-      normal_triple(ctr_meso, g, meso[0], meso[1], meso[2]);
+      normal_triple_lean(ltab, ctr_meso, g, meso[0], meso[1], meso[2]);
       pin(meso[0]);
       pin(meso[1]);
       pin(meso[2]);
@@ -201,10 +247,12 @@ struct RngEarly {
       conv = uniform01(ctr_conv + g);
       pin(conv);
     }
+#endif
   }
 };
 template <unsigned CT>
-__global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(const StepParams S) {
+__global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD : MPHIP_LEAN_WAVES_PER_SIMD) void step_kernel(
+  const StepParams S) {
   extern __shared__ double s_axes[];
   const unsigned mask = kRuntimeMask<CT> ? S.mask : CT;
   const DevMet &M = S.met;
@@ -221,6 +269,15 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     for (int i = threadIdx.x; i < (int) (sizeof(DevClim) / sizeof(double)); i += blockDim.x)
       dst[i] = src[i];
     clim = (const DevClim *) dst;
+  }
+  // ... and the table of the lean logarithm behind it (3 kB)
+  const double *ltab = nullptr;
+  if (!kRuntimeMask<CT> && (mask & (MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO))) {
+    double *dst = s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8
+      + sizeof(DevClim) / sizeof(double);
+    for (int i = threadIdx.x; i < 3 * kLogTabN; i += blockDim.x)
+      dst[i] = M.logtab[i];
+    ltab = dst;
   }
   __syncthreads();
 
@@ -299,11 +356,13 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     pre.ctr_meso = S.ctr_meso;
     pre.ctr_conv = S.ctr_conv;
     pre.g = g;
+    pre.ltab = ltab;
 
     // the specialised instantiations run the lean versions (lat/lon grid, pressure table: launch_step)
     constexpr bool lean = !kRuntimeMask<CT>;
     WindCache wc;
-    wind_cache_reset(wc, CT != kMaskGeneric);
+    if (CT != kMaskGenericML)   // (model-level winds: the corners are first needed by module_diff_meso -- defined there,
+      wind_cache_reset(wc, CT != kMaskGeneric);   //  or 48 registers would be held through the whole advection)
     if (mask & MPHIP_MOD_POSITION) {
       if (lean)
         position_fast(M, A, P);
@@ -340,7 +399,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     }
     if (mask & MPHIP_MOD_DIFF_TURB) {
       if (lean)
-        diff_turb_fast(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr);
+        diff_turb_fast(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr, ltab);
       else
         diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr);
     }
@@ -353,8 +412,10 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void step_kernel(co
     }
     if (mask & MPHIP_MOD_DIFF_MESO) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
+      if (CT == kMaskGenericML)
+        wind_cache_reset(wc, true);
       if (lean)
-        diff_meso_fast(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc);
+        diff_meso_fast(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc, ltab);
       else
         diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc);
       a.up[i] = up;
@@ -1179,11 +1240,16 @@ __global__ __launch_bounds__(256, MPHIP_METEO_WAVES_PER_SIMD) void meteo_kernel(
 // self-test kernels
 // ---------------------------------------------------------------------------
 
-__global__ void test_sincosf_kernel(uint32_t first, uint32_t count, float *__restrict__ c, float *__restrict__ s) {
+__global__ void test_sincosf_kernel(uint32_t first, uint32_t count, float *__restrict__ c, float *__restrict__ s,
+                                    int lean) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const float x = __uint_as_float(first + i);
-    c[i] = libm_sincosf(x, 1);
-    s[i] = libm_sincosf(x, 0);
+    if (lean)
+      sincosf_lean(x, s[i], c[i]);
+    else {
+      c[i] = libm_sincosf(x, 1);
+      s[i] = libm_sincosf(x, 0);
+    }
   }
 }
 
@@ -1204,6 +1270,9 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
   for (int i = threadIdx.x; i < (int) (sizeof(DevClim) / sizeof(double)); i += blockDim.x)
     dst[i] = src[i];
   const DevClim &clim = *(const DevClim *) dst;
+  double *ltab = dst + sizeof(DevClim) / sizeof(double);
+  for (int i = threadIdx.x; i < 3 * kLogTabN; i += blockDim.x)
+    ltab[i] = M.logtab[i];
   __syncthreads();
   const int nb = S.nblocks_logical;
   const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
@@ -1300,6 +1369,87 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
         NoHook none;
         advect_n<4>(M, A, Q, none, wc);
         acc += Q.lon + Q.lat + Q.p;
+      } else if (PIECE == 16) {
+        Stencil s;
+        stencil_3d_fast(M, A, p, lon, lat, s);
+        acc += s.wp + s.wx + s.wy + (double) (s.ip + s.ix + s.iy);
+      } else if (PIECE == 17) {
+        Stencil s = stencil_zero();
+        horiz_fast(M, A, lon, lat, s);
+        acc += s.wx + s.wy + (double) (s.ix + s.iy);
+      } else if (PIECE == 18) {   // one Runge-Kutta stage's interpolation, lean
+        Stencil s;
+        stencil_3d_fast(M, A, p, lon, lat, s);
+        WindCorners c;
+        load_wind(M, s, c);
+        double u, v, w;
+        wind_uvw_fast(c, s, time_weight(M, P.time + r), u, v, w);
+        acc += u + v + w;
+      } else if (PIECE == 19) {
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        position_fast(M, A, Q);
+        acc += Q.lon + Q.lat + Q.p;
+      } else if (PIECE == 20) {
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        diff_turb_fast(ctl, M, A, clim, Q, S.ctr_turb + (uint64_t) r, g, nullptr, ltab);
+        acc += Q.lon + Q.lat + Q.p;
+      } else if (PIECE == 21) {
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        conv_sedi_fast(ctl, M, A, Q, MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI, S.ctr_conv + (uint64_t) r, g, nullptr, 1.0, 1000.0);
+        acc += Q.p;
+      } else if (PIECE == 22) {
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        float up = 0.1f * r, vp = 0.2f, wp = 1e-4f;
+        WindCache wc;
+        wind_cache_reset(wc, true);
+        diff_meso_fast(ctl, M, A, Q, up, vp, wp, S.ctr_meso + (uint64_t) r, g, nullptr, wc, ltab);
+        acc += Q.lon + Q.lat + Q.p + (double) (up + vp + wp);
+      } else if (PIECE == 23) {
+        Particle Q = P;
+        Q.lon = lon;
+        Q.lat = lat;
+        Q.p = p;
+        WindCache wc;
+        wind_cache_reset(wc, true);
+        NoHook none;
+        advect_rk4_fast(M, A, Q, none, wc);
+        acc += Q.lon + Q.lat + Q.p;
+      } else if (PIECE == 24) {
+        double rr = 0.0;
+        normal_pair_from((S.ctr_turb + g + (uint64_t) r) * kSquaresKey, acc, rr);
+        acc += rr;
+      } else if (PIECE == 25) {
+        acc += log_unit(uniform01(S.ctr_turb + g + (uint64_t) r));
+      } else if (PIECE == 26) {
+        float sv, cv;
+        libm_sincosf_both((float) (6.28 * uniform01(S.ctr_turb + g + (uint64_t) r)), sv, cv);
+        acc += (double) sv + (double) cv;
+      } else if (PIECE == 27) {
+        double rr = 0.0, ee = 0.0;
+        normal_pair_lean(ltab, (S.ctr_turb + g + (uint64_t) r) * kSquaresKey, ee, rr);
+        acc += rr + ee;
+      } else if (PIECE == 28) {
+        acc += log_tab(ltab, u64_to_double(squares(S.ctr_turb + g + (uint64_t) r) | 1));
+      } else if (PIECE == 29) {
+        float sv, cv;
+        sincosf_lean((float) (6.28 * uniform01(S.ctr_turb + g + (uint64_t) r)), sv, cv);
+        acc += (double) sv + (double) cv;
+      } else if (PIECE == 30) {
+        double r0, r1, r2;
+        normal_triple_lean(ltab, S.ctr_turb + (uint64_t) r, g, r0, r1, r2);
+        acc += r0 + r1 + r2;
       } else {
         acc += lon + lat + p;
       }
@@ -1309,11 +1459,16 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
 }
 
 // out[i], i < n: what module_rng(ctl, rs, n, method) leaves in rs[i]
-__global__ void test_rng_kernel(uint64_t ctr, long long n, int method, double *__restrict__ out) {
+__global__ void test_rng_kernel(uint64_t ctr, long long n, int method, double *__restrict__ out,
+                                const double *__restrict__ ltab) {
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
     if (method == 0)
       out[i] = uniform01(ctr + (uint64_t) i);
-    else {
+    else if (method == 3) {   // the lean kernels' normals (table logarithm; ltab in global memory here)
+      double e, o;
+      normal_pair_lean(ltab, (ctr + ((uint64_t) i & ~1ull)) * kSquaresKey, e, o);
+      out[i] = (i & 1) ? o : e;
+    } else {
       double e, o;
       normal_pair(ctr, (uint64_t) i & ~1ull, e, o);
       out[i] = (i & 1) ? o : e;

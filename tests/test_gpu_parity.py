@@ -51,10 +51,13 @@ def _compare(o, s, tol=TOL):
 # building blocks
 # ---------------------------------------------------------------------------
 
-def test_sincosf_is_bit_identical_to_libm():
+@pytest.mark.parametrize("lean", [0, 1])
+def test_sincosf_is_bit_identical_to_libm(lean):
     """The Box-Muller angle goes through single-precision cosf/sinf
-    (mptrac.c:5824-5825); the device restatement must give glibc's bits."""
+    (mptrac.c:5824-5825); the device restatement must give glibc's bits --
+    both the general one and the one of the lean kernels (sincosf_lean)."""
     _, s = _pair("advect", n=16)
+    s.set_option("test_lean", lean)
     L = B.lib()
     fp = C.POINTER(C.c_float)
     two_pi_bits = 0x40c90fdb
@@ -97,6 +100,9 @@ def test_rng_stream_matches_module_rng(ctr, n):
             assert np.array_equal(dev, ref)              # uniforms: bit-exact
         else:
             assert cases.rel_err(dev, ref) <= 1e-14      # log(): device vs glibc ulp
+            lean = s.test_rng(ctr, n, 3)                 # the lean kernels' normals (table-driven logarithm)
+            assert cases.rel_err(lean, ref) <= 1e-14
+            assert float(np.max(np.abs(lean - ref) / np.maximum(np.abs(ref), 1e-300))) <= 1e-13
     s.close()
 
 

@@ -15,7 +15,11 @@ from mptrac_amd import hip  # noqa: E402
 PIECES = {0: "empty (load state, store)", 1: "stencil_3d", 2: "stencil_2d", 3: "RK stage: stencil_3d + 12 loads + u,v,w",
           4: "normal_triple", 5: "module_position", 6: "stencil_2d + {ps,pbl} interpolation", 7: "temperature_at",
           8: "dx2coord + dy2coord", 9: "tropo_weight", 10: "sedi()", 11: "uniform01", 12: "module_diff_turb",
-          13: "module_convection + module_sedi", 14: "module_diff_meso", 15: "module_advect RK4 (no corner cache)"}
+          13: "module_convection + module_sedi", 14: "module_diff_meso", 15: "module_advect RK4 (no corner cache)",
+          16: "lean: stencil_3d", 17: "lean: horizontal stencil", 18: "lean: RK stage (stencil + loads + u,v,w)",
+          19: "lean: module_position", 20: "lean: module_diff_turb", 21: "lean: convection + sedi",
+          22: "lean: module_diff_meso", 23: "lean: module_advect RK4 (corner cache)", 24: "normal_pair (uniforms included)",
+          25: "log_unit(uniform01)", 26: "sincosf(2 pi uniform01)"}
 
 
 def main():
