@@ -24,7 +24,7 @@ constexpr unsigned kAdvTurb = kAdv | MPHIP_MOD_DIFF_TURB;
 constexpr unsigned kAdvDiff = kAdvTurb | MPHIP_MOD_DIFF_MESO;
 constexpr unsigned kAdvTurbConvSedi = kAdvTurb | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kAdvDiffConvSedi = kAdvDiff | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
-constexpr unsigned kAdvDiffConvSediDecay = kAdvDiffConvSedi | MPHIP_MOD_DECAY;
+constexpr unsigned kTailOnly = MPHIP_MOD_TIMESTEPS;   // no mover: a launch of loss / decay / deposition modules only
 constexpr unsigned kParticleBits = 0x3fffu | MPHIP_MOD_ISOSURF | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2
   | MPHIP_MOD_ISOSURF_INIT;
 
@@ -115,7 +115,7 @@ struct mphip_ctx {
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;
   bool force_generic = false;
-  bool test_lean = false;             // mphip_test_sincosf evaluates the lean kernels' version
+  int sort_bits = 0;                  // digit width of the radix sort (0 = fewest passes; 8, 9, 10: tuning / tests)
   int steps_since_resort = 1 << 30;
 
   // sort
@@ -599,8 +599,9 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // ... and run the lean code: lat/lon grid with a pressure look-up table
   const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
     && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // 32-bit byte offsets into the packed grids
-  const unsigned sel = (ctx->ctl.advect == 4 && !rare && !ml_ && !ctx->force_generic && lean_ok)
-    ? ((mask | MPHIP_MOD_TIMESTEPS) & ~kStoreDt) : kMaskGeneric;
+  // (the lean instantiations are keyed on the movers; loss / decay / deposition are run-time bits in all of them)
+  const unsigned sel = ((ctx->ctl.advect == 4 || !(mask & MPHIP_MOD_ADVECT)) && !rare && !ml_ && !ctx->force_generic && lean_ok)
+    ? ((mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules)) : kMaskGeneric;
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
   case M:                                                                                             \
@@ -611,7 +612,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiff)
     STEP_CASE(kAdvTurbConvSedi)
     STEP_CASE(kAdvDiffConvSedi)
-    STEP_CASE(kAdvDiffConvSediDecay)
+    STEP_CASE(kTailOnly)
 #undef STEP_CASE
   default:
     if (rare || ctx->force_generic)
@@ -797,7 +798,26 @@ void perm_swap(mphip_ctx *ctx, bool with_cache) {
 int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep_t = nullptr) {
   const long long n = ctx->np;
   const int ntiles = (int) ((n + kSortTile - 1) / kSortTile);
-  const size_t m = (size_t) kRadix * ntiles;
+  // number of key bits that can be non-zero -> digit width with the fewest passes (8 bits if it is a tie)
+  unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
+  if (tile > 0) {
+    const unsigned long long ntx = (ctx->nx + tile - 1) / tile, nty = (ctx->ny + tile - 1) / tile;
+    kmax = ntx * nty * ctx->npl * tile * tile;
+  }
+  if (kmax > 0xffffffffULL)
+    return fail(ctx, "meteo grid too large for the 32-bit sort key");
+  int key_bits = 1;
+  while (key_bits < 32 && (kmax >> key_bits) != 0)
+    key_bits++;
+  int bits = ctx->sort_bits;
+  if (bits == 0) {
+    bits = 8;
+    for (int b = 9; b <= kRadixMaxBits; b++)
+      if ((key_bits + b - 1) / b < (key_bits + bits - 1) / bits)
+        bits = b;
+  }
+  const int passes = (key_bits + bits - 1) / bits;
+  const size_t m = ((size_t) 1 << bits) * ntiles;
   const int nchunks = (int) ((m + kScanChunk - 1) / kScanChunk);
   if (nchunks > kScanThreads)
     return fail(ctx, "too many particles for the two-level scan of module_sort");
@@ -812,28 +832,26 @@ int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep
   TimestepArgs ts = { (double) ctx->ctl.direction, ctx->ctl.t_start, ctx->ctl.t_stop, timestep_t ? *timestep_t : 0.0 };
   hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
                      ctx->d_keys[0], ctx->d_vals[0], ts, timestep_t ? ctx->d_dt : nullptr);
-  // number of 8-bit digits that can be non-zero
-  unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
-  if (tile > 0) {
-    const unsigned long long ntx = (ctx->nx + tile - 1) / tile, nty = (ctx->ny + tile - 1) / tile;
-    kmax = ntx * nty * ctx->npl * tile * tile;
-  }
-  if (kmax > 0xffffffffULL)
-    return fail(ctx, "meteo grid too large for the 32-bit sort key");
-  int passes = 1;
-  while (passes < 4 && (kmax >> (8 * passes)) != 0)
-    passes++;
   int cur = 0;
   for (int pass = 0; pass < passes; pass++) {
-    const int shift = 8 * pass;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur], n, shift,
-                       ntiles, ctx->d_counts);
-    hipLaunchKernelGGL(sort_scan_local_kernel, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream, ctx->d_counts, m,
-                       d_chunks);
-    hipLaunchKernelGGL(sort_scan_chunks_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_chunks, nchunks);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur],
-                       ctx->d_vals[cur], ctx->d_keys[cur ^ 1], ctx->d_vals[cur ^ 1], n, shift, ntiles, ctx->d_counts,
-                       d_chunks);
+    const int shift = bits * pass;
+#define SORT_PASS(B)                                                                                                   \
+  hipLaunchKernelGGL(sort_hist_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur], n, shift, \
+                     ntiles, ctx->d_counts);                                                                           \
+  hipLaunchKernelGGL(sort_scan_local_kernel, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream, ctx->d_counts, m,      \
+                     d_chunks);                                                                                        \
+  hipLaunchKernelGGL(sort_scan_chunks_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_chunks, nchunks);         \
+  hipLaunchKernelGGL(sort_scatter_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur],       \
+                     ctx->d_vals[cur], ctx->d_keys[cur ^ 1], ctx->d_vals[cur ^ 1], n, shift, ntiles, ctx->d_counts,    \
+                     d_chunks)
+    if (bits == 8) {
+      SORT_PASS(8);
+    } else if (bits == 9) {
+      SORT_PASS(9);
+    } else {
+      SORT_PASS(10);
+    }
+#undef SORT_PASS
     cur ^= 1;
   }
   HIPCHK(hipGetLastError());
@@ -1875,8 +1893,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     ctx->force_generic = value != 0;
     return 0;
   }
-  if (strcmp(name, "test_lean") == 0) {   // self tests: evaluate the lean kernels' sine / cosine
-    ctx->test_lean = value != 0;
+  if (strcmp(name, "sort_bits") == 0) {
+    if (!(value == 0 || (value >= 8 && value <= kRadixMaxBits)))
+      return fail(ctx, "sort_bits must be 0 (automatic), 8, 9 or 10");
+    ctx->sort_bits = (int) value;
     return 0;
   }
   if (strcmp(name, "locality_tile") == 0) {
@@ -1932,8 +1952,7 @@ int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, floa
   float *dc = nullptr, *ds = nullptr;
   HIPCHK(hipMalloc((void **) &dc, (size_t) count * sizeof(float)));
   HIPCHK(hipMalloc((void **) &ds, (size_t) count * sizeof(float)));
-  hipLaunchKernelGGL(test_sincosf_kernel, dim3(grid_for(count)), dim3(256), 0, ctx->stream, bits_first, count, dc, ds,
-                     ctx->test_lean ? 1 : 0);
+  hipLaunchKernelGGL(test_sincosf_kernel, dim3(grid_for(count)), dim3(256), 0, ctx->stream, bits_first, count, dc, ds);
   HIPCHK(hipMemcpyAsync(cos_out, dc, (size_t) count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(sin_out, ds, (size_t) count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1979,8 +1998,7 @@ int mphip_test_piece(mphip_ctx *ctx, int piece, int reps, double *checksum) {
     PIECE_CASE(0) PIECE_CASE(1) PIECE_CASE(2) PIECE_CASE(3) PIECE_CASE(4) PIECE_CASE(5) PIECE_CASE(6) PIECE_CASE(7)
     PIECE_CASE(8) PIECE_CASE(9) PIECE_CASE(10) PIECE_CASE(11) PIECE_CASE(12) PIECE_CASE(13) PIECE_CASE(14)
     PIECE_CASE(15) PIECE_CASE(16) PIECE_CASE(17) PIECE_CASE(18) PIECE_CASE(19) PIECE_CASE(20) PIECE_CASE(21)
-    PIECE_CASE(22) PIECE_CASE(23) PIECE_CASE(24) PIECE_CASE(25) PIECE_CASE(26) PIECE_CASE(27) PIECE_CASE(28)
-    PIECE_CASE(29) PIECE_CASE(30)
+    PIECE_CASE(22) PIECE_CASE(23) PIECE_CASE(24) PIECE_CASE(25) PIECE_CASE(26)
 #undef PIECE_CASE
   default:
     (void) hipFree(d);

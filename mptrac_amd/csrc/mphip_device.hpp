@@ -199,33 +199,78 @@ __device__ __forceinline__ double fsqrt(double x) {
 #endif
 }
 
-// log(u) for the Box-Muller radius, u = r / 2^64 in [0, 1]: the fdlibm algorithm (argument reduced to
-// [sqrt(1/2), sqrt(2)), s = f / (2 + f), degree-14 even polynomial); within one ulp of the C library
-// on that range (checked on the CPU).  log(0) = -inf like the library.
-__device__ __forceinline__ double log_unit(double x) {
-#if MPHIP_EXACT_DIV
-  return log(x);
-#else
-  int hx = __double2hiint(x);
-  int k = (hx >> 20) - 1023;
-  hx &= 0x000fffff;
-  const int i = (hx + 0x95f64) & 0x100000;
-  k += i >> 20;
-  const double xn = __hiloint2double(hx | (i ^ 0x3ff00000), __double2loint(x));
-  const double f = xn - 1.0;
-  const double s = fdiv(f, 2.0 + f);
-  const double dk = (double) k;
-  const double z = s * s, w = z * z;
-  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
-  const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01
-    + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
-  const double R = t2 + t1;
-  const bool mid = ((hx - 0x6147a) | (0x6b851 - hx)) > 0;
-  const double hfsq = 0.5 * f * f;
-  const double a = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
-  const double b = dk * 6.93147180369123816490e-01 - ((s * (f - R) - dk * 1.90821492927058770002e-10) - f);
-  return x == 0.0 ? -__builtin_inf() : (mid ? a : b);
-#endif
+// ---- one-instruction forms the compiler does not pick by itself ---------------
+
+__device__ __forceinline__ double vmin(double a, double b) {   // v_min_f64 without the canonicalising copies
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// the same with a wave-uniform second operand (kernel argument): stays in its SGPR pair
+__device__ __forceinline__ double vmin_s(double a, double s) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));
+  return r;
+}
+
+__device__ __forceinline__ double vmax_s(double a, double s) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));
+  return r;
+}
+
+// min(max(x, 0), hi) with a wave-uniform hi >= 0
+__device__ __forceinline__ int clamp0_s(int x, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+  return r;
+}
+
+// x * y + c with a literal constant c: the constant goes into an SGPR pair (two scalar moves beside the
+// vector pipe) -- left to itself the compiler often builds it in a VGPR pair with two v_mov per Horner step
+__device__ __forceinline__ double fma_k(double x, double y, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "s"(c));
+  return r;
+}
+
+// 1 / b to an ulp or two (rcp + two Newton steps)
+__device__ __forceinline__ double frcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+}
+
+// cos_latitude with the polynomial constants in SGPRs
+__device__ __forceinline__ double cos_latitude_k(double x) {
+  const double ax = fabs(x);
+  const bool hi = ax > 0.78539816339744830962;
+  const double y = hi ? (1.57079632679489655800e+00 - ax) + 6.12323399573676603587e-17 : ax;
+  const double z = y * y;
+  double a = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  a = fma_k(z, a, 2.75573137070700676789e-06);
+  a = fma_k(z, a, -1.98412698298579493134e-04);
+  a = fma_k(z, a, 8.33333333332248946124e-03);
+  a = fma_k(z, a, -1.66666666666666324348e-01);
+  const double ps = y + y * z * a;
+  double b = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  b = fma_k(z, b, -2.75573143513906633035e-07);
+  b = fma_k(z, b, 2.48015872894767294178e-05);
+  b = fma_k(z, b, -1.38888888888741095749e-03);
+  b = fma_k(z, b, 4.16666666666666019037e-02);
+  const double pc = 1.0 - (0.5 * z - z * z * b);
+  return hi ? ps : pc;
+}
+
+__device__ __forceinline__ double cos_latitude(double x) {
+  return cos_latitude_k(x);
 }
 
 // FMOD, mptrac.h:1121-1122.  (int)(x / y) is 0 whenever |x| < y, so the
@@ -244,33 +289,27 @@ __device__ __forceinline__ double deg2rad(double deg) {   // mptrac.h:857
 // polynomial on [0, pi/4], sine polynomial of pi/2 - |x| above, both evaluated
 // and selected (no divergent branch, no argument-reduction code for the general
 // case).  Below one ulp, like the C library's cos() the reference calls.
-__device__ __forceinline__ double cos_latitude(double x) {
-  const double ax = fabs(x);
-  const bool hi = ax > 0.78539816339744830962;
-  // pi/2 = 1.57079632679489655800e+00 + 6.12323399573676603587e-17; the first difference is exact
-  const double y = hi ? (1.57079632679489655800e+00 - ax) + 6.12323399573676603587e-17 : ax;
-  const double z = y * y;
-  const double ps = y + y * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03
-    + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06
-    + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
-  const double pc = 1.0 - (0.5 * z - z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03
-    + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07
-    + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))))));
-  return hi ? ps : pc;
-}
-
+// (The products of the conversion functions are rounded before the caller adds them to a coordinate, as in
+// the reference's `lon += DX2COORD(...)`: contraction is switched off inside them, so that no call site
+// fuses the last multiply into its addition while another -- behind a select -- cannot.)
 __device__ __forceinline__ double dx2deg(double dx, double lat) {   // mptrac.h:904-906
+#pragma clang fp contract(off)
   if (lat < -89.999 || lat > 89.999)
     return 0;
 #if MPHIP_EXACT_DIV
   return dx * 180. / (kPi * kRE * cos(deg2rad(lat)));
 #else
-  return fdiv(dx * 180., kPi * kRE * cos_latitude(deg2rad(lat)));
+  return (dx * 180.) * frcp(kPi * kRE * cos_latitude(deg2rad(lat)));   // (as DegPerMetre of the lean kernels: same bits)
 #endif
 }
 
 __device__ __forceinline__ double dy2deg(double dy) {   // mptrac.h:922
-  return div_const(dy * 180., kPi * kRE, 1.0 / (kPi * kRE));
+#pragma clang fp contract(off)
+#if MPHIP_EXACT_DIV
+  return dy * 180. / (kPi * kRE);
+#else
+  return (dy * 180.) * (1.0 / (kPi * kRE));
+#endif
 }
 
 __device__ __forceinline__ double dx2coord(int coord_type, double dx, double lat) {   // mptrac.h:966
@@ -1035,56 +1074,40 @@ __device__ __forceinline__ double uniform01(uint64_t ctr) {
 // short polynomials, all in double precision, result rounded to float).
 // Restated from the published algorithm; valid for |x| < 120 (the Box-Muller
 // angle is in [0, 2 pi]).  Bit-identical to glibc 2.35 for every float in
-// [0, 2 pi] (tests/test_sincosf.py).
-struct SinCosTab {
-  double c0, c1, c2, c3, c4, s1, s2, s3;
-};
-
-// both polynomials of the reduced argument: sp = sine polynomial of x, cp = cosine polynomial with the
-// sign csign folded into its coefficients (as the library's two tables)
-__device__ __forceinline__ void sincosf_polys(double x, double x2, double csign, float &sp, float &cp) {
-  {
-    const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
-    const double x3 = x * x2;
-    const double s1 = s2c + x2 * s3c;
-    const double x7 = x3 * x2;
-    const double s = x + x3 * s1c;
-    sp = (float) (s + x7 * s1);
-  }
-  {
-    const double c0 = csign * 0x1p0, c1c = csign * -0x1.ffffffd0c621cp-2, c2c = csign * 0x1.55553e1068f19p-5;
-    const double c3c = csign * -0x1.6c087e89a359dp-10, c4c = csign * 0x1.99343027bf8c3p-16;
-    const double x4 = x2 * x2;
-    const double c2 = c3c + x2 * c4c;
-    const double c1 = c0 + x2 * c1c;
-    const double x6 = x4 * x2;
-    const double c = c1 + x4 * c2c;
-    cp = (float) (c + x6 * c2);
-  }
-}
-
-__device__ __forceinline__ uint32_t abstop12(float x) {
-  return (__float_as_uint(x) >> 20) & 0x7ff;
-}
-
-// sinf(y) and cosf(y) for 0 <= y < 120.  glibc branches to shorter paths for |y| < pi/4 and |y| < 2^-12;
-// the general path below returns the same bits there (n = 0, x - 0 * hpi = x, and the polynomial rounds
-// to y resp. 1.0f), so it is used for every lane -- one eighth of the Box-Muller angles would otherwise
-// diverge.  The library evaluates one polynomial per function, chosen by the parity of the quadrant n:
-// sine -> (n even ? sine : cosine polynomial), cosine the other way round, same reduced argument and signs
-// for both; here each polynomial is evaluated once and the two results are assigned by that parity
-// (a branch on n would run both sides in every wavefront, twice).
+// [0, 2 pi] (sampled on the device by the GPU suite, exhaustively on the CPU at design time).
+//
+// glibc branches to shorter paths for |y| < pi/4 and |y| < 2^-12; the general path below returns the same
+// bits there (n = 0, x - 0 * hpi = x, and the polynomial rounds to y resp. 1.0f), so it is used for every
+// lane -- one eighth of the Box-Muller angles would otherwise diverge.  The library evaluates one
+// polynomial per function, chosen by the parity of the quadrant n: sine -> (n even ? sine : cosine
+// polynomial), cosine the other way round, same reduced argument and signs for both; here each polynomial
+// is evaluated once and the two results are assigned by that parity (a branch on n would run both sides
+// in every wavefront, twice).  The sign of the cosine polynomial (the library's second coefficient table)
+// is applied to its rounded result instead of to its five coefficients -- rounding commutes with
+// negation: same bits, five multiplies fewer.
 __device__ __forceinline__ void libm_sincosf_both(float y, float &sinv, float &cosv) {
   double x = (double) y;
   const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
-  const double r = x * hpi_inv;
-  const int n = ((int32_t) r + 0x800000) >> 24;
+  const int n = ((int32_t) (x * hpi_inv) + 0x800000) >> 24;
   x = x - n * hpi;
-  const int q = n & 3;
-  const double sgn = (q == 1 || q == 2) ? -1.0 : 1.0;
-  const double csign = (n & 2) ? -1.0 : 1.0;
+  const double xs = __hiloint2double(__double2hiint(x) ^ (((n + 1) & 2) << 30), __double2loint(x));   // quadrants 1, 2: -x
+  const double x2 = x * x;
   float sp, cp;
-  sincosf_polys(x * sgn, x * x, csign, sp, cp);
+  {
+    const double x3 = xs * x2;
+    const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+    const double x7 = x3 * x2;
+    const double sn = __builtin_fma(x3, -0x1.555545995a603p-3, xs);
+    sp = (float) __builtin_fma(x7, s1, sn);
+  }
+  {
+    const double x4 = x2 * x2;
+    const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+    const double c1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 0x1p0);
+    const double x6 = x4 * x2;
+    const double c = __builtin_fma(x4, 0x1.55553e1068f19p-5, c1);
+    cp = __uint_as_float(__float_as_uint((float) __builtin_fma(x6, c2, c)) ^ ((uint32_t) (n & 2) << 30));
+  }
   const bool even = (n & 1) == 0;
   sinv = even ? sp : cp;
   cosv = even ? cp : sp;
@@ -1097,24 +1120,57 @@ __device__ __forceinline__ float libm_sincosf(float y, int which) {
   return which ? cv : sv;
 }
 
+// log(X 2^-64) for X = (double) of a non-zero 64-bit integer, i.e. log(u) of the uniform behind a Box-Muller
+// radius: table-driven (tools/gen_log_table.py; `tab` = kLogTabN x {1/c, -log(1/c) hi, lo}, in LDS in the
+// lean kernels, in global memory otherwise), no division, ~27 instructions.  Within 1.4 ulp of the exact
+// logarithm (CPU check of the same arithmetic over 2 x 10^7 arguments; the C library is within 0.52).
+__device__ __forceinline__ double log_tab(const double *__restrict__ tab, double X) {
+  const int hx = __double2hiint(X);
+  const int t = hx - 0x3fe60000;                       // x = 2^k z, z in [0.6875, 1.375)
+  const int i = (t >> 13) & (kLogTabN - 1);
+  const int k = t >> 20;
+  const double z = __hiloint2double(hx - (t & (int) 0xfff00000), __double2loint(X));
+  const double *e = tab + 3 * i;
+  const double invc = e[0], lh = e[1], ll = e[2];
+  const double r = __builtin_fma(z, invc, -1.0);     // |r| <= 2^-7, one rounding
+  const double kd = (double) (k - 64);
+  double p = r * (1.0 / 7) - 1.0 / 6;                  // (one SGPR constant per instruction on gfx950)
+  p = fma_k(r, p, 1.0 / 5);
+  p = fma_k(r, p, -1.0 / 4);
+  p = fma_k(r, p, 1.0 / 3);
+  p = fma_k(r, p, -1.0 / 2);
+  const double w = __builtin_fma(kd, kLn2Hi, lh);     // k ln2_hi is exact (trailing zeros)
+  const double hi = w + r;
+  const double lo = ((w - hi) + r) + __builtin_fma(kd, kLn2Lo, ll);
+  return __builtin_fma(r * r, p, lo) + hi;
+}
+
+// (double) r of a 64-bit integer in three instructions (both halves convert exactly, the fma rounds once)
+__device__ __forceinline__ double u64_to_double(uint64_t r) {
+  return __builtin_fma((double) (uint32_t) (r >> 32), 0x1p32, (double) (uint32_t) r);
+}
+
 // Element i of the array module_rng(..., method = 1) would have produced for
 // base counter c0 (mptrac.c:5821-5826): Box-Muller over the flat pairs
 // (2j, 2j+1) of the uniform stream.
 // y = (c0 + 2j) * key
-__device__ __forceinline__ void normal_pair_from(uint64_t y, double &even, double &odd) {
-  const double ua = uniform01_from(y);
-  const double ub = uniform01_from(y + kSquaresKey);
-  const double r = fsqrt(-2.0 * log_unit(ua));
-  const double phi = 2.0 * kPi * ub;
-  const float phif = (float) phi;
+__device__ __forceinline__ void normal_pair_from(const double *__restrict__ ltab, uint64_t y, double &even, double &odd) {
+  const uint64_t ra = squares_from(y), rb = squares_from(y + kSquaresKey);
+#if MPHIP_EXACT_DIV
+  const double r = sqrt(-2.0 * log((double) ra * 0x1p-64));
+#else
+  const double r = fsqrt(-2.0 * (ra == 0 ? -__builtin_inf() : log_tab(ltab, u64_to_double(ra))));
+#endif
+  const float phif = (float) (u64_to_double(rb) * (2.0 * kPi * 0x1p-64));   // 2 pi u, u = r 2^-64 (exact scaling)
   float sv, cv;
   libm_sincosf_both(phif, sv, cv);
   even = r * cv;
   odd = r * sv;
 }
 
-__device__ __forceinline__ void normal_pair(uint64_t c0, uint64_t j2, double &even, double &odd) {
-  normal_pair_from((c0 + j2) * kSquaresKey, even, odd);
+__device__ __forceinline__ void normal_pair(const double *__restrict__ ltab, uint64_t c0, uint64_t j2, double &even,
+                                            double &odd) {
+  normal_pair_from(ltab, (c0 + j2) * kSquaresKey, even, odd);
 }
 
 // the three normals rs[3g], rs[3g+1], rs[3g+2] of global particle g.  They
@@ -1122,14 +1178,14 @@ __device__ __forceinline__ void normal_pair(uint64_t c0, uint64_t j2, double &ev
 // outputs depends on the parity of 3g, i.e. alternates between neighbouring
 // lanes -- so both pairs are evaluated by every lane and the outputs selected,
 // instead of branching on the parity (a branch would run both sides per wave).
-__device__ __forceinline__ void normal_triple(uint64_t c0, uint64_t g, double &r0, double &r1, double &r2) {
+__device__ __forceinline__ void normal_triple(const double *__restrict__ ltab, uint64_t c0, uint64_t g, double &r0,
+                                              double &r1, double &r2) {
   const uint64_t i0 = 3 * g;
   const bool odd = (i0 & 1) != 0;
-  const uint64_t ja = i0 - (odd ? 1 : 0);
-  const uint64_t y = (c0 + ja) * kSquaresKey;
+  const uint64_t y = (c0 + (i0 & ~1ull)) * kSquaresKey;
   double ea, oa, eb, ob;
-  normal_pair_from(y, ea, oa);
-  normal_pair_from(y + 2 * kSquaresKey, eb, ob);
+  normal_pair_from(ltab, y, ea, oa);
+  normal_pair_from(ltab, y + 2 * kSquaresKey, eb, ob);
   r0 = odd ? oa : ea;
   r1 = odd ? eb : oa;
   r2 = odd ? ob : eb;
@@ -1707,7 +1763,7 @@ __device__ __forceinline__ double kz_blend(const mphip_ctl_t &ctl, double pt, do
 
 // module_diff_turb, mptrac.c:4603-4733
 __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevClim &C,
-                                          Particle &P, uint64_t ctr, uint64_t g, const double *pre = nullptr) {
+                                          Particle &P, uint64_t ctr, uint64_t g, const double *pre, const double *ltab) {
   const int ct = M.coord_type;
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
@@ -1733,7 +1789,7 @@ __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &
     rs1 = pre[1];
     rs2 = pre[2];
   } else
-    normal_triple(ctr, g, rs0, rs1, rs2);
+    normal_triple(ltab, ctr, g, rs0, rs1, rs2);
 
   if (Kx > 0) {
     const double sigma_h = fsqrt(2.0 * Kx * dt_abs);
@@ -1778,7 +1834,7 @@ __device__ __forceinline__ double tvirt(double t, double h2o) {   // TVIRT, mptr
 }
 
 __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particle &P, float &up, float &vp,
-                                         float &wp, uint64_t ctr, uint64_t g) {
+                                         float &wp, uint64_t ctr, uint64_t g, const double *ltab) {
   const int ct = M.coord_type;
   double dsigw_dz = 0.0, sig_u = 0.0, sig_v = 0.0, sig_w = 0.0, tau_u = 0.0, tau_v = 0.0, tau_w = 0.0;
   Stencil s = stencil_zero();
@@ -1889,7 +1945,7 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
     return;
 
   double rs0, rs1, rs2;
-  normal_triple(ctr, g, rs0, rs1, rs2);
+  normal_triple(ltab, ctr, g, rs0, rs1, rs2);
   const double dt = P.dt, dt_abs = fabs(P.dt);
   const double ru = exp(-dt_abs / tau_u);
   const double ru2 = sqrt(dmax(0.0, 1.0 - ru * ru));
@@ -1921,7 +1977,7 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
 // module_diff_meso, mptrac.c:4280-4338
 __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                           float &up, float &vp, float &wp, uint64_t ctr, uint64_t g,
-                                          const double *pre, WindCache &wc) {
+                                          const double *pre, WindCache &wc, const double *ltab) {
   // HIP's __fadd_rn / __fmul_rn are plain operators, so contraction has to be
   // switched off here for the single-precision statistics to round like the
   // reference's separate multiply and add (the variance is a small difference
@@ -1973,7 +2029,7 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
     rs1 = pre[1];
     rs2 = pre[2];
   } else
-    normal_triple(ctr, g, rs0, rs1, rs2);
+    normal_triple(ltab, ctr, g, rs0, rs1, rs2);
 
   if (ctl.turb_mesox > 0) {
     up = (float) (r * up + r2 * rs0 * ctl.turb_mesox * sd[0]);
@@ -2160,74 +2216,6 @@ __device__ __forceinline__ bool in_boundary_region(const mphip_ctl_t &ctl, const
 // selects), axis end values from the kernel arguments instead of LDS, no per-axis direction branches.
 // =============================================================================
 
-__device__ __forceinline__ double vmin(double a, double b) {   // v_min_f64 without the canonicalising copies
-  double r;
-  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-__device__ __forceinline__ double vmax(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// the same with a wave-uniform second operand (kernel argument): stays in its SGPR pair
-__device__ __forceinline__ double vmin_s(double a, double s) {
-  double r;
-  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));
-  return r;
-}
-
-__device__ __forceinline__ double vmax_s(double a, double s) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));
-  return r;
-}
-
-// min(max(x, 0), hi) with a wave-uniform hi >= 0
-__device__ __forceinline__ int clamp0_s(int x, int hi) {
-  int r;
-  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
-  return r;
-}
-
-// x * y + c with a literal constant c: the constant goes into an SGPR pair (two scalar moves beside the
-// vector pipe) -- left to itself the compiler often builds it in a VGPR pair with two v_mov per Horner step
-__device__ __forceinline__ double fma_k(double x, double y, double c) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "s"(c));
-  return r;
-}
-
-// 1 / b to an ulp or two (rcp + two Newton steps)
-__device__ __forceinline__ double frcp(double b) {
-  double r = __builtin_amdgcn_rcp(b);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-  return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-}
-
-// cos_latitude with the polynomial constants in SGPRs
-__device__ __forceinline__ double cos_latitude_k(double x) {
-  const double ax = fabs(x);
-  const bool hi = ax > 0.78539816339744830962;
-  const double y = hi ? (1.57079632679489655800e+00 - ax) + 6.12323399573676603587e-17 : ax;
-  const double z = y * y;
-  double a = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  a = fma_k(z, a, 2.75573137070700676789e-06);
-  a = fma_k(z, a, -1.98412698298579493134e-04);
-  a = fma_k(z, a, 8.33333333332248946124e-03);
-  a = fma_k(z, a, -1.66666666666666324348e-01);
-  const double ps = y + y * z * a;
-  double b = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  b = fma_k(z, b, -2.75573143513906633035e-07);
-  b = fma_k(z, b, 2.48015872894767294178e-05);
-  b = fma_k(z, b, -1.38888888888741095749e-03);
-  b = fma_k(z, b, 4.16666666666666019037e-02);
-  const double pc = 1.0 - (0.5 * z - z * z * b);
-  return hi ? ps : pc;
-}
-
 // Metre -> degree factors of one latitude: DX2DEG(dx, lat) = dx * kx, DY2DEG(dy) = dy * ky with dx, dy in
 // metres (mptrac.h:904-906, 922; the / 1000 of DX2COORD folded in).  One cosine and one reciprocal serve
 // every conversion at that latitude (the four of a Runge-Kutta step use the same one, mptrac.c:3628, 3672).
@@ -2243,96 +2231,13 @@ __device__ __forceinline__ DegPerMetre deg_per_metre(double lat) {
 }
 
 __device__ __forceinline__ double dx2deg_k(const DegPerMetre &d, double dx_metres) {
+#pragma clang fp contract(off)
   return ((dx_metres * 1e-3) * 180.) * d.kx;
 }
 
 __device__ __forceinline__ double dy2deg_k(double dy_metres) {
+#pragma clang fp contract(off)
   return ((dy_metres * 1e-3) * 180.) * (1.0 / (kPi * kRE));
-}
-
-// ---- random numbers -----------------------------------------------------------
-
-// log(X 2^-64) for X = (double) of a non-zero 64-bit integer: table-driven (tools/gen_log_table.py; table in
-// LDS), no division, ~27 instructions against ~58 of log_unit(); within 1.4 ulp of the exact logarithm (CPU
-// check of the same arithmetic over 2 x 10^7 arguments) where log_unit() / the C library are within 1 / 0.5
-__device__ __forceinline__ double log_tab(const double *__restrict__ tab, double X) {
-  const int hx = __double2hiint(X);
-  const int t = hx - 0x3fe60000;                       // x = 2^k z, z in [0.6875, 1.375)
-  const int i = (t >> 13) & (kLogTabN - 1);
-  const int k = t >> 20;
-  const double z = __hiloint2double(hx - (t & (int) 0xfff00000), __double2loint(X));
-  const double *e = tab + 3 * i;
-  const double invc = e[0], lh = e[1], ll = e[2];
-  const double r = __builtin_fma(z, invc, -1.0);     // |r| <= 2^-7, one rounding
-  const double kd = (double) (k - 64);
-  double p = r * (1.0 / 7) - 1.0 / 6;                  // (one SGPR constant per instruction on gfx950)
-  p = fma_k(r, p, 1.0 / 5);
-  p = fma_k(r, p, -1.0 / 4);
-  p = fma_k(r, p, 1.0 / 3);
-  p = fma_k(r, p, -1.0 / 2);
-  const double w = __builtin_fma(kd, kLn2Hi, lh);     // k ln2_hi is exact (trailing zeros)
-  const double hi = w + r;
-  const double lo = ((w - hi) + r) + __builtin_fma(kd, kLn2Lo, ll);
-  return __builtin_fma(r * r, p, lo) + hi;
-}
-
-// (double) r of a 64-bit integer in three instructions (both halves convert exactly, the fma rounds once)
-__device__ __forceinline__ double u64_to_double(uint64_t r) {
-  return __builtin_fma((double) (uint32_t) (r >> 32), 0x1p32, (double) (uint32_t) r);
-}
-
-// libm_sincosf_both with the sign of the cosine polynomial applied to its rounded result instead of to its
-// five coefficients (rounding commutes with negation: same bits)
-__device__ __forceinline__ void sincosf_lean(float y, float &sinv, float &cosv) {
-  double x = (double) y;
-  const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
-  const int n = ((int32_t) (x * hpi_inv) + 0x800000) >> 24;
-  x = x - n * hpi;
-  const double xs = __hiloint2double(__double2hiint(x) ^ (((n + 1) & 2) << 30), __double2loint(x));   // quadrants 1, 2: -x
-  const double x2 = x * x;
-  float sp, cp;
-  {
-    const double x3 = xs * x2;
-    const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
-    const double x7 = x3 * x2;
-    const double sn = __builtin_fma(x3, -0x1.555545995a603p-3, xs);
-    sp = (float) __builtin_fma(x7, s1, sn);
-  }
-  {
-    const double x4 = x2 * x2;
-    const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
-    const double c1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 0x1p0);
-    const double x6 = x4 * x2;
-    const double c = __builtin_fma(x4, 0x1.55553e1068f19p-5, c1);
-    cp = __uint_as_float(__float_as_uint((float) __builtin_fma(x6, c2, c)) ^ ((uint32_t) (n & 2) << 30));
-  }
-  const bool even = (n & 1) == 0;
-  sinv = even ? sp : cp;
-  cosv = even ? cp : sp;
-}
-
-// normal_pair_from / normal_triple on these (same values up to the last place of the logarithm)
-__device__ __forceinline__ void normal_pair_lean(const double *__restrict__ ltab, uint64_t y, double &even, double &odd) {
-  const uint64_t ra = squares_from(y), rb = squares_from(y + kSquaresKey);
-  const double r = fsqrt(-2.0 * (ra == 0 ? -__builtin_inf() : log_tab(ltab, u64_to_double(ra))));
-  const float phif = (float) (u64_to_double(rb) * (2.0 * kPi * 0x1p-64));   // 2 pi u, u = r 2^-64 (exact scaling)
-  float sv, cv;
-  sincosf_lean(phif, sv, cv);
-  even = r * cv;
-  odd = r * sv;
-}
-
-__device__ __forceinline__ void normal_triple_lean(const double *__restrict__ ltab, uint64_t c0, uint64_t g, double &r0,
-                                                   double &r1, double &r2) {
-  const uint64_t i0 = 3 * g;
-  const bool odd = (i0 & 1) != 0;
-  const uint64_t y = (c0 + (i0 & ~1ull)) * kSquaresKey;
-  double ea, oa, eb, ob;
-  normal_pair_lean(ltab, y, ea, oa);
-  normal_pair_lean(ltab, y + 2 * kSquaresKey, eb, ob);
-  r0 = odd ? oa : ea;
-  r1 = odd ? eb : oa;
-  r2 = odd ? ob : eb;
 }
 
 // ---- stencil set-up ---------------------------------------------------------
@@ -2671,7 +2576,7 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
     rs1 = pre[1];
     rs2 = pre[2];
   } else
-    normal_triple_lean(ltab, ctr, g, rs0, rs1, rs2);
+    normal_triple(ltab, ctr, g, rs0, rs1, rs2);
 
   if (Kx > 0) {
     const double sigma_h = fsqrt(2.0 * Kx * dt_abs);
@@ -2757,7 +2662,7 @@ __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const Dev
     rs1 = pre[1];
     rs2 = pre[2];
   } else
-    normal_triple_lean(ltab, ctr, g, rs0, rs1, rs2);
+    normal_triple(ltab, ctr, g, rs0, rs1, rs2);
 
   if (ctl.turb_mesox > 0) {
     up = (float) (r * up + r2 * rs0 * ctl.turb_mesox * sd[0]);

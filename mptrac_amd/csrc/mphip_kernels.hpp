@@ -41,6 +41,7 @@ constexpr bool kRuntimeMask = (CT == kMaskGeneric || CT == kMaskGenericPL || CT 
 constexpr unsigned kRareModules = MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT | MPHIP_MOD_ISOSURF | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
 constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a later launch reads it)
+constexpr unsigned kTailModules = MPHIP_MOD_LOSS_ZERO | MPHIP_MOD_DECAY | MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI | MPHIP_MOD_ISOSURF | MPHIP_MOD_POSITION2;
 
@@ -157,6 +158,87 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
   apply_loss(ctl, a, i, aux, ctl.qnt_mloss_dry, v_dep / dz);
 }
 
+// module_wet_depo / module_dry_depo of the lean kernels: the general value code on the lean stencil set-up
+// (one horizontal stencil at the final position serves both modules)
+__device__ __forceinline__ void wet_depo_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
+                                              long long i, const Particle &P, Stencil &s) {
+  SurfB c2;
+  load_sfb(M.sfc, M, s, c2);
+  const double wt = time_weight(M, P.time);
+  const double pct = sfb_time_2d(c2, s, wt, 0);
+  if (!isfinite(pct) || P.p <= pct)
+    return;
+  const double pcb = sfb_time_2d(c2, s, wt, 1);
+  const double cl = sfb_time_2d(c2, s, wt, 2);
+  const double Is = pow(1. / ctl.wet_depo_pre[0] * cl, 1. / ctl.wet_depo_pre[1]);
+  if (Is < 0.01)
+    return;
+  vert_fast(M, A, P.p, s);
+  CloudCorners c;
+  load_cloud(M, s, c);
+  const double lwc = cloud_time_3d(c, s, wt, 0);
+  const double rwc = cloud_time_3d(c, s, wt, 1);
+  const double iwc = cloud_time_3d(c, s, wt, 2);
+  const double swc = cloud_time_3d(c, s, wt, 3);
+  const bool inside = (lwc > 0 || rwc > 0 || iwc > 0 || swc > 0);
+  const double t = temp_fast(M, s, wt);
+
+  double lambda = 0;
+  if (inside) {
+    double eta;
+    if (t > kWdTLiquid)
+      eta = 1;
+    else if (t <= kWdTIce)
+      eta = ctl.wet_depo_ic_ret_ratio;
+    else
+      eta = lin(kWdTLiquid, 1, kWdTIce, ctl.wet_depo_ic_ret_ratio, t);
+    if (ctl.wet_depo_ic_a > 0)
+      lambda = ctl.wet_depo_ic_a * pow(Is, ctl.wet_depo_ic_b) * eta;
+    else if (ctl.wet_depo_ic_h[0] > 0) {
+      double h = ctl.wet_depo_ic_h[0] * exp(ctl.wet_depo_ic_h[1] * (1. / t - 1. / kTRef));
+      if (ctl.wet_depo_so2_ph > 0) {
+        const double H_ion = pow(10., -ctl.wet_depo_so2_ph);
+        const double K_1 = kSO2K1Ref * exp(kSO2K1Temp * (1. / t - 1. / kTRef));
+        const double K_2 = kSO2K2Ref * exp(kSO2K2Temp * (1. / t - 1. / kTRef));
+        h *= (1. + K_1 / H_ion + K_1 * K_2 / (H_ion * H_ion));
+      }
+      const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
+      lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
+    }
+  } else {
+    const double eta = (t > kWdTLiquidBC) ? 1 : ctl.wet_depo_bc_ret_ratio;
+    if (ctl.wet_depo_bc_a > 0)
+      lambda = ctl.wet_depo_bc_a * pow(Is, ctl.wet_depo_bc_b) * eta;
+    else if (ctl.wet_depo_bc_h[0] > 0) {
+      const double h = ctl.wet_depo_bc_h[0] * exp(ctl.wet_depo_bc_h[1] * (1. / t - 1. / kTRef));
+      const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
+      lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
+    }
+  }
+  const double aux = exp(-P.dt * lambda);
+  apply_loss(ctl, a, i, aux, ctl.qnt_mloss_wet, lambda);
+}
+
+__device__ __forceinline__ void dry_depo_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
+                                              long long i, const Particle &P, Stencil &s) {
+  SurfA c2;
+  load_pair_2d32(M.sfa, M, s, c2);
+  const double wt = time_weight(M, P.time);
+  const double ps = pair_time_2d_fast(c2, s, wt, 0);
+  if (P.p < ps - ctl.dry_depo_dp)
+    return;
+  const double dz = 1000. * (zfromp(ps - ctl.dry_depo_dp) - zfromp(ps));
+  double v_dep;
+  if (ctl.qnt_rp > 0 && ctl.qnt_rhop > 0) {   // "> 0" as the reference, mptrac.c:4769
+    vert_fast(M, A, P.p, s);
+    const double t = temp_fast(M, s, wt);
+    v_dep = sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
+  } else
+    v_dep = ctl.dry_depo_vdep;
+  const double aux = exp(-P.dt * v_dep / dz);
+  apply_loss(ctl, a, i, aux, ctl.qnt_mloss_dry, v_dep / dz);
+}
+
 // One thread per particle, grid-stride.  Workgroup b of the launch is mapped
 // to logical block (b % 8) * (n / 8) + b / 8 so that each XCD (the dispatcher
 // places workgroup b on XCD b % 8) walks one contiguous eighth of the particle
@@ -205,12 +287,12 @@ struct RngEarly {
     const uint64_t i0 = 3 * g;
     const uint64_t y = (c0 + (i0 & ~1ull)) * kSquaresKey;
     if (which == 0) {
-      normal_pair_lean(ltab, y, e, o);
+      normal_pair_from(ltab, y, e, o);
       pin(e);
       pin(o);
     } else {
       double eb, ob;
-      normal_pair_lean(ltab, y + 2 * kSquaresKey, eb, ob);
+      normal_pair_from(ltab, y + 2 * kSquaresKey, eb, ob);
       const bool odd = (i0 & 1) != 0;
       out[0] = odd ? o : e;
       out[1] = odd ? eb : o;
@@ -232,13 +314,13 @@ struct RngEarly {
     }
 #else
     if (stage == 0 && (mask & MPHIP_MOD_DIFF_TURB)) {
-      normal_triple_lean(ltab, ctr_turb, g, turb[0], turb[1], turb[2]);
+      normal_triple(ltab, ctr_turb, g, turb[0], turb[1], turb[2]);
       pin(turb[0]);
       pin(turb[1]);
       pin(turb[2]);
     }
     if (stage == 1 && (mask & MPHIP_MOD_DIFF_MESO)) {
-      normal_triple_lean(ltab, ctr_meso, g, meso[0], meso[1], meso[2]);
+      normal_triple(ltab, ctr_meso, g, meso[0], meso[1], meso[2]);
       pin(meso[0]);
       pin(meso[1]);
       pin(meso[2]);
@@ -263,7 +345,7 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
   // climatological tropopause table next to the axes (7.7 kB): the weights of
   // module_diff_turb / module_decay index it per lane, several times a step
   const DevClim *clim = S.clim;
-  if (mask & (MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DECAY)) {
+  if ((mask | (kRuntimeMask<CT> ? 0u : (S.mask & kTailModules))) & (MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DECAY)) {
     double *dst = s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8;
     const double *src = (const double *) S.clim;
     for (int i = threadIdx.x; i < (int) (sizeof(DevClim) / sizeof(double)); i += blockDim.x)
@@ -271,7 +353,7 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
     clim = (const DevClim *) dst;
   }
   // ... and the table of the lean logarithm behind it (3 kB)
-  const double *ltab = nullptr;
+  const double *ltab = M.logtab;   // (the general instantiations read it from global memory)
   if (!kRuntimeMask<CT> && (mask & (MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO))) {
     double *dst = s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8
       + sizeof(DevClim) / sizeof(double);
@@ -401,11 +483,11 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
       if (lean)
         diff_turb_fast(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr, ltab);
       else
-        diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr);
+        diff_turb(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr, ltab);
     }
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_DIFF_PBL)) {
       float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
-      diff_pbl(M, A, P, up, vp, wp, S.ctr_pbl, g);
+      diff_pbl(M, A, P, up, vp, wp, S.ctr_pbl, g, ltab);
       a.up[i] = up;
       a.vp[i] = vp;
       a.wp[i] = wp;
@@ -417,7 +499,7 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
       if (lean)
         diff_meso_fast(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc, ltab);
       else
-        diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc);
+        diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc, ltab);
       a.up[i] = up;
       a.vp[i] = vp;
       a.wp[i] = wp;
@@ -453,18 +535,32 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
 
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_BOUND_COND))
       bound_cond(ctl, M, A, a, i, P);
-    if (mask & MPHIP_MOD_LOSS_ZERO)
+    // the loss / decay / deposition modules behind the movers: in the lean instantiations a run-time choice
+    // too (their template mask names the movers), so that they serve every combination of these modules
+    const unsigned tmask = lean ? (S.mask & kTailModules) : mask;
+    if (tmask & MPHIP_MOD_LOSS_ZERO)
       a.q[ctl.qnt_loss_rate][i] = 0;
-    if (mask & MPHIP_MOD_DECAY) {   // module_decay, mptrac.c:4241-4261
+    if (tmask & MPHIP_MOD_DECAY) {   // module_decay, mptrac.c:4241-4261
       const double w = tropo_weight(ctl, *clim, P.time, P.lat, P.p);
       const double tdec = w * ctl.tdec_trop + (1 - w) * ctl.tdec_strat;
       const double aux = exp(-P.dt / tdec);
       apply_loss(ctl, a, i, aux, ctl.qnt_mloss_decay, 1. / tdec);
     }
-    if (mask & MPHIP_MOD_WET_DEPO)
-      wet_depo(ctl, M, A, a, i, P);
-    if (mask & MPHIP_MOD_DRY_DEPO)
-      dry_depo(ctl, M, A, a, i, P);
+    if (lean) {
+      if (tmask & (MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO)) {
+        Stencil sd = stencil_zero();
+        horiz_fast(M, A, P.lon, P.lat, sd);
+        if (tmask & MPHIP_MOD_WET_DEPO)
+          wet_depo_fast(ctl, M, A, a, i, P, sd);
+        if (tmask & MPHIP_MOD_DRY_DEPO)
+          dry_depo_fast(ctl, M, A, a, i, P, sd);
+      }
+    } else {
+      if (mask & MPHIP_MOD_WET_DEPO)
+        wet_depo(ctl, M, A, a, i, P);
+      if (mask & MPHIP_MOD_DRY_DEPO)
+        dry_depo(ctl, M, A, a, i, P);
+    }
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_BOUND_COND2))
       bound_cond(ctl, M, A, a, i, P);
   }
@@ -663,13 +759,18 @@ __global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, uint32_t *__restri
 constexpr int kSortThreads = 256;
 constexpr int kSortRounds = 16;                            // keys per thread
 constexpr int kSortTile = kSortThreads * kSortRounds;      // keys per workgroup
-constexpr int kRadix = 256;
+// Digit width BITS (8, 9 or 10) is chosen per sort so that the key needs the fewest passes: the 26-bit cell
+// key of a 721 x 361 x 137 grid sorts in three 9-bit passes instead of four 8-bit ones.
+constexpr int kRadixMaxBits = 10;
 
 // per-tile digit histogram -> counts[digit * ntiles + tile]
+template <int BITS>
 __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t *__restrict__ keys, long long n,
                                                                  int shift, int ntiles, uint32_t *__restrict__ counts) {
+  constexpr int kRadix = 1 << BITS;
   __shared__ uint32_t h[kRadix];
-  h[threadIdx.x] = 0;
+  for (int d = threadIdx.x; d < kRadix; d += kSortThreads)
+    h[d] = 0;
   __syncthreads();
   const long long base = (long long) blockIdx.x * kSortTile;
 #pragma unroll 4
@@ -679,7 +780,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t 
       atomicAdd(&h[(keys[i] >> shift) & (kRadix - 1)], 1u);
   }
   __syncthreads();
-  counts[(size_t) threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+  for (int d = threadIdx.x; d < kRadix; d += kSortThreads)
+    counts[(size_t) d * ntiles + blockIdx.x] = h[d];
 }
 
 // Exclusive prefix sum over the m counters in two levels: every workgroup
@@ -753,12 +855,15 @@ __global__ __launch_bounds__(kScanThreads) void sort_scan_chunks_kernel(uint32_t
 //   stable; the lanes of a round that hold the same digit are found with eight
 //   ballots, and a per-wave counter row in LDS carries the running count from
 //   round to round (no workgroup barrier inside the loop).
+template <int BITS>
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32_t *__restrict__ keys_in,
                                                                     const int *__restrict__ vals_in,
                                                                     uint32_t *__restrict__ keys_out,
                                                                     int *__restrict__ vals_out, long long n, int shift,
                                                                     int ntiles, const uint32_t *__restrict__ offsets,
                                                                     const uint32_t *__restrict__ chunk_offsets) {
+  constexpr int kRadix = 1 << BITS;
+  constexpr int kDigitsPerThread = kRadix / kSortThreads;   // 1, 2 or 4 consecutive digits per thread
   constexpr int kWaves = kSortThreads / 64;
   constexpr int kPerWave = kSortTile / kWaves;
   __shared__ uint32_t s_key[kSortTile];
@@ -770,7 +875,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int w = 0; w < kWaves; w++)
-    s_cnt[w][threadIdx.x] = 0;
+    for (int d = threadIdx.x; d < kRadix; d += kSortThreads)
+      s_cnt[w][d] = 0;
   __syncthreads();
 
   const long long base = (long long) blockIdx.x * kSortTile + (long long) wave * kPerWave + lane;
@@ -791,7 +897,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
     const uint32_t d = (key[r] >> shift) & (kRadix - 1);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < BITS; b++) {
       const unsigned long long bal = __ballot((d >> b) & 1);
       peers &= ((d >> b) & 1) ? bal : ~bal;
     }
@@ -803,21 +909,32 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
   }
   __syncthreads();
 
-  // thread = digit: prefix over the waves, then over the digits
+  // a thread takes kDigitsPerThread consecutive digits: prefix over the waves, then over the digits
   {
-    const int d = threadIdx.x;
-    uint32_t tot = 0;
+    uint32_t tot[kDigitsPerThread], sum = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; w++) {
-      const uint32_t c = s_cnt[w][d];
-      s_cnt[w][d] = tot;
-      tot += c;
+    for (int k = 0; k < kDigitsPerThread; k++) {
+      const int d = threadIdx.x * kDigitsPerThread + k;
+      uint32_t t = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) {
+        const uint32_t c = s_cnt[w][d];
+        s_cnt[w][d] = t;
+        t += c;
+      }
+      tot[k] = t;
+      sum += t;
     }
     uint32_t all;
-    const uint32_t dbase = block_exclusive_scan(tot, s_wsum, &all);
-    const size_t slot = (size_t) d * ntiles + blockIdx.x;
-    s_dbase[d] = dbase;
-    s_gdelta[d] = offsets[slot] + chunk_offsets[slot / kScanChunk] - dbase;
+    uint32_t dbase = block_exclusive_scan(sum, s_wsum, &all);
+#pragma unroll
+    for (int k = 0; k < kDigitsPerThread; k++) {
+      const int d = threadIdx.x * kDigitsPerThread + k;
+      const size_t slot = (size_t) d * ntiles + blockIdx.x;
+      s_dbase[d] = dbase;
+      s_gdelta[d] = offsets[slot] + chunk_offsets[slot / kScanChunk] - dbase;
+      dbase += tot[k];
+    }
   }
   __syncthreads();
 
@@ -1240,16 +1357,11 @@ __global__ __launch_bounds__(256, MPHIP_METEO_WAVES_PER_SIMD) void meteo_kernel(
 // self-test kernels
 // ---------------------------------------------------------------------------
 
-__global__ void test_sincosf_kernel(uint32_t first, uint32_t count, float *__restrict__ c, float *__restrict__ s,
-                                    int lean) {
+__global__ void test_sincosf_kernel(uint32_t first, uint32_t count, float *__restrict__ c, float *__restrict__ s) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const float x = __uint_as_float(first + i);
-    if (lean)
-      sincosf_lean(x, s[i], c[i]);
-    else {
-      c[i] = libm_sincosf(x, 1);
-      s[i] = libm_sincosf(x, 0);
-    }
+    c[i] = libm_sincosf(x, 1);
+    s[i] = libm_sincosf(x, 0);
   }
 }
 
@@ -1308,7 +1420,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
         acc += wind_time_3d(c, s, wt, 0) + wind_time_3d(c, s, wt, 1) + wind_time_3d(c, s, wt, 2);
       } else if (PIECE == 4) {
         double r0, r1, r2;
-        normal_triple(S.ctr_turb + (uint64_t) r, g, r0, r1, r2);
+        normal_triple(M.logtab, S.ctr_turb + (uint64_t) r, g, r0, r1, r2);   // (table in global memory)
         acc += r0 + r1 + r2;
       } else if (PIECE == 5) {
         Particle Q = P;
@@ -1339,7 +1451,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
         Q.lon = lon;
         Q.lat = lat;
         Q.p = p;
-        diff_turb(ctl, M, A, clim, Q, S.ctr_turb + (uint64_t) r, g);
+        diff_turb(ctl, M, A, clim, Q, S.ctr_turb + (uint64_t) r, g, nullptr, ltab);
         acc += Q.lon + Q.lat + Q.p;
       } else if (PIECE == 13) {   // module_convection + module_sedi
         Particle Q = P;
@@ -1357,7 +1469,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
         float up = 0.1f * r, vp = 0.2f, wp = 1e-4f;
         WindCache wc;
         wind_cache_reset(wc, false);
-        diff_meso(ctl, M, A, Q, up, vp, wp, S.ctr_meso + (uint64_t) r, g, nullptr, wc);
+        diff_meso(ctl, M, A, Q, up, vp, wp, S.ctr_meso + (uint64_t) r, g, nullptr, wc, ltab);
         acc += Q.lon + Q.lat + Q.p + (double) (up + vp + wp);
       } else if (PIECE == 15) {   // module_advect (RK4) without the wind-corner cache
         Particle Q = P;
@@ -1427,29 +1539,15 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
         advect_rk4_fast(M, A, Q, none, wc);
         acc += Q.lon + Q.lat + Q.p;
       } else if (PIECE == 24) {
-        double rr = 0.0;
-        normal_pair_from((S.ctr_turb + g + (uint64_t) r) * kSquaresKey, acc, rr);
-        acc += rr;
+        double rr = 0.0, ee = 0.0;
+        normal_pair_from(ltab, (S.ctr_turb + g + (uint64_t) r) * kSquaresKey, ee, rr);
+        acc += rr + ee;
       } else if (PIECE == 25) {
-        acc += log_unit(uniform01(S.ctr_turb + g + (uint64_t) r));
+        acc += log_tab(ltab, u64_to_double(squares(S.ctr_turb + g + (uint64_t) r) | 1));
       } else if (PIECE == 26) {
         float sv, cv;
         libm_sincosf_both((float) (6.28 * uniform01(S.ctr_turb + g + (uint64_t) r)), sv, cv);
         acc += (double) sv + (double) cv;
-      } else if (PIECE == 27) {
-        double rr = 0.0, ee = 0.0;
-        normal_pair_lean(ltab, (S.ctr_turb + g + (uint64_t) r) * kSquaresKey, ee, rr);
-        acc += rr + ee;
-      } else if (PIECE == 28) {
-        acc += log_tab(ltab, u64_to_double(squares(S.ctr_turb + g + (uint64_t) r) | 1));
-      } else if (PIECE == 29) {
-        float sv, cv;
-        sincosf_lean((float) (6.28 * uniform01(S.ctr_turb + g + (uint64_t) r)), sv, cv);
-        acc += (double) sv + (double) cv;
-      } else if (PIECE == 30) {
-        double r0, r1, r2;
-        normal_triple_lean(ltab, S.ctr_turb + (uint64_t) r, g, r0, r1, r2);
-        acc += r0 + r1 + r2;
       } else {
         acc += lon + lat + p;
       }
@@ -1464,13 +1562,9 @@ __global__ void test_rng_kernel(uint64_t ctr, long long n, int method, double *_
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
     if (method == 0)
       out[i] = uniform01(ctr + (uint64_t) i);
-    else if (method == 3) {   // the lean kernels' normals (table logarithm; ltab in global memory here)
+    else {
       double e, o;
-      normal_pair_lean(ltab, (ctr + ((uint64_t) i & ~1ull)) * kSquaresKey, e, o);
-      out[i] = (i & 1) ? o : e;
-    } else {
-      double e, o;
-      normal_pair(ctr, (uint64_t) i & ~1ull, e, o);
+      normal_pair(ltab, ctr, (uint64_t) i & ~1ull, e, o);
       out[i] = (i & 1) ? o : e;
     }
   }

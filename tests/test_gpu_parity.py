@@ -51,13 +51,10 @@ def _compare(o, s, tol=TOL):
 # building blocks
 # ---------------------------------------------------------------------------
 
-@pytest.mark.parametrize("lean", [0, 1])
-def test_sincosf_is_bit_identical_to_libm(lean):
+def test_sincosf_is_bit_identical_to_libm():
     """The Box-Muller angle goes through single-precision cosf/sinf
-    (mptrac.c:5824-5825); the device restatement must give glibc's bits --
-    both the general one and the one of the lean kernels (sincosf_lean)."""
+    (mptrac.c:5824-5825); the device restatement must give glibc's bits."""
     _, s = _pair("advect", n=16)
-    s.set_option("test_lean", lean)
     L = B.lib()
     fp = C.POINTER(C.c_float)
     two_pi_bits = 0x40c90fdb
@@ -99,10 +96,8 @@ def test_rng_stream_matches_module_rng(ctr, n):
         if method == 0:
             assert np.array_equal(dev, ref)              # uniforms: bit-exact
         else:
-            assert cases.rel_err(dev, ref) <= 1e-14      # log(): device vs glibc ulp
-            lean = s.test_rng(ctr, n, 3)                 # the lean kernels' normals (table-driven logarithm)
-            assert cases.rel_err(lean, ref) <= 1e-14
-            assert float(np.max(np.abs(lean - ref) / np.maximum(np.abs(ref), 1e-300))) <= 1e-13
+            assert cases.rel_err(dev, ref) <= 1e-14      # log(): the device's table-driven one vs glibc, ulps
+            assert float(np.max(np.abs(dev - ref) / np.maximum(np.abs(ref), 1e-300))) <= 1e-13
     s.close()
 
 
@@ -170,6 +165,30 @@ def test_fused_step_equals_module_sequence():
     assert a.get_cache()["rng_ctr"] == b.get_cache()["rng_ctr"]
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("over", [dict(diffusion=0, conv_cape=-999.0, conv_mix_pbl=0, qnt_rp=-1, qnt_rhop=-1),
+                                  dict(turb_mesox=0.0, turb_mesoz=0.0, conv_cape=-999.0, conv_mix_pbl=0, qnt_rp=-1, qnt_rhop=-1),
+                                  dict(),
+                                  dict(tdec_trop=259200.0, tdec_strat=259200.0, dry_depo_vdep=0.15, wet_depo_ic_a=1e-4,
+                                       wet_depo_ic_b=0.8, wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6)],
+                         ids=["advect", "advect_turb", "c3_set", "c3_set_decay_deposition"])
+def test_lean_instantiations_equal_the_general_code(over):
+    """The specialised (lean) instantiations of the step kernel -- straight-line stencil set-up, packed corner
+    differences, one reciprocal per latitude -- and the general instantiation compute the same bits."""
+    ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=6001)
+    ctl.update(over)
+    runs = []
+    for generic in (0, 1):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("generic_kernel", generic)
+        s.timesteps_init(0.0, 0.0)
+        for t in cases.step_times(s.ctl)[:6]:
+            s.run_timestep(t)
+        runs.append(s.state())
+        s.close()
+    for k in ("time", "lon", "lat", "p", "q", "uvwp"):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
 
 
 def test_met_swap_over_two_intervals():
@@ -269,6 +288,23 @@ def test_sort_keys_and_order_bit_exact(lon0, n):
     if lon0 == 0.0 and n > 1:
         ix = (keys_s // (m0.ny * m0.np)).astype(int)
         assert (ix == 0).sum() >= (r["lon"] < 0).sum()
+    s.close()
+
+
+@pytest.mark.parametrize("bits", [8, 9, 10])
+def test_sort_digit_widths(bits):
+    """The radix sort picks the digit width with the fewest passes for the key range of the grid (8, 9 or
+    10 bits); every width must give the oracle's permutation (ties by original index)."""
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=30011)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.set_option("sort_bits", bits)
+    keys_o, perm_o = o.sort()
+    keys_s, perm_s = s.sort()
+    assert np.array_equal(np.sort(keys_o), keys_s) and np.array_equal(perm_o, perm_s)
+    g, r = s.state(), o.state()
+    for k in ("time", "lon", "lat", "p", "q"):
+        assert np.array_equal(g[k], r[k]), k
     s.close()
 
 

@@ -19,7 +19,7 @@ PIECES = {0: "empty (load state, store)", 1: "stencil_3d", 2: "stencil_2d", 3: "
           16: "lean: stencil_3d", 17: "lean: horizontal stencil", 18: "lean: RK stage (stencil + loads + u,v,w)",
           19: "lean: module_position", 20: "lean: module_diff_turb", 21: "lean: convection + sedi",
           22: "lean: module_diff_meso", 23: "lean: module_advect RK4 (corner cache)", 24: "normal_pair (uniforms included)",
-          25: "log_unit(uniform01)", 26: "sincosf(2 pi uniform01)"}
+          25: "log_tab(squares)", 26: "sincosf(2 pi uniform01)"}
 
 
 def main():
