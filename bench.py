@@ -13,8 +13,9 @@ periodic column), fp64, inputs resident in HBM before the timed region.
 
 N > 1: one process per GPU, particles sharded by global index range (weak
 scaling: 10^7 per GPU), meteo grids replicated, no communication inside the
-step; one gridded-output reduction (RCCL all-reduce through the C ABI's hook)
-closes the timed region, as BASELINE configs[3] prescribes.
+step; one gridded-output reduction (RCCL all-reduce issued by the C library on
+the simulation's stream, include/mptrac_hip.h: mphip_comm_init) closes the timed
+region, as BASELINE configs[3] prescribes.
 
 The JSON line also carries the HBM roofline of the fused step kernel
 (algorithmic bytes / measured kernel time, HIP events on the launch stream)
@@ -135,6 +136,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2 * 10 ** 6)     # x 20 steps: about 10 s on 16 host cores
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--use-torch", action="store_true", help="go through torch.distributed even at N = 1")
+    ap.add_argument("--torch-allreduce", action="store_true",
+                    help="N > 1: reduce through the torch.distributed callback instead of the library's RCCL communicator")
+    ap.add_argument("--rccl-single", action="store_true",
+                    help="N = 1: give the context a one-rank RCCL communicator (exercises the native reduction path)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="(diagnostic) do not bracket the step kernel with HIP events; roofline is then not reported")
     args = ap.parse_args()
@@ -166,9 +171,13 @@ def main():
     ctl, clim, met0, met1, atm, n_local, n_total = build_inputs(args.workload, rank, world, steps_total, particles=args.particles)
     sim = hip.Simulation(ctl, clim, met0, met1, atm, device=local_rank,
                          shard=(rank * n_local, (rank + 1) * n_local), n_total=n_total)
-    if use_dist:
+    if use_dist and args.torch_allreduce:
         from mptrac_amd import dist as mdist
         sim.set_allreduce(mdist.make_allreduce_hook("cuda"))
+    elif use_dist or args.rccl_single:
+        # the library's own RCCL communicator: all-reduces on the simulation's stream, no Python in the data path
+        from mptrac_amd import dist as mdist
+        mdist.init_rccl(sim, dist)
     if args.eager_meteo:
         sim.set_option("lazy_meteo", 0)
     sim.timesteps_init(0.0, 0.0)

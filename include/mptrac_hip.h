@@ -245,6 +245,22 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
 
 int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
 
+/* Multi-GPU without a host language in the data path: one process per GPU, every process owns one context
+ * with an index range of the particles (mphip_update_atm: ip0, np_total) and the same meteo data.  The only
+ * exchanges are the cell sums of module_mixing (mptrac.c:5289-5316: one grouped all-reduce per mixing step --
+ * the sums of all mixed quantities as doubles, the cell counts once as 32-bit integers) and write_grid's sums
+ * (mptrac.c:13862-13872).  With a communicator they are RCCL all-reduces issued on the context's own stream;
+ * the host thread never waits for them.  librccl is loaded with dlopen at the first call, single-GPU callers
+ * do not need it.  Replaces the rank -> device binding of the reference's driver (src/trac.c:70-81).
+ *   mphip_comm_unique_id: rank 0 creates the 128-byte identifier (ncclGetUniqueId) and hands it to the other
+ *     ranks by whatever the host has (MPI_Bcast, a TCP socket as host/trac.c does, torch.distributed);
+ *   mphip_comm_init: collective over all ranks (ncclCommInitRank), after hipSetDevice of mphip_create;
+ *   mphip_comm_destroy: back to a single rank (mphip_destroy does it too).
+ * A communicator takes precedence over an all-reduce hook. */
+int mphip_comm_unique_id(void *id128);
+int mphip_comm_init(mphip_ctx *ctx, int nranks, int rank, const void *id128);
+int mphip_comm_destroy(mphip_ctx *ctx);
+
 /* Tuning knobs without a reference counterpart.
  *   "locality_sort_interval" (default 60): the device keeps the particles stored
  *   in meteo-grid-cell order and re-sorts every this many time steps so that

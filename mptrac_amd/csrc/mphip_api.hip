@@ -2,6 +2,8 @@
 // context, device mirrors of the reference structs, the module scheduler of
 // mptrac_run_timestep and the kernel launches.  Built for gfx950 only.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -130,8 +132,13 @@ struct mphip_ctx {
   double *d_sums = nullptr;
   size_t sums_cap = 0;
 
+  int *d_cnt = nullptr;               // particles per mixing cell (32-bit: the reference's `int count[]`)
+  size_t cnt_cap = 0;
+
   mphip_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
+  void *comm = nullptr;               // RCCL communicator (ncclComm_t) of mphip_comm_init, NULL = single rank / hook
+  int comm_ranks = 1, comm_rank = 0;
 
   // profiling of the fused step kernel
   bool prof = false;
@@ -952,12 +959,111 @@ int ensure_sums(mphip_ctx *ctx, size_t n) {
   return 0;
 }
 
-int run_allreduce(mphip_ctx *ctx, double *buf, size_t count) {
+// ---- RCCL (loaded on first use: single-GPU callers need no librccl) ------------
+// Only the handful of entry points the gridded reductions need; types restated from rccl.h (stable NCCL ABI).
+struct Rccl {
+  typedef struct { char internal[128]; } UniqueId;
+  int (*GetUniqueId)(UniqueId *) = nullptr;
+  int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+constexpr int kNcclInt32 = 2, kNcclFloat64 = 8, kNcclSum = 0;
+
+Rccl &rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void *h = nullptr;
+    for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" })
+      if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+        break;
+    if (!h) {
+      r.why = std::string("cannot load librccl.so: ") + dlerror();
+      return;
+    }
+    auto sym = [&](const char *n) {
+      void *p = dlsym(h, n);
+      if (!p)
+        r.why = std::string("librccl.so lacks ") + n;
+      return p;
+    };
+    r.GetUniqueId = (decltype(r.GetUniqueId)) sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank)) sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy)) sym("ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce)) sym("ncclAllReduce");
+    r.GroupStart = (decltype(r.GroupStart)) sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd)) sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString)) sym("ncclGetErrorString");
+    r.ok = r.why.empty();
+  });
+  return r;
+}
+
+// RCCL writes a version banner to stdout when it initialises; callers of this library own stdout (bench.py
+// prints exactly one JSON line there), so the banner goes to stderr instead
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0)
+      dup2(2, 1);
+  }
+  ~StdoutToStderr() {
+    fflush(stdout);
+    if (saved >= 0) {
+      dup2(saved, 1);
+      close(saved);
+    }
+  }
+};
+
+#define RCCLCHK(call)                                                                        \
+  do {                                                                                       \
+    const int e_ = (call);                                                                   \
+    if (e_ != 0)                                                                             \
+      return fail(ctx, std::string(#call) + ": " + rccl().GetErrorString(e_));               \
+  } while (0)
+
+// Sum over the ranks, in place: `count` doubles at dbuf and (optionally) `icount` 32-bit integers at ibuf.
+// With a communicator (mphip_comm_init) both go to RCCL as one group on the context's stream and the host does
+// not wait; with an all-reduce hook (tests, staged host collectives) the stream is drained and the integers
+// travel as doubles in `scratch` (icount doubles).
+int run_allreduce(mphip_ctx *ctx, double *dbuf, size_t count, int *ibuf = nullptr, size_t icount = 0,
+                  double *scratch = nullptr) {
+  if (ctx->comm) {
+    Rccl &R = rccl();
+    RCCLCHK(R.GroupStart());
+    if (count)
+      RCCLCHK(R.AllReduce(dbuf, dbuf, count, kNcclFloat64, kNcclSum, ctx->comm, ctx->stream));
+    if (icount)
+      RCCLCHK(R.AllReduce(ibuf, ibuf, icount, kNcclInt32, kNcclSum, ctx->comm, ctx->stream));
+    RCCLCHK(R.GroupEnd());
+    return 0;
+  }
   if (!ctx->allreduce)
     return 0;
+  if (icount) {
+    hipLaunchKernelGGL(int_to_double_kernel, dim3(grid_for((long long) icount)), dim3(256), 0, ctx->stream, ibuf, scratch,
+                       icount);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (ctx->allreduce(buf, count, ctx->allreduce_user))
+  if (count && ctx->allreduce(dbuf, count, ctx->allreduce_user))
     return fail(ctx, "all-reduce hook reported an error");
+  if (icount) {
+    if (ctx->allreduce(scratch, icount, ctx->allreduce_user))
+      return fail(ctx, "all-reduce hook reported an error");
+    hipLaunchKernelGGL(double_to_int_kernel, dim3(grid_for((long long) icount)), dim3(256), 0, ctx->stream, scratch, ibuf,
+                       icount);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -990,33 +1096,43 @@ int do_mixing(mphip_ctx *ctx, double t) {
   const int ngrid = c.mixing_nx * c.mixing_ny * c.mixing_nz;
   const int nens = c.nens > 0 ? c.nens : 1;
   const size_t ntot = (size_t) ngrid * nens;
-  if (ensure_sums(ctx, 2 * ntot))
-    return 1;
   const DevAtm a = dev_atm(ctx);
+  // the mixed quantities (hot-path subset of mptrac.c:5223-5230), all in one pass
+  MixSet mq;
+  mq.n = 0;
+  for (int iq : { c.qnt_m, c.qnt_vmr, c.qnt_aoa })
+    if (iq >= 0)
+      mq.q[mq.n++] = a.q[iq];
+  if (mq.n == 0)
+    return 0;
+  // [sums of quantity 0 | 1 | 2 | scratch for a doubles-only all-reduce hook]
+  const bool hook = !ctx->comm && ctx->allreduce;
+  if (ensure_sums(ctx, ((size_t) mq.n + (hook ? 1 : 0)) * ntot))
+    return 1;
+  if (ntot > ctx->cnt_cap) {
+    if (dev_alloc(ctx, &ctx->d_cnt, ntot))
+      return 1;
+    ctx->cnt_cap = ntot;
+  }
   BoxGrid G = { c.mixing_lon0, c.mixing_lon1, c.mixing_lat0, c.mixing_lat1, c.mixing_z0, c.mixing_z1,
                 c.mixing_nx, c.mixing_ny, c.mixing_nz };
   const int nb = grid_for(std::max<long long>(ctx->np, 1));
-  if (ctx->np)
+  HIPCHK(hipMemsetAsync(ctx->d_sums, 0, (size_t) mq.n * ntot * sizeof(double), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_cnt, 0, ntot * sizeof(int), ctx->stream));
+  const double *ens = (c.nens > 0 && c.qnt_ens >= 0) ? a.q[c.qnt_ens] : nullptr;
+  if (ctx->np) {
     hipLaunchKernelGGL(box_index_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
                        t + 0.5 * c.dt_mod, ctx->d_cell);
-  const double *ens = (c.nens > 0 && c.qnt_ens >= 0) ? a.q[c.qnt_ens] : nullptr;
-  const int quantities[3] = { c.qnt_m, c.qnt_vmr, c.qnt_aoa };   // hot-path subset of mptrac.c:5223-5230
-  for (int k = 0; k < 3; k++) {
-    const int iq = quantities[k];
-    if (iq < 0)
-      continue;
-    HIPCHK(hipMemsetAsync(ctx->d_sums, 0, 2 * ntot * sizeof(double), ctx->stream));
-    if (ctx->np) {
-      const AccumGeom g = accum_geom(ctx, 2);
-      hipLaunchKernelGGL(mix_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, a.q[iq],
-                         ens, ngrid, ntot, ctx->d_sums, g.T, g.per_block);
-    }
-    if (run_allreduce(ctx, ctx->d_sums, 2 * ntot))
-      return 1;
-    if (ctx->np)
-      hipLaunchKernelGGL(mix_relax_kernel, dim3(nb), dim3(256), 0, ctx->stream, c, ctx->d_clim, a, ctx->d_cell,
-                         a.q[iq], ens, ngrid, ntot, ctx->d_sums);
+    const AccumGeom g = accum_geom(ctx, mq.n + 1);
+    hipLaunchKernelGGL(mix_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, mq, ens,
+                       ngrid, ntot, ctx->d_sums, ctx->d_cnt, g.T, g.per_block);
   }
+  // one exchange per mixing step: the sums of every mixed quantity and the cell counts
+  if (run_allreduce(ctx, ctx->d_sums, (size_t) mq.n * ntot, ctx->d_cnt, ntot, ctx->d_sums + (size_t) mq.n * ntot))
+    return 1;
+  if (ctx->np)
+    hipLaunchKernelGGL(mix_relax_kernel, dim3(nb), dim3(256), 0, ctx->stream, c, ctx->d_clim, a, ctx->d_cell, mq, ens,
+                       ngrid, ntot, ctx->d_sums, ctx->d_cnt);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1135,6 +1251,8 @@ void mphip_destroy(mphip_ctx *ctx) {
     return;
   (void) hipSetDevice(ctx->device);
   (void) hipStreamSynchronize(ctx->stream);
+  if (ctx->comm)
+    (void) rccl().CommDestroy(ctx->comm);
   if (ctx->uploader.joinable())
     ctx->uploader.join();
   if (ctx->copy_stream) {
@@ -1195,6 +1313,7 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_counts);
   dev_free(ctx->d_cell);
   dev_free(ctx->d_sums);
+  dev_free(ctx->d_cnt);
   for (auto e : ctx->ev)
     (void) hipEventDestroy(e);
   (void) hipStreamDestroy(ctx->stream);
@@ -1853,6 +1972,57 @@ int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user) {
     return 1;
   ctx->allreduce = fn;
   ctx->allreduce_user = user;
+  return 0;
+}
+
+int mphip_comm_unique_id(void *id128) {
+  if (!id128)
+    return 1;
+  Rccl &R = rccl();
+  if (!R.ok) {
+    fprintf(stderr, "mptrac_hip: %s\n", R.why.c_str());
+    return 2;
+  }
+  Rccl::UniqueId id;
+  StdoutToStderr quiet;
+  if (R.GetUniqueId(&id) != 0)
+    return 3;
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+int mphip_comm_init(mphip_ctx *ctx, int nranks, int rank, const void *id128) {
+  if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
+    return fail(ctx, "bad communicator arguments");
+  Rccl &R = rccl();
+  if (!R.ok)
+    return fail(ctx, R.why);
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->comm) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    RCCLCHK(R.CommDestroy(ctx->comm));
+    ctx->comm = nullptr;
+  }
+  Rccl::UniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  StdoutToStderr quiet;
+  RCCLCHK(R.CommInitRank(&ctx->comm, nranks, id, rank));
+  ctx->comm_ranks = nranks;
+  ctx->comm_rank = rank;
+  return 0;
+}
+
+int mphip_comm_destroy(mphip_ctx *ctx) {
+  if (!ctx)
+    return 1;
+  if (ctx->comm) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    RCCLCHK(rccl().CommDestroy(ctx->comm));
+    ctx->comm = nullptr;
+  }
+  ctx->comm_ranks = 1;
+  ctx->comm_rank = 0;
   return 0;
 }
 

@@ -1113,15 +1113,23 @@ struct LdsTable {
   }
 };
 
-// sums[0 .. ntot) += q, sums[ntot .. 2 ntot) += 1 (counts kept as doubles so
-// that one all-reduce of doubles covers both; exact below 2^53)
-__global__ __launch_bounds__(256) void mix_accumulate_kernel(DevAtm a, const int *__restrict__ cell,
-                                                             const double *__restrict__ q,
+// module_mixing's cell sums for every mixed quantity in one pass (mptrac.c:5223-5230, 5289-5303):
+// sums[k * ntot + idx] += q_k, cnt[idx] += 1 with idx = ens * ngrid + cell.  The particle count is the
+// same for all quantities and is kept once, as 32-bit integers (a third fewer bytes through the all-reduce
+// than [sum | count] pairs of doubles per quantity).
+constexpr int kMixMax = 3;   // mass, volume mixing ratio, age of air (the hot-path subset of the reference's list)
+struct MixSet {
+  double *q[kMixMax];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void mix_accumulate_kernel(DevAtm a, const int *__restrict__ cell, MixSet mq,
                                                              const double *__restrict__ ens, int ngrid, size_t ntot,
-                                                             double *__restrict__ sums, int T, long long per_block) {
+                                                             double *__restrict__ sums, int *__restrict__ cnt, int T,
+                                                             long long per_block) {
   extern __shared__ double s_tab[];
   LdsTable tab;
-  tab.init(s_tab, T, 2);
+  tab.init(s_tab, T, mq.n + 1);   // value mq.n of an entry: the count
   const long long first = blockIdx.x * per_block;
   const long long last = first + per_block < a.np ? first + per_block : a.np;
   for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
@@ -1129,22 +1137,34 @@ __global__ __launch_bounds__(256) void mix_accumulate_kernel(DevAtm a, const int
     if (c >= 0) {
       const size_t idx = (size_t) (ens ? (int) ens[i] : 0) * (size_t) ngrid + (size_t) c;
       const int slot = idx < 0x7fffffffu ? tab.slot_for((int) idx) : -1;
-      if (slot >= 0) {
-        tab.add(slot, 0, q[i]);
-        tab.add(slot, 1, 1.0);
-      } else {
-        unsafeAtomicAdd(&sums[idx], q[i]);
-        unsafeAtomicAdd(&sums[ntot + idx], 1.0);
+      for (int k = 0; k < mq.n; k++) {
+        const double v = mq.q[k][i];
+        if (slot >= 0)
+          tab.add(slot, k, v);
+        else
+          unsafeAtomicAdd(&sums[(size_t) k * ntot + idx], v);
       }
+      if (slot >= 0)
+        tab.add(slot, mq.n, 1.0);
+      else
+        atomicAdd(&cnt[idx], 1);
     }
   }
-  tab.flush(sums, ntot);
+  __syncthreads();
+  for (int i = threadIdx.x; i < tab.T; i += blockDim.x) {
+    const int key = tab.keys[i];
+    if (key >= 0) {
+      for (int k = 0; k < mq.n; k++)
+        unsafeAtomicAdd(&sums[(size_t) k * ntot + (size_t) key], tab.vals[(size_t) k * tab.T + i]);
+      atomicAdd(&cnt[key], (int) tab.vals[(size_t) mq.n * tab.T + i]);
+    }
+  }
 }
 
-// q += (mean - q) * mixparam, mptrac.c:5324-5339
-__global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a, const int *__restrict__ cell,
-                                 double *__restrict__ q, const double *__restrict__ ens, int ngrid, size_t ntot,
-                                 const double *__restrict__ sums) {
+// q += (mean - q) * mixparam for every mixed quantity, mptrac.c:5305-5339
+__global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a, const int *__restrict__ cell, MixSet mq,
+                                 const double *__restrict__ ens, int ngrid, size_t ntot,
+                                 const double *__restrict__ sums, const int *__restrict__ cnt) {
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
        i += (long long) gridDim.x * blockDim.x) {
     const int c = cell[i];
@@ -1155,12 +1175,26 @@ __global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a,
         const double w = tropo_weight(ctl, *clim, a.time[i], a.lat[i], a.p[i]);
         mixparam = w * ctl.mixing_trop + (1.0 - w) * ctl.mixing_strat;
       }
-      const double cnt = sums[ntot + idx];
-      const double mean = cnt > 0 ? sums[idx] / cnt : sums[idx];
-      const double v = q[i];
-      q[i] = v + (mean - v) * mixparam;
+      const int n = cnt[idx];
+      for (int k = 0; k < mq.n; k++) {
+        const double sum = sums[(size_t) k * ntot + idx];
+        const double mean = n > 0 ? sum / n : sum;
+        const double v = mq.q[k][i];
+        mq.q[k][i] = v + (mean - v) * mixparam;
+      }
     }
   }
+}
+
+// counts <-> doubles around an all-reduce hook that only knows doubles (tests, staged host collectives)
+__global__ void int_to_double_kernel(const int *__restrict__ in, double *__restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+    out[i] = (double) in[i];
+}
+
+__global__ void double_to_int_kernel(const double *__restrict__ in, int *__restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+    out[i] = (int) in[i];
 }
 
 // buf[0 .. ncell) += 1, buf[(1 + iq) ncell ..] += q, buf[(1 + nq + iq) ncell ..] += q^2

@@ -36,6 +36,24 @@ def init_process_group(backend):
     return dist
 
 
+def init_rccl(sim, dist=None):
+    """Gives `sim` (hip.Simulation) an RCCL communicator over all ranks of the process group: rank 0 creates
+    the identifier, torch.distributed only carries its 128 bytes to the others; from then on the gridded
+    reductions are ncclAllReduce calls of the C library on the simulation's own stream (no Python, no host
+    synchronisation in the data path).  Without a process group: a single-rank communicator."""
+    from .hip import Simulation
+    if dist is None or not dist.is_initialized():
+        sim.comm_init(1, 0, Simulation.comm_unique_id())
+        return
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    uid = Simulation.comm_unique_id() if rank == 0 else bytes(128)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0)
+    sim.comm_init(world, rank, bytes(t.cpu().tolist()))
+
+
 def make_allreduce_hook(device_kind):
     """Returns fn(ptr, count) summing `count` doubles at address `ptr` over all
     ranks in place.  device_kind "cuda": HIP device memory (RCCL);

@@ -101,6 +101,9 @@ def load(build=True):
     L.mphip_get_sort.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
     L.mphip_grid_sums.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), _dp, _dp]
     L.mphip_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    L.mphip_comm_unique_id.argtypes = [C.c_void_p]
+    L.mphip_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mphip_comm_destroy.argtypes = [C.c_void_p]
     L.mphip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.mphip_synchronize.argtypes = [C.c_void_p]
     L.mphip_profile_begin.argtypes = [C.c_void_p]
@@ -346,6 +349,21 @@ class Simulation:
                 return 1
         self._cb = ALLREDUCE_FN(_cb)
         self._chk(self.L.mphip_set_allreduce(self.h, self._cb, None))
+
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL identifier (created on rank 0, handed to the other ranks by the host)."""
+        buf = C.create_string_buffer(128)
+        if load().mphip_comm_unique_id(buf):
+            raise MphipError("mphip_comm_unique_id failed (librccl not loadable?)")
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        """RCCL communicator of this context: the gridded reductions become all-reduces on its stream."""
+        self._chk(self.L.mphip_comm_init(self.h, int(nranks), int(rank), C.c_char_p(bytes(unique_id))))
+
+    def comm_destroy(self):
+        self._chk(self.L.mphip_comm_destroy(self.h))
 
     def profile_begin(self):
         self._chk(self.L.mphip_profile_begin(self.h))

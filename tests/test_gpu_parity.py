@@ -592,6 +592,37 @@ def test_index_range_shards_reproduce_the_single_context_run():
         sim.close()
 
 
+def test_rccl_communicator_single_rank():
+    """The native reduction path (mphip_comm_init: ncclAllReduce of the mixing sums + 32-bit counts and of the
+    gridded-output sums, on the context's stream, librccl loaded with dlopen) with a one-rank communicator --
+    what one GPU can exercise of it -- against the oracle, and bit-identical to the run without a communicator."""
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=12000)
+    ctl["mixing_dt"] = 180.0
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    runs = []
+    for with_comm in (True, False):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        if with_comm:
+            s.comm_init(1, 0, hip.Simulation.comm_unique_id())
+        s.timesteps_init(0.0, 0.0)
+        for t in cases.step_times(s.ctl)[:8]:
+            s.run_timestep(t)
+            if with_comm:
+                o.run_timestep(t)
+        if with_comm:
+            _compare(o, s, tol=1e-12)
+            co, mo, so = o.grid_sums(o.time[0])
+            cs, ms, ss = s.grid_sums(o.time[0])
+            assert np.array_equal(co, cs) and cases.rel_err(ms, mo) <= 1e-12
+            s.comm_destroy()
+        runs.append(s.state())
+        s.close()
+    for k in ("time", "lon", "lat", "p", "uvwp"):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+    assert cases.rel_err(runs[0]["q"], runs[1]["q"]) <= 1e-13      # (atomic sums: order differs from run to run)
+
+
 # ---------------------------------------------------------------------------
 # full-size properties (BASELINE sizes; no oracle run at this size)
 # ---------------------------------------------------------------------------
