@@ -80,7 +80,9 @@ def build_host(force=False, verbose=False, dims=None):
     and the trac driver.  Plain gcc; links against libmptrac_hip.so."""
     os.makedirs(LIBDIR, exist_ok=True)
     dims = dict(HOST_DIMS, **(dims or {}))
-    src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "mptrac.h", "trac.c")]
+    src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "mptrac.h", "trac.c", "ctlfile.c", "nc_classic.c",
+                                               "nc_classic.h", "rendezvous.c")]
+    lib_src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "ctlfile.c", "nc_classic.c", "rendezvous.c")]
     if not (force or _stale(HOST_LIB, src) or _stale(TRAC_BIN, src)):
         return HOST_LIB, TRAC_BIN
     defs = [f"-D{k}={v}" for k, v in dims.items()]
@@ -88,8 +90,8 @@ def build_host(force=False, verbose=False, dims=None):
     common = ["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-W", "-Wno-format-security", "-fPIC", "-mcmodel=medium",
               *defs]
     rpath = ["-L" + LIBDIR, "-lmptrac_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread"]
-    cmds = [common + ["-shared", "-o", HOST_LIB, os.path.join(HOST_DIR, "mptrac.c")] + rpath,
-            common + ["-o", TRAC_BIN, os.path.join(HOST_DIR, "trac.c"), os.path.join(HOST_DIR, "mptrac.c")] + rpath]
+    cmds = [common + ["-shared", "-o", HOST_LIB] + lib_src + rpath,
+            common + ["-o", TRAC_BIN, os.path.join(HOST_DIR, "trac.c")] + lib_src + rpath]
     for cmd in cmds:
         if verbose:
             print(" ".join(cmd))

@@ -15,6 +15,7 @@
 #include <time.h>
 
 #include "../../include/mptrac_hip.h"
+#include "nc_classic.h"
 
 /* process-global device state; the reference's interface is not re-entrant
  * either (file-static RNG state, mptrac.c:32-40) */
@@ -24,12 +25,17 @@ static const met_t *g_met_host[2];     /* host snapshots mirrored in device slot
 static struct {
   met_t *met;              /* the spare buffer */
   pthread_t thread;
-  int active;              /* a reader thread is running or waits to be joined */
-  int ok;                  /* file read and upload started */
+  int active;              /* a reader thread was started for `filename` */
+  int joined;              /* ... and has been joined */
+  int done;                /* set by the reader when it is through (atomic) */
+  int file_ok;             /* the file was read into `met` */
+  int ok;                  /* its upload was started (mphip_prefetch_met) */
   ctl_t *ctl;
   clim_t *clim;
   char filename[LEN];
 } g_ahead;
+static long long g_ip0, g_np_total = -1; /* index range of this rank's particles (mptrac_amd_shard); -1: all of them */
+static int g_rank, g_world = 1;
 static int g_nq;                        /* ctl->nq of the last control upload */
 static int g_isosurf;                   /* ctl->isosurf of the last control upload */
 static int g_meteo_fields;              /* a module_meteo quantity is requested: upload the fields only it reads */
@@ -43,83 +49,7 @@ static int g_meteo_fields;              /* a module_meteo quantity is requested:
 /* small utilities                                                            */
 /* -------------------------------------------------------------------------- */
 
-void jsec2time(const double jsec, int *year, int *mon, int *day, int *hour, int *min, int *sec,
-               double *remain) {
-  /* seconds since 2000-01-01T00:00Z, mptrac.c:3265-3294 */
-  struct tm t0 = { 0 }, *t1;
-  t0.tm_year = 100;
-  t0.tm_mday = 1;
-  const time_t jsec0 = (time_t) jsec + timegm(&t0);
-  t1 = gmtime(&jsec0);
-  *year = t1->tm_year + 1900;
-  *mon = t1->tm_mon + 1;
-  *day = t1->tm_mday;
-  *hour = t1->tm_hour;
-  *min = t1->tm_min;
-  *sec = t1->tm_sec;
-  *remain = jsec - floor(jsec);
-}
-
-void time2jsec(const int year, const int mon, const int day, const int hour, const int min,
-               const int sec, const double remain, double *jsec) {
-  struct tm t0 = { 0 }, t1 = { 0 };
-  t0.tm_year = 100;
-  t0.tm_mday = 1;
-  t1.tm_year = year - 1900;
-  t1.tm_mon = mon - 1;
-  t1.tm_mday = day;
-  t1.tm_hour = hour;
-  t1.tm_min = min;
-  t1.tm_sec = sec;
-  *jsec = (double) timegm(&t1) - (double) timegm(&t0) + remain;
-}
-
-double scan_ctl(const char *filename, int argc, char *argv[], const char *varname, const int arridx,
-                const char *defvalue, char *value) {
-  /* Same look-up rules as mptrac.c:12434-12502: "KEY = VALUE" lines of the
-   * control file, overridden by trailing "KEY VALUE" arguments; KEY[i] and
-   * KEY[*] for arrays; a file name ending in '-' means arguments only. */
-  FILE *in = NULL;
-  char fullname1[LEN], fullname2[LEN], rval[LEN];
-  int contain = 0;
-
-  if (filename[strlen(filename) - 1] != '-')
-    if (!(in = fopen(filename, "r")))
-      ERRMSG("Cannot open file!");
-  if (arridx >= 0) {
-    sprintf(fullname1, "%s[%d]", varname, arridx);
-    sprintf(fullname2, "%s[*]", varname);
-  } else {
-    sprintf(fullname1, "%s", varname);
-    sprintf(fullname2, "%s", varname);
-  }
-  if (in != NULL) {
-    char dummy[LEN], line[LEN], rvarname[LEN];
-    while (fgets(line, LEN, in))
-      if (sscanf(line, "%4999s %4999s %4999s", rvarname, dummy, rval) == 3)
-        if (strcasecmp(rvarname, fullname1) == 0 || strcasecmp(rvarname, fullname2) == 0) {
-          contain = 1;
-          break;
-        }
-    fclose(in);
-  }
-  for (int i = 1; i < argc - 1; i++)
-    if (strcasecmp(argv[i], fullname1) == 0 || strcasecmp(argv[i], fullname2) == 0) {
-      sprintf(rval, "%s", argv[i + 1]);
-      contain = 1;
-      break;
-    }
-  if (!contain) {
-    if (strlen(defvalue) > 0)
-      sprintf(rval, "%s", defvalue);
-    else
-      ERRMSG("Missing variable %s!\n", fullname1);
-  }
-  LOG(1, "%s = %s", fullname1, rval);
-  if (value != NULL)
-    sprintf(value, "%s", rval);
-  return atof(rval);
-}
+/* scan_ctl, jsec2time, time2jsec: ctlfile.c */
 
 /* -------------------------------------------------------------------------- */
 /* alloc / free                                                               */
@@ -143,10 +73,9 @@ void mptrac_alloc(ctl_t **ctl, cache_t **cache, clim_t **clim, met_t **met0, met
 
 void mptrac_free(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t *met0, met_t *met1, atm_t *atm,
                  depo_t *depo, dd_t *dd) {
-  if (g_ahead.active) {
+  if (g_ahead.active && !g_ahead.joined)
     pthread_join(g_ahead.thread, NULL);
-    g_ahead.active = 0;
-  }
+  g_ahead.active = g_ahead.joined = 0;
   if (g_ctx) {
     mphip_destroy(g_ctx);
     g_ctx = NULL;
@@ -249,6 +178,21 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   ctl->dt_met = scan_ctl(filename, argc, argv, "DT_MET", -1, "3600", NULL);
   ctl->met_type = (int) scan_ctl(filename, argc, argv, "MET_TYPE", -1, "0", NULL);
   ctl->met_dt_out = scan_ctl(filename, argc, argv, "MET_DT_OUT", -1, "0.1", NULL);
+  ctl->met_nc_scale = (int) scan_ctl(filename, argc, argv, "MET_NC_SCALE", -1, "1", NULL);
+  ctl->met_pbl = (int) scan_ctl(filename, argc, argv, "MET_PBL", -1, "3", NULL);
+  ctl->met_cape = (int) scan_ctl(filename, argc, argv, "MET_CAPE", -1, "1", NULL);
+  if (ctl->met_type == 0) {
+    /* netCDF input is taken as stored: no down-sampling, smoothing, detrending, re-gridding (mptrac.c:7770-7830) */
+    static const struct {
+      const char *key, *def;
+    } untouched[] = { { "MET_DX", "1" }, { "MET_DY", "1" }, { "MET_DP", "1" }, { "MET_SX", "1" }, { "MET_SY", "1" },
+      { "MET_SP", "1" }, { "MET_DETREND", "-999" }, { "MET_NP", "0" }, { "MET_VERT_COORD", "0" }, { "MET_CLAMS", "0" },
+      { "MET_CONVENTION", "0" }, { "MET_RELHUM", "0" }, { NULL, NULL } };
+    for (int k = 0; untouched[k].key; k++)
+      if (scan_ctl(filename, argc, argv, untouched[k].key, -1, untouched[k].def, NULL) != atof(untouched[k].def))
+        ERRMSG("%s: the meteo preprocessing of the reference is not part of this build (netCDF input is used as stored)!",
+               untouched[k].key);
+  }
 
   /* modules (mptrac.c:7196-7263) */
   ctl->sort_dt = scan_ctl(filename, argc, argv, "SORT_DT", -1, "-999", NULL);
@@ -290,18 +234,47 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   ctl->bound_dzs = scan_ctl(filename, argc, argv, "BOUND_DZS", -1, "-999", NULL);
   ctl->bound_zetas = scan_ctl(filename, argc, argv, "BOUND_ZETAS", -1, "-999", NULL);
   ctl->bound_pbl = (int) scan_ctl(filename, argc, argv, "BOUND_PBL", -1, "0", NULL);
-  ctl->molmass = scan_ctl(filename, argc, argv, "MOLMASS", -1, "-999", NULL);
-
-  /* wet / dry deposition, decay, mixing (mptrac.c:7425-7543) */
+  /* SPECIES presets (values: mptrac.c:7291-7383): molar mass and Henry's-law constants become the defaults of
+   * MOLMASS / WET_DEPO_*_H below; a species that also switches the OH chemistry on is only accepted with that
+   * chemistry explicitly off, because this build does not provide it */
+  static const struct {
+    const char *name;
+    double molmass, henry_ref, henry_temp;
+    int oh_reaction;
+  } species[] = {
+    { "CF2Cl2", 120.907, 3e-5, 3500.0, 0 }, { "CFCl3", 137.359, 1.1e-4, 3300.0, 0 }, { "CH4", 16.043, 1.4e-5, 1600.0, 2 },
+    { "CO", 28.01, 9.7e-6, 1300.0, 3 }, { "CO2", 44.009, 3.3e-4, 2400.0, 0 }, { "H2O", 18.01528, 0, 0, 0 },
+    { "N2O", 44.013, 2.4e-4, 2600.0, 0 }, { "NH3", 17.031, 5.9e-1, 4200.0, 2 }, { "HNO3", 63.012, 2.1e3, 8700.0, 0 },
+    { "NO", 30.006, 1.9e-5, 1600.0, 3 }, { "NO2", 46.005, 1.2e-4, 2400.0, 3 }, { "O3", 47.997, 1e-4, 2800.0, 2 },
+    { "SF6", 146.048, 2.4e-6, 3100.0, 0 }, { "SO2", 64.066, 1.3e-2, 2900.0, 3 }, { NULL, 0, 0, 0, 0 }
+  };
   char defstr[LEN];
+  double molmass_default = 0, henry_default[2] = { 0, 0 };   /* calloc'ed ctl_t of the reference */
+  int oh_default = 0;
+  scan_ctl(filename, argc, argv, "SPECIES", -1, "-", ctl->species);
+  for (int k = 0; species[k].name; k++)
+    if (strcasecmp(ctl->species, species[k].name) == 0) {
+      molmass_default = species[k].molmass;
+      henry_default[0] = species[k].henry_ref;
+      henry_default[1] = species[k].henry_temp;
+      oh_default = species[k].oh_reaction;
+    }
+  sprintf(defstr, "%g", molmass_default);
+  ctl->molmass = scan_ctl(filename, argc, argv, "MOLMASS", -1, defstr, NULL);
+  sprintf(defstr, "%d", oh_default);
+  if ((int) scan_ctl(filename, argc, argv, "OH_CHEM_REACTION", -1, defstr, NULL) != 0)
+    ERRMSG("OH_CHEM_REACTION%s: the OH chemistry is not implemented in this build (set OH_CHEM_REACTION 0 to run "
+           "the species as a passive tracer with its deposition parameters)!", oh_default ? " (switched on by SPECIES)" : "");
+
+  /* wet / dry deposition, decay, mixing (mptrac.c:7425-7543): the species sets the defaults of the in-cloud
+   * constants and of the below-cloud WET_DEPO_BC_H[0]; WET_DEPO_BC_H[1] is not a control parameter */
   for (int k = 0; k < 2; k++) {
-    ctl->wet_depo_ic_h[k] = scan_ctl(filename, argc, argv, "WET_DEPO_IC_H", k, "0", NULL);
-    ctl->wet_depo_bc_h[k] = k == 0 ? scan_ctl(filename, argc, argv, "WET_DEPO_BC_H", k, "0", NULL)
-      : ctl->wet_depo_ic_h[1];
+    sprintf(defstr, "%g", henry_default[k]);
+    ctl->wet_depo_ic_h[k] = scan_ctl(filename, argc, argv, "WET_DEPO_IC_H", k, defstr, NULL);
   }
-  /* the reference scans WET_DEPO_BC_H[0] only (mptrac.c:7431-7435); [1] is set per species */
-  sprintf(defstr, "%g", ctl->wet_depo_ic_h[1]);
-  ctl->wet_depo_bc_h[1] = scan_ctl(filename, argc, argv, "WET_DEPO_BC_H", 1, defstr, NULL);
+  sprintf(defstr, "%g", henry_default[0]);
+  ctl->wet_depo_bc_h[0] = scan_ctl(filename, argc, argv, "WET_DEPO_BC_H", 0, defstr, NULL);
+  ctl->wet_depo_bc_h[1] = henry_default[1];
   ctl->wet_depo_so2_ph = scan_ctl(filename, argc, argv, "WET_DEPO_SO2_PH", -1, "0", NULL);
   ctl->wet_depo_ic_a = scan_ctl(filename, argc, argv, "WET_DEPO_IC_A", -1, "0", NULL);
   ctl->wet_depo_ic_b = scan_ctl(filename, argc, argv, "WET_DEPO_IC_B", -1, "0", NULL);
@@ -378,8 +351,8 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
       if (val[0] != '-')
         ERRMSG("%s is not implemented in this host layer!", names[k]);
     }
-    static const char *const switches[] = { "OH_CHEM_REACTION", "H2O2_CHEM_REACTION", "KPP_CHEM", "TRACER_CHEM",
-      "RADIO_DECAY", "GRID_TYPE", "DD", NULL };
+    static const char *const switches[] = { "H2O2_CHEM_REACTION", "KPP_CHEM", "TRACER_CHEM", "RADIO_DECAY", "RADIO_DEPO",
+      "GRID_TYPE", "DD", "MET_MPI_SHARE", NULL };
     for (int k = 0; switches[k]; k++)
       if ((int) scan_ctl(filename, argc, argv, switches[k], -1, "0", NULL) != 0)
         ERRMSG("%s is not implemented in this host layer!", switches[k]);
@@ -668,12 +641,16 @@ static void met_bin_body(FILE *f, int write, met_t *met) {
   free(help);
 }
 
+static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met);
+
 int mptrac_read_met(const char *filename, const ctl_t *ctl, const clim_t *clim, met_t *met, dd_t *dd) {
   (void) clim;
   (void) dd;
   LOG(1, "Read meteo data: %s", filename);
+  if (ctl->met_type == 0)
+    return read_met_nc(filename, ctl, met);
   if (ctl->met_type != 1)
-    ERRMSG("This build reads MET_TYPE 1 (raw binary) meteo files only!");
+    ERRMSG("This build reads MET_TYPE 0 (classic netCDF, grids without preprocessing) and 1 (raw binary) meteo files!");
   FILE *in;
   if (!(in = fopen(filename, "r"))) {
     WARN("Cannot open file!");
@@ -732,6 +709,242 @@ void mptrac_write_met(const char *filename, const ctl_t *ctl, met_t *met) {
   fclose(out);
 }
 
+/* -------------------------------------------------------------------------- */
+/* meteo I/O: netCDF (MET_TYPE 0), classic format, for grids that need no       */
+/* preprocessing                                                               */
+/* -------------------------------------------------------------------------- */
+
+/* The reference's netCDF reader (read_met_nc_grid / _surface / _levels, mptrac.c:9638-10250) is followed by its
+ * meteo preprocessing (geopotential heights, boundary layer, tropopause, cloud and CAPE diagnostics, polar
+ * winds, periodic column, ...; mptrac.c:7770-7830), which is outside this repository's scope.  What is
+ * read here is what needs none of that: Cartesian / UTM grids (MET_COORD_TYPE 1, the reference's
+ * tests/coord_test) with the fields stored in the file.  Rules restated from the reference's reader:
+ *   - time from the file name (<metbase>_YYYY_MM_DD_HH.nc), axes x / y in metres, levels in Pa -> hPa, descending;
+ *   - a field is looked up under alternative names, layout [time][level][y][x], first time;
+ *   - value = scl * stored (single precision); packed shorts: scl * (stored * scale_factor + add_offset);
+ *     _FillValue, missing_value (when non-zero) and |value| >= 1e14 give NaN;
+ *   - read_met_extrapolate (mptrac.c:9470-9506): levels at and below the lowest one where t, u, v or w is
+ *     not finite are filled from the level above. */
+
+typedef struct {
+  ncc_file *nc;
+  const ctl_t *ctl;
+  const met_t *met;
+  int nc_scale;
+} nc_reader;
+
+static int nc_lookup(const nc_reader *r, const char *const *names) {
+  for (int k = 0; names[k]; k++) {
+    const int v = ncc_find_var(r->nc, names[k]);
+    if (v >= 0)
+      return v;
+  }
+  return -1;
+}
+
+/* one level field ([np][ny][nx] in the file) or surface field (nlev = 0: [ny][nx]) into dest[(ix * EY + iy) * stride + ip] */
+static int nc_field(const nc_reader *r, const char *const *names, const int nlev, const float scl, float *dest,
+                    const size_t stride) {
+  const int var = nc_lookup(r, names);
+  if (var < 0)
+    return 0;
+  const met_t *met = r->met;
+  const int nd = ncc_var_ndims(r->nc, var), lev = nlev > 0 ? nlev : 1;
+  const long long n = (long long) lev * met->ny * met->nx;
+  /* [time] [level] y x: check the trailing extents */
+  if (nd < (nlev > 0 ? 3 : 2) || ncc_var_dim(r->nc, var, nd - 1, NULL) != met->nx
+      || ncc_var_dim(r->nc, var, nd - 2, NULL) != met->ny || (nlev > 0 && ncc_var_dim(r->nc, var, nd - 3, NULL) != nlev))
+    ERRMSG("Meteo field has unexpected dimensions!");
+  double fill = 0, miss = 0, scale = 1, offset = 0;
+  const int has_fill = ncc_get_att(r->nc, var, "_FillValue", &fill);
+  const int has_miss = ncc_get_att(r->nc, var, "missing_value", &miss);
+  const int packed = r->nc_scale && ncc_get_att(r->nc, var, "add_offset", &offset)
+    && ncc_get_att(r->nc, var, "scale_factor", &scale);
+  float *help;
+  ALLOC(help, float, (size_t) n);
+  if (packed) {
+    short *raw;
+    ALLOC(raw, short, (size_t) n);
+    if (!ncc_read_short(r->nc, var, 0, 0, n, raw))
+      ERRMSG("netCDF: %s", ncc_error(r->nc));
+    const short fillval = has_fill ? (short) fill : 0, missval = has_miss ? (short) miss : 0;
+    const float scalfac = (float) scale, off = (float) offset;
+    for (long long i = 0; i < n; i++) {
+      const float v = raw[i] * scalfac + off;
+      help[i] = ((fillval == 0 || raw[i] != fillval) && (missval == 0 || raw[i] != missval) && fabsf(v) < 1e14f)
+        ? scl * v : NAN;
+    }
+    free(raw);
+  } else {
+    if (!ncc_read_float(r->nc, var, 0, 0, n, help))
+      ERRMSG("netCDF: %s", ncc_error(r->nc));
+    const float fillval = has_fill ? (float) fill : 0.f, missval = has_miss ? (float) miss : 0.f;
+    for (long long i = 0; i < n; i++) {
+      const float v = help[i];
+      help[i] = ((fillval == 0 || v != fillval) && (missval == 0 || v != missval) && fabsf(v) < 1e14f) ? scl * v : NAN;
+    }
+  }
+  for (int ix = 0; ix < met->nx; ix++)
+    for (int iy = 0; iy < met->ny; iy++)
+      for (int ip = 0; ip < lev; ip++)
+        dest[((size_t) ix * EY + (size_t) iy) * stride + (size_t) ip] = help[((size_t) ip * met->ny + iy) * met->nx + ix];
+  free(help);
+  return 1;
+}
+
+#define NAMES(...) ((const char *const[]) { __VA_ARGS__, NULL })
+#define NC_3D(field, scl, ...) nc_field(&r, NAMES(__VA_ARGS__), met->np, scl, &met->field[0][0][0], EP)
+#define NC_2D(field, scl, ...) nc_field(&r, NAMES(__VA_ARGS__), 0, scl, &met->field[0][0], 1)
+
+static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
+  char err[256];
+  ncc_file *nc = ncc_open(filename, err, sizeof(err));
+  if (!nc) {
+    if (strcmp(err, "cannot open file") == 0) {
+      WARN("Cannot open file!");
+      return 0;
+    }
+    ERRMSG("%s: %s", filename, err);
+  }
+  if (ctl->met_coord_type == 0)
+    ERRMSG("netCDF meteo files on a longitude / latitude grid need the reference's meteo preprocessing, which this "
+           "build does not provide: convert them to MET_TYPE 1 with the reference's met_conv tool!");
+  met->coord_type = ctl->met_coord_type;
+  nc_reader r = { nc, ctl, met, ctl->met_nc_scale };
+
+  /* time from the file name: ..._YYYY_MM_DD_HH.nc */
+  const size_t len = strlen(filename);
+  int year, mon, day, hour;
+  if (len < 16 || sscanf(filename + len - 16, "%4d_%2d_%2d_%2d", &year, &mon, &day, &hour) != 4 || year < 1900
+      || year > 2100 || mon < 1 || mon > 12 || day < 1 || day > 31 || hour < 0 || hour > 23)
+    ERRMSG("Cannot read time from filename!");
+  time2jsec(year, mon, day, hour, 0, 0, 0, &met->time);
+
+  /* axes */
+  long long nx, ny;
+  if (ncc_find_dim(nc, "x", &nx) < 0 || ncc_find_dim(nc, "y", &ny) < 0)
+    ERRMSG("Cannot read netCDF dimension x / y!");
+  if (nx < 2 || nx > EX || ny < 2 || ny > EY)
+    ERRMSG("Dimension x / y is out of range!");
+  met->nx = (int) nx;
+  met->ny = (int) ny;
+  const int vx = ncc_find_var(nc, "x"), vy = ncc_find_var(nc, "y");
+  if (vx < 0 || vy < 0 || !ncc_read_double(nc, vx, 0, 0, nx, met->lon) || !ncc_read_double(nc, vy, 0, 0, ny, met->lat))
+    ERRMSG("Cannot read the x / y coordinates!");
+  const int vu = nc_lookup(&r, NAMES("u", "U"));
+  if (vu < 0)
+    ERRMSG("Variable 'u' or 'U' not found, cannot determine vertical dimension!");
+  const int nd = ncc_var_ndims(nc, vu);
+  if (nd != 3 && nd != 4)
+    ERRMSG("Cannot determine vertical dimension!");
+  const char *levname;
+  const long long np = ncc_var_dim(nc, vu, nd == 4 ? 1 : 0, &levname);
+  if (np < 2 || np > EP)
+    ERRMSG("Number of levels out of range!");
+  met->np = (int) np;
+  const int vl = ncc_find_var(nc, levname);
+  if (vl < 0 || !ncc_read_double(nc, vl, 0, 0, np, met->p))
+    ERRMSG("Cannot read the pressure levels!");
+  for (int ip = 0; ip < met->np; ip++)
+    met->p[ip] /= 100.;
+  for (int ix = 2; ix < met->nx; ix++)
+    if (fabs(fabs(met->lon[ix] - met->lon[ix - 1]) - fabs(met->lon[1] - met->lon[0])) > 0.001)
+      ERRMSG("No regular grid spacing in longitudes!");
+  LOG(2, "Grid: %d x %d x %d, %g ... %g hPa", met->nx, met->ny, met->np, met->p[0], met->p[met->np - 1]);
+
+  /* surface fields */
+  if (NC_2D(ps, 1.0f, "lnsp", "LNSP")) {
+    for (int ix = 0; ix < met->nx; ix++)
+      for (int iy = 0; iy < met->ny; iy++)
+        met->ps[ix][iy] = (float) (exp(met->ps[ix][iy]) / 100.);
+  } else if (!NC_2D(ps, 0.01f, "ps", "PS", "sp", "SP")) {
+    WARN("Cannot not read surface pressure data (use lowest level)!");
+    for (int ix = 0; ix < met->nx; ix++)
+      for (int iy = 0; iy < met->ny; iy++)
+        met->ps[ix][iy] = (float) met->p[0];
+  }
+  (void) NC_2D(zs, (float) (1. / (1000. * 9.80665)), "z", "Z");
+  (void) NC_2D(ts, 1.0f, "t2m", "T2M", "2t", "2T", "t2", "T2");
+  (void) NC_2D(us, 1.0f, "u10m", "U10M", "10u", "10U", "u10", "U10");
+  (void) NC_2D(vs, 1.0f, "v10m", "V10M", "10v", "10V", "v10", "V10");
+  (void) NC_2D(ess, 1.0f, "iews", "IEWS");
+  (void) NC_2D(nss, 1.0f, "inss", "INSS");
+  (void) NC_2D(shf, 1.0f, "ishf", "ISHF");
+  (void) NC_2D(lsm, 1.0f, "lsm", "LSM");
+  (void) NC_2D(sst, 1.0f, "sstk", "SSTK", "sst", "SST");
+  int have_pbl = 0;
+  if (ctl->met_pbl == 0)
+    have_pbl = NC_2D(pbl, 0.01f, "blp", "BLP");
+  int have_cape = 0;
+  if (ctl->met_cape == 0)
+    have_cape = NC_2D(cape, 1.0f, "cape", "CAPE") && NC_2D(cin, 1.0f, "cin", "CIN");
+
+  /* level fields */
+  if (!NC_3D(t, 1.0f, "t", "T", "temp", "TEMP"))
+    ERRMSG("Cannot read temperature!");
+  if (!NC_3D(u, 1.0f, "u", "U"))
+    ERRMSG("Cannot read zonal wind!");
+  if (!NC_3D(v, 1.0f, "v", "V"))
+    ERRMSG("Cannot read meridional wind!");
+  if (!NC_3D(w, 0.01f, "w", "W", "omega", "OMEGA"))
+    WARN("Cannot read vertical velocity!");
+  if (!NC_3D(h2o, (float) (MA / 18.01528), "q", "Q", "sh", "SH"))
+    WARN("Cannot read specific humidity!");
+  if (!NC_3D(o3, (float) (MA / 47.997), "o3", "O3"))
+    WARN("Cannot read ozone data!");
+  const int have_cloud = NC_3D(lwc, 1.0f, "clwc", "CLWC") & NC_3D(rwc, 1.0f, "crwc", "CRWC")
+    & NC_3D(iwc, 1.0f, "ciwc", "CIWC") & NC_3D(swc, 1.0f, "cswc", "CSWC");
+  (void) NC_3D(cc, 1.0f, "cc", "CC");
+  ncc_close(nc);
+  for (int ip = 1; ip < met->np; ip++)
+    if (met->p[ip - 1] < met->p[ip])
+      ERRMSG("Pressure levels must be descending!");
+
+  /* read_met_extrapolate */
+  for (int ix = 0; ix < met->nx; ix++)
+    for (int iy = 0; iy < met->ny; iy++) {
+      int ip0;
+      for (ip0 = met->np - 1; ip0 >= 0; ip0--)
+        if (!isfinite(met->t[ix][iy][ip0]) || !isfinite(met->u[ix][iy][ip0]) || !isfinite(met->v[ix][iy][ip0])
+            || !isfinite(met->w[ix][iy][ip0]))
+          break;
+      for (int ip = ip0; ip >= 0; ip--) {
+        float (*f3[11])[EY][EP] = { met->t, met->u, met->v, met->w, met->h2o, met->o3, met->lwc, met->rwc, met->iwc,
+          met->swc, met->cc };
+        for (int k = 0; k < 11; k++)
+          f3[k][ix][iy][ip] = ip + 1 < EP ? f3[k][ix][iy][ip + 1] : 0.f;
+      }
+    }
+
+  /* Fields the reference derives in its preprocessing.  The boundary-layer pressure enters module_diff_turb
+   * only through weights that multiply TURB_DX_PBL / TURB_DZ_PBL against TURB_DX_TROP / TURB_DZ_TROP: with
+   * equal values (the defaults) and none of the other consumers active any finite value below the
+   * tropopause gives the reference's result, and surface pressure - 100 hPa is used.  Everything else that
+   * would need a derived field is refused. */
+  if (!have_pbl) {
+    if (ctl->turb_dx_pbl != ctl->turb_dx_trop || ctl->turb_dz_pbl != ctl->turb_dz_trop || ctl->conv_mix_pbl
+        || ctl->turb_pbl_scheme != 0 || ctl->bound_pbl || ctl->qnt_pbl >= 0)
+      ERRMSG("This configuration uses the boundary-layer pressure, which the reference derives in its meteo "
+             "preprocessing (not provided): supply it in the file (MET_PBL 0, variable blp) or use MET_TYPE 1 files!");
+    for (int ix = 0; ix < met->nx; ix++)
+      for (int iy = 0; iy < met->ny; iy++)
+        met->pbl[ix][iy] = met->ps[ix][iy] - 100.f;
+  }
+  (void) have_cloud;
+  if (ctl->conv_cape >= 0)
+    ERRMSG("CONV_CAPE needs the equilibrium level from the reference's meteo preprocessing (not provided)!");
+  if (ctl->wet_depo_ic_a > 0 || ctl->wet_depo_ic_h[0] > 0)
+    ERRMSG("Wet deposition needs the cloud diagnostics (pct, pcb, cl) of the reference's meteo preprocessing (not provided)!");
+  static const char *const derived[] = { "pt", "tt", "zt", "h2ot", "zg", "pv", "pct", "pcb", "cl", "plcl", "plfc", "pel",
+    "cape", "cin", "o3c", NULL };
+  for (int iq = 0; iq < ctl->nq; iq++)
+    for (int k = 0; derived[k]; k++)
+      if (strcasecmp(ctl->qnt_name[iq], derived[k]) == 0 && !(have_cape && (k == 12 || k == 13)))
+        ERRMSG("Quantity %s comes from the reference's meteo preprocessing, which netCDF input does not get here!",
+               ctl->qnt_name[iq]);
+  return 1;
+}
+
 static void get_met_filename(const ctl_t *ctl, const double t, const int direct, char *filename) {
   /* <metbase>_YYYY_MM_DD_HH.bin on the DT_MET raster (mptrac.c:2620-2700) */
   double t6, r;
@@ -741,7 +954,7 @@ static void get_met_filename(const ctl_t *ctl, const double t, const int direct,
   else
     t6 = ceil(t / ctl->dt_met) * ctl->dt_met;
   jsec2time(t6, &year, &mon, &day, &hour, &min, &sec, &r);
-  sprintf(filename, "%s_%d_%02d_%02d_%02d.bin", ctl->metbase, year, mon, day, hour);
+  sprintf(filename, "%s_%d_%02d_%02d_%02d.%s", ctl->metbase, year, mon, day, hour, ctl->met_type == 0 ? "nc" : "bin");
 }
 
 /* -------------------------------------------------------------------------- */
@@ -900,29 +1113,23 @@ static void upload_met(met_t *met, int slot) {
   HIP(mphip_update_met(g_ctx, slot, &m));
 }
 
-/* Read-ahead of the next meteo file (HIP_MET_PREFETCH 1, forward runs): while
- * the time steps of the current interval run, a reader thread loads the file
- * after met1 into a third met_t and starts its upload on the back end's copy
- * stream (mphip_prefetch_met); at the hand-over mptrac_get_met rotates the
- * three host pointers and commits instead of reading and uploading on the
- * stepping path.  Costs one more met_t of host memory, hence off by default. */
+/* Read-ahead of the next meteo file (HIP_MET_PREFETCH 1, forward runs): while the time steps of the current
+ * interval run, a reader thread loads the file after met1 into a third met_t.  The thread touches nothing but
+ * that buffer; the stepping thread notices that the file has arrived (poll_read_ahead, called once per time
+ * step), starts its upload on the back end's copy stream (mphip_prefetch_met) and, at the hand-over,
+ * mptrac_get_met rotates the three host pointers and commits instead of reading and uploading on the stepping
+ * path -- so every call into the back end comes from one thread.  Costs one more met_t of host memory, hence
+ * off by default. */
 
 static void *read_ahead_main(void *arg) {
   (void) arg;
-  g_ahead.ok = 0;
   FILE *probe = fopen(g_ahead.filename, "r");   /* past the last file of the run: nothing to do */
-  if (!probe)
-    return NULL;
-  fclose(probe);
-  if (!mptrac_read_met(g_ahead.filename, g_ahead.ctl, g_ahead.clim, g_ahead.met, NULL))
-    return NULL;
-  mphip_met_t m;
-  describe_met(g_ahead.met, &m);
-  if (mphip_prefetch_met(g_ctx, &m) != 0) {
-    WARN("Meteo read-ahead: %s", mphip_last_error(g_ctx));
-    return NULL;
+  if (probe) {
+    fclose(probe);
+    if (mptrac_read_met(g_ahead.filename, g_ahead.ctl, g_ahead.clim, g_ahead.met, NULL))
+      g_ahead.file_ok = 1;
   }
-  g_ahead.ok = 1;
+  __atomic_store_n(&g_ahead.done, 1, __ATOMIC_RELEASE);
   return NULL;
 }
 
@@ -933,16 +1140,36 @@ static void start_read_ahead(ctl_t *ctl, clim_t *clim, const met_t *met1) {
     ALLOC(g_ahead.met, met_t, 1);
   g_ahead.ctl = ctl;
   g_ahead.clim = clim;
+  g_ahead.file_ok = g_ahead.ok = 0;
+  g_ahead.done = 0;
   get_met_filename(ctl, met1->time + 1, 1, g_ahead.filename);
   if (pthread_create(&g_ahead.thread, NULL, read_ahead_main, NULL) == 0)
     g_ahead.active = 1;
 }
 
+/* the reader has finished: join it and hand the snapshot to the back end's copy stream (stepping thread) */
+static void poll_read_ahead(int wait) {
+  if (!g_ahead.active || g_ahead.joined)
+    return;
+  if (!wait && !__atomic_load_n(&g_ahead.done, __ATOMIC_ACQUIRE))
+    return;
+  pthread_join(g_ahead.thread, NULL);
+  g_ahead.joined = 1;
+  if (g_ahead.file_ok) {
+    mphip_met_t m;
+    describe_met(g_ahead.met, &m);
+    if (mphip_prefetch_met(g_ctx, &m) != 0) {
+      WARN("Meteo read-ahead: %s", mphip_last_error(g_ctx));
+    } else
+      g_ahead.ok = 1;
+  }
+}
+
 static void cancel_read_ahead(void) {
   if (!g_ahead.active)
     return;
-  pthread_join(g_ahead.thread, NULL);
-  g_ahead.active = 0;
+  poll_read_ahead(1);
+  g_ahead.active = g_ahead.joined = 0;
   if (g_ahead.ok)
     HIP(mphip_discard_prefetch(g_ctx));
 }
@@ -951,8 +1178,8 @@ static void cancel_read_ahead(void) {
 static int take_read_ahead(const char *filename, met_t **met0, met_t **met1) {
   if (!g_ahead.active)
     return 0;
-  pthread_join(g_ahead.thread, NULL);
-  g_ahead.active = 0;
+  poll_read_ahead(1);
+  g_ahead.active = g_ahead.joined = 0;
   if (!g_ahead.ok)
     return 0;
   if (strcmp(filename, g_ahead.filename) != 0) {   /* not the file this hand-over needs */
@@ -991,7 +1218,8 @@ void mptrac_update_device(const ctl_t *ctl, const cache_t *cache, const clim_t *
     const double *q[MPHIP_NQ_MAX] = { 0 };
     for (int iq = 0; iq < g_nq; iq++)
       q[iq] = atm->q[iq];
-    HIP(mphip_update_atm(g_ctx, atm->np, 0, atm->np, g_nq, atm->time, atm->p, atm->lon, atm->lat, q));
+    HIP(mphip_update_atm(g_ctx, atm->np, g_ip0, g_np_total >= 0 ? g_np_total : atm->np, g_nq, atm->time, atm->p,
+                         atm->lon, atm->lat, q));
   }
   if (cache != NULL) {
     HIP(mphip_update_cache(g_ctx, &cache->uvwp[0][0], NULL));
@@ -1030,30 +1258,22 @@ void mptrac_update_host(const ctl_t *ctl, const cache_t *cache, const clim_t *cl
 /* init / meteo handling / time step                                          */
 /* -------------------------------------------------------------------------- */
 
+/* Start and stop time of a run (reference interface: src/mptrac.h module_timesteps_init): the run starts at
+ * the first release time in the direction of travel, rounded outwards to the DT_MOD raster, and -- unless
+ * T_STOP was given -- ends at the last one. */
 void module_timesteps_init(ctl_t *ctl, const atm_t *atm) {
-  /* host bookkeeping of mptrac.c:6046-6073 (gsl_stats_min/max -> loops) */
-  double tmin = atm->time[0], tmax = atm->time[0];
+  double first = atm->time[0], last = atm->time[0];
   for (int ip = 1; ip < atm->np; ip++) {
-    if (atm->time[ip] < tmin)
-      tmin = atm->time[ip];
-    if (atm->time[ip] > tmax)
-      tmax = atm->time[ip];
+    first = fmin(first, atm->time[ip]);
+    last = fmax(last, atm->time[ip]);
   }
-  if (ctl->direction == 1) {
-    ctl->t_start = tmin;
-    if (ctl->t_stop > 1e99)
-      ctl->t_stop = tmax;
-  } else {
-    ctl->t_start = tmax;
-    if (ctl->t_stop > 1e99)
-      ctl->t_stop = tmin;
-  }
-  if (ctl->direction * (ctl->t_stop - ctl->t_start) <= 0)
+  const int forward = ctl->direction == 1;
+  const double begin = forward ? first : last, end = forward ? last : first;
+  if (ctl->t_stop > 1e99)   /* not set in the control file */
+    ctl->t_stop = end;
+  if (ctl->direction * (ctl->t_stop - begin) <= 0)
     ERRMSG("Nothing to do! Check T_STOP and DIRECTION!");
-  if (ctl->direction == 1)
-    ctl->t_start = floor(ctl->t_start / ctl->dt_mod) * ctl->dt_mod;
-  else
-    ctl->t_start = ceil(ctl->t_start / ctl->dt_mod) * ctl->dt_mod;
+  ctl->t_start = (forward ? floor(begin / ctl->dt_mod) : ceil(begin / ctl->dt_mod)) * ctl->dt_mod;
 }
 
 void mptrac_init(ctl_t *ctl, cache_t *cache, clim_t *clim, atm_t *atm, depo_t *depo, const int ntask) {
@@ -1064,62 +1284,74 @@ void mptrac_init(ctl_t *ctl, cache_t *cache, clim_t *clim, atm_t *atm, depo_t *d
   mptrac_update_device(ctl, cache, clim, NULL, NULL, atm);
 }
 
-void mptrac_get_met(ctl_t *ctl, clim_t *clim, const double t, met_t **met0, met_t **met1, dd_t *dd) {
-  /* double-buffer logic of mptrac.c:6438-6559 */
-  static int init;
+/* one snapshot of the DT_MET raster: the file at or before (side = -1) / at or after (side = +1) time t */
+static void load_snapshot(ctl_t *ctl, clim_t *clim, const double t, const int side, met_t *met, dd_t *dd) {
   char filename[LEN];
-  met_t *mets;
+  get_met_filename(ctl, t, side, filename);
+  if (!mptrac_read_met(filename, ctl, clim, met, dd))
+    ERRMSG("Cannot open file!");
+}
 
-  if (t == ctl->t_start || !init) {
-    init = 1;
+static void swap_snapshots(met_t **a, met_t **b) {
+  met_t *tmp = *a;
+  *a = *b;
+  *b = tmp;
+}
+
+/* both snapshots must describe the same grid (axes to 1e-3) */
+static void check_same_grid(const met_t *a, const met_t *b) {
+  if (a->coord_type != b->coord_type)
+    ERRMSG("Coordinate types do not match!");
+  if (a->nx == 0 || b->nx == 0)
+    return;
+  if (a->nx != b->nx || a->ny != b->ny || a->np != b->np)
+    ERRMSG("Meteo grid dimensions do not match!");
+  const struct {
+    const double *x, *y;
+    int n;
+    const char *what;
+  } axes[3] = { { a->lon, b->lon, a->nx, "longitudes" }, { a->lat, b->lat, a->ny, "latitudes" },
+    { a->p, b->p, a->np, "pressure levels" } };
+  for (int k = 0; k < 3; k++)
+    for (int i = 0; i < axes[k].n; i++)
+      if (fabs(axes[k].x[i] - axes[k].y[i]) > 0.001)
+        ERRMSG("Meteo grid %s do not match!", axes[k].what);
+}
+
+/* Keeps met0 / met1 bracketing the model time (reference interface: src/mptrac.h mptrac_get_met): at the start
+ * of a run both snapshots are read -- met0 at or before, met1 at or after t on the DT_MET raster, with the
+ * start time itself belonging to the interval the run moves into --; when t leaves the interval the snapshot
+ * left behind is replaced by the next file in that direction and the two pointers trade places, so that the
+ * caller (and the device, which follows the pointers) never re-reads the snapshot that stays. */
+void mptrac_get_met(ctl_t *ctl, clim_t *clim, const double t, met_t **met0, met_t **met1, dd_t *dd) {
+  static int primed;
+  const int forward = ctl->direction == 1;
+  if (!primed || t == ctl->t_start) {
+    primed = 1;
     cancel_read_ahead();
-    get_met_filename(ctl, t + (ctl->direction == -1 ? -1 : 0), -1, filename);
-    if (!mptrac_read_met(filename, ctl, clim, *met0, dd))
-      ERRMSG("Cannot open file!");
-    get_met_filename(ctl, t + (ctl->direction == 1 ? 1 : 0), 1, filename);
-    if (!mptrac_read_met(filename, ctl, clim, *met1, dd))
-      ERRMSG("Cannot open file!");
+    load_snapshot(ctl, clim, forward ? t : t - 1, -1, *met0, dd);
+    load_snapshot(ctl, clim, forward ? t + 1 : t, +1, *met1, dd);
     mptrac_update_device(NULL, NULL, NULL, met0, met1, NULL);
     start_read_ahead(ctl, clim, *met1);
   }
-  if (t > (*met1)->time) {
-    get_met_filename(ctl, t, 1, filename);
+  if (t > (*met1)->time) {          /* moved past the later snapshot */
+    char filename[LEN];
+    get_met_filename(ctl, t, +1, filename);
     if (!take_read_ahead(filename, met0, met1)) {
-      mets = *met1;
-      *met1 = *met0;
-      *met0 = mets;
-      if (!mptrac_read_met(filename, ctl, clim, *met1, dd))
-        ERRMSG("Cannot open file!");
-      map_met_slot(*met0, 0);   /* device slots follow the pointer swap */
+      swap_snapshots(met0, met1);
+      load_snapshot(ctl, clim, t, +1, *met1, dd);
+      map_met_slot(*met0, 0);       /* the device slots follow the pointers */
       mptrac_update_device(NULL, NULL, NULL, NULL, met1, NULL);
     }
     start_read_ahead(ctl, clim, *met1);
   }
-  if (t < (*met0)->time) {
-    mets = *met1;
-    *met1 = *met0;
-    *met0 = mets;
-    get_met_filename(ctl, t, -1, filename);
-    if (!mptrac_read_met(filename, ctl, clim, *met0, dd))
-      ERRMSG("Cannot open file!");
+  if (t < (*met0)->time) {          /* moved before the earlier one (backward runs) */
+    swap_snapshots(met0, met1);
+    load_snapshot(ctl, clim, t, -1, *met0, dd);
     map_met_slot(*met1, 1);
     mptrac_update_device(NULL, NULL, NULL, met0, NULL, NULL);
   }
-  if ((*met0)->coord_type != (*met1)->coord_type)
-    ERRMSG("Coordinate types do not match!");
-  if ((*met0)->nx != 0 && (*met1)->nx != 0) {
-    if ((*met0)->nx != (*met1)->nx || (*met0)->ny != (*met1)->ny || (*met0)->np != (*met1)->np)
-      ERRMSG("Meteo grid dimensions do not match!");
-    for (int ix = 0; ix < (*met0)->nx; ix++)
-      if (fabs((*met0)->lon[ix] - (*met1)->lon[ix]) > 0.001)
-        ERRMSG("Meteo grid longitudes do not match!");
-    for (int iy = 0; iy < (*met0)->ny; iy++)
-      if (fabs((*met0)->lat[iy] - (*met1)->lat[iy]) > 0.001)
-        ERRMSG("Meteo grid latitudes do not match!");
-    for (int ip = 0; ip < (*met0)->np; ip++)
-      if (fabs((*met0)->p[ip] - (*met1)->p[ip]) > 0.001)
-        ERRMSG("Meteo grid pressure levels do not match!");
-  }
+  check_same_grid(*met0, *met1);
 }
 
 void mptrac_run_timestep(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t **met0, met_t **met1, atm_t *atm,
@@ -1133,6 +1365,7 @@ void mptrac_run_timestep(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t **met0,
   need_ctx(ctl);
   map_met_slot(*met0, 0);
   map_met_slot(*met1, 1);
+  poll_read_ahead(0);   /* a meteo file that has arrived starts its upload beside this and the following steps */
   /* module_isosurf_init, ISOSURF 4: read the balloon pressure time series (mptrac.c:4925-4951);
    * modes 1-3 are evaluated on the device */
   if (t == ctl->t_start && ctl->isosurf == 4) {
@@ -1236,7 +1469,13 @@ void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1
   ALLOC(np, int, ncell);
   ALLOC(mean, double, ncell * (size_t) (ctl->nq > 0 ? ctl->nq : 1));
   ALLOC(sigma, double, ncell * (size_t) (ctl->nq > 0 ? ctl->nq : 1));
-  HIP(mphip_grid_sums(g_ctx, t, np, mean, sigma));
+  HIP(mphip_grid_sums(g_ctx, t, np, mean, sigma));   /* summed over the ranks of the job */
+  if (g_rank != 0) {                                  /* rank 0 writes the file */
+    free(np);
+    free(mean);
+    free(sigma);
+    return;
+  }
 
   const double dz = (ctl->grid_z1 - ctl->grid_z0) / ctl->grid_nz;
   const double dlon = (ctl->grid_lon1 - ctl->grid_lon0) / ctl->grid_nx;
@@ -1316,6 +1555,8 @@ void mptrac_write_output(const char *dirname, const ctl_t *ctl, met_t *met0, met
     sprintf(ext, ctl->atm_type_out == 0 ? "tab" : "bin");
     sprintf(filename, "%s/%s_%04d_%02d_%02d_%02d_%02d_%02d.%s", dirname, ctl->atm_basename, year, mon, day,
             hour, min, sec, ext);
+    if (g_world > 1)   /* every rank writes its index range: <name>.rank<k> */
+      sprintf(filename + strlen(filename), ".rank%d", g_rank);
     mptrac_write_atm(filename, ctl, atm, t);
   }
   if (ctl->grid_basename[0] != '-' && fmod(t, ctl->grid_dt_out) == 0) {
@@ -1323,4 +1564,57 @@ void mptrac_write_output(const char *dirname, const ctl_t *ctl, met_t *met0, met
             hour, min, sec);
     write_grid(filename, ctl, met0, met1, atm, t);
   }
+}
+
+/* -------------------------------------------------------------------------- */
+/* one process per GPU                                                        */
+/* -------------------------------------------------------------------------- */
+
+void mptrac_amd_job_from_env(mptrac_amd_job_t *job) {
+  const char *e;
+  memset(job, 0, sizeof(*job));
+  job->world = 1;
+  if ((e = getenv("WORLD_SIZE")))
+    job->world = atoi(e) > 0 ? atoi(e) : 1;
+  if ((e = getenv("RANK")))
+    job->rank = atoi(e);
+  job->local_rank = job->rank;
+  if ((e = getenv("LOCAL_RANK")))
+    job->local_rank = atoi(e);
+  snprintf(job->addr, sizeof(job->addr), "%s", (e = getenv("MASTER_ADDR")) ? e : "127.0.0.1");
+  job->port = ((e = getenv("MASTER_PORT")) ? atoi(e) : 29511) + 1;
+  if (job->rank < 0 || job->rank >= job->world)
+    ERRMSG("RANK / WORLD_SIZE of the environment do not fit!");
+}
+
+void mptrac_amd_shard(atm_t *atm, const mptrac_amd_job_t *job) {
+  g_rank = job->rank;
+  g_world = job->world;
+  if (job->world <= 1)
+    return;
+  const long long n = atm->np, lo = n * job->rank / job->world, hi = n * (job->rank + 1) / job->world;
+  const size_t bytes = (size_t) (hi - lo) * sizeof(double);
+  memmove(atm->time, atm->time + lo, bytes);
+  memmove(atm->p, atm->p + lo, bytes);
+  memmove(atm->lon, atm->lon + lo, bytes);
+  memmove(atm->lat, atm->lat + lo, bytes);
+  for (int iq = 0; iq < NQ; iq++)
+    memmove(atm->q[iq], atm->q[iq] + lo, bytes);
+  atm->np = (int) (hi - lo);
+  g_ip0 = lo;
+  g_np_total = n;
+  LOG(1, "Rank %d of %d: particles %lld ... %lld of %lld", job->rank, job->world, lo, hi - 1, n);
+}
+
+void mptrac_amd_comm_init(const ctl_t *ctl, const mptrac_amd_job_t *job) {
+  if (job->world <= 1)
+    return;
+  need_ctx(ctl);
+  char id[128];
+  memset(id, 0, sizeof(id));
+  if (job->rank == 0 && mphip_comm_unique_id(id) != 0)
+    ERRMSG("Cannot create the RCCL identifier (is librccl.so available?)");
+  if (!mptrac_amd_bcast(id, sizeof(id), job->rank, job->world, job->addr, job->port))
+    ERRMSG("Rendezvous of the ranks at %s:%d failed!", job->addr, job->port);
+  HIP(mphip_comm_init(g_ctx, job->world, job->rank, id));
 }

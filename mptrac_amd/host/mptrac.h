@@ -121,6 +121,7 @@ typedef struct {
 #undef X
   /* time and meteo input */
   int direction, met_coord_type, met_type;
+  int met_nc_scale, met_pbl, met_cape;   /* netCDF input (MET_TYPE 0): packed data, source of pbl / cape */
   double t_start, t_stop, dt_mod, dt_met, met_utm_ref_lat, met_dt_out;
   char metbase[LEN];
   /* modules */
@@ -154,6 +155,7 @@ typedef struct {
   double grid_z0, grid_z1, grid_lon0, grid_lon1, grid_lat0, grid_lat1;
   int grid_nx, grid_ny, grid_nz;
   double molmass;
+  char species[LEN];
   /* back-end options (no reference counterpart) */
   int hip_device;
   int hip_locality_interval;
@@ -257,6 +259,23 @@ void clim_tropo_init(clim_t *clim);                                             
 void module_timesteps_init(ctl_t *ctl, const atm_t *atm);                       /* mptrac.c:6046 */
 void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1, const atm_t *atm,
                 const double t);                                                /* mptrac.c:13751 */
+
+/* ---- one process per GPU (no reference counterpart) -------------------------- */
+/* The reference's driver binds MPI ranks to devices and gives every rank its own work directories
+ * (src/trac.c:70-98).  Here the ranks of a job share ONE simulation: every rank keeps an index range of the
+ * particles, the meteo data are replicated, and the gridded sums (module_mixing, write_grid) are all-reduced
+ * by RCCL inside the back end.  Rank and world size come from the launcher's environment (RANK, WORLD_SIZE,
+ * LOCAL_RANK, MASTER_ADDR, MASTER_PORT). */
+typedef struct {
+  int rank, world, local_rank, port;
+  char addr[64];
+} mptrac_amd_job_t;
+void mptrac_amd_job_from_env(mptrac_amd_job_t *job);
+/* keep particles [np * rank / world, np * (rank + 1) / world) of a freshly read atm_t; uploads announce the range */
+void mptrac_amd_shard(atm_t *atm, const mptrac_amd_job_t *job);
+/* RCCL communicator of the job (collective; after mptrac_init) */
+void mptrac_amd_comm_init(const ctl_t *ctl, const mptrac_amd_job_t *job);
+int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr, int port);
 
 #ifdef __cplusplus
 }

@@ -6,9 +6,14 @@
  *
  *   trac <dirlist> <ctl> <atm_in> [KEY VALUE ...]
  *
- * One process drives one GPU (control key HIP_DEVICE).  The reference's MPI
- * farm over work directories (trac.c:70-98) is not reproduced: directories
- * are processed one after the other.
+ * One process drives one GPU.  Started once, it uses the device of the control key HIP_DEVICE.  Started
+ * N times by a launcher that exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+ * (e.g. `python -m torch.distributed.run --nproc-per-node N --no-python trac ...`), the N processes share
+ * every simulation: rank k binds to device LOCAL_RANK (the reference binds MPI ranks to devices the same way,
+ * src/trac.c:70-81), keeps the k-th index range of the particles, reads the same meteo files, and the gridded
+ * sums of module_mixing and of the gridded output are all-reduced by RCCL inside the back end.  Rank 0 writes
+ * the gridded output; particle files are written per rank (<name>.rank<k>).  The reference's farm over work
+ * directories (trac.c:83-98) is not reproduced: directories are processed one after the other.
  */
 #include "mptrac.h"
 
@@ -37,6 +42,8 @@ int main(int argc, char *argv[]) {
   }
   if (!(dirlist = fopen(argv[1], "r")))
     ERRMSG("Cannot open directory list!");
+  mptrac_amd_job_t job;
+  mptrac_amd_job_from_env(&job);
 
   while (fscanf(dirlist, "%4999s", dirname) != EOF) {
 
@@ -48,7 +55,12 @@ int main(int argc, char *argv[]) {
     sprintf(filename, "%s/%s", dirname, argv[3]);
     if (!mptrac_read_atm(filename, ctl, atm))
       ERRMSG("Cannot open file!");
+    if (job.world > 1) {
+      ctl->hip_device = job.local_rank;
+      mptrac_amd_shard(atm, &job);
+    }
     mptrac_init(ctl, cache, clim, atm, depo, 0);
+    mptrac_amd_comm_init(ctl, &job);
 
     /* ---- loop over time steps (trac.c:131-163) ---- */
     const double w0 = wall();
@@ -69,7 +81,7 @@ int main(int argc, char *argv[]) {
 
     /* ---- report (trac.c:172-188) ---- */
     LOG(1, "SIZE_NP = %d", atm->np);
-    LOG(1, "SIZE_TASKS = %d", 1);
+    LOG(1, "SIZE_TASKS = %d", job.world);
     LOG(1, "MEMORY_ATM = %g MByte", sizeof(atm_t) / 1024. / 1024.);
     LOG(1, "MEMORY_CACHE = %g MByte", sizeof(cache_t) / 1024. / 1024.);
     LOG(1, "MEMORY_METEO = %g MByte", 2 * sizeof(met_t) / 1024. / 1024.);

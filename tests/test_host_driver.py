@@ -185,6 +185,38 @@ def test_trac_writes_the_reference_coord_test_files_byte_for_byte(tmp_path):
                 name, len(bad) + abs(len(gl) - len(rl)), len(rl), gl[bad[0]] if bad else None, rl[bad[0]] if bad else None))
 
 
+@pytest.mark.gpu
+def test_trac_runs_the_reference_coord_test_command_line_on_its_netcdf_files(tmp_path):
+    """tests/coord_test/run.sh of the reference as it stands: control file, command line (MET_TYPE left at its
+    default 0 = netCDF) and the three classic-netCDF meteo files -- read by the host layer's own reader, no
+    conversion step -- give the thirteen golden particle files byte for byte."""
+    import shutil
+    import ref_coord as R
+    tmp = str(tmp_path)
+    _, trac = build.build_host()
+    shutil.copy(os.path.join(R.HERE, R.OUTPUTS[0]), os.path.join(tmp, "atm_split.tab"))
+    keys = {"NQ": 4, "QNT_NAME[0]": "t", "QNT_NAME[1]": "u", "QNT_NAME[2]": "v", "QNT_NAME[3]": "w",
+            "METBASE": os.path.join(R.HERE, "era5_utm32"), "TRACER_CHEM": 0, "DIFFUSION": 1, "DT_MET": 3600.0,
+            "T_STOP": R.T0 + 7200.0}
+    hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
+    open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
+    r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_split.tab", "ATM_BASENAME", "atm",
+                        "MET_CAPE", "0", "DT_MOD", "600", "ATM_DT_OUT", "600", "MET_COORD_TYPE", "1",
+                        "MET_UTM_REF_LON", "11.5692782", "MET_UTM_REF_LAT", "48.1507476"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert "era5_utm32_2025_05_01_01.nc" in out
+    for name in R.OUTPUTS.values():
+        got = open(os.path.join(tmp, name)).read()
+        ref = open(os.path.join(R.HERE, name)).read()
+        if got != ref:
+            gl, rl = got.splitlines(), ref.splitlines()
+            bad = [i for i in range(min(len(gl), len(rl))) if gl[i] != rl[i]]
+            raise AssertionError("%s: %d of %d lines differ, first: %r vs %r" % (
+                name, len(bad) + abs(len(gl) - len(rl)), len(rl), gl[bad[0]] if bad else None, rl[bad[0]] if bad else None))
+
+
 def _atm_test_run(tmp, extra_args=()):
     """`trac` on the particle file of the reference's tests/atm_test (10000 parcels: aoa, m, vmr); the outputs at t = 0 are written
     after the first call of the time step, which moves nothing (dt = 0)."""

@@ -214,3 +214,140 @@ def test_host_layer_calendar_functions_match_the_reference_time_table():
                     assert got == lines[k], (got, lines[k])
                     k += 2
     assert k == len(lines) == 270
+
+
+# ---------------------------------------------------------------------------
+# host layer: control files, classic netCDF, rendezvous (no GPU: the library is only loaded)
+# ---------------------------------------------------------------------------
+
+def _host_lib():
+    import ctypes as C
+    from mptrac_amd import build
+    lib, _ = build.build_host()
+    return C.CDLL(lib)
+
+
+def test_control_file_lookup_rules(tmp_path):
+    """scan_ctl: "NAME = VALUE" lines, first match wins, case-insensitive, NAME[i] / NAME[*], command-line pairs
+    override the file, '-' means arguments only, defaults for missing keys."""
+    import ctypes as C
+    L = _host_lib()
+    L.scan_ctl.restype = C.c_double
+    L.scan_ctl.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_int, C.c_char_p, C.c_char_p]
+    path = str(tmp_path / "trac.ctl")
+    open(path, "w").write("# comment line\nDT_MOD = 240\ndt_mod = 999\nQNT_NAME[*] = any\nQNT_NAME[1] = rp\n"
+                          "TWO_TOKENS 5\nT_STOP =   3600   trailing words\n")
+    args = [b"trac", b"dirlist", b"trac.ctl", b"atm.tab", b"T_STOP", b"7200", b"ATM_BASENAME", b"atm"]
+    argv = (C.c_char_p * len(args))(*args)
+
+    def scan(name, idx=-1, default=b"", filename=path.encode()):
+        buf = C.create_string_buffer(5000)
+        v = L.scan_ctl(filename, len(args), argv, name, idx, default, buf)
+        return v, buf.value.decode()
+    assert scan(b"DT_MOD") == (240.0, "240")                     # first match in the file
+    assert scan(b"T_STOP") == (7200.0, "7200")                   # the command line overrides the file
+    assert scan(b"QNT_NAME", 1)[1] == "any"                      # NAME[*] comes first in the file
+    assert scan(b"QNT_NAME", 0)[1] == "any"
+    assert scan(b"TWO_TOKENS", default=b"7") == (7.0, "7")       # a setting needs name, separator and value
+    assert scan(b"ADVECT", default=b"2") == (2.0, "2")
+    assert scan(b"atm_basename")[1] == "atm"                     # names are case-insensitive
+    assert scan(b"DT_MOD", default=b"180", filename=b"-") == (180.0, "180")   # '-': arguments only
+
+
+def test_species_presets_and_rejected_keys(tmp_path):
+    """SPECIES sets the defaults of MOLMASS and the Henry constants (mptrac.c:7291-7383); a species that implies
+    the OH chemistry, and switches this build does not implement, stop the run instead of being ignored."""
+    import subprocess
+    from mptrac_amd import build
+    import hostfiles as hf
+    _, trac = build.build_host()
+    tmp = str(tmp_path)
+    open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
+    open(os.path.join(tmp, "atm.tab"), "w").write("0 10 0 0 1\n")
+
+    def run(keys):
+        hf.write_ctl(os.path.join(tmp, "trac.ctl"), dict({"NQ": 1, "QNT_NAME[0]": "m", "MET_TYPE": 1}, **keys))
+        r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm.tab"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT)
+        return r.returncode, r.stdout.decode()
+    rc, out = run({"SPECIES": "SO2"})
+    assert rc != 0 and "OH chemistry" in out and "MOLMASS = 64.066" in out
+    rc, out = run({"SPECIES": "SO2", "OH_CHEM_REACTION": 0, "METBASE": os.path.join(tmp, "nothing")})
+    assert "WET_DEPO_IC_H[0] = 0.013" in out and "WET_DEPO_IC_H[1] = 2900" in out and "WET_DEPO_BC_H[0] = 0.013" in out
+    assert "OH chemistry" not in out                       # (stops later: no device / no meteo files here)
+    rc, out = run({"SPECIES": "CO2", "MOLMASS": 44.5, "METBASE": os.path.join(tmp, "nothing")})
+    assert "MOLMASS = 44.5" in out and "WET_DEPO_IC_H[1] = 2400" in out
+    for key in ("RADIO_DEPO", "RADIO_DECAY", "KPP_CHEM", "H2O2_CHEM_REACTION"):
+        rc, out = run({key: 1})
+        assert rc != 0 and key in out and "not implemented" in out
+
+
+def test_classic_netcdf_reader_against_scipy():
+    """The host layer's own CDF-1 / CDF-2 reader (no netCDF library in the image) on the three meteo files of
+    the reference's tests/coord_test: axes, dimensions, attributes and every value of t, u, v, w, sp."""
+    import ctypes as C
+    from scipy.io import netcdf_file
+    L = _host_lib()
+    L.ncc_open.restype = C.c_void_p
+    L.ncc_open.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.ncc_close.argtypes = [C.c_void_p]
+    L.ncc_find_var.argtypes = [C.c_void_p, C.c_char_p]
+    L.ncc_var_ndims.argtypes = [C.c_void_p, C.c_int]
+    L.ncc_var_dim.restype = C.c_longlong
+    L.ncc_var_dim.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p)]
+    L.ncc_get_att.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_double)]
+    L.ncc_read_double.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.POINTER(C.c_double)]
+    L.ncc_read_float.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.POINTER(C.c_float)]
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_coord_test")
+    for hour in range(3):
+        path = os.path.join(here, "era5_utm32_2025_05_01_%02d.nc" % hour)
+        err = C.create_string_buffer(256)
+        nc = L.ncc_open(path.encode(), err, 256)
+        assert nc, err.value
+        f = netcdf_file(path, "r", mmap=False)
+        for name in ("x", "y", "plev", "t", "u", "v", "w", "sp"):
+            var, v = f.variables[name], L.ncc_find_var(nc, name.encode())
+            assert v >= 0 and L.ncc_var_ndims(nc, v) == len(var.shape)
+            for d, (dname, dlen) in enumerate(zip(var.dimensions, var.shape)):
+                got = C.c_char_p()
+                assert L.ncc_var_dim(nc, v, d, C.byref(got)) == dlen and got.value.decode() == dname
+            ref = np.array(var[:]).ravel()
+            if var.typecode() == "d":
+                out = np.empty(ref.size)
+                assert L.ncc_read_double(nc, v, 0, 0, ref.size, out.ctypes.data_as(C.POINTER(C.c_double)))
+            else:
+                out = np.empty(ref.size, dtype=np.float32)
+                assert L.ncc_read_float(nc, v, 0, 0, ref.size, out.ctypes.data_as(C.POINTER(C.c_float)))
+            assert np.array_equal(out, ref, equal_nan=True), name
+            fill = getattr(var, "_FillValue", None)
+            if fill is not None:
+                got = C.c_double()
+                assert L.ncc_get_att(nc, v, b"_FillValue", C.byref(got)) and np.float32(got.value) == np.float32(fill)
+        assert L.ncc_find_var(nc, b"no_such_variable") < 0
+        L.ncc_close(nc)
+    bad = os.path.join(here, "atm_2025_05_01_00_00_00.tab")
+    err = C.create_string_buffer(256)
+    assert not L.ncc_open(bad.encode(), err, 256) and b"classic" in err.value
+
+
+def test_rank_rendezvous_hands_the_identifier_to_every_rank():
+    """mptrac_amd_bcast (host/rendezvous.c): rank 0's 128 bytes reach three other processes over TCP on
+    127.0.0.1, whichever side is up first."""
+    import socket
+    import subprocess
+    from mptrac_amd import build
+    lib, _ = build.build_host()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = ("import ctypes as C, sys, time\n"
+              "L = C.CDLL(%r)\nrank, world, port = int(sys.argv[1]), 4, %d\n"
+              "time.sleep(0.4 * (rank == 0))\n"
+              "buf = C.create_string_buffer(bytes((7 * i + 1) %% 256 for i in range(128)) if rank == 0 else bytes(128), 128)\n"
+              "assert L.mptrac_amd_bcast(buf, 128, rank, world, b'127.0.0.1', port) == 1\n"
+              "assert buf.raw == bytes((7 * i + 1) %% 256 for i in range(128)), rank\nprint('ok', rank)\n") % (lib, port)
+    procs = [subprocess.Popen([sys.executable, "-c", worker, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(4)]
+    for r, p in enumerate(procs):
+        out = p.communicate(timeout=120)[0].decode()
+        assert p.returncode == 0 and "ok %d" % r in out, out
