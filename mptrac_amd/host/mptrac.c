@@ -121,6 +121,102 @@ static const char *unsupported_qnt[] = {
   "current_subdomain", "target_subdomain", NULL
 };
 
+/* Scalar control parameters of the hot path: (kind, ctl_t member, key, default) -- defaults as the reference's
+ * control-parameter documentation (docs/manual/control-parameters.md; src/mptrac.c:6974-7648).  D: double,
+ * I: integer, S: text.  Keys whose default depends on other settings are read explicitly in mptrac_read_ctl. */
+#define CTL_SCALARS(D, I, S) \
+  I(met_coord_type, "MET_COORD_TYPE", "0") \
+  I(direction, "DIRECTION", "1") \
+  D(t_stop, "T_STOP", "1e100") \
+  D(dt_mod, "DT_MOD", "180") \
+  S(metbase, "METBASE", "-") \
+  D(dt_met, "DT_MET", "3600") \
+  I(met_type, "MET_TYPE", "0") \
+  D(met_dt_out, "MET_DT_OUT", "0.1") \
+  I(met_nc_scale, "MET_NC_SCALE", "1") \
+  I(met_pbl, "MET_PBL", "3") \
+  I(met_cape, "MET_CAPE", "1") \
+  D(sort_dt, "SORT_DT", "-999") \
+  I(rng_type, "RNG_TYPE", "1") \
+  I(advect, "ADVECT", "2") \
+  I(advect_vert_coord, "ADVECT_VERT_COORD", "0") \
+  I(diffusion, "DIFFUSION", "0") \
+  I(turb_pbl_scheme, "TURB_PBL_SCHEME", "0") \
+  D(turb_dx_pbl, "TURB_DX_PBL", "50") \
+  D(turb_dx_trop, "TURB_DX_TROP", "50") \
+  D(turb_dx_strat, "TURB_DX_STRAT", "0") \
+  D(turb_dz_pbl, "TURB_DZ_PBL", "0") \
+  D(turb_dz_trop, "TURB_DZ_TROP", "0") \
+  D(turb_dz_strat, "TURB_DZ_STRAT", "0.1") \
+  D(turb_mesox, "TURB_MESOX", "0.16") \
+  D(turb_mesoz, "TURB_MESOZ", "0.16") \
+  D(turb_pbl_trans, "TURB_PBL_TRANS", "0") \
+  I(conv_mix_pbl, "CONV_MIX_PBL", "0") \
+  D(conv_pbl_trans, "CONV_PBL_TRANS", "0") \
+  D(conv_cape, "CONV_CAPE", "-999") \
+  D(conv_cin, "CONV_CIN", "-999") \
+  D(conv_dt, "CONV_DT", "-999") \
+  I(isosurf, "ISOSURF", "0") \
+  S(balloon, "BALLOON", "-") \
+  D(bound_mass, "BOUND_MASS", "-999") \
+  D(bound_mass_trend, "BOUND_MASS_TREND", "0") \
+  D(bound_vmr, "BOUND_VMR", "-999") \
+  D(bound_vmr_trend, "BOUND_VMR_TREND", "0") \
+  D(bound_lat0, "BOUND_LAT0", "-999") \
+  D(bound_lat1, "BOUND_LAT1", "-999") \
+  D(bound_p0, "BOUND_P0", "-999") \
+  D(bound_p1, "BOUND_P1", "-999") \
+  D(bound_dps, "BOUND_DPS", "-999") \
+  D(bound_dzs, "BOUND_DZS", "-999") \
+  D(bound_zetas, "BOUND_ZETAS", "-999") \
+  I(bound_pbl, "BOUND_PBL", "0") \
+  D(wet_depo_so2_ph, "WET_DEPO_SO2_PH", "0") \
+  D(wet_depo_ic_a, "WET_DEPO_IC_A", "0") \
+  D(wet_depo_ic_b, "WET_DEPO_IC_B", "0") \
+  D(wet_depo_bc_a, "WET_DEPO_BC_A", "0") \
+  D(wet_depo_bc_b, "WET_DEPO_BC_B", "0") \
+  D(wet_depo_ic_ret_ratio, "WET_DEPO_IC_RET_RATIO", "1") \
+  D(wet_depo_bc_ret_ratio, "WET_DEPO_BC_RET_RATIO", "1") \
+  D(dry_depo_vdep, "DRY_DEPO_VDEP", "0") \
+  D(dry_depo_dp, "DRY_DEPO_DP", "30") \
+  D(mixing_dt, "MIXING_DT", "3600.") \
+  D(mixing_trop, "MIXING_TROP", "-999") \
+  D(mixing_strat, "MIXING_STRAT", "-999") \
+  D(mixing_z0, "MIXING_Z0", "-5") \
+  D(mixing_z1, "MIXING_Z1", "85") \
+  I(mixing_nz, "MIXING_NZ", "90") \
+  D(mixing_lon0, "MIXING_LON0", "-180") \
+  D(mixing_lon1, "MIXING_LON1", "180") \
+  I(mixing_nx, "MIXING_NX", "360") \
+  D(mixing_lat0, "MIXING_LAT0", "-90") \
+  D(mixing_lat1, "MIXING_LAT1", "90") \
+  I(mixing_ny, "MIXING_NY", "180") \
+  D(tdec_trop, "TDEC_TROP", "0") \
+  D(tdec_strat, "TDEC_STRAT", "0") \
+  I(nens, "NENS", "0") \
+  S(atm_basename, "ATM_BASENAME", "-") \
+  D(atm_dt_out, "ATM_DT_OUT", "86400") \
+  I(atm_filter, "ATM_FILTER", "0") \
+  I(atm_stride, "ATM_STRIDE", "1") \
+  I(atm_type, "ATM_TYPE", "0") \
+  I(atm_type_out, "ATM_TYPE_OUT", "-1") \
+  S(grid_basename, "GRID_BASENAME", "-") \
+  D(grid_dt_out, "GRID_DT_OUT", "86400") \
+  I(grid_sparse, "GRID_SPARSE", "0") \
+  I(grid_stddev, "GRID_STDDEV", "0") \
+  D(grid_z0, "GRID_Z0", "-5") \
+  D(grid_z1, "GRID_Z1", "85") \
+  I(grid_nz, "GRID_NZ", "1") \
+  D(grid_lon0, "GRID_LON0", "-180") \
+  D(grid_lon1, "GRID_LON1", "180") \
+  I(grid_nx, "GRID_NX", "360") \
+  D(grid_lat0, "GRID_LAT0", "-90") \
+  D(grid_lat1, "GRID_LAT1", "90") \
+  I(grid_ny, "GRID_NY", "180") \
+  I(hip_device, "HIP_DEVICE", "0") \
+  I(hip_locality_interval, "HIP_LOCALITY_SORT_INTERVAL", "60") \
+  I(hip_met_prefetch, "HIP_MET_PREFETCH", "0")
+
 void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   LOG(1, "\nMassive-Parallel Trajectory Calculations (MPTRAC), MI355X build (%s)\n", mphip_version());
 
@@ -165,22 +261,20 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
 #undef X
   }
 
-  /* coordinates, time steps, meteo input (mptrac.c:6974-7030) */
-  ctl->met_coord_type = (int) scan_ctl(filename, argc, argv, "MET_COORD_TYPE", -1, "0", NULL);
+  /* every scalar key of the table above */
+#define SCAN_D(field, key, def) ctl->field = scan_ctl(filename, argc, argv, key, -1, def, NULL);
+#define SCAN_I(field, key, def) ctl->field = (int) scan_ctl(filename, argc, argv, key, -1, def, NULL);
+#define SCAN_S(field, key, def) scan_ctl(filename, argc, argv, key, -1, def, ctl->field);
+  CTL_SCALARS(SCAN_D, SCAN_I, SCAN_S)
+#undef SCAN_D
+#undef SCAN_I
+#undef SCAN_S
+
+  /* checks and the keys that depend on others */
   ctl->met_utm_ref_lat = (ctl->met_coord_type != 0)
     ? scan_ctl(filename, argc, argv, "MET_UTM_REF_LAT", -1, "", NULL) : 0;
-  ctl->direction = (int) scan_ctl(filename, argc, argv, "DIRECTION", -1, "1", NULL);
   if (ctl->direction != -1 && ctl->direction != 1)
     ERRMSG("Set DIRECTION to -1 or 1!");
-  ctl->t_stop = scan_ctl(filename, argc, argv, "T_STOP", -1, "1e100", NULL);
-  ctl->dt_mod = scan_ctl(filename, argc, argv, "DT_MOD", -1, "180", NULL);
-  scan_ctl(filename, argc, argv, "METBASE", -1, "-", ctl->metbase);
-  ctl->dt_met = scan_ctl(filename, argc, argv, "DT_MET", -1, "3600", NULL);
-  ctl->met_type = (int) scan_ctl(filename, argc, argv, "MET_TYPE", -1, "0", NULL);
-  ctl->met_dt_out = scan_ctl(filename, argc, argv, "MET_DT_OUT", -1, "0.1", NULL);
-  ctl->met_nc_scale = (int) scan_ctl(filename, argc, argv, "MET_NC_SCALE", -1, "1", NULL);
-  ctl->met_pbl = (int) scan_ctl(filename, argc, argv, "MET_PBL", -1, "3", NULL);
-  ctl->met_cape = (int) scan_ctl(filename, argc, argv, "MET_CAPE", -1, "1", NULL);
   if (ctl->met_type == 0) {
     /* netCDF input is taken as stored: no down-sampling, smoothing, detrending, re-gridding (mptrac.c:7770-7830) */
     static const struct {
@@ -195,45 +289,11 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   }
 
   /* modules (mptrac.c:7196-7263) */
-  ctl->sort_dt = scan_ctl(filename, argc, argv, "SORT_DT", -1, "-999", NULL);
-  ctl->rng_type = (int) scan_ctl(filename, argc, argv, "RNG_TYPE", -1, "1", NULL);
-  ctl->advect = (int) scan_ctl(filename, argc, argv, "ADVECT", -1, "2", NULL);
   if (!(ctl->advect == 1 || ctl->advect == 2 || ctl->advect == 4))
     ERRMSG("Set ADVECT to 1, 2, or 4!");
-  ctl->advect_vert_coord = (int) scan_ctl(filename, argc, argv, "ADVECT_VERT_COORD", -1, "0", NULL);
-  ctl->diffusion = (int) scan_ctl(filename, argc, argv, "DIFFUSION", -1, "0", NULL);
-  ctl->turb_pbl_scheme = (int) scan_ctl(filename, argc, argv, "TURB_PBL_SCHEME", -1, "0", NULL);
-  ctl->turb_dx_pbl = scan_ctl(filename, argc, argv, "TURB_DX_PBL", -1, "50", NULL);
-  ctl->turb_dx_trop = scan_ctl(filename, argc, argv, "TURB_DX_TROP", -1, "50", NULL);
-  ctl->turb_dx_strat = scan_ctl(filename, argc, argv, "TURB_DX_STRAT", -1, "0", NULL);
-  ctl->turb_dz_pbl = scan_ctl(filename, argc, argv, "TURB_DZ_PBL", -1, "0", NULL);
-  ctl->turb_dz_trop = scan_ctl(filename, argc, argv, "TURB_DZ_TROP", -1, "0", NULL);
-  ctl->turb_dz_strat = scan_ctl(filename, argc, argv, "TURB_DZ_STRAT", -1, "0.1", NULL);
-  ctl->turb_mesox = scan_ctl(filename, argc, argv, "TURB_MESOX", -1, "0.16", NULL);
-  ctl->turb_mesoz = scan_ctl(filename, argc, argv, "TURB_MESOZ", -1, "0.16", NULL);
-  ctl->turb_pbl_trans = scan_ctl(filename, argc, argv, "TURB_PBL_TRANS", -1, "0", NULL);
   if (ctl->turb_pbl_trans < 0 || ctl->turb_pbl_trans > 1)
     ERRMSG("TURB_PBL_TRANS must be in the range [0, 1]!");
-  ctl->conv_mix_pbl = (int) scan_ctl(filename, argc, argv, "CONV_MIX_PBL", -1, "0", NULL);
-  ctl->conv_pbl_trans = scan_ctl(filename, argc, argv, "CONV_PBL_TRANS", -1, "0", NULL);
-  ctl->conv_cape = scan_ctl(filename, argc, argv, "CONV_CAPE", -1, "-999", NULL);
-  ctl->conv_cin = scan_ctl(filename, argc, argv, "CONV_CIN", -1, "-999", NULL);
-  ctl->conv_dt = scan_ctl(filename, argc, argv, "CONV_DT", -1, "-999", NULL);
   /* isosurface and boundary conditions (mptrac.c:7207-7209, 7266-7289) */
-  ctl->isosurf = (int) scan_ctl(filename, argc, argv, "ISOSURF", -1, "0", NULL);
-  scan_ctl(filename, argc, argv, "BALLOON", -1, "-", ctl->balloon);
-  ctl->bound_mass = scan_ctl(filename, argc, argv, "BOUND_MASS", -1, "-999", NULL);
-  ctl->bound_mass_trend = scan_ctl(filename, argc, argv, "BOUND_MASS_TREND", -1, "0", NULL);
-  ctl->bound_vmr = scan_ctl(filename, argc, argv, "BOUND_VMR", -1, "-999", NULL);
-  ctl->bound_vmr_trend = scan_ctl(filename, argc, argv, "BOUND_VMR_TREND", -1, "0", NULL);
-  ctl->bound_lat0 = scan_ctl(filename, argc, argv, "BOUND_LAT0", -1, "-999", NULL);
-  ctl->bound_lat1 = scan_ctl(filename, argc, argv, "BOUND_LAT1", -1, "-999", NULL);
-  ctl->bound_p0 = scan_ctl(filename, argc, argv, "BOUND_P0", -1, "-999", NULL);
-  ctl->bound_p1 = scan_ctl(filename, argc, argv, "BOUND_P1", -1, "-999", NULL);
-  ctl->bound_dps = scan_ctl(filename, argc, argv, "BOUND_DPS", -1, "-999", NULL);
-  ctl->bound_dzs = scan_ctl(filename, argc, argv, "BOUND_DZS", -1, "-999", NULL);
-  ctl->bound_zetas = scan_ctl(filename, argc, argv, "BOUND_ZETAS", -1, "-999", NULL);
-  ctl->bound_pbl = (int) scan_ctl(filename, argc, argv, "BOUND_PBL", -1, "0", NULL);
   /* SPECIES presets (values: mptrac.c:7291-7383): molar mass and Henry's-law constants become the defaults of
    * MOLMASS / WET_DEPO_*_H below; a species that also switches the OH chemistry on is only accepted with that
    * chemistry explicitly off, because this build does not provide it */
@@ -275,59 +335,16 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   sprintf(defstr, "%g", henry_default[0]);
   ctl->wet_depo_bc_h[0] = scan_ctl(filename, argc, argv, "WET_DEPO_BC_H", 0, defstr, NULL);
   ctl->wet_depo_bc_h[1] = henry_default[1];
-  ctl->wet_depo_so2_ph = scan_ctl(filename, argc, argv, "WET_DEPO_SO2_PH", -1, "0", NULL);
-  ctl->wet_depo_ic_a = scan_ctl(filename, argc, argv, "WET_DEPO_IC_A", -1, "0", NULL);
-  ctl->wet_depo_ic_b = scan_ctl(filename, argc, argv, "WET_DEPO_IC_B", -1, "0", NULL);
-  ctl->wet_depo_bc_a = scan_ctl(filename, argc, argv, "WET_DEPO_BC_A", -1, "0", NULL);
-  ctl->wet_depo_bc_b = scan_ctl(filename, argc, argv, "WET_DEPO_BC_B", -1, "0", NULL);
   ctl->wet_depo_pre[0] = scan_ctl(filename, argc, argv, "WET_DEPO_PRE", 0, "0.5", NULL);
   ctl->wet_depo_pre[1] = scan_ctl(filename, argc, argv, "WET_DEPO_PRE", 1, "0.36", NULL);
-  ctl->wet_depo_ic_ret_ratio = scan_ctl(filename, argc, argv, "WET_DEPO_IC_RET_RATIO", -1, "1", NULL);
-  ctl->wet_depo_bc_ret_ratio = scan_ctl(filename, argc, argv, "WET_DEPO_BC_RET_RATIO", -1, "1", NULL);
-  ctl->dry_depo_vdep = scan_ctl(filename, argc, argv, "DRY_DEPO_VDEP", -1, "0", NULL);
-  ctl->dry_depo_dp = scan_ctl(filename, argc, argv, "DRY_DEPO_DP", -1, "30", NULL);
-  ctl->mixing_dt = scan_ctl(filename, argc, argv, "MIXING_DT", -1, "3600.", NULL);
-  ctl->mixing_trop = scan_ctl(filename, argc, argv, "MIXING_TROP", -1, "-999", NULL);
-  ctl->mixing_strat = scan_ctl(filename, argc, argv, "MIXING_STRAT", -1, "-999", NULL);
-  ctl->mixing_z0 = scan_ctl(filename, argc, argv, "MIXING_Z0", -1, "-5", NULL);
-  ctl->mixing_z1 = scan_ctl(filename, argc, argv, "MIXING_Z1", -1, "85", NULL);
-  ctl->mixing_nz = (int) scan_ctl(filename, argc, argv, "MIXING_NZ", -1, "90", NULL);
-  ctl->mixing_lon0 = scan_ctl(filename, argc, argv, "MIXING_LON0", -1, "-180", NULL);
-  ctl->mixing_lon1 = scan_ctl(filename, argc, argv, "MIXING_LON1", -1, "180", NULL);
-  ctl->mixing_nx = (int) scan_ctl(filename, argc, argv, "MIXING_NX", -1, "360", NULL);
-  ctl->mixing_lat0 = scan_ctl(filename, argc, argv, "MIXING_LAT0", -1, "-90", NULL);
-  ctl->mixing_lat1 = scan_ctl(filename, argc, argv, "MIXING_LAT1", -1, "90", NULL);
-  ctl->mixing_ny = (int) scan_ctl(filename, argc, argv, "MIXING_NY", -1, "180", NULL);
   if (ctl->mixing_nx < 1 || ctl->mixing_ny < 1 || ctl->mixing_nz < 1 || ctl->mixing_lon0 >= ctl->mixing_lon1
       || ctl->mixing_lat0 >= ctl->mixing_lat1 || ctl->mixing_z0 >= ctl->mixing_z1
       || ctl->mixing_lat0 < -90 || ctl->mixing_lat1 > 90)
     ERRMSG("Invalid mixing grid!");
-  ctl->tdec_trop = scan_ctl(filename, argc, argv, "TDEC_TROP", -1, "0", NULL);
-  ctl->tdec_strat = scan_ctl(filename, argc, argv, "TDEC_STRAT", -1, "0", NULL);
-  ctl->nens = (int) scan_ctl(filename, argc, argv, "NENS", -1, "0", NULL);
 
   /* output (mptrac.c:7551-7648) */
-  scan_ctl(filename, argc, argv, "ATM_BASENAME", -1, "-", ctl->atm_basename);
-  ctl->atm_dt_out = scan_ctl(filename, argc, argv, "ATM_DT_OUT", -1, "86400", NULL);
-  ctl->atm_filter = (int) scan_ctl(filename, argc, argv, "ATM_FILTER", -1, "0", NULL);
-  ctl->atm_stride = (int) scan_ctl(filename, argc, argv, "ATM_STRIDE", -1, "1", NULL);
-  ctl->atm_type = (int) scan_ctl(filename, argc, argv, "ATM_TYPE", -1, "0", NULL);
-  ctl->atm_type_out = (int) scan_ctl(filename, argc, argv, "ATM_TYPE_OUT", -1, "-1", NULL);
   if (ctl->atm_type_out == -1)
     ctl->atm_type_out = ctl->atm_type;
-  scan_ctl(filename, argc, argv, "GRID_BASENAME", -1, "-", ctl->grid_basename);
-  ctl->grid_dt_out = scan_ctl(filename, argc, argv, "GRID_DT_OUT", -1, "86400", NULL);
-  ctl->grid_sparse = (int) scan_ctl(filename, argc, argv, "GRID_SPARSE", -1, "0", NULL);
-  ctl->grid_stddev = (int) scan_ctl(filename, argc, argv, "GRID_STDDEV", -1, "0", NULL);
-  ctl->grid_z0 = scan_ctl(filename, argc, argv, "GRID_Z0", -1, "-5", NULL);
-  ctl->grid_z1 = scan_ctl(filename, argc, argv, "GRID_Z1", -1, "85", NULL);
-  ctl->grid_nz = (int) scan_ctl(filename, argc, argv, "GRID_NZ", -1, "1", NULL);
-  ctl->grid_lon0 = scan_ctl(filename, argc, argv, "GRID_LON0", -1, "-180", NULL);
-  ctl->grid_lon1 = scan_ctl(filename, argc, argv, "GRID_LON1", -1, "180", NULL);
-  ctl->grid_nx = (int) scan_ctl(filename, argc, argv, "GRID_NX", -1, "360", NULL);
-  ctl->grid_lat0 = scan_ctl(filename, argc, argv, "GRID_LAT0", -1, "-90", NULL);
-  ctl->grid_lat1 = scan_ctl(filename, argc, argv, "GRID_LAT1", -1, "90", NULL);
-  ctl->grid_ny = (int) scan_ctl(filename, argc, argv, "GRID_NY", -1, "180", NULL);
   if (ctl->grid_nx < 1 || ctl->grid_ny < 1 || ctl->grid_nz < 1)
     ERRMSG("Invalid output grid dimensions!");
   if (ctl->grid_lon0 >= ctl->grid_lon1 || ctl->grid_lat0 >= ctl->grid_lat1 || ctl->grid_z0 >= ctl->grid_z1
@@ -335,9 +352,6 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
     ERRMSG("Invalid output grid boundaries!");
 
   /* back-end options */
-  ctl->hip_device = (int) scan_ctl(filename, argc, argv, "HIP_DEVICE", -1, "0", NULL);
-  ctl->hip_locality_interval = (int) scan_ctl(filename, argc, argv, "HIP_LOCALITY_SORT_INTERVAL", -1, "60", NULL);
-  ctl->hip_met_prefetch = (int) scan_ctl(filename, argc, argv, "HIP_MET_PREFETCH", -1, "0", NULL);
 
   /* what this host layer / the device do not implement must not be requested silently: the reference's
    * other output writers (mptrac.c:7574-7713), chemistry and radioactive decay switches (7386-7411),
@@ -430,147 +444,143 @@ void mptrac_read_clim(const ctl_t *ctl, clim_t *clim) {
 /* particle I/O                                                               */
 /* -------------------------------------------------------------------------- */
 
-#define FREAD(ptr, type, size, in) {                                    \
-    if (fread(ptr, sizeof(type), size, in) != size)                     \
-      ERRMSG("Error while reading!");                                   \
-  }
-#define FWRITE(ptr, type, size, out) {                                  \
-    if (fwrite(ptr, sizeof(type), size, out) != size)                   \
-      ERRMSG("Error while writing!");                                   \
-  }
+/* binary records: `count` items of `size` bytes, all or nothing */
+static void get_items(FILE *f, void *dst, size_t size, size_t count) {
+  if (fread(dst, size, count, f) != count)
+    ERRMSG("Error while reading!");
+}
 
+static void put_items(FILE *f, const void *src, size_t size, size_t count) {
+  if (fwrite(src, size, count, f) != count)
+    ERRMSG("Error while writing!");
+}
+
+static int get_int(FILE *f) {
+  int v;
+  get_items(f, &v, sizeof(int), 1);
+  return v;
+}
+
+/* the per-particle columns of an atm_t in file order: time, pressure, longitude, latitude, quantities */
+static int atm_columns(const ctl_t *ctl, atm_t *atm, double *col[4 + NQ]) {
+  col[0] = atm->time;
+  col[1] = atm->p;
+  col[2] = atm->lon;
+  col[3] = atm->lat;
+  for (int iq = 0; iq < ctl->nq; iq++)
+    col[4 + iq] = atm->q[iq];
+  return 4 + ctl->nq;
+}
+
+/* ASCII table (reference format: docs/manual/input-data.md; src/mptrac.c read_atm_asc): one particle per line --
+ * time, altitude [km], longitude, latitude, then the quantities; lines that do not start with a number are
+ * comments, a line that starts with numbers but ends early is an error */
 static int read_atm_asc(const char *filename, const ctl_t *ctl, atm_t *atm) {
-  /* columns: time, altitude [km], lon, lat, q[0..nq) (mptrac.c:8380-8418) */
-  FILE *in;
-  if (!(in = fopen(filename, "r"))) {
+  FILE *in = fopen(filename, "r");
+  if (!in) {
     WARN("Cannot open file!");
     return 0;
   }
+  double *col[4 + NQ];
+  const int ncol = atm_columns(ctl, atm, col);
   char line[LEN];
   while (fgets(line, LEN, in)) {
-    char *tok = strtok(line, " \t");
     double v[4 + NQ];
-    int k = 0;
-    for (; tok && k < 4 + ctl->nq; k++, tok = strtok(NULL, " \t"))
-      if (sscanf(tok, "%lg", &v[k]) != 1)
-        break;
-    if (k == 0 && (line[0] == '#' || line[0] == '\n' || line[0] == '\0'))
+    int got = 0;
+    for (char *tok = strtok(line, " \t"); tok && got < ncol && sscanf(tok, "%lg", &v[got]) == 1; tok = strtok(NULL, " \t"))
+      got++;
+    if (got == 0 || (got < ncol && line[0] == '#'))
       continue;
-    if (k < 4 + ctl->nq) {
-      if (line[0] == '#' || k == 0)
-        continue;
+    if (got < ncol)
       ERRMSG("Error while reading!");
-    }
-    atm->time[atm->np] = v[0];
-    atm->p[atm->np] = P(v[1]);
-    atm->lon[atm->np] = v[2];
-    atm->lat[atm->np] = v[3];
-    for (int iq = 0; iq < ctl->nq; iq++)
-      atm->q[iq][atm->np] = v[4 + iq];
-    if ((++atm->np) > NP)
+    if (atm->np >= NP)
       ERRMSG("Too many data points!");
+    v[1] = P(v[1]);   /* altitude -> pressure */
+    for (int k = 0; k < ncol; k++)
+      col[k][atm->np] = v[k];
+    atm->np++;
   }
   fclose(in);
   return 1;
 }
 
+/* binary particle file, version 100: [100] [np] then the columns as double[np] each, [999] */
 static int read_atm_bin(const char *filename, const ctl_t *ctl, atm_t *atm) {
-  /* version 100 layout, mptrac.c:8422-8475 */
-  FILE *in;
-  if (!(in = fopen(filename, "r")))
+  FILE *in = fopen(filename, "r");
+  if (!in)
     return 0;
-  int version;
-  FREAD(&version, int, 1, in);
-  if (version != 100)
+  if (get_int(in) != 100)
     ERRMSG("Wrong version of binary data!");
-  FREAD(&atm->np, int, 1, in);
+  atm->np = get_int(in);
   if (atm->np < 0 || atm->np > NP)
     ERRMSG("Too many data points!");
-  FREAD(atm->time, double, (size_t) atm->np, in);
-  FREAD(atm->p, double, (size_t) atm->np, in);
-  FREAD(atm->lon, double, (size_t) atm->np, in);
-  FREAD(atm->lat, double, (size_t) atm->np, in);
-  for (int iq = 0; iq < ctl->nq; iq++)
-    FREAD(atm->q[iq], double, (size_t) atm->np, in);
-  int final;
-  FREAD(&final, int, 1, in);
-  if (final != 999)
+  double *col[4 + NQ];
+  const int ncol = atm_columns(ctl, atm, col);
+  for (int k = 0; k < ncol; k++)
+    get_items(in, col[k], sizeof(double), (size_t) atm->np);
+  if (get_int(in) != 999)
     ERRMSG("Error while reading binary data!");
   fclose(in);
   return 1;
 }
 
 int mptrac_read_atm(const char *filename, const ctl_t *ctl, atm_t *atm) {
-  /* mptrac.c:6588-6659 */
-  int result;
-  atm->np = 0;
   LOG(1, "Read atmospheric data: %s", filename);
-  if (ctl->atm_type == 0)
-    result = read_atm_asc(filename, ctl, atm);
-  else if (ctl->atm_type == 1)
-    result = read_atm_bin(filename, ctl, atm);
-  else
+  atm->np = 0;
+  if (ctl->atm_type != 0 && ctl->atm_type != 1)
     ERRMSG("Atmospheric data type not supported (this build reads ATM_TYPE 0 and 1)!");
-  if (result != 1)
+  if (!(ctl->atm_type == 0 ? read_atm_asc(filename, ctl, atm) : read_atm_bin(filename, ctl, atm)))
     return 0;
   if (atm->np < 1)
     ERRMSG("Can not read any data!");
   LOG(2, "Number of particles: %d", atm->np);
-  return result;
+  return 1;
 }
 
+/* ASCII table as the reference writes it: numbered column legend, blank line, one particle per line;
+ * ATM_FILTER 1 blanks (NaN), 2 drops the particles whose time is not within half a step of t */
 static void write_atm_asc(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t) {
-  /* mptrac.c:12774-12868 */
-  FILE *out;
-  const double t0 = t - 0.5 * ctl->dt_mod, t1 = t + 0.5 * ctl->dt_mod;
-  if (!(out = fopen(filename, "w")))
+  FILE *out = fopen(filename, "w");
+  if (!out)
     ERRMSG("Cannot create file!");
-  if (ctl->met_coord_type == 0)
-    fprintf(out, "# $1 = time [s]\n# $2 = altitude [km]\n# $3 = longitude [deg]\n# $4 = latitude [deg]\n");
-  else
-    fprintf(out, "# $1 = time [s]\n# $2 = altitude [km]\n# $3 = x [m]\n# $4 = y [m]\n");
+  const int cartesian = ctl->met_coord_type != 0;
+  const char *legend[4] = { "time [s]", "altitude [km]", cartesian ? "x [m]" : "longitude [deg]",
+    cartesian ? "y [m]" : "latitude [deg]" };
+  for (int k = 0; k < 4; k++)
+    fprintf(out, "# $%d = %s\n", k + 1, legend[k]);
   for (int iq = 0; iq < ctl->nq; iq++)
     fprintf(out, "# $%i = %s [%s]\n", iq + 5, ctl->qnt_name[iq], ctl->qnt_unit[iq]);
-  fprintf(out, "\n");
+  fputc('\n', out);
+  const char *position = cartesian ? "%.2f %g %.2f %.2f" : "%.2f %g %g %g";
   for (int ip = 0; ip < atm->np; ip += ctl->atm_stride) {
-    if (ctl->atm_filter == 2 && (atm->time[ip] < t0 || atm->time[ip] > t1))
+    const int outside = atm->time[ip] < t - 0.5 * ctl->dt_mod || atm->time[ip] > t + 0.5 * ctl->dt_mod;
+    if (outside && ctl->atm_filter == 2)
       continue;
-    if (ctl->met_coord_type == 0)
-      fprintf(out, "%.2f %g %g %g", atm->time[ip], Z(atm->p[ip]), atm->lon[ip], atm->lat[ip]);
-    else
-      fprintf(out, "%.2f %g %.2f %.2f", atm->time[ip], Z(atm->p[ip]), atm->lon[ip], atm->lat[ip]);
+    fprintf(out, position, atm->time[ip], Z(atm->p[ip]), atm->lon[ip], atm->lat[ip]);
     for (int iq = 0; iq < ctl->nq; iq++) {
-      fprintf(out, " ");
-      if (ctl->atm_filter == 1 && (atm->time[ip] < t0 || atm->time[ip] > t1))
-        fprintf(out, ctl->qnt_format[iq], NAN);
-      else
-        fprintf(out, ctl->qnt_format[iq], atm->q[iq][ip]);
+      fputc(' ', out);
+      fprintf(out, ctl->qnt_format[iq], (outside && ctl->atm_filter == 1) ? NAN : atm->q[iq][ip]);
     }
-    fprintf(out, "\n");
+    fputc('\n', out);
   }
   fclose(out);
 }
 
 static void write_atm_bin(const char *filename, const ctl_t *ctl, const atm_t *atm) {
-  /* mptrac.c:12872-12918 */
-  FILE *out;
-  if (!(out = fopen(filename, "w")))
+  FILE *out = fopen(filename, "w");
+  if (!out)
     ERRMSG("Cannot create file!");
-  int version = 100, final = 999;
-  FWRITE(&version, int, 1, out);
-  FWRITE(&atm->np, int, 1, out);
-  FWRITE(atm->time, double, (size_t) atm->np, out);
-  FWRITE(atm->p, double, (size_t) atm->np, out);
-  FWRITE(atm->lon, double, (size_t) atm->np, out);
-  FWRITE(atm->lat, double, (size_t) atm->np, out);
-  for (int iq = 0; iq < ctl->nq; iq++)
-    FWRITE(atm->q[iq], double, (size_t) atm->np, out);
-  FWRITE(&final, int, 1, out);
+  const int head[2] = { 100, atm->np }, tail = 999;
+  put_items(out, head, sizeof(int), 2);
+  double *col[4 + NQ];
+  const int ncol = atm_columns(ctl, (atm_t *) atm, col);
+  for (int k = 0; k < ncol; k++)
+    put_items(out, col[k], sizeof(double), (size_t) atm->np);
+  put_items(out, &tail, sizeof(int), 1);
   fclose(out);
 }
 
 void mptrac_write_atm(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t) {
-  /* mptrac.c:8117-8155 */
   LOG(1, "Write atmospheric data: %s", filename);
   if (ctl->atm_type_out == 0)
     write_atm_asc(filename, ctl, atm, t);
@@ -584,65 +594,62 @@ void mptrac_write_atm(const char *filename, const ctl_t *ctl, const atm_t *atm, 
 /* meteo I/O: the reference's raw binary format (MET_TYPE 1, version 104)     */
 /* -------------------------------------------------------------------------- */
 
-static void bin_2d(FILE *f, int write, const met_t *met, float var[EX][EY], float *help) {
-  /* one [nx][ny] float block, read or skipped (var == NULL) or written */
-  const size_t n = (size_t) met->nx * (size_t) met->ny;
-  if (write) {
-    for (int ix = 0; ix < met->nx; ix++)
-      for (int iy = 0; iy < met->ny; iy++)
-        help[(size_t) ix * met->ny + iy] = var ? var[ix][iy] : 0.f;
-    FWRITE(help, float, n, f);
-  } else {
-    FREAD(help, float, n, f);
-    if (var)
-      for (int ix = 0; ix < met->nx; ix++)
-        for (int iy = 0; iy < met->ny; iy++)
-          var[ix][iy] = help[(size_t) ix * met->ny + iy];
-  }
+/* One field of a MET_TYPE 1 file: compact [nx][ny] or [nx][ny][np] floats <-> the fixed-extent member of met_t
+ * (nlev = 0: surface field).  On reading, level fields are limited to [lo, hi] as the reference does
+ * (read_met_bin_3d); dst == NULL skips the block, src == NULL writes zeros. */
+static void met_block(FILE *f, const int write, const met_t *met, float *field, const int nlev, const float lo,
+                      const float hi, float *buf) {
+  const size_t lev = nlev > 0 ? (size_t) nlev : 1, stride = nlev > 0 ? EP : 1;
+  const size_t n = (size_t) met->nx * (size_t) met->ny * lev;
+  if (!write)
+    get_items(f, buf, sizeof(float), n);
+  size_t k = 0;
+  for (int ix = 0; ix < met->nx; ix++)
+    for (int iy = 0; iy < met->ny; iy++) {
+      float *cell = field ? field + ((size_t) ix * EY + (size_t) iy) * stride : NULL;
+      for (size_t ip = 0; ip < lev; ip++, k++) {
+        if (write)
+          buf[k] = cell ? cell[ip] : 0.f;
+        else if (cell)
+          cell[ip] = nlev > 0 ? fminf(fmaxf(buf[k], lo), hi) : buf[k];
+      }
+    }
+  if (write)
+    put_items(f, buf, sizeof(float), n);
 }
 
-static void bin_3d(FILE *f, int write, const met_t *met, float var[EX][EY][EP], float *help, float lo, float hi) {
-  const size_t n = (size_t) met->nx * (size_t) met->ny * (size_t) met->np;
-  if (write) {
-    for (int ix = 0; ix < met->nx; ix++)
-      for (int iy = 0; iy < met->ny; iy++)
-        for (int ip = 0; ip < met->np; ip++)
-          help[((size_t) ix * met->ny + iy) * met->np + ip] = var ? var[ix][iy][ip] : 0.f;
-    FWRITE(help, float, n, f);
-  } else {
-    FREAD(help, float, n, f);
-    if (var)
-      for (int ix = 0; ix < met->nx; ix++)
-        for (int iy = 0; iy < met->ny; iy++)
-          for (int ip = 0; ip < met->np; ip++) {
-            /* bounds check of read_met_bin_3d, mptrac.c:9172-9177 */
-            float v = help[((size_t) ix * met->ny + iy) * met->np + ip];
-            var[ix][iy][ip] = v < lo ? lo : (v > hi ? hi : v);
-          }
-  }
-}
-
+/* the 24 surface and 13 level fields in file order (version 104 of the format) */
 static void met_bin_body(FILE *f, int write, met_t *met) {
-  /* field order of read_met_bin / write_met_bin (mptrac.c:8990-9028, 14245-14300):
-   * 24 surface fields, 13 level fields */
-  float *help;
-  ALLOC(help, float, (size_t) met->nx * (size_t) met->ny * (size_t) met->np);
-  float (*s2[24])[EY] = { met->ps, met->ts, met->zs, met->us, met->vs, met->ess, met->nss, met->shf, met->lsm,
-    met->sst, met->pbl, met->pt, met->tt, met->zt, met->h2ot, met->pct, met->pcb, met->cl, met->plcl, met->plfc,
-    met->pel, met->cape, met->cin, met->o3c };
+  float *buf;
+  ALLOC(buf, float, (size_t) met->nx * (size_t) met->ny * (size_t) met->np);
+  float *surface[24] = { &met->ps[0][0], &met->ts[0][0], &met->zs[0][0], &met->us[0][0], &met->vs[0][0], &met->ess[0][0],
+    &met->nss[0][0], &met->shf[0][0], &met->lsm[0][0], &met->sst[0][0], &met->pbl[0][0], &met->pt[0][0], &met->tt[0][0],
+    &met->zt[0][0], &met->h2ot[0][0], &met->pct[0][0], &met->pcb[0][0], &met->cl[0][0], &met->plcl[0][0],
+    &met->plfc[0][0], &met->pel[0][0], &met->cape[0][0], &met->cin[0][0], &met->o3c[0][0] };
   for (int k = 0; k < 24; k++)
-    bin_2d(f, write, met, s2[k], help);
-  float (*s3[13])[EY][EP] = { met->z, met->t, met->u, met->v, met->w, met->pv, met->h2o, met->o3, met->lwc, met->rwc,
-    met->iwc, met->swc, met->cc };
-  const float lo[13] = { -1e34f, 0, -1e34f, -1e34f, -1e34f, -1e34f, 0, 0, 0, 0, 0, 0, 0 };
-  const float hi[13] = { 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1e34f, 1 };
+    met_block(f, write, met, surface[k], 0, 0.f, 0.f, buf);
+  const struct {
+    float *field, lo, hi;
+  } level[13] = { { &met->z[0][0][0], -1e34f, 1e34f }, { &met->t[0][0][0], 0, 1e34f }, { &met->u[0][0][0], -1e34f, 1e34f },
+    { &met->v[0][0][0], -1e34f, 1e34f }, { &met->w[0][0][0], -1e34f, 1e34f }, { &met->pv[0][0][0], -1e34f, 1e34f },
+    { &met->h2o[0][0][0], 0, 1e34f }, { &met->o3[0][0][0], 0, 1e34f }, { &met->lwc[0][0][0], 0, 1e34f },
+    { &met->rwc[0][0][0], 0, 1e34f }, { &met->iwc[0][0][0], 0, 1e34f }, { &met->swc[0][0][0], 0, 1e34f },
+    { &met->cc[0][0][0], 0, 1 } };
   for (int k = 0; k < 13; k++)
-    bin_3d(f, write, met, s3[k], help, lo[k], hi[k]);
-  free(help);
+    met_block(f, write, met, level[k].field, met->np, level[k].lo, level[k].hi, buf);
+  free(buf);
 }
 
 static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met);
 
+static int extent_from_file(FILE *in, const int max, const char *what) {
+  const int n = get_int(in);
+  if (n < 2 || n > max)
+    ERRMSG("Number of %s out of range!", what);
+  return n;
+}
+
+/* MET_TYPE 1: [1] [104] time nx ny np lon[] lat[] p[] fields [999] (reference: read_met_bin, write_met_bin) */
 int mptrac_read_met(const char *filename, const ctl_t *ctl, const clim_t *clim, met_t *met, dd_t *dd) {
   (void) clim;
   (void) dd;
@@ -651,61 +658,46 @@ int mptrac_read_met(const char *filename, const ctl_t *ctl, const clim_t *clim, 
     return read_met_nc(filename, ctl, met);
   if (ctl->met_type != 1)
     ERRMSG("This build reads MET_TYPE 0 (classic netCDF, grids without preprocessing) and 1 (raw binary) meteo files!");
-  FILE *in;
-  if (!(in = fopen(filename, "r"))) {
+  FILE *in = fopen(filename, "r");
+  if (!in) {
     WARN("Cannot open file!");
     return 0;
   }
-  int met_type, version;
-  FREAD(&met_type, int, 1, in);
-  if (met_type != ctl->met_type)
+  if (get_int(in) != ctl->met_type)
     ERRMSG("Wrong MET_TYPE of binary data!");
-  FREAD(&version, int, 1, in);
-  if (version != 104)
+  if (get_int(in) != 104)
     ERRMSG("Wrong version of binary data!");
-  FREAD(&met->time, double, 1, in);
+  get_items(in, &met->time, sizeof(double), 1);
   met->coord_type = ctl->met_coord_type;
-  FREAD(&met->nx, int, 1, in);
-  if (met->nx < 2 || met->nx > EX)
-    ERRMSG("Number of longitudes out of range!");
-  FREAD(&met->ny, int, 1, in);
-  if (met->ny < 2 || met->ny > EY)
-    ERRMSG("Number of latitudes out of range!");
-  FREAD(&met->np, int, 1, in);
-  if (met->np < 2 || met->np > EP)
-    ERRMSG("Number of levels out of range!");
-  FREAD(met->lon, double, (size_t) met->nx, in);
-  FREAD(met->lat, double, (size_t) met->ny, in);
-  FREAD(met->p, double, (size_t) met->np, in);
+  met->nx = extent_from_file(in, EX, "longitudes");
+  met->ny = extent_from_file(in, EY, "latitudes");
+  met->np = extent_from_file(in, EP, "levels");
+  get_items(in, met->lon, sizeof(double), (size_t) met->nx);
+  get_items(in, met->lat, sizeof(double), (size_t) met->ny);
+  get_items(in, met->p, sizeof(double), (size_t) met->np);
   met_bin_body(in, 0, met);
-  int final;
-  FREAD(&final, int, 1, in);
-  if (final != 999)
+  if (get_int(in) != 999)
     ERRMSG("Error while reading binary data!");
   fclose(in);
   return 1;
 }
 
 void mptrac_write_met(const char *filename, const ctl_t *ctl, met_t *met) {
-  /* write_met_bin, mptrac.c:14188-14314 */
   LOG(1, "Write meteo data: %s", filename);
   if (ctl->met_type != 1)
     ERRMSG("This build writes MET_TYPE 1 (raw binary) meteo files only!");
-  FILE *out;
-  if (!(out = fopen(filename, "w")))
+  FILE *out = fopen(filename, "w");
+  if (!out)
     ERRMSG("Cannot create file!");
-  int version = 104, final = 999;
-  FWRITE(&ctl->met_type, int, 1, out);
-  FWRITE(&version, int, 1, out);
-  FWRITE(&met->time, double, 1, out);
-  FWRITE(&met->nx, int, 1, out);
-  FWRITE(&met->ny, int, 1, out);
-  FWRITE(&met->np, int, 1, out);
-  FWRITE(met->lon, double, (size_t) met->nx, out);
-  FWRITE(met->lat, double, (size_t) met->ny, out);
-  FWRITE(met->p, double, (size_t) met->np, out);
+  const int head[2] = { ctl->met_type, 104 }, dims[3] = { met->nx, met->ny, met->np }, tail = 999;
+  put_items(out, head, sizeof(int), 2);
+  put_items(out, &met->time, sizeof(double), 1);
+  put_items(out, dims, sizeof(int), 3);
+  put_items(out, met->lon, sizeof(double), (size_t) met->nx);
+  put_items(out, met->lat, sizeof(double), (size_t) met->ny);
+  put_items(out, met->p, sizeof(double), (size_t) met->np);
   met_bin_body(out, 1, met);
-  FWRITE(&final, int, 1, out);
+  put_items(out, &tail, sizeof(int), 1);
   fclose(out);
 }
 
@@ -1397,24 +1389,22 @@ void mptrac_run_timestep(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t **met0,
  * locate_irr 3495-3521, locate_reg 3559-3574).  One call per output cell and
  * output time, on the host like the reference; particles are never
  * interpolated here. */
+/* interval of a monotonic axis (either direction) that the reference's bisection (locate_irr) selects for x:
+ * halve [lo, hi] until the two nodes are neighbours; a node equal to x belongs to the upper interval on an
+ * ascending axis and to the lower one on a descending axis */
 static int grid_locate_irr(const double *xx, const int n, const double x) {
-  int ilo = 0, ihi = n - 1, i = (ihi + ilo) >> 1;
-  if (xx[i] < xx[i + 1])
-    while (ihi > ilo + 1) {
-      i = (ihi + ilo) >> 1;
-      if (xx[i] > x)
-        ihi = i;
-      else
-        ilo = i;
-  } else
-    while (ihi > ilo + 1) {
-      i = (ihi + ilo) >> 1;
-      if (xx[i] <= x)
-        ihi = i;
-      else
-        ilo = i;
-    }
-  return ilo;
+  int lo = 0, hi = n - 1;
+  const int mid0 = (lo + hi) / 2;
+  const int ascending = xx[mid0] < xx[mid0 + 1];
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) / 2;
+    const int beyond = ascending ? xx[mid] > x : xx[mid] <= x;
+    if (beyond)
+      hi = mid;
+    else
+      lo = mid;
+  }
+  return lo;
 }
 
 static double grid_temperature(const met_t *met0, const met_t *met1, const double ts, const double p,
