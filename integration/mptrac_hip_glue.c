@@ -1,0 +1,193 @@
+/*
+ * mptrac_hip_glue.c -- route A of INTEGRATION.md, complete: the code a maintainer of the reference adds to
+ * its src/mptrac.c (at the end of the file, or as `#include "mptrac_hip_glue.c"` there) to run the
+ * time-step loop on the MI355X back end while keeping the reference's own host code, structs, readers and
+ * writers.  Everything is inside `#ifdef MPTRAC_HIP`; it uses the reference's types (ctl_t, met_t, atm_t,
+ * cache_t, clim_t from src/mptrac.h) and only the C ABI of include/mptrac_hip.h.
+ *
+ * Build of the reference with it (src/Makefile):
+ *     HIP ?= 0
+ *     ifeq ($(HIP),1)
+ *       CFLAGS  += -DMPTRAC_HIP -I$(MPTRAC_AMD)/include
+ *       LDFLAGS += -L$(MPTRAC_AMD)/mptrac_amd/lib -lmptrac_hip -Wl,-rpath,$(MPTRAC_AMD)/mptrac_amd/lib
+ *     endif
+ *
+ * Every member of ctl_t / met_t / clim_t / cache_t / atm_t named here exists in the reference's mptrac.h:
+ * integration/check_glue_fields.py verifies that against /root/reference (tests/test_abi.py runs it).  The
+ * file cannot be compiled in this repository's image (the reference's header needs GSL and netCDF).
+ *
+ * Call sites (reference file:line -> what replaces the OpenACC region there):
+ *   mptrac_alloc          mptrac.c:6336-6372   mptrac_hip_alloc(rank)            instead of `acc enter data create`
+ *   mptrac_free           mptrac.c:6398-6430   mptrac_hip_free()                 instead of `acc exit data delete`
+ *   mptrac_update_device  mptrac.c:8005-8057   mptrac_hip_update_device(...)     instead of `acc update device`
+ *   mptrac_update_host    mptrac.c:8061-8113   mptrac_hip_update_host(...)       instead of `acc update host`
+ *   mptrac_get_met        mptrac.c:6488-6491, 6513-6516  mptrac_hip_swap_met()   next to the pointer swap
+ *   mptrac_run_timestep   mptrac.c:7862-8000   mptrac_hip_run_timestep(t); return;
+ *   write_grid            mptrac.c:13836-13872 mptrac_hip_grid_sums(...)         instead of the binning loop
+ */
+#ifdef MPTRAC_HIP
+
+#include "mptrac_hip.h"
+
+static mphip_ctx *hip_ctx;     /* process-global like rng_ctr (mptrac.c:32-40): the interface is not re-entrant */
+static int hip_nq;
+
+#define HIPCALL(x) {                                    \
+    if ((x) != 0)                                       \
+      ERRMSG("%s", mphip_last_error(hip_ctx));          \
+  }
+
+/* members that carry the same name in ctl_t and mphip_ctl_t */
+#define HIP_CTL_SAME_NAME(X)                                                                             \
+  X(direction) X(met_coord_type) X(t_start) X(t_stop) X(dt_mod) X(dt_met) X(met_utm_ref_lat) X(nq)       \
+  X(qnt_m) X(qnt_vmr) X(qnt_rp) X(qnt_rhop) X(qnt_ens) X(qnt_loss_rate) X(qnt_mloss_decay)               \
+  X(qnt_mloss_wet) X(qnt_mloss_dry) X(qnt_zeta) X(qnt_eta) X(qnt_aoa) X(nens) X(advect)                  \
+  X(advect_vert_coord) X(rng_type) X(diffusion) X(turb_pbl_scheme) X(conv_mix_pbl)                       \
+  X(turb_dx_pbl) X(turb_dx_trop) X(turb_dx_strat) X(turb_dz_pbl) X(turb_dz_trop) X(turb_dz_strat)        \
+  X(turb_mesox) X(turb_mesoz) X(turb_pbl_trans) X(conv_pbl_trans) X(conv_cape) X(conv_cin) X(conv_dt)    \
+  X(sort_dt) X(tdec_trop) X(tdec_strat) X(mixing_dt) X(mixing_trop) X(mixing_strat)                      \
+  X(mixing_z0) X(mixing_z1) X(mixing_lon0) X(mixing_lon1) X(mixing_lat0) X(mixing_lat1)                  \
+  X(mixing_nx) X(mixing_ny) X(mixing_nz)                                                                 \
+  X(wet_depo_ic_a) X(wet_depo_ic_b) X(wet_depo_bc_a) X(wet_depo_bc_b) X(wet_depo_so2_ph)                 \
+  X(wet_depo_ic_ret_ratio) X(wet_depo_bc_ret_ratio) X(dry_depo_vdep) X(dry_depo_dp)                      \
+  X(grid_z0) X(grid_z1) X(grid_lon0) X(grid_lon1) X(grid_lat0) X(grid_lat1) X(grid_nx) X(grid_ny)        \
+  X(grid_nz) X(met_dt_out) X(isosurf) X(bound_pbl) X(bound_mass) X(bound_mass_trend) X(bound_vmr)        \
+  X(bound_vmr_trend) X(bound_lat0) X(bound_lat1) X(bound_p0) X(bound_p1) X(bound_dps) X(bound_dzs)       \
+  X(bound_zetas)
+
+/* module_meteo outputs: mphip_ctl_t::qnt_met[MPHIP_MQ_<X>] = ctl_t::qnt_<x> */
+#define HIP_CTL_METEO_QNT(X)                                                                             \
+  X(PS, ps) X(TS, ts) X(ZS, zs) X(US, us) X(VS, vs) X(ESS, ess) X(NSS, nss) X(SHF, shf) X(LSM, lsm)       \
+  X(SST, sst) X(PBL, pbl) X(PT, pt) X(TT, tt) X(ZT, zt) X(H2OT, h2ot) X(ZG, zg) X(P, p) X(T, t)           \
+  X(RHO, rho) X(U, u) X(V, v) X(W, w) X(H2O, h2o) X(O3, o3) X(LWC, lwc) X(RWC, rwc) X(IWC, iwc)           \
+  X(SWC, swc) X(CC, cc) X(PCT, pct) X(PCB, pcb) X(CL, cl) X(PLCL, plcl) X(PLFC, plfc) X(PEL, pel)         \
+  X(CAPE, cape) X(CIN, cin) X(O3C, o3c) X(VH, vh) X(VZ, vz) X(PSAT, psat) X(PSICE, psice) X(PW, pw)       \
+  X(SH, sh) X(RH, rh) X(RHICE, rhice) X(THETA, theta) X(ZETA_D, zeta_d) X(TVIRT, tvirt)                  \
+  X(LAPSE, lapse) X(PV, pv) X(TDEW, tdew) X(TICE, tice)
+
+static void hip_ctl(const ctl_t *c, mphip_ctl_t *d) {
+  memset(d, 0, sizeof(*d));
+#define X(f) d->f = c->f;
+  HIP_CTL_SAME_NAME(X)
+#undef X
+#define X(E, f) d->qnt_met[MPHIP_MQ_##E] = c->qnt_##f;
+  HIP_CTL_METEO_QNT(X)
+#undef X
+  for (int k = 0; k < 2; k++) {
+    d->wet_depo_pre[k] = c->wet_depo_pre[k];
+    d->wet_depo_ic_h[k] = c->wet_depo_ic_h[k];
+    d->wet_depo_bc_h[k] = c->wet_depo_bc_h[k];
+  }
+  /* what the device does not implement must not run silently on stale host data */
+  if (c->oh_chem_reaction != 0 || c->h2o2_chem_reaction != 0 || c->kpp_chem || c->tracer_chem || c->radio_decay)
+    ERRMSG("MPTRAC_HIP: chemistry and radioactive decay are not implemented on the device!");
+  if (c->qnt_hno3 >= 0 || c->qnt_oh >= 0 || c->qnt_h2o2 >= 0 || c->qnt_ho2 >= 0 || c->qnt_o1d >= 0 || c->qnt_tnat >= 0
+      || c->qnt_tsts >= 0)
+    ERRMSG("MPTRAC_HIP: the climatology-based quantities of module_meteo are not implemented on the device!");
+}
+
+/* level fields: met_t member -> MPHIP_* slot (float [EX][EY][EP]); the model-level ones use met->npl levels */
+#define HIP_MET_3D(X)                                                                                    \
+  X(U, u) X(V, v) X(W, w) X(T, t) X(LWC, lwc) X(RWC, rwc) X(IWC, iwc) X(SWC, swc) X(H2O, h2o)             \
+  X(Z, z) X(PV, pv) X(O3, o3) X(CC, cc)                                                                  \
+  X(PL, pl) X(UL, ul) X(VL, vl) X(WL, wl) X(ZETAL, zetal) X(ZETA_DOTL, zeta_dotl)
+/* surface fields (float [EX][EY]) */
+#define HIP_MET_2D(X)                                                                                    \
+  X(PS, ps) X(PBL, pbl) X(CAPE, cape) X(CIN, cin) X(PEL, pel) X(PCT, pct) X(PCB, pcb) X(CL, cl)           \
+  X(ESS, ess) X(NSS, nss) X(SHF, shf) X(TS, ts) X(ZS, zs) X(US, us) X(VS, vs) X(LSM, lsm) X(SST, sst)     \
+  X(PT, pt) X(TT, tt) X(ZT, zt) X(H2OT, h2ot) X(PLCL, plcl) X(PLFC, plfc) X(O3C, o3c)
+
+static void hip_met_view(met_t *m, mphip_met_t *v) {
+  memset(v, 0, sizeof(*v));
+  v->time = m->time;
+  v->coord_type = m->coord_type;
+  v->nx = m->nx;
+  v->ny = m->ny;
+  v->np = m->np;
+  v->npl = m->npl;
+  v->lon = m->lon;
+  v->lat = m->lat;
+  v->p = m->p;
+  v->sx = v->sx_ml = (long long) EY * EP;   /* float u[EX][EY][EP] */
+  v->sy = v->sy_ml = EP;
+  v->sx2 = EY;                              /* float ps[EX][EY] */
+#define X(E, f) v->f3[MPHIP_##E] = &m->f[0][0][0];
+  HIP_MET_3D(X)
+#undef X
+#define X(E, f) v->f2[MPHIP_##E] = &m->f[0][0];
+  HIP_MET_2D(X)
+#undef X
+}
+
+void mptrac_hip_alloc(const int rank) {
+  int ndev = 1;
+  if (mphip_create(&hip_ctx, rank % ndev) != 0)
+    ERRMSG("MPTRAC_HIP: no usable HIP device!");
+}
+
+void mptrac_hip_free(void) {
+  mphip_destroy(hip_ctx);
+  hip_ctx = NULL;
+}
+
+void mptrac_hip_update_device(const ctl_t *ctl, const cache_t *cache, const clim_t *clim, met_t **met0,
+                              met_t **met1, const atm_t *atm) {
+  if (ctl != NULL) {
+    mphip_ctl_t d;
+    hip_ctl(ctl, &d);
+    HIPCALL(mphip_update_ctl(hip_ctx, &d));
+    hip_nq = ctl->nq;
+  }
+  if (clim != NULL)
+    HIPCALL(mphip_update_clim(hip_ctx, clim->tropo_ntime, clim->tropo_nlat, clim->tropo_time, clim->tropo_lat,
+                              &clim->tropo[0][0], 73));
+  mphip_met_t v;
+  if (met0 != NULL) {
+    hip_met_view(*met0, &v);
+    HIPCALL(mphip_update_met(hip_ctx, 0, &v));
+  }
+  if (met1 != NULL) {
+    hip_met_view(*met1, &v);
+    HIPCALL(mphip_update_met(hip_ctx, 1, &v));
+  }
+  if (atm != NULL) {
+    const double *q[NQ];
+    for (int iq = 0; iq < hip_nq; iq++)
+      q[iq] = atm->q[iq];
+    HIPCALL(mphip_update_atm(hip_ctx, atm->np, 0, atm->np, hip_nq, atm->time, atm->p, atm->lon, atm->lat, q));
+  }
+  if (cache != NULL) {
+    HIPCALL(mphip_update_cache(hip_ctx, &cache->uvwp[0][0], &rng_ctr));
+    HIPCALL(mphip_update_iso(hip_ctx, cache->iso_var, cache->iso_n > 0 ? cache->iso_ts : NULL,
+                             cache->iso_n > 0 ? cache->iso_ps : NULL, cache->iso_n));
+  }
+}
+
+void mptrac_hip_update_host(cache_t *cache, atm_t *atm) {
+  if (atm != NULL) {
+    double *q[NQ];
+    for (int iq = 0; iq < hip_nq; iq++)
+      q[iq] = atm->q[iq];
+    HIPCALL(mphip_get_atm(hip_ctx, atm->time, atm->p, atm->lon, atm->lat, q));
+  }
+  if (cache != NULL)
+    HIPCALL(mphip_get_cache(hip_ctx, &cache->uvwp[0][0], cache->dt, &rng_ctr));
+}
+
+/* next to `mets = *met1; *met1 = *met0; *met0 = mets;`: the device slots trade places, nothing is copied */
+void mptrac_hip_swap_met(void) {
+  HIPCALL(mphip_swap_met(hip_ctx));
+}
+
+/* the whole body of mptrac_run_timestep: module order, gating (SORT_DT, CONV_DT, MIXING_DT, MET_DT_OUT ...)
+ * and the rng_ctr bookkeeping are reproduced inside the back end */
+void mptrac_hip_run_timestep(const double t) {
+  HIPCALL(mphip_run_timestep(hip_ctx, t));
+}
+
+/* write_grid: np[idx], mean[iq][idx], sigma[iq][idx] as flat arrays with idx = ARRAY_3D(ix, iy, ny, iz, nz) */
+void mptrac_hip_grid_sums(const double t, int *np, double *mean, double *sigma) {
+  HIPCALL(mphip_grid_sums(hip_ctx, t, np, mean, sigma));
+}
+
+#endif   /* MPTRAC_HIP */

@@ -68,3 +68,17 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 for pat in (r"^\s*(from|import)\s+oracle", r"mptrac_oracle", r"orc_[a-z_]+\(", r"oracle/"):
                     assert not re.search(pat, txt, flags=re.M), f"{f} reaches into the oracle ({pat})"
+
+
+def test_integration_glue_names_only_members_the_reference_has():
+    """integration/mptrac_hip_glue.c (route A of INTEGRATION.md) is written against the reference's own
+    structs; every ctl_t / met_t / clim_t / cache_t / atm_t member it names must exist in the reference's
+    src/mptrac.h and every member of mphip_ctl_t must be filled.  Runs where the reference tree is present."""
+    import subprocess
+    import sys
+    if not os.path.exists("/root/reference/src/mptrac.h"):
+        pytest.skip("reference tree not present on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "integration", "check_glue_fields.py")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
