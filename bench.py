@@ -103,29 +103,61 @@ def build_inputs(workload, rank, world, steps_total, particles=None):
     return ctl, load_clim_tropo(), met0, met1, atm, n_per_gpu, n_total
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(workload, ctl, clim, met0, met1, atm, n_sample, n_steps):
-    """The OpenMP oracle (oracle/, "port") on the first n_sample particles of
-    the same workload, all usable host cores."""
+    """The OpenMP oracle (oracle/: this repository's C restatement of the reference's CPU path, "port" -- the
+    reference itself cannot be built in this image) on the first n_sample particles of the same
+    workload: all usable host cores, and one thread on a tenth of the sample."""
     from oracle import binding as B
-    cores = B.lib().orc_set_num_threads(B.usable_cores())
-    sub = {k: (v[:n_sample].copy() if k != "q" else v[:, :n_sample].copy()) for k, v in atm.items()}
-    o = B.Oracle(ctl, clim, met0, met1, sub)
-    o.timesteps_init()
-    dt = o.ctl.dt_mod
-    o.run_timestep(0.0)            # the dt = 0 first call (moves nothing)
-    o.run_timestep(dt)             # warm-up step
-    t0 = time.time()
-    for k in range(2, 2 + n_steps):
-        o.run_timestep(k * dt)
-    wall = time.time() - t0
-    return {"value": n_sample * n_steps / wall, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_sample} particles of workload {workload}, {n_steps} steps, OpenMP oracle"}
+
+    def timed(n, steps, threads):
+        used = B.lib().orc_set_num_threads(threads)
+        sub = {k: (v[:n].copy() if k != "q" else v[:, :n].copy()) for k, v in atm.items()}
+        o = B.Oracle(ctl, clim, met0, met1, sub)
+        o.timesteps_init()
+        dt = o.ctl.dt_mod
+        o.run_timestep(0.0)            # the dt = 0 first call (moves nothing)
+        o.run_timestep(dt)             # warm-up step
+        t0 = time.time()
+        for k in range(2, 2 + steps):
+            o.run_timestep(k * dt)
+        return n * steps / (time.time() - t0), used
+    rate, cores = timed(n_sample, n_steps, B.usable_cores())
+    n1 = max(1000, n_sample // 10)
+    rate1, _ = timed(n1, max(2, n_steps // 2), 1)
+    return {"value": rate, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "nproc": os.cpu_count(), "value_1_thread": rate1,
+            "sample": f"first {n_sample} particles of workload {workload}, {n_steps} steps, OpenMP oracle "
+                      f"({cores} threads); 1 thread: first {n1} particles, {max(2, n_steps // 2)} steps"}
+
+
+def build_id():
+    """Hash of the kernel sources: ties the committed PMC profile (profiles/pmc_traffic.json) to the build it
+    was taken from."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "mptrac_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)   # one meteo interval of the survey's control set (T_STOP 3600, DT_MOD 180)
+    # 60 steps = three meteo intervals of the survey's control set (DT_MOD 180) and exactly one re-sort of the
+    # internal locality order (every 60 steps) inside the timed region, whatever its phase
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--particles", type=float, default=0,
@@ -236,8 +268,9 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             prof = json.load(open(tfile))
-            traffic = prof.get(args.workload)
-            valu_busy = prof.get("_valu_busy_frac", {}).get(args.workload)
+            if prof.get("_build_id") == build_id():      # counters of THIS build only (tools/profile.sh)
+                traffic = prof.get(args.workload)
+                valu_busy = prof.get("_valu_busy_frac", {}).get(args.workload)
         if args.particles:      # the committed PMC profile belongs to the workload's own particle count
             traffic = valu_busy = None
         out = {
@@ -266,7 +299,7 @@ def main():
                          "bytes_per_particle_step": a_per,
                          # SURVEY 8(d) caveat: the fused step is fp64-VALU-bound, not HBM-bound; share of SIMD
                          # cycles executing VALU instructions from the committed rocprofv3 PMC profile
-                         "valu_busy_frac": valu_busy},
+                         "valu_busy_frac": valu_busy, "build_id": build_id()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, ctl, clim, met0, met1, atm,

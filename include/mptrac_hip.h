@@ -229,6 +229,9 @@ int mphip_get_iso(mphip_ctx *ctx, double *iso_var);
 
 /* mptrac_run_timestep, mptrac.c:7851-8001: the reference's module order and
  * gating, fused into as few launches as the order allows. */
+/* module_mixing (mptrac.c:5169-5347) mixes the quantities of the hot path -- mass, volume mixing ratio, age
+ * of air (qnt_m, qnt_vmr, qnt_aoa) -- in one pass; the chemistry and radionuclide quantities of the
+ * reference's list (mptrac.c:5223-5230) are not part of this back end and are left untouched. */
 int mphip_run_timestep(mphip_ctx *ctx, double t);
 /* One reference module_* on its own (same state hand-over through the device
  * copy of cache->dt); `modules` is one MPHIP_MOD_* bit or an OR of the

@@ -37,6 +37,7 @@ struct MetSlot {
   float *f2[MPHIP_N2D] = {};
   bool has3[MPHIP_N3D] = {};
   bool has2[MPHIP_N2D] = {};
+  std::vector<double> lon, lat, p;    // the snapshot's own axes: the reference interpolates on those of the current met0
   float ps11 = 0.f;                   // ps at grid node [1][1] (module_position reflects there)
 };
 
@@ -46,6 +47,7 @@ struct mphip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
+  std::mutex err_lock;
 
   mphip_ctl_t ctl;
   bool have_ctl = false;
@@ -149,8 +151,10 @@ struct mphip_ctx {
 namespace {
 
 int fail(mphip_ctx *ctx, const std::string &msg) {
-  if (ctx)
+  if (ctx) {   // (the uploader thread of mphip_prefetch_met reports through here too)
+    std::lock_guard<std::mutex> guard(ctx->err_lock);
     ctx->err = msg;
+  }
   return 1;
 }
 
@@ -361,6 +365,16 @@ int ensure_packed(mphip_ctx *ctx) {
   const MetSlot &s0 = ctx->slot[0 ^ ctx->flip], &s1 = ctx->slot[1 ^ ctx->flip];
   if (!s0.valid || !s1.valid)
     return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
+  // after a hand-over (mphip_swap_met / mphip_commit_met) the new met0 is the old met1: the reference accepts
+  // axes that differ by up to 1e-3 between files (mptrac.c:6543-6556) and always uses those of the current
+  // met0, so the device axes follow it
+  if (!s0.lon.empty() && (s0.lon != ctx->h_lon || s0.lat != ctx->h_lat || s0.p != ctx->h_p)) {
+    ctx->h_lon = s0.lon;
+    ctx->h_lat = s0.lat;
+    ctx->h_p = s0.p;
+    if (upload_axes(ctx))
+      return 1;
+  }
   const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
   PackArgs a;
   bool any_cloud = false, any_ml = false, any_pbl = false, any_mx = false, any_mx2 = false;
@@ -1335,6 +1349,15 @@ int mphip_update_ctl(mphip_ctx *ctx, const mphip_ctl_t *ctl) {
     return fail(ctx, "Set ADVECT_VERT_COORD to 0, 1, 2, or 3!");
   if (!(ctl->advect == 0 || ctl->advect == 1 || ctl->advect == 2 || ctl->advect == 4))
     return fail(ctx, "Set ADVECT to 1, 2, or 4!");
+  // module_meteo runs after the loss / mixing / deposition modules here and is evaluated lazily: none of the
+  // quantities it fills may be one those modules read or write
+  for (int k = 0; k < MPHIP_NMQ; k++)
+    if (ctl->qnt_met[k] >= 0)
+      for (int other : { ctl->qnt_m, ctl->qnt_vmr, ctl->qnt_aoa, ctl->qnt_loss_rate, ctl->qnt_mloss_decay,
+                         ctl->qnt_mloss_wet, ctl->qnt_mloss_dry, ctl->qnt_rp, ctl->qnt_rhop, ctl->qnt_ens,
+                         ctl->qnt_zeta, ctl->qnt_eta })
+        if (ctl->qnt_met[k] == other)
+          return fail(ctx, "a module_meteo quantity shares its index with a mass / mixing-ratio / loss / particle quantity");
   if (ctx->have_ctl && flush_meteo(ctx))   // a deferred module_meteo belongs to the old parameters
     return 1;
   if (!ctx->have_ctl || ctx->ctl.advect_vert_coord != ctl->advect_vert_coord)
@@ -1433,15 +1456,18 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     ctx->d_cloud = ctx->d_sfa = ctx->d_sfb = ctx->d_sfc = ctx->d_sfd = nullptr;
   }
   ctx->coord_type = met->coord_type;
+  MetSlot &S = ctx->slot[slot ^ ctx->flip];
+  S.lon.assign(met->lon, met->lon + met->nx);
+  S.lat.assign(met->lat, met->lat + met->ny);
+  S.p.assign(met->p, met->p + met->np);
   // the reference interpolates on met0's axes (mptrac.c:3010-3020); slot 0 defines them
   if (slot == 0 || new_grid || ctx->h_lon.empty()) {
-    ctx->h_lon.assign(met->lon, met->lon + met->nx);
-    ctx->h_lat.assign(met->lat, met->lat + met->ny);
-    ctx->h_p.assign(met->p, met->p + met->np);
+    ctx->h_lon = S.lon;
+    ctx->h_lat = S.lat;
+    ctx->h_p = S.p;
     if (upload_axes(ctx))
       return 1;
   }
-  MetSlot &S = ctx->slot[slot ^ ctx->flip];
   if (upload_fields(ctx, S, met, new_grid, ctx->stream))
     return 1;
   HIPCHK(hipStreamSynchronize(ctx->stream));   // the host arrays may be reused by the caller
@@ -1519,6 +1545,9 @@ int mphip_prefetch_met(mphip_ctx *ctx, const mphip_met_t *met) {
   ctx->uploader_err.clear();
   ctx->next_pending = true;
   ctx->next.time = met->time;
+  ctx->next.lon.assign(met->lon, met->lon + met->nx);
+  ctx->next.lat.assign(met->lat, met->lat + met->ny);
+  ctx->next.p.assign(met->p, met->p + met->np);
   ctx->uploader = std::thread([ctx, desc]() {
     int rc = hipSetDevice(ctx->device) == hipSuccess ? 0 : 1;
     if (!rc)

@@ -213,6 +213,41 @@ def test_met_swap_over_two_intervals():
     s.close()
 
 
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_axes_follow_met0_across_a_handover(prefetch):
+    """The reference tolerates axes that differ by up to 1e-3 between meteo files (mptrac.c:6543-6556) and always
+    interpolates and sorts on the axes of the current met0: after a hand-over those are the old met1's.  Three
+    snapshots whose latitude / pressure axes differ by a few 1e-4."""
+    from mptrac_amd.synth import Met
+    ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=3000)
+    ctl.update(t_stop=7200.0, sort_dt=720.0)
+
+    def shifted(m, dlat, fp):
+        return Met(m.time, m.lon, m.lat + dlat, m.p * fp, m.f3, m.f2)
+    m2 = synthetic_met("C1", 7200.0, 0.8, fields=cases.PRESSURE_LEVEL_FIELDS)
+    m1, m2 = shifted(m1, 4e-4, 1.0 + 3e-7), shifted(m2, -3e-4, 1.0 - 2e-7)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    if prefetch:
+        s.prefetch_met(m2)
+    swapped = False
+    for t in cases.step_times(o.ctl):
+        if t > 3600.0 and not swapped:
+            o.swap_met(m2)
+            if prefetch:
+                s.commit_met()
+            else:
+                s.swap_met(m2)
+            swapped = True
+        o.run_timestep(t)
+        s.run_timestep(t)
+    assert swapped
+    _compare(o, s)
+    s.close()
+
+
 @pytest.mark.parametrize("case", ["diff", "full", "zeta_full", "bound_pbl_zeta"])
 def test_met_prefetch_and_commit_equal_the_synchronous_swap(case):
     """mphip_prefetch_met / mphip_commit_met (upload of the next snapshot on a copy stream beside the
