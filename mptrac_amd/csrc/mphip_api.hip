@@ -136,6 +136,9 @@ struct mphip_ctx {
 
   int *d_cnt = nullptr;               // particles per mixing cell (32-bit: the reference's `int count[]`)
   size_t cnt_cap = 0;
+  int deterministic_sums = 1;         // cell sums in the reference's serial order (0: floating-point atomics)
+  unsigned long long *d_lists = nullptr;   // work space of the ordered sums (sequence, runs, sort buffers)
+  size_t lists_cap = 0;
 
   mphip_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
@@ -815,21 +818,16 @@ void perm_swap(mphip_ctx *ctx, bool with_cache) {
   }
 }
 
-// keys + stable LSD radix sort of (key, index); returns the buffer holding the result
-int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep_t = nullptr) {
-  const long long n = ctx->np;
+// stable LSD radix sort of n (key, value) pairs that starts in keys[0] / vals[0] and ping-pongs between the two
+// buffer pairs; *cur_out = the pair that holds the result
+// (n_dev: the number of pairs lives on the device and n is only its upper bound)
+int radix_passes(mphip_ctx *ctx, uint32_t *const keys[2], int *const vals[2], long long n, int key_bits, int *cur_out,
+                 const uint32_t *n_dev = nullptr) {
+  *cur_out = 0;
+  if (n <= 0)
+    return 0;
   const int ntiles = (int) ((n + kSortTile - 1) / kSortTile);
-  // number of key bits that can be non-zero -> digit width with the fewest passes (8 bits if it is a tie)
-  unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
-  if (tile > 0) {
-    const unsigned long long ntx = (ctx->nx + tile - 1) / tile, nty = (ctx->ny + tile - 1) / tile;
-    kmax = ntx * nty * ctx->npl * tile * tile;
-  }
-  if (kmax > 0xffffffffULL)
-    return fail(ctx, "meteo grid too large for the 32-bit sort key");
-  int key_bits = 1;
-  while (key_bits < 32 && (kmax >> key_bits) != 0)
-    key_bits++;
+  // digit width with the fewest passes (8 bits if it is a tie)
   int bits = ctx->sort_bits;
   if (bits == 0) {
     bits = 8;
@@ -841,30 +839,24 @@ int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep
   const size_t m = ((size_t) 1 << bits) * ntiles;
   const int nchunks = (int) ((m + kScanChunk - 1) / kScanChunk);
   if (nchunks > kScanThreads)
-    return fail(ctx, "too many particles for the two-level scan of module_sort");
+    return fail(ctx, "too many particles for the two-level scan of the radix sort");
   if (m + kScanThreads > ctx->counts_cap) {
     if (dev_alloc(ctx, &ctx->d_counts, m + kScanThreads))   // counters + chunk totals
       return 1;
     ctx->counts_cap = m + kScanThreads;
   }
   uint32_t *d_chunks = ctx->d_counts + m;
-  const DevMet M = dev_met(ctx);
-  const DevAtm a = dev_atm(ctx);
-  TimestepArgs ts = { (double) ctx->ctl.direction, ctx->ctl.t_start, ctx->ctl.t_stop, timestep_t ? *timestep_t : 0.0 };
-  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
-                     ctx->d_keys[0], ctx->d_vals[0], ts, timestep_t ? ctx->d_dt : nullptr);
   int cur = 0;
   for (int pass = 0; pass < passes; pass++) {
     const int shift = bits * pass;
 #define SORT_PASS(B)                                                                                                   \
-  hipLaunchKernelGGL(sort_hist_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur], n, shift, \
-                     ntiles, ctx->d_counts);                                                                           \
+  hipLaunchKernelGGL(sort_hist_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur], n, shift,       \
+                     ntiles, ctx->d_counts, n_dev);                                                                    \
   hipLaunchKernelGGL(sort_scan_local_kernel, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream, ctx->d_counts, m,      \
-                     d_chunks);                                                                                        \
+                     d_chunks, (const uint32_t *) nullptr);                                                            \
   hipLaunchKernelGGL(sort_scan_chunks_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_chunks, nchunks);         \
-  hipLaunchKernelGGL(sort_scatter_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, ctx->d_keys[cur],       \
-                     ctx->d_vals[cur], ctx->d_keys[cur ^ 1], ctx->d_vals[cur ^ 1], n, shift, ntiles, ctx->d_counts,    \
-                     d_chunks)
+  hipLaunchKernelGGL(sort_scatter_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur], vals[cur],   \
+                     keys[cur ^ 1], vals[cur ^ 1], n, shift, ntiles, ctx->d_counts, d_chunks, n_dev)
     if (bits == 8) {
       SORT_PASS(8);
     } else if (bits == 9) {
@@ -876,8 +868,33 @@ int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep
     cur ^= 1;
   }
   HIPCHK(hipGetLastError());
-  *result_buf = cur;
+  *cur_out = cur;
   return 0;
+}
+
+int bits_for(unsigned long long kmax) {   // number of key bits that can be non-zero for keys <= kmax
+  int key_bits = 1;
+  while (key_bits < 32 && (kmax >> key_bits) != 0)
+    key_bits++;
+  return key_bits;
+}
+
+// module_sort keys + sort of (key, index); returns the buffer holding the result
+int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep_t = nullptr) {
+  const long long n = ctx->np;
+  unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
+  if (tile > 0) {
+    const unsigned long long ntx = (ctx->nx + tile - 1) / tile, nty = (ctx->ny + tile - 1) / tile;
+    kmax = ntx * nty * ctx->npl * tile * tile;
+  }
+  if (kmax > 0xffffffffULL)
+    return fail(ctx, "meteo grid too large for the 32-bit sort key");
+  const DevMet M = dev_met(ctx);
+  const DevAtm a = dev_atm(ctx);
+  TimestepArgs ts = { (double) ctx->ctl.direction, ctx->ctl.t_start, ctx->ctl.t_stop, timestep_t ? *timestep_t : 0.0 };
+  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
+                     ctx->d_keys[0], ctx->d_vals[0], ts, timestep_t ? ctx->d_dt : nullptr);
+  return radix_passes(ctx, ctx->d_keys, ctx->d_vals, n, bits_for(kmax), result_buf);
 }
 
 // put every per-particle array back into the external slot order
@@ -1103,6 +1120,73 @@ AccumGeom accum_geom(const mphip_ctx *ctx, int nv) {
   return g;
 }
 
+// Sums of VALS per cell in the reference's serial order (steps 1-4 of "Cell sums" in mphip_kernels.hpp).
+// ctx->d_cell holds the cell of every stored particle; writes sums[v * ntot + cell] (nv values) and the counts
+// as integers and / or doubles (either may be NULL).
+template <class VALS>
+int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size_t ntot, double *sums, int *cnt,
+                      double *cnt_as_double) {
+  const long long n = ctx->np;
+  // cells per group: a vertical column of the grid if that fits the table in LDS
+  const int G = column >= 1 && column <= kGroupMax ? column : kGroupMax;
+  const size_t ngroups = (ntot + G - 1) / G;
+  if (ntot >= 0x7fffffffULL)
+    return fail(ctx, "too many grid cells for 32-bit cell indices");
+  HIPCHK(hipMemsetAsync(sums, 0, (size_t) nv * ntot * sizeof(double), ctx->stream));
+  if (cnt)
+    HIPCHK(hipMemsetAsync(cnt, 0, ntot * sizeof(int), ctx->stream));
+  if (cnt_as_double)
+    HIPCHK(hipMemsetAsync(cnt_as_double, 0, ntot * sizeof(double), ctx->stream));
+  if (n == 0)
+    return 0;
+  // one allocation, 32-bit words: [sequence cell | sequence slot | keys 0 | ids 0 | keys 1 | ids 1 | run starts
+  // (n + 1) | runs per tile (ntiles + 1)]
+  const int ntiles = (int) ((n + kRunTile - 1) / kRunTile);
+  const size_t words32 = 7 * (size_t) n + 1 + (size_t) ntiles + 1;
+  if ((words32 + 1) / 2 > ctx->lists_cap) {
+    if (dev_alloc(ctx, &ctx->d_lists, (words32 + 1) / 2))
+      return 1;
+    ctx->lists_cap = (words32 + 1) / 2;
+  }
+  uint32_t *base = (uint32_t *) ctx->d_lists;
+  int *seq_cell = (int *) base, *seq_slot = (int *) (base + n);
+  uint32_t *keys[2] = { base + 2 * n, base + 4 * n };
+  int *ids[2] = { (int *) (base + 3 * n), (int *) (base + 5 * n) };
+  uint32_t *run_start = base + 6 * n, *tile_runs = base + 7 * n + 1;
+  const int *seq = ctx->d_cell;
+  if (!ctx->ext_identity) {
+    hipLaunchKernelGGL(cell_pairs_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_cell, ctx->d_ext, n,
+                       seq_cell, seq_slot);
+    seq = seq_cell;
+  } else {
+    seq_slot = nullptr;
+  }
+  hipLaunchKernelGGL(run_heads_count_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, seq, n, G, tile_runs);
+  hipLaunchKernelGGL(run_offsets_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, tile_runs, ntiles);
+  hipLaunchKernelGGL(run_compact_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, seq, n, G, tile_runs, ntiles,
+                     (uint32_t) ngroups, keys[0], ids[0], run_start);
+  // the number of runs stays on the device (tile_runs[ntiles]): the launches below cover the upper bound n and
+  // read it there, the host does not wait
+  const uint32_t *nruns_dev = tile_runs + ntiles;
+  int cur = 0;
+  if (radix_passes(ctx, keys, ids, n, bits_for(ngroups), &cur, nruns_dev))
+    return 1;
+  const int nblocks = (int) std::min<long long>((n + 255) / 256, 16384);
+  hipLaunchKernelGGL(cell_sum_groups_kernel<VALS>, dim3(nblocks), dim3(256), 0, ctx->stream, vals, keys[cur], ids[cur],
+                     nruns_dev, (uint32_t) ngroups, run_start, seq, seq_slot, G, ntot, sums, cnt, cnt_as_double);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ensure_cell_counts(mphip_ctx *ctx, size_t ntot) {
+  if (ntot > ctx->cnt_cap) {
+    if (dev_alloc(ctx, &ctx->d_cnt, ntot))
+      return 1;
+    ctx->cnt_cap = ntot;
+  }
+  return 0;
+}
+
 int do_mixing(mphip_ctx *ctx, double t) {
   const mphip_ctl_t &c = ctx->ctl;
   if (!ctx->have_clim)
@@ -1123,30 +1207,35 @@ int do_mixing(mphip_ctx *ctx, double t) {
   const bool hook = !ctx->comm && ctx->allreduce;
   if (ensure_sums(ctx, ((size_t) mq.n + (hook ? 1 : 0)) * ntot))
     return 1;
-  if (ntot > ctx->cnt_cap) {
-    if (dev_alloc(ctx, &ctx->d_cnt, ntot))
-      return 1;
-    ctx->cnt_cap = ntot;
-  }
+  if (ensure_cell_counts(ctx, ntot))
+    return 1;
   BoxGrid G = { c.mixing_lon0, c.mixing_lon1, c.mixing_lat0, c.mixing_lat1, c.mixing_z0, c.mixing_z1,
                 c.mixing_nx, c.mixing_ny, c.mixing_nz };
   const int nb = grid_for(std::max<long long>(ctx->np, 1));
-  HIPCHK(hipMemsetAsync(ctx->d_sums, 0, (size_t) mq.n * ntot * sizeof(double), ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_cnt, 0, ntot * sizeof(int), ctx->stream));
   const double *ens = (c.nens > 0 && c.qnt_ens >= 0) ? a.q[c.qnt_ens] : nullptr;
-  if (ctx->np) {
+  const bool ordered = ctx->deterministic_sums != 0;
+  if (ctx->np)
     hipLaunchKernelGGL(box_index_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
-                       t + 0.5 * c.dt_mod, ctx->d_cell);
-    const AccumGeom g = accum_geom(ctx, mq.n + 1);
-    hipLaunchKernelGGL(mix_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, mq, ens,
-                       ngrid, ntot, ctx->d_sums, ctx->d_cnt, g.T, g.per_block);
+                       t + 0.5 * c.dt_mod, ctx->d_cell, ens, ngrid);
+  if (ordered) {
+    MixVals vals = { mq };
+    if (ordered_cell_sums(ctx, vals, mq.n, c.mixing_nz, ntot, ctx->d_sums, ctx->d_cnt, (double *) nullptr))
+      return 1;
+  } else {
+    HIPCHK(hipMemsetAsync(ctx->d_sums, 0, (size_t) mq.n * ntot * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_cnt, 0, ntot * sizeof(int), ctx->stream));
+    if (ctx->np) {
+      const AccumGeom g = accum_geom(ctx, mq.n + 1);
+      hipLaunchKernelGGL(mix_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, mq, ntot,
+                         ctx->d_sums, ctx->d_cnt, g.T, g.per_block);
+    }
   }
   // one exchange per mixing step: the sums of every mixed quantity and the cell counts
   if (run_allreduce(ctx, ctx->d_sums, (size_t) mq.n * ntot, ctx->d_cnt, ntot, ctx->d_sums + (size_t) mq.n * ntot))
     return 1;
   if (ctx->np)
-    hipLaunchKernelGGL(mix_relax_kernel, dim3(nb), dim3(256), 0, ctx->stream, c, ctx->d_clim, a, ctx->d_cell, mq, ens,
-                       ngrid, ntot, ctx->d_sums, ctx->d_cnt);
+    hipLaunchKernelGGL(mix_relax_kernel, dim3(nb), dim3(256), 0, ctx->stream, c, ctx->d_clim, a, ctx->d_cell, mq, ntot,
+                       ctx->d_sums, ctx->d_cnt);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1328,6 +1417,7 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_cell);
   dev_free(ctx->d_sums);
   dev_free(ctx->d_cnt);
+  dev_free(ctx->d_lists);
   for (auto e : ctx->ev)
     (void) hipEventDestroy(e);
   (void) hipStreamDestroy(ctx->stream);
@@ -1971,19 +2061,31 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
   const size_t total = ncell * (size_t) (1 + 2 * ctx->nq);
   if (ensure_sums(ctx, total))
     return 1;
-  HIPCHK(hipMemsetAsync(ctx->d_sums, 0, total * sizeof(double), ctx->stream));
+  const bool ordered = ctx->deterministic_sums != 0;
+  const DevAtm a = dev_atm(ctx);
   if (ctx->np) {
-    const DevAtm a = dev_atm(ctx);
     BoxGrid G = { c.grid_lon0, c.grid_lon1, c.grid_lat0, c.grid_lat1, c.grid_z0, c.grid_z1, c.grid_nx, c.grid_ny,
                   c.grid_nz };
-    const int nb = grid_for(ctx->np);
-    hipLaunchKernelGGL(box_index_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
-                       t + 0.5 * c.dt_mod, ctx->d_cell);
-    const AccumGeom g = accum_geom(ctx, 1 + 2 * ctx->nq);
-    hipLaunchKernelGGL(grid_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, ctx->nq,
-                       ncell, ctx->d_sums, g.T, g.per_block);
-    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(box_index_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
+                       t + 0.5 * c.dt_mod, ctx->d_cell, (const double *) nullptr, 0);
   }
+  if (ordered) {
+    GridVals vals;
+    for (int iq = 0; iq < ctx->nq; iq++)
+      vals.q[iq] = a.q[iq];
+    vals.nq = ctx->nq;
+    // [counts | sums of q | sums of q^2], as grid_accumulate_kernel
+    if (ordered_cell_sums(ctx, vals, 2 * ctx->nq, c.grid_nz, ncell, ctx->d_sums + ncell, (int *) nullptr, ctx->d_sums))
+      return 1;
+  } else {
+    HIPCHK(hipMemsetAsync(ctx->d_sums, 0, total * sizeof(double), ctx->stream));
+    if (ctx->np) {
+      const AccumGeom g = accum_geom(ctx, 1 + 2 * ctx->nq);
+      hipLaunchKernelGGL(grid_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, ctx->nq,
+                         ncell, ctx->d_sums, g.T, g.per_block);
+    }
+  }
+  HIPCHK(hipGetLastError());
   if (run_allreduce(ctx, ctx->d_sums, total))
     return 1;
   std::vector<double> h(total);
@@ -2096,6 +2198,14 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (!(value == 0 || (value >= 8 && value <= kRadixMaxBits)))
       return fail(ctx, "sort_bits must be 0 (automatic), 8, 9 or 10");
     ctx->sort_bits = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "deterministic_sums") == 0) {
+    // 1 (default): cell sums of module_mixing / the gridded output add in the reference's serial order;
+    // 0: floating-point atomics (order of arrival)
+    if (!(value == 0 || value == 1))
+      return fail(ctx, "deterministic_sums must be 0 or 1");
+    ctx->deterministic_sums = (int) value;
     return 0;
   }
   if (strcmp(name, "locality_tile") == 0) {

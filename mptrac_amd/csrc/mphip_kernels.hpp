@@ -766,8 +766,11 @@ constexpr int kRadixMaxBits = 10;
 // per-tile digit histogram -> counts[digit * ntiles + tile]
 template <int BITS>
 __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t *__restrict__ keys, long long n,
-                                                                 int shift, int ntiles, uint32_t *__restrict__ counts) {
+                                                                 int shift, int ntiles, uint32_t *__restrict__ counts,
+                                                                 const uint32_t *__restrict__ n_dev = nullptr) {
   constexpr int kRadix = 1 << BITS;
+  if (n_dev)   // the number of pairs is only known on the device; the launch covers an upper bound
+    n = (long long) *n_dev;
   __shared__ uint32_t h[kRadix];
   for (int d = threadIdx.x; d < kRadix; d += kSortThreads)
     h[d] = 0;
@@ -815,15 +818,25 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
   return off + x - v;
 }
 
+// (`src`: scan these values into `counts` instead of scanning `counts` in place; `largest`: their maximum)
 __global__ __launch_bounds__(kScanThreads) void sort_scan_local_kernel(uint32_t *__restrict__ counts, size_t m,
-                                                                       uint32_t *__restrict__ chunk_sums) {
+                                                                       uint32_t *__restrict__ chunk_sums,
+                                                                       const uint32_t *__restrict__ src = nullptr,
+                                                                       uint32_t *__restrict__ largest = nullptr) {
   __shared__ uint32_t wsum[kScanThreads / 64];
   const size_t base = (size_t) blockIdx.x * kScanChunk + (size_t) threadIdx.x * kScanPer;
-  uint32_t v[kScanPer], sum = 0;
+  uint32_t v[kScanPer], sum = 0, big = 0;
 #pragma unroll
   for (int k = 0; k < kScanPer; k++) {
-    v[k] = base + k < m ? counts[base + k] : 0;
+    v[k] = base + k < m ? (src ? src[base + k] : counts[base + k]) : 0;
     sum += v[k];
+    big = v[k] > big ? v[k] : big;
+  }
+  if (largest) {   // *largest = max over all values (one atomic per wave)
+    for (int d = 32; d > 0; d >>= 1)
+      big = max(big, (uint32_t) __shfl_xor((int) big, d));
+    if ((threadIdx.x & 63) == 0 && big > 0)
+      atomicMax(largest, big);
   }
   uint32_t total;
   uint32_t off = block_exclusive_scan(sum, wsum, &total);
@@ -861,8 +874,11 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
                                                                     uint32_t *__restrict__ keys_out,
                                                                     int *__restrict__ vals_out, long long n, int shift,
                                                                     int ntiles, const uint32_t *__restrict__ offsets,
-                                                                    const uint32_t *__restrict__ chunk_offsets) {
+                                                                    const uint32_t *__restrict__ chunk_offsets,
+                                                                    const uint32_t *__restrict__ n_dev = nullptr) {
   constexpr int kRadix = 1 << BITS;
+  if (n_dev)
+    n = (long long) *n_dev;
   constexpr int kDigitsPerThread = kRadix / kSortThreads;   // 1, 2 or 4 consecutive digits per thread
   constexpr int kWaves = kSortThreads / 64;
   constexpr int kPerWave = kSortTile / kWaves;
@@ -1032,7 +1048,9 @@ struct BoxGrid {
 };
 
 // cell index of every particle, -1 if outside (mptrac.c:5201-5218, 13836-13855)
-__global__ void box_index_kernel(DevAtm a, BoxGrid G, double t0, double t1, int *__restrict__ cell) {
+// (with `ens`: the index inside the ensemble member's copy of the grid, ens * ngrid + cell, mptrac.c:5291-5294)
+__global__ __launch_bounds__(256) void box_index_kernel(DevAtm a, BoxGrid G, double t0, double t1, int *__restrict__ cell,
+                                                        const double *__restrict__ ens, int ngrid) {
   const double dz = (G.z1 - G.z0) / G.nz;
   const double dlon = (G.lon1 - G.lon0) / G.nx;
   const double dlat = (G.lat1 - G.lat0) / G.ny;
@@ -1047,7 +1065,7 @@ __global__ void box_index_kernel(DevAtm a, BoxGrid G, double t0, double t1, int 
       const int iy = (int) ((lat - G.lat0) / dlat);
       const int iz = (int) ((zpart - G.z0) / dz);
       if (!(ix >= G.nx || iy >= G.ny || iz >= G.nz))
-        c = (ix * G.ny + iy) * G.nz + iz;
+        c = (ix * G.ny + iy) * G.nz + iz + (ens ? (int) ens[i] * ngrid : 0);
     }
     cell[i] = c;
   }
@@ -1124,25 +1142,23 @@ struct MixSet {
 };
 
 __global__ __launch_bounds__(256) void mix_accumulate_kernel(DevAtm a, const int *__restrict__ cell, MixSet mq,
-                                                             const double *__restrict__ ens, int ngrid, size_t ntot,
-                                                             double *__restrict__ sums, int *__restrict__ cnt, int T,
-                                                             long long per_block) {
+                                                             size_t ntot, double *__restrict__ sums,
+                                                             int *__restrict__ cnt, int T, long long per_block) {
   extern __shared__ double s_tab[];
   LdsTable tab;
   tab.init(s_tab, T, mq.n + 1);   // value mq.n of an entry: the count
   const long long first = blockIdx.x * per_block;
   const long long last = first + per_block < a.np ? first + per_block : a.np;
   for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
-    const int c = cell[i];
-    if (c >= 0) {
-      const size_t idx = (size_t) (ens ? (int) ens[i] : 0) * (size_t) ngrid + (size_t) c;
-      const int slot = idx < 0x7fffffffu ? tab.slot_for((int) idx) : -1;
+    const int idx = cell[i];
+    if (idx >= 0) {
+      const int slot = tab.slot_for(idx);
       for (int k = 0; k < mq.n; k++) {
         const double v = mq.q[k][i];
         if (slot >= 0)
           tab.add(slot, k, v);
         else
-          unsafeAtomicAdd(&sums[(size_t) k * ntot + idx], v);
+          unsafeAtomicAdd(&sums[(size_t) k * ntot + (size_t) idx], v);
       }
       if (slot >= 0)
         tab.add(slot, mq.n, 1.0);
@@ -1161,26 +1177,301 @@ __global__ __launch_bounds__(256) void mix_accumulate_kernel(DevAtm a, const int
   }
 }
 
+// tropo_weight (mptrac.c:12748-12770, clim_tropo mptrac.c:213-237) in the reference's operation order with true
+// divisions and no fused multiply-adds -- the step kernel's version multiplies by stored reciprocals.  With the
+// ordered cell sums module_mixing then returns the bits of the serial code.
+__device__ double tropo_weight_exact(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat, double p) {
+#pragma clang fp contract(off)
+  if (ctl.met_coord_type != 0)
+    lat = ctl.met_utm_ref_lat;
+  double sec = fmod_trunc(time, 365.25 * 86400.);
+  while (sec < 0)
+    sec += 365.25 * 86400.;
+  const int it = locate_irr(C.time, C.ntime, sec, 1);
+  const int il = locate_reg(C.lat, C.nlat, lat);
+  const double x0 = C.lat[il], x1 = C.lat[il + 1];
+  const double pa = C.tropo[it][il] + (C.tropo[it][il + 1] - C.tropo[it][il]) / (x1 - x0) * (lat - x0);
+  const double pb = C.tropo[it + 1][il] + (C.tropo[it + 1][il + 1] - C.tropo[it + 1][il]) / (x1 - x0) * (lat - x0);
+  const double pt = pa + (pb - pa) / (C.time[it + 1] - C.time[it]) * (sec - C.time[it]);
+  const double p1 = pt * 0.866877899;
+  const double p0 = pt / 0.866877899;
+  if (p > p0)
+    return 1;
+  if (p < p1)
+    return 0;
+  return 1.0 + (0.0 - 1.0) / (p1 - p0) * (p - p0);
+}
+
 // q += (mean - q) * mixparam for every mixed quantity, mptrac.c:5305-5339
 __global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a, const int *__restrict__ cell, MixSet mq,
-                                 const double *__restrict__ ens, int ngrid, size_t ntot,
-                                 const double *__restrict__ sums, const int *__restrict__ cnt) {
+                                 size_t ntot, const double *__restrict__ sums, const int *__restrict__ cnt) {
+#pragma clang fp contract(off)
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
        i += (long long) gridDim.x * blockDim.x) {
-    const int c = cell[i];
-    if (c >= 0) {
-      const size_t idx = (size_t) (ens ? (int) ens[i] : 0) * (size_t) ngrid + (size_t) c;
+    const int idx = cell[i];
+    if (idx >= 0) {
       double mixparam = 1.0;
       if (ctl.mixing_trop < 1 || ctl.mixing_strat < 1) {
-        const double w = tropo_weight(ctl, *clim, a.time[i], a.lat[i], a.p[i]);
+        const double w = tropo_weight_exact(ctl, *clim, a.time[i], a.lat[i], a.p[i]);
         mixparam = w * ctl.mixing_trop + (1.0 - w) * ctl.mixing_strat;
       }
       const int n = cnt[idx];
       for (int k = 0; k < mq.n; k++) {
-        const double sum = sums[(size_t) k * ntot + idx];
+        const double sum = sums[(size_t) k * ntot + (size_t) idx];
         const double mean = n > 0 ? sum / n : sum;
         const double v = mq.q[k][i];
         mq.q[k][i] = v + (mean - v) * mixparam;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Cell sums in the reference's order.  The reference accumulates serially over the particle index
+// (module_mixing mptrac.c:5289-5303, write_grid mptrac.c:13862-13872): cell sum = ((q_a + q_b) + q_c) ... in
+// ascending ip.  Floating-point atomics add in whatever order the hardware serves them, so their sums differ
+// from that in the last bits and from run to run.  Here every cell is owned by one wave, which adds the cell's
+// summands one after the other in ascending external index -- bit-identical to the serial loop:
+//   1. the cells of the particles as a sequence in external order (the stored order after module_sort; else
+//      scattered through the permutation, cell_pairs_kernel);
+//   2. the cells are taken in groups of G consecutive indices (a vertical column of the grid, or 128 cells), and
+//      the sequence is cut into runs of equal group (run_heads_count / run_offsets / run_compact: an
+//      order-preserving compaction).  The stored orders follow the meteo grid, so the particles of a column
+//      are neighbours: ~100 times fewer runs than particles after module_sort;
+//   3. the runs are sorted by group with the stable radix sort of module_sort: the runs of one group end up side
+//      by side, in ascending external index;
+//   4. one wave per group streams the group's particles in that order, 64 at a time, into a table of the G cells
+//      in LDS.  Lanes that hit the same cell take turns in lane order (ds_min on a claim word decides whose
+//      turn it is), so every cell adds in exactly the serial order; the table is then written out
+//      (cell_sum_groups_kernel).  No global atomics at all.
+// ---------------------------------------------------------------------------
+
+constexpr int kGroupMax = 128;
+constexpr int kRunPerThread = 16;
+constexpr int kRunTile = 256 * kRunPerThread;   // sequence positions per workgroup of the compaction
+
+// values a cell sums up: count() values per particle, handled kBatch at a time
+struct MixVals {   // module_mixing: the mixed quantities
+  static constexpr int kBatch = 3;
+  MixSet mq;
+  __device__ __forceinline__ int count() const { return mq.n; }
+  __device__ __forceinline__ double get(int k, long long i) const { return mq.q[k][i]; }
+};
+
+struct GridVals {  // write_grid: q and q^2 of every quantity (kernel weight 1, mptrac.c:3305-3306)
+  static constexpr int kBatch = 4;
+  const double *q[MPHIP_NQ_MAX];
+  int nq;
+  __device__ __forceinline__ int count() const { return 2 * nq; }
+  __device__ __forceinline__ double get(int k, long long i) const {
+    const double v = 1.0 * q[k < nq ? k : k - nq][i];
+    return k < nq ? v : v * v;
+  }
+};
+
+// sequence in external order: seq_cell[ip] = cell, seq_slot[ip] = where the particle is stored
+__global__ void cell_pairs_kernel(const int *__restrict__ cell, const int *__restrict__ ext, long long n,
+                                  int *__restrict__ seq_cell, int *__restrict__ seq_slot) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+    const int at = ext[i];
+    seq_cell[at] = cell[i];
+    seq_slot[at] = (int) i;
+  }
+}
+
+__device__ __forceinline__ int group_of(int cell, int G) {
+  return cell >= 0 ? cell / G : -1;
+}
+
+// a run starts where the group changes; every thread looks at kRunPerThread consecutive positions
+__device__ __forceinline__ unsigned run_head_flags(const int *__restrict__ seq, long long n, long long first, int G) {
+  unsigned flags = 0;
+  if (first < n) {
+    int prev = first > 0 ? group_of(seq[first - 1], G) : 0;
+#pragma unroll
+    for (int k = 0; k < kRunPerThread; k++)
+      if (first + k < n) {
+        const int g = group_of(seq[first + k], G);
+        if (first + k == 0 || g != prev)
+          flags |= 1u << k;
+        prev = g;
+      }
+  }
+  return flags;
+}
+
+__global__ __launch_bounds__(256) void run_heads_count_kernel(const int *__restrict__ seq, long long n, int G,
+                                                              uint32_t *__restrict__ tile_runs) {
+  __shared__ uint32_t wsum[4];
+  const long long first = (long long) blockIdx.x * kRunTile + (long long) threadIdx.x * kRunPerThread;
+  uint32_t total;
+  block_exclusive_scan((uint32_t) __builtin_popcount(run_head_flags(seq, n, first, G)), wsum, &total);
+  if (threadIdx.x == 0)
+    tile_runs[blockIdx.x] = total;
+}
+
+// exclusive scan of the per-tile run counts in place (one workgroup, any length); tile_runs[ntiles] = number of runs
+__global__ __launch_bounds__(kScanThreads) void run_offsets_kernel(uint32_t *__restrict__ tile_runs, int ntiles) {
+  __shared__ uint32_t wsum[kScanThreads / 64];
+  uint32_t carry = 0;
+  for (int base = 0; base < ntiles; base += kScanThreads) {
+    const int i = base + (int) threadIdx.x;
+    const uint32_t v = i < ntiles ? tile_runs[i] : 0;
+    uint32_t total;
+    const uint32_t off = block_exclusive_scan(v, wsum, &total);
+    if (i < ntiles)
+      tile_runs[i] = carry + off;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    tile_runs[ntiles] = carry;
+}
+
+// run r: key = its group (`outside` for particles that are not in the grid), id = r, start = first position;
+// run_start[number of runs] = n closes the last run
+__global__ __launch_bounds__(256) void run_compact_kernel(const int *__restrict__ seq, long long n, int G,
+                                                          const uint32_t *__restrict__ tile_offset, int ntiles,
+                                                          uint32_t outside, uint32_t *__restrict__ run_key,
+                                                          int *__restrict__ run_id, uint32_t *__restrict__ run_start) {
+  __shared__ uint32_t wsum[4];
+  const long long first = (long long) blockIdx.x * kRunTile + (long long) threadIdx.x * kRunPerThread;
+  const unsigned flags = run_head_flags(seq, n, first, G);
+  uint32_t total;
+  uint32_t r = tile_offset[blockIdx.x] + block_exclusive_scan((uint32_t) __builtin_popcount(flags), wsum, &total);
+#pragma unroll
+  for (int k = 0; k < kRunPerThread; k++)
+    if (flags & (1u << k)) {
+      const int g = group_of(seq[first + k], G);
+      run_key[r] = g >= 0 ? (uint32_t) g : outside;
+      run_id[r] = (int) r;
+      run_start[r] = (uint32_t) (first + k);
+      r++;
+    }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    run_start[tile_offset[ntiles]] = (uint32_t) n;
+}
+
+// Sums over the sorted runs (keys[j] = group, ids[j] = run; the runs of a group are neighbours, in ascending
+// external index; *nruns_dev of them).  Wave w looks at runs 64 w ... 64 w + 63 and does the groups that begin
+// there.  sums[v * ntot + cell], cnt[cell] / cnt_as_double[cell] (either may be NULL) must be zero on entry:
+// groups without particles are not touched.
+template <class VALS>
+__global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const uint32_t *__restrict__ keys,
+                                                              const int *__restrict__ ids,
+                                                              const uint32_t *__restrict__ nruns_dev, uint32_t outside,
+                                                              const uint32_t *__restrict__ run_start,
+                                                              const int *__restrict__ seq_cell,
+                                                              const int *__restrict__ seq_slot, int G, size_t ntot,
+                                                              double *__restrict__ sums, int *__restrict__ cnt,
+                                                              double *__restrict__ cnt_as_double) {
+  constexpr int B = VALS::kBatch;
+  __shared__ double s_tab[4][B][kGroupMax];
+  __shared__ uint32_t s_cnt[4][kGroupMax], s_claim[4][kGroupMax];
+  __shared__ uint32_t s_excl[4][64], s_first[4][64];
+  const long long nruns = (long long) *nruns_dev;
+  const int nv = vals.count();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long nwaves = (long long) gridDim.x * 4;
+  for (long long jbase = ((long long) blockIdx.x * 4 + wave) * 64; jbase < nruns; jbase += nwaves * 64) {
+    const long long j = jbase + lane;
+    const uint32_t mine = j < nruns ? keys[j] : outside;
+    const uint32_t before = j > 0 && j < nruns ? keys[j - 1] : outside;
+    unsigned long long heads = __ballot(mine != outside && (j == 0 || before != mine));
+    while (heads) {
+      const int src = __builtin_ctzll(heads);
+      heads &= heads - 1;
+      const long long j0 = jbase + src;
+      const uint32_t g = (uint32_t) __builtin_amdgcn_readlane((int) mine, src);
+      // end of the group's runs: the first position of another key (found 64 positions at a time)
+      long long j1 = j0;
+      for (;;) {
+        const long long k = j1 + lane;
+        const unsigned long long same = __ballot(k < nruns && keys[k] == g);
+        const int run = same == ~0ull ? 64 : __builtin_ctzll(~same);
+        j1 += run;
+        if (run < 64)
+          break;
+      }
+      const long long cell0 = (long long) g * G;
+      for (int v0 = 0; v0 < nv; v0 += B) {
+        for (int sl = lane; sl < G; sl += 64) {
+#pragma unroll
+          for (int b = 0; b < B; b++)
+            s_tab[wave][b][sl] = 0.0;
+          s_cnt[wave][sl] = 0;
+          s_claim[wave][sl] = ~0u;
+        }
+        // windows of 64 runs: lane l holds run jw + l; the window's particles are numbered through
+        for (long long jw = j0; jw < j1; jw += 64) {
+          const int r = jw + lane < j1 ? ids[jw + lane] : -1;
+          const uint32_t first = r >= 0 ? run_start[r] : 0;
+          const uint32_t len = r >= 0 ? run_start[r + 1] - first : 0;
+          uint32_t incl = len;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = (uint32_t) __shfl_up((int) incl, d);
+            if (lane >= d)
+              incl += y;
+          }
+          const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+          __builtin_amdgcn_wave_barrier();
+          s_excl[wave][lane] = incl - len;
+          s_first[wave][lane] = first;
+          __builtin_amdgcn_wave_barrier();
+          for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const bool live = e < total;
+            // the run of particle e: the last lane whose exclusive prefix is <= e
+            int w = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+              if (s_excl[wave][w + step] <= e)
+                w += step;
+            const uint32_t p = live ? s_first[wave][w] + (e - s_excl[wave][w]) : 0;
+            const int sl = live ? (int) ((long long) seq_cell[p] - cell0) : 0;
+            const long long slot = live ? (seq_slot ? (long long) seq_slot[p] : (long long) p) : 0;
+            double x[B];
+#pragma unroll
+            for (int b = 0; b < B; b++)
+              x[b] = live && v0 + b < nv ? vals.get(v0 + b, slot) : 0.0;
+            // lanes of the same cell add in lane order
+            bool pending = live;
+            while (__ballot(pending)) {
+              if (pending)
+                atomicMin(&s_claim[wave][sl], (uint32_t) lane);
+              __builtin_amdgcn_wave_barrier();
+              const bool turn = pending && s_claim[wave][sl] == (uint32_t) lane;
+              __builtin_amdgcn_wave_barrier();
+              if (turn) {
+#pragma unroll
+                for (int b = 0; b < B; b++)
+                  s_tab[wave][b][sl] += x[b];
+                s_cnt[wave][sl] += 1;
+                s_claim[wave][sl] = ~0u;
+                pending = false;
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int sl = lane; sl < G; sl += 64) {
+          const long long c = cell0 + sl;
+          if (c < (long long) ntot) {
+#pragma unroll
+            for (int b = 0; b < B; b++)
+              if (v0 + b < nv)
+                sums[(size_t) (v0 + b) * ntot + (size_t) c] = s_tab[wave][b][sl];
+            if (v0 == 0) {
+              if (cnt)
+                cnt[c] = (int) s_cnt[wave][sl];
+              if (cnt_as_double)
+                cnt_as_double[c] = (double) s_cnt[wave][sl];
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }

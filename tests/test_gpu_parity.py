@@ -343,21 +343,97 @@ def test_sort_digit_widths(bits):
     s.close()
 
 
-def test_mixing_and_grid_sums():
+def _oracle_takes_device_state(o, s):
+    """Both sides continue from the same bits (the device's)."""
+    g = s.state()
+    for k in ("time", "p", "lon", "lat"):
+        getattr(o, k)[:] = g[k]
+    o.q[:] = g["q"]
+    return g
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_mixing_and_grid_sums(mode):
+    """module_mixing and the gridded-output sums from identical inputs.  deterministic_sums 1 (default) adds every
+    cell's summands in the reference's order of the particle index: every bit equals the serial code's;
+    0 = floating-point atomics, order of arrival."""
     o, s = _pair("full", n=20000)
+    s.set_option("deterministic_sums", mode)
     ts = cases.step_times(o.ctl)
     for t in ts[:2]:
         o.run_timestep(t)
         s.run_timestep(t)
     t = ts[1]                      # particle times equal the last step's t
+    _oracle_takes_device_state(o, s)
     o.module("mixing", t)
     s.module("mixing", t)
-    _compare(o, s, tol=1e-12)      # atomics reorder the per-cell sums
+    g, r = s.state(), o.state()
     co, mo, so = o.grid_sums(o.time[0])
     cs, ms, ss = s.grid_sums(o.time[0])
     assert co.sum() > 0 and np.array_equal(co, cs)       # counts: exact
-    assert cases.rel_err(ms, mo) <= 1e-12 and cases.rel_err(ss, so) <= 1e-12
+    if mode:
+        assert np.array_equal(g["q"], r["q"])
+        assert np.array_equal(ms, mo) and np.array_equal(ss, so)
+    else:
+        err, row = cases.q_rows_err(o.ctl, g["q"], r["q"])
+        assert err <= 1e-12, (row, err)
+        assert cases.rel_err(ms, mo) <= 1e-12 and cases.rel_err(ss, so) <= 1e-12
     s.close()
+
+
+def test_ordered_cell_sums_with_long_lists():
+    """~100 particles per cell of the default mixing grid plus 30000 in one cell and 3000 in another (cells beyond
+    64 particles are walked by the whole wave), stored in the locality order (the sequence in external order comes
+    from the permutation, many short runs), with and without an ensemble: bit-identical to the serial sums and
+    from run to run."""
+    from mptrac_amd.ctl import ctl_from_quantities
+    names = cases.QUANTITIES + ("aoa", "ens")
+    n = 120000
+    for nens in (0, 3):
+        ctl = {k: v for k, v in cases.CASES["full"].items() if k not in ("mixing_nx", "mixing_ny", "mixing_nz")}
+        ctl.update(mixing_dt=180.0, nens=nens, grid_nx=36, grid_ny=18, grid_nz=10, **ctl_from_quantities(names))
+        m0 = synthetic_met("C1", 0.0, 1.0, fields=cases.PRESSURE_LEVEL_FIELDS)
+        m1 = synthetic_met("C1", 3600.0, 1.25, fields=cases.PRESSURE_LEVEL_FIELDS)
+        atm = _crowded(n, names)
+        rng = np.random.default_rng(5)
+        big = rng.permutation(n)[:33000]
+        atm["lon"][big[:30000]] = 3.5 + 0.2 * rng.random(30000)
+        atm["lat"][big[:30000]] = 4.5 + 0.2 * rng.random(30000)
+        atm["p"][big[:30000]] = atm["p"][big[0]] * (1.0 + 1e-3 * rng.random(30000))
+        atm["lon"][big[30000:]] = 7.5 + 0.2 * rng.random(3000)
+        atm["lat"][big[30000:]] = 2.5 + 0.2 * rng.random(3000)
+        atm["p"][big[30000:]] = atm["p"][big[30000]] * (1.0 + 1e-3 * rng.random(3000))
+        atm["q"][names.index("ens")] = (np.arange(n) * 5 % max(nens, 1)).astype(np.float64)
+        clim = cases.load_clim_tropo()
+        o = B.Oracle(ctl, clim, m0, m1, atm)
+        o.timesteps_init()
+        results = []
+        for rep in range(2):
+            s = hip.Simulation(ctl, clim, m0, m1, atm)
+            s.set_option("locality_sort_interval", 1)
+            s.timesteps_init(0.0, 0.0)
+            ts = cases.step_times(s.ctl)
+            for t in ts[:2]:
+                s.run_timestep(t)          # (the second step runs module_mixing inside)
+            if rep == 0:
+                o.dt[:] = s.get_cache()["dt"]
+                _oracle_takes_device_state(o, s)
+                o.module("mixing", ts[1])
+            s.module("mixing", ts[1])
+            g = s.state()
+            results.append((g["q"], *s.grid_sums(ts[1])))
+            if rep == 0:
+                r = o.state()
+                im = names.index("m")
+                assert np.abs(r["q"][im] - atm["q"][im]).max() > 1e-4
+                assert np.array_equal(g["q"], r["q"])
+                co, mo, so = o.grid_sums(ts[1])
+                assert co.max() > 30000
+                assert np.array_equal(co, results[0][1]) and np.array_equal(mo, results[0][2])
+                assert np.array_equal(so, results[0][3])
+            s.close()
+        for x, y in zip(*results):
+            assert np.array_equal(x, y)
 
 
 # ---------------------------------------------------------------------------
@@ -556,12 +632,12 @@ def test_deferred_module_meteo_is_not_observable(case):
         if isinstance(a, dict):
             for key in ("time", "lon", "lat", "p", "q"):
                 assert np.array_equal(a[key], b[key], equal_nan=True), key
-        else:       # gridded sums: counts exact; the floating-point sums are atomic accumulations whose
-            cnt_a, mean_a, sig_a = a      # order differs from run to run
+        else:       # gridded sums: added in the order of the particle index, the same bits every run
+            cnt_a, mean_a, sig_a = a
             cnt_b, mean_b, sig_b = b
             assert np.array_equal(cnt_a, cnt_b) and cnt_a.sum() > 0
-            assert np.allclose(mean_a, mean_b, rtol=1e-12, atol=0, equal_nan=True)
-            assert np.allclose(sig_a, sig_b, rtol=1e-12, atol=0, equal_nan=True)
+            assert np.array_equal(mean_a, mean_b, equal_nan=True)
+            assert np.array_equal(sig_a, sig_b, equal_nan=True)
 
 
 def test_module_meteo_missing_field_is_an_error():
@@ -655,7 +731,7 @@ def test_rccl_communicator_single_rank():
         s.close()
     for k in ("time", "lon", "lat", "p", "uvwp"):
         assert np.array_equal(runs[0][k], runs[1][k]), k
-    assert cases.rel_err(runs[0]["q"], runs[1]["q"]) <= 1e-13      # (atomic sums: order differs from run to run)
+    assert np.array_equal(runs[0]["q"], runs[1]["q"])      # (ordered cell sums: the same bits every run)
 
 
 # ---------------------------------------------------------------------------
@@ -725,7 +801,7 @@ def test_locality_order_is_not_observable(case):
         runs[name] = s.state()
         runs[name]["ctr"] = s.get_cache()["rng_ctr"]
         s.close()
-    tol_q = 0.0 if case != "full" else 1e-13        # mixing sums use atomics
+    tol_q = 0.0        # (the mixing sums add in the order of the external index, whatever the stored order)
     for name in ("every3", "every1_peek"):
         for k in ("time", "lon", "lat", "p", "uvwp"):
             assert np.array_equal(runs[name][k], runs["off"][k]), (name, k)
