@@ -853,7 +853,7 @@ int radix_passes(mphip_ctx *ctx, uint32_t *const keys[2], int *const vals[2], lo
   hipLaunchKernelGGL(sort_hist_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur], n, shift,       \
                      ntiles, ctx->d_counts, n_dev);                                                                    \
   hipLaunchKernelGGL(sort_scan_local_kernel, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream, ctx->d_counts, m,      \
-                     d_chunks, (const uint32_t *) nullptr);                                                            \
+                     d_chunks, n_dev, 1 << B);                                                                         \
   hipLaunchKernelGGL(sort_scan_chunks_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_chunks, nchunks);         \
   hipLaunchKernelGGL(sort_scatter_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur], vals[cur],   \
                      keys[cur ^ 1], vals[cur ^ 1], n, shift, ntiles, ctx->d_counts, d_chunks, n_dev)
@@ -1127,8 +1127,13 @@ template <class VALS>
 int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size_t ntot, double *sums, int *cnt,
                       double *cnt_as_double) {
   const long long n = ctx->np;
-  // cells per group: a vertical column of the grid if that fits the table in LDS
-  const int G = column >= 1 && column <= kGroupMax ? column : kGroupMax;
+  // cells per group: whole vertical columns of the grid, as many as fit the table in LDS while there are
+  // still >= 2^14 groups to spread over the waves
+  int G = kGroupMax;
+  if (column >= 1 && column <= kGroupMax) {
+    const size_t ncol = std::max<size_t>(1, std::min<size_t>(kGroupMax / column, ntot / column / 16384));
+    G = column * (int) ncol;
+  }
   const size_t ngroups = (ntot + G - 1) / G;
   if (ntot >= 0x7fffffffULL)
     return fail(ctx, "too many grid cells for 32-bit cell indices");
@@ -1172,8 +1177,20 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
   if (radix_passes(ctx, keys, ids, n, bits_for(ngroups), &cur, nruns_dev))
     return 1;
   const int nblocks = (int) std::min<long long>((n + 255) / 256, 16384);
-  hipLaunchKernelGGL(cell_sum_groups_kernel<VALS>, dim3(nblocks), dim3(256), 0, ctx->stream, vals, keys[cur], ids[cur],
-                     nruns_dev, (uint32_t) ngroups, run_start, seq, seq_slot, G, ntot, sums, cnt, cnt_as_double);
+#define GROUPS(B)                                                                                                      \
+  hipLaunchKernelGGL((cell_sum_groups_kernel<VALS, B>), dim3(nblocks), dim3(256), 0, ctx->stream, vals, keys[cur],     \
+                     ids[cur], nruns_dev, (uint32_t) ngroups, run_start, seq, seq_slot, G, ntot, sums, cnt,            \
+                     cnt_as_double)
+  if (nv == 1) {   // (values per pass: as many as there are, up to four)
+    GROUPS(1);
+  } else if (nv == 2) {
+    GROUPS(2);
+  } else if (nv == 3) {
+    GROUPS(3);
+  } else {
+    GROUPS(4);
+  }
+#undef GROUPS
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1187,17 +1204,37 @@ int ensure_cell_counts(mphip_ctx *ctx, size_t ntot) {
   return 0;
 }
 
-int do_mixing(mphip_ctx *ctx, double t) {
+// module_mixing, mptrac.c:5169-5347:
+//   mixing_plan   what is mixed, the grid, the buffers
+//   mixing_cells  the box of every particle
+//   mixing_sums   sums and counts per box, all-reduce over the ranks
+//   mixing_relax  every particle towards the mean of its box
+struct MixGrid {
+  BoxGrid grid;
+  double t0, t1;
+  const double *ens;
+  int ngrid;
+};
+
+struct MixPlan {
+  MixGrid box;      // the grid and the time window
+  MixSet mq;        // what is mixed
+  size_t ntot;      // boxes (times ensemble members)
+};
+
+// false in *active: nothing to mix
+int mixing_plan(mphip_ctx *ctx, double t, MixPlan *P, bool *active) {
   const mphip_ctl_t &c = ctx->ctl;
+  *active = false;
   if (!ctx->have_clim)
     return fail(ctx, "climatological tropopause data were not uploaded");
   const int ngrid = c.mixing_nx * c.mixing_ny * c.mixing_nz;
   const int nens = c.nens > 0 ? c.nens : 1;
   const size_t ntot = (size_t) ngrid * nens;
   const DevAtm a = dev_atm(ctx);
+  memset(P, 0, sizeof(*P));
   // the mixed quantities (hot-path subset of mptrac.c:5223-5230), all in one pass
-  MixSet mq;
-  mq.n = 0;
+  MixSet &mq = P->mq;
   for (int iq : { c.qnt_m, c.qnt_vmr, c.qnt_aoa })
     if (iq >= 0)
       mq.q[mq.n++] = a.q[iq];
@@ -1205,39 +1242,67 @@ int do_mixing(mphip_ctx *ctx, double t) {
     return 0;
   // [sums of quantity 0 | 1 | 2 | scratch for a doubles-only all-reduce hook]
   const bool hook = !ctx->comm && ctx->allreduce;
-  if (ensure_sums(ctx, ((size_t) mq.n + (hook ? 1 : 0)) * ntot))
+  if (ensure_sums(ctx, ((size_t) mq.n + (hook ? 1 : 0)) * ntot) || ensure_cell_counts(ctx, ntot))
     return 1;
-  if (ensure_cell_counts(ctx, ntot))
-    return 1;
-  BoxGrid G = { c.mixing_lon0, c.mixing_lon1, c.mixing_lat0, c.mixing_lat1, c.mixing_z0, c.mixing_z1,
-                c.mixing_nx, c.mixing_ny, c.mixing_nz };
-  const int nb = grid_for(std::max<long long>(ctx->np, 1));
-  const double *ens = (c.nens > 0 && c.qnt_ens >= 0) ? a.q[c.qnt_ens] : nullptr;
-  const bool ordered = ctx->deterministic_sums != 0;
-  if (ctx->np)
-    hipLaunchKernelGGL(box_index_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
-                       t + 0.5 * c.dt_mod, ctx->d_cell, ens, ngrid);
-  if (ordered) {
+  P->ntot = ntot;
+  P->box.grid = BoxGrid{ c.mixing_lon0, c.mixing_lon1, c.mixing_lat0, c.mixing_lat1, c.mixing_z0, c.mixing_z1,
+                          c.mixing_nx, c.mixing_ny, c.mixing_nz };
+  P->box.t0 = t - 0.5 * c.dt_mod;
+  P->box.t1 = t + 0.5 * c.dt_mod;
+  P->box.ens = (c.nens > 0 && c.qnt_ens >= 0) ? a.q[c.qnt_ens] : nullptr;
+  P->box.ngrid = ngrid;
+  *active = true;
+  return 0;
+}
+
+int mixing_cells(mphip_ctx *ctx, const MixPlan &P) {
+  if (ctx->np == 0)
+    return 0;
+  const MixGrid &h = P.box;
+  hipLaunchKernelGGL(box_index_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, dev_atm(ctx), h.grid, h.t0, h.t1,
+                     ctx->d_cell, h.ens, h.ngrid);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int mixing_sums(mphip_ctx *ctx, const MixPlan &P) {
+  const MixSet &mq = P.mq;
+  const size_t ntot = P.ntot;
+  if (ctx->deterministic_sums != 0) {
     MixVals vals = { mq };
-    if (ordered_cell_sums(ctx, vals, mq.n, c.mixing_nz, ntot, ctx->d_sums, ctx->d_cnt, (double *) nullptr))
+    if (ordered_cell_sums(ctx, vals, mq.n, ctx->ctl.mixing_nz, ntot, ctx->d_sums, ctx->d_cnt, (double *) nullptr))
       return 1;
   } else {
     HIPCHK(hipMemsetAsync(ctx->d_sums, 0, (size_t) mq.n * ntot * sizeof(double), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_cnt, 0, ntot * sizeof(int), ctx->stream));
     if (ctx->np) {
       const AccumGeom g = accum_geom(ctx, mq.n + 1);
-      hipLaunchKernelGGL(mix_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, mq, ntot,
-                         ctx->d_sums, ctx->d_cnt, g.T, g.per_block);
+      hipLaunchKernelGGL(mix_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, dev_atm(ctx), ctx->d_cell,
+                         mq, ntot, ctx->d_sums, ctx->d_cnt, g.T, g.per_block);
+      HIPCHK(hipGetLastError());
     }
   }
   // one exchange per mixing step: the sums of every mixed quantity and the cell counts
-  if (run_allreduce(ctx, ctx->d_sums, (size_t) mq.n * ntot, ctx->d_cnt, ntot, ctx->d_sums + (size_t) mq.n * ntot))
-    return 1;
-  if (ctx->np)
-    hipLaunchKernelGGL(mix_relax_kernel, dim3(nb), dim3(256), 0, ctx->stream, c, ctx->d_clim, a, ctx->d_cell, mq, ntot,
-                       ctx->d_sums, ctx->d_cnt);
+  return run_allreduce(ctx, ctx->d_sums, (size_t) mq.n * ntot, ctx->d_cnt, ntot, ctx->d_sums + (size_t) mq.n * ntot);
+}
+
+int mixing_relax(mphip_ctx *ctx, const MixPlan &P) {
+  if (ctx->np == 0)
+    return 0;
+  hipLaunchKernelGGL(mix_relax_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, ctx->ctl, ctx->d_clim,
+                     dev_atm(ctx), ctx->d_cell, P.mq, P.ntot, ctx->d_sums, ctx->d_cnt);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int do_mixing(mphip_ctx *ctx, double t) {
+  MixPlan P;
+  bool active;
+  if (mixing_plan(ctx, t, &P, &active))
+    return 1;
+  if (!active)
+    return 0;
+  return mixing_cells(ctx, P) || mixing_sums(ctx, P) || mixing_relax(ctx, P);
 }
 
 void unpin_all(mphip_ctx *ctx, std::vector<std::pair<uintptr_t, uintptr_t>> &list) {

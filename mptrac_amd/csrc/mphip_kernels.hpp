@@ -15,6 +15,91 @@ namespace mphip {
 // fused step
 // ---------------------------------------------------------------------------
 
+// ---------------------------------------------------------------------------
+// module_mixing (mptrac.c:5169-5347) per particle: the box a particle is in, and the relaxation towards the
+// box mean (kernels box_index_kernel and mix_relax_kernel below).  Both were also tried as parts of the
+// time-step launches around module_mixing: the box index at the end of the launch that moves the particles cost
+// that launch 40 - 70 us (a logarithm and three true divisions per particle) against 67 us for the kernel of its
+// own, the relaxation at the start of the launch of the deposition modules 150 us against 127 us -- no gain.
+// ---------------------------------------------------------------------------
+
+struct BoxGrid {
+  double lon0, lon1, lat0, lat1, z0, z1;
+  int nx, ny, nz;
+};
+
+constexpr int kMixMax = 3;   // mass, volume mixing ratio, age of air (the hot-path subset of the reference's list)
+struct MixSet {
+  double *q[kMixMax];
+  int n;
+};
+
+// cell index of a particle, -1 if outside (mptrac.c:5201-5218, 13836-13855); with an ensemble the index inside
+// the member's copy of the grid, ens * ngrid + cell (mptrac.c:5291-5294)
+__device__ __forceinline__ int box_cell(const BoxGrid &G, double t0, double t1, double time, double lon, double lat,
+                                        double p, const double *__restrict__ ens, long long i, int ngrid) {
+  const double dz = (G.z1 - G.z0) / G.nz;
+  const double dlon = (G.lon1 - G.lon0) / G.nx;
+  const double dlat = (G.lat1 - G.lat0) / G.ny;
+  const double zpart = zfromp(p);
+  int c = -1;
+  if (!(time < t0 || time > t1 || lon < G.lon0 || lon >= G.lon1 || lat < G.lat0 || lat >= G.lat1 || zpart < G.z0
+        || zpart >= G.z1)) {
+    const int ix = (int) ((lon - G.lon0) / dlon);
+    const int iy = (int) ((lat - G.lat0) / dlat);
+    const int iz = (int) ((zpart - G.z0) / dz);
+    if (!(ix >= G.nx || iy >= G.ny || iz >= G.nz))
+      c = (ix * G.ny + iy) * G.nz + iz + (ens ? (int) ens[i] * ngrid : 0);
+  }
+  return c;
+}
+
+// tropo_weight (mptrac.c:12748-12770, clim_tropo mptrac.c:213-237) in the reference's operation order with true
+// divisions and no fused multiply-adds -- the step kernel's version multiplies by stored reciprocals.  With the
+// ordered cell sums module_mixing then returns the bits of the serial code.
+__device__ inline double tropo_weight_exact(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat, double p) {
+#pragma clang fp contract(off)
+  if (ctl.met_coord_type != 0)
+    lat = ctl.met_utm_ref_lat;
+  double sec = fmod_trunc(time, 365.25 * 86400.);
+  while (sec < 0)
+    sec += 365.25 * 86400.;
+  const int it = locate_irr(C.time, C.ntime, sec, 1);
+  const int il = locate_reg(C.lat, C.nlat, lat);
+  const double x0 = C.lat[il], x1 = C.lat[il + 1];
+  const double pa = C.tropo[it][il] + (C.tropo[it][il + 1] - C.tropo[it][il]) / (x1 - x0) * (lat - x0);
+  const double pb = C.tropo[it + 1][il] + (C.tropo[it + 1][il + 1] - C.tropo[it + 1][il]) / (x1 - x0) * (lat - x0);
+  const double pt = pa + (pb - pa) / (C.time[it + 1] - C.time[it]) * (sec - C.time[it]);
+  const double p1 = pt * 0.866877899;
+  const double p0 = pt / 0.866877899;
+  if (p > p0)
+    return 1;
+  if (p < p1)
+    return 0;
+  return 1.0 + (0.0 - 1.0) / (p1 - p0) * (p - p0);
+}
+
+// q += (mean - q) * mixparam for every mixed quantity of particle i in cell idx, mptrac.c:5305-5339
+__device__ inline void mix_relax_one(const mphip_ctl_t &ctl, const DevClim &clim, const MixSet &mq, long long i, int idx,
+                                     double time, double lat, double p, size_t ntot, const double *__restrict__ sums,
+                                     const int *__restrict__ cnt) {
+#pragma clang fp contract(off)
+  if (idx < 0)
+    return;
+  double mixparam = 1.0;
+  if (ctl.mixing_trop < 1 || ctl.mixing_strat < 1) {
+    const double w = tropo_weight_exact(ctl, clim, time, lat, p);
+    mixparam = w * ctl.mixing_trop + (1.0 - w) * ctl.mixing_strat;
+  }
+  const int n = cnt[idx];
+  for (int k = 0; k < mq.n; k++) {
+    const double sum = sums[(size_t) k * ntot + (size_t) idx];
+    const double mean = n > 0 ? sum / n : sum;
+    const double v = mq.q[k][i];
+    mq.q[k][i] = v + (mean - v) * mixparam;
+  }
+}
+
 struct StepParams {
   mphip_ctl_t ctl;
   DevMet met;
@@ -769,8 +854,12 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t 
                                                                  int shift, int ntiles, uint32_t *__restrict__ counts,
                                                                  const uint32_t *__restrict__ n_dev = nullptr) {
   constexpr int kRadix = 1 << BITS;
-  if (n_dev)   // the number of pairs is only known on the device; the launch covers an upper bound
-    n = (long long) *n_dev;
+  if (n_dev) {   // the number of pairs is only known on the device: the launch covers an upper bound, the
+    n = (long long) *n_dev;   // counter layout follows the actual number of tiles
+    ntiles = (int) ((n + kSortTile - 1) / kSortTile);
+    if ((int) blockIdx.x >= ntiles)
+      return;
+  }
   __shared__ uint32_t h[kRadix];
   for (int d = threadIdx.x; d < kRadix; d += kSortThreads)
     h[d] = 0;
@@ -818,25 +907,22 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
   return off + x - v;
 }
 
-// (`src`: scan these values into `counts` instead of scanning `counts` in place; `largest`: their maximum)
 __global__ __launch_bounds__(kScanThreads) void sort_scan_local_kernel(uint32_t *__restrict__ counts, size_t m,
                                                                        uint32_t *__restrict__ chunk_sums,
-                                                                       const uint32_t *__restrict__ src = nullptr,
-                                                                       uint32_t *__restrict__ largest = nullptr) {
+                                                                       const uint32_t *__restrict__ n_dev = nullptr,
+                                                                       int radix = 0) {
   __shared__ uint32_t wsum[kScanThreads / 64];
+  if (n_dev) {   // (see sort_hist_kernel) radix counters for each of the actual tiles
+    m = (size_t) radix * (((size_t) *n_dev + kSortTile - 1) / kSortTile);
+    if ((size_t) blockIdx.x * kScanChunk >= m)
+      return;
+  }
   const size_t base = (size_t) blockIdx.x * kScanChunk + (size_t) threadIdx.x * kScanPer;
-  uint32_t v[kScanPer], sum = 0, big = 0;
+  uint32_t v[kScanPer], sum = 0;
 #pragma unroll
   for (int k = 0; k < kScanPer; k++) {
-    v[k] = base + k < m ? (src ? src[base + k] : counts[base + k]) : 0;
+    v[k] = base + k < m ? counts[base + k] : 0;
     sum += v[k];
-    big = v[k] > big ? v[k] : big;
-  }
-  if (largest) {   // *largest = max over all values (one atomic per wave)
-    for (int d = 32; d > 0; d >>= 1)
-      big = max(big, (uint32_t) __shfl_xor((int) big, d));
-    if ((threadIdx.x & 63) == 0 && big > 0)
-      atomicMax(largest, big);
   }
   uint32_t total;
   uint32_t off = block_exclusive_scan(sum, wsum, &total);
@@ -877,8 +963,12 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
                                                                     const uint32_t *__restrict__ chunk_offsets,
                                                                     const uint32_t *__restrict__ n_dev = nullptr) {
   constexpr int kRadix = 1 << BITS;
-  if (n_dev)
+  if (n_dev) {
     n = (long long) *n_dev;
+    ntiles = (int) ((n + kSortTile - 1) / kSortTile);
+    if ((int) blockIdx.x >= ntiles)
+      return;
+  }
   constexpr int kDigitsPerThread = kRadix / kSortThreads;   // 1, 2 or 4 consecutive digits per thread
   constexpr int kWaves = kSortThreads / 64;
   constexpr int kPerWave = kSortTile / kWaves;
@@ -1042,33 +1132,18 @@ __global__ void keys_to_double_kernel(const uint32_t *__restrict__ k, double *__
 // module_mixing (mptrac.c:5169-5347) and write_grid sums (mptrac.c:13815-13872)
 // ---------------------------------------------------------------------------
 
-struct BoxGrid {
-  double lon0, lon1, lat0, lat1, z0, z1;
-  int nx, ny, nz;
-};
-
-// cell index of every particle, -1 if outside (mptrac.c:5201-5218, 13836-13855)
-// (with `ens`: the index inside the ensemble member's copy of the grid, ens * ngrid + cell, mptrac.c:5291-5294)
 __global__ __launch_bounds__(256) void box_index_kernel(DevAtm a, BoxGrid G, double t0, double t1, int *__restrict__ cell,
                                                         const double *__restrict__ ens, int ngrid) {
-  const double dz = (G.z1 - G.z0) / G.nz;
-  const double dlon = (G.lon1 - G.lon0) / G.nx;
-  const double dlat = (G.lat1 - G.lat0) / G.ny;
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
-       i += (long long) gridDim.x * blockDim.x) {
-    const double lon = a.lon[i], lat = a.lat[i], time = a.time[i];
-    const double zpart = zfromp(a.p[i]);
-    int c = -1;
-    if (!(time < t0 || time > t1 || lon < G.lon0 || lon >= G.lon1 || lat < G.lat0 || lat >= G.lat1
-          || zpart < G.z0 || zpart >= G.z1)) {
-      const int ix = (int) ((lon - G.lon0) / dlon);
-      const int iy = (int) ((lat - G.lat0) / dlat);
-      const int iz = (int) ((zpart - G.z0) / dz);
-      if (!(ix >= G.nx || iy >= G.ny || iz >= G.nz))
-        c = (ix * G.ny + iy) * G.nz + iz + (ens ? (int) ens[i] * ngrid : 0);
-    }
-    cell[i] = c;
-  }
+       i += (long long) gridDim.x * blockDim.x)
+    cell[i] = box_cell(G, t0, t1, a.time[i], a.lon[i], a.lat[i], a.p[i], ens, i, ngrid);
+}
+
+__global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a, const int *__restrict__ cell, MixSet mq,
+                                 size_t ntot, const double *__restrict__ sums, const int *__restrict__ cnt) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
+       i += (long long) gridDim.x * blockDim.x)
+    mix_relax_one(ctl, *clim, mq, i, cell[i], a.time[i], a.lat[i], a.p[i], ntot, sums, cnt);
 }
 
 // Block-private accumulation table in LDS.  The particles are stored in the
@@ -1135,12 +1210,6 @@ struct LdsTable {
 // sums[k * ntot + idx] += q_k, cnt[idx] += 1 with idx = ens * ngrid + cell.  The particle count is the
 // same for all quantities and is kept once, as 32-bit integers (a third fewer bytes through the all-reduce
 // than [sum | count] pairs of doubles per quantity).
-constexpr int kMixMax = 3;   // mass, volume mixing ratio, age of air (the hot-path subset of the reference's list)
-struct MixSet {
-  double *q[kMixMax];
-  int n;
-};
-
 __global__ __launch_bounds__(256) void mix_accumulate_kernel(DevAtm a, const int *__restrict__ cell, MixSet mq,
                                                              size_t ntot, double *__restrict__ sums,
                                                              int *__restrict__ cnt, int T, long long per_block) {
@@ -1177,55 +1246,6 @@ __global__ __launch_bounds__(256) void mix_accumulate_kernel(DevAtm a, const int
   }
 }
 
-// tropo_weight (mptrac.c:12748-12770, clim_tropo mptrac.c:213-237) in the reference's operation order with true
-// divisions and no fused multiply-adds -- the step kernel's version multiplies by stored reciprocals.  With the
-// ordered cell sums module_mixing then returns the bits of the serial code.
-__device__ double tropo_weight_exact(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat, double p) {
-#pragma clang fp contract(off)
-  if (ctl.met_coord_type != 0)
-    lat = ctl.met_utm_ref_lat;
-  double sec = fmod_trunc(time, 365.25 * 86400.);
-  while (sec < 0)
-    sec += 365.25 * 86400.;
-  const int it = locate_irr(C.time, C.ntime, sec, 1);
-  const int il = locate_reg(C.lat, C.nlat, lat);
-  const double x0 = C.lat[il], x1 = C.lat[il + 1];
-  const double pa = C.tropo[it][il] + (C.tropo[it][il + 1] - C.tropo[it][il]) / (x1 - x0) * (lat - x0);
-  const double pb = C.tropo[it + 1][il] + (C.tropo[it + 1][il + 1] - C.tropo[it + 1][il]) / (x1 - x0) * (lat - x0);
-  const double pt = pa + (pb - pa) / (C.time[it + 1] - C.time[it]) * (sec - C.time[it]);
-  const double p1 = pt * 0.866877899;
-  const double p0 = pt / 0.866877899;
-  if (p > p0)
-    return 1;
-  if (p < p1)
-    return 0;
-  return 1.0 + (0.0 - 1.0) / (p1 - p0) * (p - p0);
-}
-
-// q += (mean - q) * mixparam for every mixed quantity, mptrac.c:5305-5339
-__global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a, const int *__restrict__ cell, MixSet mq,
-                                 size_t ntot, const double *__restrict__ sums, const int *__restrict__ cnt) {
-#pragma clang fp contract(off)
-  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
-       i += (long long) gridDim.x * blockDim.x) {
-    const int idx = cell[i];
-    if (idx >= 0) {
-      double mixparam = 1.0;
-      if (ctl.mixing_trop < 1 || ctl.mixing_strat < 1) {
-        const double w = tropo_weight_exact(ctl, *clim, a.time[i], a.lat[i], a.p[i]);
-        mixparam = w * ctl.mixing_trop + (1.0 - w) * ctl.mixing_strat;
-      }
-      const int n = cnt[idx];
-      for (int k = 0; k < mq.n; k++) {
-        const double sum = sums[(size_t) k * ntot + (size_t) idx];
-        const double mean = n > 0 ? sum / n : sum;
-        const double v = mq.q[k][i];
-        mq.q[k][i] = v + (mean - v) * mixparam;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // Cell sums in the reference's order.  The reference accumulates serially over the particle index
 // (module_mixing mptrac.c:5289-5303, write_grid mptrac.c:13862-13872): cell sum = ((q_a + q_b) + q_c) ... in
@@ -1234,7 +1254,7 @@ __global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a,
 // summands one after the other in ascending external index -- bit-identical to the serial loop:
 //   1. the cells of the particles as a sequence in external order (the stored order after module_sort; else
 //      scattered through the permutation, cell_pairs_kernel);
-//   2. the cells are taken in groups of G consecutive indices (a vertical column of the grid, or 128 cells), and
+//   2. the cells are taken in groups of G consecutive indices (whole vertical columns of the grid, <= 128 cells), and
 //      the sequence is cut into runs of equal group (run_heads_count / run_offsets / run_compact: an
 //      order-preserving compaction).  The stored orders follow the meteo grid, so the particles of a column
 //      are neighbours: ~100 times fewer runs than particles after module_sort;
@@ -1242,24 +1262,23 @@ __global__ void mix_relax_kernel(mphip_ctl_t ctl, const DevClim *clim, DevAtm a,
 //      by side, in ascending external index;
 //   4. one wave per group streams the group's particles in that order, 64 at a time, into a table of the G cells
 //      in LDS.  Lanes that hit the same cell take turns in lane order (ds_min on a claim word decides whose
-//      turn it is), so every cell adds in exactly the serial order; the table is then written out
-//      (cell_sum_groups_kernel).  No global atomics at all.
+//      turn it is; cells with many of the 64 are added up from the lanes one after the other), so every cell
+//      adds in exactly the serial order; the table is then written out (cell_sum_groups_kernel).  No global
+//      atomics at all.
 // ---------------------------------------------------------------------------
 
 constexpr int kGroupMax = 128;
-constexpr int kRunPerThread = 16;
-constexpr int kRunTile = 256 * kRunPerThread;   // sequence positions per workgroup of the compaction
+constexpr int kRunRounds = 16;
+constexpr int kRunTile = 256 * kRunRounds;   // sequence positions per workgroup of the compaction
 
-// values a cell sums up: count() values per particle, handled kBatch at a time
+// values a cell sums up: count() values per particle (the kernel handles B of them per pass)
 struct MixVals {   // module_mixing: the mixed quantities
-  static constexpr int kBatch = 3;
   MixSet mq;
   __device__ __forceinline__ int count() const { return mq.n; }
   __device__ __forceinline__ double get(int k, long long i) const { return mq.q[k][i]; }
 };
 
 struct GridVals {  // write_grid: q and q^2 of every quantity (kernel weight 1, mptrac.c:3305-3306)
-  static constexpr int kBatch = 4;
   const double *q[MPHIP_NQ_MAX];
   int nq;
   __device__ __forceinline__ int count() const { return 2 * nq; }
@@ -1283,31 +1302,44 @@ __device__ __forceinline__ int group_of(int cell, int G) {
   return cell >= 0 ? cell / G : -1;
 }
 
-// a run starts where the group changes; every thread looks at kRunPerThread consecutive positions
-__device__ __forceinline__ unsigned run_head_flags(const int *__restrict__ seq, long long n, long long first, int G) {
-  unsigned flags = 0;
-  if (first < n) {
-    int prev = first > 0 ? group_of(seq[first - 1], G) : 0;
+// A run starts where the group changes.  A workgroup looks at kRunTile consecutive positions: wave w at the w-th
+// quarter, 64 neighbouring positions per round (coalesced), one ballot per round = the heads of the round.
+struct RunHeads {
+  unsigned long long heads[kRunRounds];   // per round: lanes that start a run
+  int group[kRunRounds];                  // this lane's group per round
+  uint32_t count;                         // runs that start in this wave's part
+};
+
+__device__ __forceinline__ RunHeads run_heads_of_wave(const int *__restrict__ seq, long long n, int G) {
+  RunHeads H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long first = (long long) blockIdx.x * kRunTile + (long long) wave * (kRunTile / 4);
+  int carry = first > 0 && first <= n ? group_of(seq[first - 1], G) : 0;   // group of the position before the round
+  H.count = 0;
 #pragma unroll
-    for (int k = 0; k < kRunPerThread; k++)
-      if (first + k < n) {
-        const int g = group_of(seq[first + k], G);
-        if (first + k == 0 || g != prev)
-          flags |= 1u << k;
-        prev = g;
-      }
+  for (int r = 0; r < kRunRounds; r++) {
+    const long long i = first + r * 64 + lane;
+    const int g = i < n ? group_of(seq[i], G) : 0;
+    int prev = __shfl_up(g, 1);
+    if (lane == 0)
+      prev = carry;
+    H.heads[r] = __ballot(i < n && (i == 0 || g != prev));
+    H.group[r] = g;
+    H.count += (uint32_t) __builtin_popcountll(H.heads[r]);
+    carry = __builtin_amdgcn_readlane(g, 63);
   }
-  return flags;
+  return H;
 }
 
 __global__ __launch_bounds__(256) void run_heads_count_kernel(const int *__restrict__ seq, long long n, int G,
                                                               uint32_t *__restrict__ tile_runs) {
   __shared__ uint32_t wsum[4];
-  const long long first = (long long) blockIdx.x * kRunTile + (long long) threadIdx.x * kRunPerThread;
-  uint32_t total;
-  block_exclusive_scan((uint32_t) __builtin_popcount(run_head_flags(seq, n, first, G)), wsum, &total);
+  const RunHeads H = run_heads_of_wave(seq, n, G);
+  if ((threadIdx.x & 63) == 0)
+    wsum[threadIdx.x >> 6] = H.count;
+  __syncthreads();
   if (threadIdx.x == 0)
-    tile_runs[blockIdx.x] = total;
+    tile_runs[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // exclusive scan of the per-tile run counts in place (one workgroup, any length); tile_runs[ntiles] = number of runs
@@ -1335,28 +1367,43 @@ __global__ __launch_bounds__(256) void run_compact_kernel(const int *__restrict_
                                                           uint32_t outside, uint32_t *__restrict__ run_key,
                                                           int *__restrict__ run_id, uint32_t *__restrict__ run_start) {
   __shared__ uint32_t wsum[4];
-  const long long first = (long long) blockIdx.x * kRunTile + (long long) threadIdx.x * kRunPerThread;
-  const unsigned flags = run_head_flags(seq, n, first, G);
-  uint32_t total;
-  uint32_t r = tile_offset[blockIdx.x] + block_exclusive_scan((uint32_t) __builtin_popcount(flags), wsum, &total);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const RunHeads H = run_heads_of_wave(seq, n, G);
+  if (lane == 0)
+    wsum[wave] = H.count;
+  __syncthreads();
+  uint32_t r0 = tile_offset[blockIdx.x];
+  for (int w = 0; w < wave; w++)
+    r0 += wsum[w];
+  const long long first = (long long) blockIdx.x * kRunTile + (long long) wave * (kRunTile / 4);
 #pragma unroll
-  for (int k = 0; k < kRunPerThread; k++)
-    if (flags & (1u << k)) {
-      const int g = group_of(seq[first + k], G);
-      run_key[r] = g >= 0 ? (uint32_t) g : outside;
+  for (int k = 0; k < kRunRounds; k++) {
+    const unsigned long long heads = H.heads[k];
+    if ((heads >> lane) & 1) {
+      const uint32_t r = r0 + (uint32_t) __builtin_popcountll(heads & ((1ull << lane) - 1));
+      run_key[r] = H.group[k] >= 0 ? (uint32_t) H.group[k] : outside;
       run_id[r] = (int) r;
-      run_start[r] = (uint32_t) (first + k);
-      r++;
+      run_start[r] = (uint32_t) (first + k * 64 + lane);
     }
+    r0 += (uint32_t) __builtin_popcountll(heads);
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0)
     run_start[tile_offset[ntiles]] = (uint32_t) n;
+}
+
+// x of lane l (l uniform in the wave)
+__device__ __forceinline__ double lane_value(double x, int l) {
+  const unsigned long long u = (unsigned long long) __double_as_longlong(x);
+  const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) u, l);
+  const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (u >> 32), l);
+  return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
 }
 
 // Sums over the sorted runs (keys[j] = group, ids[j] = run; the runs of a group are neighbours, in ascending
 // external index; *nruns_dev of them).  Wave w looks at runs 64 w ... 64 w + 63 and does the groups that begin
 // there.  sums[v * ntot + cell], cnt[cell] / cnt_as_double[cell] (either may be NULL) must be zero on entry:
 // groups without particles are not touched.
-template <class VALS>
+template <class VALS, int B>
 __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const uint32_t *__restrict__ keys,
                                                               const int *__restrict__ ids,
                                                               const uint32_t *__restrict__ nruns_dev, uint32_t outside,
@@ -1365,7 +1412,6 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
                                                               const int *__restrict__ seq_slot, int G, size_t ntot,
                                                               double *__restrict__ sums, int *__restrict__ cnt,
                                                               double *__restrict__ cnt_as_double) {
-  constexpr int B = VALS::kBatch;
   __shared__ double s_tab[4][B][kGroupMax];
   __shared__ uint32_t s_cnt[4][kGroupMax], s_claim[4][kGroupMax];
   __shared__ uint32_t s_excl[4][64], s_first[4][64];
@@ -1435,9 +1481,13 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
 #pragma unroll
             for (int b = 0; b < B; b++)
               x[b] = live && v0 + b < nv ? vals.get(v0 + b, slot) : 0.0;
-            // lanes of the same cell add in lane order
+            // lanes of the same cell add in lane order: rounds in which the lowest pending lane of every cell adds
+            // its value (a few rounds when the 64 particles spread over many cells) ...
             bool pending = live;
-            while (__ballot(pending)) {
+            for (int round = 0;; round++) {
+              const int left = __builtin_popcountll(__ballot(pending));
+              if (left == 0 || (round >= 2 && left > 24))
+                break;
               if (pending)
                 atomicMin(&s_claim[wave][sl], (uint32_t) lane);
               __builtin_amdgcn_wave_barrier();
@@ -1450,6 +1500,35 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
                 s_cnt[wave][sl] += 1;
                 s_claim[wave][sl] = ~0u;
                 pending = false;
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+            // ... then cell by cell: the values of the cell's lanes are read from the lanes in ascending order
+            // and added to the table entry by every lane alike (few cells with many particles each)
+            unsigned long long rest = __ballot(pending);
+            while (rest) {
+              const int l0 = __builtin_ctzll(rest);
+              const int s0 = __builtin_amdgcn_readlane(sl, l0);
+              unsigned long long same = __ballot(pending && sl == s0);
+              rest &= ~same;
+              double acc[B];
+#pragma unroll
+              for (int b = 0; b < B; b++)
+                acc[b] = s_tab[wave][b][s0];
+              const uint32_t more = (uint32_t) __builtin_popcountll(same);
+              while (same) {
+                const int l = __builtin_ctzll(same);
+                same &= same - 1;
+#pragma unroll
+                for (int b = 0; b < B; b++)
+                  acc[b] += lane_value(x[b], l);
+              }
+              __builtin_amdgcn_wave_barrier();
+              if (lane == l0) {
+#pragma unroll
+                for (int b = 0; b < B; b++)
+                  s_tab[wave][b][s0] = acc[b];
+                s_cnt[wave][s0] += more;
               }
               __builtin_amdgcn_wave_barrier();
             }
