@@ -119,11 +119,38 @@ static void hip_met_view(met_t *m, mphip_met_t *v) {
 #undef X
 }
 
+/* rank -> device as the reference binds MPI ranks to OpenACC devices (src/trac.c:70-81) */
 void mptrac_hip_alloc(const int rank) {
-  int ndev = 1;
+  const char *per_node = getenv("MPTRAC_HIP_DEVICES");     /* GPUs per node, default 8 */
+  const int ndev = per_node != NULL && atoi(per_node) > 0 ? atoi(per_node) : 8;
   if (mphip_create(&hip_ctx, rank % ndev) != 0)
     ERRMSG("MPTRAC_HIP: no usable HIP device!");
 }
+
+#ifdef MPI
+/* Optional: the ranks of MPI_COMM_WORLD share ONE simulation -- rank k keeps the k-th index range of the
+ * particles (the caller trims atm to it and passes ip0 / np_total to mptrac_hip_update_atm_range), and the
+ * gridded sums of module_mixing and write_grid are all-reduced by RCCL inside the back end, on its stream.
+ * Call once after mptrac_hip_alloc.  (The reference's own MPI mode farms work directories over the ranks,
+ * src/trac.c:83-98; that needs nothing from the back end.) */
+void mptrac_hip_comm_init(void) {
+  int rank, size;
+  unsigned char id[128];
+  MPI_Comm_rank(MPI_COMM_WORLD, &rank);
+  MPI_Comm_size(MPI_COMM_WORLD, &size);
+  if (rank == 0 && mphip_comm_unique_id(id) != 0)
+    ERRMSG("MPTRAC_HIP: cannot create an RCCL unique id!");
+  MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
+  HIPCALL(mphip_comm_init(hip_ctx, size, rank, id));
+}
+
+void mptrac_hip_update_atm_range(const atm_t *atm, const long long ip0, const long long np_total) {
+  const double *q[NQ];
+  for (int iq = 0; iq < hip_nq; iq++)
+    q[iq] = atm->q[iq];
+  HIPCALL(mphip_update_atm(hip_ctx, atm->np, ip0, np_total, hip_nq, atm->time, atm->p, atm->lon, atm->lat, q));
+}
+#endif
 
 void mptrac_hip_free(void) {
   mphip_destroy(hip_ctx);

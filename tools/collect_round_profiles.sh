@@ -1,0 +1,14 @@
+set -u
+cd $GRAFT_REPO_ROOT
+T=r02b
+bash tools/profile.sh $T > gpurun_out/${T}_profile.log 2>&1
+python tools/summarize_prof.py gpurun_out/prof_$T > gpurun_out/prof_$T/summary.txt 2>&1
+bash tools/profile_valu_mix.sh ${T}mix > gpurun_out/${T}_mix.log 2>&1
+bash tools/profile_mem.sh ${T}mem > gpurun_out/${T}_mem.log 2>&1
+python tools/summarize_prof.py gpurun_out/prof_${T}mem > gpurun_out/prof_${T}mem/summary.txt 2>&1
+for w in C5 C3z C3m C2; do
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${T}_$w -o s -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_${T}_$w.log 2>&1)
+  python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_$w.json
+done
+python bench.py > gpurun_out/${T}_bench_C3.json 2> gpurun_out/${T}_bench_C3.err
+tail -c 600 gpurun_out/${T}_bench_C3.json
