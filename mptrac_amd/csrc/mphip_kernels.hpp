@@ -1289,8 +1289,11 @@ struct GridVals {  // write_grid: q and q^2 of every quantity (kernel weight 1, 
 };
 
 // sequence in external order: seq_cell[ip] = cell, seq_slot[ip] = where the particle is stored
+// (`gate`: the kernels of the general pass do nothing unless *gate is set -- see ordered_cell_sums)
 __global__ void cell_pairs_kernel(const int *__restrict__ cell, const int *__restrict__ ext, long long n,
-                                  int *__restrict__ seq_cell, int *__restrict__ seq_slot) {
+                                  int *__restrict__ seq_cell, int *__restrict__ seq_slot, const int *__restrict__ gate) {
+  if (gate && *gate == 0)
+    return;
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
     const int at = ext[i];
     seq_cell[at] = cell[i];
@@ -1332,8 +1335,11 @@ __device__ __forceinline__ RunHeads run_heads_of_wave(const int *__restrict__ se
 }
 
 __global__ __launch_bounds__(256) void run_heads_count_kernel(const int *__restrict__ seq, long long n, int G,
-                                                              uint32_t *__restrict__ tile_runs) {
+                                                              uint32_t *__restrict__ tile_runs,
+                                                              const int *__restrict__ gate) {
   __shared__ uint32_t wsum[4];
+  if (gate && *gate == 0)
+    return;
   const RunHeads H = run_heads_of_wave(seq, n, G);
   if ((threadIdx.x & 63) == 0)
     wsum[threadIdx.x >> 6] = H.count;
@@ -1343,8 +1349,15 @@ __global__ __launch_bounds__(256) void run_heads_count_kernel(const int *__restr
 }
 
 // exclusive scan of the per-tile run counts in place (one workgroup, any length); tile_runs[ntiles] = number of runs
-__global__ __launch_bounds__(kScanThreads) void run_offsets_kernel(uint32_t *__restrict__ tile_runs, int ntiles) {
+// (gate closed: no runs)
+__global__ __launch_bounds__(kScanThreads) void run_offsets_kernel(uint32_t *__restrict__ tile_runs, int ntiles,
+                                                                   const int *__restrict__ gate) {
   __shared__ uint32_t wsum[kScanThreads / 64];
+  if (gate && *gate == 0) {
+    if (threadIdx.x == 0)
+      tile_runs[ntiles] = 0;
+    return;
+  }
   uint32_t carry = 0;
   for (int base = 0; base < ntiles; base += kScanThreads) {
     const int i = base + (int) threadIdx.x;
@@ -1365,8 +1378,11 @@ __global__ __launch_bounds__(kScanThreads) void run_offsets_kernel(uint32_t *__r
 __global__ __launch_bounds__(256) void run_compact_kernel(const int *__restrict__ seq, long long n, int G,
                                                           const uint32_t *__restrict__ tile_offset, int ntiles,
                                                           uint32_t outside, uint32_t *__restrict__ run_key,
-                                                          int *__restrict__ run_id, uint32_t *__restrict__ run_start) {
+                                                          int *__restrict__ run_id, uint32_t *__restrict__ run_start,
+                                                          const int *__restrict__ gate) {
   __shared__ uint32_t wsum[4];
+  if (gate && *gate == 0)
+    return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const RunHeads H = run_heads_of_wave(seq, n, G);
   if (lane == 0)
@@ -1399,25 +1415,115 @@ __device__ __forceinline__ double lane_value(double x, int l) {
   return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
 }
 
-// Sums over the sorted runs (keys[j] = group, ids[j] = run; the runs of a group are neighbours, in ascending
-// external index; *nruns_dev of them).  Wave w looks at runs 64 w ... 64 w + 63 and does the groups that begin
-// there.  sums[v * ntot + cell], cnt[cell] / cnt_as_double[cell] (either may be NULL) must be zero on entry:
-// groups without particles are not touched.
-template <class VALS, int B>
+// LDS of one wave of cell_sum_groups_kernel
+template <int B>
+struct GroupTable {
+  double sum[B][kGroupMax];
+  uint32_t cnt[kGroupMax], claim[kGroupMax];
+  uint32_t excl[64], first[64];   // the current window of 64 runs: exclusive prefix of the lengths, first positions
+};
+
+// the 64 lanes add x[0..B) to the table entries sl (lanes with live == false do nothing), entry by entry in lane order
+template <int B>
+__device__ __forceinline__ void group_table_add(GroupTable<B> &T, int lane, bool live, int sl, const double (&x)[B]) {
+  // rounds in which the lowest pending lane of every cell adds its value (a few rounds when the 64 particles
+  // spread over many cells) ...
+  bool pending = live;
+  for (int round = 0;; round++) {
+    const int left = __builtin_popcountll(__ballot(pending));
+    if (left == 0 || (round >= 2 && left > 24))
+      break;
+    if (pending)
+      atomicMin(&T.claim[sl], (uint32_t) lane);
+    __builtin_amdgcn_wave_barrier();
+    const bool turn = pending && T.claim[sl] == (uint32_t) lane;
+    __builtin_amdgcn_wave_barrier();
+    if (turn) {
+#pragma unroll
+      for (int b = 0; b < B; b++)
+        T.sum[b][sl] += x[b];
+      T.cnt[sl] += 1;
+      T.claim[sl] = ~0u;
+      pending = false;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ... then cell by cell: the values of the cell's lanes are read from the lanes in ascending order and added
+  // to the table entry by every lane alike (few cells with many particles each)
+  unsigned long long rest = __ballot(pending);
+  while (rest) {
+    const int l0 = __builtin_ctzll(rest);
+    const int s0 = __builtin_amdgcn_readlane(sl, l0);
+    unsigned long long same = __ballot(pending && sl == s0);
+    rest &= ~same;
+    double acc[B];
+#pragma unroll
+    for (int b = 0; b < B; b++)
+      acc[b] = T.sum[b][s0];
+    const uint32_t more = (uint32_t) __builtin_popcountll(same);
+    while (same) {
+      const int l = __builtin_ctzll(same);
+      same &= same - 1;
+#pragma unroll
+      for (int b = 0; b < B; b++)
+        acc[b] += lane_value(x[b], l);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == l0) {
+#pragma unroll
+      for (int b = 0; b < B; b++)
+        T.sum[b][s0] = acc[b];
+      T.cnt[s0] += more;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+constexpr int kSortCap = 1024;   // particles of a group that one wave can put into index order in LDS
+
+// bitonic sort of m (a power of two >= 64) 64-bit keys in LDS by one wave, ascending
+__device__ __forceinline__ void wave_sort(unsigned long long *__restrict__ a, int m, int lane) {
+  for (int k = 2; k <= m; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __builtin_amdgcn_wave_barrier();
+      for (int t = lane; t < m / 2; t += 64) {
+        const int i = 2 * t - (t & (j - 1));   // lower element of pair t (bit log2(j) is zero)
+        const unsigned long long lo = a[i], hi = a[i + j];
+        const bool up = (i & k) == 0;
+        if ((lo > hi) == up) {
+          a[i] = hi;
+          a[i + j] = lo;
+        }
+      }
+    }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Sums over the sorted runs (keys[j] = group, ids[j] = run; the runs of a group are neighbours; *nruns_dev of
+// them).  Wave w looks at runs 64 w ... 64 w + 63 and does the groups that begin there.
+//   BYINDEX false: the sequence the runs were cut from is in external order already (seq_slot: where particle
+//     number p of the sequence is stored, NULL = at p): the group's particles are streamed as they come.
+//   BYINDEX true: the sequence is the stored order (ext[p] = external index of the particle stored at p): the wave
+//     collects the group's particles, sorts them by external index in LDS (<= kSortCap of them; a larger group
+//     sets *overflow and is left to the general pass that follows) and streams them in that order.
+// sums[v * ntot + cell], cnt[cell] / cnt_as_double[cell] (either may be NULL) must be zero on entry: groups
+// without particles are not touched.
+template <class VALS, int B, bool BYINDEX>
 __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const uint32_t *__restrict__ keys,
                                                               const int *__restrict__ ids,
                                                               const uint32_t *__restrict__ nruns_dev, uint32_t outside,
                                                               const uint32_t *__restrict__ run_start,
                                                               const int *__restrict__ seq_cell,
-                                                              const int *__restrict__ seq_slot, int G, size_t ntot,
-                                                              double *__restrict__ sums, int *__restrict__ cnt,
-                                                              double *__restrict__ cnt_as_double) {
-  __shared__ double s_tab[4][B][kGroupMax];
-  __shared__ uint32_t s_cnt[4][kGroupMax], s_claim[4][kGroupMax];
-  __shared__ uint32_t s_excl[4][64], s_first[4][64];
+                                                              const int *__restrict__ seq_slot,
+                                                              const int *__restrict__ ext, int *__restrict__ overflow,
+                                                              int G, size_t ntot, double *__restrict__ sums,
+                                                              int *__restrict__ cnt, double *__restrict__ cnt_as_double) {
+  __shared__ GroupTable<B> s_table[4];
+  __shared__ unsigned long long s_sort[BYINDEX ? 4 : 1][BYINDEX ? kSortCap : 1];
   const long long nruns = (long long) *nruns_dev;
   const int nv = vals.count();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  GroupTable<B> &T = s_table[wave];
   const long long nwaves = (long long) gridDim.x * 4;
   for (long long jbase = ((long long) blockIdx.x * 4 + wave) * 64; jbase < nruns; jbase += nwaves * 64) {
     const long long j = jbase + lane;
@@ -1440,15 +1546,9 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
           break;
       }
       const long long cell0 = (long long) g * G;
-      for (int v0 = 0; v0 < nv; v0 += B) {
-        for (int sl = lane; sl < G; sl += 64) {
-#pragma unroll
-          for (int b = 0; b < B; b++)
-            s_tab[wave][b][sl] = 0.0;
-          s_cnt[wave][sl] = 0;
-          s_claim[wave][sl] = ~0u;
-        }
-        // windows of 64 runs: lane l holds run jw + l; the window's particles are numbered through
+      // BYINDEX: the group's particles as (external index, position) keys, in index order
+      uint32_t nsorted = 0;
+      if (BYINDEX) {
         for (long long jw = j0; jw < j1; jw += 64) {
           const int r = jw + lane < j1 ? ids[jw + lane] : -1;
           const uint32_t first = r >= 0 ? run_start[r] : 0;
@@ -1461,76 +1561,83 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
               incl += y;
           }
           const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
-          __builtin_amdgcn_wave_barrier();
-          s_excl[wave][lane] = incl - len;
-          s_first[wave][lane] = first;
-          __builtin_amdgcn_wave_barrier();
-          for (uint32_t e0 = 0; e0 < total; e0 += 64) {
-            const uint32_t e = e0 + lane;
-            const bool live = e < total;
-            // the run of particle e: the last lane whose exclusive prefix is <= e
-            int w = 0;
+          if (nsorted + total > (uint32_t) kSortCap) {
+            nsorted = ~0u;
+            break;
+          }
+          for (uint32_t q = 0; q < len; q++) {   // (runs are a few particles long)
+            const uint32_t p = first + q;
+            s_sort[wave][nsorted + (incl - len) + q] = ((unsigned long long) (uint32_t) ext[p] << 32) | p;
+          }
+          nsorted += total;
+        }
+        if (nsorted == ~0u) {
+          if (lane == 0)
+            *overflow = 1;
+          continue;
+        }
+        int m = 64;
+        while ((uint32_t) m < nsorted)
+          m <<= 1;
+        for (int t = (int) nsorted + lane; t < m; t += 64)
+          s_sort[wave][t] = ~0ull;
+        wave_sort(s_sort[wave], m, lane);
+      }
+      for (int v0 = 0; v0 < nv; v0 += B) {
+        for (int sl = lane; sl < G; sl += 64) {
 #pragma unroll
-            for (int step = 32; step > 0; step >>= 1)
-              if (s_excl[wave][w + step] <= e)
-                w += step;
-            const uint32_t p = live ? s_first[wave][w] + (e - s_excl[wave][w]) : 0;
-            const int sl = live ? (int) ((long long) seq_cell[p] - cell0) : 0;
-            const long long slot = live ? (seq_slot ? (long long) seq_slot[p] : (long long) p) : 0;
+          for (int b = 0; b < B; b++)
+            T.sum[b][sl] = 0.0;
+          T.cnt[sl] = 0;
+          T.claim[sl] = ~0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (BYINDEX) {
+          for (uint32_t e0 = 0; e0 < nsorted; e0 += 64) {
+            const bool live = e0 + lane < nsorted;
+            const long long slot = live ? (long long) (uint32_t) s_sort[wave][e0 + lane] : 0;
+            const int sl = live ? (int) ((long long) seq_cell[slot] - cell0) : 0;
             double x[B];
 #pragma unroll
             for (int b = 0; b < B; b++)
               x[b] = live && v0 + b < nv ? vals.get(v0 + b, slot) : 0.0;
-            // lanes of the same cell add in lane order: rounds in which the lowest pending lane of every cell adds
-            // its value (a few rounds when the 64 particles spread over many cells) ...
-            bool pending = live;
-            for (int round = 0;; round++) {
-              const int left = __builtin_popcountll(__ballot(pending));
-              if (left == 0 || (round >= 2 && left > 24))
-                break;
-              if (pending)
-                atomicMin(&s_claim[wave][sl], (uint32_t) lane);
-              __builtin_amdgcn_wave_barrier();
-              const bool turn = pending && s_claim[wave][sl] == (uint32_t) lane;
-              __builtin_amdgcn_wave_barrier();
-              if (turn) {
+            group_table_add<B>(T, lane, live, sl, x);
+          }
+        } else {
+          // windows of 64 runs: lane l holds run jw + l; the window's particles are numbered through
+          for (long long jw = j0; jw < j1; jw += 64) {
+            const int r = jw + lane < j1 ? ids[jw + lane] : -1;
+            const uint32_t first = r >= 0 ? run_start[r] : 0;
+            const uint32_t len = r >= 0 ? run_start[r + 1] - first : 0;
+            uint32_t incl = len;
 #pragma unroll
-                for (int b = 0; b < B; b++)
-                  s_tab[wave][b][sl] += x[b];
-                s_cnt[wave][sl] += 1;
-                s_claim[wave][sl] = ~0u;
-                pending = false;
-              }
-              __builtin_amdgcn_wave_barrier();
+            for (int d = 1; d < 64; d <<= 1) {
+              const uint32_t y = (uint32_t) __shfl_up((int) incl, d);
+              if (lane >= d)
+                incl += y;
             }
-            // ... then cell by cell: the values of the cell's lanes are read from the lanes in ascending order
-            // and added to the table entry by every lane alike (few cells with many particles each)
-            unsigned long long rest = __ballot(pending);
-            while (rest) {
-              const int l0 = __builtin_ctzll(rest);
-              const int s0 = __builtin_amdgcn_readlane(sl, l0);
-              unsigned long long same = __ballot(pending && sl == s0);
-              rest &= ~same;
-              double acc[B];
+            const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, 63);
+            __builtin_amdgcn_wave_barrier();
+            T.excl[lane] = incl - len;
+            T.first[lane] = first;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t e0 = 0; e0 < total; e0 += 64) {
+              const uint32_t e = e0 + lane;
+              const bool live = e < total;
+              // the run of particle e: the last lane whose exclusive prefix is <= e
+              int w = 0;
+#pragma unroll
+              for (int step = 32; step > 0; step >>= 1)
+                if (T.excl[w + step] <= e)
+                  w += step;
+              const uint32_t p = live ? T.first[w] + (e - T.excl[w]) : 0;
+              const int sl = live ? (int) ((long long) seq_cell[p] - cell0) : 0;
+              const long long slot = live ? (seq_slot ? (long long) seq_slot[p] : (long long) p) : 0;
+              double x[B];
 #pragma unroll
               for (int b = 0; b < B; b++)
-                acc[b] = s_tab[wave][b][s0];
-              const uint32_t more = (uint32_t) __builtin_popcountll(same);
-              while (same) {
-                const int l = __builtin_ctzll(same);
-                same &= same - 1;
-#pragma unroll
-                for (int b = 0; b < B; b++)
-                  acc[b] += lane_value(x[b], l);
-              }
-              __builtin_amdgcn_wave_barrier();
-              if (lane == l0) {
-#pragma unroll
-                for (int b = 0; b < B; b++)
-                  s_tab[wave][b][s0] = acc[b];
-                s_cnt[wave][s0] += more;
-              }
-              __builtin_amdgcn_wave_barrier();
+                x[b] = live && v0 + b < nv ? vals.get(v0 + b, slot) : 0.0;
+              group_table_add<B>(T, lane, live, sl, x);
             }
           }
         }
@@ -1541,12 +1648,12 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
 #pragma unroll
             for (int b = 0; b < B; b++)
               if (v0 + b < nv)
-                sums[(size_t) (v0 + b) * ntot + (size_t) c] = s_tab[wave][b][sl];
+                sums[(size_t) (v0 + b) * ntot + (size_t) c] = T.sum[b][sl];
             if (v0 == 0) {
               if (cnt)
-                cnt[c] = (int) s_cnt[wave][sl];
+                cnt[c] = (int) T.cnt[sl];
               if (cnt_as_double)
-                cnt_as_double[c] = (double) s_cnt[wave][sl];
+                cnt_as_double[c] = (double) T.cnt[sl];
             }
           }
         }
