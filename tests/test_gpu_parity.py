@@ -436,6 +436,44 @@ def test_ordered_cell_sums_with_long_lists():
             assert np.array_equal(x, y)
 
 
+GRID_SHAPES = [
+    # nx, ny, nz, lon0, lon1, lat0, lat1, z0, z1
+    (1, 1, 1, -180.0, 180.0, -90.0, 90.0, 0.0, 40.0),          # one cell holds everything
+    (360, 180, 1, -180.0, 180.0, -90.0, 90.0, 0.0, 40.0),      # the default 2-D output grid
+    (7, 5, 200, -30.0, 40.0, -20.0, 35.0, 2.0, 22.0),          # columns longer than a cell group, most particles outside
+    (37, 19, 129, -180.0, 180.0, -90.0, 90.0, -5.0, 35.0),     # a column is one cell more than a group
+    (3, 2, 64, 10.0, 10.5, 20.0, 20.2, 5.0, 6.0),              # (almost) nobody inside
+]
+
+
+@pytest.mark.parametrize("shape", GRID_SHAPES, ids=["1x1x1", "360x180x1", "7x5x200", "37x19x129", "tiny_window"])
+@pytest.mark.parametrize("order", ["external", "locality"])
+def test_ordered_grid_sums_on_odd_grids(shape, order):
+    """Gridded-output sums (counts, sums of q and of q^2) against the serial sums, bit for bit, on grids that
+    stress the grouping of the ordered sums: a single cell, one level, columns longer than a group of cells, a
+    window that holds few or no particles -- with the particles stored in the caller's order and in the internal
+    locality order (external index = a permutation)."""
+    nx, ny, nz, lon0, lon1, lat0, lat1, z0, z1 = shape
+    ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=30011)
+    ctl = dict(ctl, grid_nx=nx, grid_ny=ny, grid_nz=nz, grid_lon0=lon0, grid_lon1=lon1, grid_lat0=lat0,
+               grid_lat1=lat1, grid_z0=z0, grid_z1=z1)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.set_option("locality_sort_interval", 1 if order == "locality" else 0)
+    s.timesteps_init(0.0, 0.0)
+    ts = cases.step_times(s.ctl)
+    for t in ts[:3]:
+        s.run_timestep(t)
+    _oracle_takes_device_state(o, s)
+    co, mo, so = o.grid_sums(ts[2])
+    cs, ms, ss = s.grid_sums(ts[2])
+    assert np.array_equal(co, cs)
+    assert np.array_equal(mo, ms) and np.array_equal(so, ss)
+    if nx * ny * nz == 1:
+        assert co[0] == 30011
+    s.close()
+
+
 # ---------------------------------------------------------------------------
 # edge cases
 # ---------------------------------------------------------------------------
