@@ -51,6 +51,9 @@ static int g_meteo_fields;              /* a module_meteo quantity is requested:
 
 /* scan_ctl, jsec2time, time2jsec: ctlfile.c */
 
+/* a condition the input has to meet, else the run stops with the message */
+#define REQUIRE(ok, ...) { if (!(ok)) ERRMSG(__VA_ARGS__); }
+
 /* -------------------------------------------------------------------------- */
 /* alloc / free                                                               */
 /* -------------------------------------------------------------------------- */
@@ -59,16 +62,13 @@ void mptrac_alloc(ctl_t **ctl, cache_t **cache, clim_t **clim, met_t **met0, met
                   depo_t **depo, dd_t **dd) {
   /* one calloc per struct as the reference (mptrac.c:6294-6372); the device
    * context is created in mptrac_init, once the device ordinal is known */
-  ALLOC(*ctl, ctl_t, 1);
-  ALLOC(*cache, cache_t, 1);
-  ALLOC(*clim, clim_t, 1);
-  ALLOC(*met0, met_t, 1);
-  ALLOC(*met1, met_t, 1);
-  ALLOC(*atm, atm_t, 1);
+#define ZEROED(pp) ALLOC(*(pp), __typeof__(**(pp)), 1)
+  ZEROED(ctl); ZEROED(cache); ZEROED(clim); ZEROED(met0); ZEROED(met1); ZEROED(atm);
   if (depo)
-    ALLOC(*depo, depo_t, 1);
+    ZEROED(depo);
   if (dd)
-    ALLOC(*dd, dd_t, 1);
+    ZEROED(dd);
+#undef ZEROED
 }
 
 void mptrac_free(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t *met0, met_t *met1, atm_t *atm,
@@ -273,8 +273,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   /* checks and the keys that depend on others */
   ctl->met_utm_ref_lat = (ctl->met_coord_type != 0)
     ? scan_ctl(filename, argc, argv, "MET_UTM_REF_LAT", -1, "", NULL) : 0;
-  if (ctl->direction != -1 && ctl->direction != 1)
-    ERRMSG("Set DIRECTION to -1 or 1!");
+  REQUIRE(ctl->direction == -1 || ctl->direction == 1, "Set DIRECTION to -1 or 1!");
   if (ctl->met_type == 0) {
     /* netCDF input is taken as stored: no down-sampling, smoothing, detrending, re-gridding (mptrac.c:7770-7830) */
     static const struct {
@@ -289,10 +288,8 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   }
 
   /* modules (mptrac.c:7196-7263) */
-  if (!(ctl->advect == 1 || ctl->advect == 2 || ctl->advect == 4))
-    ERRMSG("Set ADVECT to 1, 2, or 4!");
-  if (ctl->turb_pbl_trans < 0 || ctl->turb_pbl_trans > 1)
-    ERRMSG("TURB_PBL_TRANS must be in the range [0, 1]!");
+  REQUIRE(ctl->advect == 1 || ctl->advect == 2 || ctl->advect == 4, "Set ADVECT to 1, 2, or 4!");
+  REQUIRE(ctl->turb_pbl_trans >= 0 && ctl->turb_pbl_trans <= 1, "TURB_PBL_TRANS must be in the range [0, 1]!");
   /* isosurface and boundary conditions (mptrac.c:7207-7209, 7266-7289) */
   /* SPECIES presets (values: mptrac.c:7291-7383): molar mass and Henry's-law constants become the defaults of
    * MOLMASS / WET_DEPO_*_H below; a species that also switches the OH chemistry on is only accepted with that
@@ -337,19 +334,16 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   ctl->wet_depo_bc_h[1] = henry_default[1];
   ctl->wet_depo_pre[0] = scan_ctl(filename, argc, argv, "WET_DEPO_PRE", 0, "0.5", NULL);
   ctl->wet_depo_pre[1] = scan_ctl(filename, argc, argv, "WET_DEPO_PRE", 1, "0.36", NULL);
-  if (ctl->mixing_nx < 1 || ctl->mixing_ny < 1 || ctl->mixing_nz < 1 || ctl->mixing_lon0 >= ctl->mixing_lon1
-      || ctl->mixing_lat0 >= ctl->mixing_lat1 || ctl->mixing_z0 >= ctl->mixing_z1
-      || ctl->mixing_lat0 < -90 || ctl->mixing_lat1 > 90)
-    ERRMSG("Invalid mixing grid!");
+  REQUIRE(ctl->mixing_nx >= 1 && ctl->mixing_ny >= 1 && ctl->mixing_nz >= 1 && ctl->mixing_lon0 < ctl->mixing_lon1
+          && ctl->mixing_lat0 < ctl->mixing_lat1 && ctl->mixing_z0 < ctl->mixing_z1 && ctl->mixing_lat0 >= -90
+          && ctl->mixing_lat1 <= 90, "Invalid mixing grid!");
 
   /* output (mptrac.c:7551-7648) */
-  if (ctl->atm_type_out == -1)
+  if (ctl->atm_type_out < 0)   /* -1: as the input */
     ctl->atm_type_out = ctl->atm_type;
-  if (ctl->grid_nx < 1 || ctl->grid_ny < 1 || ctl->grid_nz < 1)
-    ERRMSG("Invalid output grid dimensions!");
-  if (ctl->grid_lon0 >= ctl->grid_lon1 || ctl->grid_lat0 >= ctl->grid_lat1 || ctl->grid_z0 >= ctl->grid_z1
-      || ctl->grid_lat0 < -90 || ctl->grid_lat1 > 90)
-    ERRMSG("Invalid output grid boundaries!");
+  REQUIRE(ctl->grid_nx >= 1 && ctl->grid_ny >= 1 && ctl->grid_nz >= 1, "Invalid output grid dimensions!");
+  REQUIRE(ctl->grid_lon0 < ctl->grid_lon1 && ctl->grid_lat0 < ctl->grid_lat1 && ctl->grid_z0 < ctl->grid_z1
+          && ctl->grid_lat0 >= -90 && ctl->grid_lat1 <= 90, "Invalid output grid boundaries!");
 
   /* back-end options */
 
@@ -373,12 +367,10 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   }
   if (ctl->rng_type != 1)
     ERRMSG("This build implements RNG_TYPE 1 (Squares) only!");
-  if (ctl->advect_vert_coord < 0 || ctl->advect_vert_coord > 3)
-    ERRMSG("Set ADVECT_VERT_COORD to 0, 1, 2, or 3!");
-  if (ctl->advect_vert_coord == 1 && ctl->qnt_zeta < 0)
-    ERRMSG("Please add zeta to your quantities for diabatic calculations!");   /* mptrac.c:6992 */
-  if (ctl->advect_vert_coord == 3 && ctl->qnt_eta < 0)
-    ERRMSG("Please add eta to your quantities for etadot calculations!");      /* mptrac.c:6994 */
+  REQUIRE(ctl->advect_vert_coord >= 0 && ctl->advect_vert_coord <= 3, "Set ADVECT_VERT_COORD to 0, 1, 2, or 3!");
+  REQUIRE(ctl->advect_vert_coord != 1 || ctl->qnt_zeta >= 0,                   /* messages: mptrac.c:6992-6994 */
+          "Please add zeta to your quantities for diabatic calculations!");
+  REQUIRE(ctl->advect_vert_coord != 3 || ctl->qnt_eta >= 0, "Please add eta to your quantities for etadot calculations!");
   /* MET_TYPE 1 files carry pressure-level fields only (mptrac.c:8887-9043); the model-level options of
    * the back end are reached through the C ABI (mphip_update_met with pl, ul, vl, wl, zetal, zeta_dotl) */
   if (ctl->advect_vert_coord == 2)
@@ -541,8 +533,7 @@ int mptrac_read_atm(const char *filename, const ctl_t *ctl, atm_t *atm) {
  * ATM_FILTER 1 blanks (NaN), 2 drops the particles whose time is not within half a step of t */
 static void write_atm_asc(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t) {
   FILE *out = fopen(filename, "w");
-  if (!out)
-    ERRMSG("Cannot create file!");
+  REQUIRE(out, "Cannot create file!");
   const int cartesian = ctl->met_coord_type != 0;
   const char *legend[4] = { "time [s]", "altitude [km]", cartesian ? "x [m]" : "longitude [deg]",
     cartesian ? "y [m]" : "latitude [deg]" };
@@ -568,8 +559,7 @@ static void write_atm_asc(const char *filename, const ctl_t *ctl, const atm_t *a
 
 static void write_atm_bin(const char *filename, const ctl_t *ctl, const atm_t *atm) {
   FILE *out = fopen(filename, "w");
-  if (!out)
-    ERRMSG("Cannot create file!");
+  REQUIRE(out, "Cannot create file!");
   const int head[2] = { 100, atm->np }, tail = 999;
   put_items(out, head, sizeof(int), 2);
   double *col[4 + NQ];
@@ -589,6 +579,9 @@ void mptrac_write_atm(const char *filename, const ctl_t *ctl, const atm_t *atm, 
   else
     ERRMSG("Atmospheric data type not supported (this build writes ATM_TYPE_OUT 0 and 1)!");
 }
+
+/* every column (i, j) of the grid */
+#define EACH_COLUMN(met, i, j) for (int i = 0; i < (met)->nx; i++) for (int j = 0; j < (met)->ny; j++)
 
 /* -------------------------------------------------------------------------- */
 /* meteo I/O: the reference's raw binary format (MET_TYPE 1, version 104)     */
@@ -687,8 +680,7 @@ void mptrac_write_met(const char *filename, const ctl_t *ctl, met_t *met) {
   if (ctl->met_type != 1)
     ERRMSG("This build writes MET_TYPE 1 (raw binary) meteo files only!");
   FILE *out = fopen(filename, "w");
-  if (!out)
-    ERRMSG("Cannot create file!");
+  REQUIRE(out, "Cannot create file!");
   const int head[2] = { ctl->met_type, 104 }, dims[3] = { met->nx, met->ny, met->np }, tail = 999;
   put_items(out, head, sizeof(int), 2);
   put_items(out, &met->time, sizeof(double), 1);
@@ -776,10 +768,10 @@ static int nc_field(const nc_reader *r, const char *const *names, const int nlev
       help[i] = ((fillval == 0 || v != fillval) && (missval == 0 || v != missval) && fabsf(v) < 1e14f) ? scl * v : NAN;
     }
   }
-  for (int ix = 0; ix < met->nx; ix++)
-    for (int iy = 0; iy < met->ny; iy++)
-      for (int ip = 0; ip < lev; ip++)
-        dest[((size_t) ix * EY + (size_t) iy) * stride + (size_t) ip] = help[((size_t) ip * met->ny + iy) * met->nx + ix];
+  /* file order [level][y][x] -> met_t order [x][y][level] */
+  EACH_COLUMN(met, i, j)
+    for (int k = 0; k < lev; k++)
+      dest[((size_t) i * EY + (size_t) j) * stride + (size_t) k] = help[((size_t) k * met->ny + j) * met->nx + i];
   free(help);
   return 1;
 }
@@ -837,23 +829,21 @@ static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
   const int vl = ncc_find_var(nc, levname);
   if (vl < 0 || !ncc_read_double(nc, vl, 0, 0, np, met->p))
     ERRMSG("Cannot read the pressure levels!");
-  for (int ip = 0; ip < met->np; ip++)
-    met->p[ip] /= 100.;
-  for (int ix = 2; ix < met->nx; ix++)
-    if (fabs(fabs(met->lon[ix] - met->lon[ix - 1]) - fabs(met->lon[1] - met->lon[0])) > 0.001)
-      ERRMSG("No regular grid spacing in longitudes!");
+  for (int k = 0; k < met->np; k++)
+    met->p[k] /= 100.0;   /* Pa -> hPa */
+  const double dx = fabs(met->lon[1] - met->lon[0]);
+  for (int i = 2; i < met->nx; i++)
+    REQUIRE(fabs(fabs(met->lon[i] - met->lon[i - 1]) - dx) <= 0.001, "No regular grid spacing in longitudes!");
   LOG(2, "Grid: %d x %d x %d, %g ... %g hPa", met->nx, met->ny, met->np, met->p[0], met->p[met->np - 1]);
 
   /* surface fields */
-  if (NC_2D(ps, 1.0f, "lnsp", "LNSP")) {
-    for (int ix = 0; ix < met->nx; ix++)
-      for (int iy = 0; iy < met->ny; iy++)
-        met->ps[ix][iy] = (float) (exp(met->ps[ix][iy]) / 100.);
+  if (NC_2D(ps, 1.0f, "lnsp", "LNSP")) {   /* logarithm of the surface pressure in Pa */
+    EACH_COLUMN(met, i, j)
+      met->ps[i][j] = (float) (exp(met->ps[i][j]) / 100.);
   } else if (!NC_2D(ps, 0.01f, "ps", "PS", "sp", "SP")) {
     WARN("Cannot not read surface pressure data (use lowest level)!");
-    for (int ix = 0; ix < met->nx; ix++)
-      for (int iy = 0; iy < met->ny; iy++)
-        met->ps[ix][iy] = (float) met->p[0];
+    EACH_COLUMN(met, i, j)
+      met->ps[i][j] = (float) met->p[0];
   }
   (void) NC_2D(zs, (float) (1. / (1000. * 9.80665)), "z", "Z");
   (void) NC_2D(ts, 1.0f, "t2m", "T2M", "2t", "2T", "t2", "T2");
@@ -864,23 +854,16 @@ static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
   (void) NC_2D(shf, 1.0f, "ishf", "ISHF");
   (void) NC_2D(lsm, 1.0f, "lsm", "LSM");
   (void) NC_2D(sst, 1.0f, "sstk", "SSTK", "sst", "SST");
-  int have_pbl = 0;
-  if (ctl->met_pbl == 0)
-    have_pbl = NC_2D(pbl, 0.01f, "blp", "BLP");
-  int have_cape = 0;
-  if (ctl->met_cape == 0)
-    have_cape = NC_2D(cape, 1.0f, "cape", "CAPE") && NC_2D(cin, 1.0f, "cin", "CIN");
+  const int have_pbl = ctl->met_pbl == 0 && NC_2D(pbl, 0.01f, "blp", "BLP");
+  const int have_cape = ctl->met_cape == 0 && NC_2D(cape, 1.0f, "cape", "CAPE") && NC_2D(cin, 1.0f, "cin", "CIN");
 
   /* level fields */
-  if (!NC_3D(t, 1.0f, "t", "T", "temp", "TEMP"))
-    ERRMSG("Cannot read temperature!");
-  if (!NC_3D(u, 1.0f, "u", "U"))
-    ERRMSG("Cannot read zonal wind!");
-  if (!NC_3D(v, 1.0f, "v", "V"))
-    ERRMSG("Cannot read meridional wind!");
-  if (!NC_3D(w, 0.01f, "w", "W", "omega", "OMEGA"))
+  REQUIRE(NC_3D(t, 1.0f, "t", "T", "temp", "TEMP"), "Cannot read temperature!");
+  REQUIRE(NC_3D(u, 1.0f, "u", "U"), "Cannot read zonal wind!");
+  REQUIRE(NC_3D(v, 1.0f, "v", "V"), "Cannot read meridional wind!");
+  if (!NC_3D(w, 0.01f, "w", "W", "omega", "OMEGA"))   /* Pa/s -> hPa/s */
     WARN("Cannot read vertical velocity!");
-  if (!NC_3D(h2o, (float) (MA / 18.01528), "q", "Q", "sh", "SH"))
+  if (!NC_3D(h2o, (float) (MA / 18.01528), "q", "Q", "sh", "SH"))   /* mass -> volume mixing ratio */
     WARN("Cannot read specific humidity!");
   if (!NC_3D(o3, (float) (MA / 47.997), "o3", "O3"))
     WARN("Cannot read ozone data!");
@@ -888,25 +871,22 @@ static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
     & NC_3D(iwc, 1.0f, "ciwc", "CIWC") & NC_3D(swc, 1.0f, "cswc", "CSWC");
   (void) NC_3D(cc, 1.0f, "cc", "CC");
   ncc_close(nc);
-  for (int ip = 1; ip < met->np; ip++)
-    if (met->p[ip - 1] < met->p[ip])
-      ERRMSG("Pressure levels must be descending!");
+  for (int k = 1; k < met->np; k++)
+    REQUIRE(met->p[k - 1] >= met->p[k], "Pressure levels must be descending!");
 
-  /* read_met_extrapolate */
-  for (int ix = 0; ix < met->nx; ix++)
-    for (int iy = 0; iy < met->ny; iy++) {
-      int ip0;
-      for (ip0 = met->np - 1; ip0 >= 0; ip0--)
-        if (!isfinite(met->t[ix][iy][ip0]) || !isfinite(met->u[ix][iy][ip0]) || !isfinite(met->v[ix][iy][ip0])
-            || !isfinite(met->w[ix][iy][ip0]))
-          break;
-      for (int ip = ip0; ip >= 0; ip--) {
-        float (*f3[11])[EY][EP] = { met->t, met->u, met->v, met->w, met->h2o, met->o3, met->lwc, met->rwc, met->iwc,
-          met->swc, met->cc };
-        for (int k = 0; k < 11; k++)
-          f3[k][ix][iy][ip] = ip + 1 < EP ? f3[k][ix][iy][ip + 1] : 0.f;
-      }
-    }
+  /* below the lowest level with valid t, u, v, w every level field continues with that level's value
+   * (reference: read_met_extrapolate) */
+  EACH_COLUMN(met, i, j) {
+    int low = met->np - 1;
+    while (low >= 0 && isfinite(met->t[i][j][low]) && isfinite(met->u[i][j][low]) && isfinite(met->v[i][j][low])
+           && isfinite(met->w[i][j][low]))
+      low--;
+    float (*f3[11])[EY][EP] = { met->t, met->u, met->v, met->w, met->h2o, met->o3, met->lwc, met->rwc, met->iwc,
+      met->swc, met->cc };
+    for (int k = low; k >= 0; k--)
+      for (int f = 0; f < 11; f++)
+        f3[f][i][j][k] = k + 1 < EP ? f3[f][i][j][k + 1] : 0.f;
+  }
 
   /* Fields the reference derives in its preprocessing.  The boundary-layer pressure enters module_diff_turb
    * only through weights that multiply TURB_DX_PBL / TURB_DZ_PBL against TURB_DX_TROP / TURB_DZ_TROP: with
@@ -918,9 +898,8 @@ static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
         || ctl->turb_pbl_scheme != 0 || ctl->bound_pbl || ctl->qnt_pbl >= 0)
       ERRMSG("This configuration uses the boundary-layer pressure, which the reference derives in its meteo "
              "preprocessing (not provided): supply it in the file (MET_PBL 0, variable blp) or use MET_TYPE 1 files!");
-    for (int ix = 0; ix < met->nx; ix++)
-      for (int iy = 0; iy < met->ny; iy++)
-        met->pbl[ix][iy] = met->ps[ix][iy] - 100.f;
+    EACH_COLUMN(met, i, j)
+      met->pbl[i][j] = met->ps[i][j] - 100.f;
   }
   (void) have_cloud;
   if (ctl->conv_cape >= 0)
@@ -1193,27 +1172,27 @@ void mptrac_update_device(const ctl_t *ctl, const cache_t *cache, const clim_t *
                           met_t **met1, const atm_t *atm) {
   /* NULL = skip, as the reference (mptrac.c:8005-8057) */
   need_ctx(ctl);
-  if (ctl != NULL) {
+  if (ctl) {
     mphip_ctl_t d;
     to_device_ctl(ctl, &d);
     HIP(mphip_update_ctl(g_ctx, &d));
     g_nq = ctl->nq;
   }
-  if (clim != NULL)
+  if (clim)
     HIP(mphip_update_clim(g_ctx, clim->tropo_ntime, clim->tropo_nlat, clim->tropo_time, clim->tropo_lat,
                           &clim->tropo[0][0], 73));
-  if (met0 != NULL)
+  if (met0)
     upload_met(*met0, 0);
-  if (met1 != NULL)
+  if (met1)
     upload_met(*met1, 1);
-  if (atm != NULL) {
+  if (atm) {
     const double *q[MPHIP_NQ_MAX] = { 0 };
     for (int iq = 0; iq < g_nq; iq++)
       q[iq] = atm->q[iq];
     HIP(mphip_update_atm(g_ctx, atm->np, g_ip0, g_np_total >= 0 ? g_np_total : atm->np, g_nq, atm->time, atm->p,
                          atm->lon, atm->lat, q));
   }
-  if (cache != NULL) {
+  if (cache) {
     HIP(mphip_update_cache(g_ctx, &cache->uvwp[0][0], NULL));
     if (g_isosurf >= 1 && g_isosurf <= 3)
       HIP(mphip_update_iso(g_ctx, cache->iso_var, NULL, NULL, 0));
@@ -1231,14 +1210,14 @@ void mptrac_update_host(const ctl_t *ctl, const cache_t *cache, const clim_t *cl
   (void) met1;
   if (!g_ctx)
     return;
-  if (atm != NULL) {
+  if (atm) {
     atm_t *a = (atm_t *) atm;   /* the reference's signature is const; the data are refreshed */
     double *q[MPHIP_NQ_MAX] = { 0 };
     for (int iq = 0; iq < g_nq; iq++)
       q[iq] = a->q[iq];
     HIP(mphip_get_atm(g_ctx, a->time, a->p, a->lon, a->lat, q));
   }
-  if (cache != NULL) {
+  if (cache) {
     cache_t *c = (cache_t *) cache;
     HIP(mphip_get_cache(g_ctx, &c->uvwp[0][0], c->dt, NULL));
     if (g_isosurf >= 1 && g_isosurf <= 3)
@@ -1467,63 +1446,65 @@ void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1
     return;
   }
 
-  const double dz = (ctl->grid_z1 - ctl->grid_z0) / ctl->grid_nz;
-  const double dlon = (ctl->grid_lon1 - ctl->grid_lon0) / ctl->grid_nx;
-  const double dlat = (ctl->grid_lat1 - ctl->grid_lat0) / ctl->grid_ny;
-  FILE *out;
-  if (!(out = fopen(filename, "w")))
-    ERRMSG("Cannot create file!");
-  fprintf(out, "# $1 = time [s]\n# $2 = altitude [km]\n# $3 = longitude [deg]\n# $4 = latitude [deg]\n"
-          "# $5 = surface area [km^2]\n# $6 = layer depth [km]\n# $7 = column density (implicit) [kg/m^2]\n"
-          "# $8 = volume mixing ratio (implicit) [ppv]\n# $9 = number of particles [1]\n");
-  for (int iq = 0; iq < ctl->nq; iq++)
-    fprintf(out, "# $%i = %s (mean) [%s]\n", 10 + iq, ctl->qnt_name[iq], ctl->qnt_unit[iq]);
-  if (ctl->grid_stddev)
-    for (int iq = 0; iq < ctl->nq; iq++)
-      fprintf(out, "# $%i = %s (stddev) [%s]\n", 10 + ctl->nq + iq, ctl->qnt_name[iq], ctl->qnt_unit[iq]);
-  fprintf(out, "\n");
-  for (int ix = 0; ix < ctl->grid_nx; ix++) {
-    if (ix > 0 && ctl->grid_ny > 1 && !ctl->grid_sparse)
-      fprintf(out, "\n");
-    for (int iy = 0; iy < ctl->grid_ny; iy++) {
-      if (iy > 0 && ctl->grid_nz > 1 && !ctl->grid_sparse)
-        fprintf(out, "\n");
-      const double lat = ctl->grid_lat0 + dlat * (iy + 0.5);
-      const double area = dlat * dlon * SQR(RE * M_PI / 180.) * cos(DEG2RAD(lat));
-      for (int iz = 0; iz < ctl->grid_nz; iz++) {
-        const size_t idx = (size_t) ARRAY_3D(ix, iy, ctl->grid_ny, iz, ctl->grid_nz);
-        const double cd = ctl->qnt_m >= 0 ? mean[(size_t) ctl->qnt_m * ncell + idx] / (1e6 * area) : NAN;
-        double vmr_impl = NAN;   /* mptrac.c:13885-13900 */
-        if (ctl->qnt_m >= 0 && ctl->molmass > 0 && met0 != NULL && met1 != NULL) {
-          vmr_impl = 0;
-          if (mean[(size_t) ctl->qnt_m * ncell + idx] > 0) {
-            const double press = P(ctl->grid_z0 + dz * (iz + 0.5));
-            const double temp = grid_temperature(met0, met1, t, press, ctl->grid_lon0 + dlon * (ix + 0.5), lat);
-            vmr_impl = MA / ctl->molmass * cd / (100. * press / (RA * temp) * dz * 1e3);
-          }
+  /* cell sizes and centres */
+  const double step_z = (ctl->grid_z1 - ctl->grid_z0) / ctl->grid_nz, step_lon = (ctl->grid_lon1 - ctl->grid_lon0) / ctl->grid_nx,
+               step_lat = (ctl->grid_lat1 - ctl->grid_lat0) / ctl->grid_ny;
+  FILE *out = fopen(filename, "w");
+  REQUIRE(out, "Cannot create file!");
+  static const char *const legend[9] = { "time [s]", "altitude [km]", "longitude [deg]", "latitude [deg]",
+    "surface area [km^2]", "layer depth [km]", "column density (implicit) [kg/m^2]", "volume mixing ratio (implicit) [ppv]",
+    "number of particles [1]" };
+  int column = 0;
+  for (int k = 0; k < 9; k++)
+    fprintf(out, "# $%d = %s\n", ++column, legend[k]);
+  for (int pass = 0; pass < (ctl->grid_stddev ? 2 : 1); pass++)
+    for (int q = 0; q < ctl->nq; q++)
+      fprintf(out, "# $%i = %s (%s) [%s]\n", ++column, ctl->qnt_name[q], pass ? "stddev" : "mean", ctl->qnt_unit[q]);
+  fputc('\n', out);
+  /* blocks of the table are separated by blank lines (one per new longitude if there are several latitudes, one
+   * per new latitude if there are several levels); sparse tables have none */
+  const int blocks = !ctl->grid_sparse;
+  for (size_t col = 0; col < (size_t) ctl->grid_nx * (size_t) ctl->grid_ny; col++) {
+    const int i = (int) (col / (size_t) ctl->grid_ny), j = (int) (col % (size_t) ctl->grid_ny);
+    if (blocks && j == 0 && i > 0 && ctl->grid_ny > 1)
+      fputc('\n', out);
+    if (blocks && j > 0 && ctl->grid_nz > 1)
+      fputc('\n', out);
+    const double lon = ctl->grid_lon0 + step_lon * (i + 0.5), lat = ctl->grid_lat0 + step_lat * (j + 0.5);
+    const double area = step_lat * step_lon * SQR(RE * M_PI / 180.) * cos(DEG2RAD(lat));
+    for (int k = 0; k < ctl->grid_nz; k++) {
+      const size_t cell = (size_t) ARRAY_3D(i, j, ctl->grid_ny, k, ctl->grid_nz);
+      const double z = ctl->grid_z0 + step_z * (k + 0.5);
+      const double mass = ctl->qnt_m >= 0 ? mean[(size_t) ctl->qnt_m * ncell + cell] : NAN;
+      const double cd = mass / (1e6 * area);
+      /* implicit volume mixing ratio from the mass in the cell and the air density at its centre (mptrac.c:13885-13900) */
+      double vmr_impl = NAN;
+      if (ctl->qnt_m >= 0 && ctl->molmass > 0 && met0 && met1) {
+        vmr_impl = 0;
+        if (mass > 0) {
+          const double press = P(z);
+          const double temp = grid_temperature(met0, met1, t, press, lon, lat);
+          vmr_impl = MA / ctl->molmass * cd / (100. * press / (RA * temp) * step_z * 1e3);
         }
-        if (ctl->grid_sparse && !(vmr_impl > 0))   /* sparse output keeps cells with vmr_impl > 0 only */
-          continue;
-        fprintf(out, "%.2f %g %g %g %g %g %g %g %d", t, ctl->grid_z0 + dz * (iz + 0.5),
-                ctl->grid_lon0 + dlon * (ix + 0.5), lat, area, dz, cd, vmr_impl, np[idx]);
-        for (int iq = 0; iq < ctl->nq; iq++) {
-          const double m = np[idx] > 0 ? mean[(size_t) iq * ncell + idx] / np[idx] : NAN;
-          fprintf(out, " ");
-          fprintf(out, ctl->qnt_format[iq], m);
-        }
-        if (ctl->grid_stddev)
-          for (int iq = 0; iq < ctl->nq; iq++) {
-            double sd = NAN;
-            if (np[idx] > 0) {
-              const double m = mean[(size_t) iq * ncell + idx] / np[idx];
-              const double var = sigma[(size_t) iq * ncell + idx] / np[idx] - SQR(m);
-              sd = var > 0 ? sqrt(var) : 0;
-            }
-            fprintf(out, " ");
-            fprintf(out, ctl->qnt_format[iq], sd);
-          }
-        fprintf(out, "\n");
       }
+      if (ctl->grid_sparse && !(vmr_impl > 0))   /* sparse output keeps cells with vmr_impl > 0 only */
+        continue;
+      fprintf(out, "%.2f %g %g %g %g %g %g %g %d", t, z, lon, lat, area, step_z, cd, vmr_impl, np[cell]);
+      for (int pass = 0; pass < (ctl->grid_stddev ? 2 : 1); pass++)
+        for (int q = 0; q < ctl->nq; q++) {
+          double v = NAN;
+          if (np[cell] > 0) {
+            const double m = mean[(size_t) q * ncell + cell] / np[cell];
+            v = m;
+            if (pass) {
+              const double var = sigma[(size_t) q * ncell + cell] / np[cell] - SQR(m);
+              v = var > 0 ? sqrt(var) : 0;
+            }
+          }
+          fputc(' ', out);
+          fprintf(out, ctl->qnt_format[q], v);
+        }
+      fputc('\n', out);
     }
   }
   fclose(out);
