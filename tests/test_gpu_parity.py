@@ -953,6 +953,46 @@ def test_full_size_stochastic_parity_1e6():
     s.close()
 
 
+def test_full_size_mixing_properties_1e7():
+    """module_mixing at BASELINE configs[4]'s size -- 10^7 particles, the default 360 x 180 x 90 boxes -- with the
+    particles stored in the caller's (random) order and in the internal locality order (no oracle run at this
+    size; properties instead): identical bits from run to run and in both storage orders (the sums add in the
+    order of the particle index, whatever the storage order); with one mixing parameter for all particles mixing
+    conserves the total of every box -- hence the global total -- to rounding; the gridded output counts every
+    particle once; the atomic variant agrees to 1e-12."""
+    from mptrac_amd.ctl import ctl_from_quantities
+    n = 10 ** 7
+    names = ("m", "vmr")
+    ctl = dict(cases.BASE, mixing_trop=1e-2, mixing_strat=1e-2, mixing_dt=180.0, **ctl_from_quantities(names))
+    m0 = synthetic_met("C1", 0.0, 1.0, fields=cases.PRESSURE_LEVEL_FIELDS)
+    m1 = synthetic_met("C1", 3600.0, 1.25, fields=cases.PRESSURE_LEVEL_FIELDS)
+    atm = synthetic_particles(n, seed=3, quantities=names)
+    atm["q"][1] = 1e-9 * (1.0 + np.abs(atm["lat"]) / 90.0)
+    clim = cases.load_clim_tropo()
+    results = {}
+    for name, interval, mode in (("caller", 0, 1), ("locality", 1, 1), ("locality_again", 1, 1), ("atomics", 1, 0)):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("locality_sort_interval", interval)
+        s.set_option("deterministic_sums", mode)
+        s.timesteps_init(0.0, 0.0)
+        s.run_timestep(0.0)          # (dt = 0: nothing moves; the particles are put into the storage order and mixed)
+        s.module("mixing", 0.0)      # mixed once more, in that order
+        results[name] = s.get_atm()["q"]
+        if name == "caller":
+            cnt, mean, _ = s.grid_sums(0.0)
+            assert int(cnt.sum()) == n
+            assert abs(mean[0].sum() - atm["q"][0].sum()) <= 1e-9 * atm["q"][0].sum()
+        s.close()
+    assert np.abs(results["caller"][0] - atm["q"][0]).max() > 1e-6      # (masses follow the longitude: boxes are nearly uniform)
+    for k in range(2):
+        total0, total1 = float(np.sum(atm["q"][k], dtype=np.longdouble)), float(np.sum(results["caller"][k], dtype=np.longdouble))
+        assert abs(total1 - total0) <= 1e-12 * abs(total0)
+    assert np.array_equal(results["caller"], results["locality"])
+    assert np.array_equal(results["locality"], results["locality_again"])
+    err = float(np.max(np.abs(results["atomics"] - results["caller"]) / np.abs(results["caller"])))
+    assert err <= 1e-12, err
+
+
 def test_sort_scales_to_1e8_keys():
     """The radix sort's two-level scan covers 10^8 particles in one context
     (288 GB of HBM hold them easily): sortedness, permutation, stability."""
