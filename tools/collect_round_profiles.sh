@@ -1,6 +1,6 @@
 set -u
 cd $GRAFT_REPO_ROOT
-T=r02b
+T=r02c
 bash tools/profile.sh $T > gpurun_out/${T}_profile.log 2>&1
 python tools/summarize_prof.py gpurun_out/prof_$T > gpurun_out/prof_$T/summary.txt 2>&1
 bash tools/profile_valu_mix.sh ${T}mix > gpurun_out/${T}_mix.log 2>&1
@@ -12,3 +12,6 @@ for w in C5 C3z C3m C2; do
 done
 python bench.py > gpurun_out/${T}_bench_C3.json 2> gpurun_out/${T}_bench_C3.err
 tail -c 600 gpurun_out/${T}_bench_C3.json
+python bench.py --particles 1e8 --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3_1e8.json
+python bench.py --workload C3x --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3x.json
+python bench.py --workload C1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C1.json
