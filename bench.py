@@ -208,13 +208,34 @@ def main():
     ctl, clim, met0, met1, atm, n_local, n_total = build_inputs(args.workload, rank, world, steps_total, particles=args.particles)
     sim = hip.Simulation(ctl, clim, met0, met1, atm, device=local_rank,
                          shard=(rank * n_local, (rank + 1) * n_local), n_total=n_total)
+    reduction = "none (one rank)"
     if use_dist and args.torch_allreduce:
         from mptrac_amd import dist as mdist
         sim.set_allreduce(mdist.make_allreduce_hook("cuda"))
+        reduction = "torch.distributed callback"
     elif use_dist or args.rccl_single:
         # the library's own RCCL communicator: all-reduces on the simulation's stream, no Python in the data path
         from mptrac_amd import dist as mdist
-        mdist.init_rccl(sim, dist)
+        ok = 1
+        try:
+            mdist.init_rccl(sim, dist)
+        except Exception as exc:      # e.g. no librccl the loader can find: say so and keep the run alive
+            sys.stderr.write(f"rank {rank}: native RCCL communicator unavailable ({exc}); "
+                             "reducing through torch.distributed instead\n")
+            ok = 0
+        if use_dist and world > 1:    # every rank takes the same path
+            import torch
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            try:
+                sim.comm_destroy()
+            except Exception:
+                pass
+            if use_dist:
+                sim.set_allreduce(mdist.make_allreduce_hook("cuda"))
+        reduction = "rccl (native, on the step stream)" if ok else "torch.distributed callback"
     if args.eager_meteo:
         sim.set_option("lazy_meteo", 0)
     sim.timesteps_init(0.0, 0.0)
@@ -296,7 +317,8 @@ def main():
                        "particles_per_gpu": n_local, "particles_total": n_total,
                        **({"particles_override": True} if args.particles else {}),
                        "grid": [met0.nx, met0.ny, met0.np], "dt_mod": dt,
-                       "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce"},
+                       "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce",
+                       "reduction": reduction},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "step_kernel (fused time step)", "kernel_ms": kernel_ms_per_launch,
