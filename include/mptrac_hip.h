@@ -242,8 +242,9 @@ int mphip_module(mphip_ctx *ctx, unsigned modules, double t);
 int mphip_get_sort(mphip_ctx *ctx, double *keys, int *perm);
 
 /* write_grid's binning loop (mptrac.c:13815-13872) on the device: cnt[ncell],
- * mean[nq][ncell], sigma[nq][ncell] raw sums, summed over ranks through the
- * all-reduce hook if one is set. */
+ * mean[nq][ncell], sigma[nq][ncell] raw sums (added in ascending particle index like the reference's loop,
+ * option "deterministic_sums"), summed over the ranks through the communicator or the all-reduce hook if
+ * one is set. */
 int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *sigma);
 
 int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
@@ -288,6 +289,11 @@ int mphip_comm_destroy(mphip_ctx *ctx);
  *   "pin_host_atm" (default 0): page-lock the caller's particle arrays handed to
  *   mphip_update_atm / mphip_get_atm with one registration spanning them (for
  *   a persistent atm_t whose arrays lie in one allocation);
+ *   "deterministic_sums" (default 1): the cell sums of module_mixing and of mphip_grid_sums add every cell's
+ *   summands in ascending particle index, as the reference's serial loops do (mptrac.c:5289-5303,
+ *   13862-13872): same bits as the serial code, from run to run and for any storage order.  0 = floating-point
+ *   atomics (order of arrival; faster when single cells hold very many particles);
+ *   "sort_bits" (default 0 = the width with the fewest passes; 8, 9, 10): digit width of the radix sort;
  *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel. */
 int mphip_set_option(mphip_ctx *ctx, const char *name, double value);
 int mphip_synchronize(mphip_ctx *ctx);
