@@ -1123,9 +1123,12 @@ AccumGeom accum_geom(const mphip_ctx *ctx, int nv) {
 // Sums of VALS per cell in the reference's serial order (steps 1-4 of "Cell sums" in mphip_kernels.hpp).
 // ctx->d_cell holds the cell of every stored particle; writes sums[v * ntot + cell] (nv values) and the counts
 // as integers and / or doubles (either may be NULL).
+// `every_cell`: cells of groups without particles must read zero afterwards (an all-reduce or the host looks at
+// all of them); module_mixing on a single rank only ever reads the cells its particles are in, which the
+// group kernel has written, and skips the clearing passes
 template <class VALS>
 int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size_t ntot, double *sums, int *cnt,
-                      double *cnt_as_double) {
+                      double *cnt_as_double, bool every_cell = true) {
   const long long n = ctx->np;
   // cells per group: whole vertical columns of the grid, as many as fit the table in LDS while there are
   // still >= 2^14 groups to spread over the waves
@@ -1137,11 +1140,13 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
   const size_t ngroups = (ntot + G - 1) / G;
   if (ntot >= 0x7fffffffULL)
     return fail(ctx, "too many grid cells for 32-bit cell indices");
-  HIPCHK(hipMemsetAsync(sums, 0, (size_t) nv * ntot * sizeof(double), ctx->stream));
-  if (cnt)
-    HIPCHK(hipMemsetAsync(cnt, 0, ntot * sizeof(int), ctx->stream));
-  if (cnt_as_double)
-    HIPCHK(hipMemsetAsync(cnt_as_double, 0, ntot * sizeof(double), ctx->stream));
+  if (every_cell) {
+    HIPCHK(hipMemsetAsync(sums, 0, (size_t) nv * ntot * sizeof(double), ctx->stream));
+    if (cnt)
+      HIPCHK(hipMemsetAsync(cnt, 0, ntot * sizeof(int), ctx->stream));
+    if (cnt_as_double)
+      HIPCHK(hipMemsetAsync(cnt_as_double, 0, ntot * sizeof(double), ctx->stream));
+  }
   if (n == 0)
     return 0;
   // one allocation, 32-bit words: [sequence cell | sequence slot | keys 0 | ids 0 | keys 1 | ids 1 | run starts
@@ -1291,7 +1296,8 @@ int mixing_sums(mphip_ctx *ctx, const MixPlan &P) {
   const size_t ntot = P.ntot;
   if (ctx->deterministic_sums != 0) {
     MixVals vals = { mq };
-    if (ordered_cell_sums(ctx, vals, mq.n, ctx->ctl.mixing_nz, ntot, ctx->d_sums, ctx->d_cnt, (double *) nullptr))
+    const bool exchanged = ctx->comm != nullptr || ctx->allreduce != nullptr;
+    if (ordered_cell_sums(ctx, vals, mq.n, ctx->ctl.mixing_nz, ntot, ctx->d_sums, ctx->d_cnt, (double *) nullptr, exchanged))
       return 1;
   } else {
     HIPCHK(hipMemsetAsync(ctx->d_sums, 0, (size_t) mq.n * ntot * sizeof(double), ctx->stream));
