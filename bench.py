@@ -52,6 +52,13 @@ WORKLOADS = {
                                wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6),
            ("m", "rp", "rhop"), ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "lwc",
                                  "rwc", "iwc", "swc")),
+    # C5 without module_mixing: the deposition modules run inside the launch that moves the particles
+    # (not a baseline configuration; measures what the split around module_mixing costs)
+    "C5n": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1, sort_dt=180.0,
+                                tdec_trop=259200.0, tdec_strat=259200.0, dry_depo_vdep=0.15, wet_depo_ic_a=1e-4,
+                                wet_depo_ic_b=0.8, wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6),
+            ("m", "rp", "rhop"), ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "lwc",
+                                  "rwc", "iwc", "swc")),
     # C3 + inter-parcel mixing every step WITHOUT module_sort: the ordered cell sums on the internal locality
     # order (not a baseline configuration; measures that path)
     "C3x": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1,
@@ -73,7 +80,7 @@ def algorithmic_bytes_per_pstep(workload, met, np_local):
     step can touch, once per launch."""
     state = {"C3": 64 + 24 + 16,   # time,lon,lat,p R+W; uvwp R+W; rp,rhop R
              "C3m": 64 + 24 + 16,  # (the step kernel's bytes; module_meteo is a separate kernel)
-             "C5": 64 + 24 + 16 + 16, "C3x": 64 + 24 + 16 + 16,
+             "C5": 64 + 24 + 16 + 16, "C3x": 64 + 24 + 16 + 16, "C5n": 64 + 24 + 16 + 16,
              "C3z": 64 + 24 + 16 + 16,
              "C2": 64, "C1": 64}[workload]
     wind = met.nx * met.ny * met.np * 32            # {u,v,w,t} x 2 snapshots, float
