@@ -81,18 +81,32 @@ struct mphip_ctx {
   std::string uploader_err;
   int nx = 0, ny = 0, npl = 0, coord_type = 0;   // npl: pressure levels (met_t::np)
   int nml = 0;                                    // model levels (met_t::npl), 0 = none uploaded
-  float *d_mlw = nullptr, *d_zl2 = nullptr, *d_pl2 = nullptr;
-  int *d_ml_mono = nullptr;
-  bool ml_monotonic = false;
+  // Packed two-snapshot grids (layouts: mphip_device.hpp).  `pk` is the set the kernels read; `pk_next` is
+  // built beside the time steps from (met1, prefetched snapshot) on the copy stream and trades places with it
+  // in mphip_commit_met, so that a hand-over costs the stepping stream nothing.
+  struct PackedGrids {
+    float *wind = nullptr, *temp = nullptr, *h2o = nullptr;
+    float *mlw = nullptr, *zl2 = nullptr, *pl2 = nullptr;   // model levels: {ul,vl,zeta_dot|wl}, {zetal}, {pl} pairs
+    f32x4 *mx = nullptr, *mx2 = nullptr;                      // level / surface pair records of module_meteo
+    f32x4 *cloud = nullptr, *sfa = nullptr, *sfb = nullptr, *sfc = nullptr, *sfd = nullptr;
+    f32x4 *cp2 = nullptr;                                     // {cape,pel} pair records (module_convection)
+    int *ml_mono = nullptr;                                   // cleared by the pack kernel if a height column is not monotonic
+    bool ml_monotonic = false;
+    void release() {
+      for (void *q : { (void *) wind, (void *) temp, (void *) h2o, (void *) mlw, (void *) zl2, (void *) pl2, (void *) mx,
+                       (void *) mx2, (void *) cloud, (void *) sfa, (void *) sfb, (void *) sfc, (void *) sfd, (void *) cp2,
+                       (void *) ml_mono })
+        if (q)
+          (void) hipFree(q);
+      *this = PackedGrids();
+    }
+  };
+  PackedGrids pk, pk_next;
+  bool pk_next_valid = false;         // pk_next holds (met1, prefetched snapshot), packed with the control parameters of then
   std::vector<double> h_lon, h_lat, h_p;
   double *d_axes = nullptr;           // axes blob (layout: DevMet::axes)
   int lut_base = 0, lut_size = 0;
   size_t axes_bytes = 0;
-  float *d_wind = nullptr, *d_temp = nullptr;     // packed two-snapshot grids (layouts: mphip_device.hpp)
-  f32x4 *d_mx = nullptr, *d_mx2 = nullptr;        // level / surface pair records of module_meteo
-  f32x4 *d_cloud = nullptr, *d_sfa = nullptr, *d_sfb = nullptr, *d_sfc = nullptr, *d_sfd = nullptr;
-  f32x4 *d_cp2 = nullptr;                         // {cape,pel} pair records (module_convection)
-  float *d_h2o = nullptr;
   bool packed_dirty = true;
 
   // particles
@@ -225,21 +239,21 @@ DevAtm dev_atm(const mphip_ctx *c) {
 
 DevMet dev_met(const mphip_ctx *c) {
   DevMet M;
-  M.wind = c->d_wind;
-  M.temp = c->d_temp;
-  M.cloud = c->d_cloud;
-  M.mx = c->d_mx;
-  M.mx2 = c->d_mx2;
-  M.sfa = c->d_sfa;
-  M.sfb = c->d_sfb;
-  M.cp2 = c->d_cp2;
-  M.sfc = c->d_sfc;
-  M.sfd = c->d_sfd;
-  M.h2o = c->d_h2o;
-  M.mlw = c->d_mlw;
-  M.zl2 = c->d_zl2;
-  M.pl2 = c->d_pl2;
-  M.ml_monotonic = c->ml_monotonic ? 1 : 0;
+  M.wind = c->pk.wind;
+  M.temp = c->pk.temp;
+  M.cloud = c->pk.cloud;
+  M.mx = c->pk.mx;
+  M.mx2 = c->pk.mx2;
+  M.sfa = c->pk.sfa;
+  M.sfb = c->pk.sfb;
+  M.cp2 = c->pk.cp2;
+  M.sfc = c->pk.sfc;
+  M.sfd = c->pk.sfd;
+  M.h2o = c->pk.h2o;
+  M.mlw = c->pk.mlw;
+  M.zl2 = c->pk.zl2;
+  M.pl2 = c->pk.pl2;
+  M.ml_monotonic = c->pk.ml_monotonic ? 1 : 0;
   for (int t = 0; t < 2; t++) {
     M.zl[t] = c->slot[t ^ c->flip].f3[MPHIP_ZETAL];
     M.pll[t] = c->slot[t ^ c->flip].f3[MPHIP_PL];
@@ -361,16 +375,115 @@ int upload_axes(mphip_ctx *ctx) {
   return 0;
 }
 
-// (re)build the packed two-snapshot grids from the per-slot staging copies
-int ensure_packed(mphip_ctx *ctx) {
-  if (!ctx->packed_dirty)
-    return 0;
-  const MetSlot &s0 = ctx->slot[0 ^ ctx->flip], &s1 = ctx->slot[1 ^ ctx->flip];
-  if (!s0.valid || !s1.valid)
-    return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
-  // after a hand-over (mphip_swap_met / mphip_commit_met) the new met0 is the old met1: the reference accepts
-  // axes that differ by up to 1e-3 between files (mptrac.c:6543-6556) and always uses those of the current
-  // met0, so the device axes follow it
+// arrays of a packed set for the fields the two snapshots carry (allocated on first need; hipMalloc, so
+// called from the stepping thread only)
+struct PackPlan {
+  bool cloud = false, ml = false, pbl = false, mx = false, mx2 = false, ml_heights = false, coord2 = false;
+};
+
+PackPlan pack_plan(const mphip_ctx *ctx, const MetSlot &s0, const MetSlot &s1) {
+  PackPlan P;
+  const MetSlot *ss[2] = { &s0, &s1 };
+  for (int t = 0; t < 2; t++) {
+    for (int f = MPHIP_LWC; f <= MPHIP_SWC; f++)
+      P.cloud = P.cloud || ss[t]->has3[f];
+    for (int f = MPHIP_Z; f <= MPHIP_CC; f++)
+      P.mx = P.mx || ss[t]->has3[f];
+    for (int f = MPHIP_TS; f <= MPHIP_O3C; f++)
+      P.mx2 = P.mx2 || ss[t]->has2[f];
+    P.ml = P.ml || ss[t]->has3[MPHIP_UL] || ss[t]->has3[MPHIP_VL] || ss[t]->has3[MPHIP_ZETA_DOTL] || ss[t]->has3[MPHIP_WL];
+    P.pbl = P.pbl || ss[t]->has3[MPHIP_H2O] || ss[t]->has2[MPHIP_ESS] || ss[t]->has2[MPHIP_NSS] || ss[t]->has2[MPHIP_SHF];
+  }
+  P.ml = P.ml && (size_t) ctx->nx * ctx->ny * ctx->nml > 0;
+  // packed height pairs: {zetal}, {pl}; ADVECT_VERT_COORD 2 searches in pl only
+  P.coord2 = ctx->have_ctl && ctx->ctl.advect_vert_coord == 2;
+  P.ml_heights = P.ml && s0.has3[MPHIP_PL] && s1.has3[MPHIP_PL]
+    && (P.coord2 || (s0.has3[MPHIP_ZETAL] && s1.has3[MPHIP_ZETAL]));
+  return P;
+}
+
+int pack_alloc(mphip_ctx *ctx, mphip_ctx::PackedGrids &K, const PackPlan &P) {
+  const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
+  const size_t ncell_ml = (size_t) ctx->nx * ctx->ny * ctx->nml;
+  if (P.ml && !K.mlw
+      && (dev_alloc(ctx, &K.mlw, 6 * ncell_ml) || dev_alloc(ctx, &K.zl2, 2 * ncell_ml) || dev_alloc(ctx, &K.pl2, 2 * ncell_ml)))
+    return 1;
+  if (!K.ml_mono && dev_alloc(ctx, &K.ml_mono, 1))
+    return 1;
+  if (!K.wind && (dev_alloc(ctx, &K.wind, 6 * ncell) || dev_alloc(ctx, &K.temp, 2 * ncell)))
+    return 1;
+  if (!K.cp2 && dev_alloc(ctx, &K.cp2, ncol))
+    return 1;
+  if (!K.sfa && (dev_alloc(ctx, &K.sfa, ncol) || dev_alloc(ctx, &K.sfb, 2 * ncol) || dev_alloc(ctx, &K.sfc, 2 * ncol)))
+    return 1;
+  if (P.cloud && !K.cloud && dev_alloc(ctx, &K.cloud, 2 * ncell))
+    return 1;
+  if (P.mx && !K.mx && dev_alloc(ctx, &K.mx, 2 * ncell))
+    return 1;
+  if (P.mx2 && !K.mx2 && dev_alloc(ctx, &K.mx2, 7 * ncol))
+    return 1;
+  if (P.pbl && !K.sfd && (dev_alloc(ctx, &K.sfd, 2 * ncol) || dev_alloc(ctx, &K.h2o, 2 * ncell)))
+    return 1;
+  return 0;
+}
+
+// build the packed set K from the staging copies of two snapshots on `stream` (arrays allocated: pack_alloc).
+// No hipMalloc, no use of ctx->err: also called by the uploader thread.  *mono_pending: the monotonicity flag of
+// the height columns has to be read back after the kernel (pack_finish).
+int pack_launch(mphip_ctx *ctx, mphip_ctx::PackedGrids &K, const PackPlan &P, const MetSlot &s0, const MetSlot &s1,
+                hipStream_t stream) {
+  const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
+  PackArgs a;
+  const MetSlot *ss[2] = { &s0, &s1 };
+  for (int t = 0; t < 2; t++) {
+    for (int f = 0; f < MPHIP_N3D; f++)
+      a.f3[t][f] = ss[t]->has3[f] ? ss[t]->f3[f] : nullptr;
+    for (int f = 0; f < MPHIP_N2D; f++)
+      a.f2[t][f] = ss[t]->has2[f] ? ss[t]->f2[f] : nullptr;
+  }
+  if (P.ml_heights) {
+    const int one = 1;
+    if (hipMemcpyAsync(K.ml_mono, &one, sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess)
+      return 1;
+  }
+  a.wind = K.wind;
+  a.temp = K.temp;
+  a.cloud = P.cloud ? K.cloud : nullptr;
+  a.mx = P.mx ? K.mx : nullptr;
+  a.mx2 = P.mx2 ? K.mx2 : nullptr;
+  a.sfa = K.sfa;
+  a.sfb = K.sfb;
+  a.cp2 = K.cp2;
+  a.sfc = K.sfc;
+  a.sfd = P.pbl ? K.sfd : nullptr;
+  a.h2o = P.pbl ? K.h2o : nullptr;
+  a.mlw = P.ml ? K.mlw : nullptr;
+  a.mlw_third = P.coord2 ? MPHIP_WL : MPHIP_ZETA_DOTL;
+  a.zl2 = P.ml_heights ? K.zl2 : nullptr;
+  a.pl2 = P.ml_heights ? K.pl2 : nullptr;
+  a.ml_mono = K.ml_mono;
+  a.nml = ctx->nml;
+  a.ncell = ncell;
+  a.ncol = ncol;
+  a.ncell_ml = (size_t) ctx->nx * ctx->ny * ctx->nml;
+  hipLaunchKernelGGL(pack_kernel, dim3(grid_for((long long) ncell)), dim3(256), 0, stream, a);
+  if (hipGetLastError() != hipSuccess)
+    return 1;
+  K.ml_monotonic = false;
+  if (P.ml_heights) {   // (model levels only) the fast kernel relies on monotonic height columns
+    int mono = 0;
+    if (hipMemcpyAsync(&mono, K.ml_mono, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess
+        || hipStreamSynchronize(stream) != hipSuccess)
+      return 1;
+    K.ml_monotonic = mono != 0;
+  }
+  return 0;
+}
+
+// the device axes follow the current met0: after a hand-over (mphip_swap_met / mphip_commit_met) the new met0 is
+// the old met1, and the reference accepts axes that differ by up to 1e-3 between files (mptrac.c:6543-6556)
+int axes_follow_met0(mphip_ctx *ctx) {
+  const MetSlot &s0 = ctx->slot[0 ^ ctx->flip];
   if (!s0.lon.empty() && (s0.lon != ctx->h_lon || s0.lat != ctx->h_lat || s0.p != ctx->h_p)) {
     ctx->h_lon = s0.lon;
     ctx->h_lat = s0.lat;
@@ -378,84 +491,23 @@ int ensure_packed(mphip_ctx *ctx) {
     if (upload_axes(ctx))
       return 1;
   }
-  const size_t ncell = (size_t) ctx->nx * ctx->ny * ctx->npl, ncol = (size_t) ctx->nx * ctx->ny;
-  PackArgs a;
-  bool any_cloud = false, any_ml = false, any_pbl = false, any_mx = false, any_mx2 = false;
-  const MetSlot *ss[2] = { &s0, &s1 };
-  for (int t = 0; t < 2; t++) {
-    for (int f = 0; f < MPHIP_N3D; f++)
-      a.f3[t][f] = ss[t]->has3[f] ? ss[t]->f3[f] : nullptr;
-    for (int f = 0; f < MPHIP_N2D; f++)
-      a.f2[t][f] = ss[t]->has2[f] ? ss[t]->f2[f] : nullptr;
-    for (int f = MPHIP_LWC; f <= MPHIP_SWC; f++)
-      any_cloud = any_cloud || ss[t]->has3[f];
-    for (int f = MPHIP_Z; f <= MPHIP_CC; f++)
-      any_mx = any_mx || ss[t]->has3[f];
-    for (int f = MPHIP_TS; f <= MPHIP_O3C; f++)
-      any_mx2 = any_mx2 || ss[t]->has2[f];
-    any_ml = any_ml || ss[t]->has3[MPHIP_UL] || ss[t]->has3[MPHIP_VL] || ss[t]->has3[MPHIP_ZETA_DOTL]
-      || ss[t]->has3[MPHIP_WL];
-    any_pbl = any_pbl || ss[t]->has3[MPHIP_H2O] || ss[t]->has2[MPHIP_ESS] || ss[t]->has2[MPHIP_NSS]
-      || ss[t]->has2[MPHIP_SHF];
-  }
-  const size_t ncell_ml = (size_t) ctx->nx * ctx->ny * ctx->nml;
-  any_ml = any_ml && ncell_ml > 0;
-  if (any_ml && !ctx->d_mlw
-      && (dev_alloc(ctx, &ctx->d_mlw, 6 * ncell_ml) || dev_alloc(ctx, &ctx->d_zl2, 2 * ncell_ml)
-          || dev_alloc(ctx, &ctx->d_pl2, 2 * ncell_ml) || dev_alloc(ctx, &ctx->d_ml_mono, 1)))
+  return 0;
+}
+
+// (re)build the packed two-snapshot grids from the per-slot staging copies
+int ensure_packed(mphip_ctx *ctx) {
+  if (!ctx->packed_dirty)
+    return 0;
+  const MetSlot &s0 = ctx->slot[0 ^ ctx->flip], &s1 = ctx->slot[1 ^ ctx->flip];
+  if (!s0.valid || !s1.valid)
+    return fail(ctx, "meteo data for both met0 and met1 must be uploaded before stepping");
+  if (axes_follow_met0(ctx))
     return 1;
-  // packed height pairs: {zetal}, {pl}; ADVECT_VERT_COORD 2 searches in pl only
-  const bool coord2 = ctx->have_ctl && ctx->ctl.advect_vert_coord == 2;
-  const bool ml_heights = any_ml && s0.has3[MPHIP_PL] && s1.has3[MPHIP_PL]
-    && (coord2 || (s0.has3[MPHIP_ZETAL] && s1.has3[MPHIP_ZETAL]));
-  if (ml_heights) {
-    const int one = 1;
-    HIPCHK(hipMemcpyAsync(ctx->d_ml_mono, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  }
-  if (!ctx->d_wind && (dev_alloc(ctx, &ctx->d_wind, 6 * ncell) || dev_alloc(ctx, &ctx->d_temp, 2 * ncell)))
+  const PackPlan P = pack_plan(ctx, s0, s1);
+  if (pack_alloc(ctx, ctx->pk, P))
     return 1;
-  if (!ctx->d_cp2 && dev_alloc(ctx, &ctx->d_cp2, ncol))
-    return 1;
-  if (!ctx->d_sfa && (dev_alloc(ctx, &ctx->d_sfa, ncol) || dev_alloc(ctx, &ctx->d_sfb, 2 * ncol)
-                      || dev_alloc(ctx, &ctx->d_sfc, 2 * ncol)))
-    return 1;
-  if (any_cloud && !ctx->d_cloud && dev_alloc(ctx, &ctx->d_cloud, 2 * ncell))
-    return 1;
-  if (any_mx && !ctx->d_mx && dev_alloc(ctx, &ctx->d_mx, 2 * ncell))
-    return 1;
-  if (any_mx2 && !ctx->d_mx2 && dev_alloc(ctx, &ctx->d_mx2, 7 * ncol))
-    return 1;
-  if (any_pbl && !ctx->d_sfd && (dev_alloc(ctx, &ctx->d_sfd, 2 * ncol) || dev_alloc(ctx, &ctx->d_h2o, 2 * ncell)))
-    return 1;
-  a.wind = ctx->d_wind;
-  a.temp = ctx->d_temp;
-  a.cloud = any_cloud ? ctx->d_cloud : nullptr;
-  a.mx = any_mx ? ctx->d_mx : nullptr;
-  a.mx2 = any_mx2 ? ctx->d_mx2 : nullptr;
-  a.sfa = ctx->d_sfa;
-  a.sfb = ctx->d_sfb;
-  a.cp2 = ctx->d_cp2;
-  a.sfc = ctx->d_sfc;
-  a.sfd = any_pbl ? ctx->d_sfd : nullptr;
-  a.h2o = any_pbl ? ctx->d_h2o : nullptr;
-  a.mlw = any_ml ? ctx->d_mlw : nullptr;
-  a.mlw_third = coord2 ? MPHIP_WL : MPHIP_ZETA_DOTL;
-  a.zl2 = ml_heights ? ctx->d_zl2 : nullptr;
-  a.pl2 = ml_heights ? ctx->d_pl2 : nullptr;
-  a.ml_mono = ctx->d_ml_mono;
-  a.nml = ctx->nml;
-  a.ncell = ncell;
-  a.ncol = ncol;
-  a.ncell_ml = ncell_ml;
-  hipLaunchKernelGGL(pack_kernel, dim3(grid_for((long long) ncell)), dim3(256), 0, ctx->stream, a);
-  HIPCHK(hipGetLastError());
-  ctx->ml_monotonic = false;
-  if (ml_heights) {
-    int mono = 0;
-    HIPCHK(hipMemcpyAsync(&mono, ctx->d_ml_mono, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->ml_monotonic = mono != 0;
-  }
+  if (pack_launch(ctx, ctx->pk, P, s0, s1, ctx->stream))
+    return fail(ctx, "packing the meteo grids failed");
   ctx->packed_dirty = false;
   return 0;
 }
@@ -617,7 +669,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   }
   const bool ml_ = ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3;   // winds from the model levels
   // model levels: the fast path needs monotonic height columns and none of the rarely used modules
-  const bool ml_fast = ml_ && ctx->ml_monotonic && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
+  const bool ml_fast = ml_ && ctx->pk.ml_monotonic && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
   const bool rare = (ml_ && !ml_fast) || (mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u));
   // the specialised instantiations take module_timesteps / the dt store from the run-time mask
   // ... and run the lean code: lat/lon grid with a pressure look-up table
@@ -1468,21 +1520,8 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_clim);
   dev_free(ctx->d_logtab);
   dev_free(ctx->d_axes);
-  dev_free(ctx->d_wind);
-  dev_free(ctx->d_temp);
-  dev_free(ctx->d_cloud);
-  dev_free(ctx->d_mx);
-  dev_free(ctx->d_mx2);
-  dev_free(ctx->d_sfa);
-  dev_free(ctx->d_sfb);
-  dev_free(ctx->d_cp2);
-  dev_free(ctx->d_sfc);
-  dev_free(ctx->d_sfd);
-  dev_free(ctx->d_h2o);
-  dev_free(ctx->d_mlw);
-  dev_free(ctx->d_zl2);
-  dev_free(ctx->d_pl2);
-  dev_free(ctx->d_ml_mono);
+  ctx->pk.release();
+  ctx->pk_next.release();
   for (auto p : ctx->d_arr)
     dev_free(p);
   for (auto p : ctx->d_alt)
@@ -1617,25 +1656,15 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
     }
     ctx->next.valid = false;
     ctx->next_pending = false;
-    dev_free(ctx->d_mlw);
-    dev_free(ctx->d_zl2);
-    dev_free(ctx->d_pl2);
-    ctx->d_mlw = ctx->d_zl2 = ctx->d_pl2 = nullptr;
-    dev_free(ctx->d_wind);
-    dev_free(ctx->d_temp);
-    dev_free(ctx->d_cloud);
-    dev_free(ctx->d_mx);
-    dev_free(ctx->d_mx2);
-    ctx->d_mx = ctx->d_mx2 = nullptr;
-    dev_free(ctx->d_sfa);
-    dev_free(ctx->d_sfb);
-    dev_free(ctx->d_cp2);
-    ctx->d_cp2 = nullptr;
-    dev_free(ctx->d_sfc);
-    dev_free(ctx->d_sfd);
-    dev_free(ctx->d_h2o);
-    ctx->d_wind = ctx->d_temp = ctx->d_h2o = nullptr;
-    ctx->d_cloud = ctx->d_sfa = ctx->d_sfb = ctx->d_sfc = ctx->d_sfd = nullptr;
+    ctx->pk.release();
+    ctx->pk_next.release();
+    ctx->pk_next_valid = false;
+  }
+  if (ctx->next_pending) {   // a snapshot uploaded now changes what the prefetched pair would have been packed from
+    if (ctx->uploader.joinable())
+      ctx->uploader.join();
+    HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+    ctx->pk_next_valid = false;
   }
   ctx->coord_type = met->coord_type;
   MetSlot &S = ctx->slot[slot ^ ctx->flip];
@@ -1730,10 +1759,33 @@ int mphip_prefetch_met(mphip_ctx *ctx, const mphip_met_t *met) {
   ctx->next.lon.assign(met->lon, met->lon + met->nx);
   ctx->next.lat.assign(met->lat, met->lat + met->ny);
   ctx->next.p.assign(met->p, met->p + met->np);
-  ctx->uploader = std::thread([ctx, desc]() {
+  // The packed grids of the step after the hand-over -- (today's met1, the new snapshot) -- are built on the copy
+  // stream as well, into the second set of packed arrays: the hand-over then costs the stepping stream nothing.
+  // Which fields the new snapshot carries is known from its description; the arrays are allocated here, on the
+  // calling thread, the uploader thread only launches.  (Pressure-level configurations; the model-level records
+  // depend on a monotonicity check that is read back, and on ADVECT_VERT_COORD: they are packed at the commit.)
+  ctx->pk_next_valid = false;
+  bool pack_ahead = ctx->nml == 0;
+  PackPlan plan;
+  if (pack_ahead) {
+    MetSlot probe = ctx->next;   // (presence flags only)
+    for (int f = 0; f < MPHIP_N3D; f++)
+      probe.has3[f] = met->f3[f] != nullptr;
+    for (int f = 0; f < MPHIP_N2D; f++)
+      probe.has2[f] = met->f2[f] != nullptr;
+    plan = pack_plan(ctx, ctx->slot[1 ^ ctx->flip], probe);
+    if (pack_alloc(ctx, ctx->pk_next, plan))
+      return 1;
+  }
+  ctx->uploader = std::thread([ctx, desc, pack_ahead, plan]() {
     int rc = hipSetDevice(ctx->device) == hipSuccess ? 0 : 1;
     if (!rc)
       rc = upload_fields(ctx, ctx->next, &desc, false, ctx->copy_stream);
+    if (!rc && pack_ahead) {
+      // met1 of today is met0 after the commit; its staging arrays are not written while it is a current slot
+      rc = pack_launch(ctx, ctx->pk_next, plan, ctx->slot[1 ^ ctx->flip], ctx->next, ctx->copy_stream);
+      ctx->pk_next_valid = rc == 0;
+    }
     if (!rc && hipEventRecord(ctx->next_ready, ctx->copy_stream) != hipSuccess)
       rc = 1;
     ctx->uploader_rc = rc;
@@ -1769,7 +1821,17 @@ int mphip_commit_met(mphip_ctx *ctx) {
   ctx->flip ^= 1;                                    // old met1 -> met0, prefetched -> met1
   ctx->next.valid = false;
   ctx->next_pending = false;
-  ctx->packed_dirty = true;
+  if (ctx->pk_next_valid) {
+    // the packed grids of (new met0, new met1) are ready on the copy stream (the stepping stream waits for
+    // next_ready above): the two sets trade places
+    std::swap(ctx->pk, ctx->pk_next);
+    ctx->pk_next_valid = false;
+    ctx->packed_dirty = false;
+    if (axes_follow_met0(ctx))
+      return 1;
+  } else {
+    ctx->packed_dirty = true;
+  }
   return 0;
 }
 
@@ -1783,6 +1845,7 @@ int mphip_discard_prefetch(mphip_ctx *ctx) {
   HIPCHK(hipStreamSynchronize(ctx->copy_stream));
   ctx->next.valid = false;
   ctx->next_pending = false;
+  ctx->pk_next_valid = false;
   return 0;
 }
 
