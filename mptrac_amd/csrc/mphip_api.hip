@@ -151,6 +151,7 @@ struct mphip_ctx {
   int *d_cnt = nullptr;               // particles per mixing cell (32-bit: the reference's `int count[]`)
   size_t cnt_cap = 0;
   int deterministic_sums = 1;         // cell sums in the reference's serial order (0: floating-point atomics)
+  int sum_path = 0;                   // ordered sums: 0 = by crowding, 1 = groups of cells per wave, 2 = a lane per (cell, value)
   unsigned long long *d_lists = nullptr;   // work space of the ordered sums (sequence, runs, sort buffers)
   size_t lists_cap = 0;
 
@@ -1192,6 +1193,35 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
   const size_t ngroups = (ntot + G - 1) / G;
   if (ntot >= 0x7fffffffULL)
     return fail(ctx, "too many grid cells for 32-bit cell indices");
+  // crowded cells (a 2-D output grid, a dense plume on a coarse grid): sort the whole particle list by cell and
+  // give every (cell, value) chain a lane -- "crowded cells" in mphip_kernels.hpp
+  const bool chains = ctx->sum_path == 2 || (ctx->sum_path == 0 && (double) n >= 16.0 * (double) ntot);
+  if (chains && n > 0) {
+    const size_t words32 = 4 * (size_t) n + 2 * ntot;
+    if ((words32 + 1) / 2 > ctx->lists_cap) {
+      if (dev_alloc(ctx, &ctx->d_lists, (words32 + 1) / 2))
+        return 1;
+      ctx->lists_cap = (words32 + 1) / 2;
+    }
+    uint32_t *base = (uint32_t *) ctx->d_lists;
+    uint32_t *keys[2] = { base, base + 2 * n };
+    int *slots[2] = { (int *) (base + n), (int *) (base + 3 * n) };
+    uint32_t *first = base + 4 * n, *last = first + ntot;
+    HIPCHK(hipMemsetAsync(first, 0, 2 * ntot * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(cell_slot_pairs_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_cell,
+                       ctx->ext_identity ? (const int *) nullptr : ctx->d_ext, n, (uint32_t) ntot, keys[0], slots[0]);
+    int cur = 0;
+    if (radix_passes(ctx, keys, slots, n, bits_for(ntot), &cur))
+      return 1;
+    hipLaunchKernelGGL(cell_bounds_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, keys[cur], n, (uint32_t) ntot,
+                       first, last);
+    const int width = nv < 64 ? nv : 64;
+    const long long waves = ((long long) ntot + 64 / width - 1) / (64 / width);
+    hipLaunchKernelGGL(cell_sum_chains_kernel<VALS>, dim3(grid_for(waves * 64)), dim3(256), 0, ctx->stream, vals,
+                       slots[cur], first, last, ntot, sums, cnt, cnt_as_double);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (every_cell) {
     HIPCHK(hipMemsetAsync(sums, 0, (size_t) nv * ntot * sizeof(double), ctx->stream));
     if (cnt)
@@ -2353,6 +2383,12 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (!(value == 0 || (value >= 8 && value <= kRadixMaxBits)))
       return fail(ctx, "sort_bits must be 0 (automatic), 8, 9 or 10");
     ctx->sort_bits = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "sum_path") == 0) {   // tests: force one of the two ordered-sum algorithms (0: choose by crowding)
+    if (!(value == 0 || value == 1 || value == 2))
+      return fail(ctx, "sum_path must be 0, 1 or 2");
+    ctx->sum_path = (int) value;
     return 0;
   }
   if (strcmp(name, "deterministic_sums") == 0) {

@@ -1663,6 +1663,76 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
   }
 }
 
+// ---- crowded cells: one lane per (cell, value) -------------------------------------------------------------
+// When the cells hold many particles each (a 2-D output grid: 10^7 particles on 360 x 180 cells), the whole
+// (cell, slot) list is sorted by cell -- laid out in external order first, so that the stable sort leaves every
+// cell's particles in ascending external index -- and lane (cell, value) walks its cell's list and adds: the
+// chains are long, there are cells x values of them, and the lanes of a cell share the list reads.
+
+__global__ void cell_slot_pairs_kernel(const int *__restrict__ cell, const int *__restrict__ ext, long long n,
+                                       uint32_t outside, uint32_t *__restrict__ keys, int *__restrict__ slots) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+    const long long at = ext ? (long long) ext[i] : i;
+    const int c = cell[i];
+    keys[at] = c >= 0 ? (uint32_t) c : outside;
+    slots[at] = (int) i;
+  }
+}
+
+// first[c], last[c]: the range of cell c in the sorted list (both zero on entry: cells without particles)
+__global__ void cell_bounds_kernel(const uint32_t *__restrict__ keys, long long n, uint32_t outside,
+                                   uint32_t *__restrict__ first, uint32_t *__restrict__ last) {
+  for (long long j = blockIdx.x * (long long) blockDim.x + threadIdx.x; j < n; j += (long long) gridDim.x * blockDim.x) {
+    const uint32_t k = keys[j];
+    if (k == outside)
+      continue;
+    if (j == 0 || keys[j - 1] != k)
+      first[k] = (uint32_t) j;
+    if (j == n - 1 || keys[j + 1] != k)
+      last[k] = (uint32_t) (j + 1);
+  }
+}
+
+template <class VALS>
+__global__ __launch_bounds__(256) void cell_sum_chains_kernel(VALS vals, const int *__restrict__ slots,
+                                                              const uint32_t *__restrict__ first,
+                                                              const uint32_t *__restrict__ last, size_t ntot,
+                                                              double *__restrict__ sums, int *__restrict__ cnt,
+                                                              double *__restrict__ cnt_as_double) {
+  const int nv = vals.count();
+  const int width = nv < 64 ? nv : 64;        // lanes per cell
+  const int per_wave = 64 / width;            // cells per wave
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / width, v0 = lane % width;
+  const size_t wave = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t) gridDim.x * blockDim.x) >> 6;
+  if (sub >= per_wave)
+    return;
+  for (size_t c = wave * per_wave + sub; c < ntot; c += nwaves * per_wave) {
+    const uint32_t b = first[c], e = last[c];
+    for (int v = v0; v < nv; v += width) {
+      double sum = 0.0;
+      uint32_t k = b;
+      for (; k + 4 <= e; k += 4) {   // four loads in flight, added in order
+        const double x0 = vals.get(v, (long long) slots[k]), x1 = vals.get(v, (long long) slots[k + 1]);
+        const double x2 = vals.get(v, (long long) slots[k + 2]), x3 = vals.get(v, (long long) slots[k + 3]);
+        sum += x0;
+        sum += x1;
+        sum += x2;
+        sum += x3;
+      }
+      for (; k < e; k++)
+        sum += vals.get(v, (long long) slots[k]);
+      sums[(size_t) v * ntot + c] = sum;
+    }
+    if (v0 == 0) {
+      if (cnt)
+        cnt[c] = (int) (e - b);
+      if (cnt_as_double)
+        cnt_as_double[c] = (double) (e - b);
+    }
+  }
+}
+
 // counts <-> doubles around an all-reduce hook that only knows doubles (tests, staged host collectives)
 __global__ void int_to_double_kernel(const int *__restrict__ in, double *__restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)

@@ -352,13 +352,14 @@ def _oracle_takes_device_state(o, s):
     return g
 
 
-@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("mode", [1, 2, 0], ids=["ordered", "ordered_chains", "atomics"])
 def test_mixing_and_grid_sums(mode):
     """module_mixing and the gridded-output sums from identical inputs.  deterministic_sums 1 (default) adds every
     cell's summands in the reference's order of the particle index: every bit equals the serial code's;
     0 = floating-point atomics, order of arrival."""
     o, s = _pair("full", n=20000)
-    s.set_option("deterministic_sums", mode)
+    s.set_option("deterministic_sums", min(mode, 1))
+    s.set_option("sum_path", 2 if mode == 2 else 0)
     ts = cases.step_times(o.ctl)
     for t in ts[:2]:
         o.run_timestep(t)
@@ -448,11 +449,13 @@ GRID_SHAPES = [
 
 @pytest.mark.parametrize("shape", GRID_SHAPES, ids=["1x1x1", "360x180x1", "7x5x200", "37x19x129", "tiny_window"])
 @pytest.mark.parametrize("order", ["external", "locality"])
-def test_ordered_grid_sums_on_odd_grids(shape, order):
+@pytest.mark.parametrize("path", [1, 2], ids=["groups", "chains"])
+def test_ordered_grid_sums_on_odd_grids(shape, order, path):
     """Gridded-output sums (counts, sums of q and of q^2) against the serial sums, bit for bit, on grids that
     stress the grouping of the ordered sums: a single cell, one level, columns longer than a group of cells, a
     window that holds few or no particles -- with the particles stored in the caller's order and in the internal
-    locality order (external index = a permutation)."""
+    locality order (external index = a permutation), through both algorithms of the ordered sums (a wave per
+    group of cells; a lane per (cell, value) chain of the list sorted by cell -- normally chosen by crowding)."""
     nx, ny, nz, lon0, lon1, lat0, lat1, z0, z1 = shape
     ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=30011)
     ctl = dict(ctl, grid_nx=nx, grid_ny=ny, grid_nz=nz, grid_lon0=lon0, grid_lon1=lon1, grid_lat0=lat0,
@@ -460,6 +463,7 @@ def test_ordered_grid_sums_on_odd_grids(shape, order):
     o = B.Oracle(ctl, clim, m0, m1, atm)
     s = hip.Simulation(ctl, clim, m0, m1, atm)
     s.set_option("locality_sort_interval", 1 if order == "locality" else 0)
+    s.set_option("sum_path", path)
     s.timesteps_init(0.0, 0.0)
     ts = cases.step_times(s.ctl)
     for t in ts[:3]:
