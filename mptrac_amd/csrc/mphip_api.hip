@@ -890,7 +890,11 @@ int radix_passes(mphip_ctx *ctx, uint32_t *const keys[2], int *const vals[2], lo
   }
   const int passes = (key_bits + bits - 1) / bits;
   const size_t m = ((size_t) 1 << bits) * ntiles;
-  const int nchunks = (int) ((m + kScanChunk - 1) / kScanChunk);
+  // chunk length of the two-level scan: 4096 counters while <= 1024 chunks cover m, else 16384
+  const bool small = (m + kScanThreads * kScanPerSmall - 1) / (kScanThreads * kScanPerSmall) <= (size_t) kScanThreads;
+  const int chunk_shift = small ? 12 : 14;
+  static_assert(kScanThreads * kScanPerSmall == 1 << 12 && kScanThreads * kScanPerLarge == 1 << 14, "chunk lengths");
+  const int nchunks = (int) ((m + ((size_t) 1 << chunk_shift) - 1) >> chunk_shift);
   if (nchunks > kScanThreads)
     return fail(ctx, "too many particles for the two-level scan of the radix sort");
   if (m + kScanThreads > ctx->counts_cap) {
@@ -905,11 +909,15 @@ int radix_passes(mphip_ctx *ctx, uint32_t *const keys[2], int *const vals[2], lo
 #define SORT_PASS(B)                                                                                                   \
   hipLaunchKernelGGL(sort_hist_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur], n, shift,       \
                      ntiles, ctx->d_counts, n_dev);                                                                    \
-  hipLaunchKernelGGL(sort_scan_local_kernel, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream, ctx->d_counts, m,      \
-                     d_chunks, n_dev, 1 << B);                                                                         \
+  if (small)                                                                                                           \
+    hipLaunchKernelGGL(sort_scan_local_kernel<kScanPerSmall>, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream,       \
+                       ctx->d_counts, m, d_chunks, n_dev, 1 << B);                                                     \
+  else                                                                                                                 \
+    hipLaunchKernelGGL(sort_scan_local_kernel<kScanPerLarge>, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream,       \
+                       ctx->d_counts, m, d_chunks, n_dev, 1 << B);                                                     \
   hipLaunchKernelGGL(sort_scan_chunks_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_chunks, nchunks);         \
   hipLaunchKernelGGL(sort_scatter_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur], vals[cur],   \
-                     keys[cur ^ 1], vals[cur ^ 1], n, shift, ntiles, ctx->d_counts, d_chunks, n_dev)
+                     keys[cur ^ 1], vals[cur ^ 1], n, shift, ntiles, ctx->d_counts, d_chunks, chunk_shift, n_dev)
     if (bits == 8) {
       SORT_PASS(8);
     } else if (bits == 9) {

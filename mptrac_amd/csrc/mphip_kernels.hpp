@@ -877,12 +877,13 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t 
 }
 
 // Exclusive prefix sum over the m counters in two levels: every workgroup
-// scans its chunk of kScanChunk counters in place and publishes the chunk
-// total; a single workgroup then scans the chunk totals (m / kScanChunk <=
-// 1024 of them); the scatter kernel adds the two.
+// scans its chunk of 1024 x PER counters in place and publishes the chunk
+// total; a single workgroup then scans the chunk totals (<= 1024 of them);
+// the scatter kernel adds the two.  PER = 4 while that covers m (more, shorter
+// chunks: 10 instead of 19 us for the 1.25e6 counters of 1e7 keys), 16 beyond
+// (up to 2.6e8 keys per context).
 constexpr int kScanThreads = 1024;
-constexpr int kScanPer = 16;     // 1024 x 16 counters per chunk, <= 1024 chunks: up to 2.6e8 particles per context
-constexpr int kScanChunk = kScanThreads * kScanPer;
+constexpr int kScanPerSmall = 4, kScanPerLarge = 16;
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wsum, uint32_t *total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -907,27 +908,29 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
   return off + x - v;
 }
 
+template <int PER>
 __global__ __launch_bounds__(kScanThreads) void sort_scan_local_kernel(uint32_t *__restrict__ counts, size_t m,
                                                                        uint32_t *__restrict__ chunk_sums,
                                                                        const uint32_t *__restrict__ n_dev = nullptr,
                                                                        int radix = 0) {
+  constexpr int kScanChunk = kScanThreads * PER;
   __shared__ uint32_t wsum[kScanThreads / 64];
   if (n_dev) {   // (see sort_hist_kernel) radix counters for each of the actual tiles
     m = (size_t) radix * (((size_t) *n_dev + kSortTile - 1) / kSortTile);
     if ((size_t) blockIdx.x * kScanChunk >= m)
       return;
   }
-  const size_t base = (size_t) blockIdx.x * kScanChunk + (size_t) threadIdx.x * kScanPer;
-  uint32_t v[kScanPer], sum = 0;
+  const size_t base = (size_t) blockIdx.x * kScanChunk + (size_t) threadIdx.x * PER;
+  uint32_t v[PER], sum = 0;
 #pragma unroll
-  for (int k = 0; k < kScanPer; k++) {
+  for (int k = 0; k < PER; k++) {
     v[k] = base + k < m ? counts[base + k] : 0;
     sum += v[k];
   }
   uint32_t total;
   uint32_t off = block_exclusive_scan(sum, wsum, &total);
 #pragma unroll
-  for (int k = 0; k < kScanPer; k++) {
+  for (int k = 0; k < PER; k++) {
     if (base + k < m)
       counts[base + k] = off;
     off += v[k];
@@ -961,6 +964,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
                                                                     int *__restrict__ vals_out, long long n, int shift,
                                                                     int ntiles, const uint32_t *__restrict__ offsets,
                                                                     const uint32_t *__restrict__ chunk_offsets,
+                                                                    int chunk_shift,   // log2 of the scan's chunk length
                                                                     const uint32_t *__restrict__ n_dev = nullptr) {
   constexpr int kRadix = 1 << BITS;
   if (n_dev) {
@@ -1038,7 +1042,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
       const int d = threadIdx.x * kDigitsPerThread + k;
       const size_t slot = (size_t) d * ntiles + blockIdx.x;
       s_dbase[d] = dbase;
-      s_gdelta[d] = offsets[slot] + chunk_offsets[slot / kScanChunk] - dbase;
+      s_gdelta[d] = offsets[slot] + chunk_offsets[slot >> chunk_shift] - dbase;
       dbase += tot[k];
     }
   }
