@@ -874,8 +874,9 @@ void perm_swap(mphip_ctx *ctx, bool with_cache) {
 // stable LSD radix sort of n (key, value) pairs that starts in keys[0] / vals[0] and ping-pongs between the two
 // buffer pairs; *cur_out = the pair that holds the result
 // (n_dev: the number of pairs lives on the device and n is only its upper bound)
+// (index_sort: the values are the positions 0, 1, 2 ...; vals[0] is not read, the first pass generates them)
 int radix_passes(mphip_ctx *ctx, uint32_t *const keys[2], int *const vals[2], long long n, int key_bits, int *cur_out,
-                 const uint32_t *n_dev = nullptr) {
+                 const uint32_t *n_dev = nullptr, bool index_sort = false) {
   *cur_out = 0;
   if (n <= 0)
     return 0;
@@ -916,8 +917,9 @@ int radix_passes(mphip_ctx *ctx, uint32_t *const keys[2], int *const vals[2], lo
     hipLaunchKernelGGL(sort_scan_local_kernel<kScanPerLarge>, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream,       \
                        ctx->d_counts, m, d_chunks, n_dev, 1 << B);                                                     \
   hipLaunchKernelGGL(sort_scan_chunks_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_chunks, nchunks);         \
-  hipLaunchKernelGGL(sort_scatter_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur], vals[cur],   \
-                     keys[cur ^ 1], vals[cur ^ 1], n, shift, ntiles, ctx->d_counts, d_chunks, chunk_shift, n_dev)
+  hipLaunchKernelGGL(sort_scatter_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur],              \
+                     index_sort && pass == 0 ? (const int *) nullptr : vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,     \
+                     shift, ntiles, ctx->d_counts, d_chunks, chunk_shift, n_dev)
     if (bits == 8) {
       SORT_PASS(8);
     } else if (bits == 9) {
@@ -954,8 +956,8 @@ int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep
   const DevAtm a = dev_atm(ctx);
   TimestepArgs ts = { (double) ctx->ctl.direction, ctx->ctl.t_start, ctx->ctl.t_stop, timestep_t ? *timestep_t : 0.0 };
   hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
-                     ctx->d_keys[0], ctx->d_vals[0], ts, timestep_t ? ctx->d_dt : nullptr);
-  return radix_passes(ctx, ctx->d_keys, ctx->d_vals, n, bits_for(kmax), result_buf);
+                     ctx->d_keys[0], (int *) nullptr, ts, timestep_t ? ctx->d_dt : nullptr);
+  return radix_passes(ctx, ctx->d_keys, ctx->d_vals, n, bits_for(kmax), result_buf, nullptr, true);
 }
 
 // put every per-particle array back into the external slot order
@@ -1262,8 +1264,8 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
     hipLaunchKernelGGL(run_heads_count_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, seq, n, G, tile_runs, gate);
     hipLaunchKernelGGL(run_offsets_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, tile_runs, ntiles, gate);
     hipLaunchKernelGGL(run_compact_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, seq, n, G, tile_runs, ntiles,
-                       (uint32_t) ngroups, keys[0], ids[0], run_start, gate);
-    return radix_passes(ctx, keys, ids, n, key_bits, cur, nruns_dev);
+                       (uint32_t) ngroups, keys[0], (int *) nullptr, run_start, gate);
+    return radix_passes(ctx, keys, ids, n, key_bits, cur, nruns_dev, true);
   };
 #define GROUPS(B, BYINDEX, SEQ, SLOT)                                                                                  \
   hipLaunchKernelGGL((cell_sum_groups_kernel<VALS, B, BYINDEX>), dim3(nblocks), dim3(256), 0, ctx->stream, vals,       \

@@ -837,7 +837,8 @@ __global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, uint32_t *__restri
     else
       keys[i] = (uint32_t) ((((ix / tile) * nty + iy / tile) * M.np + iz) * (tile * tile)
                             + (ix % tile) * tile + iy % tile);
-    idx[i] = (int) i;
+    if (idx)
+      idx[i] = (int) i;
   }
 }
 
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
     const long long i = base + r * 64;
     const bool valid = i < n;
     key[r] = valid ? keys_in[i] : 0xffffffffu;
-    val[r] = valid ? vals_in[i] : 0;
+    val[r] = valid ? (vals_in ? vals_in[i] : (int) i) : 0;   // (no value array: the position itself, first pass of an index sort)
   }
   volatile uint32_t *cnt = s_cnt[wave];
 #pragma unroll
@@ -1402,7 +1403,8 @@ __global__ __launch_bounds__(256) void run_compact_kernel(const int *__restrict_
     if ((heads >> lane) & 1) {
       const uint32_t r = r0 + (uint32_t) __builtin_popcountll(heads & ((1ull << lane) - 1));
       run_key[r] = H.group[k] >= 0 ? (uint32_t) H.group[k] : outside;
-      run_id[r] = (int) r;
+      if (run_id)
+        run_id[r] = (int) r;
       run_start[r] = (uint32_t) (first + k * 64 + lane);
     }
     r0 += (uint32_t) __builtin_popcountll(heads);
