@@ -184,6 +184,9 @@ def main():
                     help="N > 1: reduce through the torch.distributed callback instead of the library's RCCL communicator")
     ap.add_argument("--rccl-single", action="store_true",
                     help="N = 1: give the context a one-rank RCCL communicator (exercises the native reduction path)")
+    ap.add_argument("--atomic-sums", action="store_true",
+                    help="cell sums of module_mixing / the gridded output with floating-point atomics (option "
+                         "deterministic_sums 0) instead of the reference's order")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="(diagnostic) do not bracket the step kernel with HIP events; roofline is then not reported")
     args = ap.parse_args()
@@ -245,6 +248,8 @@ def main():
         reduction = "rccl (native, on the step stream)" if ok else "torch.distributed callback"
     if args.eager_meteo:
         sim.set_option("lazy_meteo", 0)
+    if args.atomic_sums:
+        sim.set_option("deterministic_sums", 0)
     sim.timesteps_init(0.0, 0.0)
     dt = sim.ctl.dt_mod
 
