@@ -478,6 +478,31 @@ def test_ordered_grid_sums_on_odd_grids(shape, order, path):
     s.close()
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8193])
+def test_ordered_sums_at_tile_and_wave_boundaries(n):
+    """Particle counts around the wave (64) and tile (4096) sizes of the run compaction and of the sort, in both
+    storage orders: module_mixing and the gridded sums against the serial code, bit for bit."""
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=n)
+    ctl = dict(ctl, mixing_dt=180.0)
+    for interval in (0, 1):
+        o = B.Oracle(ctl, clim, m0, m1, atm)
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("locality_sort_interval", interval)
+        s.timesteps_init(0.0, 0.0)
+        ts = cases.step_times(s.ctl)
+        for t in ts[:2]:
+            s.run_timestep(t)
+        _oracle_takes_device_state(o, s)
+        o.module("mixing", ts[1])
+        s.module("mixing", ts[1])
+        g, r = s.state(), o.state()
+        assert np.array_equal(g["q"], r["q"])
+        co, mo, so = o.grid_sums(ts[1])
+        cs, ms, ss = s.grid_sums(ts[1])
+        assert np.array_equal(co, cs) and np.array_equal(mo, ms) and np.array_equal(so, ss)
+        s.close()
+
+
 # ---------------------------------------------------------------------------
 # edge cases
 # ---------------------------------------------------------------------------
