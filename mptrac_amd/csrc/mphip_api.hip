@@ -142,6 +142,24 @@ struct mphip_ctx {
   uint32_t *d_counts = nullptr;
   size_t counts_cap = 0;
   int sorted_buf = -1;                // which d_keys/d_vals pair holds the last result
+  // module_sort of the NEXT time step, started beside the rest of this one (option "sort_ahead"): once the launch
+  // that moves the particles has run, their positions are final for this step -- module_mixing and the deposition
+  // modules only change quantities -- so the keys and the radix sort of the next step's module_sort (and its
+  // module_timesteps) can run on a second stream, into buffers of their own, while the main stream does the
+  // rest of the step.  The next mphip_run_timestep takes the result if it is called with the expected time and
+  // nothing touched the particles, the grids or the control parameters in between; otherwise it is dropped.
+  bool sort_ahead = true;
+  hipStream_t ahead_stream = nullptr;
+  hipEvent_t ahead_mark = nullptr, ahead_done = nullptr;
+  uint32_t *ahead_keys[2] = {};
+  int *ahead_vals[2] = {};
+  uint32_t *ahead_counts = nullptr;
+  size_t ahead_counts_cap = 0;
+  double *ahead_dt = nullptr;
+  long long ahead_cap = 0;
+  bool ahead_valid = false;
+  double ahead_t = 0;
+  int ahead_cur = 0;
 
   // mixing / grid sums
   int *d_cell = nullptr;
@@ -943,7 +961,7 @@ int bits_for(unsigned long long kmax) {   // number of key bits that can be non-
 }
 
 // module_sort keys + sort of (key, index); returns the buffer holding the result
-int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep_t = nullptr) {
+int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep_t) {
   const long long n = ctx->np;
   unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
   if (tile > 0) {
@@ -960,12 +978,73 @@ int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep
   return radix_passes(ctx, ctx->d_keys, ctx->d_vals, n, bits_for(kmax), result_buf, nullptr, true);
 }
 
+// ---- module_sort ahead of time (mphip_ctx::sort_ahead) -----------------------------------------------------
+
+// the sort buffers of the context <-> the buffers of the sort that runs ahead
+void ahead_swap_buffers(mphip_ctx *ctx) {
+  for (int k = 0; k < 2; k++) {
+    std::swap(ctx->d_keys[k], ctx->ahead_keys[k]);
+    std::swap(ctx->d_vals[k], ctx->ahead_vals[k]);
+  }
+  std::swap(ctx->d_counts, ctx->ahead_counts);
+  std::swap(ctx->counts_cap, ctx->ahead_counts_cap);
+  std::swap(ctx->d_dt, ctx->ahead_dt);
+}
+
+// forget a sort that runs ahead (something it depends on is about to change); waits for its kernels, which may
+// still be reading the particle arrays
+int ahead_drop(mphip_ctx *ctx) {
+  if (!ctx->ahead_valid)
+    return 0;
+  ctx->ahead_valid = false;
+  HIPCHK(hipStreamSynchronize(ctx->ahead_stream));
+  return 0;
+}
+
+// keys, module_timesteps and radix sort of the module_sort call that mphip_run_timestep(t_next) will make, on
+// the second stream, behind the kernels queued on the main stream so far
+int ahead_launch(mphip_ctx *ctx, double t_next) {
+  const long long n = ctx->np;
+  if (!ctx->ahead_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->ahead_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ahead_mark, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ahead_done, hipEventDisableTiming));
+  }
+  if (n > ctx->ahead_cap) {
+    for (int k = 0; k < 2; k++)
+      if (dev_alloc(ctx, &ctx->ahead_keys[k], (size_t) n) || dev_alloc(ctx, &ctx->ahead_vals[k], (size_t) n))
+        return 1;
+    if (dev_alloc(ctx, &ctx->ahead_dt, (size_t) n))
+      return 1;
+    ctx->ahead_cap = n;
+  }
+  HIPCHK(hipEventRecord(ctx->ahead_mark, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(ctx->ahead_stream, ctx->ahead_mark, 0));
+  // the sort code runs as it is, on the other stream and the other buffers
+  hipStream_t main_stream = ctx->stream;
+  ahead_swap_buffers(ctx);
+  ctx->stream = ctx->ahead_stream;
+  int cur = 0;
+  const int rc = sort_pairs(ctx, 0, &cur, &t_next);
+  ctx->stream = main_stream;
+  ahead_swap_buffers(ctx);
+  if (rc)
+    return 1;
+  HIPCHK(hipEventRecord(ctx->ahead_done, ctx->ahead_stream));
+  ctx->ahead_valid = true;
+  ctx->ahead_t = t_next;
+  ctx->ahead_cur = cur;
+  return 0;
+}
+
 // put every per-particle array back into the external slot order
 int restore_external_order(mphip_ctx *ctx) {
   if (ctx->ext_identity || ctx->np == 0) {
     ctx->ext_identity = true;
     return 0;
   }
+  if (ahead_drop(ctx))
+    return 1;
   PermArgs g = perm_args(ctx, true);
   const PermGeom pg = perm_geom(ctx->np);
   hipLaunchKernelGGL(perm_scatter_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_ext, ctx->np, pg);
@@ -982,13 +1061,13 @@ int restore_external_order(mphip_ctx *ctx) {
 int locality_sort(mphip_ctx *ctx) {
   if (ctx->np == 0)
     return 0;
-  if (ensure_packed(ctx))
+  if (ahead_drop(ctx) || ensure_packed(ctx))
     return 1;
   int cur = 0;
   // measured (tools/gpu_ablate.py tiles): 4 x 4 columns for the pressure-level kernels, 8 x 8 for the model-level ones
   const bool ml_winds = ctx->have_ctl && ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3;
   const int tile = ctx->locality_tile > 0 ? ctx->locality_tile : (ml_winds ? 8 : 4);
-  if (sort_pairs(ctx, tile, &cur))
+  if (sort_pairs(ctx, tile, &cur, nullptr))
     return 1;
   PermArgs g = perm_args(ctx, true);
   g.ext_in = ctx->ext_identity ? nullptr : ctx->d_ext;
@@ -1010,11 +1089,19 @@ int do_sort(mphip_ctx *ctx, const double *timestep_t = nullptr) {
   const long long n = ctx->np;
   if (n == 0)
     return 0;
-  if (ensure_packed(ctx) || restore_external_order(ctx))
-    return 1;
   int cur = 0;
-  if (sort_pairs(ctx, 0, &cur, timestep_t))   // with timestep_t: module_timesteps in the key kernel
-    return 1;
+  if (timestep_t && ctx->ahead_valid && ctx->ahead_t == *timestep_t && ctx->ext_identity) {
+    // keys, dt and the sorted permutation were computed beside the previous time step: take them over
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ahead_done, 0));
+    ahead_swap_buffers(ctx);
+    ctx->ahead_valid = false;
+    cur = ctx->ahead_cur;
+  } else {
+    if (ahead_drop(ctx) || ensure_packed(ctx) || restore_external_order(ctx))
+      return 1;
+    if (sort_pairs(ctx, 0, &cur, timestep_t))   // with timestep_t: module_timesteps in the key kernel
+      return 1;
+  }
   ctx->sorted_buf = cur;
   const PermGeom pg = perm_geom(n);
   if (timestep_t && ctx->fuse_sort) {
@@ -1562,6 +1649,18 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_axes);
   ctx->pk.release();
   ctx->pk_next.release();
+  if (ctx->ahead_stream) {
+    (void) hipStreamSynchronize(ctx->ahead_stream);
+    (void) hipStreamDestroy(ctx->ahead_stream);
+    (void) hipEventDestroy(ctx->ahead_mark);
+    (void) hipEventDestroy(ctx->ahead_done);
+  }
+  for (int k = 0; k < 2; k++) {
+    dev_free(ctx->ahead_keys[k]);
+    dev_free(ctx->ahead_vals[k]);
+  }
+  dev_free(ctx->ahead_counts);
+  dev_free(ctx->ahead_dt);
   for (auto p : ctx->d_arr)
     dev_free(p);
   for (auto p : ctx->d_alt)
@@ -1600,6 +1699,8 @@ const char *mphip_last_error(const mphip_ctx *ctx) {
 }
 
 int mphip_update_ctl(mphip_ctx *ctx, const mphip_ctl_t *ctl) {
+  if (ctx && ahead_drop(ctx))
+    return 1;
   if (!ctx || !ctl)
     return fail(ctx, "null argument");
   if (ctl->nq < 0 || ctl->nq > MPHIP_NQ_MAX)
@@ -1659,6 +1760,8 @@ int mphip_update_clim(mphip_ctx *ctx, int ntime, int nlat, const double *tropo_t
 }
 
 int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
+  if (ctx && ahead_drop(ctx))
+    return 1;
   if (!ctx || !met || slot < 0 || slot > 1)
     return fail(ctx, "bad argument");
   if (met->nx < 2 || met->ny < 2 || met->np < 2 || !met->lon || !met->lat || !met->p)
@@ -1729,6 +1832,8 @@ int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met) {
 }
 
 int mphip_swap_met(mphip_ctx *ctx) {
+  if (ctx && ahead_drop(ctx))
+    return 1;
   if (!ctx)
     return 1;
   if (flush_meteo(ctx))
@@ -1847,6 +1952,8 @@ static int join_uploader(mphip_ctx *ctx) {
 }
 
 int mphip_commit_met(mphip_ctx *ctx) {
+  if (ctx && ahead_drop(ctx))
+    return 1;
   if (!ctx)
     return 1;
   if (!ctx->next_pending)
@@ -1898,6 +2005,8 @@ int mphip_prefetch_done(mphip_ctx *ctx) {
 
 int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_total, int nq, const double *time,
                      const double *p, const double *lon, const double *lat, const double *const *q) {
+  if (ctx && ahead_drop(ctx))
+    return 1;
   if (!ctx || np < 0 || nq < 0 || nq > MPHIP_NQ_MAX || ip0 < 0 || np_total < ip0 + np)
     return fail(ctx, "bad particle counts");
   if (np > 2147483647LL)
@@ -1998,6 +2107,8 @@ int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *
 }
 
 int mphip_update_cache(mphip_ctx *ctx, const float *uvwp, const uint64_t *rng_ctr) {
+  if (ctx && ahead_drop(ctx))
+    return 1;
   if (!ctx)
     return 1;
   HIPCHK(hipSetDevice(ctx->device));
@@ -2039,6 +2150,8 @@ int mphip_get_cache(mphip_ctx *ctx, float *uvwp, double *dt, uint64_t *rng_ctr) 
 }
 
 int mphip_update_iso(mphip_ctx *ctx, const double *iso_var, const double *iso_ts, const double *iso_ps, int iso_n) {
+  if (ctx && ahead_drop(ctx))
+    return 1;
   if (!ctx)
     return 1;
   HIPCHK(hipSetDevice(ctx->device));
@@ -2169,14 +2282,24 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   // runs after them here (own kernel, every particle)
   const bool meteo_now = c.met_dt_out > 0 && (c.met_dt_out < c.dt_mod || fmod(t, c.met_dt_out) == 0);
   const bool mixing_now = c.mixing_trop >= 0 && c.mixing_strat >= 0 && (c.mixing_dt <= 0 || fmod(t, c.mixing_dt) == 0);
+  // module_sort of the next step can start as soon as this step's particles have moved (sort_ahead)
+  const double t_next = t + c.direction * c.dt_mod;
+  const bool sort_next = ctx->sort_ahead && ctx->np > 0 && ctx->ext_identity && c.sort_dt > 0
+    && fmod(t_next, c.sort_dt) == 0 && c.direction * (t_next - c.t_stop) <= 0;
   if (!mixing_now) {
     if (launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
+      return 1;
+    if (sort_next && ahead_launch(ctx, t_next))
       return 1;
     return meteo_now ? schedule_meteo(ctx) : 0;
   }
   if (tail && (mask & MPHIP_MOD_TIMESTEPS))
     mask |= kStoreDt;
-  if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl) || do_mixing(ctx, t))
+  if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
+    return 1;
+  if (sort_next && ahead_launch(ctx, t_next))   // ... beside module_mixing and the deposition launch
+    return 1;
+  if (do_mixing(ctx, t))
     return 1;
   if (tail && launch_step(ctx, tail, t, 0, 0, 0))
     return 1;
@@ -2184,6 +2307,8 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
 }
 
 int mphip_module(mphip_ctx *ctx, unsigned modules, double t) {
+  if (ctx && ahead_drop(ctx))
+    return 1;
   if (!ctx)
     return 1;
   if (!ctx->have_ctl)
@@ -2393,6 +2518,12 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (!(value == 0 || (value >= 8 && value <= kRadixMaxBits)))
       return fail(ctx, "sort_bits must be 0 (automatic), 8, 9 or 10");
     ctx->sort_bits = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "sort_ahead") == 0) {   // 0: module_sort runs when mphip_run_timestep reaches it
+    if (ahead_drop(ctx))
+      return 1;
+    ctx->sort_ahead = value != 0;
     return 0;
   }
   if (strcmp(name, "sum_path") == 0) {   // tests: force one of the two ordered-sum algorithms (0: choose by crowding)

@@ -1176,6 +1176,45 @@ def test_ensemble_mixing(nens):
     s.close()
 
 
+@pytest.mark.parametrize("sort_dt", [180.0, 360.0])
+def test_sort_ahead_of_time_is_not_observable(sort_dt):
+    """module_sort of the next time step starts on a second stream as soon as this step's particles have moved
+    (option sort_ahead, default on) and is taken over if the next call comes with the expected time: the same
+    bits as sorting when the call arrives -- with a sort every step and every other step, a download in between,
+    a single-module call in between (drops the prepared sort) and a meteo hand-over."""
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=30000)
+    ctl = dict(ctl, sort_dt=sort_dt, mixing_dt=180.0, t_stop=7200.0)
+    m2 = synthetic_met("C1", 7200.0, 1.5, fields=cases.PRESSURE_LEVEL_FIELDS)
+    runs = []
+    for ahead in (1, 0):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("sort_ahead", ahead)
+        s.timesteps_init(0.0, 0.0)
+        seen = []
+        for k, t in enumerate(cases.step_times(s.ctl)[:30]):
+            if k == 21:
+                s.swap_met(m2)
+            s.run_timestep(t)
+            if k == 5:
+                seen.append(s.state())              # download between two steps
+            if k == 9:
+                s.module("position", t)             # touches the particles: a prepared sort must be dropped
+            if k == 12:
+                seen.append(s.sort())               # module_sort on its own
+        seen.append(s.state())
+        seen.append(s.get_cache()["dt"])
+        runs.append(seen)
+        s.close()
+    for a, b in zip(*runs):
+        if isinstance(a, dict):
+            for key in ("time", "lon", "lat", "p", "q", "uvwp"):
+                assert np.array_equal(a[key], b[key]), key
+        elif isinstance(a, tuple):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        else:
+            assert np.array_equal(a, b)
+
+
 def test_long_run_400_steps_with_prefetched_handovers():
     """Drift check (was tools/gpu_soak.py): 2 x 10^4 particles, every module of the `full` case with
     module_meteo, module_sort every 10 and mixing every 5 steps, 400 time steps over 20 h, three meteo hand-overs
