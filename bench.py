@@ -302,15 +302,16 @@ def main():
         a_per, a_state, a_met = algorithmic_bytes_per_pstep(args.workload, met0, n_local)
         bytes_per_launch = a_per * n_local
         achieved = bytes_per_launch / (kernel_ms_per_launch * 1e-3) / 1e9
-        traffic = valu_busy = None
+        traffic = valu_busy = fp64_frac = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             prof = json.load(open(tfile))
             if prof.get("_build_id") == build_id():      # counters of THIS build only (tools/profile.sh)
                 traffic = prof.get(args.workload)
                 valu_busy = prof.get("_valu_busy_frac", {}).get(args.workload)
+                fp64_frac = prof.get("_fp64_valu_frac", {}).get(args.workload)
         if args.particles:      # the committed PMC profile belongs to the workload's own particle count
-            traffic = valu_busy = None
+            traffic = valu_busy = fp64_frac = None
         out = {
             "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -338,7 +339,7 @@ def main():
                          "bytes_per_particle_step": a_per,
                          # SURVEY 8(d) caveat: the fused step is fp64-VALU-bound, not HBM-bound; share of SIMD
                          # cycles executing VALU instructions from the committed rocprofv3 PMC profile
-                         "valu_busy_frac": valu_busy, "build_id": build_id()},
+                         "valu_busy_frac": valu_busy, "fp64_valu_frac": fp64_frac, "build_id": build_id()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, ctl, clim, met0, met1, atm,

@@ -30,5 +30,21 @@ if "valu_busy_frac" in raw:
                 "(tools/summarize_prof.py); %.0f VALU instructions per 64 particle-steps"
                 % raw.get("valu_insts_per_64_particle_steps", float("nan")),
     }
+# share of fp64 arithmetic among the VALU instructions, from the instruction-mix passes of the same build
+# (tools/profile_valu_mix.sh -> gpurun_out/prof_<tag>mix/valu_mix.txt), if they were run
+mix_file = os.path.join(src.rstrip("/") + "mix", "valu_mix.txt")
+if os.path.exists(mix_file):
+    mix = {}
+    for line in open(mix_file):
+        f = line.split()
+        if len(f) >= 4 and f[0].startswith("SQ_"):
+            mix[f[0]] = float(f[3])
+    fp64 = sum(mix.get("SQ_INSTS_VALU_%s_F64" % k, 0.0) for k in ("ADD", "MUL", "FMA", "TRANS"))
+    if mix.get("SQ_INSTS_VALU"):
+        out["_fp64_valu_frac"] = {
+            workload: round(fp64 / mix["SQ_INSTS_VALU"], 3),
+            "_how": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 / SQ_INSTS_VALU of a steady step_kernel dispatch "
+                    "(tools/profile_valu_mix.sh, same build)",
+        }
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
