@@ -961,21 +961,36 @@ int bits_for(unsigned long long kmax) {   // number of key bits that can be non-
 }
 
 // module_sort keys + sort of (key, index); returns the buffer holding the result
-int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep_t) {
-  const long long n = ctx->np;
+// largest sort key + 1 of the (tiled) cell order; 0 = does not fit 32 bits
+unsigned long long sort_key_range(const mphip_ctx *ctx, int tile) {
   unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
   if (tile > 0) {
     const unsigned long long ntx = (ctx->nx + tile - 1) / tile, nty = (ctx->ny + tile - 1) / tile;
     kmax = ntx * nty * ctx->npl * tile * tile;
   }
-  if (kmax > 0xffffffffULL)
+  return kmax > 0xffffffffULL ? 0 : kmax;
+}
+
+// keys of module_sort (and module_timesteps with timestep_t, and module_mixing's box index with box) -> d_keys[0]
+int sort_keys(mphip_ctx *ctx, int tile, const double *timestep_t, const BoxArgs *box) {
+  if (!sort_key_range(ctx, tile))
     return fail(ctx, "meteo grid too large for the 32-bit sort key");
   const DevMet M = dev_met(ctx);
   const DevAtm a = dev_atm(ctx);
   TimestepArgs ts = { (double) ctx->ctl.direction, ctx->ctl.t_start, ctx->ctl.t_stop, timestep_t ? *timestep_t : 0.0 };
-  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(n)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
-                     ctx->d_keys[0], (int *) nullptr, ts, timestep_t ? ctx->d_dt : nullptr);
-  return radix_passes(ctx, ctx->d_keys, ctx->d_vals, n, bits_for(kmax), result_buf, nullptr, true);
+  BoxArgs none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(ctx->np)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
+                     ctx->d_keys[0], (int *) nullptr, ts, timestep_t ? ctx->d_dt : nullptr, box ? *box : none);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep_t) {
+  if (sort_keys(ctx, tile, timestep_t, nullptr))
+    return 1;
+  return radix_passes(ctx, ctx->d_keys, ctx->d_vals, ctx->np, bits_for(sort_key_range(ctx, tile)), result_buf, nullptr,
+                      true);
 }
 
 // ---- module_sort ahead of time (mphip_ctx::sort_ahead) -----------------------------------------------------
@@ -1003,7 +1018,9 @@ int ahead_drop(mphip_ctx *ctx) {
 
 // keys, module_timesteps and radix sort of the module_sort call that mphip_run_timestep(t_next) will make, on
 // the second stream, behind the kernels queued on the main stream so far
-int ahead_launch(mphip_ctx *ctx, double t_next) {
+// (box: module_mixing of the current step is still to come -- the key kernel then runs on the main stream and
+// leaves the box index of every particle in box->cell on the way, one pass over the particle arrays less)
+int ahead_launch(mphip_ctx *ctx, double t_next, const BoxArgs *box = nullptr) {
   const long long n = ctx->np;
   if (!ctx->ahead_stream) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->ahead_stream, hipStreamNonBlocking));
@@ -1018,14 +1035,20 @@ int ahead_launch(mphip_ctx *ctx, double t_next) {
       return 1;
     ctx->ahead_cap = n;
   }
-  HIPCHK(hipEventRecord(ctx->ahead_mark, ctx->stream));
-  HIPCHK(hipStreamWaitEvent(ctx->ahead_stream, ctx->ahead_mark, 0));
   // the sort code runs as it is, on the other stream and the other buffers
   hipStream_t main_stream = ctx->stream;
   ahead_swap_buffers(ctx);
+  int cur = 0, rc = 0;
+  if (box)
+    rc = sort_keys(ctx, 0, &t_next, box);
+  if (!rc && (hipEventRecord(ctx->ahead_mark, main_stream) != hipSuccess
+              || hipStreamWaitEvent(ctx->ahead_stream, ctx->ahead_mark, 0) != hipSuccess))
+    rc = fail(ctx, "stream hand-over of the sort ahead of time failed");
   ctx->stream = ctx->ahead_stream;
-  int cur = 0;
-  const int rc = sort_pairs(ctx, 0, &cur, &t_next);
+  if (!rc && !box)
+    rc = sort_keys(ctx, 0, &t_next, nullptr);
+  if (!rc)
+    rc = radix_passes(ctx, ctx->d_keys, ctx->d_vals, n, bits_for(sort_key_range(ctx, 0)), &cur, nullptr, true);
   ctx->stream = main_stream;
   ahead_swap_buffers(ctx);
   if (rc)
@@ -1501,14 +1524,15 @@ int mixing_relax(mphip_ctx *ctx, const MixPlan &P) {
   return 0;
 }
 
-int do_mixing(mphip_ctx *ctx, double t) {
+// (cells_ready: the box indices are in d_cell already, left there by the key kernel of a sort ahead of time)
+int do_mixing(mphip_ctx *ctx, double t, bool cells_ready = false) {
   MixPlan P;
   bool active;
   if (mixing_plan(ctx, t, &P, &active))
     return 1;
   if (!active)
     return 0;
-  return mixing_cells(ctx, P) || mixing_sums(ctx, P) || mixing_relax(ctx, P);
+  return (!cells_ready && mixing_cells(ctx, P)) || mixing_sums(ctx, P) || mixing_relax(ctx, P);
 }
 
 void unpin_all(mphip_ctx *ctx, std::vector<std::pair<uintptr_t, uintptr_t>> &list) {
@@ -2297,9 +2321,16 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
     mask |= kStoreDt;
   if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
     return 1;
-  if (sort_next && ahead_launch(ctx, t_next))   // ... beside module_mixing and the deposition launch
-    return 1;
-  if (do_mixing(ctx, t))
+  bool cells_ready = false;
+  if (sort_next) {   // ... beside module_mixing and the deposition launch
+    MixPlan plan;
+    if (mixing_plan(ctx, t, &plan, &cells_ready))
+      return 1;
+    const BoxArgs box = { ctx->d_cell, plan.box.grid, plan.box.t0, plan.box.t1, plan.box.ens, plan.box.ngrid };
+    if (ahead_launch(ctx, t_next, cells_ready ? &box : nullptr))
+      return 1;
+  }
+  if (do_mixing(ctx, t, cells_ready))
     return 1;
   if (tail && launch_step(ctx, tail, t, 0, 0, 0))
     return 1;

@@ -803,8 +803,19 @@ struct TimestepArgs {
   double direction, t_start, t_stop, t;
 };
 
+// ... and, when module_mixing of the current step is still to come, its box index on the way (the same four
+// arrays are read): cell == NULL = off
+struct BoxArgs {
+  int *cell;
+  BoxGrid grid;
+  double t0, t1;
+  const double *ens;
+  int ngrid;
+};
+
 __global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, uint32_t *__restrict__ keys,
-                                int *__restrict__ idx, const TimestepArgs ts, double *__restrict__ dt_out) {
+                                int *__restrict__ idx, const TimestepArgs ts, double *__restrict__ dt_out,
+                                const BoxArgs box) {
   const int wrapped = tile > 0;
   const int nty = tile > 0 ? (M.ny + tile - 1) / tile : 0;
   extern __shared__ double s_axes[];
@@ -813,6 +824,8 @@ __global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, uint32_t *__restri
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < a.np;
        i += (long long) gridDim.x * blockDim.x) {
     double lon = a.lon[i], lat = a.lat[i];
+    if (box.cell)
+      box.cell[i] = box_cell(box.grid, box.t0, box.t1, a.time[i], lon, lat, a.p[i], box.ens, i, box.ngrid);
     if (dt_out) {   // module_timesteps, mptrac.c:6016-6041
       const double time = a.time[i];
       double dt = 0.0;
