@@ -227,6 +227,58 @@ def _host_lib():
     return C.CDLL(lib)
 
 
+def test_job_from_environment_and_index_range_shards():
+    """One process per GPU in the C driver: rank / world size / rendezvous address come from the launcher's
+    environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT), and every rank keeps the index range
+    [np rank / world, np (rank + 1) / world) of the particles it read -- the ranges of all ranks tile the set."""
+    import ctypes as C
+    import subprocess
+    import sys
+    from mptrac_amd import build
+    lib, _ = build.build_host()
+    NP, NQ = build.HOST_DIMS["NP"], build.HOST_DIMS["NQ"]
+    code = r"""
+import ctypes as C, sys, json
+NP, NQ = %d, %d
+class Job(C.Structure):
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("local_rank", C.c_int), ("port", C.c_int), ("addr", C.c_char * 64)]
+class Atm(C.Structure):
+    _fields_ = [("np", C.c_int), ("time", C.c_double * NP), ("p", C.c_double * NP), ("lon", C.c_double * NP),
+                ("lat", C.c_double * NP), ("q", (C.c_double * NP) * NQ)]
+L = C.CDLL(%r)
+job = Job()
+L.mptrac_amd_job_from_env(C.byref(job))
+atm = Atm()
+atm.np = 1003
+for i in range(1003):
+    atm.time[i] = i; atm.lon[i] = 2 * i; atm.q[NQ - 1][i] = 3 * i
+L.mptrac_amd_shard(C.byref(atm), C.byref(job))
+print(json.dumps({"rank": job.rank, "world": job.world, "local": job.local_rank, "port": job.port,
+                  "addr": job.addr.decode(), "np": atm.np, "first": atm.time[0], "last": atm.time[atm.np - 1],
+                  "lon0": atm.lon[0], "q0": atm.q[NQ - 1][0]}))
+""" % (NP, NQ, lib)
+    import json
+    import os
+    seen = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="10.1.2.3",
+                   MASTER_PORT="29000")
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert (d["rank"], d["world"], d["local"], d["addr"]) == (rank, 3, rank, "10.1.2.3") and d["port"] == 29001
+        lo, hi = 1003 * rank // 3, 1003 * (rank + 1) // 3
+        assert d["np"] == hi - lo and d["first"] == lo and d["last"] == hi - 1
+        assert d["lon0"] == 2 * lo and d["q0"] == 3 * lo
+        seen.append((lo, hi))
+    assert seen[0][0] == 0 and seen[-1][1] == 1003 and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    # without a launcher: one rank
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert (d["rank"], d["world"], d["np"], d["addr"]) == (0, 1, 1003, "127.0.0.1")
+
+
 def test_control_file_lookup_rules(tmp_path):
     """scan_ctl: "NAME = VALUE" lines, first match wins, case-insensitive, NAME[i] / NAME[*], command-line pairs
     override the file, '-' means arguments only, defaults for missing keys."""
