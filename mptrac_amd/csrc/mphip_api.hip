@@ -39,6 +39,9 @@ struct MetSlot {
   bool has2[MPHIP_N2D] = {};
   std::vector<double> lon, lat, p;    // the snapshot's own axes: the reference interpolates on those of the current met0
   float ps11 = 0.f;                   // ps at grid node [1][1] (module_position reflects there)
+  // smallest surface pressure of the snapshot (-inf if a value is not finite: no shortcut then) and smallest
+  // finite cloud-top pressure: lower bounds of what the deposition modules interpolate (DevMet::ps_skip, pct_skip)
+  double ps_min = -HUGE_VAL, pct_min = -HUGE_VAL;
 };
 
 }   // namespace
@@ -133,6 +136,7 @@ struct mphip_ctx {
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;
   bool force_generic = false;
+  bool compact_depo = true;           // deposition-only launches through depo_kernel (0: the fused kernel's tail)
   int sort_bits = 0;                  // digit width of the radix sort (0 = fewest passes; 8, 9, 10: tuning / tests)
   int steps_since_resort = 1 << 30;
 
@@ -312,6 +316,9 @@ DevMet dev_met(const mphip_ctx *c) {
   M.p_step = M.p_ascending ? 1 : -1;
   M.ps11[0] = c->slot[0 ^ c->flip].ps11;
   M.ps11[1] = c->slot[1 ^ c->flip].ps11;
+  // a little below the smallest value of either snapshot: what lies below that is below every interpolated value
+  M.ps_skip = std::min(c->slot[0].ps_min, c->slot[1].ps_min) - 1e-6;
+  M.pct_skip = std::min(c->slot[0].pct_min, c->slot[1].pct_min) - 1e-6;
   M.logtab = c->d_logtab;
   return M;
 }
@@ -697,6 +704,19 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // (the lean instantiations are keyed on the movers; loss / decay / deposition are run-time bits in all of them)
   const unsigned sel = ((ctx->ctl.advect == 4 || !(mask & MPHIP_MOD_ADVECT)) && !rare && !ml_ && !ctx->force_generic && lean_ok)
     ? ((mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules)) : kMaskGeneric;
+  // module_wet_depo / module_dry_depo alone (the launch behind module_mixing): the kernel that packs the few
+  // particles with anything to do into full waves
+  constexpr unsigned kDepo = MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
+  const size_t depo_lds = ((axes_lds_bytes(ctx) + 15) & ~(size_t) 15) + (size_t) per_block * sizeof(int);
+  if (sel == kTailOnly && (mask & kDepo) && !(mask & ~kDepo) && ctx->compact_depo && !ctx->fused_perm
+      && depo_lds <= 64 * 1024) {
+    hipLaunchKernelGGL(depo_kernel, dim3(nb), dim3(256), depo_lds, ctx->stream, S);
+    HIPCHK(hipGetLastError());
+    ctx->fused_perm = nullptr;
+    if (ctx->prof)
+      HIPCHK(hipEventRecord(e1, ctx->stream));
+    return 0;
+  }
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
   case M:                                                                                             \
@@ -1574,6 +1594,33 @@ int upload_fields(mphip_ctx *ctx, MetSlot &S, const mphip_met_t *met, bool new_g
     }
   }
   S.ps11 = met->f2[MPHIP_PS] ? met->f2[MPHIP_PS][(size_t) met->sx2 + 1] : 0.f;
+  S.ps_min = S.pct_min = -HUGE_VAL;
+  if (met->f2[MPHIP_PS]) {
+    double lo = HUGE_VAL;
+    bool finite = true;
+    for (int ix = 0; ix < met->nx && finite; ix++)
+      for (int iy = 0; iy < met->ny; iy++) {
+        const float v = met->f2[MPHIP_PS][(size_t) ix * (size_t) met->sx2 + iy];
+        if (!std::isfinite(v)) {
+          finite = false;
+          break;
+        }
+        lo = std::min(lo, (double) v);
+      }
+    if (finite)
+      S.ps_min = lo;
+  }
+  if (met->f2[MPHIP_PCT]) {
+    double lo = HUGE_VAL;
+    for (int ix = 0; ix < met->nx; ix++)
+      for (int iy = 0; iy < met->ny; iy++) {
+        const float v = met->f2[MPHIP_PCT][(size_t) ix * (size_t) met->sx2 + iy];
+        if (std::isfinite(v))
+          lo = std::min(lo, (double) v);
+      }
+    if (lo < HUGE_VAL)
+      S.pct_min = lo;
+  }
   for (int f = 0; f < MPHIP_N2D; f++) {
     S.has2[f] = met->f2[f] != nullptr;
     if (!S.has2[f])
@@ -2549,6 +2596,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (!(value == 0 || (value >= 8 && value <= kRadixMaxBits)))
       return fail(ctx, "sort_bits must be 0 (automatic), 8, 9 or 10");
     ctx->sort_bits = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "compact_depo") == 0) {   // 0: deposition-only launches run the tail of the fused kernel
+    ctx->compact_depo = value != 0;
     return 0;
   }
   if (strcmp(name, "sort_ahead") == 0) {   // 0: module_sort runs when mphip_run_timestep reaches it

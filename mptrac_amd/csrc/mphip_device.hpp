@@ -78,6 +78,11 @@ struct DevMet {
   double p_min, p_search_max;    // smallest node of the pressure axis, largest double below its largest node
   int p_cmp_off, p_step;         // ascending axis: 1, +1; descending: 0, -1 (the node that decides table index vs neighbour)
   float ps11[2];                 // ps of met0 / met1 at grid node [1][1] (module_position, quirk Q1)
+  // lower bounds of the surface pressure / the finite cloud-top pressures of both snapshots (minus a guard band;
+  // -inf = unknown): a particle between the snapshots with p < ps_skip - dry_depo_dp lies above the surface layer
+  // of module_dry_depo wherever it is, one with p <= pct_skip above every cloud top of module_wet_depo -- both
+  // modules return for it before they gather anything, with the result the gathers would have led to
+  double ps_skip, pct_skip;
   const double *logtab;          // table of log_tab() (kLogTabN x 3 doubles), copied to LDS by the step kernel
 };
 

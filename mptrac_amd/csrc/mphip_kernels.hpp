@@ -160,9 +160,28 @@ __device__ __forceinline__ void apply_loss(const mphip_ctl_t &ctl, const DevAtm 
     a.q[ctl.qnt_vmr][i] *= aux;
 }
 
+// Shortcuts of the deposition modules (DevMet::ps_skip / pct_skip).  Both modules start with an interpolation of
+// a surface field and return if the particle is above it; for a time weight in [0, 1] the interpolated value
+// (bilinear or nearest neighbour, then blended in time) is not below the smallest value of the two snapshots,
+// so a particle below that bound (minus a guard band for the rounding) returns either way.
+__device__ __forceinline__ bool between_snapshots(const DevMet &M, const Particle &P) {
+  const double wt = time_weight(M, P.time);
+  return wt >= 0.0 && wt <= 1.0;
+}
+
+__device__ __forceinline__ bool above_every_cloud_top(const DevMet &M, const Particle &P) {
+  return P.p <= M.pct_skip && between_snapshots(M, P);
+}
+
+__device__ __forceinline__ bool above_every_surface_layer(const mphip_ctl_t &ctl, const DevMet &M, const Particle &P) {
+  return P.p < M.ps_skip - ctl.dry_depo_dp && between_snapshots(M, P);
+}
+
 // module_wet_depo, mptrac.c:6170-6289
 __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
                                          long long i, const Particle &P) {
+  if (above_every_cloud_top(M, P))
+    return;
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
   SurfB c2;
@@ -225,6 +244,8 @@ __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M
 // module_dry_depo, mptrac.c:4753-4796
 __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
                                          long long i, const Particle &P) {
+  if (above_every_surface_layer(ctl, M, P))
+    return;
   Stencil s = stencil_zero();
   stencil_2d(M, A, P.lon, P.lat, s);
   SurfA c2;
@@ -247,6 +268,8 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
 // (one horizontal stencil at the final position serves both modules)
 __device__ __forceinline__ void wet_depo_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
                                               long long i, const Particle &P, Stencil &s) {
+  if (above_every_cloud_top(M, P))
+    return;
   SurfB c2;
   load_sfb(M.sfc, M, s, c2);
   const double wt = time_weight(M, P.time);
@@ -306,6 +329,8 @@ __device__ __forceinline__ void wet_depo_fast(const mphip_ctl_t &ctl, const DevM
 
 __device__ __forceinline__ void dry_depo_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
                                               long long i, const Particle &P, Stencil &s) {
+  if (above_every_surface_layer(ctl, M, P))
+    return;
   SurfA c2;
   load_pair_2d32(M.sfa, M, s, c2);
   const double wt = time_weight(M, P.time);
@@ -632,12 +657,15 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
       apply_loss(ctl, a, i, aux, ctl.qnt_mloss_decay, 1. / tdec);
     }
     if (lean) {
-      if (tmask & (MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO)) {
+      // (particles above every cloud top / surface layer of the two snapshots need no stencil at all)
+      const bool wet = (tmask & MPHIP_MOD_WET_DEPO) && !above_every_cloud_top(M, P);
+      const bool dry = (tmask & MPHIP_MOD_DRY_DEPO) && !above_every_surface_layer(ctl, M, P);
+      if (wet || dry) {
         Stencil sd = stencil_zero();
         horiz_fast(M, A, P.lon, P.lat, sd);
-        if (tmask & MPHIP_MOD_WET_DEPO)
+        if (wet)
           wet_depo_fast(ctl, M, A, a, i, P, sd);
-        if (tmask & MPHIP_MOD_DRY_DEPO)
+        if (dry)
           dry_depo_fast(ctl, M, A, a, i, P, sd);
       }
     } else {
@@ -648,6 +676,77 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
     }
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_BOUND_COND2))
       bound_cond(ctl, M, A, a, i, P);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Deposition launch (module_wet_depo and / or module_dry_depo alone: what follows module_mixing in a time step).
+// Most particles leave these modules at once -- above every cloud top, above the surface layer -- but in the
+// stored orders every wave holds a few that do not, and a wave pays for a gather round whatever the number of
+// lanes that take part.  So a workgroup first sorts out which of its particles have anything to do (two
+// comparisons against the bounds of DevMet::pct_skip / ps_skip: only p, time and dt are read), packs their
+// numbers into a list in LDS, and then works through the list: full waves for the stencils, the gathers and the
+// pow / exp of the modules, none for the rest.  Same arithmetic per particle as
+// the fused kernel (wet_depo_fast, dry_depo_fast); lean configurations only (launch_step).
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void depo_kernel(const StepParams S) {
+  extern __shared__ double s_axes[];
+  __shared__ int s_count;
+  const DevMet &M = S.met;
+  const DevAtm &a = S.atm;
+  const mphip_ctl_t &ctl = S.ctl;
+  const Axes A = load_axes(M, s_axes);
+  // the list of the workgroup's busy particles behind the axes (per_block entries: launch_step sizes the LDS)
+  int *s_list = (int *) (s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8);
+  if (threadIdx.x == 0)
+    s_count = 0;
+  __syncthreads();
+  const unsigned tmask = S.mask;
+  const int nb = S.nblocks_logical;
+  const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
+  const long long first = (long long) lb * S.per_block;
+  long long last = first + S.per_block;
+  if (last > a.np)
+    last = a.np;
+  const int lane = threadIdx.x & 63;
+  // which particles have anything to do: p, time and dt only
+  for (long long i = first + threadIdx.x; i < first + S.per_block; i += 256) {   // (whole waves stay together)
+    bool busy = false;
+    if (i < last && a.dt[i] != 0) {   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
+      Particle P;
+      P.time = a.time[i];
+      P.p = a.p[i];
+      busy = ((tmask & MPHIP_MOD_WET_DEPO) && !above_every_cloud_top(M, P))
+        || ((tmask & MPHIP_MOD_DRY_DEPO) && !above_every_surface_layer(ctl, M, P));
+    }
+    const unsigned long long mine = __ballot(busy);
+    int at = 0;
+    if (lane == 0 && mine)
+      at = atomicAdd(&s_count, __builtin_popcountll(mine));
+    at = __builtin_amdgcn_readfirstlane(at);
+    if (busy)
+      s_list[at + __builtin_popcountll(mine & ((1ull << lane) - 1))] = (int) (i - first);
+  }
+  __syncthreads();
+  // ... and those, in full waves (the order inside the list does not matter: particles are independent)
+  const int total = s_count;
+  for (int t = threadIdx.x; t < total; t += 256) {
+    const long long ip = first + s_list[t];
+    Particle P;
+    P.time = a.time[ip];
+    P.lon = a.lon[ip];
+    P.lat = a.lat[ip];
+    P.p = a.p[ip];
+    P.dt = a.dt[ip];
+    const bool wet = (tmask & MPHIP_MOD_WET_DEPO) && !above_every_cloud_top(M, P);
+    const bool dry = (tmask & MPHIP_MOD_DRY_DEPO) && !above_every_surface_layer(ctl, M, P);
+    Stencil sd = stencil_zero();
+    horiz_fast(M, A, P.lon, P.lat, sd);
+    if (wet)
+      wet_depo_fast(ctl, M, A, a, ip, P, sd);
+    if (dry)
+      dry_depo_fast(ctl, M, A, a, ip, P, sd);
   }
 }
 

@@ -1215,6 +1215,31 @@ def test_sort_ahead_of_time_is_not_observable(sort_dt):
             assert np.array_equal(a, b)
 
 
+def test_deposition_launch_with_packed_waves_equals_the_fused_tail():
+    """The deposition modules behind module_mixing run in a kernel of their own that first packs the particles
+    with anything to do into full waves (option compact_depo, default on); with the option off they run as the
+    tail of the fused kernel -- the same bits, for the exponential-law and the Henry-law wet deposition, as single
+    modules and inside time steps."""
+    for case in ("full", "wet_henry"):
+        ctl, clim, m0, m1, atm = cases.make_case(case, n=20011)
+        ctl = dict(ctl, mixing_dt=180.0, mixing_trop=1e-3, mixing_strat=1e-6)
+        runs = []
+        for compact in (1, 0):
+            s = hip.Simulation(ctl, clim, m0, m1, atm)
+            s.set_option("compact_depo", compact)
+            s.timesteps_init(0.0, 0.0)
+            ts = cases.step_times(s.ctl)
+            for t in ts[:6]:
+                s.run_timestep(t)
+            s.module("wet_depo", ts[5])
+            s.module("dry_depo", ts[5])
+            runs.append(s.state())
+            s.close()
+        for k in ("time", "lon", "lat", "p", "q", "uvwp"):
+            assert np.array_equal(runs[0][k], runs[1][k]), (case, k)
+        assert np.abs(runs[0]["q"] - atm["q"]).max() > 0
+
+
 def test_long_run_400_steps_with_prefetched_handovers():
     """Drift check (was tools/gpu_soak.py): 2 x 10^4 particles, every module of the `full` case with
     module_meteo, module_sort every 10 and mixing every 5 steps, 400 time steps over 20 h, three meteo hand-overs
