@@ -294,6 +294,9 @@ int mphip_comm_destroy(mphip_ctx *ctx);
  *   13862-13872): same bits as the serial code, from run to run and for any storage order.  0 = floating-point
  *   atomics (order of arrival; faster when single cells hold very many particles);
  *   "sort_bits" (default 0 = the width with the fewest passes; 8, 9, 10): digit width of the radix sort;
+ *   "compact_depo" (default 1): a launch of module_wet_depo / module_dry_depo alone (what follows module_mixing in
+ *   a time step) first packs the particles with anything to do into full waves; 0 = tail of the fused kernel.
+ *   Not observable;
  *   "sort_ahead" (default 1): keys, module_timesteps and radix sort of the next time step's module_sort start on a
  *   second stream as soon as this step's particles have moved, beside module_mixing and the deposition modules;
  *   taken over by the next mphip_run_timestep if it comes with the expected time and nothing they depend on was
