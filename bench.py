@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--atomic-sums", action="store_true",
                     help="cell sums of module_mixing / the gridded output with floating-point atomics (option "
                          "deterministic_sums 0) instead of the reference's order")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="mphip_set_option(NAME, VALUE) before the run (tuning experiments)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="(diagnostic) do not bracket the step kernel with HIP events; roofline is then not reported")
     args = ap.parse_args()
@@ -250,6 +252,9 @@ def main():
         sim.set_option("lazy_meteo", 0)
     if args.atomic_sums:
         sim.set_option("deterministic_sums", 0)
+    for kv in args.option:
+        name, value = kv.split("=")
+        sim.set_option(name, float(value))
     sim.timesteps_init(0.0, 0.0)
     dt = sim.ctl.dt_mod
 
