@@ -687,7 +687,9 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
 // comparisons against the bounds of DevMet::pct_skip / ps_skip: only p, time and dt are read), packs their
 // numbers into a list in LDS, and then works through the list: full waves for the stencils, the gathers and the
 // pow / exp of the modules, none for the rest.  Same arithmetic per particle as
-// the fused kernel (wet_depo_fast, dry_depo_fast); lean configurations only (launch_step).
+// the fused kernel (wet_depo_fast, dry_depo_fast); lean configurations only (launch_step).  (module_mixing's
+// relaxation inside the first pass of this kernel was measured as well: 2.36 against 2.28 ms per step of C5 --
+// its dependent gathers delay the list and the barrier behind it.)
 // ---------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void depo_kernel(const StepParams S) {
