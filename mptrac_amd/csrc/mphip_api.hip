@@ -1356,7 +1356,7 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
       return 1;
     hipLaunchKernelGGL(cell_bounds_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, keys[cur], n, (uint32_t) ntot,
                        first, last);
-    const int width = nv < 64 ? nv : 64;
+    const int width = nv < 1 ? 1 : nv < 64 ? nv : 64;   // nv == 0: counts only (gridded output without quantities)
     const long long waves = ((long long) ntot + 64 / width - 1) / (64 / width);
     hipLaunchKernelGGL(cell_sum_chains_kernel<VALS>, dim3(grid_for(waves * 64)), dim3(256), 0, ctx->stream, vals,
                        slots[cur], first, last, ntot, sums, cnt, cnt_as_double);
@@ -2109,6 +2109,14 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
         return 1;
     if (dev_alloc(ctx, &ctx->d_cell, n))
       return 1;
+    // the buffers of the sort that runs ahead trade places with d_keys / d_vals / d_dt when a sort is adopted,
+    // so after that they have whatever size those had: one capacity cannot describe them -- start over
+    for (int k = 0; k < 2; k++)
+      if (dev_alloc(ctx, &ctx->ahead_keys[k], 0) || dev_alloc(ctx, &ctx->ahead_vals[k], 0))
+        return 1;
+    if (dev_alloc(ctx, &ctx->ahead_dt, 0))
+      return 1;
+    ctx->ahead_cap = 0;
     dev_free(ctx->d_iso);
     dev_free(ctx->d_iso_alt);
     ctx->d_iso = ctx->d_iso_alt = nullptr;

@@ -1820,7 +1820,7 @@ __global__ __launch_bounds__(256) void cell_sum_chains_kernel(VALS vals, const i
                                                               double *__restrict__ sums, int *__restrict__ cnt,
                                                               double *__restrict__ cnt_as_double) {
   const int nv = vals.count();
-  const int width = nv < 64 ? nv : 64;        // lanes per cell
+  const int width = nv < 1 ? 1 : nv < 64 ? nv : 64;   // lanes per cell (one for the counts when there are no values)
   const int per_wave = 64 / width;            // cells per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane / width, v0 = lane % width;

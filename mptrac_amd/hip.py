@@ -251,6 +251,15 @@ class Simulation:
         self._chk(self.L.mphip_update_atm(self.h, self.n, self.lo, self.n_total, self.nq,
                                           *[_ptr(a, _dp) for a in arrs], qp))
 
+    def replace_particles(self, atm):
+        """A new particle set (any count) in the same context: what a C caller does when it hands a different
+        atm_t to mptrac_update_device."""
+        self.atm_is_local = False
+        self.n_total = len(atm["time"])
+        self.lo, self.hi = 0, self.n_total
+        self.n = self.n_total
+        self.update_atm(atm)
+
     # -- mptrac_update_host ---------------------------------------------------
     def get_atm(self, out=None):
         """Particle arrays in the caller's order; `out` = a dict returned earlier, to download into the

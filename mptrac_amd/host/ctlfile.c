@@ -15,12 +15,16 @@
 
 #include <ctype.h>
 #include <strings.h>
+#include <sys/stat.h>
 
 /* ---- control file table ---------------------------------------------------- */
 
 /* "NAME <any token> VALUE" lines of one control file, in file order */
 static struct {
   char *path;       /* the file the table belongs to (NULL: none loaded) */
+  struct timespec mtime;   /* what the file looked like when it was parsed: a file rewritten under the */
+  off_t size;              /* same name (an ensemble driver, a test) is parsed again */
+  ino_t inode;
   char **name;
   char **value;
   size_t n, cap;
@@ -63,12 +67,18 @@ static void ctlfile_drop(void) {
 }
 
 static void ctlfile_load(const char *path) {
-  if (g_ctlfile.path && strcmp(g_ctlfile.path, path) == 0)
+  struct stat st;
+  const int have_stat = stat(path, &st) == 0;
+  if (g_ctlfile.path && strcmp(g_ctlfile.path, path) == 0 && have_stat && st.st_size == g_ctlfile.size
+      && st.st_ino == g_ctlfile.inode && st.st_mtim.tv_sec == g_ctlfile.mtime.tv_sec
+      && st.st_mtim.tv_nsec == g_ctlfile.mtime.tv_nsec)
     return;
   ctlfile_drop();
   FILE *in = fopen(path, "r");
   if (!in)
     ERRMSG("Cannot open file!");
+  if (fstat(fileno(in), &st) != 0)
+    memset(&st, 0, sizeof(st));
   char line[LEN];
   while (fgets(line, LEN, in)) {
     /* a setting needs three tokens: the name, a separator (conventionally "="), the value */
@@ -89,6 +99,15 @@ static void ctlfile_load(const char *path) {
   }
   fclose(in);
   g_ctlfile.path = dup_token(path, strlen(path));
+  g_ctlfile.mtime = st.st_mtim;
+  g_ctlfile.size = st.st_size;
+  g_ctlfile.inode = st.st_ino;
+}
+
+/* Forget the parsed control file: the next look-up reads the file again.  mptrac_read_ctl starts with this, so
+ * that every call sees the file as it is now (the reference re-reads it for every key). */
+void ctlfile_invalidate(void) {
+  ctlfile_drop();
 }
 
 /* Value of a control parameter (reference interface: src/mptrac.h scan_ctl).

@@ -35,6 +35,7 @@ static struct {
   char filename[LEN];
 } g_ahead;
 static long long g_ip0, g_np_total = -1; /* index range of this rank's particles (mptrac_amd_shard); -1: all of them */
+static double g_release_first, g_release_last; /* release times of the whole run, taken before the shard was cut */
 static int g_rank, g_world = 1;
 static int g_nq;                        /* ctl->nq of the last control upload */
 static int g_isosurf;                   /* ctl->isosurf of the last control upload */
@@ -83,6 +84,8 @@ void mptrac_free(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t *met0, met_t *m
   free(g_ahead.met);
   g_ahead.met = NULL;
   g_met_host[0] = g_met_host[1] = NULL;
+  g_ip0 = 0;   /* the next run of this process is cut (or not) by its own mptrac_amd_shard */
+  g_np_total = -1;
   free(ctl);
   free(cache);
   free(clim);
@@ -219,6 +222,7 @@ static const char *unsupported_qnt[] = {
 
 void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   LOG(1, "\nMassive-Parallel Trajectory Calculations (MPTRAC), MI355X build (%s)\n", mphip_version());
+  ctlfile_invalidate();   /* read the control file as it is now, not as an earlier call found it */
 
   /* quantities, mptrac.c:6737-6971 */
   ctl->qnt_m = ctl->qnt_vmr = ctl->qnt_rp = ctl->qnt_rhop = ctl->qnt_ens = ctl->qnt_loss_rate = -1;
@@ -1232,12 +1236,24 @@ void mptrac_update_host(const ctl_t *ctl, const cache_t *cache, const clim_t *cl
 /* Start and stop time of a run (reference interface: src/mptrac.h module_timesteps_init): the run starts at
  * the first release time in the direction of travel, rounded outwards to the DT_MOD raster, and -- unless
  * T_STOP was given -- ends at the last one. */
-void module_timesteps_init(ctl_t *ctl, const atm_t *atm) {
-  double first = atm->time[0], last = atm->time[0];
+static void release_time_range(const atm_t *atm, double *first, double *last) {
+  *first = *last = atm->time[0];
   for (int ip = 1; ip < atm->np; ip++) {
-    first = fmin(first, atm->time[ip]);
-    last = fmax(last, atm->time[ip]);
+    *first = fmin(*first, atm->time[ip]);
+    *last = fmax(*last, atm->time[ip]);
   }
+}
+
+void module_timesteps_init(ctl_t *ctl, const atm_t *atm) {
+  double first, last;
+  if (g_np_total >= 0) {
+    /* one of N processes: every rank must step through the same model times (the all-reduces of
+     * module_mixing and of the gridded output pair up step by step), so the range is the one of the whole
+     * particle file, not of this rank's index range -- which may even be empty */
+    first = g_release_first;
+    last = g_release_last;
+  } else
+    release_time_range(atm, &first, &last);
   const int forward = ctl->direction == 1;
   const double begin = forward ? first : last, end = forward ? last : first;
   if (ctl->t_stop > 1e99)   /* not set in the control file */
@@ -1563,6 +1579,9 @@ void mptrac_amd_shard(atm_t *atm, const mptrac_amd_job_t *job) {
   g_world = job->world;
   if (job->world <= 1)
     return;
+  if (atm->np <= 0)
+    ERRMSG("Need at least one particle!");
+  release_time_range(atm, &g_release_first, &g_release_last);
   const long long n = atm->np, lo = n * job->rank / job->world, hi = n * (job->rank + 1) / job->world;
   const size_t bytes = (size_t) (hi - lo) * sizeof(double);
   memmove(atm->time, atm->time + lo, bytes);

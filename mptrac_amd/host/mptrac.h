@@ -251,6 +251,7 @@ void mptrac_write_output(const char *dirname, const ctl_t *ctl, met_t *met0, met
 /* utilities of the reference that the driver and tools use */
 double scan_ctl(const char *filename, int argc, char *argv[], const char *varname, const int arridx,
                 const char *defvalue, char *value);                             /* mptrac.c:12434 */
+void ctlfile_invalidate(void);   /* forget the parsed control file (scan_ctl reads it again) */
 void jsec2time(const double jsec, int *year, int *mon, int *day, int *hour, int *min, int *sec,
                double *remain);                                                 /* mptrac.c:3265 */
 void time2jsec(const int year, const int mon, const int day, const int hour, const int min,

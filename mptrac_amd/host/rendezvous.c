@@ -12,7 +12,9 @@
 
 #include <arpa/inet.h>
 #include <errno.h>
+#include <netdb.h>
 #include <netinet/in.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <time.h>
 #include <unistd.h>
@@ -39,28 +41,67 @@ static int recv_all(int fd, char *p, size_t n) {
   return 1;
 }
 
-/* rank 0 sends buf[0 .. n) to each of the world - 1 other ranks; they receive it.  1 = ok. */
+/* MASTER_ADDR may be a dotted address or a host name ("localhost", the node's name as a launcher exports it) */
+static int resolve_ipv4(const char *addr, int port, struct sockaddr_in *sa) {
+  memset(sa, 0, sizeof(*sa));
+  sa->sin_family = AF_INET;
+  sa->sin_port = htons((unsigned short) port);
+  if (inet_pton(AF_INET, addr, &sa->sin_addr) == 1)
+    return 1;
+  struct addrinfo hints, *res = NULL;
+  memset(&hints, 0, sizeof(hints));
+  hints.ai_family = AF_INET;
+  hints.ai_socktype = SOCK_STREAM;
+  if (getaddrinfo(addr, NULL, &hints, &res) != 0 || !res)
+    return 0;
+  sa->sin_addr = ((struct sockaddr_in *) res->ai_addr)->sin_addr;
+  freeaddrinfo(res);
+  return 1;
+}
+
+/* seconds rank 0 waits for all peers, and a peer for rank 0 (MPTRAC_RENDEZVOUS_TIMEOUT, default 120) */
+static int rendezvous_timeout(void) {
+  const char *e = getenv("MPTRAC_RENDEZVOUS_TIMEOUT");
+  const int s = e ? atoi(e) : 0;
+  return s > 0 ? s : 120;
+}
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+/* rank 0 sends buf[0 .. n) to each of the world - 1 other ranks; they receive it.  1 = ok, 0 = failed or timed
+ * out (a peer that died before it connected must not leave rank 0 waiting for ever). */
 int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr, int port) {
   if (world <= 1)
     return 1;
-  struct sockaddr_in sa;
-  memset(&sa, 0, sizeof(sa));
-  sa.sin_family = AF_INET;
-  sa.sin_port = htons((unsigned short) port);
-  if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1)
-    return 0;
+  const double deadline = now_s() + rendezvous_timeout();
   if (rank == 0) {
+    /* listen on every interface: the peers reach this process through whatever MASTER_ADDR resolves to for them */
+    struct sockaddr_in any;
+    memset(&any, 0, sizeof(any));
+    any.sin_family = AF_INET;
+    any.sin_port = htons((unsigned short) port);
+    any.sin_addr.s_addr = htonl(INADDR_ANY);
     const int ls = socket(AF_INET, SOCK_STREAM, 0);
     int one = 1;
     if (ls < 0)
       return 0;
     setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-    if (bind(ls, (struct sockaddr *) &sa, sizeof(sa)) != 0 || listen(ls, world) != 0) {
+    if (bind(ls, (struct sockaddr *) &any, sizeof(any)) != 0 || listen(ls, world) != 0) {
       close(ls);
       return 0;
     }
     int ok = 1;
     for (int k = 1; k < world && ok; k++) {
+      struct pollfd pfd = { ls, POLLIN, 0 };
+      const double left = deadline - now_s();
+      if (left <= 0 || poll(&pfd, 1, (int) (left * 1000.0) + 1) <= 0) {
+        ok = 0;
+        break;
+      }
       const int fd = accept(ls, NULL, NULL);
       ok = fd >= 0 && send_all(fd, buf, n);
       if (fd >= 0)
@@ -69,12 +110,17 @@ int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr,
     close(ls);
     return ok;
   }
+  struct sockaddr_in sa;
+  if (!resolve_ipv4(addr, port, &sa))
+    return 0;
   /* the other ranks: rank 0 may not listen yet */
-  for (int attempt = 0; attempt < 600; attempt++) {
+  while (now_s() < deadline) {
     const int fd = socket(AF_INET, SOCK_STREAM, 0);
     if (fd < 0)
       return 0;
     if (connect(fd, (struct sockaddr *) &sa, sizeof(sa)) == 0) {
+      struct timeval tv = { rendezvous_timeout(), 0 };
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
       const int ok = recv_all(fd, buf, n);
       close(fd);
       return ok;

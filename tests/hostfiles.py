@@ -65,3 +65,20 @@ def write_ctl(path, keys):
     with open(path, "w") as f:
         for k, v in keys.items():
             f.write(f"{k} = {v}\n")
+
+
+def compile_c_test(name):
+    """gcc tests/c/<name>.c against the host layer's header and library -> path of the program."""
+    import subprocess
+    from mptrac_amd import build
+    lib, _ = build.build_host()
+    here = os.path.dirname(os.path.abspath(__file__))
+    out_dir = os.path.join(here, "c", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    src, exe = os.path.join(here, "c", name + ".c"), os.path.join(out_dir, name)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+        defs = [f"-D{k}={v}" for k, v in build.HOST_DIMS.items()]
+        subprocess.check_call(["gcc", "-O1", "-std=gnu99", "-Wall", "-mcmodel=medium", *defs, "-I", build.HOST_DIR,
+                               "-o", exe, src, "-L" + build.LIBDIR, "-lmptrac", "-lmptrac_hip",
+                               "-Wl,-rpath," + build.LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    return exe

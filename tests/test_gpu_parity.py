@@ -478,6 +478,56 @@ def test_ordered_grid_sums_on_odd_grids(shape, order, path):
     s.close()
 
 
+@pytest.mark.parametrize("path", [0, 1, 2], ids=["auto", "groups", "chains"])
+@pytest.mark.parametrize("shape", [(4, 2, 1), (36, 18, 5)], ids=["crowded", "sparse"])
+def test_gridded_counts_without_quantities(shape, path):
+    """NQ = 0: the gridded output is the particle count per cell alone (the reference's write_grid supports
+    it, mptrac.c:13815-13872) -- through every algorithm of the ordered sums, which size their work by the
+    number of values per cell (none here)."""
+    ctl, clim, m0, m1, atm = cases.make_case("advect", n=30011, quantities=())
+    nx, ny, nz = shape
+    ctl = dict(ctl, grid_nx=nx, grid_ny=ny, grid_nz=nz, grid_z0=0.0, grid_z1=30.0)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    assert s.nq == 0
+    s.set_option("sum_path", path)
+    s.timesteps_init(0.0, 0.0)
+    ts = cases.step_times(s.ctl)
+    for t in ts[:3]:
+        s.run_timestep(t)
+    _oracle_takes_device_state(o, s)
+    co = o.grid_sums(ts[2])[0]
+    cs = s.grid_sums(ts[2])[0]
+    assert co.sum() > 20000 and np.array_equal(co, cs)
+    s.close()
+
+
+def test_context_reused_with_other_particle_counts():
+    """One context, particle sets of 3000 -> 1500 -> 3000 -> 4500 particles with module_sort (and its sort that
+    runs ahead, whose buffers trade places with the context's when a prepared sort is adopted) every step: every
+    phase gives the bits of a fresh context started from the same inputs and random-number counter."""
+    ctl, clim, m0, m1, _ = cases.make_case("full", n=10)
+    ctl = dict(ctl, sort_dt=180.0, mixing_dt=180.0)
+    sets = [cases.make_case("full", n=n, seed=100 + n)[4] for n in (3000, 1500, 3000, 4500)]
+    s = hip.Simulation(ctl, clim, m0, m1, sets[0])
+    s.timesteps_init(0.0, 0.0)
+    ts = cases.step_times(s.ctl)
+    for k, atm in enumerate(sets):
+        if k:
+            s.replace_particles(atm)
+        ctr = s.get_cache()["rng_ctr"]
+        f = hip.Simulation(ctl, clim, m0, m1, atm, rng_ctr=ctr)
+        f.timesteps_init(0.0, 0.0)
+        for t in ts[:6]:
+            s.run_timestep(t)
+            f.run_timestep(t)
+        a, b = s.state(), f.state()
+        for key in ("time", "lon", "lat", "p", "q", "uvwp"):
+            assert np.array_equal(a[key], b[key]), (k, key)
+        f.close()
+    s.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8193])
 def test_ordered_sums_at_tile_and_wave_boundaries(n):
     """Particle counts around the wave (64) and tile (4096) sizes of the run compaction and of the sort, in both

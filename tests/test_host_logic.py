@@ -279,6 +279,39 @@ print(json.dumps({"rank": job.rank, "world": job.world, "local": job.local_rank,
     assert (d["rank"], d["world"], d["np"], d["addr"]) == (0, 1, 1003, "127.0.0.1")
 
 
+def test_sharded_run_steps_through_the_times_of_the_whole_particle_file():
+    """Ranks of one run must agree on t_start / t_stop (their all-reduces pair up step by step): with release
+    times that grow along the file -- the usual emission file -- every rank's module_timesteps_init gives the
+    range of the WHOLE file, not of its own index range; a rank whose range is empty (more ranks than particles)
+    gets it too.  (tests/c/shard_times.c)"""
+    from hostfiles import compile_c_test
+    exe = compile_c_test("shard_times")
+    for n, world in ((10, 4), (2, 4), (7, 1)):
+        seen = []
+        for rank in range(world):
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+            if world > 1:
+                env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+            out = subprocess.run([exe, str(n), "DT_MOD", "180"], env=env, capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+            line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+            seen.append((int(line[1]), float(line[2]), float(line[3])))
+        assert sum(d[0] for d in seen) == n
+        assert all(d[1:] == (900.0, 1000.0 + 900.0 * (n - 1)) for d in seen), seen
+        if n < world:
+            assert any(d[0] == 0 for d in seen)
+
+
+def test_control_file_is_read_again_by_every_read_ctl(tmp_path):
+    """The parsed control file is cached per path between look-ups, but mptrac_read_ctl always sees the file as
+    it is now (the reference re-reads it for every key): an ensemble driver may rewrite the file in place --
+    same name, same length, possibly the same time stamp.  (tests/c/reread_ctl.c)"""
+    from hostfiles import compile_c_test
+    exe = compile_c_test("reread_ctl")
+    out = subprocess.run([exe, str(tmp_path / "trac.ctl")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "RESULT ok" in out.stdout, out.stdout[-2000:]
+
+
 def test_control_file_lookup_rules(tmp_path):
     """scan_ctl: "NAME = VALUE" lines, first match wins, case-insensitive, NAME[i] / NAME[*], command-line pairs
     override the file, '-' means arguments only, defaults for missing keys."""
@@ -398,8 +431,34 @@ def test_rank_rendezvous_hands_the_identifier_to_every_rank():
               "buf = C.create_string_buffer(bytes((7 * i + 1) %% 256 for i in range(128)) if rank == 0 else bytes(128), 128)\n"
               "assert L.mptrac_amd_bcast(buf, 128, rank, world, b'127.0.0.1', port) == 1\n"
               "assert buf.raw == bytes((7 * i + 1) %% 256 for i in range(128)), rank\nprint('ok', rank)\n") % (lib, port)
-    procs = [subprocess.Popen([sys.executable, "-c", worker, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-             for r in range(4)]
-    for r, p in enumerate(procs):
-        out = p.communicate(timeout=120)[0].decode()
-        assert p.returncode == 0 and "ok %d" % r in out, out
+    for addr in ("127.0.0.1", "localhost"):       # a launcher may export a host name
+        w = worker.replace("b'127.0.0.1'", "b%r" % addr)
+        procs = [subprocess.Popen([sys.executable, "-c", w, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                 for r in range(4)]
+        for r, p in enumerate(procs):
+            out = p.communicate(timeout=120)[0].decode()
+            assert p.returncode == 0 and "ok %d" % r in out, out
+
+
+def test_rank_rendezvous_gives_up_when_a_peer_never_comes():
+    """Rank 0 waits for its peers for MPTRAC_RENDEZVOUS_TIMEOUT seconds, not for ever; so does a peer whose
+    rank 0 never listens; a name that does not resolve fails at once."""
+    import ctypes as C
+    import socket
+    import time
+    L = _host_lib()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MPTRAC_RENDEZVOUS_TIMEOUT"] = "1"
+    try:
+        buf = C.create_string_buffer(128)
+        for rank in (0, 1):
+            t0 = time.time()
+            assert L.mptrac_amd_bcast(buf, 128, rank, 2, b"127.0.0.1", port) == 0
+            assert 0.9 < time.time() - t0 < 10.0
+        t0 = time.time()
+        assert L.mptrac_amd_bcast(buf, 128, 1, 2, b"no-such-host.invalid", port) == 0
+        assert time.time() - t0 < 10.0
+    finally:
+        del os.environ["MPTRAC_RENDEZVOUS_TIMEOUT"]
