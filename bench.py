@@ -189,6 +189,12 @@ def main():
                          "deterministic_sums 0) instead of the reference's order")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="mphip_set_option(NAME, VALUE) before the run (tuning experiments)")
+    ap.add_argument("--device-warmup-ms", type=float, default=120.0,
+                    help="keep the GPU under the step kernel's load for this long right before the timed region (on a "
+                         "scratch copy of the workload; 0 = off).  An MI355X that comes from idle runs the step kernel "
+                         "10-25 %% slower for its first ~30 ms under load (power management: 0.99 -> 1.13 -> 0.88 ms, "
+                         "profiles/r03_clock_ramp.txt); a production run is thousands of steps long, so the timed "
+                         "steps are taken at the settled clocks")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="(diagnostic) do not bracket the step kernel with HIP events; roofline is then not reported")
     args = ap.parse_args()
@@ -220,6 +226,19 @@ def main():
     ctl, clim, met0, met1, atm, n_local, n_total = build_inputs(args.workload, rank, world, steps_total, particles=args.particles)
     sim = hip.Simulation(ctl, clim, met0, met1, atm, device=local_rank,
                          shard=(rank * n_local, (rank + 1) * n_local), n_total=n_total)
+    # a second, throw-away copy of the workload: its time steps bring the device to its settled clocks without
+    # touching the particles that are timed (at most 4e7 particles: the effect is one of short launches)
+    scratch = None
+    if args.device_warmup_ms > 0:
+        n_scr = min(n_local, 4 * 10 ** 7)
+        scr_atm = {k: (v[:n_scr] if k != "q" else v[:, :n_scr]) for k, v in atm.items()}
+        # (its own, long meteo interval -- the same arrays under a later time stamp -- so that it can take as many
+        # steps as the warm-up needs)
+        scr_span = 3600.0 * 24
+        scr_met1 = type(met1)(scr_span, met1.lon, met1.lat, met1.p, met1.f3, met1.f2)
+        scratch = hip.Simulation(dict(ctl, dt_met=scr_span, t_stop=scr_span), clim, met0, scr_met1, scr_atm,
+                                 device=local_rank, shard=(0, n_scr), n_total=n_scr)
+        scr_steps = int(scr_span / ctl["dt_mod"]) - 1
     reduction = "none (one rank)"
     if use_dist and args.torch_allreduce:
         from mptrac_amd import dist as mdist
@@ -272,6 +291,22 @@ def main():
         sim.run_timestep(k * dt)
         k += 1
     sim.grid_sums(k * dt)           # warm the reduction path (RCCL communicator set-up)
+    if scratch is not None:
+        # the launches of the scratch copy queue up without host synchronisation; the timed region starts
+        # behind them with no idle gap
+        scratch.timesteps_init(0.0, 0.0)
+        scratch.run_timestep(0.0)
+        scratch.run_timestep(dt)    # (first step: sort into the locality order)
+        scratch.synchronize()
+        t_w = time.perf_counter()
+        j = 2
+        while (time.perf_counter() - t_w) * 1e3 < args.device_warmup_ms and j < scr_steps:
+            for _ in range(8):
+                if j < scr_steps:
+                    scratch.run_timestep(j * dt)
+                    j += 1
+            scratch.synchronize()
+        warm_steps, warm_ms = j - 2, (time.perf_counter() - t_w) * 1e3
     barrier()
 
     if not args.no_kernel_events:
@@ -336,7 +371,9 @@ def main():
                        **({"particles_override": True} if args.particles else {}),
                        "grid": [met0.nx, met0.ny, met0.np], "dt_mod": dt,
                        "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce",
-                       "reduction": reduction},
+                       "reduction": reduction,
+                       "device_warmup": (f"{warm_steps} untimed steps of a scratch copy ({warm_ms:.0f} ms) before "
+                                         "the timed region: settled clocks" if scratch is not None else "none")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "step_kernel (fused time step)", "kernel_ms": kernel_ms_per_launch,
@@ -352,6 +389,8 @@ def main():
         print(json.dumps(out), flush=True)
 
     sim.close()
+    if scratch is not None:
+        scratch.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

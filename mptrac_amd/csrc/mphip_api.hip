@@ -1403,7 +1403,7 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
                      keys[cur], ids[cur], nruns_dev, (uint32_t) ngroups, run_start, SEQ, SLOT, ctx->d_ext, overflow, G, \
                      ntot, sums, cnt, cnt_as_double)
 #define GROUPS_BY_WIDTH(BYINDEX, SEQ, SLOT)                                                                            \
-  if (nv == 1) {   /* values per pass: as many as there are, up to four */                                             \
+  if (nv <= 1) {   /* values per pass: as many as there are, up to four */                                             \
     GROUPS(1, BYINDEX, SEQ, SLOT);                                                                                     \
   } else if (nv == 2) {                                                                                                \
     GROUPS(2, BYINDEX, SEQ, SLOT);                                                                                     \

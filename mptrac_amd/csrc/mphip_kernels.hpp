@@ -373,6 +373,29 @@ __device__ __forceinline__ void dry_depo_fast(const mphip_ctl_t &ctl, const DevM
 #define MPHIP_RNG_EARLY 0
 #endif
 
+// Particle state is streamed: every array element is read once and written once per launch, while the lines of
+// the meteo records are shared by neighbouring waves.  MPHIP_STATE_NT 1 marks the state accesses of the step
+// kernel non-temporal, so that they do not push meteo lines out of the L2.
+#ifndef MPHIP_STATE_NT
+#define MPHIP_STATE_NT 0
+#endif
+template <class T>
+__device__ __forceinline__ T ld_state(const T *p) {
+#if MPHIP_STATE_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void st_state(T *p, T v) {
+#if MPHIP_STATE_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // keeps a value where it was computed (the optimiser would sink the whole chain to its first use)
 __device__ __forceinline__ void pin(double &x) {
   asm volatile("" : "+v"(x));
@@ -501,10 +524,10 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
       P.lat = a.s_lat[src];
       P.p = a.s_p[src];
     } else {
-      P.time = a.time[i];
-      P.lon = a.lon[i];
-      P.lat = a.lat[i];
-      P.p = a.p[i];
+      P.time = ld_state(&a.time[i]);
+      P.lon = ld_state(&a.lon[i]);
+      P.lat = ld_state(&a.lat[i]);
+      P.p = ld_state(&a.p[i]);
     }
     if (CT == kMaskGeneric && (mask & (MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT))) {   // no dt guard (check_dt = 0)
       P.dt = 0;
@@ -538,7 +561,7 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
       continue;
     }
     // random numbers belong to the external slot (rs[3 * ip + k], mptrac.c:4645)
-    const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) a.ext[i] : i));
+    const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) ld_state(&a.ext[i]) : i));
 
     // specialised instantiations = RK4 on pressure levels (launch_step): 4 stages, all hooks run
     constexpr bool early = MPHIP_RNG_EARLY && !kRuntimeMask<CT> && (CT & MPHIP_MOD_ADVECT);
@@ -603,22 +626,22 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
       a.wp[i] = wp;
     }
     if (mask & MPHIP_MOD_DIFF_MESO) {
-      float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
+      float up = ld_state(&a.up[i]), vp = ld_state(&a.vp[i]), wp = ld_state(&a.wp[i]);
       if (CT == kMaskGenericML)
         wind_cache_reset(wc, true);
       if (lean)
         diff_meso_fast(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc, ltab);
       else
         diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc, ltab);
-      a.up[i] = up;
-      a.vp[i] = vp;
-      a.wp[i] = wp;
+      st_state(&a.up[i], up);
+      st_state(&a.vp[i], vp);
+      st_state(&a.wp[i], wp);
     }
     if (lean) {
       if (mask & (MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI)) {
         const bool sedi_on = (mask & MPHIP_MOD_SEDI) != 0;
         conv_sedi_fast(ctl, M, A, P, mask, S.ctr_conv, g, early ? &pre.conv : nullptr,
-                       sedi_on ? a.q[ctl.qnt_rp][i] : 0.0, sedi_on ? a.q[ctl.qnt_rhop][i] : 0.0);
+                       sedi_on ? ld_state(&a.q[ctl.qnt_rp][i]) : 0.0, sedi_on ? ld_state(&a.q[ctl.qnt_rhop][i]) : 0.0);
       }
     } else {
       if (mask & MPHIP_MOD_CONVECTION)
@@ -636,11 +659,11 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
     }
 
     if ((mask & MPHIP_MOD_ADVECT) || fused_sort)
-      a.time[i] = P.time;
+      st_state(&a.time[i], P.time);
     if ((mask & kMovers) || fused_sort) {
-      a.lon[i] = P.lon;
-      a.lat[i] = P.lat;
-      a.p[i] = P.p;
+      st_state(&a.lon[i], P.lon);
+      st_state(&a.lat[i], P.lat);
+      st_state(&a.p[i], P.p);
     }
 
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_BOUND_COND))
@@ -1703,7 +1726,7 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
           s_sort[wave][t] = ~0ull;
         wave_sort(s_sort[wave], m, lane);
       }
-      for (int v0 = 0; v0 < nv; v0 += B) {
+      for (int v0 = 0; v0 < (nv > 0 ? nv : 1); v0 += B) {   // (no values: one pass for the counts)
         for (int sl = lane; sl < G; sl += 64) {
 #pragma unroll
           for (int b = 0; b < B; b++)
