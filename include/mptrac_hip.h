@@ -212,6 +212,10 @@ int mphip_discard_prefetch(mphip_ctx *ctx);
 int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_total, int nq,
                      const double *time, const double *p, const double *lon, const double *lat,
                      const double *const *q);
+/* One quantity array of the particles, in the caller's order: for a host-side writer that changes a single
+ * quantity of the model state (write_station sets the station flag, mptrac.c:15143-15145 -- on the reference's
+ * CPU path that is the state the next time step sees). */
+int mphip_update_quantity(mphip_ctx *ctx, int iq, const double *q);
 /* mptrac_update_host(..., atm), mptrac.c:8105-8110 */
 int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *lat,
                   double *const *q);

@@ -72,7 +72,7 @@ HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(LIBDIR, "libmptrac.so")
 TRAC_BIN = os.path.join(LIBDIR, "trac")
 # small test extents by default; production builds pass the reference's -DNP=... -DEX=... values
-HOST_DIMS = {"NP": 200000, "NQ": 12, "EX": 364, "EY": 186, "EP": 64}
+HOST_DIMS = {"NP": 200000, "NQ": 15, "EX": 364, "EY": 186, "EP": 64}
 
 
 def build_host(force=False, verbose=False, dims=None):
@@ -81,8 +81,8 @@ def build_host(force=False, verbose=False, dims=None):
     os.makedirs(LIBDIR, exist_ok=True)
     dims = dict(HOST_DIMS, **(dims or {}))
     src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "mptrac.h", "trac.c", "ctlfile.c", "nc_classic.c",
-                                               "nc_classic.h", "rendezvous.c")]
-    lib_src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "ctlfile.c", "nc_classic.c", "rendezvous.c")]
+                                               "nc_classic.h", "rendezvous.c", "output.c")]
+    lib_src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "ctlfile.c", "nc_classic.c", "rendezvous.c", "output.c")]
     if not (force or _stale(HOST_LIB, src) or _stale(TRAC_BIN, src)):
         return HOST_LIB, TRAC_BIN
     defs = [f"-D{k}={v}" for k, v in dims.items()]

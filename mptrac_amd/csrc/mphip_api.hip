@@ -132,6 +132,7 @@ struct mphip_ctx {
   int *d_ext = nullptr, *d_ext_alt = nullptr;
   bool ext_identity = true;
   int locality_interval = 60;         // re-sort every this many steps (0 = keep the caller's order)
+  bool locality_zorder = false;       // tiles of the locality key numbered along a Z-order curve instead of row by row
   int locality_tile = 0;              // horizontal tile edge of the locality key (columns); 0 = 4, or 8 with model-level winds
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;
@@ -983,11 +984,30 @@ int bits_for(unsigned long long kmax) {   // number of key bits that can be non-
 
 // module_sort keys + sort of (key, index); returns the buffer holding the result
 // largest sort key + 1 of the (tiled) cell order; 0 = does not fit 32 bits
+int bits_of(unsigned long long v) {   // bits needed for the numbers 0 ... v
+  int b = 0;
+  while (v >> b)
+    b++;
+  return b;
+}
+
+// tiles of the locality key in Z-order: number of interleaved bit pairs (-1: row-major tile numbers)
+int tile_zbits(const mphip_ctx *ctx, int tile) {
+  if (tile <= 0 || !ctx->locality_zorder)
+    return -1;
+  const unsigned long long ntx = (ctx->nx + tile - 1) / tile, nty = (ctx->ny + tile - 1) / tile;
+  return std::min(bits_of(ntx - 1), bits_of(nty - 1));
+}
+
 unsigned long long sort_key_range(const mphip_ctx *ctx, int tile) {
   unsigned long long kmax = (unsigned long long) ctx->nx * ctx->ny * ctx->npl;
   if (tile > 0) {
     const unsigned long long ntx = (ctx->nx + tile - 1) / tile, nty = (ctx->ny + tile - 1) / tile;
-    kmax = ntx * nty * ctx->npl * tile * tile;
+    unsigned long long ntiles = ntx * nty;
+    const int m = tile_zbits(ctx, tile);
+    if (m >= 0)   // upper bound: every pattern of the interleaved bits under the largest value of the bits on top
+      ntiles = ((std::max(ntx - 1, nty - 1) >> m) + 1) << (2 * m);
+    kmax = ntiles * ctx->npl * tile * tile;
   }
   return kmax > 0xffffffffULL ? 0 : kmax;
 }
@@ -1002,7 +1022,7 @@ int sort_keys(mphip_ctx *ctx, int tile, const double *timestep_t, const BoxArgs 
   BoxArgs none;
   memset(&none, 0, sizeof(none));
   hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(ctx->np)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
-                     ctx->d_keys[0], (int *) nullptr, ts, timestep_t ? ctx->d_dt : nullptr, box ? *box : none);
+                     tile_zbits(ctx, tile), ctx->d_keys[0], (int *) nullptr, ts, timestep_t ? ctx->d_dt : nullptr, box ? *box : none);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2152,6 +2172,29 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
   return 0;
 }
 
+int mphip_update_quantity(mphip_ctx *ctx, int iq, const double *q) {
+  if (!ctx || !q)
+    return fail(ctx, "null argument");
+  if (iq < 0 || iq >= ctx->nq)
+    return fail(ctx, "no such quantity");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (flush_meteo(ctx))   // (a pending module_meteo may be about to write this array)
+    return 1;
+  if (ctx->np == 0)
+    return 0;
+  const size_t bytes = (size_t) ctx->np * sizeof(double);
+  if (ctx->ext_identity) {
+    HIPCHK(hipMemcpyAsync(ctx->d_arr[4 + iq], q, bytes, hipMemcpyHostToDevice, ctx->stream));
+  } else {   // through the alternate buffer (free between two sorts), then into the stored order
+    HIPCHK(hipMemcpyAsync(ctx->d_alt[4 + iq], q, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(gather_by_ext_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, ctx->d_alt[4 + iq],
+                       ctx->d_ext, ctx->d_arr[4 + iq], ctx->np);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *lat, double *const *q) {
   if (!ctx)
     return 1;
@@ -2635,6 +2678,11 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (!(value == 0 || value == 1))
       return fail(ctx, "deterministic_sums must be 0 or 1");
     ctx->deterministic_sums = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "locality_zorder") == 0) {
+    ctx->locality_zorder = value != 0;
+    ctx->steps_since_resort = 1 << 30;
     return 0;
   }
   if (strcmp(name, "locality_tile") == 0) {

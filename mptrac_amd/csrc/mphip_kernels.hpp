@@ -937,7 +937,17 @@ struct BoxArgs {
   int ngrid;
 };
 
-__global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, uint32_t *__restrict__ keys,
+// Z-order number of tile (tx, ty): the low `m` bits of both interleaved (x above y), what is left of the longer
+// coordinate on top.  Tiles that are neighbours in either direction are then close in the stored order, so
+// the columns two tiles share are still in the L2 when the second one needs them.
+__host__ __device__ __forceinline__ uint32_t tile_z_order(uint32_t tx, uint32_t ty, int m) {
+  uint32_t z = 0;
+  for (int b = 0; b < m; b++)
+    z |= ((ty >> b) & 1u) << (2 * b) | ((tx >> b) & 1u) << (2 * b + 1);
+  return z | ((tx >> m) | (ty >> m)) << (2 * m);   // (only one of the two has bits left)
+}
+
+__global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, int zbits, uint32_t *__restrict__ keys,
                                 int *__restrict__ idx, const TimestepArgs ts, double *__restrict__ dt_out,
                                 const BoxArgs box) {
   const int wrapped = tile > 0;
@@ -971,9 +981,11 @@ __global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, uint32_t *__restri
     const int iz = locate_p(M, A, a.p[i]);
     if (tile == 0)
       keys[i] = (uint32_t) ((ix * M.ny + iy) * M.np + iz);
-    else
-      keys[i] = (uint32_t) ((((ix / tile) * nty + iy / tile) * M.np + iz) * (tile * tile)
-                            + (ix % tile) * tile + iy % tile);
+    else {
+      const uint32_t t = zbits >= 0 ? tile_z_order((uint32_t) (ix / tile), (uint32_t) (iy / tile), zbits)
+                                    : (uint32_t) ((ix / tile) * nty + iy / tile);
+      keys[i] = (uint32_t) ((t * M.np + iz) * (tile * tile) + (ix % tile) * tile + iy % tile);
+    }
     if (idx)
       idx[i] = (int) i;
   }
@@ -1263,6 +1275,13 @@ __global__ void perm_scatter_kernel(PermArgs g, const int *__restrict__ ext, lon
     for (int a = 0; a < g.n4; a++)
       g.out4[a][dst] = g.in4[a][i];
   }
+}
+
+// out[i] = in[ext[i]]: one array handed over in the caller's order into the stored order
+__global__ void gather_by_ext_kernel(const double *__restrict__ in, const int *__restrict__ ext, double *__restrict__ out,
+                                     long long n) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+    out[i] = in[ext[i]];
 }
 
 __global__ void keys_to_double_kernel(const uint32_t *__restrict__ k, double *__restrict__ out, long long n) {

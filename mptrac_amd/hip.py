@@ -92,6 +92,7 @@ def load(build=True):
     L.mphip_update_atm.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int,
                                    _dp, _dp, _dp, _dp, C.POINTER(_dp)]
     L.mphip_get_atm.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.POINTER(_dp)]
+    L.mphip_update_quantity.argtypes = [C.c_void_p, C.c_int, _dp]
     L.mphip_update_cache.argtypes = [C.c_void_p, _fp, C.POINTER(C.c_uint64)]
     L.mphip_get_cache.argtypes = [C.c_void_p, _fp, _dp, C.POINTER(C.c_uint64)]
     L.mphip_update_iso.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
@@ -250,6 +251,12 @@ class Simulation:
             qp[iq] = _ptr(q[iq], _dp)
         self._chk(self.L.mphip_update_atm(self.h, self.n, self.lo, self.n_total, self.nq,
                                           *[_ptr(a, _dp) for a in arrs], qp))
+
+    def update_quantity(self, iq, values):
+        """One quantity array in the caller's order (mphip_update_quantity)."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.shape == (self.n,)
+        self._chk(self.L.mphip_update_quantity(self.h, int(iq), _ptr(v, _dp)))
 
     def replace_particles(self, atm):
         """A new particle set (any count) in the same context: what a C caller does when it hands a different

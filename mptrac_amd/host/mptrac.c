@@ -9,6 +9,7 @@
  */
 #define _GNU_SOURCE
 #include "mptrac.h"
+#include <stddef.h>
 
 #include <pthread.h>
 #include <strings.h>
@@ -101,16 +102,40 @@ void mptrac_free(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t *met0, met_t *m
 /* -------------------------------------------------------------------------- */
 
 static const struct {
-  const char *name, *unit;
-} qnt_units[] = {
-  /* names and units of the reference's SET_QNT table (mptrac.c:6853-6969),
-   * hot-path quantities only */
-  { "ens", "-" }, { "m", "kg" }, { "vmr", "ppv" }, { "rp", "microns" }, { "rhop", "kg/m^3" },
-  { "loss_rate", "s^-1" }, { "mloss_decay", "kg" }, { "mloss_wet", "kg" }, { "mloss_dry", "kg" },
-  { "idx", "-" }, { "stat", "-" }, { "zeta", "K" }, { "eta", "1" }, { "aoa", "s" },
-#define X(n, u) { #n, u },
-  MPTRAC_METEO_QNT(X)
-#undef X
+  const char *name, *longname, *unit;
+} qnt_table[] = {
+  /* names, descriptions and units of the reference's SET_QNT table (mptrac.c:6857-6969): the quantities of
+   * the hot path and of module_meteo */
+  { "idx", "particle index", "-" }, { "ens", "ensemble index", "-" }, { "stat", "station flag", "-" },
+  { "m", "mass", "kg" }, { "vmr", "volume mixing ratio", "ppv" }, { "rp", "particle radius", "microns" },
+  { "rhop", "particle density", "kg/m^3" }, { "loss_rate", "total loss rate", "s^-1" },
+  { "mloss_decay", "mass loss due to exponential decay", "kg" }, { "mloss_wet", "mass loss due to wet deposition", "kg" },
+  { "mloss_dry", "mass loss due to dry deposition", "kg" }, { "zeta", "zeta coordinate", "K" },
+  { "eta", "eta coordinate", "1" }, { "aoa", "age of air", "s" },
+  { "ps", "surface pressure", "hPa" }, { "ts", "surface temperature", "K" }, { "zs", "surface height", "km" },
+  { "us", "surface zonal wind", "m/s" }, { "vs", "surface meridional wind", "m/s" },
+  { "ess", "eastward turbulent surface stress", "N/m^2" }, { "nss", "northward turbulent surface stress", "N/m^2" },
+  { "shf", "surface sensible heat flux", "W/m^2" }, { "lsm", "land-sea mask", "1" },
+  { "sst", "sea surface temperature", "K" }, { "pbl", "planetary boundary layer", "hPa" },
+  { "pt", "tropopause pressure", "hPa" }, { "tt", "tropopause temperature", "K" },
+  { "zt", "tropopause geopotential height", "km" }, { "h2ot", "tropopause water vapor", "ppv" },
+  { "zg", "geopotential height", "km" }, { "p", "pressure", "hPa" }, { "t", "temperature", "K" },
+  { "rho", "air density", "kg/m^3" }, { "u", "zonal wind", "m/s" }, { "v", "meridional wind", "m/s" },
+  { "w", "vertical velocity", "hPa/s" }, { "h2o", "water vapor", "ppv" }, { "o3", "ozone", "ppv" },
+  { "lwc", "cloud liquid water content", "kg/kg" }, { "rwc", "cloud rain water content", "kg/kg" },
+  { "iwc", "cloud ice water content", "kg/kg" }, { "swc", "cloud snow water content", "kg/kg" },
+  { "cc", "cloud cover", "1" }, { "pct", "cloud top pressure", "hPa" }, { "pcb", "cloud bottom pressure", "hPa" },
+  { "cl", "total column cloud water", "kg/m^2" }, { "plcl", "lifted condensation level", "hPa" },
+  { "plfc", "level of free convection", "hPa" }, { "pel", "equilibrium level", "hPa" },
+  { "cape", "convective available potential energy", "J/kg" }, { "cin", "convective inhibition", "J/kg" },
+  { "o3c", "total column ozone", "DU" }, { "psat", "saturation pressure over water", "hPa" },
+  { "psice", "saturation pressure over ice", "hPa" }, { "pw", "partial water vapor pressure", "hPa" },
+  { "sh", "specific humidity", "kg/kg" }, { "rh", "relative humidity", "%" },
+  { "rhice", "relative humidity over ice", "%" }, { "theta", "potential temperature", "K" },
+  { "zeta_d", "diagnosed zeta coordinate", "K" }, { "tvirt", "virtual temperature", "K" },
+  { "lapse", "temperature lapse rate", "K/km" }, { "vh", "horizontal velocity", "m/s" },
+  { "vz", "vertical velocity", "m/s" }, { "pv", "potential vorticity", "PVU" },
+  { "tdew", "dew point temperature", "K" }, { "tice", "frost point temperature", "K" },
 };
 
 static const char *unsupported_qnt[] = {
@@ -216,6 +241,53 @@ static const char *unsupported_qnt[] = {
   D(grid_lat0, "GRID_LAT0", "-90") \
   D(grid_lat1, "GRID_LAT1", "90") \
   I(grid_ny, "GRID_NY", "180") \
+  I(grid_type, "GRID_TYPE", "0") \
+  I(obs_type, "OBS_TYPE", "0") \
+  S(csi_basename, "CSI_BASENAME", "-") \
+  S(csi_kernel, "CSI_KERNEL", "-") \
+  D(csi_dt_out, "CSI_DT_OUT", "86400") \
+  S(csi_obsfile, "CSI_OBSFILE", "-") \
+  D(csi_obsmin, "CSI_OBSMIN", "0") \
+  D(csi_modmin, "CSI_MODMIN", "0") \
+  D(csi_z0, "CSI_Z0", "-5") \
+  D(csi_z1, "CSI_Z1", "85") \
+  I(csi_nz, "CSI_NZ", "1") \
+  D(csi_lon0, "CSI_LON0", "-180") \
+  D(csi_lon1, "CSI_LON1", "180") \
+  I(csi_nx, "CSI_NX", "360") \
+  D(csi_lat0, "CSI_LAT0", "-90") \
+  D(csi_lat1, "CSI_LAT1", "90") \
+  I(csi_ny, "CSI_NY", "180") \
+  S(ens_basename, "ENS_BASENAME", "-") \
+  D(ens_dt_out, "ENS_DT_OUT", "86400") \
+  S(prof_basename, "PROF_BASENAME", "-") \
+  S(prof_obsfile, "PROF_OBSFILE", "-") \
+  D(prof_z0, "PROF_Z0", "0") \
+  D(prof_z1, "PROF_Z1", "60") \
+  I(prof_nz, "PROF_NZ", "60") \
+  D(prof_lon0, "PROF_LON0", "-180") \
+  D(prof_lon1, "PROF_LON1", "180") \
+  I(prof_nx, "PROF_NX", "360") \
+  D(prof_lat0, "PROF_LAT0", "-90") \
+  D(prof_lat1, "PROF_LAT1", "90") \
+  I(prof_ny, "PROF_NY", "180") \
+  S(sample_basename, "SAMPLE_BASENAME", "-") \
+  S(sample_kernel, "SAMPLE_KERNEL", "-") \
+  S(sample_obsfile, "SAMPLE_OBSFILE", "-") \
+  D(sample_dx, "SAMPLE_DX", "50") \
+  D(sample_dz, "SAMPLE_DZ", "-999") \
+  S(stat_basename, "STAT_BASENAME", "-") \
+  D(stat_lon, "STAT_LON", "0") \
+  D(stat_lat, "STAT_LAT", "0") \
+  D(stat_r, "STAT_R", "50") \
+  D(stat_t0, "STAT_T0", "-1e100") \
+  D(stat_t1, "STAT_T1", "1e100") \
+  S(vtk_basename, "VTK_BASENAME", "-") \
+  D(vtk_dt_out, "VTK_DT_OUT", "86400") \
+  I(vtk_stride, "VTK_STRIDE", "1") \
+  D(vtk_scale, "VTK_SCALE", "1.0") \
+  D(vtk_offset, "VTK_OFFSET", "0.0") \
+  I(vtk_sphere, "VTK_SPHERE", "0") \
   I(hip_device, "HIP_DEVICE", "0") \
   I(hip_locality_interval, "HIP_LOCALITY_SORT_INTERVAL", "60") \
   I(hip_met_prefetch, "HIP_MET_PREFETCH", "0")
@@ -227,7 +299,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   /* quantities, mptrac.c:6737-6971 */
   ctl->qnt_m = ctl->qnt_vmr = ctl->qnt_rp = ctl->qnt_rhop = ctl->qnt_ens = ctl->qnt_loss_rate = -1;
   ctl->qnt_mloss_decay = ctl->qnt_mloss_wet = ctl->qnt_mloss_dry = ctl->qnt_zeta = ctl->qnt_eta = -1;
-  ctl->qnt_aoa = -1;
+  ctl->qnt_aoa = ctl->qnt_stat = -1;
 #define X(n, u) ctl->qnt_##n = -1;
   MPTRAC_METEO_QNT(X)
 #undef X
@@ -239,16 +311,23 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
     scan_ctl(filename, argc, argv, "QNT_FORMAT", iq, "%g", ctl->qnt_format[iq]);
     if (strcasecmp(ctl->qnt_name[iq], "aoa") == 0)   /* mptrac.c:6852-6853 */
       sprintf(ctl->qnt_format[iq], "%%.2f");
-    sprintf(ctl->qnt_unit[iq], "-");
-    for (size_t k = 0; k < sizeof(qnt_units) / sizeof(qnt_units[0]); k++)
-      if (strcasecmp(ctl->qnt_name[iq], qnt_units[k].name) == 0)
-        sprintf(ctl->qnt_unit[iq], "%s", qnt_units[k].unit);
+    int known = 0;
+    ctl->qnt_longname[iq][0] = '\0';
+    for (size_t k = 0; k < sizeof(qnt_table) / sizeof(qnt_table[0]); k++)
+      if (strcasecmp(ctl->qnt_name[iq], qnt_table[k].name) == 0) {
+        sprintf(ctl->qnt_longname[iq], "%s", qnt_table[k].longname);
+        sprintf(ctl->qnt_unit[iq], "%s", qnt_table[k].unit);
+        known = 1;
+      }
     for (int k = 0; unsupported_qnt[k]; k++)
       if (strcasecmp(ctl->qnt_name[iq], unsupported_qnt[k]) == 0)
         ERRMSG("Quantity %s is filled by the chemistry / climatology / decomposition code of the reference, "
                "which this build does not provide!", ctl->qnt_name[iq]);
+    if (!known)   /* a quantity the model does not know is carried along; its unit has to be given (mptrac.c:6970) */
+      scan_ctl(filename, argc, argv, "QNT_UNIT", iq, "", ctl->qnt_unit[iq]);
     const char *n = ctl->qnt_name[iq];
     if (!strcasecmp(n, "m")) ctl->qnt_m = iq;
+    else if (!strcasecmp(n, "stat")) ctl->qnt_stat = iq;
     else if (!strcasecmp(n, "vmr")) ctl->qnt_vmr = iq;
     else if (!strcasecmp(n, "rp")) ctl->qnt_rp = iq;
     else if (!strcasecmp(n, "rhop")) ctl->qnt_rhop = iq;
@@ -355,8 +434,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
    * other output writers (mptrac.c:7574-7713), chemistry and radioactive decay switches (7386-7411),
    * kernel-weighted and netCDF gridded output, domain decomposition */
   {
-    static const char *const names[] = { "DEPO_BASENAME", "CSI_BASENAME", "ENS_BASENAME", "PROF_BASENAME",
-      "SAMPLE_BASENAME", "STAT_BASENAME", "VTK_BASENAME", "GRID_KERNEL", "ATM_GPFILE", "GRID_GPFILE", NULL };
+    static const char *const names[] = { "DEPO_BASENAME", "GRID_KERNEL", "ATM_GPFILE", "GRID_GPFILE", NULL };
     char val[LEN];
     for (int k = 0; names[k]; k++) {
       scan_ctl(filename, argc, argv, names[k], -1, "-", val);
@@ -364,11 +442,32 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
         ERRMSG("%s is not implemented in this host layer!", names[k]);
     }
     static const char *const switches[] = { "H2O2_CHEM_REACTION", "KPP_CHEM", "TRACER_CHEM", "RADIO_DECAY", "RADIO_DEPO",
-      "GRID_TYPE", "DD", "MET_MPI_SHARE", NULL };
+      "DD", "MET_MPI_SHARE", NULL };
     for (int k = 0; switches[k]; k++)
       if ((int) scan_ctl(filename, argc, argv, switches[k], -1, "0", NULL) != 0)
         ERRMSG("%s is not implemented in this host layer!", switches[k]);
   }
+  /* netCDF outputs are written in the classic format (host/nc_classic.c): no compression (accepted, without
+   * effect), and no lossy quantisation -- that would change the stored values, so it is refused */
+  {
+    char key[LEN];
+    for (int iq = 0; iq < ctl->nq; iq++)
+      for (int k = 0; k < 2; k++) {
+        sprintf(key, "%s", k ? "GRID_NC_QUANT" : "ATM_NC_QUANT");
+        if ((int) scan_ctl(filename, argc, argv, key, iq, "0", NULL) != 0)
+          ERRMSG("%s: quantisation of netCDF output needs the netCDF-4 library, which this build does not use!", key);
+      }
+    if ((int) scan_ctl(filename, argc, argv, "ATM_NC_LEVEL", -1, "0", NULL) != 0
+        || (int) scan_ctl(filename, argc, argv, "GRID_NC_LEVEL", -1, "0", NULL) != 0)
+      WARN("netCDF output is written uncompressed (classic format): ATM_NC_LEVEL / GRID_NC_LEVEL have no effect");
+  }
+  REQUIRE(ctl->grid_type == 0 || ctl->grid_type == 1, "Set GRID_TYPE to 0 or 1!");
+  REQUIRE(ctl->csi_nx >= 1 && ctl->csi_ny >= 1 && ctl->csi_nz >= 1 && ctl->csi_lon0 < ctl->csi_lon1
+          && ctl->csi_lat0 < ctl->csi_lat1 && ctl->csi_z0 < ctl->csi_z1 && ctl->csi_lat0 >= -90 && ctl->csi_lat1 <= 90,
+          "Invalid CSI grid!");
+  REQUIRE(ctl->prof_nx >= 1 && ctl->prof_ny >= 1 && ctl->prof_nz >= 1 && ctl->prof_lon0 < ctl->prof_lon1
+          && ctl->prof_lat0 < ctl->prof_lat1 && ctl->prof_z0 < ctl->prof_z1 && ctl->prof_lat0 >= -90
+          && ctl->prof_lat1 <= 90, "Invalid profile grid!");
   if (ctl->rng_type != 1)
     ERRMSG("This build implements RNG_TYPE 1 (Squares) only!");
   REQUIRE(ctl->advect_vert_coord >= 0 && ctl->advect_vert_coord <= 3, "Set ADVECT_VERT_COORD to 0, 1, 2, or 3!");
@@ -520,12 +619,264 @@ static int read_atm_bin(const char *filename, const ctl_t *ctl, atm_t *atm) {
   return 1;
 }
 
+/* ---- netCDF particle files (classic format; host/nc_classic.c) ---- */
+
+/* a whole one-dimensional (or [1][n]) variable as doubles; `need`: stop if it is missing, else warn and leave
+ * `dst` alone.  1 = read */
+static int nc_column(ncc_file *nc, const char *name, long long n, double *dst, int need) {
+  const int var = ncc_find_var(nc, name);
+  if (var < 0) {
+    if (need)
+      ERRMSG("Cannot find variable %s in the netCDF file!", name);
+    WARN("netCDF variable %s is missing!", name);
+    return 0;
+  }
+  if (!ncc_read_double(nc, var, 0, 0, n, dst))
+    ERRMSG("Cannot read variable %s: %s", name, ncc_error(nc));
+  return 1;
+}
+
+static ncc_file *nc_open_or_null(const char *filename) {
+  char why[256];
+  ncc_file *nc = ncc_open(filename, why, sizeof(why));
+  if (!nc) {
+    FILE *probe = fopen(filename, "r");
+    if (probe) {   /* the file exists but is not a classic netCDF file: say why instead of "not found" */
+      fclose(probe);
+      ERRMSG("%s: %s", filename, why);
+    }
+  }
+  return nc;
+}
+
+static long long nc_particles(ncc_file *nc, const char *dim) {
+  long long n = 0;
+  if (ncc_find_dim(nc, dim, &n) < 0)
+    ERRMSG("Cannot find dimension %s in the netCDF file!", dim);
+  if (n < 1 || n > NP)
+    ERRMSG("Dimension %s is out of range!", dim);
+  return n;
+}
+
+/* ATM_TYPE 2 (mptrac.c:8541-8573): dimension obs; time, press, lon, lat and one variable per quantity */
+static int read_atm_nc(const char *filename, const ctl_t *ctl, atm_t *atm) {
+  ncc_file *nc = nc_open_or_null(filename);
+  if (!nc)
+    return 0;
+  const long long n = nc_particles(nc, "obs");
+  atm->np = (int) n;
+  nc_column(nc, "time", n, atm->time, 1);
+  nc_column(nc, "press", n, atm->p, 1);
+  nc_column(nc, "lon", n, atm->lon, 1);
+  nc_column(nc, "lat", n, atm->lat, 1);
+  for (int iq = 0; iq < ctl->nq; iq++)
+    nc_column(nc, ctl->qnt_name[iq], n, atm->q[iq], 0);
+  ncc_close(nc);
+  return 1;
+}
+
+/* ATM_TYPE 3 / 4, CLaMS position files (mptrac.c:8478-8537): dimension NPARTS; LON, LAT, TIME_INIT (or one
+ * scalar time), PRESS_INIT or PRESS, ZETA with diabatic advection, quantities by name */
+static int read_atm_clams(const char *filename, const ctl_t *ctl, atm_t *atm) {
+  if (ctl->met_coord_type != 0)
+    ERRMSG("CLaMS atmospheric files support only lat/lon grids");
+  ncc_file *nc = nc_open_or_null(filename);
+  if (!nc)
+    return 0;
+  const long long n = nc_particles(nc, "NPARTS");
+  atm->np = (int) n;
+  if (ncc_find_var(nc, "TIME_INIT") >= 0)
+    nc_column(nc, "TIME_INIT", n, atm->time, 1);
+  else {
+    WARN("TIME_INIT not found use time instead!");
+    double t_file;
+    nc_column(nc, "time", 1, &t_file, 1);
+    for (long long ip = 0; ip < n; ip++)
+      atm->time[ip] = t_file;
+  }
+  if (ctl->advect_vert_coord == 1) {
+    nc_column(nc, "ZETA", n, atm->q[ctl->qnt_zeta], 1);
+    nc_column(nc, "PRESS", n, atm->p, 0);
+  } else if (ncc_find_var(nc, "PRESS_INIT") >= 0)
+    nc_column(nc, "PRESS_INIT", n, atm->p, 1);
+  else {
+    WARN("PRESS_INIT not found use PRESS instead!");
+    nc_column(nc, "PRESS", n, atm->p, 1);
+  }
+  for (int iq = 0; iq < ctl->nq; iq++)
+    nc_column(nc, ctl->qnt_name[iq], n, atm->q[iq], 0);
+  nc_column(nc, "LON", n, atm->lon, 1);
+  nc_column(nc, "LAT", n, atm->lat, 1);
+  ncc_close(nc);
+  return 1;
+}
+
+int mptrac_amd_read_obs_nc(const char *filename, double *rt, double *rz, double *rlon, double *rlat, double *robs) {
+  ncc_file *nc = nc_open_or_null(filename);
+  if (!nc)
+    ERRMSG("Cannot open file!");
+  long long n = 0;
+  if (ncc_find_dim(nc, "nobs", &n) < 0 || n < 1 || n > NOBS)
+    ERRMSG("Dimension nobs is missing or out of range!");
+  nc_column(nc, "time", n, rt, 1);
+  nc_column(nc, "alt", n, rz, 1);
+  nc_column(nc, "lon", n, rlon, 1);
+  nc_column(nc, "lat", n, rlat, 1);
+  nc_column(nc, "obs", n, robs, 1);
+  ncc_close(nc);
+  return (int) n;
+}
+
+#define NCW(call) { if ((call) < 0) ERRMSG("netCDF output failed: %s", nccw_error(w)); }
+
+static int ncw_var(nccw_file *w, const char *name, int type, int ndims, const int *dims, const char *longname,
+                   const char *units) {
+  const int v = nccw_def_var(w, name, type, ndims, dims);
+  NCW(v);
+  NCW(nccw_put_att_text(w, v, "long_name", longname));
+  NCW(nccw_put_att_text(w, v, "units", units));
+  return v;
+}
+
+static void ncw_put(nccw_file *w, const char *name, long long rec, const double *data) {
+  NCW(nccw_put_double(w, nccw_find_var(w, name), rec, data));
+}
+
+static nccw_file *ncw_create(const char *filename) {
+  nccw_file *w = nccw_create(filename);
+  if (!w)
+    ERRMSG("Cannot create file!");
+  return w;
+}
+
+/* ATM_TYPE_OUT 2 (mptrac.c:13139-13185) */
+static void write_atm_nc(const char *filename, const ctl_t *ctl, const atm_t *atm) {
+  nccw_file *w = ncw_create(filename);
+  const int obs = nccw_def_dim(w, "obs", atm->np);
+  NCW(obs);
+  ncw_var(w, "time", NCC_DOUBLE, 1, &obs, "time", "seconds since 2000-01-01 00:00:00 UTC");
+  ncw_var(w, "press", NCC_DOUBLE, 1, &obs, "pressure", "hPa");
+  ncw_var(w, "lon", NCC_DOUBLE, 1, &obs, "longitude", "degrees_east");
+  ncw_var(w, "lat", NCC_DOUBLE, 1, &obs, "latitude", "degrees_north");
+  for (int iq = 0; iq < ctl->nq; iq++)
+    ncw_var(w, ctl->qnt_name[iq], NCC_DOUBLE, 1, &obs, ctl->qnt_longname[iq], ctl->qnt_unit[iq]);
+  NCW(nccw_put_att_text(w, -1, "featureType", "point"));
+  NCW(nccw_enddef(w));
+  ncw_put(w, "time", 0, atm->time);
+  ncw_put(w, "press", 0, atm->p);
+  ncw_put(w, "lon", 0, atm->lon);
+  ncw_put(w, "lat", 0, atm->lat);
+  for (int iq = 0; iq < ctl->nq; iq++)
+    ncw_put(w, ctl->qnt_name[iq], 0, atm->q[iq]);
+  NCW(nccw_close(w));
+}
+
+/* the variables of a CLaMS file: positions per particle (`per_time`: with a leading time dimension), quantities
+ * always [time][NPARTS] */
+static void clams_define(nccw_file *w, const ctl_t *ctl, int tid, int pid, int per_time) {
+  const int both[2] = { tid, pid };
+  ncw_var(w, "time", NCC_DOUBLE, 1, &tid, "Time", "seconds since 2000-01-01 00:00:00 UTC");
+  static const char *const pos[4][3] = { { "LAT", "Latitude", "deg" }, { "LON", "Longitude", "deg" },
+    { "PRESS", "Pressure", "hPa" }, { "ZETA", "Zeta", "K" } };
+  for (int k = 0; k < 4; k++)
+    ncw_var(w, pos[k][0], NCC_DOUBLE, per_time ? 2 : 1, per_time ? both : &pid, pos[k][1], pos[k][2]);
+  for (int iq = 0; iq < ctl->nq; iq++)
+    ncw_var(w, ctl->qnt_name[iq], NCC_DOUBLE, 2, both, ctl->qnt_name[iq], ctl->qnt_unit[iq]);
+  NCW(nccw_put_att_text(w, -1, "exp_VERTCOOR_name", "zeta"));
+  NCW(nccw_put_att_text(w, -1, "model", "MPTRAC"));
+  NCW(nccw_enddef(w));
+}
+
+/* the vertical coordinate a CLaMS file carries as ZETA: the advected zeta, else the diagnosed one */
+static const double *clams_zeta(const ctl_t *ctl, const atm_t *atm, int diagnosed_only) {
+  if (!diagnosed_only && ctl->advect_vert_coord == 1)
+    return atm->q[ctl->qnt_zeta];
+  if (ctl->qnt_zeta_d >= 0 && (diagnosed_only || ctl->qnt_zeta >= 0))
+    return atm->q[ctl->qnt_zeta_d];
+  return NULL;
+}
+
+static void clams_put(nccw_file *w, const ctl_t *ctl, const atm_t *atm, long long rec, const double *zeta) {
+  ncw_put(w, "time", rec, atm->time);   /* (one value: the time of the first particle, as the reference writes it) */
+  ncw_put(w, "LAT", rec, atm->lat);
+  ncw_put(w, "LON", rec, atm->lon);
+  ncw_put(w, "PRESS", rec, atm->p);
+  if (zeta)
+    ncw_put(w, "ZETA", rec, zeta);
+  for (int iq = 0; iq < ctl->nq; iq++)
+    ncw_put(w, ctl->qnt_name[iq], rec, atm->q[iq]);
+}
+
+/* ATM_TYPE_OUT 4: CLaMS position file (mptrac.c:12922-12974) */
+static void write_atm_clams(const char *filename, const ctl_t *ctl, const atm_t *atm) {
+  if (ctl->met_coord_type != 0)
+    ERRMSG("CLaMS atmospheric files support only lat/lon grids");
+  if (ctl->qnt_zeta_d < 0)
+    ERRMSG("CLaMS position files need the quantity zeta_d!");
+  nccw_file *w = ncw_create(filename);
+  const int tid = nccw_def_dim(w, "time", 1), pid = nccw_def_dim(w, "NPARTS", atm->np);
+  NCW(tid);
+  NCW(pid);
+  clams_define(w, ctl, tid, pid, 0);
+  clams_put(w, ctl, atm, 0, clams_zeta(ctl, atm, 1));
+  NCW(nccw_close(w));
+}
+
+/* ATM_TYPE_OUT 3: CLaMS trajectory file traj_fix_3d_<start>_<stop>.nc in the directory of `filename`, one record
+ * per output time, and at the stop time the position file init_fix_<stop>.nc (mptrac.c:12978-13135) */
+static void write_atm_clams_traj(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t) {
+  static nccw_file *traj;
+  if (ctl->met_coord_type != 0)
+    ERRMSG("CLaMS atmospheric files support only lat/lon grids");
+  char dir[2 * LEN], path[3 * LEN];
+  snprintf(dir, sizeof(dir), "%s", filename);
+  char *slash = strrchr(dir, '/');
+  if (slash)
+    *slash = '\0';
+  else
+    sprintf(dir, ".");
+  int y0, m0, d0, h0, y1, m1, d1, h1, y, m, d, h, mi, se;
+  double r;
+  jsec2time(ctl->t_start, &y0, &m0, &d0, &h0, &mi, &se, &r);
+  jsec2time(ctl->t_stop, &y1, &m1, &d1, &h1, &mi, &se, &r);
+  jsec2time(t, &y, &m, &d, &h, &mi, &se, &r);
+  if (!traj) {
+    snprintf(path, sizeof(path), "%s/traj_fix_3d_%02d%02d%02d%02d_%02d%02d%02d%02d.nc", dir, y0 % 100, m0, d0, h0,
+             y1 % 100, m1, d1, h1);
+    LOG(1, "Write traj file: %s", path);
+    traj = ncw_create(path);
+    nccw_file *w = traj;
+    const int tid = nccw_def_dim(w, "time", 0), pid = nccw_def_dim(w, "NPARTS", atm->np);
+    NCW(tid);
+    NCW(pid);
+    NCW(nccw_def_dim(w, "TMDT", 7));
+    clams_define(w, ctl, tid, pid, 1);
+  }
+  clams_put(traj, ctl, atm, nccw_numrecs(traj), clams_zeta(ctl, atm, 0));
+  if (y == y1 && m == m1 && d == d1 && h == h1) {
+    nccw_file *w = traj;
+    NCW(nccw_close(w));
+    traj = NULL;
+    snprintf(path, sizeof(path), "%s/init_fix_%02d%02d%02d%02d.nc", dir, y1 % 100, m1, d1, h1);
+    LOG(1, "Write init file: %s", path);
+    if (ctl->qnt_zeta_d < 0)
+      ERRMSG("CLaMS position files need the quantity zeta_d!");
+    write_atm_clams(path, ctl, atm);
+  }
+}
+
 int mptrac_read_atm(const char *filename, const ctl_t *ctl, atm_t *atm) {
   LOG(1, "Read atmospheric data: %s", filename);
   atm->np = 0;
-  if (ctl->atm_type != 0 && ctl->atm_type != 1)
-    ERRMSG("Atmospheric data type not supported (this build reads ATM_TYPE 0 and 1)!");
-  if (!(ctl->atm_type == 0 ? read_atm_asc(filename, ctl, atm) : read_atm_bin(filename, ctl, atm)))
+  int ok;
+  switch (ctl->atm_type) {
+  case 0: ok = read_atm_asc(filename, ctl, atm); break;
+  case 1: ok = read_atm_bin(filename, ctl, atm); break;
+  case 2: ok = read_atm_nc(filename, ctl, atm); break;
+  case 3: case 4: ok = read_atm_clams(filename, ctl, atm); break;
+  default: ERRMSG("Atmospheric data type not supported!");
+  }
+  if (!ok)
     return 0;
   if (atm->np < 1)
     ERRMSG("Can not read any data!");
@@ -580,8 +931,14 @@ void mptrac_write_atm(const char *filename, const ctl_t *ctl, const atm_t *atm, 
     write_atm_asc(filename, ctl, atm, t);
   else if (ctl->atm_type_out == 1)
     write_atm_bin(filename, ctl, atm);
+  else if (ctl->atm_type_out == 2)
+    write_atm_nc(filename, ctl, atm);
+  else if (ctl->atm_type_out == 3)
+    write_atm_clams_traj(filename, ctl, atm, t);
+  else if (ctl->atm_type_out == 4)
+    write_atm_clams(filename, ctl, atm);
   else
-    ERRMSG("Atmospheric data type not supported (this build writes ATM_TYPE_OUT 0 and 1)!");
+    ERRMSG("Atmospheric data type not supported!");
 }
 
 /* every column (i, j) of the grid */
@@ -1402,8 +1759,8 @@ static int grid_locate_irr(const double *xx, const int n, const double x) {
   return lo;
 }
 
-static double grid_temperature(const met_t *met0, const met_t *met1, const double ts, const double p,
-                               const double lon, const double lat) {
+double mptrac_amd_intpol_3d(const met_t *met0, const met_t *met1, size_t field_offset, const double ts,
+                            const double p, const double lon, const double lat) {
   double lon2 = FMOD(lon, 360.);
   if (lon2 < met0->lon[0])
     lon2 += 360;
@@ -1424,11 +1781,11 @@ static double grid_temperature(const met_t *met0, const met_t *met1, const doubl
   double v[2];
   const met_t *mm[2] = { met0, met1 };
   for (int k = 0; k < 2; k++) {
-    const met_t *m = mm[k];
-    double a00 = wp * (m->t[ix][iy][ip] - m->t[ix][iy][ip + 1]) + m->t[ix][iy][ip + 1];
-    const double a01 = wp * (m->t[ix][iy + 1][ip] - m->t[ix][iy + 1][ip + 1]) + m->t[ix][iy + 1][ip + 1];
-    double a10 = wp * (m->t[ix + 1][iy][ip] - m->t[ix + 1][iy][ip + 1]) + m->t[ix + 1][iy][ip + 1];
-    const double a11 = wp * (m->t[ix + 1][iy + 1][ip] - m->t[ix + 1][iy + 1][ip + 1]) + m->t[ix + 1][iy + 1][ip + 1];
+    const float (*f)[EY][EP] = (const float (*)[EY][EP]) ((const char *) mm[k] + field_offset);
+    double a00 = wp * (f[ix][iy][ip] - f[ix][iy][ip + 1]) + f[ix][iy][ip + 1];
+    const double a01 = wp * (f[ix][iy + 1][ip] - f[ix][iy + 1][ip + 1]) + f[ix][iy + 1][ip + 1];
+    double a10 = wp * (f[ix + 1][iy][ip] - f[ix + 1][iy][ip + 1]) + f[ix + 1][iy][ip + 1];
+    const double a11 = wp * (f[ix + 1][iy + 1][ip] - f[ix + 1][iy + 1][ip + 1]) + f[ix + 1][iy + 1][ip + 1];
     a00 = wy * (a00 - a01) + a01;
     a10 = wy * (a10 - a11) + a11;
     v[k] = wx * (a00 - a10) + a10;
@@ -1437,34 +1794,30 @@ static double grid_temperature(const met_t *met0, const met_t *met1, const doubl
   return wt * (v[0] - v[1]) + v[1];
 }
 
-void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1, const atm_t *atm,
-                const double t) {
-  /* Binning and sums on the device (mphip_grid_sums; mptrac.c:13815-13872),
-   * post-processing and ASCII layout as mptrac.c:13875-13918, 13954-14056;
-   * the implicit volume mixing ratio (MOLMASS set, mass quantity present) uses
-   * the temperature at the cell centre, interpolated on the host as in the
-   * reference. */
-  (void) atm;
-  if (ctl->met_coord_type != 0)
-    ERRMSG("Only lat/lon grid supported");
-  LOG(1, "Write grid data: %s", filename);
-  const size_t ncell = (size_t) ctl->grid_nx * (size_t) ctl->grid_ny * (size_t) ctl->grid_nz;
+/* what write_grid derives per box from the device's sums: column density, implicit volume mixing ratio, number of
+ * particles, mean (and standard deviation) of every quantity -- then laid out as text or as netCDF */
+typedef struct {
+  size_t ncell;
+  double step_z, step_lon, step_lat;
+  double *z, *lon, *lat, *area;   /* box centres and column areas */
+  double *cd, *vmr_impl;
   int *np;
-  double *mean, *sigma;
-  ALLOC(np, int, ncell);
-  ALLOC(mean, double, ncell * (size_t) (ctl->nq > 0 ? ctl->nq : 1));
-  ALLOC(sigma, double, ncell * (size_t) (ctl->nq > 0 ? ctl->nq : 1));
-  HIP(mphip_grid_sums(g_ctx, t, np, mean, sigma));   /* summed over the ranks of the job */
-  if (g_rank != 0) {                                  /* rank 0 writes the file */
-    free(np);
-    free(mean);
-    free(sigma);
-    return;
-  }
+  double *mean, *sigma;            /* [nq][ncell] */
+} grid_result;
 
-  /* cell sizes and centres */
-  const double step_z = (ctl->grid_z1 - ctl->grid_z0) / ctl->grid_nz, step_lon = (ctl->grid_lon1 - ctl->grid_lon0) / ctl->grid_nx,
-               step_lat = (ctl->grid_lat1 - ctl->grid_lat0) / ctl->grid_ny;
+static void grid_result_free(grid_result *g) {
+  free(g->z);
+  free(g->lon);
+  free(g->lat);
+  free(g->area);
+  free(g->cd);
+  free(g->vmr_impl);
+  free(g->np);
+  free(g->mean);
+  free(g->sigma);
+}
+
+static void write_grid_asc(const char *filename, const ctl_t *ctl, const grid_result *g, const double t) {
   FILE *out = fopen(filename, "w");
   REQUIRE(out, "Cannot create file!");
   static const char *const legend[9] = { "time [s]", "altitude [km]", "longitude [deg]", "latitude [deg]",
@@ -1486,70 +1839,228 @@ void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1
       fputc('\n', out);
     if (blocks && j > 0 && ctl->grid_nz > 1)
       fputc('\n', out);
-    const double lon = ctl->grid_lon0 + step_lon * (i + 0.5), lat = ctl->grid_lat0 + step_lat * (j + 0.5);
-    const double area = step_lat * step_lon * SQR(RE * M_PI / 180.) * cos(DEG2RAD(lat));
     for (int k = 0; k < ctl->grid_nz; k++) {
       const size_t cell = (size_t) ARRAY_3D(i, j, ctl->grid_ny, k, ctl->grid_nz);
-      const double z = ctl->grid_z0 + step_z * (k + 0.5);
-      const double mass = ctl->qnt_m >= 0 ? mean[(size_t) ctl->qnt_m * ncell + cell] : NAN;
-      const double cd = mass / (1e6 * area);
-      /* implicit volume mixing ratio from the mass in the cell and the air density at its centre (mptrac.c:13885-13900) */
-      double vmr_impl = NAN;
-      if (ctl->qnt_m >= 0 && ctl->molmass > 0 && met0 && met1) {
-        vmr_impl = 0;
-        if (mass > 0) {
-          const double press = P(z);
-          const double temp = grid_temperature(met0, met1, t, press, lon, lat);
-          vmr_impl = MA / ctl->molmass * cd / (100. * press / (RA * temp) * step_z * 1e3);
-        }
-      }
-      if (ctl->grid_sparse && !(vmr_impl > 0))   /* sparse output keeps cells with vmr_impl > 0 only */
+      if (ctl->grid_sparse && !(g->vmr_impl[cell] > 0))   /* sparse output keeps cells with vmr_impl > 0 only */
         continue;
-      fprintf(out, "%.2f %g %g %g %g %g %g %g %d", t, z, lon, lat, area, step_z, cd, vmr_impl, np[cell]);
+      fprintf(out, "%.2f %g %g %g %g %g %g %g %d", t, g->z[k], g->lon[i], g->lat[j], g->area[j], g->step_z, g->cd[cell],
+              g->vmr_impl[cell], g->np[cell]);
       for (int pass = 0; pass < (ctl->grid_stddev ? 2 : 1); pass++)
         for (int q = 0; q < ctl->nq; q++) {
-          double v = NAN;
-          if (np[cell] > 0) {
-            const double m = mean[(size_t) q * ncell + cell] / np[cell];
-            v = m;
-            if (pass) {
-              const double var = sigma[(size_t) q * ncell + cell] / np[cell] - SQR(m);
-              v = var > 0 ? sqrt(var) : 0;
-            }
-          }
           fputc(' ', out);
-          fprintf(out, ctl->qnt_format[q], v);
+          fprintf(out, ctl->qnt_format[q], (pass ? g->sigma : g->mean)[(size_t) q * g->ncell + cell]);
         }
       fputc('\n', out);
     }
   }
   fclose(out);
-  free(np);
-  free(mean);
-  free(sigma);
+}
+
+/* GRID_TYPE 1 (mptrac.c:14058-14183): dimensions time, z, lat, lon (and dz); the box fields as [time][z][lat][lon] */
+static void write_grid_nc(const char *filename, const ctl_t *ctl, const grid_result *g, const double t) {
+  nccw_file *w = ncw_create(filename);
+  int dim[5];
+  NCW(dim[0] = nccw_def_dim(w, "time", 1));
+  NCW(dim[1] = nccw_def_dim(w, "z", ctl->grid_nz));
+  NCW(dim[2] = nccw_def_dim(w, "lat", ctl->grid_ny));
+  NCW(dim[3] = nccw_def_dim(w, "lon", ctl->grid_nx));
+  NCW(dim[4] = nccw_def_dim(w, "dz", 1));
+  ncw_var(w, "time", NCC_DOUBLE, 1, &dim[0], "time", "seconds since 2000-01-01 00:00:00 UTC");
+  ncw_var(w, "z", NCC_DOUBLE, 1, &dim[1], "altitude", "km");
+  ncw_var(w, "lat", NCC_DOUBLE, 1, &dim[2], "latitude", "degrees_north");
+  ncw_var(w, "lon", NCC_DOUBLE, 1, &dim[3], "longitude", "degrees_east");
+  ncw_var(w, "dz", NCC_DOUBLE, 1, &dim[1], "layer depth", "km");
+  ncw_var(w, "area", NCC_DOUBLE, 1, &dim[2], "surface area", "km**2");
+  ncw_var(w, "cd", NCC_FLOAT, 4, dim, "column density", "kg m**-2");
+  ncw_var(w, "vmr_impl", NCC_FLOAT, 4, dim, "volume mixing ratio (implicit)", "ppv");
+  ncw_var(w, "np", NCC_INT, 4, dim, "number of particles", "1");
+  char name[2 * LEN], longname[2 * LEN];
+  for (int pass = 0; pass < (ctl->grid_stddev ? 2 : 1); pass++)
+    for (int q = 0; q < ctl->nq; q++) {
+      sprintf(name, "%s_%s", ctl->qnt_name[q], pass ? "stddev" : "mean");
+      sprintf(longname, "%s (%s)", ctl->qnt_longname[q], pass ? "stddev" : "mean");
+      ncw_var(w, name, NCC_DOUBLE, 4, dim, longname, ctl->qnt_unit[q]);
+    }
+  NCW(nccw_enddef(w));
+  ncw_put(w, "time", 0, &t);
+  ncw_put(w, "lon", 0, g->lon);
+  ncw_put(w, "lat", 0, g->lat);
+  ncw_put(w, "z", 0, g->z);
+  ncw_put(w, "area", 0, g->area);
+  {
+    /* (the variable dz has nz elements; the reference writes the one layer depth, the rest stays unset) */
+    double *depth;
+    ALLOC(depth, double, ctl->grid_nz);
+    depth[0] = g->step_z;
+    ncw_put(w, "dz", 0, depth);
+    free(depth);
+  }
+  /* [lon][lat][z] of the sums -> [z][lat][lon] of the file */
+  double *turned;
+  ALLOC(turned, double, g->ncell);
+#define TURN(expr)                                                                                  \
+  for (int i = 0; i < ctl->grid_nx; i++)                                                            \
+    for (int j = 0; j < ctl->grid_ny; j++)                                                          \
+      for (int k = 0; k < ctl->grid_nz; k++) {                                                      \
+        const size_t cell = (size_t) ARRAY_3D(i, j, ctl->grid_ny, k, ctl->grid_nz);                 \
+        turned[ARRAY_3D(k, j, ctl->grid_ny, i, ctl->grid_nx)] = (expr);                             \
+      }
+  TURN(g->cd[cell]);
+  ncw_put(w, "cd", 0, turned);
+  TURN(g->vmr_impl[cell]);
+  ncw_put(w, "vmr_impl", 0, turned);
+  TURN((double) g->np[cell]);
+  ncw_put(w, "np", 0, turned);
+  for (int pass = 0; pass < (ctl->grid_stddev ? 2 : 1); pass++)
+    for (int q = 0; q < ctl->nq; q++) {
+      sprintf(name, "%s_%s", ctl->qnt_name[q], pass ? "stddev" : "mean");
+      TURN((pass ? g->sigma : g->mean)[(size_t) q * g->ncell + cell]);
+      ncw_put(w, name, 0, turned);
+    }
+#undef TURN
+  free(turned);
+  NCW(nccw_close(w));
+}
+
+void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1, const atm_t *atm,
+                const double t) {
+  /* Binning and sums on the device (mphip_grid_sums; mptrac.c:13815-13872),
+   * post-processing as mptrac.c:13875-13918, layout as write_grid_asc / write_grid_nc;
+   * the implicit volume mixing ratio (MOLMASS set, mass quantity present) uses
+   * the temperature at the cell centre, interpolated on the host as in the
+   * reference. */
+  (void) atm;
+  if (ctl->met_coord_type != 0)
+    ERRMSG("Only lat/lon grid supported");
+  LOG(1, "Write grid data: %s", filename);
+  grid_result g;
+  memset(&g, 0, sizeof(g));
+  g.ncell = (size_t) ctl->grid_nx * (size_t) ctl->grid_ny * (size_t) ctl->grid_nz;
+  const size_t nqa = (size_t) (ctl->nq > 0 ? ctl->nq : 1);
+  ALLOC(g.np, int, g.ncell);
+  ALLOC(g.mean, double, g.ncell * nqa);
+  ALLOC(g.sigma, double, g.ncell * nqa);
+  HIP(mphip_grid_sums(g_ctx, t, g.np, g.mean, g.sigma));   /* summed over the ranks of the job */
+  if (g_rank != 0) {                                        /* rank 0 writes the file */
+    grid_result_free(&g);
+    return;
+  }
+  g.step_z = (ctl->grid_z1 - ctl->grid_z0) / ctl->grid_nz;
+  g.step_lon = (ctl->grid_lon1 - ctl->grid_lon0) / ctl->grid_nx;
+  g.step_lat = (ctl->grid_lat1 - ctl->grid_lat0) / ctl->grid_ny;
+  ALLOC(g.z, double, ctl->grid_nz);
+  ALLOC(g.lon, double, ctl->grid_nx);
+  ALLOC(g.lat, double, ctl->grid_ny);
+  ALLOC(g.area, double, ctl->grid_ny);
+  ALLOC(g.cd, double, g.ncell);
+  ALLOC(g.vmr_impl, double, g.ncell);
+  for (int k = 0; k < ctl->grid_nz; k++)
+    g.z[k] = ctl->grid_z0 + g.step_z * (k + 0.5);
+  for (int i = 0; i < ctl->grid_nx; i++)
+    g.lon[i] = ctl->grid_lon0 + g.step_lon * (i + 0.5);
+  for (int j = 0; j < ctl->grid_ny; j++) {
+    g.lat[j] = ctl->grid_lat0 + g.step_lat * (j + 0.5);
+    g.area[j] = g.step_lat * g.step_lon * SQR(RE * M_PI / 180.) * cos(DEG2RAD(g.lat[j]));
+  }
+  for (int i = 0; i < ctl->grid_nx; i++)
+    for (int j = 0; j < ctl->grid_ny; j++)
+      for (int k = 0; k < ctl->grid_nz; k++) {
+        const size_t cell = (size_t) ARRAY_3D(i, j, ctl->grid_ny, k, ctl->grid_nz);
+        const double mass = ctl->qnt_m >= 0 ? g.mean[(size_t) ctl->qnt_m * g.ncell + cell] : NAN;
+        g.cd[cell] = mass / (1e6 * g.area[j]);
+        /* implicit volume mixing ratio from the mass in the cell and the air density at its centre (mptrac.c:13885-13900) */
+        g.vmr_impl[cell] = NAN;
+        if (ctl->qnt_m >= 0 && ctl->molmass > 0 && met0 && met1) {
+          g.vmr_impl[cell] = 0;
+          if (mass > 0) {
+            const double press = P(g.z[k]);
+            const double temp = mptrac_amd_intpol_3d(met0, met1, offsetof(met_t, t), t, press, g.lon[i], g.lat[j]);
+            g.vmr_impl[cell] = MA / ctl->molmass * g.cd[cell] / (100. * press / (RA * temp) * g.step_z * 1e3);
+          }
+        }
+        /* sums -> mean and standard deviation (after the column density: it uses the summed mass) */
+        for (int q = 0; q < ctl->nq; q++) {
+          double *mean = &g.mean[(size_t) q * g.ncell + cell], *sigma = &g.sigma[(size_t) q * g.ncell + cell];
+          if (g.np[cell] > 0) {
+            *mean /= g.np[cell];
+            const double var = *sigma / g.np[cell] - SQR(*mean);
+            *sigma = var > 0 ? sqrt(var) : 0;
+          } else
+            *mean = *sigma = NAN;
+        }
+      }
+  if (ctl->grid_type == 0)
+    write_grid_asc(filename, ctl, &g, t);
+  else
+    write_grid_nc(filename, ctl, &g, t);
+  grid_result_free(&g);
+}
+
+int mptrac_amd_world(void) {
+  return g_world;
 }
 
 void mptrac_write_output(const char *dirname, const ctl_t *ctl, met_t *met0, met_t *met1, atm_t *atm,
                          depo_t *depo, const double t) {
-  /* atm and grid branches of mptrac.c:8230-8275 */
+  /* mptrac.c:8230-8330 without the radioactive deposition output */
   (void) depo;
-  char ext[10], filename[2 * LEN];
+  char filename[2 * LEN], stamp[64];
   double r;
   int year, mon, day, hour, min, sec;
   jsec2time(t, &year, &mon, &day, &hour, &min, &sec, &r);
-  if (ctl->atm_basename[0] != '-' && (fmod(t, ctl->atm_dt_out) == 0 || t == ctl->t_stop)) {
+  sprintf(stamp, "%04d_%02d_%02d_%02d_%02d_%02d", year, mon, day, hour, min, sec);
+  const int atm_due = ctl->atm_basename[0] != '-' && (fmod(t, ctl->atm_dt_out) == 0 || t == ctl->t_stop);
+  const int grid_due = ctl->grid_basename[0] != '-' && fmod(t, ctl->grid_dt_out) == 0;
+  const int ens_due = ctl->ens_basename[0] != '-' && fmod(t, ctl->ens_dt_out) == 0;
+  const int vtk_due = ctl->vtk_basename[0] != '-' && fmod(t, ctl->vtk_dt_out) == 0;
+  /* the analysis outputs that look at the particles in every time step */
+  const int every_step = ctl->csi_basename[0] != '-' || ctl->prof_basename[0] != '-' || ctl->sample_basename[0] != '-'
+    || ctl->stat_basename[0] != '-';
+  if ((ens_due || vtk_due || every_step) && g_world > 1)
+    ERRMSG("CSI, ensemble, profile, sample, station and VTK output need all particles in one process!");
+  if (atm_due || ens_due || vtk_due || every_step)
     mptrac_update_host(NULL, NULL, NULL, NULL, NULL, atm);
-    sprintf(ext, ctl->atm_type_out == 0 ? "tab" : "bin");
-    sprintf(filename, "%s/%s_%04d_%02d_%02d_%02d_%02d_%02d.%s", dirname, ctl->atm_basename, year, mon, day,
-            hour, min, sec, ext);
+  if (atm_due) {
+    sprintf(filename, "%s/%s_%s.%s", dirname, ctl->atm_basename, stamp,
+            ctl->atm_type_out == 0 ? "tab" : ctl->atm_type_out == 1 ? "bin" : "nc");
     if (g_world > 1)   /* every rank writes its index range: <name>.rank<k> */
       sprintf(filename + strlen(filename), ".rank%d", g_rank);
     mptrac_write_atm(filename, ctl, atm, t);
   }
-  if (ctl->grid_basename[0] != '-' && fmod(t, ctl->grid_dt_out) == 0) {
-    sprintf(filename, "%s/%s_%04d_%02d_%02d_%02d_%02d_%02d.tab", dirname, ctl->grid_basename, year, mon, day,
-            hour, min, sec);
+  if (grid_due) {
+    sprintf(filename, "%s/%s_%s.%s", dirname, ctl->grid_basename, stamp, ctl->grid_type == 0 ? "tab" : "nc");
     write_grid(filename, ctl, met0, met1, atm, t);
+  }
+  if (ctl->csi_basename[0] != '-') {
+    sprintf(filename, "%s/%s.tab", dirname, ctl->csi_basename);
+    write_csi(filename, ctl, atm, t);
+  }
+  if (ens_due) {
+    sprintf(filename, "%s/%s_%s.tab", dirname, ctl->ens_basename, stamp);
+    write_ens(filename, ctl, atm, t);
+  }
+  if (ctl->prof_basename[0] != '-') {
+    sprintf(filename, "%s/%s.tab", dirname, ctl->prof_basename);
+    write_prof(filename, ctl, met0, met1, atm, t);
+  }
+  if (ctl->sample_basename[0] != '-') {
+    sprintf(filename, "%s/%s.tab", dirname, ctl->sample_basename);
+    write_sample(filename, ctl, met0, met1, atm, t);
+  }
+  if (ctl->stat_basename[0] != '-') {
+    sprintf(filename, "%s/%s.tab", dirname, ctl->stat_basename);
+    write_station(filename, ctl, atm, t);
+    /* write_station marks the particles it has listed in the quantity "stat" of the host copy; on the
+     * reference's CPU path that is the model state, so the marks go back to the device */
+    if (ctl->qnt_stat >= 0)
+      HIP(mphip_update_quantity(g_ctx, ctl->qnt_stat, atm->q[ctl->qnt_stat]));
+  }
+  if (vtk_due) {
+    static int nvtk;
+    if (t == ctl->t_start)
+      nvtk = 0;
+    sprintf(filename, "%s/%s_%05d.vtk", dirname, ctl->vtk_basename, ++nvtk);
+    write_vtk(filename, ctl, atm, t);
   }
 }
 

@@ -74,6 +74,17 @@ extern "C" {
 #define SQR(x) ((x) * (x))
 #define DEG2RAD(deg) ((deg) * (M_PI / 180.0))
 #define ARRAY_3D(ix, iy, ny, iz, nz) (((ix) * (ny) + (iy)) * (nz) + (iz))
+#define ARRAY_2D(ix, iy, ny) ((ix) * (ny) + (iy))
+#define RAD2DEG(rad) ((rad) * (180.0 / M_PI))
+#ifndef NENS
+#define NENS 2000             /* ensemble members of the analysis outputs, mptrac.h:584 */
+#endif
+#ifndef NCSI
+#define NCSI 1000000          /* grid boxes in the verification statistics, mptrac.h:579 */
+#endif
+#ifndef NOBS
+#define NOBS 10000000         /* observations, mptrac.h:589 */
+#endif
 
 /* logging as the reference (mptrac.h:2303-2410): ERRMSG prints and exits */
 #define LOG(level, ...) {                                               \
@@ -112,8 +123,8 @@ extern "C" {
 typedef struct {
   /* quantities */
   int nq;
-  char qnt_name[NQ][LEN], qnt_unit[NQ][LEN], qnt_format[NQ][LEN];
-  int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens, qnt_loss_rate;
+  char qnt_name[NQ][LEN], qnt_longname[NQ][LEN], qnt_unit[NQ][LEN], qnt_format[NQ][LEN];
+  int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens, qnt_stat, qnt_loss_rate;
   int qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry, qnt_zeta, qnt_eta, qnt_aoa;
   /* module_meteo outputs: qnt_ps, qnt_ts, ..., qnt_tice (mptrac.h:2518-2740) */
 #define X(n, u) int qnt_##n;
@@ -153,7 +164,24 @@ typedef struct {
   double grid_dt_out;
   int grid_sparse, grid_stddev;
   double grid_z0, grid_z1, grid_lon0, grid_lon1, grid_lat0, grid_lat1;
-  int grid_nx, grid_ny, grid_nz;
+  int grid_nx, grid_ny, grid_nz, grid_type;
+  /* the other writers of mptrac_write_output (mptrac.h:3227-3423) */
+  int obs_type;
+  char csi_basename[LEN], csi_kernel[LEN], csi_obsfile[LEN];
+  double csi_dt_out, csi_obsmin, csi_modmin, csi_z0, csi_z1, csi_lon0, csi_lon1, csi_lat0, csi_lat1;
+  int csi_nx, csi_ny, csi_nz;
+  char ens_basename[LEN];
+  double ens_dt_out;
+  char prof_basename[LEN], prof_obsfile[LEN];
+  double prof_z0, prof_z1, prof_lon0, prof_lon1, prof_lat0, prof_lat1;
+  int prof_nx, prof_ny, prof_nz;
+  char sample_basename[LEN], sample_kernel[LEN], sample_obsfile[LEN];
+  double sample_dx, sample_dz;
+  char stat_basename[LEN];
+  double stat_lon, stat_lat, stat_r, stat_t0, stat_t1;
+  char vtk_basename[LEN];
+  double vtk_dt_out, vtk_scale, vtk_offset;
+  int vtk_stride, vtk_sphere;
   double molmass;
   char species[LEN];
   /* back-end options (no reference counterpart) */
@@ -260,6 +288,27 @@ void clim_tropo_init(clim_t *clim);                                             
 void module_timesteps_init(ctl_t *ctl, const atm_t *atm);                       /* mptrac.c:6046 */
 void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1, const atm_t *atm,
                 const double t);                                                /* mptrac.c:13751 */
+/* analysis outputs (host/output.c); they work on the particles the caller downloaded */
+void write_csi(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t);       /* mptrac.c:13188 */
+void write_ens(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t);       /* mptrac.c:13475 */
+void write_prof(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1, const atm_t *atm,
+                const double t);                                                /* mptrac.c:14683 */
+void write_sample(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1, const atm_t *atm,
+                  const double t);                                              /* mptrac.c:14918 */
+void write_station(const char *filename, const ctl_t *ctl, atm_t *atm, const double t);         /* mptrac.c:15083 */
+void write_vtk(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t);       /* mptrac.c:15172 */
+void read_obs(const char *filename, const ctl_t *ctl, double *rt, double *rz, double *rlon, double *rlat,
+              double *robs, int *nobs);                                         /* mptrac.c:12333 */
+void read_kernel(const char *filename, double kz[EP], double kw[EP], int *nk);  /* mptrac.c:8846 */
+double kernel_weight(const double kz[EP], const double kw[EP], const int nk, const double p);   /* mptrac.c:3298 */
+void geo2cart(const double z, const double lon, const double lat, double *x);   /* mptrac.c:2601 */
+void cart2geo(const double *x, double *z, double *lon, double *lat);            /* mptrac.c:74 */
+int mptrac_amd_read_obs_nc(const char *filename, double *rt, double *rz, double *rlon, double *rlat, double *robs);
+int mptrac_amd_world(void);   /* processes that share this run (1 without a launcher) */
+/* a level field (selected by its offset in met_t) at a point, both snapshots blended in time: what
+ * intpol_met_time_3d returns (mptrac.c:3112-3137) -- for the few profile / sample points of the writers */
+double mptrac_amd_intpol_3d(const met_t *met0, const met_t *met1, size_t field_offset, double ts, double p,
+                            double lon, double lat);
 
 /* ---- one process per GPU (no reference counterpart) -------------------------- */
 /* The reference's driver binds MPI ranks to devices and gives every rank its own work directories

@@ -413,3 +413,350 @@ int ncc_read_short(ncc_file *nc, int var, long long rec, long long first, long l
   free(buf);
   return 1;
 }
+
+/* ==========================================================================================================
+ * Writer: CDF-2 files (classic data model, 64-bit offsets) -- what the host layer's netCDF outputs need:
+ * dimensions (one of them may be the record dimension), text attributes, variables of type int / float /
+ * double, whole-variable writes and record-by-record appends.  Files written here can be read by any netCDF
+ * library; the reference writes netCDF-4 (HDF5) files with the same names, dimensions and attributes.
+ * ========================================================================================================== */
+
+typedef struct {
+  char *name;
+  char *text;
+} nccw_att;
+
+typedef struct {
+  char *name;
+  int type, ndims, dimid[8];
+  int natt;
+  nccw_att att[8];
+  int is_record;
+  long long nelem;   /* elements of the whole variable, or of one record */
+  long long vsize, begin;
+} nccw_var;
+
+struct nccw_file {
+  FILE *f;
+  char *path;
+  int defined;
+  int ndim, rec_dim;
+  char *dim_name[16];
+  long long dim_len[16];
+  int natt;
+  nccw_att att[16];
+  int nvar;
+  nccw_var var[64];
+  long long recsize, rec_begin, numrecs;
+  char err[256];
+};
+
+static char *dup_str(const char *s) {
+  char *d = malloc(strlen(s) + 1);
+  if (d)
+    strcpy(d, s);
+  return d;
+}
+
+nccw_file *nccw_create(const char *path) {
+  nccw_file *w = calloc(1, sizeof(nccw_file));
+  if (!w)
+    return NULL;
+  w->f = fopen(path, "w+b");
+  w->path = dup_str(path);
+  w->rec_dim = -1;
+  if (!w->f || !w->path) {
+    nccw_close(w);
+    return NULL;
+  }
+  return w;
+}
+
+const char *nccw_error(const nccw_file *w) {
+  return w ? w->err : "no file";
+}
+
+static int wfail(nccw_file *w, const char *msg) {
+  snprintf(w->err, sizeof(w->err), "%s", msg);
+  return -1;
+}
+
+int nccw_def_dim(nccw_file *w, const char *name, long long len) {
+  if (w->defined || w->ndim >= 16)
+    return wfail(w, "cannot define another dimension");
+  if (len == 0) {
+    if (w->rec_dim >= 0)
+      return wfail(w, "only one record dimension");
+    w->rec_dim = w->ndim;
+  }
+  w->dim_name[w->ndim] = dup_str(name);
+  w->dim_len[w->ndim] = len;
+  return w->ndim++;
+}
+
+int nccw_def_var(nccw_file *w, const char *name, int type, int ndims, const int *dimids) {
+  if (w->defined || w->nvar >= 64 || ndims > 8 || !type_size(type))
+    return wfail(w, "cannot define another variable");
+  nccw_var *v = &w->var[w->nvar];
+  memset(v, 0, sizeof(*v));
+  v->name = dup_str(name);
+  v->type = type;
+  v->ndims = ndims;
+  v->nelem = 1;
+  for (int d = 0; d < ndims; d++) {
+    if (dimids[d] < 0 || dimids[d] >= w->ndim)
+      return wfail(w, "unknown dimension");
+    v->dimid[d] = dimids[d];
+    if (dimids[d] == w->rec_dim) {
+      if (d != 0)
+        return wfail(w, "the record dimension must come first");
+      v->is_record = 1;
+    } else
+      v->nelem *= w->dim_len[dimids[d]];
+  }
+  return w->nvar++;
+}
+
+int nccw_put_att_text(nccw_file *w, int var, const char *name, const char *text) {
+  if (w->defined)
+    return wfail(w, "attributes belong to the definition phase");
+  nccw_att *a;
+  if (var < 0) {
+    if (w->natt >= 16)
+      return wfail(w, "too many global attributes");
+    a = &w->att[w->natt++];
+  } else {
+    if (var >= w->nvar || w->var[var].natt >= 8)
+      return wfail(w, "too many attributes");
+    a = &w->var[var].att[w->var[var].natt++];
+  }
+  a->name = dup_str(name);
+  a->text = dup_str(text);
+  return 0;
+}
+
+static void put_u32(FILE *f, uint32_t v) {
+  const unsigned char b[4] = { (unsigned char) (v >> 24), (unsigned char) (v >> 16), (unsigned char) (v >> 8),
+                               (unsigned char) v };
+  fwrite(b, 1, 4, f);
+}
+
+static void put_u64(FILE *f, uint64_t v) {
+  put_u32(f, (uint32_t) (v >> 32));
+  put_u32(f, (uint32_t) v);
+}
+
+static void put_padded(FILE *f, const char *s, size_t n) {
+  static const char zero[4] = { 0, 0, 0, 0 };
+  fwrite(s, 1, n, f);
+  fwrite(zero, 1, (4 - n % 4) % 4, f);
+}
+
+static void put_name(FILE *f, const char *s) {
+  put_u32(f, (uint32_t) strlen(s));
+  put_padded(f, s, strlen(s));
+}
+
+static void put_atts(FILE *f, int n, const nccw_att *a) {
+  put_u32(f, n ? TAG_ATT : 0);
+  put_u32(f, (uint32_t) n);
+  for (int i = 0; i < n; i++) {
+    put_name(f, a[i].name);
+    put_u32(f, T_CHAR);
+    put_u32(f, (uint32_t) strlen(a[i].text));
+    put_padded(f, a[i].text, strlen(a[i].text));
+  }
+}
+
+static size_t name_bytes(const char *s) {
+  return 4 + ((strlen(s) + 3) & ~(size_t) 3);
+}
+
+static size_t atts_bytes(int n, const nccw_att *a) {
+  size_t b = 8;
+  for (int i = 0; i < n; i++)
+    b += name_bytes(a[i].name) + 8 + ((strlen(a[i].text) + 3) & ~(size_t) 3);
+  return b;
+}
+
+static void write_header(nccw_file *w) {
+  FILE *f = w->f;
+  fseeko(f, 0, SEEK_SET);
+  fwrite("CDF\002", 1, 4, f);
+  put_u32(f, (uint32_t) w->numrecs);
+  put_u32(f, w->ndim ? TAG_DIM : 0);
+  put_u32(f, (uint32_t) w->ndim);
+  for (int d = 0; d < w->ndim; d++) {
+    put_name(f, w->dim_name[d]);
+    put_u32(f, (uint32_t) w->dim_len[d]);
+  }
+  put_atts(f, w->natt, w->att);
+  put_u32(f, w->nvar ? TAG_VAR : 0);
+  put_u32(f, (uint32_t) w->nvar);
+  for (int i = 0; i < w->nvar; i++) {
+    const nccw_var *v = &w->var[i];
+    put_name(f, v->name);
+    put_u32(f, (uint32_t) v->ndims);
+    for (int d = 0; d < v->ndims; d++)
+      put_u32(f, (uint32_t) v->dimid[d]);
+    put_atts(f, v->natt, v->att);
+    put_u32(f, (uint32_t) v->type);
+    put_u32(f, v->vsize > 0xffffffffLL ? 0xffffffffu : (uint32_t) v->vsize);
+    put_u64(f, (uint64_t) v->begin);
+  }
+}
+
+int nccw_enddef(nccw_file *w) {
+  if (w->defined)
+    return 0;
+  size_t header = 4 + 4 + 8;
+  for (int d = 0; d < w->ndim; d++)
+    header += name_bytes(w->dim_name[d]) + 4;
+  header += atts_bytes(w->natt, w->att) + 8;
+  for (int i = 0; i < w->nvar; i++)
+    header += name_bytes(w->var[i].name) + 4 + 4 * (size_t) w->var[i].ndims + atts_bytes(w->var[i].natt, w->var[i].att)
+      + 4 + 4 + 8;
+  long long at = (long long) header;
+  for (int i = 0; i < w->nvar; i++) {   /* fixed-size variables first, in order of definition */
+    nccw_var *v = &w->var[i];
+    v->vsize = (v->nelem * type_size(v->type) + 3) & ~3LL;
+    if (!v->is_record) {
+      v->begin = at;
+      at += v->vsize;
+    }
+  }
+  w->rec_begin = at;
+  w->recsize = 0;
+  for (int i = 0; i < w->nvar; i++)
+    if (w->var[i].is_record) {
+      w->var[i].begin = at + w->recsize;
+      w->recsize += w->var[i].vsize;
+    }
+  w->defined = 1;
+  write_header(w);
+  /* the file has its final fixed-size extent from the start (unwritten variables read as zeros) */
+  if (at > (long long) header) {
+    fseeko(w->f, (off_t) at - 1, SEEK_SET);
+    fputc(0, w->f);
+  }
+  return ferror(w->f) ? wfail(w, "cannot write the netCDF header") : 0;
+}
+
+static void encode(unsigned char *p, int type, double x) {
+  if (type == T_DOUBLE) {
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    for (int k = 0; k < 8; k++)
+      p[k] = (unsigned char) (u >> (56 - 8 * k));
+  } else if (type == T_FLOAT) {
+    const float fl = (float) x;
+    uint32_t u;
+    memcpy(&u, &fl, 4);
+    for (int k = 0; k < 4; k++)
+      p[k] = (unsigned char) (u >> (24 - 8 * k));
+  } else if (type == T_INT) {
+    const uint32_t u = (uint32_t) (int32_t) x;
+    for (int k = 0; k < 4; k++)
+      p[k] = (unsigned char) (u >> (24 - 8 * k));
+  } else if (type == T_SHORT) {
+    const uint16_t u = (uint16_t) (int16_t) x;
+    p[0] = (unsigned char) (u >> 8);
+    p[1] = (unsigned char) u;
+  } else
+    p[0] = (unsigned char) (signed char) x;
+}
+
+/* values of record `rec` (record variables; appends when rec == number of records so far) or of the whole
+ * variable, converted to the variable's type */
+int nccw_put_double(nccw_file *w, int var, long long rec, const double *data) {
+  if (!w->defined || var < 0 || var >= w->nvar)
+    return wfail(w, "bad variable");
+  const nccw_var *v = &w->var[var];
+  const int ts = type_size(v->type);
+  long long at = v->begin;
+  if (v->is_record) {
+    if (rec < 0 || rec > w->numrecs)
+      return wfail(w, "records are appended one after the other");
+    at += rec * w->recsize;
+  }
+  enum { CHUNK = 65536 };
+  unsigned char *buf = malloc((size_t) CHUNK * 8);
+  if (!buf)
+    return wfail(w, "out of memory");
+  fseeko(w->f, (off_t) at, SEEK_SET);
+  for (long long i0 = 0; i0 < v->nelem; i0 += CHUNK) {
+    const long long m = v->nelem - i0 < CHUNK ? v->nelem - i0 : CHUNK;
+    for (long long i = 0; i < m; i++)
+      encode(buf + i * ts, v->type, data[i0 + i]);
+    fwrite(buf, (size_t) ts, (size_t) m, w->f);
+  }
+  free(buf);
+  const long long pad = v->vsize - v->nelem * ts;
+  for (long long k = 0; k < pad; k++)
+    fputc(0, w->f);
+  if (v->is_record && rec == w->numrecs) {
+    w->numrecs = rec + 1;
+    /* the other record variables of this record exist (zeros) even if they are never written */
+    fseeko(w->f, (off_t) (w->rec_begin + w->numrecs * w->recsize - 1), SEEK_SET);
+    int c = fgetc(w->f);
+    if (c == EOF) {
+      fseeko(w->f, (off_t) (w->rec_begin + w->numrecs * w->recsize - 1), SEEK_SET);
+      fputc(0, w->f);
+    }
+    fseeko(w->f, 4, SEEK_SET);
+    put_u32(w->f, (uint32_t) w->numrecs);
+  }
+  return ferror(w->f) ? wfail(w, "write error") : 0;
+}
+
+int nccw_put_int(nccw_file *w, int var, long long rec, const int *data) {
+  if (!w->defined || var < 0 || var >= w->nvar)
+    return wfail(w, "bad variable");
+  const long long n = w->var[var].nelem;
+  double *tmp = malloc((size_t) (n > 0 ? n : 1) * sizeof(double));
+  if (!tmp)
+    return wfail(w, "out of memory");
+  for (long long i = 0; i < n; i++)
+    tmp[i] = data[i];
+  const int rc = nccw_put_double(w, var, rec, tmp);
+  free(tmp);
+  return rc;
+}
+
+int nccw_find_var(const nccw_file *w, const char *name) {
+  for (int i = 0; i < w->nvar; i++)
+    if (strcmp(w->var[i].name, name) == 0)
+      return i;
+  return -1;
+}
+
+long long nccw_numrecs(const nccw_file *w) {
+  return w->numrecs;
+}
+
+int nccw_close(nccw_file *w) {
+  if (!w)
+    return 0;
+  int rc = 0;
+  if (w->f) {
+    if (!w->defined)
+      nccw_enddef(w);
+    rc = ferror(w->f) || fclose(w->f) ? -1 : 0;
+  }
+  for (int d = 0; d < w->ndim; d++)
+    free(w->dim_name[d]);
+  for (int i = 0; i < w->natt; i++) {
+    free(w->att[i].name);
+    free(w->att[i].text);
+  }
+  for (int i = 0; i < w->nvar; i++) {
+    free(w->var[i].name);
+    for (int k = 0; k < w->var[i].natt; k++) {
+      free(w->var[i].att[k].name);
+      free(w->var[i].att[k].text);
+    }
+  }
+  free(w->path);
+  free(w);
+  return rc;
+}

@@ -1,4 +1,4 @@
-/* nc_classic.h -- classic netCDF (CDF-1 / CDF-2) reader of the host layer; see nc_classic.c */
+/* nc_classic.h -- classic netCDF (CDF-1 / CDF-2) reader and CDF-2 writer of the host layer; see nc_classic.c */
 #ifndef MPTRAC_AMD_NC_CLASSIC_H
 #define MPTRAC_AMD_NC_CLASSIC_H
 #define _FILE_OFFSET_BITS 64
@@ -23,4 +23,21 @@ int ncc_get_att(const ncc_file *nc, int var, const char *name, double *value);
 int ncc_read_double(ncc_file *nc, int var, long long rec, long long first, long long count, double *out);
 int ncc_read_float(ncc_file *nc, int var, long long rec, long long first, long long count, float *out);
 int ncc_read_short(ncc_file *nc, int var, long long rec, long long first, long long count, short *out);
+
+/* ---- writer (CDF-2) ---- */
+enum { NCC_BYTE = 1, NCC_CHAR = 2, NCC_SHORT = 3, NCC_INT = 4, NCC_FLOAT = 5, NCC_DOUBLE = 6 };
+typedef struct nccw_file nccw_file;
+
+nccw_file *nccw_create(const char *path);                           /* NULL: cannot create the file */
+const char *nccw_error(const nccw_file *w);
+int nccw_def_dim(nccw_file *w, const char *name, long long len);    /* len 0: the record dimension; returns the id, -1 on error */
+int nccw_def_var(nccw_file *w, const char *name, int type, int ndims, const int *dimids);   /* id, -1 on error */
+int nccw_put_att_text(nccw_file *w, int var, const char *name, const char *text);           /* var -1: global */
+int nccw_enddef(nccw_file *w);
+/* the whole variable, or record `rec` of a record variable (rec == records so far appends one); 0 = ok */
+int nccw_put_double(nccw_file *w, int var, long long rec, const double *data);
+int nccw_put_int(nccw_file *w, int var, long long rec, const int *data);
+int nccw_find_var(const nccw_file *w, const char *name);
+long long nccw_numrecs(const nccw_file *w);
+int nccw_close(nccw_file *w);
 #endif

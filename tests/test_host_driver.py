@@ -82,9 +82,11 @@ def test_trac_refuses_to_run_without_a_device(tmp_path):
     assert r.returncode != 0 and "HIP device" in out, out[-2000:]
 
 
-@pytest.mark.parametrize("args,msg", [(("CSI_BASENAME", "csi"), "CSI_BASENAME is not implemented"),
+@pytest.mark.parametrize("args,msg", [(("DEPO_BASENAME", "depo"), "DEPO_BASENAME is not implemented"),
                                       (("TRACER_CHEM", "1"), "TRACER_CHEM is not implemented"),
-                                      (("GRID_TYPE", "1"), "GRID_TYPE is not implemented"),
+                                      (("GRID_KERNEL", "kernel.tab"), "GRID_KERNEL is not implemented"),
+                                      (("GRID_NC_QUANT[1]", "3"), "quantisation of netCDF output"),
+                                      (("GRID_TYPE", "2"), "Set GRID_TYPE to 0 or 1"),
                                       (("ADVECT_VERT_COORD", "2"), "requires meteo data on model levels"),
                                       (("RNG_TYPE", "0"), "RNG_TYPE 1"),
                                       (("QNT_NAME[2]", "tnat"), "tnat")])
@@ -317,3 +319,91 @@ def test_trac_balloon_isosurface_and_boundary_conditions(tmp_path):
         assert cases.rel_err(got[k], ref[k]) <= 1e-10, (k, cases.rel_err(got[k], ref[k]))
     assert cases.rel_err(got["q"], ref["q"]) <= 1e-10
     assert np.all(got["p"] == got["p"][0]) and np.any(got["q"][0] > 3.9)
+
+
+@pytest.mark.gpu
+def test_trac_netcdf_and_analysis_outputs(tmp_path):
+    """The outputs besides ASCII / binary particle and grid files, through the drop-in driver on the GPU: the same
+    run once with text / binary files and once with netCDF files (GRID_TYPE 1, ATM_TYPE_OUT 2) plus every analysis
+    writer.  The netCDF files (own classic-format writer, read here by scipy) hold exactly the values of the
+    text / binary files; the station file lists every particle at most once -- its `stat` flag, set on the host
+    copy, is handed back to the device after every step (mphip_update_quantity, with the particles in the internal
+    locality order) -- and the final particle file carries as many flags as the station file has rows."""
+    from scipy.io import netcdf_file
+    quant = ("m", "rp", "rhop", "stat", "ens")
+    runs = {}
+    for name, extra in (("plain", {}),
+                        ("nc", {"GRID_TYPE": 1, "ATM_TYPE_OUT": 2, "ENS_BASENAME": "ens", "ENS_DT_OUT": 3600,
+                                "VTK_BASENAME": "cloud", "VTK_DT_OUT": 3600, "VTK_STRIDE": 50, "STAT_BASENAME": "station",
+                                "STAT_LON": 10, "STAT_LAT": 20, "STAT_R": 1500, "CSI_BASENAME": "csi", "CSI_DT_OUT": 3600,
+                                "CSI_OBSFILE": "obs.tab", "CSI_NX": 36, "CSI_NY": 18, "CSI_MODMIN": 1e-12,
+                                "CSI_OBSMIN": 0.5, "SAMPLE_BASENAME": "sample", "SAMPLE_OBSFILE": "obs.tab",
+                                "SAMPLE_DX": 800, "PROF_BASENAME": "prof", "PROF_OBSFILE": "obs.tab", "PROF_NX": 36,
+                                "PROF_NY": 18, "PROF_NZ": 10, "MOLMASS": 64})):
+        tmp = str(tmp_path / name)
+        os.makedirs(tmp)
+        keys = {"NQ": len(quant), "GRID_STDDEV": 1, "GRID_NZ": 3, "GRID_Z0": 0, "GRID_Z1": 30, "HIP_LOCALITY_SORT_INTERVAL": 3}
+        keys.update({"QNT_NAME[%d]" % i: q for i, q in enumerate(quant)})
+        keys.update(extra)
+        trac, mets, atm = _setup(tmp, n=4000, hours=1, extra=keys)
+        # particle file with the two extra quantities (flags zero, four ensemble members)
+        atm = synthetic_particles(4000, time=T0, quantities=quant)
+        atm["q"][3][:] = 0.0
+        atm["q"][4][:] = np.arange(4000) % 4
+        hf.write_atm_bin(os.path.join(tmp, "atm_in"), atm)
+        with open(os.path.join(tmp, "obs.tab"), "w") as f:      # observations at the last step of the hour
+            for lon in range(-175, 180, 10):
+                for lat in range(-85, 90, 10):
+                    f.write("%.2f 5 %d %d %g\n" % (T0 + 3600.0, lon, lat, float(lon > 0)))
+        r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, cwd=tmp)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        runs[name] = tmp
+    stamp = "2022_06_02_01_00_00"
+    # particles: netCDF == binary
+    want = hf.read_atm_bin(os.path.join(runs["plain"], "atm_%s.bin" % stamp), len(quant))
+    f = netcdf_file(os.path.join(runs["nc"], "atm_%s.nc" % stamp), "r", mmap=False)
+    assert np.array_equal(f.variables["time"][:], want["time"]) and np.array_equal(f.variables["press"][:], want["p"])
+    assert np.array_equal(f.variables["lon"][:], want["lon"]) and np.array_equal(f.variables["lat"][:], want["lat"])
+    for iq, q in enumerate(quant):
+        if q != "stat":
+            assert np.array_equal(f.variables[q][:], want["q"][iq]), q
+    flags = np.array(f.variables["stat"][:])
+    assert f.variables["m"].units == b"kg" and f.variables["ens"].long_name == b"ensemble index"
+    f.close()
+    # grid: netCDF [time][z][lat][lon] == the rows of the text table
+    rows = np.loadtxt(os.path.join(runs["plain"], "grid_%s.tab" % stamp))
+    f = netcdf_file(os.path.join(runs["nc"], "grid_%s.nc" % stamp), "r", mmap=False)
+    nx, ny, nz = 36, 18, 3
+    assert f.variables["cd"].shape == (1, nz, ny, nx) and f.variables["np"].shape == (1, nz, ny, nx)
+    table = rows.reshape(nx, ny, nz, -1)          # the text table runs lon, lat, z
+    def same(var, col, rel=0.0):
+        a = np.asarray(f.variables[var][0], dtype=np.float64).transpose(2, 1, 0)      # -> [lon][lat][z]
+        b = table[:, :, :, col]
+        ok = (np.isnan(a) & np.isnan(b)) | (np.abs(a - b) <= rel * np.abs(b)) | (a == b)
+        assert ok.all(), var
+    assert np.array_equal(f.variables["z"][:], table[0, 0, :, 1]) and np.array_equal(f.variables["lon"][:], table[:, 0, 0, 2])
+    assert np.allclose(f.variables["area"][:], table[0, :, 0, 4], rtol=1e-5)
+    same("np", 8)
+    same("cd", 6, 1e-5)                  # (a float variable against six printed digits)
+    for iq, q in enumerate(quant):
+        if q != "stat":
+            same(q + "_mean", 9 + iq, 1e-5)
+            same(q + "_stddev", 9 + len(quant) + iq, 1e-4)
+    assert f.variables["m_mean"].long_name == b"mass (mean)"
+    f.close()
+    # station: every particle once; the flags of the final particle file are the listed particles
+    rows = np.loadtxt(os.path.join(runs["nc"], "station.tab"), ndmin=2)
+    assert len(rows) > 20 and int(flags.sum()) == len(rows)
+    assert np.all(rows[:, 4 + quant.index("stat")] == 1)
+    # the other writers produced their files: one ensemble row with all particles, a VTK cloud of every 50th
+    ens = np.loadtxt(os.path.join(runs["nc"], "ens_%s.tab" % stamp), ndmin=2)
+    assert ens.shape == (1, 4 + 2 * len(quant) + 1) and ens[0, -1] == 4000
+    vtk = open(os.path.join(runs["nc"], "cloud_00002.vtk")).read()
+    assert "POINTS 80 float" in vtk and "SCALARS rhop float 1" in vtk
+    csi = np.loadtxt(os.path.join(runs["nc"], "csi.tab"), ndmin=2)
+    assert csi.shape[0] == 1 and csi[0, 0] == T0 + 3600.0 and csi[0, 5] > 100
+    sample = np.loadtxt(os.path.join(runs["nc"], "sample.tab"), ndmin=2)
+    assert sample.shape == (36 * 18, 10) and sample[:, 6].sum() > 1000
+    prof = np.loadtxt(os.path.join(runs["nc"], "prof.tab"), ndmin=2)
+    assert prof.shape[1] == 11 and prof.shape[0] % 10 == 0 and prof.shape[0] >= 10 and np.all(prof[:, 5] > 150)

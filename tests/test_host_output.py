@@ -1,0 +1,218 @@
+"""CPU tests of the host layer's outputs besides the ASCII / binary particle and grid files: the analysis writers
+(CSI, ensembles, profiles, samples, station, VTK) against the golden files of the reference's tests/trac_test,
+and the netCDF particle / grid files (classic format, own writer) against scipy's netCDF reader.
+
+The writers are host code that works on downloaded particles -- no device is involved; the library is only
+loaded."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from hostfiles import compile_c_test
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(HERE, "golden", "ref_trac_test")
+T_OBS = 360720000.0        # 2011-06-07 00:00 UTC: the time of the golden particle file and of every observation
+
+# tests/trac_test/run.sh: the thirteen quantities (the two chemistry tracers, which this build would refuse to
+# fill, are carried under neutral names -- the writers only print them) and the keys the writers read
+QUANTITIES = ["t", "u", "v", "w", "zg", "pv", "ps", "pt", "m", "stat", "ens", "qa", "qb"]
+GOLDEN_NAMES = {"qa": "Cccl3f", "qb": "Cx"}
+KEYS = {"DT_MOD": "300.0", "SPECIES": "SO2", "OH_CHEM_REACTION": "0", "CSI_OBSMIN": "1e-5", "CSI_MODMIN": "1e-5",
+        "SAMPLE_DZ": "100", "STAT_LON": "-22", "STAT_LAT": "-40", "VTK_STRIDE": "100"}
+
+
+def _run(out_dir, extra, atm=os.path.join(REF, "atm_pl_2011_06_07_00_00_00.tab"), quantities=QUANTITIES, t=T_OBS):
+    exe = compile_c_test("writers")
+    args = [exe, atm, str(out_dir), repr(t), "NQ", str(len(quantities))]
+    for i, q in enumerate(quantities):
+        args += [f"QNT_NAME[{i}]", q]
+        if q in GOLDEN_NAMES:
+            args += [f"QNT_UNIT[{i}]", "ppv"]
+    for k, v in {**KEYS, **extra}.items():
+        args += [k, v]
+    res = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "RESULT done" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+    return res.stdout
+
+
+def _rows(path):
+    """(header lines, numeric rows) of a text table; blank lines are kept as empty rows."""
+    head, rows = [], []
+    for line in open(path):
+        if line.startswith("#"):
+            head.append(line.rstrip("\n"))
+        else:
+            rows.append([float(x) for x in line.split()])
+    return head, rows
+
+
+def _golden_header(head):
+    for ours, theirs in GOLDEN_NAMES.items():
+        head = [h.replace(f"= {ours} ", f"= {theirs} ") for h in head]
+    return head
+
+
+def _close(a, b, rel):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return np.all(both_nan | (np.abs(a - b) <= rel * np.maximum(np.abs(b), 1e-300)) | (a == b))
+
+
+def test_ensemble_file_matches_the_reference_golden(tmp_path):
+    """write_ens on the golden particles = the golden ensemble file: same header, one row (quirk Q8: the
+    accumulators are addressed by the slot of the quantity `ens`), every value to the precision the six printed
+    digits of the input allow."""
+    _run(tmp_path, {"ENS_BASENAME": "ens"})
+    head, rows = _rows(tmp_path / "ens.tab")
+    ghead, grows = _rows(os.path.join(REF, "ens_pl_2011_06_07_00_00_00.tab"))
+    assert _golden_header(head) == ghead
+    rows, grows = [r for r in rows if r], [r for r in grows if r]
+    assert len(rows) == len(grows) == 1 and len(rows[0]) == len(grows[0]) == 4 + 2 * 13 + 1
+    assert rows[0][0] == grows[0][0] and rows[0][-1] == grows[0][-1] == 10000
+    assert _close(rows[0], grows[0], 2e-5), (rows[0], grows[0])
+
+
+def test_vtk_file_matches_the_reference_golden(tmp_path):
+    """write_vtk on the golden particles (every 100th) = the golden VTK file, line for line (%g of the six-digit
+    inputs reproduces them; only the altitude goes through Z(P(z)))."""
+    _run(tmp_path, {"VTK_BASENAME": "cloud"})
+    ours = open(tmp_path / "cloud.vtk").read().split("\n")
+    gold = open(os.path.join(REF, "atm_pl_00003.vtk")).read().split("\n")
+    for a, b in GOLDEN_NAMES.items():
+        ours = [ln.replace(f"SCALARS {a} ", f"SCALARS {b} ") for ln in ours]
+    assert len(ours) == len(gold)
+    for a, b in zip(ours, gold):
+        if a == b:
+            continue
+        fa, fb = [float(x) for x in a.split()], [float(x) for x in b.split()]      # (a last digit of the altitude)
+        assert len(fa) == len(fb) and _close(fa, fb, 2e-5), (a, b)
+    assert sum(a == b for a, b in zip(ours, gold)) > 0.95 * len(gold)
+
+
+def test_csi_file_matches_the_reference_golden(tmp_path):
+    """write_csi at the observation time = the golden row: contingency counts exactly, scores and error
+    statistics (own Pearson / Spearman / error norms instead of GSL's) to input precision."""
+    _run(tmp_path, {"CSI_BASENAME": "csi", "CSI_OBSFILE": os.path.join(REF, "obs.tab")})
+    head, rows = _rows(tmp_path / "csi.tab")
+    ghead, grows = _rows(os.path.join(REF, "csi_pl.tab"))
+    assert head == ghead
+    rows, grows = [r for r in rows if r], [r for r in grows if r]
+    assert len(grows) == 1 and len(rows) == 1
+    r, g = rows[0], grows[0]
+    assert r[:7] == g[:7] and r[-1] == g[-1], (r, g)      # time, member, hits, misses, false alarms, n_obs, n_for, points
+    assert _close(r[7:-1], g[7:-1], 5e-5), (r, g)
+
+
+def test_sample_file_matches_the_reference_golden_where_no_meteo_data_enter(tmp_path):
+    """write_sample: one row per observation -- particle counts and column densities of the golden file (they
+    depend on the particles alone); the volume mixing ratio needs the run's temperature field, so it is only
+    compared where it is zero."""
+    _run(tmp_path, {"SAMPLE_BASENAME": "sample", "SAMPLE_OBSFILE": os.path.join(REF, "obs.tab")})
+    head, rows = _rows(tmp_path / "sample.tab")
+    ghead, grows = _rows(os.path.join(REF, "sample_pl.tab"))
+    assert head == ghead
+    rows, grows = np.array([r for r in rows if r]), np.array([r for r in grows if r])
+    assert rows.shape == grows.shape and rows.shape[0] == 546
+    assert np.array_equal(rows[:, [0, 1, 2, 3, 5, 6, 9]], grows[:, [0, 1, 2, 3, 5, 6, 9]])
+    assert _close(rows[:, 4], grows[:, 4], 1e-6) and _close(rows[:, 7], grows[:, 7], 2e-5)
+    assert grows[:, 6].sum() > 50 and np.array_equal(rows[:, 8] == 0, grows[:, 8] == 0)
+    with_mass = grows[:, 8] > 0      # constant 250 K instead of the run's temperatures: the right magnitude
+    assert np.all(np.abs(rows[with_mass, 8] / grows[with_mass, 8] - 1) < 0.3)
+
+
+def test_profile_file_matches_the_reference_golden_where_no_meteo_data_enter(tmp_path):
+    """write_prof: the same profiles (columns with observations and particle mass) at the same levels with the
+    same observation means and counts as the golden file; zero mixing ratio where the golden one is zero."""
+    _run(tmp_path, {"PROF_BASENAME": "prof", "PROF_OBSFILE": os.path.join(REF, "obs.tab")})
+    head, rows = _rows(tmp_path / "prof.tab")
+    ghead, grows = _rows(os.path.join(REF, "prof_pl.tab"))
+    assert head == ghead
+    assert [bool(r) for r in rows] == [bool(r) for r in grows]          # the same blocks
+    rows, grows = np.array([r for r in rows if r]), np.array([r for r in grows if r])
+    assert rows.shape == grows.shape and rows.shape[0] == 3000
+    assert np.array_equal(rows[:, [0, 1, 2, 3, 4, 9, 10]], grows[:, [0, 1, 2, 3, 4, 9, 10]])
+    assert np.array_equal(rows[:, 6] == 0, grows[:, 6] == 0)
+    assert np.all(rows[:, 5] == 250.0) and np.all(rows[:, 7] == 1e-5) and np.all(rows[:, 8] == 1e-6)
+
+
+def test_station_file_lists_every_particle_once(tmp_path):
+    """write_station: the particles within STAT_R of the station, each with all quantities in the particle
+    file's own digits, and with a `stat` quantity each particle at most once."""
+    out = _run(tmp_path, {"STAT_BASENAME": "station", "STAT_R": "800"})
+    assert "RESULT done 10000" in out
+    head, rows = _rows(tmp_path / "station.tab")
+    rows = np.array([r for r in rows if r])
+    ahead, arows = _rows(os.path.join(REF, "atm_pl_2011_06_07_00_00_00.tab"))
+    atm = np.array([r for r in arows if r])
+    assert head[4:] == ahead[4:] or _golden_header(head)[4:] == ahead[4:]
+    # great-circle chord distance to the station, as the writer measures it
+    def xyz(lon, lat):
+        lam, phi = np.deg2rad(lon), np.deg2rad(lat)
+        return 6367.421 * np.stack([np.cos(phi) * np.cos(lam), np.cos(phi) * np.sin(lam), np.sin(phi)], axis=-1)
+    d2 = ((xyz(atm[:, 2], atm[:, 3]) - xyz(-22.0, -40.0)) ** 2).sum(axis=1)
+    inside = (d2 <= 800.0 ** 2) & (atm[:, 4 + QUANTITIES.index("stat")] == 0)      # (not listed by the run before)
+    assert (d2 <= 800.0 ** 2).sum() > inside.sum() > 0 and inside.sum() == len(rows)
+    want = atm[inside].copy()
+    want[:, 4 + QUANTITIES.index("stat")] = 1.0        # the flag is set before the line is printed (as in the reference)
+    assert _close(rows[:, 2:], want[:, 2:], 1e-12) and _close(rows[:, 1], want[:, 1], 2e-6)
+
+
+@pytest.mark.parametrize("atm_type_out", [2, 4])
+def test_netcdf_particle_files_round_trip_and_are_readable_by_scipy(tmp_path, atm_type_out):
+    """ATM_TYPE_OUT 2 (netCDF: dimension obs; time, press, lon, lat, one variable per quantity with long_name and
+    units) and 4 (CLaMS position file: NPARTS; LAT, LON, PRESS, ZETA, quantities [time][NPARTS]): written by the
+    host layer's own classic-netCDF writer, read back by its reader bit for bit, and readable by an independent
+    implementation of the format (scipy.io.netcdf_file) with the same values."""
+    from scipy.io import netcdf_file
+    quantities = ["m", "zeta_d", "ens"]
+    # a small text particle file
+    rng = np.random.default_rng(5)
+    n = 1234
+    cols = np.column_stack([np.full(n, 1000.0), rng.uniform(0.5, 30, n), rng.uniform(-180, 180, n),
+                            rng.uniform(-89, 89, n), rng.uniform(0, 5, n), rng.uniform(300, 2000, n),
+                            rng.integers(0, 4, n).astype(float)])
+    src = tmp_path / "in.tab"
+    np.savetxt(src, cols, fmt="%.17g")
+    out = _run(tmp_path, {"ATM_BASENAME": "out.nc", "ATM_TYPE_OUT": str(atm_type_out)}, atm=str(src),
+               quantities=quantities, t=1000.0)
+    assert "RESULT roundtrip identical" in out
+    f = netcdf_file(str(tmp_path / "out.nc"), "r", mmap=False)
+    names = {2: ("obs", "lon", "lat", "press"), 4: ("NPARTS", "LON", "LAT", "PRESS")}[atm_type_out]
+    assert f.dimensions[names[0]] == n
+    assert np.array_equal(f.variables[names[1]][:], cols[:, 2]) and np.array_equal(f.variables[names[2]][:], cols[:, 3])
+    press = 1013.25 * np.exp(-cols[:, 1] / 7.0)
+    assert np.allclose(f.variables[names[3]][:], press, rtol=1e-15)
+    m = f.variables["m"]
+    assert np.array_equal(np.asarray(m[:]).reshape(-1), cols[:, 4]) and m.units == b"kg"
+    if atm_type_out == 2:
+        assert m.long_name == b"mass" and f.featureType == b"point"
+        assert np.array_equal(f.variables["time"][:], cols[:, 0])
+    else:
+        assert f.model == b"MPTRAC" and m.shape == (1, n)
+        assert np.array_equal(f.variables["ZETA"][:], cols[:, 5])
+    f.close()
+
+
+def test_clams_trajectory_file_grows_by_one_record_per_output(tmp_path):
+    """ATM_TYPE_OUT 3: traj_fix_3d_<start>_<stop>.nc with an unlimited time dimension -- one record per call --
+    and, at the stop time, init_fix_<stop>.nc (a position file)."""
+    from scipy.io import netcdf_file
+    rng = np.random.default_rng(7)
+    n = 300
+    cols = np.column_stack([np.full(n, 86400.0), rng.uniform(1, 20, n), rng.uniform(-180, 180, n),
+                            rng.uniform(-80, 80, n), rng.uniform(0, 5, n), rng.uniform(300, 900, n)])
+    src = tmp_path / "in.tab"
+    np.savetxt(src, cols, fmt="%.17g")
+    _run(tmp_path, {"ATM_BASENAME": "ignored", "ATM_TYPE_OUT": "3"}, atm=str(src), quantities=["m", "zeta_d"], t=86400.0)
+    # 2000-01-02 00:00 is start and stop of the one-call run
+    traj = netcdf_file(str(tmp_path / "traj_fix_3d_00010200_00010200.nc"), "r", mmap=False)
+    assert traj.dimensions["time"] is None and traj.dimensions["NPARTS"] == n and traj.dimensions["TMDT"] == 7
+    assert traj.variables["LAT"].shape == (1, n) and np.array_equal(traj.variables["LAT"][0], cols[:, 3])
+    assert np.array_equal(traj.variables["m"][0], cols[:, 4]) and traj.variables["time"][0] == 86400.0
+    traj.close()
+    init = netcdf_file(str(tmp_path / "init_fix_00010200.nc"), "r", mmap=False)
+    assert np.array_equal(init.variables["LON"][:], cols[:, 2]) and np.array_equal(init.variables["ZETA"][:], cols[:, 5])
+    init.close()
