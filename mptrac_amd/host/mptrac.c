@@ -1036,10 +1036,16 @@ int mptrac_read_met(const char *filename, const ctl_t *ctl, const clim_t *clim, 
   return 1;
 }
 
+static void write_met_nc(const char *filename, const ctl_t *ctl, met_t *met);
+
 void mptrac_write_met(const char *filename, const ctl_t *ctl, met_t *met) {
   LOG(1, "Write meteo data: %s", filename);
+  if (ctl->met_type == 0) {
+    write_met_nc(filename, ctl, met);
+    return;
+  }
   if (ctl->met_type != 1)
-    ERRMSG("This build writes MET_TYPE 1 (raw binary) meteo files only!");
+    ERRMSG("This build writes MET_TYPE 0 (netCDF, classic format) and 1 (raw binary) meteo files!");
   FILE *out = fopen(filename, "w");
   REQUIRE(out, "Cannot create file!");
   const int head[2] = { ctl->met_type, 104 }, dims[3] = { met->nx, met->ny, met->np }, tail = 999;
@@ -1052,6 +1058,101 @@ void mptrac_write_met(const char *filename, const ctl_t *ctl, met_t *met) {
   met_bin_body(out, 1, met);
   put_items(out, &tail, sizeof(int), 1);
   fclose(out);
+}
+
+/* MET_TYPE 0 output (mptrac.c:14440-14618): dimensions time, lon / lat (x / y on Cartesian grids), lev; the
+ * surface fields as [time][lat][lon], the level fields as [time][lev][lat][lon], single precision, in the units
+ * of the ECMWF archives the reference reads (pressures in Pa, heights in m or as geopotential, humidity and ozone
+ * as mass mixing ratios) */
+static void write_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
+  (void) ctl;
+  static const struct {
+    const char *name, *longname, *units;
+    size_t offset;
+    double scale;
+  } surface[] = {
+    { "sp", "Surface pressure", "Pa", offsetof(met_t, ps), 100. },
+    { "z", "Geopotential", "m**2 s**-2", offsetof(met_t, zs), 1000. * 9.80665 },
+    { "t2m", "2 metre temperature", "K", offsetof(met_t, ts), 1. },
+    { "u10m", "10 metre U wind component", "m s**-1", offsetof(met_t, us), 1. },
+    { "v10m", "10 metre V wind component", "m s**-1", offsetof(met_t, vs), 1. },
+    { "iews", "Instantaneous eastward turbulent surface stress", "N m**-2", offsetof(met_t, ess), 1. },
+    { "inss", "Instantaneous northward turbulent surface stress", "N m**-2", offsetof(met_t, nss), 1. },
+    { "ishf", "Instantaneous surface sensible heat flux", "W m**-2", offsetof(met_t, shf), 1. },
+    { "lsm", "Land/sea mask", "-", offsetof(met_t, lsm), 1. },
+    { "sstk", "Sea surface temperature", "K", offsetof(met_t, sst), 1. },
+    { "blp", "Boundary layer pressure", "Pa", offsetof(met_t, pbl), 100. },
+    { "pt", "Tropopause pressure", "Pa", offsetof(met_t, pt), 100. },
+    { "tt", "Tropopause temperature", "K", offsetof(met_t, tt), 1. },
+    { "zt", "Tropopause height", "m", offsetof(met_t, zt), 1000. },
+    { "h2ot", "Tropopause water vapor", "ppv", offsetof(met_t, h2ot), 1. },
+    { "pct", "Cloud top pressure", "Pa", offsetof(met_t, pct), 100. },
+    { "pcb", "Cloud bottom pressure", "Pa", offsetof(met_t, pcb), 100. },
+    { "cl", "Total column cloud water", "kg m**2", offsetof(met_t, cl), 1. },
+    { "plcl", "Pressure at lifted condensation level (LCL)", "Pa", offsetof(met_t, plcl), 100. },
+    { "plfc", "Pressure at level of free convection (LFC)", "Pa", offsetof(met_t, plfc), 100. },
+    { "pel", "Pressure at equilibrium level (EL)", "Pa", offsetof(met_t, pel), 100. },
+    { "cape", "Convective available potential energy", "J kg**-1", offsetof(met_t, cape), 1. },
+    { "cin", "Convective inhibition", "J kg**-1", offsetof(met_t, cin), 1. },
+    { "o3c", "Total column ozone", "DU", offsetof(met_t, o3c), 1. },
+  }, level[] = {
+    { "t", "Temperature", "K", offsetof(met_t, t), 1. },
+    { "u", "U velocity", "m s**-1", offsetof(met_t, u), 1. },
+    { "v", "V velocity", "m s**-1", offsetof(met_t, v), 1. },
+    { "w", "Vertical velocity", "Pa s**-1", offsetof(met_t, w), 100. },
+    { "q", "Specific humidity", "kg kg**-1", offsetof(met_t, h2o), MH2O / MA },
+    { "o3", "Ozone mass mixing ratio", "kg kg**-1", offsetof(met_t, o3), MO3 / MA },
+    { "clwc", "Cloud liquid water content", "kg kg**-1", offsetof(met_t, lwc), 1. },
+    { "crwc", "Cloud rain water content", "kg kg**-1", offsetof(met_t, rwc), 1. },
+    { "ciwc", "Cloud ice water content", "kg kg**-1", offsetof(met_t, iwc), 1. },
+    { "cswc", "Cloud snow water content", "kg kg**-1", offsetof(met_t, swc), 1. },
+    { "cc", "Cloud cover", "-", offsetof(met_t, cc), 1. },
+  };
+  const int nsurface = (int) (sizeof(surface) / sizeof(surface[0])), nlevel = (int) (sizeof(level) / sizeof(level[0]));
+  const int lonlat = met->coord_type == 0;
+  nccw_file *w = ncw_create(filename);
+  int tid, xid, yid, lid;
+  NCW(tid = nccw_def_dim(w, "time", 1));
+  NCW(xid = nccw_def_dim(w, lonlat ? "lon" : "x", met->nx));
+  NCW(yid = nccw_def_dim(w, lonlat ? "lat" : "y", met->ny));
+  ncw_var(w, lonlat ? "lon" : "x", NCC_DOUBLE, 1, &xid, lonlat ? "longitude" : "x", lonlat ? "degrees_east" : "easting");
+  ncw_var(w, lonlat ? "lat" : "y", NCC_DOUBLE, 1, &yid, lonlat ? "latitude" : "y", lonlat ? "degrees_north" : "northing");
+  NCW(lid = nccw_def_dim(w, "lev", met->np));
+  ncw_var(w, "time", NCC_DOUBLE, 1, &tid, "time", "seconds since 2000-01-01 00:00:00 UTC");
+  ncw_var(w, "lev", NCC_DOUBLE, 1, &lid, "pressure", "Pa");
+  const int dims2[3] = { tid, yid, xid }, dims3[4] = { tid, lid, yid, xid };
+  for (int k = 0; k < nsurface; k++)
+    ncw_var(w, surface[k].name, NCC_FLOAT, 3, dims2, surface[k].longname, surface[k].units);
+  for (int k = 0; k < nlevel; k++)
+    ncw_var(w, level[k].name, NCC_FLOAT, 4, dims3, level[k].longname, level[k].units);
+  NCW(nccw_enddef(w));
+  ncw_put(w, "time", 0, &met->time);
+  ncw_put(w, lonlat ? "lon" : "x", 0, met->lon);
+  ncw_put(w, lonlat ? "lat" : "y", 0, met->lat);
+  double pa[EP];
+  for (int k = 0; k < met->np; k++)
+    pa[k] = 100. * met->p[k];
+  ncw_put(w, "lev", 0, pa);
+  double *turned;
+  ALLOC(turned, double, (size_t) met->nx * (size_t) met->ny * (size_t) met->np);
+  for (int k = 0; k < nsurface; k++) {   /* [x][y] of met_t -> [y][x]; scaled in single precision like the stored value */
+    const float (*f)[EY] = (const float (*)[EY]) ((const char *) met + surface[k].offset);
+    EACH_COLUMN(met, i, j)
+      turned[(size_t) j * (size_t) met->nx + (size_t) i] = (double) ((float) surface[k].scale * f[i][j]);
+    LOG(2, "Write 2-D variable: %s (netCDF)", surface[k].name);
+    ncw_put(w, surface[k].name, 0, turned);
+  }
+  for (int k = 0; k < nlevel; k++) {
+    const float (*f)[EY][EP] = (const float (*)[EY][EP]) ((const char *) met + level[k].offset);
+    EACH_COLUMN(met, i, j)
+      for (int l = 0; l < met->np; l++)
+        turned[((size_t) l * (size_t) met->ny + (size_t) j) * (size_t) met->nx + (size_t) i] =
+          (double) ((float) level[k].scale * f[i][j][l]);
+    LOG(2, "Write 3-D variable: %s (netCDF)", level[k].name);
+    ncw_put(w, level[k].name, 0, turned);
+  }
+  free(turned);
+  NCW(nccw_close(w));
 }
 
 /* -------------------------------------------------------------------------- */
@@ -1224,9 +1325,9 @@ static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
   REQUIRE(NC_3D(v, 1.0f, "v", "V"), "Cannot read meridional wind!");
   if (!NC_3D(w, 0.01f, "w", "W", "omega", "OMEGA"))   /* Pa/s -> hPa/s */
     WARN("Cannot read vertical velocity!");
-  if (!NC_3D(h2o, (float) (MA / 18.01528), "q", "Q", "sh", "SH"))   /* mass -> volume mixing ratio */
+  if (!NC_3D(h2o, (float) (MA / MH2O), "q", "Q", "sh", "SH"))   /* mass -> volume mixing ratio */
     WARN("Cannot read specific humidity!");
-  if (!NC_3D(o3, (float) (MA / 47.997), "o3", "O3"))
+  if (!NC_3D(o3, (float) (MA / MO3), "o3", "O3"))
     WARN("Cannot read ozone data!");
   const int have_cloud = NC_3D(lwc, 1.0f, "clwc", "CLWC") & NC_3D(rwc, 1.0f, "crwc", "CRWC")
     & NC_3D(iwc, 1.0f, "ciwc", "CIWC") & NC_3D(swc, 1.0f, "cswc", "CSWC");

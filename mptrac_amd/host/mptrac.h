@@ -64,6 +64,12 @@ extern "C" {
 #ifndef RI
 #define RI 8.3144598          /* ideal gas constant [J/(mol K)], mptrac.h:322 */
 #endif
+#ifndef MH2O
+#define MH2O 18.01528         /* molar mass of water vapour [g/mol], mptrac.h:295 */
+#endif
+#ifndef MO3
+#define MO3 48.00             /* molar mass of ozone [g/mol], mptrac.h:300 */
+#endif
 #define RA (1e3 * RI / MA)    /* specific gas constant of dry air, mptrac.h:317 */
 #define FMOD(x, y) ((x) - (int) ((x) / (y)) * (y))   /* mptrac.h:1121 */
 #ifndef M_PI

@@ -216,3 +216,30 @@ def test_clams_trajectory_file_grows_by_one_record_per_output(tmp_path):
     init = netcdf_file(str(tmp_path / "init_fix_00010200.nc"), "r", mmap=False)
     assert np.array_equal(init.variables["LON"][:], cols[:, 2]) and np.array_equal(init.variables["ZETA"][:], cols[:, 5])
     init.close()
+
+
+@pytest.mark.parametrize("coord_type", [0, 1])
+def test_meteo_snapshot_as_netcdf(tmp_path, coord_type):
+    """mptrac_write_met with MET_TYPE 0: the reference's variable names, dimension order ([time][lev][lat][lon]),
+    units and scalings (pressures in Pa, w in Pa/s, humidity and ozone as mass mixing ratios, surface height as
+    geopotential), readable by scipy; on a Cartesian grid the host layer's own reader returns the snapshot
+    (to the 1e-6 the float scalings allow).  (tests/c/met_nc.c)"""
+    from scipy.io import netcdf_file
+    exe = compile_c_test("met_nc")
+    res = subprocess.run([exe, str(tmp_path), str(coord_type)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT written")][-1].split()
+    t, ps23, w123, h2o640 = (float(x) for x in line[2:])
+    if coord_type == 1:
+        assert "RESULT readback same" in res.stdout
+    f = netcdf_file(str(tmp_path / "met_2001_02_03_04.nc"), "r", mmap=False)
+    xname, yname = ("lon", "lat") if coord_type == 0 else ("x", "y")
+    assert f.dimensions[xname] == 7 and f.dimensions[yname] == 5 and f.dimensions["lev"] == 4 and f.dimensions["time"] == 1
+    assert f.variables["time"][0] == t and np.array_equal(f.variables["lev"][:], [100000.0, 80000.0, 60000.0, 40000.0])
+    assert f.variables["sp"].shape == (1, 5, 7) and f.variables["w"].shape == (1, 4, 5, 7)
+    assert f.variables["sp"].units == b"Pa" and f.variables["q"].long_name == b"Specific humidity"
+    assert f.variables["sp"][0, 3, 2] == np.float32(100.0) * np.float32(ps23)
+    assert f.variables["w"][0, 3, 2, 1] == np.float32(100.0) * np.float32(w123)
+    assert f.variables["q"][0, 0, 4, 6] == np.float32(18.01528 / 28.9644) * np.float32(h2o640)
+    assert len(f.variables) == 4 + 24 + 11
+    f.close()
