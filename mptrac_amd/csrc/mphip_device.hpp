@@ -160,6 +160,11 @@ __device__ __forceinline__ Axes load_axes(const DevMet &M, double *smem) {
 #ifndef MPHIP_WIND_CACHE
 #define MPHIP_WIND_CACHE 1
 #endif
+// > 0: wave priority (s_setprio) while a wave computes the addresses of a gather round of the Runge-Kutta
+// stages and issues the loads -- the sooner a round is in flight, the more of its latency other waves cover
+#ifndef MPHIP_SETPRIO
+#define MPHIP_SETPRIO 0
+#endif
 
 __device__ __forceinline__ double div_const(double x, double y, double inv_y) {
 #if MPHIP_EXACT_DIV
@@ -2537,8 +2542,14 @@ __device__ __forceinline__ void advect_rk4_fast(const DevMet &M, const Axes &A, 
       x2 = P.p + dts * w;
     }
     Stencil s;
+#if MPHIP_SETPRIO
+    __builtin_amdgcn_s_setprio(MPHIP_SETPRIO);   // a wave on its way to a gather round goes first
+#endif
     stencil_3d_fast(M, A, x2, x0, x1, s);
     load_wind_cached32(M, s, wc);
+#if MPHIP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     hook(i);
     wind_cache_wait(wc);
     wind_uvw_fast(wc.c, s, time_weight(M, P.time + dts), u, v, w);

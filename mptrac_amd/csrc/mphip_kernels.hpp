@@ -715,7 +715,10 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
 // its dependent gathers delay the list and the barrier behind it.)
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void depo_kernel(const StepParams S) {
+#ifndef MPHIP_DEPO_WAVES_PER_SIMD
+#define MPHIP_DEPO_WAVES_PER_SIMD 4   // 112 VGPRs without scratch (132 when left to the compiler: three waves); C5 +2 %
+#endif
+__global__ __launch_bounds__(256, MPHIP_DEPO_WAVES_PER_SIMD) void depo_kernel(const StepParams S) {
   extern __shared__ double s_axes[];
   __shared__ int s_count;
   const DevMet &M = S.met;
