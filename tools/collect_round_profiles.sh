@@ -1,6 +1,6 @@
 set -u
 cd $GRAFT_REPO_ROOT
-T=r02c
+T=${1:-r03}
 bash tools/profile.sh $T > gpurun_out/${T}_profile.log 2>&1
 python tools/summarize_prof.py gpurun_out/prof_$T > gpurun_out/prof_$T/summary.txt 2>&1
 bash tools/profile_valu_mix.sh ${T}mix > gpurun_out/${T}_mix.log 2>&1

@@ -9,9 +9,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --device-warmup-ms 0 $*"   # (counters per launch: no scratch launches)
+# the kernel-stats pass is the DEFAULT bench command (the driver's), device warm-up included: its average
+# step_kernel<255u> duration is the one bench.py's roofline.kernel_ms has to agree with
+BENCH_STATS="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline $*"
 
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH_STATS > "$OUT/stats.log" 2>&1
 grep "^{" "$OUT/stats.log" | tail -1 > "$OUT/bench_under_profiler.json"
 
 pmc() {  # name, counters...

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --device-warmup-ms 0 $*"
 pmc() {
   local name=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "step_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1 || echo "pass $name failed"

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --workload C3m --steps 10 --warmup 2 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --workload C3m --steps 10 --warmup 2 --no-cpu-baseline --device-warmup-ms 0 $*"
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
 grep "^{" "$OUT/stats.log" | tail -1 > "$OUT/bench_under_profiler.json"
 for c in FETCH_SIZE WRITE_SIZE; do

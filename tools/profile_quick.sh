@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 120 python $ROOT/tools/gpu_ablate.py
-BENCH="python $ROOT/bench.py --steps 6 --warmup 1 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 6 --warmup 1 --no-cpu-baseline --device-warmup-ms 0"
 pmc() {
   local name=$1; shift
   timeout 120 rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/$name" -o pmc --kernel-include-regex "step_kernel" -- $BENCH > "$OUT/$name.log" 2>&1 || echo "pass $name failed"

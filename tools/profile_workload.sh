@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --workload $WL --steps 6 --warmup 1 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --workload $WL --steps 6 --warmup 1 --no-cpu-baseline --device-warmup-ms 0"
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o s -- $BENCH > "$OUT/stats.log" 2>&1
 pmc() {
   local name=$1; shift

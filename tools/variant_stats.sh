@@ -8,7 +8,7 @@ for tag in "$@"; do
   OUT=$R/gpurun_out/vs_$tag
   mkdir -p "$OUT"
   MPHIP_LIB=$R/mptrac_amd/lib/libmptrac_hip_$tag.so timeout 200 rocprofv3 --kernel-trace --stats -f csv -d "$OUT" -o s -- \
-    python $R/bench.py --no-cpu-baseline --workload $WL --steps 8 --warmup 2 > "$OUT/run.log" 2>&1
+    python $R/bench.py --no-cpu-baseline --workload $WL --steps 8 --warmup 2 --device-warmup-ms 0 > "$OUT/run.log" 2>&1
   echo "== $tag: $(grep '^{' "$OUT/run.log" | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('ms_per_step', round(d['ms_per_step'],4))")"
   python - "$OUT" "$PAT" <<'PY'
 import csv, re, sys
