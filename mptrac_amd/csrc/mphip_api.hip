@@ -915,8 +915,10 @@ void perm_swap(mphip_ctx *ctx, bool with_cache) {
 // buffer pairs; *cur_out = the pair that holds the result
 // (n_dev: the number of pairs lives on the device and n is only its upper bound)
 // (index_sort: the values are the positions 0, 1, 2 ...; vals[0] is not read, the first pass generates them)
+// (packed_first: the input is keys[0] read as n interleaved (key, value) pairs -- 2 n words that may overlap
+//  vals[0], which is then not read; the passes write to keys[1] / vals[1] first)
 int radix_passes(mphip_ctx *ctx, uint32_t *const keys[2], int *const vals[2], long long n, int key_bits, int *cur_out,
-                 const uint32_t *n_dev = nullptr, bool index_sort = false) {
+                 const uint32_t *n_dev = nullptr, bool index_sort = false, bool packed_first = false) {
   *cur_out = 0;
   if (n <= 0)
     return 0;
@@ -947,9 +949,10 @@ int radix_passes(mphip_ctx *ctx, uint32_t *const keys[2], int *const vals[2], lo
   int cur = 0;
   for (int pass = 0; pass < passes; pass++) {
     const int shift = bits * pass;
+    const int stride = packed_first && pass == 0 ? 2 : 1;
 #define SORT_PASS(B)                                                                                                   \
   hipLaunchKernelGGL(sort_hist_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur], n, shift,       \
-                     ntiles, ctx->d_counts, n_dev);                                                                    \
+                     ntiles, ctx->d_counts, n_dev, stride);                                                            \
   if (small)                                                                                                           \
     hipLaunchKernelGGL(sort_scan_local_kernel<kScanPerSmall>, dim3(nchunks), dim3(kScanThreads), 0, ctx->stream,       \
                        ctx->d_counts, m, d_chunks, n_dev, 1 << B);                                                     \
@@ -958,8 +961,9 @@ int radix_passes(mphip_ctx *ctx, uint32_t *const keys[2], int *const vals[2], lo
                        ctx->d_counts, m, d_chunks, n_dev, 1 << B);                                                     \
   hipLaunchKernelGGL(sort_scan_chunks_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, d_chunks, nchunks);         \
   hipLaunchKernelGGL(sort_scatter_kernel<B>, dim3(ntiles), dim3(kSortThreads), 0, ctx->stream, keys[cur],              \
-                     index_sort && pass == 0 ? (const int *) nullptr : vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,     \
-                     shift, ntiles, ctx->d_counts, d_chunks, chunk_shift, n_dev)
+                     index_sort && pass == 0 ? (const int *) nullptr                                                   \
+                                             : (stride == 2 ? (const int *) keys[cur] + 1 : vals[cur]),                \
+                     keys[cur ^ 1], vals[cur ^ 1], n, shift, ntiles, ctx->d_counts, d_chunks, chunk_shift, n_dev, stride)
     if (bits == 8) {
       SORT_PASS(8);
     } else if (bits == 9) {
@@ -1369,10 +1373,12 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
     int *slots[2] = { (int *) (base + n), (int *) (base + 3 * n) };
     uint32_t *first = base + 4 * n, *last = first + ntot;
     HIPCHK(hipMemsetAsync(first, 0, 2 * ntot * sizeof(uint32_t), ctx->stream));
+    // (cell, slot) pairs in external order, interleaved in the first half of the buffer; the first pass of the
+    // sort reads them from there and writes the second half
     hipLaunchKernelGGL(cell_slot_pairs_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_cell,
-                       ctx->ext_identity ? (const int *) nullptr : ctx->d_ext, n, (uint32_t) ntot, keys[0], slots[0]);
+                       ctx->ext_identity ? (const int *) nullptr : ctx->d_ext, n, (uint32_t) ntot, (uint2 *) base);
     int cur = 0;
-    if (radix_passes(ctx, keys, slots, n, bits_for(ntot), &cur))
+    if (radix_passes(ctx, keys, slots, n, bits_for(ntot), &cur, nullptr, false, true))
       return 1;
     hipLaunchKernelGGL(cell_bounds_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, keys[cur], n, (uint32_t) ntot,
                        first, last);

@@ -1005,7 +1005,8 @@ constexpr int kRadixMaxBits = 10;
 template <int BITS>
 __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t *__restrict__ keys, long long n,
                                                                  int shift, int ntiles, uint32_t *__restrict__ counts,
-                                                                 const uint32_t *__restrict__ n_dev = nullptr) {
+                                                                 const uint32_t *__restrict__ n_dev = nullptr,
+                                                                 int in_stride = 1) {   // 2: interleaved (key, value) pairs
   constexpr int kRadix = 1 << BITS;
   if (n_dev) {   // the number of pairs is only known on the device: the launch covers an upper bound, the
     n = (long long) *n_dev;   // counter layout follows the actual number of tiles
@@ -1022,7 +1023,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const uint32_t 
   for (int r = 0; r < kSortRounds; r++) {
     const long long i = base + r * kSortThreads + threadIdx.x;
     if (i < n)
-      atomicAdd(&h[(keys[i] >> shift) & (kRadix - 1)], 1u);
+      atomicAdd(&h[(keys[i * in_stride] >> shift) & (kRadix - 1)], 1u);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < kRadix; d += kSortThreads)
@@ -1118,7 +1119,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
                                                                     int ntiles, const uint32_t *__restrict__ offsets,
                                                                     const uint32_t *__restrict__ chunk_offsets,
                                                                     int chunk_shift,   // log2 of the scan's chunk length
-                                                                    const uint32_t *__restrict__ n_dev = nullptr) {
+                                                                    const uint32_t *__restrict__ n_dev = nullptr,
+                                                                    int in_stride = 1) {   // 2: the input is one array of (key, value) pairs
   constexpr int kRadix = 1 << BITS;
   if (n_dev) {
     n = (long long) *n_dev;
@@ -1150,8 +1152,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
   for (int r = 0; r < kSortRounds; r++) {
     const long long i = base + r * 64;
     const bool valid = i < n;
-    key[r] = valid ? keys_in[i] : 0xffffffffu;
-    val[r] = valid ? (vals_in ? vals_in[i] : (int) i) : 0;   // (no value array: the position itself, first pass of an index sort)
+    key[r] = valid ? keys_in[i * in_stride] : 0xffffffffu;
+    val[r] = valid ? (vals_in ? vals_in[i * in_stride] : (int) i) : 0;   // (no value array: the position itself, first pass of an index sort)
   }
   volatile uint32_t *cnt = s_cnt[wave];
 #pragma unroll
@@ -1835,12 +1837,13 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
 // chains are long, there are cells x values of them, and the lanes of a cell share the list reads.
 
 __global__ void cell_slot_pairs_kernel(const int *__restrict__ cell, const int *__restrict__ ext, long long n,
-                                       uint32_t outside, uint32_t *__restrict__ keys, int *__restrict__ slots) {
+                                       uint32_t outside, uint2 *__restrict__ pairs) {
+  // one 8-byte store per particle: the stores go all over the array (ext is a random permutation of the stored
+  // order), and a store costs a memory transaction whatever its width -- half as many as with two arrays
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
     const long long at = ext ? (long long) ext[i] : i;
     const int c = cell[i];
-    keys[at] = c >= 0 ? (uint32_t) c : outside;
-    slots[at] = (int) i;
+    pairs[at] = make_uint2(c >= 0 ? (uint32_t) c : outside, (uint32_t) i);
   }
 }
 
@@ -1858,6 +1861,9 @@ __global__ void cell_bounds_kernel(const uint32_t *__restrict__ keys, long long 
   }
 }
 
+#ifndef MPHIP_CHAIN_LOADS
+#define MPHIP_CHAIN_LOADS 8
+#endif
 template <class VALS>
 __global__ __launch_bounds__(256) void cell_sum_chains_kernel(VALS vals, const int *__restrict__ slots,
                                                               const uint32_t *__restrict__ first,
@@ -1877,13 +1883,19 @@ __global__ __launch_bounds__(256) void cell_sum_chains_kernel(VALS vals, const i
     for (int v = v0; v < nv; v += width) {
       double sum = 0.0;
       uint32_t k = b;
-      for (; k + 4 <= e; k += 4) {   // four loads in flight, added in order
-        const double x0 = vals.get(v, (long long) slots[k]), x1 = vals.get(v, (long long) slots[k + 1]);
-        const double x2 = vals.get(v, (long long) slots[k + 2]), x3 = vals.get(v, (long long) slots[k + 3]);
-        sum += x0;
-        sum += x1;
-        sum += x2;
-        sum += x3;
+      constexpr int kInFlight = MPHIP_CHAIN_LOADS;   // the walk is a chain of dependent loads: its speed is the
+      for (; k + kInFlight <= e; k += kInFlight) {   // number of them in flight; the additions stay in list order
+        int sl[kInFlight];
+        double x[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; u++)
+          sl[u] = slots[k + u];
+#pragma unroll
+        for (int u = 0; u < kInFlight; u++)
+          x[u] = vals.get(v, (long long) sl[u]);
+#pragma unroll
+        for (int u = 0; u < kInFlight; u++)
+          sum += x[u];
       }
       for (; k < e; k++)
         sum += vals.get(v, (long long) slots[k]);
