@@ -24,6 +24,7 @@
  *   mptrac_get_met        mptrac.c:6488-6491, 6513-6516  mptrac_hip_swap_met()   next to the pointer swap
  *   mptrac_run_timestep   mptrac.c:7862-8000   mptrac_hip_run_timestep(t); return;
  *   write_grid            mptrac.c:13836-13872 mptrac_hip_grid_sums(...)         instead of the binning loop
+ *   mptrac_write_output   mptrac.c:8320-8323   mptrac_hip_station_flags(ctl, atm) behind write_station
  */
 #ifdef MPTRAC_HIP
 
@@ -215,6 +216,14 @@ void mptrac_hip_run_timestep(const double t) {
 /* write_grid: np[idx], mean[iq][idx], sigma[iq][idx] as flat arrays with idx = ARRAY_3D(ix, iy, ny, iz, nz) */
 void mptrac_hip_grid_sums(const double t, int *np, double *mean, double *sigma) {
   HIPCALL(mphip_grid_sums(hip_ctx, t, np, mean, sigma));
+}
+
+/* write_station sets atm->q[qnt_stat] on the host copy (mptrac.c:15143-15145); on the reference's CPU path that
+ * is the model state of the next step (its OpenACC build loses the flags: the device copy is never updated).
+ * Hand the one quantity back instead of a whole mptrac_update_device(atm). */
+void mptrac_hip_station_flags(const ctl_t *ctl, const atm_t *atm) {
+  if (ctl->qnt_stat >= 0)
+    HIPCALL(mphip_update_quantity(hip_ctx, ctl->qnt_stat, atm->q[ctl->qnt_stat]));
 }
 
 #endif   /* MPTRAC_HIP */

@@ -502,6 +502,42 @@ def test_gridded_counts_without_quantities(shape, path):
     s.close()
 
 
+def test_one_quantity_handed_back_in_the_callers_order():
+    """mphip_update_quantity: one quantity array, in the caller's order, replaces the device's -- with the
+    particles stored in the caller's order and in the internal locality order (the array then goes through the
+    permutation); everything else is untouched, and the next steps use the new values (the mass enters decay,
+    mixing and deposition): the oracle, given the same array, stays in step."""
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=20011)
+    for interval in (0, 1):
+        o = B.Oracle(ctl, clim, m0, m1, atm)
+        o.timesteps_init()
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("locality_sort_interval", interval)
+        s.timesteps_init(0.0, 0.0)
+        ts = cases.step_times(s.ctl)
+        for t in ts[:3]:
+            o.run_timestep(t)
+            s.run_timestep(t)
+        before = s.state()
+        im = list(cases.QUANTITIES).index("m")
+        new_m = 2.0 + np.arange(s.n) * 1e-3
+        s.update_quantity(im, new_m)
+        o.q[im][:] = new_m
+        after = s.state()
+        assert np.array_equal(after["q"][im], new_m)
+        for key in ("time", "lon", "lat", "p", "uvwp"):
+            assert np.array_equal(after[key], before[key]), key
+        rest = [iq for iq in range(s.nq) if iq != im]
+        assert np.array_equal(after["q"][rest], before["q"][rest])
+        for t in ts[3:7]:
+            o.run_timestep(t)
+            s.run_timestep(t)
+        _compare(o, s)
+        with pytest.raises(hip.MphipError):
+            s.update_quantity(99, new_m)
+        s.close()
+
+
 def test_context_reused_with_other_particle_counts():
     """One context, particle sets of 3000 -> 1500 -> 3000 -> 4500 particles with module_sort (and its sort that
     runs ahead, whose buffers trade places with the context's when a prepared sort is adopted) every step: every

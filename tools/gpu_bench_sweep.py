@@ -36,5 +36,5 @@ def run(workload, interval, steps=20, warm=3):
 
 if __name__ == "__main__":
     for wl in sys.argv[1:] or ["C3"]:
-        for interval in (10, 20, 40, 80, 240):
-            run(wl, interval, steps=240)
+        for interval in (30, 60, 120, 240, 480):     # (warm = 60: past the clock ramp of a device that was idle)
+            run(wl, interval, steps=480, warm=60)
