@@ -1,0 +1,37 @@
+"""bench.py end to end at a small particle count (GPU): the one JSON line the driver parses carries every field of
+the contract, the step counts it was asked for, a roofline measured live and a CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--device-warmup-ms", "0"], ["--workload", "C5"]], ids=["default", "no_device_warmup", "C5"])
+def test_bench_prints_the_contract_line(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--particles", "2e5",
+           "--cpu-sample", "20000", "--cpu-steps", "2", "--device-warmup-ms", "30", *extra]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"] == "particle-steps/s" and d["unit"] == "particle-steps/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert abs(d["value"] - 2e5 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"] and d["value"] > 1e8
+    cfg = d["config"]
+    assert isinstance(cfg["workload"], str) and cfg["particles_per_gpu"] == 200000 and "model" not in cfg
+    assert ("none" in cfg["device_warmup"]) == ("--device-warmup-ms" in extra and extra[extra.index("--device-warmup-ms") + 1] == "0")
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["kernel_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-9 * r["achieved"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.02 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "particle-steps/s" and c["cores"] >= 1 and c["value"] > 1e4
+    assert "sample" in c and c["value_1_thread"] > 0

@@ -62,7 +62,17 @@ def draw(seed):
     return ctl, tuple(names), geom
 
 
-@pytest.mark.parametrize("seed", range(48))
+def _seeds():
+    """48 seeds in the suite; MPTRAC_FUZZ_SEEDS=first:last runs a longer campaign (tools: a few minutes of GPU)."""
+    import os
+    span = os.environ.get("MPTRAC_FUZZ_SEEDS")
+    if span:
+        a, b = (int(x) for x in span.split(":"))
+        return range(a, b)
+    return range(48)
+
+
+@pytest.mark.parametrize("seed", _seeds())
 def test_random_module_combination(seed):
     ctl, names, geom = draw(seed)
     fields = cases.PRESSURE_LEVEL_FIELDS + FIELDS_METEO_ONLY
