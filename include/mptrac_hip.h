@@ -250,6 +250,11 @@ int mphip_get_sort(mphip_ctx *ctx, double *keys, int *perm);
  * option "deterministic_sums"), summed over the ranks through the communicator or the all-reduce hook if
  * one is set. */
 int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *sigma);
+/* The vertical weighting function of write_grid (GRID_KERNEL; read_kernel + kernel_weight, mptrac.c:8846-8883,
+ * 3298-3320, used at mptrac.c:13866): nk nodes (height [km] ascending, weight -- already scaled to a largest
+ * weight of one as read_kernel does); every summand of mphip_grid_sums is then kernel * q (and its square).
+ * nk < 2 switches it off (weight one, the default). */
+int mphip_set_grid_kernel(mphip_ctx *ctx, int nk, const double *kz, const double *kw);
 
 int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
 

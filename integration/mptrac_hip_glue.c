@@ -218,6 +218,12 @@ void mptrac_hip_grid_sums(const double t, int *np, double *mean, double *sigma) 
   HIPCALL(mphip_grid_sums(hip_ctx, t, np, mean, sigma));
 }
 
+/* write_grid with GRID_KERNEL: hand the weighting function read_kernel has just read (and normalised) to the
+ * device once (mptrac.c:13779-13780); nk = 0 without a kernel file */
+void mptrac_hip_grid_kernel(const int nk, const double *kz, const double *kw) {
+  HIPCALL(mphip_set_grid_kernel(hip_ctx, nk, kz, kw));
+}
+
 /* write_station sets atm->q[qnt_stat] on the host copy (mptrac.c:15143-15145); on the reference's CPU path that
  * is the model state of the next step (its OpenACC build loses the flags: the device copy is never updated).
  * Hand the one quantity back instead of a whole mptrac_update_device(atm). */

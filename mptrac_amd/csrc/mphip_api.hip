@@ -132,6 +132,8 @@ struct mphip_ctx {
   int *d_ext = nullptr, *d_ext_alt = nullptr;
   bool ext_identity = true;
   int locality_interval = 60;         // re-sort every this many steps (0 = keep the caller's order)
+  double *d_grid_kernel = nullptr;    // GRID_KERNEL: kz[nk] | kw[nk] (mphip_set_grid_kernel)
+  int grid_nk = 0;
   bool locality_zorder = false;       // tiles of the locality key numbered along a Z-order curve instead of row by row
   int locality_tile = 0;              // horizontal tile edge of the locality key (columns); 0 = 4, or 8 with model-level winds
   int step_blocks = 8192;             // upper bound of the step kernel's grid
@@ -1786,6 +1788,7 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_sums);
   dev_free(ctx->d_cnt);
   dev_free(ctx->d_lists);
+  dev_free(ctx->d_grid_kernel);
   for (auto e : ctx->ev)
     (void) hipEventDestroy(e);
   (void) hipStreamDestroy(ctx->stream);
@@ -2521,6 +2524,8 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
     return 1;
   const bool ordered = ctx->deterministic_sums != 0;
   const DevAtm a = dev_atm(ctx);
+  const GridKernel kern = { ctx->d_grid_kernel, ctx->d_grid_kernel ? ctx->d_grid_kernel + ctx->grid_nk : nullptr, a.p,
+                            ctx->grid_nk };
   if (ctx->np) {
     BoxGrid G = { c.grid_lon0, c.grid_lon1, c.grid_lat0, c.grid_lat1, c.grid_z0, c.grid_z1, c.grid_nx, c.grid_ny,
                   c.grid_nz };
@@ -2532,6 +2537,7 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
     for (int iq = 0; iq < ctx->nq; iq++)
       vals.q[iq] = a.q[iq];
     vals.nq = ctx->nq;
+    vals.kern = kern;
     // [counts | sums of q | sums of q^2], as grid_accumulate_kernel
     if (ordered_cell_sums(ctx, vals, 2 * ctx->nq, c.grid_nz, ncell, ctx->d_sums + ncell, (int *) nullptr, ctx->d_sums))
       return 1;
@@ -2540,7 +2546,7 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
     if (ctx->np) {
       const AccumGeom g = accum_geom(ctx, 1 + 2 * ctx->nq);
       hipLaunchKernelGGL(grid_accumulate_kernel, dim3(g.nblocks), dim3(256), g.lds, ctx->stream, a, ctx->d_cell, ctx->nq,
-                         ncell, ctx->d_sums, g.T, g.per_block);
+                         ncell, ctx->d_sums, g.T, g.per_block, kern);
     }
   }
   HIPCHK(hipGetLastError());
@@ -2553,6 +2559,26 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
     cnt[i] = (int) h[i];
   memcpy(mean, h.data() + ncell, ncell * (size_t) ctx->nq * sizeof(double));
   memcpy(sigma, h.data() + ncell * (size_t) (1 + ctx->nq), ncell * (size_t) ctx->nq * sizeof(double));
+  return 0;
+}
+
+int mphip_set_grid_kernel(mphip_ctx *ctx, int nk, const double *kz, const double *kw) {
+  if (!ctx)
+    return 1;
+  if (nk < 0 || nk > 1024 || (nk >= 2 && (!kz || !kw)))
+    return fail(ctx, "bad kernel function");
+  for (int k = 1; k < nk; k++)
+    if (kz[k] < kz[k - 1])
+      return fail(ctx, "height levels of the kernel function must be ascending");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (dev_alloc(ctx, &ctx->d_grid_kernel, nk >= 2 ? 2 * (size_t) nk : 0))
+    return 1;
+  ctx->grid_nk = nk >= 2 ? nk : 0;
+  if (ctx->grid_nk) {
+    HIPCHK(hipMemcpy(ctx->d_grid_kernel, kz, (size_t) nk * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_grid_kernel + nk, kw, (size_t) nk * sizeof(double), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 

@@ -1444,12 +1444,32 @@ struct MixVals {   // module_mixing: the mixed quantities
   __device__ __forceinline__ double get(int k, long long i) const { return mq.q[k][i]; }
 };
 
-struct GridVals {  // write_grid: q and q^2 of every quantity (kernel weight 1, mptrac.c:3305-3306)
+// vertical weighting function of the gridded output (GRID_KERNEL; kernel_weight, mptrac.c:3298-3320): nk nodes
+// (height [km], weight), linear in between, constant beyond; nk < 2: weight one
+struct GridKernel {
+  const double *kz, *kw;   // device arrays
+  const double *p;         // pressure of every stored particle
+  int nk;
+  __device__ __forceinline__ double weight(long long i) const {
+    if (nk < 2)
+      return 1.0;
+    const double z = zfromp(p[i]);
+    if (z < kz[0])
+      return kw[0];
+    if (z > kz[nk - 1])
+      return kw[nk - 1];
+    const int idx = locate_irr(kz, nk, z, 1);
+    return lin(kz[idx], kw[idx], kz[idx + 1], kw[idx + 1], z);
+  }
+};
+
+struct GridVals {  // write_grid: kernel * q and its square for every quantity (mptrac.c:13862-13872)
   const double *q[MPHIP_NQ_MAX];
   int nq;
+  GridKernel kern;
   __device__ __forceinline__ int count() const { return 2 * nq; }
   __device__ __forceinline__ double get(int k, long long i) const {
-    const double v = 1.0 * q[k < nq ? k : k - nq][i];
+    const double v = kern.weight(i) * q[k < nq ? k : k - nq][i];
     return k < nq ? v : v * v;
   }
 };
@@ -1924,7 +1944,7 @@ __global__ void double_to_int_kernel(const double *__restrict__ in, int *__restr
 // buf[0 .. ncell) += 1, buf[(1 + iq) ncell ..] += q, buf[(1 + nq + iq) ncell ..] += q^2
 __global__ __launch_bounds__(256) void grid_accumulate_kernel(DevAtm a, const int *__restrict__ cell, int nq,
                                                               size_t ncell, double *__restrict__ buf, int T,
-                                                              long long per_block) {
+                                                              long long per_block, GridKernel kern) {
   extern __shared__ double s_tab[];
   LdsTable tab;
   tab.init(s_tab, T, 1 + 2 * nq);
@@ -1938,8 +1958,9 @@ __global__ __launch_bounds__(256) void grid_accumulate_kernel(DevAtm a, const in
         tab.add(slot, 0, 1.0);
       else
         unsafeAtomicAdd(&buf[c], 1.0);
+      const double kernel = kern.weight(i);
       for (int iq = 0; iq < nq; iq++) {
-        const double v = 1.0 * a.q[iq][i];   // kernel weight 1 (mptrac.c:3305-3306)
+        const double v = kernel * a.q[iq][i];
         if (slot >= 0) {
           tab.add(slot, 1 + iq, v);
           tab.add(slot, 1 + nq + iq, v * v);

@@ -101,6 +101,7 @@ def load(build=True):
     L.mphip_module.argtypes = [C.c_void_p, C.c_uint, C.c_double]
     L.mphip_get_sort.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
     L.mphip_grid_sums.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), _dp, _dp]
+    L.mphip_set_grid_kernel.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
     L.mphip_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
     L.mphip_comm_unique_id.argtypes = [C.c_void_p]
     L.mphip_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -346,6 +347,13 @@ class Simulation:
         self._chk(self.L.mphip_grid_sums(self.h, t, _ptr(cnt, C.POINTER(C.c_int)), _ptr(mean, _dp),
                                          _ptr(sigma, _dp)))
         return cnt, mean, sigma
+
+    def set_grid_kernel(self, kz=(), kw=()):
+        """Vertical weighting function of the gridded output (GRID_KERNEL); no nodes: off."""
+        kz = np.ascontiguousarray(kz, dtype=np.float64)
+        kw = np.ascontiguousarray(kw, dtype=np.float64)
+        assert kz.shape == kw.shape
+        self._chk(self.L.mphip_set_grid_kernel(self.h, len(kz), _ptr(kz, _dp), _ptr(kw, _dp)))
 
     def synchronize(self):
         self._chk(self.L.mphip_synchronize(self.h))

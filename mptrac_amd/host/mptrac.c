@@ -229,6 +229,7 @@ static const char *unsupported_qnt[] = {
   I(atm_type, "ATM_TYPE", "0") \
   I(atm_type_out, "ATM_TYPE_OUT", "-1") \
   S(grid_basename, "GRID_BASENAME", "-") \
+  S(grid_kernel, "GRID_KERNEL", "-") \
   D(grid_dt_out, "GRID_DT_OUT", "86400") \
   I(grid_sparse, "GRID_SPARSE", "0") \
   I(grid_stddev, "GRID_STDDEV", "0") \
@@ -434,7 +435,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
    * other output writers (mptrac.c:7574-7713), chemistry and radioactive decay switches (7386-7411),
    * kernel-weighted and netCDF gridded output, domain decomposition */
   {
-    static const char *const names[] = { "DEPO_BASENAME", "GRID_KERNEL", "ATM_GPFILE", "GRID_GPFILE", NULL };
+    static const char *const names[] = { "DEPO_BASENAME", "ATM_GPFILE", "GRID_GPFILE", NULL };
     char val[LEN];
     for (int k = 0; names[k]; k++) {
       scan_ctl(filename, argc, argv, names[k], -1, "-", val);
@@ -2034,6 +2035,13 @@ void write_grid(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1
   if (ctl->met_coord_type != 0)
     ERRMSG("Only lat/lon grid supported");
   LOG(1, "Write grid data: %s", filename);
+  if (t == ctl->t_start) {   /* the vertical weighting function, once per run (mptrac.c:13776-13781) */
+    static double kz[EP], kw[EP];
+    int nk = 0;
+    if (ctl->grid_kernel[0] != '-')
+      read_kernel(ctl->grid_kernel, kz, kw, &nk);
+    HIP(mphip_set_grid_kernel(g_ctx, nk, kz, kw));
+  }
   grid_result g;
   memset(&g, 0, sizeof(g));
   g.ncell = (size_t) ctl->grid_nx * (size_t) ctl->grid_ny * (size_t) ctl->grid_nz;

@@ -166,7 +166,7 @@ typedef struct {
   char atm_basename[LEN];
   double atm_dt_out;
   int atm_filter, atm_stride, atm_type, atm_type_out;
-  char grid_basename[LEN];
+  char grid_basename[LEN], grid_kernel[LEN];
   double grid_dt_out;
   int grid_sparse, grid_stddev;
   double grid_z0, grid_z1, grid_lon0, grid_lon1, grid_lat0, grid_lat1;

@@ -94,6 +94,8 @@ def lib():
                                               C.POINTER(OrcAtm), C.c_double]
         _lib.orc_grid_sums.argtypes = [C.POINTER(OrcCtl), C.POINTER(OrcAtm), C.c_double,
                                        C.POINTER(C.c_int), _dp, _dp]
+        _lib.orc_grid_sums_kernel.argtypes = [C.POINTER(OrcCtl), C.POINTER(OrcAtm), C.c_double, C.c_int, _dp, _dp,
+                                              C.POINTER(C.c_int), _dp, _dp]
         _lib.orc_intpol_met_time_3d.argtypes = [C.POINTER(OrcMet), C.POINTER(OrcMet), C.c_int] + \
             [C.c_double] * 4 + [_dp]
         for fn, nargs in (("orc_rh", 3), ("orc_rhice", 3), ("orc_tdew", 2), ("orc_tice", 2), ("orc_theta", 2),
@@ -230,13 +232,16 @@ class Oracle:
                                  _ptr(keys, _dp), _ptr(perm, C.POINTER(C.c_int)))
         return keys, perm
 
-    def grid_sums(self, t):
+    def grid_sums(self, t, kernel=None):
+        """kernel = (kz, kw): the vertical weighting function of GRID_KERNEL (already normalised)"""
         ncell = self.ctl.grid_nx * self.ctl.grid_ny * self.ctl.grid_nz
         cnt = np.zeros(ncell, dtype=np.int32)
         mean = np.zeros((self.ctl.nq, ncell))
         sigma = np.zeros((self.ctl.nq, ncell))
-        self.lib.orc_grid_sums(C.byref(self.ctl), C.byref(self.atm), C.c_double(t),
-                               _ptr(cnt, C.POINTER(C.c_int)), _ptr(mean, _dp), _ptr(sigma, _dp))
+        kz = np.ascontiguousarray(kernel[0] if kernel else [], dtype=np.float64)
+        kw = np.ascontiguousarray(kernel[1] if kernel else [], dtype=np.float64)
+        self.lib.orc_grid_sums_kernel(C.byref(self.ctl), C.byref(self.atm), C.c_double(t), len(kz), _ptr(kz, _dp),
+                                      _ptr(kw, _dp), _ptr(cnt, C.POINTER(C.c_int)), _ptr(mean, _dp), _ptr(sigma, _dp))
         return cnt, mean, sigma
 
     def state(self):

@@ -1630,8 +1630,28 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
 
 /* ---- write_grid binning (mptrac.c:13815-13872) -------------------------- */
 
+/* kernel_weight, mptrac.c:3298-3320 */
+static double kernel_weight(const double *kz, const double *kw, int nk, double p) {
+  if (nk < 2)
+    return 1.0;
+  const double z = zfromp(p);
+  if (z < kz[0])
+    return kw[0];
+  else if (z > kz[nk - 1])
+    return kw[nk - 1];
+  else {
+    const int idx = orc_locate_irr(kz, nk, z);
+    return lin(kz[idx], kw[idx], kz[idx + 1], kw[idx + 1], z);
+  }
+}
+
 void orc_grid_sums(const orc_ctl_t *ctl, const orc_atm_t *atm, double t, int *cnt, double *mean,
                    double *sigma) {
+  orc_grid_sums_kernel(ctl, atm, t, 0, NULL, NULL, cnt, mean, sigma);
+}
+
+void orc_grid_sums_kernel(const orc_ctl_t *ctl, const orc_atm_t *atm, double t, int nk, const double *kz,
+                          const double *kw, int *cnt, double *mean, double *sigma) {
   const size_t ncell = (size_t) ctl->grid_nx * (size_t) ctl->grid_ny * (size_t) ctl->grid_nz;
   memset(cnt, 0, ncell * sizeof(int));
   memset(mean, 0, ncell * (size_t) ctl->nq * sizeof(double));
@@ -1654,7 +1674,7 @@ void orc_grid_sums(const orc_ctl_t *ctl, const orc_atm_t *atm, double t, int *cn
     if (ix >= ctl->grid_nx || iy >= ctl->grid_ny || iz >= ctl->grid_nz)
       continue;
     const size_t idx = ((size_t) ix * (size_t) ctl->grid_ny + (size_t) iy) * (size_t) ctl->grid_nz + (size_t) iz;
-    const double kernel = 1.0;   /* kernel_weight without a kernel file, mptrac.c:3305-3306 */
+    const double kernel = kernel_weight(kz, kw, nk, atm->p[ip]);   /* mptrac.c:13866 */
     cnt[idx]++;
     for (int iq = 0; iq < ctl->nq; iq++) {
       mean[(size_t) iq * ncell + idx] += kernel * atm->q[iq][ip];

@@ -226,6 +226,9 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
  * (before the divide at mptrac.c:13906-13913). */
 void orc_grid_sums(const orc_ctl_t *ctl, const orc_atm_t *atm, double t,
                    int *cnt, double *mean, double *sigma);
+/* ... with the vertical weighting function of GRID_KERNEL (nk nodes kz [km], kw; nk < 2: weight one) */
+void orc_grid_sums_kernel(const orc_ctl_t *ctl, const orc_atm_t *atm, double t, int nk, const double *kz,
+                          const double *kw, int *cnt, double *mean, double *sigma);
 
 #ifdef __cplusplus
 }

@@ -478,6 +478,41 @@ def test_ordered_grid_sums_on_odd_grids(shape, order, path):
     s.close()
 
 
+@pytest.mark.parametrize("mode", ["groups", "chains", "atomics"])
+def test_gridded_sums_with_a_vertical_weighting_function(mode):
+    """GRID_KERNEL: every summand of the gridded output is kernel(z) * q (and its square), the kernel linear
+    between its nodes and constant beyond them (kernel_weight, mptrac.c:3298-3320, 13866).  The weight goes through
+    the device's logarithm (Z(p)), so the sums agree with the serial code to rounding, not to the bit; without
+    nodes the weight is exactly one again."""
+    ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=30011)
+    ctl = dict(ctl, grid_nx=36, grid_ny=18, grid_nz=4, grid_z0=0.0, grid_z1=32.0)
+    kz = np.array([2.0, 5.0, 9.0, 14.0, 20.0])
+    kw = np.array([0.1, 0.7, 1.0, 0.4, 0.05])
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.set_option("deterministic_sums", 0 if mode == "atomics" else 1)
+    s.set_option("sum_path", {"groups": 1, "chains": 2, "atomics": 0}[mode])
+    s.timesteps_init(0.0, 0.0)
+    ts = cases.step_times(s.ctl)
+    for t in ts[:3]:
+        s.run_timestep(t)
+    _oracle_takes_device_state(o, s)
+    plain = o.grid_sums(ts[2])
+    s.set_grid_kernel(kz, kw)
+    co, mo, so = o.grid_sums(ts[2], kernel=(kz, kw))
+    cs, ms, ss = s.grid_sums(ts[2])
+    assert np.array_equal(co, cs) and np.abs(mo - plain[1]).max() > 0.1
+    scale = np.abs(mo).max(axis=1, keepdims=True)
+    assert np.abs(ms - mo).max() <= 1e-12 * scale.max() and np.abs(ss - so).max() <= 1e-12 * np.abs(so).max()
+    with pytest.raises(hip.MphipError):
+        s.set_grid_kernel([3.0, 1.0], [1.0, 1.0])        # heights must ascend
+    s.set_grid_kernel()                                   # off again: the serial code's bits (ordered sums)
+    cs, ms, ss = s.grid_sums(ts[2])
+    if mode != "atomics":
+        assert np.array_equal(ms, plain[1]) and np.array_equal(ss, plain[2])
+    s.close()
+
+
 @pytest.mark.parametrize("path", [0, 1, 2], ids=["auto", "groups", "chains"])
 @pytest.mark.parametrize("shape", [(4, 2, 1), (36, 18, 5)], ids=["crowded", "sparse"])
 def test_gridded_counts_without_quantities(shape, path):

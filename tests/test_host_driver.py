@@ -84,7 +84,7 @@ def test_trac_refuses_to_run_without_a_device(tmp_path):
 
 @pytest.mark.parametrize("args,msg", [(("DEPO_BASENAME", "depo"), "DEPO_BASENAME is not implemented"),
                                       (("TRACER_CHEM", "1"), "TRACER_CHEM is not implemented"),
-                                      (("GRID_KERNEL", "kernel.tab"), "GRID_KERNEL is not implemented"),
+                                      (("GRID_GPFILE", "plot.gp"), "GRID_GPFILE is not implemented"),
                                       (("GRID_NC_QUANT[1]", "3"), "quantisation of netCDF output"),
                                       (("GRID_TYPE", "2"), "Set GRID_TYPE to 0 or 1"),
                                       (("ADVECT_VERT_COORD", "2"), "requires meteo data on model levels"),
