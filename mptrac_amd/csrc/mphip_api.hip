@@ -706,8 +706,10 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
     && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // 32-bit byte offsets into the packed grids
   // (the lean instantiations are keyed on the movers; loss / decay / deposition are run-time bits in all of them)
-  const unsigned sel = ((ctx->ctl.advect == 4 || !(mask & MPHIP_MOD_ADVECT)) && !rare && !ml_ && !ctx->force_generic && lean_ok)
-    ? ((mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules)) : kMaskGeneric;
+  // (ADVECT 2 and 1 -- midpoint, the reference's default, and Euler -- share the two-stage instantiations)
+  const unsigned scheme = (mask & MPHIP_MOD_ADVECT) && ctx->ctl.advect != 4 ? kTwoStage : 0u;
+  const unsigned sel = (!rare && !ml_ && !ctx->force_generic && lean_ok)
+    ? (((mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules)) | scheme) : kMaskGeneric;
   // module_wet_depo / module_dry_depo alone (the launch behind module_mixing): the kernel that packs the few
   // particles with anything to do into full waves
   constexpr unsigned kDepo = MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
@@ -731,6 +733,11 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiff)
     STEP_CASE(kAdvTurbConvSedi)
     STEP_CASE(kAdvDiffConvSedi)
+    STEP_CASE(kAdv | kTwoStage)
+    STEP_CASE(kAdvTurb | kTwoStage)
+    STEP_CASE(kAdvDiff | kTwoStage)
+    STEP_CASE(kAdvTurbConvSedi | kTwoStage)
+    STEP_CASE(kAdvDiffConvSedi | kTwoStage)
     STEP_CASE(kTailOnly)
 #undef STEP_CASE
   default:

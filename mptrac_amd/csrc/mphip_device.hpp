@@ -2526,15 +2526,22 @@ __device__ __forceinline__ void position_fast(const DevMet &M, const Axes &A, Pa
   }
 }
 
-// module_advect, RK4 on pressure levels (mptrac.c:3612-3677); `hook(i)` runs behind the gathers of stage i
-template <class Hook>
-__device__ __forceinline__ void advect_rk4_fast(const DevMet &M, const Axes &A, Particle &P, Hook &hook, WindCache &wc) {
+// module_advect on pressure levels (mptrac.c:3612-3677), STAGES = 4: classical Runge-Kutta (ADVECT 4);
+// STAGES = 2: the midpoint scheme (ADVECT 2, the reference's default) -- and, with `euler` set (wave-uniform,
+// from the control parameters), its first stage alone (ADVECT 1).  `hook(i)` runs behind the gathers of stage i.
+template <int STAGES, class Hook>
+__device__ __forceinline__ void advect_fast(const DevMet &M, const Axes &A, Particle &P, Hook &hook, WindCache &wc,
+                                            bool euler = false) {
   const double dt = P.dt;
   const DegPerMetre dm = deg_per_metre(P.lat);   // every stage converts at the latitude the step starts from
   double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0;
+  double x1 = P.lat;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    double dts = 0.0, x0 = P.lon, x1 = P.lat, x2 = P.p;
+  for (int i = 0; i < STAGES; i++) {
+    if (STAGES == 2 && i == 1 && euler)
+      break;
+    double dts = 0.0, x0 = P.lon, x2 = P.p;
+    x1 = P.lat;
     if (i > 0) {
       dts = (i == 3 ? 1.0 : 0.5) * dt;
       x0 = P.lon + dx2deg_k(dm, dts * u);
@@ -2553,15 +2560,31 @@ __device__ __forceinline__ void advect_rk4_fast(const DevMet &M, const Axes &A, 
     hook(i);
     wind_cache_wait(wc);
     wind_uvw_fast(wc.c, s, time_weight(M, P.time + dts), u, v, w);
-    const double k = (i == 0 || i == 3) ? 1.0 / 6.0 : 2.0 / 6.0;
-    um += k * u;
-    vm += k * v;
-    wm += k * w;
+    if (STAGES == 4) {
+      const double k = (i == 0 || i == 3) ? 1.0 / 6.0 : 2.0 / 6.0;
+      um += k * u;
+      vm += k * v;
+      wm += k * w;
+    } else {   // the step is taken with the wind of the last stage that ran
+      um = u;
+      vm = v;
+      wm = w;
+    }
   }
   P.time += dt;
-  P.lon += dx2deg_k(dm, dt * um);
+  if (STAGES == 2 && !euler) {
+    // the midpoint scheme converts the final displacement at the latitude of the midpoint (mptrac.c:3672)
+    const DegPerMetre dmid = deg_per_metre(x1);
+    P.lon += dx2deg_k(dmid, dt * um);
+  } else
+    P.lon += dx2deg_k(dm, dt * um);
   P.lat += dy2deg_k(dt * vm);
   P.p += dt * wm;
+}
+
+template <class Hook>
+__device__ __forceinline__ void advect_rk4_fast(const DevMet &M, const Axes &A, Particle &P, Hook &hook, WindCache &wc) {
+  advect_fast<4>(M, A, P, hook, wc);
 }
 
 // module_diff_turb (mptrac.c:4603-4733)

@@ -126,6 +126,9 @@ constexpr bool kRuntimeMask = (CT == kMaskGeneric || CT == kMaskGenericPL || CT 
 constexpr unsigned kRareModules = MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT | MPHIP_MOD_ISOSURF | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
 constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a later launch reads it)
+// template mask only: the lean instantiation integrates with two stages (ADVECT 2, the midpoint scheme -- the
+// reference's default; its first stage alone is ADVECT 1) instead of the four of ADVECT 4
+constexpr unsigned kTwoStage = 1u << 24;
 constexpr unsigned kTailModules = MPHIP_MOD_LOSS_ZERO | MPHIP_MOD_DECAY | MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI | MPHIP_MOD_ISOSURF | MPHIP_MOD_POSITION2;
@@ -360,6 +363,12 @@ __device__ __forceinline__ void dry_depo_fast(const mphip_ctl_t &ctl, const DevM
 #ifndef MPHIP_STEP_WAVES_PER_SIMD
 #define MPHIP_STEP_WAVES_PER_SIMD 3
 #endif
+// ... measured per instantiation (round 3): the one with every module and the model-level one gain 8 % from a
+// fourth wave although they then keep 52 / 88 bytes per lane in scratch (1.60 -> 1.48 ms, 2.89 -> 2.65 ms on the
+// C3 particles); the pressure-level one (176 bytes) does not (Euler 1.11 -> 1.31 ms)
+#ifndef MPHIP_GENERIC_WAVES_PER_SIMD
+#define MPHIP_GENERIC_WAVES_PER_SIMD 4
+#endif
 #ifndef MPHIP_LEAN_WAVES_PER_SIMD
 #define MPHIP_LEAN_WAVES_PER_SIMD 4
 #endif
@@ -466,10 +475,11 @@ struct RngEarly {
   }
 };
 template <unsigned CT>
-__global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD : MPHIP_LEAN_WAVES_PER_SIMD) void step_kernel(
+__global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
+                                   : (CT == kMaskGenericPL ? MPHIP_STEP_WAVES_PER_SIMD : MPHIP_GENERIC_WAVES_PER_SIMD)) void step_kernel(
   const StepParams S) {
   extern __shared__ double s_axes[];
-  const unsigned mask = kRuntimeMask<CT> ? S.mask : CT;
+  const unsigned mask = kRuntimeMask<CT> ? S.mask : (CT & ~kTwoStage);
   const DevMet &M = S.met;
   const DevAtm &a = S.atm;
   const mphip_ctl_t &ctl = S.ctl;
@@ -606,9 +616,12 @@ __global__ __launch_bounds__(256, kRuntimeMask<CT> ? MPHIP_STEP_WAVES_PER_SIMD :
         a.q[qnt][i] = zeta;
       } else if (lean && early)
         advect_rk4_fast(M, A, P, pre, wc);
-      else if (lean) {
+      else if (lean && (CT & kTwoStage)) {
         NoHook none;
-        advect_rk4_fast(M, A, P, none, wc);
+        advect_fast<2>(M, A, P, none, wc, ctl.advect == 1);
+      } else if (lean) {
+        NoHook none;
+        advect_fast<4>(M, A, P, none, wc);
       } else
         advect(ctl, M, A, P, wc);
     }

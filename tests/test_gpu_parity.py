@@ -173,11 +173,14 @@ def test_fused_step_equals_module_sequence():
                                   dict(tdec_trop=259200.0, tdec_strat=259200.0, dry_depo_vdep=0.15, wet_depo_ic_a=1e-4,
                                        wet_depo_ic_b=0.8, wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6)],
                          ids=["advect", "advect_turb", "c3_set", "c3_set_decay_deposition"])
-def test_lean_instantiations_equal_the_general_code(over):
+@pytest.mark.parametrize("advect", [4, 2, 1], ids=["rk4", "midpoint", "euler"])
+def test_lean_instantiations_equal_the_general_code(over, advect):
     """The specialised (lean) instantiations of the step kernel -- straight-line stencil set-up, packed corner
-    differences, one reciprocal per latitude -- and the general instantiation compute the same bits."""
+    differences, one reciprocal per latitude; four Runge-Kutta stages, or the two of the midpoint scheme (the
+    reference's default) of which the Euler scheme runs the first -- and the general instantiation compute the
+    same bits."""
     ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=6001)
-    ctl.update(over)
+    ctl.update(over, advect=advect)
     runs = []
     for generic in (0, 1):
         s = hip.Simulation(ctl, clim, m0, m1, atm)
