@@ -708,8 +708,18 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // (the lean instantiations are keyed on the movers; loss / decay / deposition are run-time bits in all of them)
   // (ADVECT 2 and 1 -- midpoint, the reference's default, and Euler -- share the two-stage instantiations)
   const unsigned scheme = (mask & MPHIP_MOD_ADVECT) && ctx->ctl.advect != 4 ? kTwoStage : 0u;
-  const unsigned sel = (!rare && !ml_ && !ctx->force_generic && lean_ok)
-    ? (((mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules)) | scheme) : kMaskGeneric;
+  // an exact module set has its own lean instantiation; any other subset of {turbulent, mesoscale diffusion,
+  // convection, sedimentation} on top of the time step's movers runs the largest one with those four switched at
+  // run time (kGated); everything else (single-module calls) takes the general instantiation
+  unsigned sel = kMaskGeneric;
+  if (!rare && !ml_ && !ctx->force_generic && lean_ok) {
+    const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules);
+    if (req == kTailOnly || req == kAdv || req == kAdvTurb || req == kAdvDiff || req == kAdvTurbConvSedi
+        || req == kAdvDiffConvSedi)
+      sel = req | (req == kTailOnly ? 0u : scheme);
+    else if ((req & ~kOptionalModules) == kAdv)
+      sel = kAdvDiffConvSedi | kGated | scheme;
+  }
   // module_wet_depo / module_dry_depo alone (the launch behind module_mixing): the kernel that packs the few
   // particles with anything to do into full waves
   constexpr unsigned kDepo = MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
@@ -738,6 +748,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiff | kTwoStage)
     STEP_CASE(kAdvTurbConvSedi | kTwoStage)
     STEP_CASE(kAdvDiffConvSedi | kTwoStage)
+    STEP_CASE(kAdvDiffConvSedi | kGated)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kTwoStage)
     STEP_CASE(kTailOnly)
 #undef STEP_CASE
   default:

@@ -129,6 +129,12 @@ constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a late
 // template mask only: the lean instantiation integrates with two stages (ADVECT 2, the midpoint scheme -- the
 // reference's default; its first stage alone is ADVECT 1) instead of the four of ADVECT 4
 constexpr unsigned kTwoStage = 1u << 24;
+// template mask only: these four modules are compiled in by the template mask AND switched by the run-time mask,
+// so that one instantiation serves every subset of them (e.g. convection without sedimentation -- a gas
+// tracer).  A flag of its own because the switches cost the headline instantiation 3 % when they were added to
+// it (0.895 -> 0.92 ms: other register allocation and schedule); exact module sets keep their own kernels.
+constexpr unsigned kGated = 1u << 25;
+constexpr unsigned kOptionalModules = MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kTailModules = MPHIP_MOD_LOSS_ZERO | MPHIP_MOD_DECAY | MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI | MPHIP_MOD_ISOSURF | MPHIP_MOD_POSITION2;
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
                                    : (CT == kMaskGenericPL ? MPHIP_STEP_WAVES_PER_SIMD : MPHIP_GENERIC_WAVES_PER_SIMD)) void step_kernel(
   const StepParams S) {
   extern __shared__ double s_axes[];
-  const unsigned mask = kRuntimeMask<CT> ? S.mask : (CT & ~kTwoStage);
+  const unsigned mask = kRuntimeMask<CT> ? S.mask : (CT & ~(kTwoStage | kGated));
   const DevMet &M = S.met;
   const DevAtm &a = S.atm;
   const mphip_ctl_t &ctl = S.ctl;
@@ -625,7 +631,9 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
       } else
         advect(ctl, M, A, P, wc);
     }
-    if (mask & MPHIP_MOD_DIFF_TURB) {
+    // (S.mask is wave-uniform: scalar tests)
+    const unsigned opt = (lean && (CT & kGated)) ? (mask & S.mask & kOptionalModules) : (mask & kOptionalModules);
+    if (opt & MPHIP_MOD_DIFF_TURB) {
       if (lean)
         diff_turb_fast(ctl, M, A, *clim, P, S.ctr_turb, g, early ? pre.turb : nullptr, ltab);
       else
@@ -638,7 +646,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
       a.vp[i] = vp;
       a.wp[i] = wp;
     }
-    if (mask & MPHIP_MOD_DIFF_MESO) {
+    if (opt & MPHIP_MOD_DIFF_MESO) {
       float up = ld_state(&a.up[i]), vp = ld_state(&a.vp[i]), wp = ld_state(&a.wp[i]);
       if (CT == kMaskGenericML)
         wind_cache_reset(wc, true);
@@ -651,15 +659,15 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
       st_state(&a.wp[i], wp);
     }
     if (lean) {
-      if (mask & (MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI)) {
-        const bool sedi_on = (mask & MPHIP_MOD_SEDI) != 0;
-        conv_sedi_fast(ctl, M, A, P, mask, S.ctr_conv, g, early ? &pre.conv : nullptr,
+      if (opt & (MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI)) {
+        const bool sedi_on = (opt & MPHIP_MOD_SEDI) != 0;
+        conv_sedi_fast(ctl, M, A, P, opt, S.ctr_conv, g, early ? &pre.conv : nullptr,
                        sedi_on ? ld_state(&a.q[ctl.qnt_rp][i]) : 0.0, sedi_on ? ld_state(&a.q[ctl.qnt_rhop][i]) : 0.0);
       }
     } else {
-      if (mask & MPHIP_MOD_CONVECTION)
+      if (opt & MPHIP_MOD_CONVECTION)
         convection(ctl, M, A, P, S.ctr_conv, g, early ? &pre.conv : nullptr);
-      if (mask & MPHIP_MOD_SEDI)
+      if (opt & MPHIP_MOD_SEDI)
         sedimentation(M, A, P, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
     }
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))

@@ -171,8 +171,16 @@ def test_fused_step_equals_module_sequence():
                                   dict(turb_mesox=0.0, turb_mesoz=0.0, conv_cape=-999.0, conv_mix_pbl=0, qnt_rp=-1, qnt_rhop=-1),
                                   dict(),
                                   dict(tdec_trop=259200.0, tdec_strat=259200.0, dry_depo_vdep=0.15, wet_depo_ic_a=1e-4,
-                                       wet_depo_ic_b=0.8, wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6)],
-                         ids=["advect", "advect_turb", "c3_set", "c3_set_decay_deposition"])
+                                       wet_depo_ic_b=0.8, wet_depo_bc_a=5e-5, wet_depo_bc_b=0.6),
+                                  # subsets of an instantiation's modules, switched at run time inside it: convection
+                                  # without sedimentation (a gas tracer), sedimentation alone, mesoscale diffusion alone
+                                  dict(qnt_rp=-1, qnt_rhop=-1),
+                                  dict(diffusion=0, conv_cape=-999.0, conv_mix_pbl=0),
+                                  dict(diffusion=0),
+                                  dict(turb_dx_trop=0.0, turb_dx_pbl=0.0, turb_dz_trop=0.0, turb_dz_strat=0.0, turb_dz_pbl=0.0,
+                                       conv_cape=-999.0, conv_mix_pbl=0, qnt_rp=-1, qnt_rhop=-1)],
+                         ids=["advect", "advect_turb", "c3_set", "c3_set_decay_deposition", "no_sedimentation",
+                              "sedimentation_only", "convection_sedimentation", "mesoscale_only"])
 @pytest.mark.parametrize("advect", [4, 2, 1], ids=["rk4", "midpoint", "euler"])
 def test_lean_instantiations_equal_the_general_code(over, advect):
     """The specialised (lean) instantiations of the step kernel -- straight-line stencil set-up, packed corner
