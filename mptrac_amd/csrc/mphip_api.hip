@@ -700,7 +700,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   const bool ml_ = ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3;   // winds from the model levels
   // model levels: the fast path needs monotonic height columns and none of the rarely used modules
   const bool ml_fast = ml_ && ctx->pk.ml_monotonic && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
-  const bool rare = (ml_ && !ml_fast) || (mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u));
+  const unsigned rare_bits = mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u);
+  const bool rare = (ml_ && !ml_fast) || rare_bits;
   // the specialised instantiations take module_timesteps / the dt store from the run-time mask
   // ... and run the lean code: lat/lon grid with a pressure look-up table
   const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
@@ -708,15 +709,19 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // (the lean instantiations are keyed on the movers; loss / decay / deposition are run-time bits in all of them)
   // (ADVECT 2 and 1 -- midpoint, the reference's default, and Euler -- share the two-stage instantiations)
   const unsigned scheme = (mask & MPHIP_MOD_ADVECT) && ctx->ctl.advect != 4 ? kTwoStage : 0u;
-  // an exact module set has its own lean instantiation; any other subset of {turbulent, mesoscale diffusion,
-  // convection, sedimentation} on top of the time step's movers runs the largest one with those four switched at
-  // run time (kGated); everything else (single-module calls) takes the general instantiation
+  // An exact module set has its own lean instantiation.  Any other subset of {turbulent, mesoscale diffusion,
+  // convection, sedimentation} on top of the time step's movers, and every set with module_bound_cond, runs the
+  // largest one with those switched at run time (kGated; module_bound_cond also in the instantiation without
+  // movers).  Everything else (single-module calls, the other rarely used modules) takes a general instantiation.
+  constexpr unsigned kBound = MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
   unsigned sel = kMaskGeneric;
-  if (!rare && !ml_ && !ctx->force_generic && lean_ok) {
-    const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules);
-    if (req == kTailOnly || req == kAdv || req == kAdvTurb || req == kAdvDiff || req == kAdvTurbConvSedi
-        || req == kAdvDiffConvSedi)
-      sel = req | (req == kTailOnly ? 0u : scheme);
+  if (!(rare_bits & ~kBound) && !ml_ && !ctx->force_generic && lean_ok) {
+    const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
+    const bool exact = req == kAdv || req == kAdvTurb || req == kAdvDiff || req == kAdvTurbConvSedi || req == kAdvDiffConvSedi;
+    if (req == kTailOnly)
+      sel = kTailOnly;
+    else if (exact && !(mask & kBound))
+      sel = req | scheme;
     else if ((req & ~kOptionalModules) == kAdv)
       sel = kAdvDiffConvSedi | kGated | scheme;
   }

@@ -687,7 +687,11 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
       st_state(&a.p[i], P.p);
     }
 
-    if (CT == kMaskGeneric && (mask & MPHIP_MOD_BOUND_COND))
+    // module_bound_cond: in the instantiation with every module, and -- switched by the run-time mask -- in the
+    // gated lean instantiations and the one without movers (the launch behind module_mixing)
+    constexpr bool bound_rt = lean && ((CT & kGated) || (CT & ~(kTwoStage | kGated)) == MPHIP_MOD_TIMESTEPS);
+    const unsigned bmask = bound_rt ? S.mask : (CT == kMaskGeneric ? mask : 0u);
+    if (bmask & MPHIP_MOD_BOUND_COND)
       bound_cond(ctl, M, A, a, i, P);
     // the loss / decay / deposition modules behind the movers: in the lean instantiations a run-time choice
     // too (their template mask names the movers), so that they serve every combination of these modules
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
       if (mask & MPHIP_MOD_DRY_DEPO)
         dry_depo(ctl, M, A, a, i, P);
     }
-    if (CT == kMaskGeneric && (mask & MPHIP_MOD_BOUND_COND2))
+    if (bmask & MPHIP_MOD_BOUND_COND2)
       bound_cond(ctl, M, A, a, i, P);
   }
 }
