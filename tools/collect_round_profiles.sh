@@ -15,3 +15,8 @@ tail -c 600 gpurun_out/${T}_bench_C3.json
 python bench.py --particles 1e8 --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3_1e8.json
 python bench.py --workload C3x --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3x.json
 python bench.py --workload C1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C1.json
+python tools/gpu_config_matrix.py > gpurun_out/${T}_config_matrix.txt 2>&1
+python tools/gpu_config_matrix.py generic_kernel=1 > gpurun_out/${T}_config_matrix_general.txt 2>&1
+python tools/gpu_bench_sweep.py C3 > gpurun_out/${T}_sustained_480_steps.txt 2>&1
+python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_C3_driver_args.json 2> /dev/null
+bash tools/piece_cost.sh ${T}pieces > gpurun_out/${T}_pieces.log 2>&1
