@@ -132,6 +132,9 @@ struct mphip_ctx {
   int *d_ext = nullptr, *d_ext_alt = nullptr;
   bool ext_identity = true;
   int locality_interval = 60;         // re-sort every this many steps (0 = keep the caller's order)
+  double *d_rec = nullptr;            // mphip_grid_sums: the quantities as one record per particle (GridVals::rec)
+  size_t rec_cap = 0;
+  bool grid_records = true;
   int chain_blocks = 0;               // workgroups of the chain walk of the ordered sums (0: default; tuning)
   double *h_sums = nullptr;           // page-locked staging of mphip_grid_sums
   size_t h_sums_cap = 0;
@@ -1822,6 +1825,7 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_cnt);
   dev_free(ctx->d_lists);
   dev_free(ctx->d_grid_kernel);
+  dev_free(ctx->d_rec);
   if (ctx->h_sums)
     (void) hipHostFree(ctx->h_sums);
   for (auto e : ctx->ev)
@@ -2573,6 +2577,25 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
       vals.q[iq] = a.q[iq];
     vals.nq = ctx->nq;
     vals.kern = kern;
+    vals.rec = nullptr;
+    // the particles' values as records (see GridVals): worth the extra pass from two quantities on; without the
+    // memory for it the sums gather from the arrays
+    if (ctx->nq >= 2 && ctx->np > 0 && ctx->grid_records) {
+      const size_t need = (size_t) ctx->np * (size_t) ctx->nq;
+      if (need > ctx->rec_cap) {
+        dev_free(ctx->d_rec);
+        ctx->d_rec = nullptr;
+        ctx->rec_cap = 0;
+        if (hipMalloc((void **) &ctx->d_rec, need * sizeof(double)) == hipSuccess)
+          ctx->rec_cap = need;
+        else
+          (void) hipGetLastError();
+      }
+      if (ctx->d_rec) {
+        hipLaunchKernelGGL(grid_records_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, vals, ctx->np, ctx->d_rec);
+        vals.rec = ctx->d_rec;
+      }
+    }
     // [counts | sums of q | sums of q^2], as grid_accumulate_kernel
     if (ordered_cell_sums(ctx, vals, 2 * ctx->nq, c.grid_nz, ncell, ctx->d_sums + ncell, (int *) nullptr, ctx->d_sums))
       return 1;
@@ -2755,6 +2778,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (!(value == 0 || value == 1))
       return fail(ctx, "deterministic_sums must be 0 or 1");
     ctx->deterministic_sums = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "grid_records") == 0) {   // tuning / tests: 0 = gather the gridded sums' values from the arrays
+    ctx->grid_records = value != 0;
     return 0;
   }
   if (strcmp(name, "chain_blocks") == 0) {

@@ -1490,14 +1490,26 @@ struct GridKernel {
 
 struct GridVals {  // write_grid: kernel * q and its square for every quantity (mptrac.c:13862-13872)
   const double *q[MPHIP_NQ_MAX];
+  // the same values as one record of nq doubles per stored particle (grid_records_kernel), or NULL: the ordered
+  // sums gather a particle's values one cell list entry at a time, and a gather pulls a whole 128-byte line --
+  // one or two lines per particle from the records instead of one per quantity from the arrays
+  const double *rec;
   int nq;
   GridKernel kern;
   __device__ __forceinline__ int count() const { return 2 * nq; }
   __device__ __forceinline__ double get(int k, long long i) const {
-    const double v = kern.weight(i) * q[k < nq ? k : k - nq][i];
+    const int kq = k < nq ? k : k - nq;
+    const double v = kern.weight(i) * (rec ? rec[(size_t) i * (size_t) nq + (size_t) kq] : q[kq][i]);
     return k < nq ? v : v * v;
   }
 };
+
+// rec[i * nq + iq] = q[iq][i] (coalesced on both sides: a wave writes 64 consecutive records)
+__global__ void grid_records_kernel(GridVals g, long long n, double *__restrict__ rec) {
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+    for (int iq = 0; iq < g.nq; iq++)
+      rec[(size_t) i * (size_t) g.nq + (size_t) iq] = g.q[iq][i];
+}
 
 // sequence in external order: seq_cell[ip] = cell, seq_slot[ip] = where the particle is stored
 // (`gate`: the kernels of the general pass do nothing unless *gate is set -- see ordered_cell_sums)

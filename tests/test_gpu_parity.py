@@ -489,6 +489,30 @@ def test_ordered_grid_sums_on_odd_grids(shape, order, path):
     s.close()
 
 
+@pytest.mark.parametrize("path", [1, 2], ids=["groups", "chains"])
+def test_gridded_sums_from_value_records_equal_the_sums_from_the_arrays(path):
+    """The ordered gridded sums gather a particle's values from one record per particle (option grid_records,
+    default on from two quantities) instead of one array per quantity: the same doubles, and the serial code's."""
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=30011)
+    ctl = dict(ctl, grid_nx=36, grid_ny=18, grid_nz=2, grid_z0=0.0, grid_z1=30.0)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.set_option("locality_sort_interval", 1)
+    s.set_option("sum_path", path)
+    s.timesteps_init(0.0, 0.0)
+    ts = cases.step_times(s.ctl)
+    for t in ts[:3]:
+        s.run_timestep(t)
+    _oracle_takes_device_state(o, s)
+    want = o.grid_sums(ts[2])
+    for records in (1, 0, 1):
+        s.set_option("grid_records", records)
+        got = s.grid_sums(ts[2])
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), records
+    s.close()
+
+
 @pytest.mark.parametrize("mode", ["groups", "chains", "atomics"])
 def test_gridded_sums_with_a_vertical_weighting_function(mode):
     """GRID_KERNEL: every summand of the gridded output is kernel(z) * q (and its square), the kernel linear
