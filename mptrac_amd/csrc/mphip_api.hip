@@ -1376,9 +1376,11 @@ AccumGeom accum_geom(const mphip_ctx *ctx, int nv) {
 // `every_cell`: cells of groups without particles must read zero afterwards (an all-reduce or the host looks at
 // all of them); module_mixing on a single rank only ever reads the cells its particles are in, which the
 // group kernel has written, and skips the clearing passes
+// (box: the cells are write_grid's box indices and have not been computed yet -- the crowded-cell path does that on
+//  its way; the other path calls box_index_kernel first)
 template <class VALS>
 int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size_t ntot, double *sums, int *cnt,
-                      double *cnt_as_double, bool every_cell = true) {
+                      double *cnt_as_double, bool every_cell = true, const GridBoxArgs *box = nullptr) {
   const long long n = ctx->np;
   // cells per group: whole vertical columns of the grid, as many as fit the table in LDS while there are
   // still >= 2^14 groups to spread over the waves
@@ -1403,30 +1405,36 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
     uint32_t *base = (uint32_t *) ctx->d_lists;
     uint32_t *keys[2] = { base, base + 2 * n };
     int *slots[2] = { (int *) (base + n), (int *) (base + 3 * n) };
-    uint32_t *first = base + 4 * n, *last = first + ntot;
-    HIPCHK(hipMemsetAsync(first, 0, 2 * ntot * sizeof(uint32_t), ctx->stream));
     // (cell, slot) pairs in external order, interleaved in the first half of the buffer; the first pass of the
     // sort reads them from there and writes the second half
+    GridBoxArgs gb;
+    memset(&gb, 0, sizeof(gb));
+    if (box)
+      gb = *box;
     hipLaunchKernelGGL(cell_slot_pairs_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, ctx->d_cell,
-                       ctx->ext_identity ? (const int *) nullptr : ctx->d_ext, n, (uint32_t) ntot, (uint2 *) base);
+                       ctx->ext_identity ? (const int *) nullptr : ctx->d_ext, n, (uint32_t) ntot, (uint2 *) base, gb,
+                       box ? 1 : 0);
     int cur = 0;
     if (radix_passes(ctx, keys, slots, n, bits_for(ntot), &cur, nullptr, false, true))
       return 1;
-    hipLaunchKernelGGL(cell_bounds_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, keys[cur], n, (uint32_t) ntot,
-                       first, last);
     const int width = nv < 1 ? 1 : nv < 64 ? nv : 64;   // nv == 0: counts only (gridded output without quantities)
     const long long waves = ((long long) ntot + 64 / width - 1) / (64 / width);
-    // (a multiple of 8 workgroups: the kernel maps them to contiguous runs of cells per XCD)
     // (measured on C3's output, 1e7 particles on 360 x 180 cells: 1.10 ms per output with every wave resident,
     // 1.21 / 1.36 / 1.86 ms with 512 / 256 / 64 workgroups -- the gathers are bound by the 128-byte lines they
     // pull for 8 bytes each, 3.1 GB per output, and fewer waves in flight do not make the lines live longer)
     int chain_blocks = ctx->chain_blocks > 0 ? ctx->chain_blocks : 8192;
+    // (a multiple of 8 workgroups: the kernel maps them to contiguous runs of cells per XCD)
     chain_blocks = std::max(8, std::min(chain_blocks, (grid_for(waves * 64) + 7) & ~7) & ~7);
+    // every cell finds its range of the sorted list itself (a pass over the list and a clearing pass less)
     hipLaunchKernelGGL(cell_sum_chains_kernel<VALS>, dim3(chain_blocks), dim3(256), 0, ctx->stream, vals,
-                       slots[cur], first, last, ntot, sums, cnt, cnt_as_double);
+                       slots[cur], (const uint32_t *) nullptr, (const uint32_t *) nullptr, keys[cur], n, ntot, sums, cnt,
+                       cnt_as_double);
     HIPCHK(hipGetLastError());
     return 0;
   }
+  if (box && n > 0)   // the other path works on ctx->d_cell
+    hipLaunchKernelGGL(box_index_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dev_atm(ctx), box->G, box->t0,
+                       box->t1, ctx->d_cell, (const double *) nullptr, 0);
   if (every_cell) {
     HIPCHK(hipMemsetAsync(sums, 0, (size_t) nv * ntot * sizeof(double), ctx->stream));
     if (cnt)
@@ -2565,12 +2573,12 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
   const DevAtm a = dev_atm(ctx);
   const GridKernel kern = { ctx->d_grid_kernel, ctx->d_grid_kernel ? ctx->d_grid_kernel + ctx->grid_nk : nullptr, a.p,
                             ctx->grid_nk };
-  if (ctx->np) {
-    BoxGrid G = { c.grid_lon0, c.grid_lon1, c.grid_lat0, c.grid_lat1, c.grid_z0, c.grid_z1, c.grid_nx, c.grid_ny,
-                  c.grid_nz };
-    hipLaunchKernelGGL(box_index_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, a, G, t - 0.5 * c.dt_mod,
-                       t + 0.5 * c.dt_mod, ctx->d_cell, (const double *) nullptr, 0);
-  }
+  const BoxGrid G = { c.grid_lon0, c.grid_lon1, c.grid_lat0, c.grid_lat1, c.grid_z0, c.grid_z1, c.grid_nx, c.grid_ny,
+                      c.grid_nz };
+  const GridBoxArgs gbox = { G, t - 0.5 * c.dt_mod, t + 0.5 * c.dt_mod, a.time, a.lon, a.lat, a.p };
+  if (ctx->np && !ordered)   // (the ordered sums compute the box index on their way)
+    hipLaunchKernelGGL(box_index_kernel, dim3(grid_for(ctx->np)), dim3(256), 0, ctx->stream, a, G, gbox.t0, gbox.t1,
+                       ctx->d_cell, (const double *) nullptr, 0);
   if (ordered) {
     GridVals vals;
     for (int iq = 0; iq < ctx->nq; iq++)
@@ -2597,7 +2605,8 @@ int mphip_grid_sums(mphip_ctx *ctx, double t, int *cnt, double *mean, double *si
       }
     }
     // [counts | sums of q | sums of q^2], as grid_accumulate_kernel
-    if (ordered_cell_sums(ctx, vals, 2 * ctx->nq, c.grid_nz, ncell, ctx->d_sums + ncell, (int *) nullptr, ctx->d_sums))
+    if (ordered_cell_sums(ctx, vals, 2 * ctx->nq, c.grid_nz, ncell, ctx->d_sums + ncell, (int *) nullptr, ctx->d_sums, true,
+                          &gbox))
       return 1;
   } else {
     HIPCHK(hipMemsetAsync(ctx->d_sums, 0, total * sizeof(double), ctx->stream));

@@ -1893,13 +1893,22 @@ __global__ __launch_bounds__(256) void cell_sum_groups_kernel(VALS vals, const u
 // cell's particles in ascending external index -- and lane (cell, value) walks its cell's list and adds: the
 // chains are long, there are cells x values of them, and the lanes of a cell share the list reads.
 
+// (box != NULL: the cell of every particle is computed here -- write_grid's box index, one pass over the
+//  particle arrays less than box_index_kernel + this kernel)
+struct GridBoxArgs {
+  BoxGrid G;
+  double t0, t1;
+  const double *time, *lon, *lat, *p;
+};
+
 __global__ void cell_slot_pairs_kernel(const int *__restrict__ cell, const int *__restrict__ ext, long long n,
-                                       uint32_t outside, uint2 *__restrict__ pairs) {
+                                       uint32_t outside, uint2 *__restrict__ pairs, const GridBoxArgs box, int use_box) {
   // one 8-byte store per particle: the stores go all over the array (ext is a random permutation of the stored
   // order), and a store costs a memory transaction whatever its width -- half as many as with two arrays
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
     const long long at = ext ? (long long) ext[i] : i;
-    const int c = cell[i];
+    const int c = use_box ? box_cell(box.G, box.t0, box.t1, box.time[i], box.lon[i], box.lat[i], box.p[i], nullptr, i, 0)
+                          : cell[i];
     pairs[at] = make_uint2(c >= 0 ? (uint32_t) c : outside, (uint32_t) i);
   }
 }
@@ -1924,7 +1933,9 @@ __global__ void cell_bounds_kernel(const uint32_t *__restrict__ keys, long long 
 template <class VALS>
 __global__ __launch_bounds__(256) void cell_sum_chains_kernel(VALS vals, const int *__restrict__ slots,
                                                               const uint32_t *__restrict__ first,
-                                                              const uint32_t *__restrict__ last, size_t ntot,
+                                                              const uint32_t *__restrict__ last,
+                                                              const uint32_t *__restrict__ sorted_keys, long long nlist,
+                                                              size_t ntot,
                                                               double *__restrict__ sums, int *__restrict__ cnt,
                                                               double *__restrict__ cnt_as_double) {
   const int nv = vals.count();
@@ -1945,7 +1956,32 @@ __global__ __launch_bounds__(256) void cell_sum_chains_kernel(VALS vals, const i
     const size_t c = gidx * per_wave + sub;
     if (c >= ntot)
       break;
-    const uint32_t b = first[c], e = last[c];
+    // the cell's range of the sorted list: first[] / last[] of cell_bounds_kernel, or (first == NULL) a search
+    // in the sorted keys -- 2 x log2(n) probes per cell against a pass over the list
+    uint32_t b, e;
+    if (first) {
+      b = first[c];
+      e = last[c];
+    } else {
+      uint32_t lo = 0, hi = (uint32_t) nlist;   // first position with key >= c
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (sorted_keys[mid] < (uint32_t) c)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      b = lo;
+      hi = (uint32_t) nlist;                    // first position with key > c
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (sorted_keys[mid] <= (uint32_t) c)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      e = lo;
+    }
     for (int v = v0; v < nv; v += width) {
       double sum = 0.0;
       uint32_t k = b;
