@@ -310,6 +310,13 @@ int mphip_comm_destroy(mphip_ctx *ctx);
  *   second stream as soon as this step's particles have moved, beside module_mixing and the deposition modules;
  *   taken over by the next mphip_run_timestep if it comes with the expected time and nothing they depend on was
  *   touched in between, dropped otherwise.  Not observable;
+ *   "grid_records" (default 1): mphip_grid_sums first interleaves the quantities of every particle into one record
+ *   (one pass), so that the ordered sums pull one or two cache lines per particle instead of one per quantity;
+ *   0 = gather from the quantity arrays.  Not observable;
+ *   "locality_zorder" (default 0): number the tiles of the internal order along a Z-order curve instead of row by
+ *   row (measured: no effect on the step kernel);
+ *   "sum_path" (default 0 = by crowding; 1, 2): tests -- force the group / the chain algorithm of the ordered sums;
+ *   "chain_blocks": tuning -- workgroups of the chain walk of the ordered sums;
  *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel. */
 int mphip_set_option(mphip_ctx *ctx, const char *name, double value);
 int mphip_synchronize(mphip_ctx *ctx);
