@@ -293,9 +293,13 @@ def main():
     # the reference's first call (t = t_start) has dt = 0 and moves nothing
     sim.run_timestep(0.0)
     k = 1
+    # (the W warm-up steps are the first load the device sees: their kernel time is reported as the cold figure)
+    if not args.no_kernel_events:
+        sim.profile_begin()
     for _ in range(args.warmup):
         sim.run_timestep(k * dt)
         k += 1
+    cold_launches, cold_ms = (0, float("nan")) if args.no_kernel_events else sim.profile_end()
     sim.grid_sums((k - 1) * dt)     # warm the reduction path (buffers, RCCL communicator) with a real output
     warm_steps, warm_ms = 0, 0.0
     if scratch is not None:
@@ -386,6 +390,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "step_kernel (fused time step)", "kernel_ms": kernel_ms_per_launch,
+                         # the same kernel over the W warm-up launches, i.e. on a device that comes from idle
+                         # (clock ramp, profiles/r03_clock_ramp.txt); not part of `achieved`
+                         "kernel_ms_from_idle": (cold_ms / cold_launches) if cold_launches else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_particle_step": a_per,
                          # SURVEY 8(d) caveat: the fused step is fp64-VALU-bound, not HBM-bound; share of SIMD
