@@ -1396,7 +1396,7 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
   // give every (cell, value) chain a lane -- "crowded cells" in mphip_kernels.hpp
   const bool chains = ctx->sum_path == 2 || (ctx->sum_path == 0 && (double) n >= 16.0 * (double) ntot);
   if (chains && n > 0) {
-    const size_t words32 = 4 * (size_t) n + 2 * ntot;
+    const size_t words32 = 4 * (size_t) n;
     if ((words32 + 1) / 2 > ctx->lists_cap) {
       if (dev_alloc(ctx, &ctx->d_lists, (words32 + 1) / 2))
         return 1;
@@ -1427,8 +1427,7 @@ int ordered_cell_sums(mphip_ctx *ctx, const VALS &vals, int nv, int column, size
     chain_blocks = std::max(8, std::min(chain_blocks, (grid_for(waves * 64) + 7) & ~7) & ~7);
     // every cell finds its range of the sorted list itself (a pass over the list and a clearing pass less)
     hipLaunchKernelGGL(cell_sum_chains_kernel<VALS>, dim3(chain_blocks), dim3(256), 0, ctx->stream, vals,
-                       slots[cur], (const uint32_t *) nullptr, (const uint32_t *) nullptr, keys[cur], n, ntot, sums, cnt,
-                       cnt_as_double);
+                       slots[cur], keys[cur], n, ntot, sums, cnt, cnt_as_double);
     HIPCHK(hipGetLastError());
     return 0;
   }

@@ -166,6 +166,7 @@ __device__ __forceinline__ Axes load_axes(const DevMet &M, double *smem) {
 #define MPHIP_SETPRIO 0
 #endif
 
+
 __device__ __forceinline__ double div_const(double x, double y, double inv_y) {
 #if MPHIP_EXACT_DIV
   (void) inv_y;

@@ -1913,27 +1913,11 @@ __global__ void cell_slot_pairs_kernel(const int *__restrict__ cell, const int *
   }
 }
 
-// first[c], last[c]: the range of cell c in the sorted list (both zero on entry: cells without particles)
-__global__ void cell_bounds_kernel(const uint32_t *__restrict__ keys, long long n, uint32_t outside,
-                                   uint32_t *__restrict__ first, uint32_t *__restrict__ last) {
-  for (long long j = blockIdx.x * (long long) blockDim.x + threadIdx.x; j < n; j += (long long) gridDim.x * blockDim.x) {
-    const uint32_t k = keys[j];
-    if (k == outside)
-      continue;
-    if (j == 0 || keys[j - 1] != k)
-      first[k] = (uint32_t) j;
-    if (j == n - 1 || keys[j + 1] != k)
-      last[k] = (uint32_t) (j + 1);
-  }
-}
-
 #ifndef MPHIP_CHAIN_LOADS
 #define MPHIP_CHAIN_LOADS 16   // (gridded output of C3: 267 us with 4, 249 with 8, 225 with 16)
 #endif
 template <class VALS>
 __global__ __launch_bounds__(256) void cell_sum_chains_kernel(VALS vals, const int *__restrict__ slots,
-                                                              const uint32_t *__restrict__ first,
-                                                              const uint32_t *__restrict__ last,
                                                               const uint32_t *__restrict__ sorted_keys, long long nlist,
                                                               size_t ntot,
                                                               double *__restrict__ sums, int *__restrict__ cnt,
@@ -1956,13 +1940,10 @@ __global__ __launch_bounds__(256) void cell_sum_chains_kernel(VALS vals, const i
     const size_t c = gidx * per_wave + sub;
     if (c >= ntot)
       break;
-    // the cell's range of the sorted list: first[] / last[] of cell_bounds_kernel, or (first == NULL) a search
-    // in the sorted keys -- 2 x log2(n) probes per cell against a pass over the list
+    // the cell's range [b, e) of the list sorted by cell: two searches in the sorted keys (2 x log2(n) probes per
+    // cell; a pass over the whole list that marks the boundaries, and a clearing pass before it, cost more)
     uint32_t b, e;
-    if (first) {
-      b = first[c];
-      e = last[c];
-    } else {
+    {
       uint32_t lo = 0, hi = (uint32_t) nlist;   // first position with key >= c
       while (lo < hi) {
         const uint32_t mid = lo + (hi - lo) / 2;
