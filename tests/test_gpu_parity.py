@@ -1248,15 +1248,17 @@ def test_model_levels_with_a_non_monotonic_height_column(case, field):
 # the BASELINE configurations on their own grids / default mixing grid / ensembles / long run
 # ---------------------------------------------------------------------------
 
-def test_c3_grid_stochastic_parity():
+@pytest.mark.parametrize("advect", [4, 2], ids=["rk4", "midpoint"])
+def test_c3_grid_stochastic_parity(advect):
     """BASELINE configs[2] on ITS OWN grid (0.5 deg, 721 x 361 x 137 -- the grid bench.py runs): 2 x 10^5
-    particles, RK4 + turbulent + mesoscale diffusion + convection + sedimentation, six steps against the
-    multi-threaded oracle.  Exercises the 137-level pressure table and the 24-bit index arithmetic at the
-    extents the headline number is quoted on."""
+    particles, RK4 (and the reference's default integrator, the midpoint scheme) + turbulent + mesoscale diffusion
+    + convection + sedimentation, six steps against the multi-threaded oracle.  Exercises the 137-level pressure
+    table and the 24-bit index arithmetic at the extents the headline number is quoted on."""
     n = 200000
     ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=n, grid="C3",
                                              fields=("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel"),
                                              quantities=("m", "rp", "rhop"))
+    ctl["advect"] = advect
     assert (m0.nx, m0.ny, m0.np) == (721, 361, 137)
     B.lib().orc_set_num_threads(B.usable_cores())
     o = B.Oracle(ctl, clim, m0, m1, atm)
