@@ -38,6 +38,9 @@ WORKLOADS = {
     # name: (grid, particles per GPU, control, quantities, meteo fields)
     "C3": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1),
            ("m", "rp", "rhop"), ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel")),
+    # C3 with the reference's DEFAULT integrator (ADVECT 2, the midpoint scheme) instead of the baseline's RK4
+    "C3d": ("C3", 10 ** 7, dict(advect=2, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1),
+            ("m", "rp", "rhop"), ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel")),
     # C3 with module_meteo every step (the reference's default MET_DT_OUT 0.1) filling the quantity set of the
     # reference's tests/trac_test (t, u, v, w, zg, pv, ps, pt); not the headline configuration (SURVEY row 22:
     # benchmarks of the reference set MET_DT_OUT 0)
@@ -80,6 +83,7 @@ def algorithmic_bytes_per_pstep(workload, met, np_local):
     step can touch, once per launch."""
     state = {"C3": 64 + 24 + 16,   # time,lon,lat,p R+W; uvwp R+W; rp,rhop R
              "C3m": 64 + 24 + 16,  # (the step kernel's bytes; module_meteo is a separate kernel)
+             "C3d": 64 + 24 + 16,
              "C5": 64 + 24 + 16 + 16, "C3x": 64 + 24 + 16 + 16, "C5n": 64 + 24 + 16 + 16,
              "C3z": 64 + 24 + 16 + 16,
              "C2": 64, "C1": 64}[workload]
