@@ -17,6 +17,33 @@
 
 #include <stddef.h>
 
+/* the writers below are defined on longitude / latitude grids only (the reference refuses the others too) */
+static void latlon_only(const ctl_t *ctl) {
+  if (ctl->met_coord_type != 0)
+    ERRMSG("Only lat/lon grid supported");
+}
+
+static FILE *create_text_file(const char *filename) {
+  FILE *f = fopen(filename, "w");
+  if (!f)
+    ERRMSG("Cannot create file!");
+  return f;
+}
+
+/* particle ip belongs to the time step around t: its time lies within half a step of t */
+typedef struct {
+  double t0, t1;
+} step_window;
+
+static step_window window_around(const ctl_t *ctl, double t) {
+  const step_window w = { t - 0.5 * ctl->dt_mod, t + 0.5 * ctl->dt_mod };
+  return w;
+}
+
+static int inside(const step_window *w, double time) {
+  return !(time < w->t0 || time > w->t1);
+}
+
 /* ---------------------------------------------------------------------------------------------------------- */
 /* geometry, kernels, observations                                                                            */
 /* ---------------------------------------------------------------------------------------------------------- */
@@ -288,8 +315,7 @@ void write_csi(const char *filename, const ctl_t *ctl, const atm_t *atm, const d
    * reference's static arrays do, mptrac.c:13383-13389, 13440-13444) */
   static double *px, *py, *psd;
 
-  if (ctl->met_coord_type != 0)
-    ERRMSG("Only lat/lon grid supported");
+  latlon_only(ctl);
   if (ctl->qnt_m < 0)
     ERRMSG("Need quantity mass!");
   const int members = ctl->nens > 0 ? ctl->nens : 1;
@@ -304,8 +330,7 @@ void write_csi(const char *filename, const ctl_t *ctl, const atm_t *atm, const d
     if (ctl->csi_kernel[0] != '-')
       read_kernel(ctl->csi_kernel, kz, kw, &nk);
     LOG(1, "Write CSI%s data: %s", ctl->nens > 0 ? " ensemble" : "", filename);
-    if (!(out = fopen(filename, "w")))
-      ERRMSG("Cannot create file!");
+    out = create_text_file(filename);
     static const char *const legend[] = { "time [s]", "ensemble ID", "number of hits (cx)", "number of misses (cy)",
       "number of false alarms (cz)", "number of observations (cx + cy)", "number of forecasts (cx + cz)", "bias (%)",
       "POD (%)", "FAR (%)", "CSI (%)", "hits by random chance", "ETS (%)", "Pearson R", "Spearman R",
@@ -322,7 +347,8 @@ void write_csi(const char *filename, const ctl_t *ctl, const atm_t *atm, const d
   if (!out)
     ERRMSG("write_csi was not called at the start time of the run!");
 
-  const double t0 = t - 0.5 * ctl->dt_mod, t1 = t + 0.5 * ctl->dt_mod;
+  const step_window now = window_around(ctl, t);
+  const double t0 = now.t0, t1 = now.t1;
   const size_t ncell = (size_t) grid.nx * (size_t) grid.ny * (size_t) grid.nz;
   double *model, *omean, *osq;
   int *ocount;
@@ -350,7 +376,7 @@ void write_csi(const char *filename, const ctl_t *ctl, const atm_t *atm, const d
 
   /* (kernel-weighted) mass per box and member -> column density [kg/m^2] */
   for (int ip = 0; ip < atm->np; ip++) {
-    if (atm->time[ip] < t0 || atm->time[ip] > t1)
+    if (!inside(&now, atm->time[ip]))
       continue;
     const int member = ctl->nens > 0 ? (int) atm->q[ctl->qnt_ens][ip] : 0;
     if (member < 0 || member >= members)
@@ -430,18 +456,17 @@ void write_csi(const char *filename, const ctl_t *ctl, const atm_t *atm, const d
  * quantity "ens", not by the member number a particle carries: the file holds one row, the statistics of all
  * particles of the time step.  Reproduced on purpose; the member numbers are still range-checked. */
 void write_ens(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t) {
-  if (ctl->met_coord_type != 0)
-    ERRMSG("Only lat/lon grid supported");
+  latlon_only(ctl);
   if (ctl->qnt_ens < 0)
     ERRMSG("Missing ensemble IDs!");
-  const double t0 = t - 0.5 * ctl->dt_mod, t1 = t + 0.5 * ctl->dt_mod;
+  const step_window now = window_around(ctl, t);
   const int row = ctl->qnt_ens;
   double sum_x[3] = { 0, 0, 0 }, sum_z = 0, sum_q[NQ], sum_qq[NQ];
   int n = 0;
   for (int iq = 0; iq < ctl->nq; iq++)
     sum_q[iq] = sum_qq[iq] = 0;
   for (int ip = 0; ip < atm->np; ip++) {
-    if (atm->time[ip] < t0 || atm->time[ip] > t1)
+    if (!inside(&now, atm->time[ip]))
       continue;
     if (atm->q[ctl->qnt_ens][ip] < 0 || atm->q[ctl->qnt_ens][ip] >= NENS)
       ERRMSG("Ensemble ID is out of range!");
@@ -458,9 +483,7 @@ void write_ens(const char *filename, const ctl_t *ctl, const atm_t *atm, const d
   }
 
   LOG(1, "Write ensemble data: %s", filename);
-  FILE *out = fopen(filename, "w");
-  if (!out)
-    ERRMSG("Cannot create file!");
+  FILE *out = create_text_file(filename);
   fprintf(out, "# $1 = time [s]\n# $2 = altitude [km]\n# $3 = longitude [deg]\n# $4 = latitude [deg]\n");
   int col = 4;
   for (int pass = 0; pass < 2; pass++)
@@ -494,8 +517,7 @@ void write_prof(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1
   static obs_table obs;
   static box_grid grid;
 
-  if (ctl->met_coord_type != 0)
-    ERRMSG("Only lat/lon grid supported");
+  latlon_only(ctl);
   if (t == ctl->t_start) {
     if (ctl->qnt_m < 0)
       ERRMSG("Need quantity mass!");
@@ -503,8 +525,7 @@ void write_prof(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1
       ERRMSG("Specify molar mass!");
     obs_load(&obs, ctl->prof_obsfile, ctl);
     LOG(1, "Write profile data: %s", filename);
-    if (!(out = fopen(filename, "w")))
-      ERRMSG("Cannot create file!");
+    out = create_text_file(filename);
     static const char *const legend[] = { "time [s]", "altitude [km]", "longitude [deg]", "latitude [deg]",
       "pressure [hPa]", "temperature [K]", "volume mixing ratio [ppv]", "H2O volume mixing ratio [ppv]",
       "O3 volume mixing ratio [ppv]", "observed BT index [K]", "number of observations" };
@@ -516,7 +537,8 @@ void write_prof(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1
   if (!out)
     ERRMSG("write_prof was not called at the start time of the run!");
 
-  const double t0 = t - 0.5 * ctl->dt_mod, t1 = t + 0.5 * ctl->dt_mod;
+  const step_window now = window_around(ctl, t);
+  const double t0 = now.t0, t1 = now.t1;
   const size_t ncol = (size_t) grid.nx * (size_t) grid.ny;
   double *mass, *osum;
   int *ocount;
@@ -533,7 +555,7 @@ void write_prof(const char *filename, const ctl_t *ctl, met_t *met0, met_t *met1
     }
   }
   for (int ip = 0; ip < atm->np; ip++) {
-    if (atm->time[ip] < t0 || atm->time[ip] > t1)
+    if (!inside(&now, atm->time[ip]))
       continue;
     const long c = box_cell(&grid, atm->lon[ip], atm->lat[ip], Z(atm->p[ip]));
     if (c >= 0)
@@ -585,16 +607,14 @@ void write_sample(const char *filename, const ctl_t *ctl, met_t *met0, met_t *me
   static double kz[EP], kw[EP];
   static int nk;
 
-  if (ctl->met_coord_type != 0)
-    ERRMSG("Only lat/lon grid supported");
+  latlon_only(ctl);
   if (t == ctl->t_start) {
     obs_load(&obs, ctl->sample_obsfile, ctl);
     nk = 0;
     if (ctl->sample_kernel[0] != '-')
       read_kernel(ctl->sample_kernel, kz, kw, &nk);
     LOG(1, "Write sample data: %s", filename);
-    if (!(out = fopen(filename, "w")))
-      ERRMSG("Cannot create file!");
+    out = create_text_file(filename);
     static const char *const legend[] = { "time [s]", "altitude [km]", "longitude [deg]", "latitude [deg]",
       "surface area [km^2]", "layer depth [km]", "number of particles [1]", "column density [kg/m^2]",
       "volume mixing ratio [ppv]", "observed BT index [K]" };
@@ -605,7 +625,8 @@ void write_sample(const char *filename, const ctl_t *ctl, met_t *met0, met_t *me
   if (!out)
     ERRMSG("write_sample was not called at the start time of the run!");
 
-  const double t0 = t - 0.5 * ctl->dt_mod, t1 = t + 0.5 * ctl->dt_mod;
+  const step_window now = window_around(ctl, t);
+  const double t0 = now.t0, t1 = now.t1;
   const double reach2 = SQR(ctl->sample_dx), area = M_PI * reach2;
   const double reach_lat = ctl->sample_dx * 180. / (M_PI * RE);   /* the radius in degrees of latitude */
   for (int i = 0; i < obs.n && obs.t[i] < t1; i++) {
@@ -659,12 +680,10 @@ void write_station(const char *filename, const ctl_t *ctl, atm_t *atm, const dou
   static FILE *out;
   static double station[3];
 
-  if (ctl->met_coord_type != 0)
-    ERRMSG("Only lat/lon grid supported");
+  latlon_only(ctl);
   if (t == ctl->t_start) {
     LOG(1, "Write station data: %s", filename);
-    if (!(out = fopen(filename, "w")))
-      ERRMSG("Cannot create file!");
+    out = create_text_file(filename);
     fprintf(out, "# $1 = time [s]\n# $2 = altitude [km]\n# $3 = longitude [deg]\n# $4 = latitude [deg]\n");
     for (int iq = 0; iq < ctl->nq; iq++)
       fprintf(out, "# $%i = %s [%s]\n", iq + 5, ctl->qnt_name[iq], ctl->qnt_unit[iq]);
@@ -706,19 +725,17 @@ void write_station(const char *filename, const ctl_t *ctl, atm_t *atm, const dou
 /* every VTK_STRIDE-th particle of this time step as a legacy-VTK point cloud (lon / lat / scaled height, or on
  * a sphere) with the quantities as point data */
 void write_vtk(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t) {
-  if (ctl->met_coord_type != 0)
-    ERRMSG("Only lat/lon grid supported");
+  latlon_only(ctl);
   LOG(1, "Write VTK data: %s", filename);
-  const double t0 = t - 0.5 * ctl->dt_mod, t1 = t + 0.5 * ctl->dt_mod;
+  const step_window now = window_around(ctl, t);
+  const double t0 = now.t0, t1 = now.t1;
   const int stride = ctl->vtk_stride > 0 ? ctl->vtk_stride : 1;
   int *pick, n = 0;
   ALLOC(pick, int, atm->np / stride + 1);
   for (int ip = 0; ip < atm->np; ip += stride)
     if (atm->time[ip] >= t0 && atm->time[ip] <= t1)
       pick[n++] = ip;
-  FILE *out = fopen(filename, "w");
-  if (!out)
-    ERRMSG("Cannot create file!");
+  FILE *out = create_text_file(filename);
   fprintf(out, "# vtk DataFile Version 3.0\nvtk output\nASCII\nDATASET POLYDATA\nPOINTS %d float\n", n);
   for (int k = 0; k < n; k++) {
     const int ip = pick[k];
