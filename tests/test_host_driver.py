@@ -287,6 +287,40 @@ def test_trac_grid_implicit_volume_mixing_ratio(tmp_path):
 
 
 @pytest.mark.gpu
+def test_trac_grid_with_a_vertical_weighting_function(tmp_path):
+    """GRID_KERNEL through the driver: the kernel file is read at the first step (heights ascending, weights scaled
+    to a largest weight of one), every particle enters the means with weight(z): the grid file of the reference's
+    atm_test particles equals the weighted means computed here from the same particle file."""
+    tmp = str(tmp_path)
+    with open(os.path.join(tmp, "kernel.tab"), "w") as f:
+        f.write("# z [km]  weight\n0 0.4\n5 2.0\n12 1.0\n30 0.2\n")
+    gold = _atm_test_run(tmp, ("GRID_KERNEL", os.path.join(tmp, "kernel.tab")))
+    rows = np.array([[float(c) for c in ln.split()] for ln in open(os.path.join(tmp, "grid_2000_01_01_00_00_00.tab"))
+                     if ln.strip() and not ln.startswith("#")])
+    atm = np.array([[float(c) for c in ln.split()] for ln in open(os.path.join(gold, "atm_2000_01_01_00_00_00.tab"))
+                    if ln.strip() and not ln.startswith("#")])
+    z, lon, lat, q = atm[:, 1], atm[:, 2], atm[:, 3], atm[:, 4:7]
+    w = np.interp(z, [0.0, 5.0, 12.0, 30.0], [0.2, 1.0, 0.5, 0.1])       # scaled by the largest weight; constant beyond the ends
+    ix, iy = np.floor((lon + 180.0) / 5.0).astype(int), np.floor((lat + 90.0) / 5.0).astype(int)
+    inside = (lon >= -180) & (lon < 180) & (lat >= -90) & (lat < 90) & (z >= -5) & (z < 85)
+    cnt = np.zeros((72, 36))
+    mean = np.zeros((3, 72, 36))
+    np.add.at(cnt, (ix[inside], iy[inside]), 1)
+    for k in range(3):
+        np.add.at(mean[k], (ix[inside], iy[inside]), w[inside] * q[inside, k])
+    got_cnt = rows[:, 8].reshape(72, 36)
+    assert np.array_equal(got_cnt, cnt) and cnt.sum() == 10000
+    for k in range(3):
+        got = rows[:, 9 + k].reshape(72, 36)
+        want = np.where(cnt > 0, mean[k] / np.maximum(cnt, 1), np.nan)
+        ok = (np.isnan(got) & np.isnan(want)) | (np.abs(got - want) <= 2e-5 * np.abs(want) + 1e-30)      # six printed digits in and out
+        assert ok.all(), k
+    plain = np.array([[float(c) for c in ln.split()] for ln in open(os.path.join(gold, "grid_2000_01_01_00_00_00.tab"))
+                      if ln.strip() and not ln.startswith("#")])
+    assert not np.allclose(np.nan_to_num(plain[:, 10]), np.nan_to_num(rows[:, 10]), rtol=1e-3)      # the weights matter
+
+
+@pytest.mark.gpu
 def test_trac_balloon_isosurface_and_boundary_conditions(tmp_path):
     """ISOSURF 4 (the driver reads the BALLOON file at the first step) and BOUND_* keys through `trac`."""
     tmp = str(tmp_path)
