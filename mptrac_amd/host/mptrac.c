@@ -812,14 +812,20 @@ static void clams_put(nccw_file *w, const ctl_t *ctl, const atm_t *atm, long lon
 static void write_atm_clams(const char *filename, const ctl_t *ctl, const atm_t *atm) {
   if (ctl->met_coord_type != 0)
     ERRMSG("CLaMS atmospheric files support only lat/lon grids");
-  if (ctl->qnt_zeta_d < 0)
-    ERRMSG("CLaMS position files need the quantity zeta_d!");
+  /* Without the quantity zeta_d the reference writes atm->q[-1] as ZETA -- the array in front of q in its atm_t,
+   * the latitudes (mptrac.c:12968; its tests/interoper_test converts a file without quantities this way).  The
+   * variable is kept, with the same values, so that such files stay readable where ZETA is mandatory. */
+  const double *zeta = clams_zeta(ctl, atm, 1);
+  if (!zeta) {
+    WARN("Quantity zeta_d is missing: ZETA of the position file is not a vertical coordinate!");
+    zeta = atm->lat;
+  }
   nccw_file *w = ncw_create(filename);
   const int tid = nccw_def_dim(w, "time", 1), pid = nccw_def_dim(w, "NPARTS", atm->np);
   NCW(tid);
   NCW(pid);
   clams_define(w, ctl, tid, pid, 0);
-  clams_put(w, ctl, atm, 0, clams_zeta(ctl, atm, 1));
+  clams_put(w, ctl, atm, 0, zeta);
   NCW(nccw_close(w));
 }
 
@@ -860,8 +866,6 @@ static void write_atm_clams_traj(const char *filename, const ctl_t *ctl, const a
     traj = NULL;
     snprintf(path, sizeof(path), "%s/init_fix_%02d%02d%02d%02d.nc", dir, y1 % 100, m1, d1, h1);
     LOG(1, "Write init file: %s", path);
-    if (ctl->qnt_zeta_d < 0)
-      ERRMSG("CLaMS position files need the quantity zeta_d!");
     write_atm_clams(path, ctl, atm);
   }
 }

@@ -243,3 +243,46 @@ def test_meteo_snapshot_as_netcdf(tmp_path, coord_type):
     assert f.variables["q"][0, 0, 4, 6] == np.float32(18.01528 / 28.9644) * np.float32(h2o640)
     assert len(f.variables) == 4 + 24 + 11
     f.close()
+
+
+INTEROP = os.path.join(HERE, "golden", "ref_interoper_test")
+
+
+def _atm_conv(args, zeta_coordinate=False):
+    exe = compile_c_test("atm_conv")
+    env = dict(os.environ, ATM_CONV_ZETA_COORDINATE="1") if zeta_coordinate else dict(os.environ)
+    res = subprocess.run([exe, "-"] + [str(a) for a in args], capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 0 and "RESULT converted" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+    return res.stdout
+
+
+def test_clams_position_file_round_trip_of_the_reference_interoper_test(tmp_path):
+    """tests/interoper_test/run.sh:19-20 of the reference: its particle file without quantities -> CLaMS position
+    file -> text file, byte for byte the reference's golden atm_output.tab (times collapse to the first particle's,
+    pressures survive the file, six printed digits)."""
+    out = _atm_conv([os.path.join(INTEROP, "atm_input.tab"), 0, tmp_path / "atm_output.nc", 4])
+    assert "ZETA of the position file is not a vertical coordinate" in out
+    _atm_conv([tmp_path / "atm_output.nc", 4, tmp_path / "atm_output.tab", 0])
+    with open(tmp_path / "atm_output.tab", "rb") as a, open(os.path.join(INTEROP, "atm_output.tab"), "rb") as b:
+        assert a.read() == b.read()
+    from scipy.io import netcdf_file
+    f = netcdf_file(str(tmp_path / "atm_output.nc"), "r", mmap=False)
+    assert f.dimensions["NPARTS"] == 10000 and np.array_equal(f.variables["ZETA"][:], f.variables["LAT"][:])
+    f.close()
+
+
+def test_clams_init_file_of_the_reference_interoper_test(tmp_path):
+    """The CLaMS init file the reference's diabatic test starts from (tests/interoper_test/data.ref/init, classic
+    netCDF: TIME_INIT, LAT, LON, ZETA, no PRESS) read with ATM_TYPE 3 and ZETA as the vertical coordinate: times,
+    longitudes, latitudes and zeta are the columns the reference printed at the start time of that run
+    (atm_2016_07_01_00_00_00.tab: no parcel has moved at t = T_START; its altitudes come from the meteo data)."""
+    quantities = ["theta", "pv", "m", "zeta", "zeta_d", "ps", "p"]
+    args = [os.path.join(INTEROP, "pos_glo_16070100.nc"), 3, tmp_path / "pos.tab", 0, "NQ", len(quantities)]
+    for i, q in enumerate(quantities):
+        args += [f"QNT_NAME[{i}]", q]
+    _atm_conv(args, zeta_coordinate=True)
+    mine = np.loadtxt(tmp_path / "pos.tab")
+    gold = np.loadtxt(os.path.join(INTEROP, "atm_2016_07_01_00_00_00.tab"))
+    assert mine.shape == gold.shape == (5662, 4 + len(quantities))
+    for col in (0, 2, 3, 4 + quantities.index("m"), 4 + quantities.index("zeta")):
+        assert np.array_equal(mine[:, col], gold[:, col]), col
