@@ -219,26 +219,38 @@ def test_trac_runs_the_reference_coord_test_command_line_on_its_netcdf_files(tmp
                 name, len(bad) + abs(len(gl) - len(rl)), len(rl), gl[bad[0]] if bad else None, rl[bad[0]] if bad else None))
 
 
-def _atm_test_run(tmp, extra_args=()):
-    """`trac` on the particle file of the reference's tests/atm_test (10000 parcels: aoa, m, vmr); the outputs at t = 0 are written
-    after the first call of the time step, which moves nothing (dt = 0)."""
+def _atm_test_run(tmp, extra_args=(), case="ref_atm_test", atm_file="atm_2000_01_01_00_00_00.tab",
+                  quantities=("aoa", "m", "vmr"), t0=0.0):
+    """`trac` on a golden particle file of the reference (default: tests/atm_test, 10000 parcels with aoa, m, vmr); the
+    outputs at t0 are written after the first call of the time step, which moves nothing (dt = 0)."""
     import shutil
     _, trac = build.build_host()
     metbase = os.path.join(tmp, "met")
     for k in range(2):
-        m = synthetic_met("tiny", 3600.0 * k, 1.0 + 0.1 * k)
+        m = synthetic_met("tiny", t0 + 3600.0 * k, 1.0 + 0.1 * k)
         hf.write_met_bin(hf.met_filename(metbase, m.time), m)
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_atm_test")
-    shutil.copy(os.path.join(gold, "atm_2000_01_01_00_00_00.tab"), os.path.join(tmp, "atm_in.tab"))
-    keys = {"NQ": 3, "QNT_NAME[0]": "aoa", "QNT_NAME[1]": "m", "QNT_NAME[2]": "vmr", "METBASE": metbase, "MET_TYPE": 1,
-            "DT_MET": 3600, "DT_MOD": 180, "T_STOP": 180, "MET_DT_OUT": 0, "ATM_BASENAME": "atm",
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", case)
+    shutil.copy(os.path.join(gold, atm_file), os.path.join(tmp, "atm_in.tab"))
+    keys = {"NQ": len(quantities), "METBASE": metbase, "MET_TYPE": 1,
+            "DT_MET": 3600, "DT_MOD": 180, "T_STOP": repr(t0 + 180), "MET_DT_OUT": 0, "ATM_BASENAME": "atm",
             "ATM_DT_OUT": 86400, "GRID_BASENAME": "grid", "GRID_DT_OUT": 86400, "GRID_NX": 72, "GRID_NY": 36}
+    for i, q in enumerate(quantities):
+        keys[f"QNT_NAME[{i}]"] = q
     hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
     open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
     r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in.tab", *extra_args],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
     return gold
+
+
+def _same_text(got_path, ref_path):
+    got, ref = open(got_path).read(), open(ref_path).read()
+    if got != ref:
+        gl, rl = got.splitlines(), ref.splitlines()
+        bad = [i for i in range(min(len(gl), len(rl))) if gl[i] != rl[i]]
+        raise AssertionError("%s: %d lines differ, first: %r vs %r" % (os.path.basename(ref_path), len(bad),
+                                                                       gl[bad[0]], rl[bad[0]]))
 
 
 @pytest.mark.gpu
@@ -250,11 +262,57 @@ def test_trac_grid_and_particle_files_equal_the_reference_atm_test_goldens(tmp_p
     tmp = str(tmp_path)
     gold = _atm_test_run(tmp)
     for name in ("grid_2000_01_01_00_00_00.tab", "atm_2000_01_01_00_00_00.tab"):
-        got, ref = open(os.path.join(tmp, name)).read(), open(os.path.join(gold, name)).read()
-        if got != ref:
-            gl, rl = got.splitlines(), ref.splitlines()
-            bad = [i for i in range(min(len(gl), len(rl))) if gl[i] != rl[i]]
-            raise AssertionError("%s: %d lines differ, first: %r vs %r" % (name, len(bad), gl[bad[0]], rl[bad[0]]))
+        _same_text(os.path.join(tmp, name), os.path.join(gold, name))
+
+
+@pytest.mark.gpu
+def test_trac_grid_file_equals_the_reference_dt_test_golden(tmp_path):
+    """The `atm2grid` golden of the reference's tests/dt_test (run.sh:47-49): 10000 parcels carrying t, u, v, w and no
+    mass, GRID_NX 72, GRID_NY 36, MOLMASS set -- column density and mixing ratio are printed as nan, the one
+    occupied cell holds the means; gridded file and particle file byte for byte."""
+    tmp = str(tmp_path)
+    t0 = 360547200.0      # 2011-06-05 00:00 UTC
+    gold = _atm_test_run(tmp, ("MOLMASS", "64.066"), case="ref_dt_test", atm_file="atm_pl_2011_06_05_00_00_00.tab",
+                         quantities=("t", "u", "v", "w"), t0=t0)
+    _same_text(os.path.join(tmp, "grid_2011_06_05_00_00_00.tab"), os.path.join(gold, "grid_2011_06_05_00_00_00.tab"))
+    _same_text(os.path.join(tmp, "atm_2011_06_05_00_00_00.tab"), os.path.join(gold, "atm_pl_2011_06_05_00_00_00.tab"))
+
+
+@pytest.mark.gpu
+def test_trac_sparse_box_grid_against_the_reference_trac_test_golden(tmp_path):
+    """The gridded output of the reference's tests/trac_test at 2011-06-07 (300 x 90 cells on -90...60 E, -60...-15 N,
+    GRID_SPARSE 1, thirteen quantities) from the golden particle file of that time.  The particle file holds six
+    digits, so a parcel within 1e-4 degrees of a cell border may change cells and the sums carry the rounding of
+    their summands: the rows are compared cell by cell -- nearly all cells with the same count, and in those the
+    column density and every mean within 2e-5 (the implicit mixing ratio needs that run's temperatures: skipped;
+    a sparse table lists the cells in which it is positive, i.e. the cells that hold mass)."""
+    tmp = str(tmp_path)
+    quantities = ("t", "u", "v", "w", "zg", "pv", "ps", "pt", "m", "stat", "ens", "qa", "qb")
+    extra = ["GRID_LON0", "-90", "GRID_LON1", "60", "GRID_LAT0", "-60", "GRID_LAT1", "-15", "GRID_NX", "300",
+             "GRID_NY", "90", "GRID_SPARSE", "1", "SPECIES", "SO2", "OH_CHEM_REACTION", "0", "DT_MOD", "300", "T_STOP", repr(360720000.0 + 300.0)]
+    for i, q in enumerate(quantities):
+        if q in ("qa", "qb"):
+            extra += [f"QNT_UNIT[{i}]", "ppv"]
+    gold = _atm_test_run(tmp, extra, case="ref_trac_test", atm_file="atm_pl_2011_06_07_00_00_00.tab",
+                         quantities=quantities, t0=360720000.0)
+
+    def rows(path):
+        out = {}
+        for ln in open(path):
+            if ln.strip() and not ln.startswith("#"):
+                c = [float(x) for x in ln.split()]
+                out[(c[2], c[3])] = c
+        return out
+    mine = rows(os.path.join(tmp, "grid_2011_06_07_00_00_00.tab"))
+    ref = rows(os.path.join(gold, "grid_pl_2011_06_07_00_00_00.tab"))
+    assert sum(c[8] for c in mine.values()) == sum(c[8] for c in ref.values())       # every parcel with mass inside the box
+    same = [k for k in ref if k in mine and mine[k][8] == ref[k][8]]
+    assert len(same) >= 0.995 * len(ref) and len(mine) <= 1.005 * len(ref), (len(same), len(ref), len(mine))
+    cols = [0, 1, 4, 5, 6] + list(range(9, 9 + len(quantities)))
+    a = np.array([[mine[k][c] for c in cols] for k in same])
+    b = np.array([[ref[k][c] for c in cols] for k in same])
+    bad = ~np.isclose(a, b, rtol=2e-5, atol=0)
+    assert bad.sum() <= 0.002 * bad.size, (bad.sum(), bad.size, a[bad][:5], b[bad][:5])
 
 
 @pytest.mark.gpu
