@@ -49,8 +49,10 @@ enum { MPHIP_PS = 0, MPHIP_PBL, MPHIP_CAPE, MPHIP_CIN, MPHIP_PEL, MPHIP_PCT, MPH
        MPHIP_N2D };
 
 /* Quantities module_meteo fills (SET_ATM list, mptrac.c:5091-5157, in that order); mphip_ctl_t::qnt_met[k]
- * is the reference's ctl->qnt_<name> (-1 = not requested).  The climatology-based ones (hno3, oh, h2o2,
- * ho2, o1d, tnat, tsts) belong to the chemistry part and are not provided. */
+ * is the reference's ctl->qnt_<name> (-1 = not requested).  The last seven come from the zonal-mean
+ * climatologies of clim_t (mphip_update_clim_zm): hno3, oh, h2o2, ho2, o1d = clim_zm / clim_oh at the particle,
+ * tnat = nat_temperature(p, h2o, hno3), tsts = (tice + tnat) / 2 (needs both, mptrac.c:5074-5076).  The
+ * self-assignments of the list (zeta, zeta_dot, eta, eta_dot) have no entry. */
 enum { MPHIP_MQ_PS = 0, MPHIP_MQ_TS, MPHIP_MQ_ZS, MPHIP_MQ_US, MPHIP_MQ_VS, MPHIP_MQ_ESS, MPHIP_MQ_NSS,
        MPHIP_MQ_SHF, MPHIP_MQ_LSM, MPHIP_MQ_SST, MPHIP_MQ_PBL, MPHIP_MQ_PT, MPHIP_MQ_TT, MPHIP_MQ_ZT,
        MPHIP_MQ_H2OT, MPHIP_MQ_ZG, MPHIP_MQ_P, MPHIP_MQ_T, MPHIP_MQ_RHO, MPHIP_MQ_U, MPHIP_MQ_V, MPHIP_MQ_W,
@@ -59,7 +61,12 @@ enum { MPHIP_MQ_PS = 0, MPHIP_MQ_TS, MPHIP_MQ_ZS, MPHIP_MQ_US, MPHIP_MQ_VS, MPHI
        MPHIP_MQ_CIN, MPHIP_MQ_O3C, MPHIP_MQ_VH, MPHIP_MQ_VZ, MPHIP_MQ_PSAT, MPHIP_MQ_PSICE, MPHIP_MQ_PW,
        MPHIP_MQ_SH, MPHIP_MQ_RH, MPHIP_MQ_RHICE, MPHIP_MQ_THETA, MPHIP_MQ_ZETA_D, MPHIP_MQ_TVIRT,
        MPHIP_MQ_LAPSE, MPHIP_MQ_PV, MPHIP_MQ_TDEW, MPHIP_MQ_TICE,
+       MPHIP_MQ_HNO3, MPHIP_MQ_OH, MPHIP_MQ_H2O2, MPHIP_MQ_HO2, MPHIP_MQ_O1D, MPHIP_MQ_TNAT, MPHIP_MQ_TSTS,
        MPHIP_NMQ };
+
+/* Zonal-mean climatologies of clim_t that module_meteo samples (clim_zm_t members hno3, oh, h2o2, ho2, o1d,
+ * mptrac.h:3745-3776, 3805-3817) */
+enum { MPHIP_ZM_HNO3 = 0, MPHIP_ZM_OH, MPHIP_ZM_H2O2, MPHIP_ZM_HO2, MPHIP_ZM_O1D, MPHIP_NZM };
 
 /* Module bits for mphip_module(); one bit per reference module_* function
  * (declarations mptrac.h:6140-7205). */
@@ -128,7 +135,6 @@ typedef struct {
    * fmod(t, met_dt_out) == 0); reference default 0.1 (mptrac.c:7197) */
   double met_dt_out;
   int qnt_met[MPHIP_NMQ];
-  int pad2;
   /* module_isosurf (ISOSURF, mptrac.c:7208) and module_bound_cond (BOUND_*, mptrac.c:7266-7289) */
   int isosurf;            /* 0 none, 1 pressure, 2 density, 3 potential temperature, 4 balloon time series */
   int bound_pbl;
@@ -136,6 +142,10 @@ typedef struct {
   int pad3;
   double bound_mass, bound_mass_trend, bound_vmr, bound_vmr_trend;
   double bound_lat0, bound_lat1, bound_p0, bound_p1, bound_dps, bound_dzs, bound_zetas;
+  /* module_meteo's OH quantity (clim_oh, mptrac.c:89-120): exponent of the diurnal scaling (OH_CHEM_BETA, 0 = none)
+   * and the reference longitude a Cartesian grid is centred on (MET_UTM_REF_LON) */
+  double oh_chem_beta;
+  double met_utm_ref_lon;
 } mphip_ctl_t;
 
 /* View of one met_t snapshot (mptrac.h:3844-4014).  The arrays stay where the
@@ -179,6 +189,12 @@ int mphip_update_ctl(mphip_ctx *ctx, const mphip_ctl_t *ctl);
  * clim_t (mptrac.h:3785-3800); tropo is [ntime][ld] with ld >= nlat. */
 int mphip_update_clim(mphip_ctx *ctx, int ntime, int nlat, const double *tropo_time,
                       const double *tropo_lat, const double *tropo, int ld);
+/* ... and one of its zonal-mean climatologies (clim_zm_t, mptrac.h:3745-3776; `which` = MPHIP_ZM_*): monthly
+ * times [s since the start of the year], descending pressures [hPa], ascending latitudes [deg] and the volume
+ * mixing ratios vmr[ntime][np][nlat] (the reference's index order, compact).  module_meteo needs the table of
+ * every climatology quantity that is requested (hno3: also for tnat); ntime = 0 removes a table. */
+int mphip_update_clim_zm(mphip_ctx *ctx, int which, int ntime, int np, int nlat, const double *time,
+                         const double *p, const double *lat, const double *vmr);
 /* mptrac_update_device(..., met0, met1, ...), mptrac.c:8034-8048; slot 0 = met0,
  * slot 1 = met1. */
 int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met);

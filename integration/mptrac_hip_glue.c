@@ -54,7 +54,7 @@ static int hip_nq;
   X(grid_z0) X(grid_z1) X(grid_lon0) X(grid_lon1) X(grid_lat0) X(grid_lat1) X(grid_nx) X(grid_ny)        \
   X(grid_nz) X(met_dt_out) X(isosurf) X(bound_pbl) X(bound_mass) X(bound_mass_trend) X(bound_vmr)        \
   X(bound_vmr_trend) X(bound_lat0) X(bound_lat1) X(bound_p0) X(bound_p1) X(bound_dps) X(bound_dzs)       \
-  X(bound_zetas)
+  X(bound_zetas) X(oh_chem_beta) X(met_utm_ref_lon)
 
 /* module_meteo outputs: mphip_ctl_t::qnt_met[MPHIP_MQ_<X>] = ctl_t::qnt_<x> */
 #define HIP_CTL_METEO_QNT(X)                                                                             \
@@ -64,7 +64,8 @@ static int hip_nq;
   X(SWC, swc) X(CC, cc) X(PCT, pct) X(PCB, pcb) X(CL, cl) X(PLCL, plcl) X(PLFC, plfc) X(PEL, pel)         \
   X(CAPE, cape) X(CIN, cin) X(O3C, o3c) X(VH, vh) X(VZ, vz) X(PSAT, psat) X(PSICE, psice) X(PW, pw)       \
   X(SH, sh) X(RH, rh) X(RHICE, rhice) X(THETA, theta) X(ZETA_D, zeta_d) X(TVIRT, tvirt)                  \
-  X(LAPSE, lapse) X(PV, pv) X(TDEW, tdew) X(TICE, tice)
+  X(LAPSE, lapse) X(PV, pv) X(TDEW, tdew) X(TICE, tice)                                                  \
+  X(HNO3, hno3) X(OH, oh) X(H2O2, h2o2) X(HO2, ho2) X(O1D, o1d) X(TNAT, tnat) X(TSTS, tsts)
 
 static void hip_ctl(const ctl_t *c, mphip_ctl_t *d) {
   memset(d, 0, sizeof(*d));
@@ -166,9 +167,26 @@ void mptrac_hip_update_device(const ctl_t *ctl, const cache_t *cache, const clim
     HIPCALL(mphip_update_ctl(hip_ctx, &d));
     hip_nq = ctl->nq;
   }
-  if (clim != NULL)
+  if (clim != NULL) {
     HIPCALL(mphip_update_clim(hip_ctx, clim->tropo_ntime, clim->tropo_nlat, clim->tropo_time, clim->tropo_lat,
                               &clim->tropo[0][0], 73));
+    /* the zonal means module_meteo samples: clim_zm_t holds vmr[CT][CP][CY], the back end takes compact tables */
+    const clim_zm_t *zm[MPHIP_NZM] = { &clim->hno3, &clim->oh, &clim->h2o2, &clim->ho2, &clim->o1d };
+    for (int k = 0; k < MPHIP_NZM; k++) {
+      double *v = NULL;
+      if (zm[k]->ntime > 0) {
+        size_t n = 0;
+        ALLOC(v, double, (size_t) zm[k]->ntime * (size_t) zm[k]->np * (size_t) zm[k]->nlat);
+        for (int it = 0; it < zm[k]->ntime; it++)
+          for (int iz = 0; iz < zm[k]->np; iz++)
+            for (int iy = 0; iy < zm[k]->nlat; iy++)
+              v[n++] = zm[k]->vmr[it][iz][iy];
+      }
+      HIPCALL(mphip_update_clim_zm(hip_ctx, k, zm[k]->ntime, zm[k]->np, zm[k]->nlat, zm[k]->time, zm[k]->p,
+                                   zm[k]->lat, v));
+      free(v);
+    }
+  }
   mphip_met_t v;
   if (met0 != NULL) {
     hip_met_view(*met0, &v);

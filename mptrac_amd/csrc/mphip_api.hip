@@ -56,6 +56,8 @@ struct mphip_ctx {
   bool have_ctl = false;
   DevClim *d_clim = nullptr;
   bool have_clim = false;
+  double *d_zm[MPHIP_NZM] = {};      // zonal-mean climatologies: [time | p | lat | vmr] each
+  DevZm zm[MPHIP_NZM] = {};
   double *d_logtab = nullptr;         // table of the lean kernels' logarithm (mphip_logtab.hpp)
 
   // meteo
@@ -811,6 +813,7 @@ MeteoDeps meteo_deps(const mphip_ctl_t &c) {
   f3(MPHIP_MQ_THETA, MPHIP_T);   f3(MPHIP_MQ_ZETA_D, MPHIP_T);  f2(MPHIP_MQ_ZETA_D, MPHIP_PS);
   f3(MPHIP_MQ_TVIRT, MPHIP_T);   f3(MPHIP_MQ_TVIRT, MPHIP_H2O); f3(MPHIP_MQ_LAPSE, MPHIP_T);
   f3(MPHIP_MQ_LAPSE, MPHIP_H2O); f3(MPHIP_MQ_TDEW, MPHIP_H2O);  f3(MPHIP_MQ_TICE, MPHIP_H2O);
+  f3(MPHIP_MQ_TNAT, MPHIP_H2O);
   return d;
 }
 
@@ -837,6 +840,15 @@ int check_meteo(mphip_ctx *ctx) {
   static const char *const n2[MPHIP_N2D] = { "ps", "pbl", "cape", "cin", "pel", "pct", "pcb", "cl", "ess", "nss", "shf",
                                              "ts", "zs", "us", "vs", "lsm", "sst", "pt", "tt", "zt", "h2ot", "plcl",
                                              "plfc", "o3c" };
+  // the climatology quantities: tables, and the rule of mptrac.c:5074-5076
+  static const struct { int q, zm; const char *name; } zmq[] = {
+    { MPHIP_MQ_HNO3, MPHIP_ZM_HNO3, "HNO3" }, { MPHIP_MQ_TNAT, MPHIP_ZM_HNO3, "HNO3" }, { MPHIP_MQ_OH, MPHIP_ZM_OH, "OH" },
+    { MPHIP_MQ_H2O2, MPHIP_ZM_H2O2, "H2O2" }, { MPHIP_MQ_HO2, MPHIP_ZM_HO2, "HO2" }, { MPHIP_MQ_O1D, MPHIP_ZM_O1D, "O1D" } };
+  for (const auto &e : zmq)
+    if (c.qnt_met[e.q] >= 0 && !ctx->d_zm[e.zm])
+      return fail(ctx, std::string("module_meteo: the ") + e.name + " climatology was not uploaded");
+  if (c.qnt_met[MPHIP_MQ_TSTS] >= 0 && (c.qnt_met[MPHIP_MQ_TICE] < 0 || c.qnt_met[MPHIP_MQ_TNAT] < 0))
+    return fail(ctx, "Need T_ice and T_NAT to calculate T_STS!");
   const MeteoDeps d = meteo_deps(c);
   for (int f = 0; f < MPHIP_N3D; f++)
     if (((d.need3 >> f) & 1u) && (!s0.has3[f] || !s1.has3[f]))
@@ -861,6 +873,8 @@ int launch_meteo(mphip_ctx *ctx) {
   G.atm = dev_atm(ctx);
   G.need3 = d.need3;
   G.need2 = d.need2;
+  for (int k = 0; k < MPHIP_NZM; k++)
+    G.zm[k] = ctx->zm[k];
   long long per_block = (ctx->np + ctx->step_blocks - 1) / ctx->step_blocks;
   per_block = std::max<long long>(256, (per_block + 255) / 256 * 256);
   int nb = (int) ((ctx->np + per_block - 1) / per_block);
@@ -1788,6 +1802,8 @@ void mphip_destroy(mphip_ctx *ctx) {
       dev_free(p);
   }
   dev_free(ctx->d_clim);
+  for (auto p : ctx->d_zm)
+    dev_free(p);
   dev_free(ctx->d_logtab);
   dev_free(ctx->d_axes);
   ctx->pk.release();
@@ -1903,6 +1919,47 @@ int mphip_update_clim(mphip_ctx *ctx, int ntime, int nlat, const double *tropo_t
   HIPCHK(hipMemcpyAsync(ctx->d_clim, &h, sizeof(DevClim), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->have_clim = true;
+  return 0;
+}
+
+int mphip_update_clim_zm(mphip_ctx *ctx, int which, int ntime, int np, int nlat, const double *time, const double *p,
+                         const double *lat, const double *vmr) {
+  if (!ctx || which < 0 || which >= MPHIP_NZM)
+    return fail(ctx, "bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (flush_meteo(ctx))   // (a deferred module_meteo reads the tables of its own step)
+    return 1;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  dev_free(ctx->d_zm[which]);
+  ctx->d_zm[which] = nullptr;
+  memset(&ctx->zm[which], 0, sizeof(DevZm));
+  if (ntime == 0)
+    return 0;
+  if (!time || !p || !lat || !vmr)
+    return fail(ctx, "null argument");
+  if (ntime < 2 || np < 2 || nlat < 2 || ntime > 4096 || np > 4096 || nlat > 4096)
+    return fail(ctx, "climatology dimensions out of range");
+  if (!(p[0] > p[1]))
+    return fail(ctx, "Pressure data are not descending!");      // messages of read_clim_zm, mptrac.c:8768, 8774
+  if (!(lat[0] < lat[1]))
+    return fail(ctx, "Latitude data are not ascending!");
+  const size_t nv = (size_t) ntime * (size_t) np * (size_t) nlat, n = (size_t) ntime + np + nlat + nv;
+  double *d = nullptr;
+  if (dev_alloc(ctx, &d, n))
+    return 1;
+  ctx->d_zm[which] = d;
+  HIPCHK(hipMemcpy(d, time, (size_t) ntime * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + ntime, p, (size_t) np * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + ntime + np, lat, (size_t) nlat * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + ntime + np + nlat, vmr, nv * sizeof(double), hipMemcpyHostToDevice));
+  DevZm &z = ctx->zm[which];
+  z.time = d;
+  z.p = d + ntime;
+  z.lat = d + ntime + np;
+  z.vmr = d + ntime + np + nlat;
+  z.ntime = ntime;
+  z.np = np;
+  z.nlat = nlat;
   return 0;
 }
 

@@ -994,6 +994,101 @@ __device__ __forceinline__ double clim_tropo(const DevClim &C, double t, double 
   return pa + div_const(pb - pa, C.time[it + 1] - C.time[it], C.inv_dtime[it]) * (sec - C.time[it]);
 }
 
+// ---- zonal-mean climatologies of clim_t (module_meteo only) ---------------------------------
+
+// view of a clim_zm_t (mptrac.h:3745-3776): vmr[ntime][np][nlat], compact, in device memory
+struct DevZm {
+  const double *time, *p, *lat, *vmr;
+  int ntime, np, nlat, pad;
+};
+
+__device__ __forceinline__ double lin_nodes(double x0, double y0, double x1, double y1, double x) {   // LIN, mptrac.h:1351
+  return y0 + (y1 - y0) / (x1 - x0) * (x - x0);
+}
+
+// clim_zm, mptrac.c:414-466
+__device__ inline double clim_zm(const DevZm &Z, double t, double lat, double p) {
+  double sec = fmod_trunc(t, 365.25 * 86400.);
+  while (sec < 0)
+    sec += 365.25 * 86400.;
+  double p_help = p;
+  if (p < Z.p[Z.np - 1])
+    p_help = Z.p[Z.np - 1];
+  else if (p > Z.p[0])
+    p_help = Z.p[0];
+  double lat_help = lat;
+  if (lat < Z.lat[0])
+    lat_help = Z.lat[0];
+  else if (lat > Z.lat[Z.nlat - 1])
+    lat_help = Z.lat[Z.nlat - 1];
+  const int isec = locate_irr(Z.time, Z.ntime, sec, 1);
+  const int ilat = locate_reg(Z.lat, Z.nlat, lat_help);
+  const int ip = locate_irr(Z.p, Z.np, p_help, 0);
+  auto vmr = [&](int it, int iz, int iy) {
+    return Z.vmr[((size_t) it * (size_t) Z.np + (size_t) iz) * (size_t) Z.nlat + (size_t) iy];
+  };
+  const double aux00 = lin_nodes(Z.p[ip], vmr(isec, ip, ilat), Z.p[ip + 1], vmr(isec, ip + 1, ilat), p_help);
+  const double aux01 = lin_nodes(Z.p[ip], vmr(isec, ip, ilat + 1), Z.p[ip + 1], vmr(isec, ip + 1, ilat + 1), p_help);
+  const double aux10 = lin_nodes(Z.p[ip], vmr(isec + 1, ip, ilat), Z.p[ip + 1], vmr(isec + 1, ip + 1, ilat), p_help);
+  const double aux11 =
+    lin_nodes(Z.p[ip], vmr(isec + 1, ip, ilat + 1), Z.p[ip + 1], vmr(isec + 1, ip + 1, ilat + 1), p_help);
+  const double aux0 = lin_nodes(Z.lat[ilat], aux00, Z.lat[ilat + 1], aux01, lat_help);
+  const double aux1 = lin_nodes(Z.lat[ilat], aux10, Z.lat[ilat + 1], aux11, lat_help);
+  const double aux = lin_nodes(Z.time[isec], aux0, Z.time[isec + 1], aux1, sec);
+  return aux > 0.0 ? aux : 0.0;
+}
+
+// cos_sza, mptrac.c:1857-1897
+__device__ inline double cos_sza(double sec, double lon, double lat) {
+  // (the hour angle is ~1e4 rad years after 2000: no contraction, so that its roundings are the host's)
+#pragma clang fp contract(off)
+  const double d2r = kPi / 180.0;
+  const double D = sec / 86400 - 0.5;
+  const double g = (357.529 + 0.98560028 * D) * d2r;
+  const double q = 280.459 + 0.98564736 * D;
+  const double L = (q + 1.915 * sin(g) + 0.020 * sin(2 * g)) * d2r;
+  const double e = (23.439 - 0.00000036 * D) * d2r;
+  const double sindec = sin(e) * sin(L);
+  const double ra = atan2(cos(e) * sin(L), cos(L));
+  const double GMST = 18.697374558 + 24.06570982441908 * D;
+  const double LST = GMST + lon / 15;
+  const double h = LST / 12 * kPi - ra;
+  const double lat_help = lat * d2r;
+  return sin(lat_help) * sindec + cos(lat_help) * sqrt(1 - sindec * sindec) * cos(h);
+}
+
+// clim_oh, mptrac.c:89-120
+__device__ inline double clim_oh(const mphip_ctl_t &ctl, const DevZm &Z, double t, double lon, double lat, double p) {
+  const double csza_thresh = cos(85. * (kPi / 180.0));
+  const double lat_ref = ctl.met_coord_type == 0 ? lat : ctl.met_utm_ref_lat;
+  double lon_ref = ctl.met_coord_type == 0 ? lon : ctl.met_utm_ref_lon;
+  while (lon_ref < -180.0)
+    lon_ref += 360.0;
+  while (lon_ref >= 180.0)
+    lon_ref -= 360.0;
+  const double oh = clim_zm(Z, t, lat_ref, p);
+  if (ctl.oh_chem_beta <= 0)
+    return oh;
+  const double csza = cos_sza(t, lon_ref, lat_ref);
+  const double denom = (csza >= csza_thresh) ? csza : csza_thresh;
+  return oh * exp(-ctl.oh_chem_beta / denom);
+}
+
+// nat_temperature, mptrac.c:8334-8355
+__device__ inline double nat_temperature(double p, double h2o, double hno3) {
+  const double h2o_help = h2o > 0.1e-6 ? h2o : 0.1e-6;
+  const double p_hno3 = hno3 * p / 1.333224;
+  const double p_h2o = h2o_help * p / 1.333224;
+  const double a = 0.009179 - 0.00088 * log10(p_h2o);
+  const double b = (38.9855 - log10(p_hno3) - 2.7836 * log10(p_h2o)) / a;
+  const double c = -11397.0 / a;
+  double tnat = (-b + sqrt(b * b - 4. * c)) / 2.;
+  const double x2 = (-b - sqrt(b * b - 4. * c)) / 2.;
+  if (x2 > 0)
+    tnat = x2;
+  return tnat;
+}
+
 // tropo_weight, mptrac.c:12748-12770, split so that the climatological
 // tropopause pressure (a function of time and latitude only) is looked up once
 // for several pressures

@@ -2053,6 +2053,7 @@ struct MeteoArgs {
   DevMet met;
   DevAtm atm;
   unsigned need3, need2;
+  DevZm zm[MPHIP_NZM];             // zonal-mean climatologies (tables of the requested quantities only)
   int nblocks_logical;             // as StepParams: contiguous runs of the locality order per block
   long long per_block;
   int xcd_map;
@@ -2190,7 +2191,28 @@ __global__ __launch_bounds__(256, MPHIP_METEO_WAVES_PER_SIMD) void meteo_kernel(
     SETQ(MPHIP_MQ_TVIRT, tvirt(t, h2o));
     SETQ(MPHIP_MQ_LAPSE, lapse_rate(t, h2o));
     SETQ(MPHIP_MQ_TDEW, tdew_of(p, h2o));
-    SETQ(MPHIP_MQ_TICE, tice_of(p, h2o));
+    const double tice = tice_of(p, h2o);
+    SETQ(MPHIP_MQ_TICE, tice);
+    // the climatology part of the list (mptrac.c:5129-5141, 5158-5163)
+    if (qm[MPHIP_MQ_HNO3] >= 0 || qm[MPHIP_MQ_OH] >= 0 || qm[MPHIP_MQ_H2O2] >= 0 || qm[MPHIP_MQ_HO2] >= 0
+        || qm[MPHIP_MQ_O1D] >= 0 || qm[MPHIP_MQ_TNAT] >= 0) {
+      const double lat_ref = G.ctl.met_coord_type == 0 ? lat : G.ctl.met_utm_ref_lat;
+      if (qm[MPHIP_MQ_HNO3] >= 0)
+        a.q[qm[MPHIP_MQ_HNO3]][i] = clim_zm(G.zm[MPHIP_ZM_HNO3], tm, lat_ref, p);
+      if (qm[MPHIP_MQ_OH] >= 0)
+        a.q[qm[MPHIP_MQ_OH]][i] = clim_oh(G.ctl, G.zm[MPHIP_ZM_OH], tm, lon, lat, p);
+      if (qm[MPHIP_MQ_H2O2] >= 0)
+        a.q[qm[MPHIP_MQ_H2O2]][i] = clim_zm(G.zm[MPHIP_ZM_H2O2], tm, lat_ref, p);
+      if (qm[MPHIP_MQ_HO2] >= 0)
+        a.q[qm[MPHIP_MQ_HO2]][i] = clim_zm(G.zm[MPHIP_ZM_HO2], tm, lat_ref, p);
+      if (qm[MPHIP_MQ_O1D] >= 0)
+        a.q[qm[MPHIP_MQ_O1D]][i] = clim_zm(G.zm[MPHIP_ZM_O1D], tm, lat_ref, p);
+      if (qm[MPHIP_MQ_TNAT] >= 0) {   // (at the particle's own latitude, Cartesian grid or not: mptrac.c:5160)
+        const double tnat = nat_temperature(p, h2o, clim_zm(G.zm[MPHIP_ZM_HNO3], tm, lat, p));
+        a.q[qm[MPHIP_MQ_TNAT]][i] = tnat;
+        SETQ(MPHIP_MQ_TSTS, 0.5 * (tice + tnat));   // of the two quantities just stored (both requested: check_meteo)
+      }
+    }
 #undef SETQ
   }
 }

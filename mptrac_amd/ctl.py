@@ -94,8 +94,7 @@ CTL_FIELDS = [
     ("pad1", C.c_int, 0),
     # module_meteo, mptrac.c:7197 and 7921-7924; qnt_met[k] = ctl->qnt_<METEO_QUANTITIES[k]>
     ("met_dt_out", C.c_double, 0.1),
-    ("qnt_met", C.c_int * 53, (-1,) * 53),
-    ("pad2", C.c_int, 0),
+    ("qnt_met", C.c_int * 60, (-1,) * 60),
     # module_isosurf (mptrac.c:7208) and module_bound_cond (mptrac.c:7266-7289)
     ("isosurf", C.c_int, 0),
     ("bound_pbl", C.c_int, 0),
@@ -112,6 +111,9 @@ CTL_FIELDS = [
     ("bound_dps", C.c_double, -999.0),
     ("bound_dzs", C.c_double, -999.0),
     ("bound_zetas", C.c_double, -999.0),
+    # module_meteo's OH climatology (clim_oh, mptrac.c:89-120): diurnal scaling, reference longitude of a Cartesian grid
+    ("oh_chem_beta", C.c_double, 0.0),
+    ("met_utm_ref_lon", C.c_double, 0.0),
 ]
 
 # quantities module_meteo fills, in the order of its SET_ATM list (mptrac.c:5091-5157) = MPHIP_MQ_*
@@ -119,8 +121,13 @@ METEO_QUANTITIES = (
     "ps", "ts", "zs", "us", "vs", "ess", "nss", "shf", "lsm", "sst", "pbl", "pt", "tt", "zt", "h2ot", "zg", "p",
     "t", "rho", "u", "v", "w", "h2o", "o3", "lwc", "rwc", "iwc", "swc", "cc", "pct", "pcb", "cl", "plcl", "plfc",
     "pel", "cape", "cin", "o3c", "vh", "vz", "psat", "psice", "pw", "sh", "rh", "rhice", "theta", "zeta_d",
-    "tvirt", "lapse", "pv", "tdew", "tice")
-assert len(METEO_QUANTITIES) == 53
+    "tvirt", "lapse", "pv", "tdew", "tice",
+    # from the zonal-mean climatologies of clim_t (ZONAL_MEANS below)
+    "hno3", "oh", "h2o2", "ho2", "o1d", "tnat", "tsts")
+assert len(METEO_QUANTITIES) == 60
+
+# zonal-mean climatologies module_meteo samples (clim_zm_t members of clim_t, mptrac.h:3805-3817) = MPHIP_ZM_*
+ZONAL_MEANS = ("hno3", "oh", "h2o2", "ho2", "o1d")
 
 
 def make_ctl_struct(name):

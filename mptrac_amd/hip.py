@@ -14,7 +14,7 @@ import weakref
 import numpy as np
 
 from . import build as _build
-from .ctl import fill_ctl, make_ctl_struct
+from .ctl import ZONAL_MEANS, fill_ctl, make_ctl_struct
 from .synth import FIELDS_2D, FIELDS_3D, FIELDS_ML
 
 NQ_MAX = 16
@@ -83,6 +83,7 @@ def load(build=True):
     L.mphip_destroy.restype = None
     L.mphip_update_ctl.argtypes = [C.c_void_p, C.POINTER(MphipCtl)]
     L.mphip_update_clim.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
+    L.mphip_update_clim_zm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
     L.mphip_update_met.argtypes = [C.c_void_p, C.c_int, C.POINTER(MphipMet)]
     L.mphip_swap_met.argtypes = [C.c_void_p]
     L.mphip_prefetch_met.argtypes = [C.c_void_p, C.POINTER(MphipMet)]
@@ -149,12 +150,15 @@ class Simulation:
         _LIVE.add(self)
         self._mets = [None, None]
         self._next_met = None
-        time, lat, tropo = clim
+        time, lat, tropo = clim[:3]
         tropo = np.ascontiguousarray(tropo, dtype=np.float64)
         self._chk(self.L.mphip_update_clim(self.h, len(time), len(lat),
                                            _ptr(np.ascontiguousarray(time, dtype=np.float64), _dp),
                                            _ptr(np.ascontiguousarray(lat, dtype=np.float64), _dp),
                                            _ptr(tropo, _dp), tropo.shape[1]))
+        # zonal-mean climatologies: optional fourth element {name: (time, p, lat, vmr[ntime][np][nlat])}
+        for name, tab in (clim[3] if len(clim) > 3 else {}).items():
+            self.update_clim_zm(name, *tab)
         self.update_ctl()
         self.set_met(0, met0)
         self.set_met(1, met1)
@@ -168,6 +172,14 @@ class Simulation:
         self.update_atm(atm)
         ctr = C.c_uint64(rng_ctr)
         self._chk(self.L.mphip_update_cache(self.h, None, C.byref(ctr)))
+
+    def update_clim_zm(self, name, time=(), p=(), lat=(), vmr=()):
+        """A zonal-mean climatology of clim_t for module_meteo (hno3, oh, h2o2, ho2, o1d); no nodes: removed."""
+        time, p, lat, vmr = (np.ascontiguousarray(a, dtype=np.float64) for a in (time, p, lat, vmr))
+        if len(time):
+            assert vmr.shape == (len(time), len(p), len(lat))
+        self._chk(self.L.mphip_update_clim_zm(self.h, ZONAL_MEANS.index(name), len(time), len(p), len(lat),
+                                              _ptr(time, _dp), _ptr(p, _dp), _ptr(lat, _dp), _ptr(vmr, _dp)))
 
     # -- plumbing -----------------------------------------------------------
     def _chk(self, rc):

@@ -136,12 +136,12 @@ static const struct {
   { "lapse", "temperature lapse rate", "K/km" }, { "vh", "horizontal velocity", "m/s" },
   { "vz", "vertical velocity", "m/s" }, { "pv", "potential vorticity", "PVU" },
   { "tdew", "dew point temperature", "K" }, { "tice", "frost point temperature", "K" },
+  { "hno3", "nitric acid", "ppv" }, { "oh", "hydroxyl radical", "ppv" }, { "h2o2", "hydrogen peroxide", "ppv" },
+  { "ho2", "hydroperoxyl radical", "ppv" }, { "o1d", "atomic oxygen", "ppv" },
+  { "tsts", "STS existence temperature", "K" }, { "tnat", "NAT existence temperature", "K" },
 };
 
 static const char *unsupported_qnt[] = {
-  /* quantities module_meteo takes from the chemistry climatologies (mptrac.c:5129-5140, 5158-5163);
-   * not provided */
-  "hno3", "oh", "h2o2", "ho2", "o1d", "tsts", "tnat",
   /* quantities only the chemistry, radioactive-decay and domain-decomposition code of the reference fills or
    * mixes (SET_QNT table, mptrac.c:6905-6969): they would be carried along unchanged here */
   "mloss_oh", "mloss_h2o2", "mloss_kpp", "Cx", "Ch2o", "Co3", "Cco", "Coh", "Ch", "Cho2", "Ch2o2", "Co1d", "Co3p",
@@ -158,6 +158,12 @@ static const char *unsupported_qnt[] = {
   D(t_stop, "T_STOP", "1e100") \
   D(dt_mod, "DT_MOD", "180") \
   S(metbase, "METBASE", "-") \
+  S(clim_hno3_filename, "CLIM_HNO3_FILENAME", "../../data/gozcards_HNO3.nc") \
+  S(clim_oh_filename, "CLIM_OH_FILENAME", "../../data/clams_radical_species_vmr.nc") \
+  S(clim_h2o2_filename, "CLIM_H2O2_FILENAME", "../../data/cams_H2O2.nc") \
+  S(clim_ho2_filename, "CLIM_HO2_FILENAME", "../../data/clams_radical_species_vmr.nc") \
+  S(clim_o1d_filename, "CLIM_O1D_FILENAME", "../../data/clams_radical_species_vmr.nc") \
+  D(oh_chem_beta, "OH_CHEM_BETA", "0") \
   D(dt_met, "DT_MET", "3600") \
   I(met_type, "MET_TYPE", "0") \
   D(met_dt_out, "MET_DT_OUT", "0.1") \
@@ -357,6 +363,8 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   /* checks and the keys that depend on others */
   ctl->met_utm_ref_lat = (ctl->met_coord_type != 0)
     ? scan_ctl(filename, argc, argv, "MET_UTM_REF_LAT", -1, "", NULL) : 0;
+  ctl->met_utm_ref_lon = (ctl->met_coord_type != 0)
+    ? scan_ctl(filename, argc, argv, "MET_UTM_REF_LON", -1, "", NULL) : 0;
   REQUIRE(ctl->direction == -1 || ctl->direction == 1, "Set DIRECTION to -1 or 1!");
   if (ctl->met_type == 0) {
     /* netCDF input is taken as stored: no down-sampling, smoothing, detrending, re-gridding (mptrac.c:7770-7830) */
@@ -531,9 +539,132 @@ void clim_tropo_init(clim_t *clim) {
     ERRMSG("Error while reading tropopause climatology!");
 }
 
+/* cos_sza (mptrac.c:1857-1897): cosine of the solar zenith angle at `sec` seconds since 2000-01-01 00:00 UTC */
+static double cos_sza(const double sec, const double lon, const double lat) {
+  const double D = sec / 86400 - 0.5;
+  const double g = DEG2RAD(357.529 + 0.98560028 * D);
+  const double q = 280.459 + 0.98564736 * D;
+  const double L = DEG2RAD(q + 1.915 * sin(g) + 0.020 * sin(2 * g));
+  const double e = DEG2RAD(23.439 - 0.00000036 * D);
+  const double sindec = sin(e) * sin(L);
+  const double ra = atan2(cos(e) * sin(L), cos(L));
+  const double GMST = 18.697374558 + 24.06570982441908 * D;
+  const double LST = GMST + lon / 15;
+  const double h = LST / 12 * M_PI - ra;
+  return sin(DEG2RAD(lat)) * sindec + cos(DEG2RAD(lat)) * sqrt(1 - SQR(sindec)) * cos(h);
+}
+
+/* One zonal-mean climatology (monthly means) from a netCDF file with the dimensions time (12), press, lat and
+ * the variable `varname`[time][press][lat] -- read_clim_zm, mptrac.c:8747-8843.  A file that cannot be opened is
+ * a warning (the table stays empty and module_meteo refuses the quantities that need it); negative entries are
+ * gaps, filled from the same column (lowest valid level, then overwritten by the highest one -- the reference's
+ * two loops, in their order). */
+static void read_clim_zm(const char *filename, const char *varname, clim_zm_t *zm) {
+  static const double month_mid[12] = { 1209600.00, 3888000.00, 6393600.00, 9072000.00, 11664000.00, 14342400.00,
+    16934400.00, 19612800.00, 22291200.00, 24883200.00, 27561600.00, 30153600.00 };
+  LOG(1, "Read %s data: %s", varname, filename);
+  char why[256];
+  ncc_file *nc = ncc_open(filename, why, sizeof(why));
+  if (!nc) {
+    WARN("%s climatology data are missing! (%s)", varname, why);
+    return;
+  }
+  long long np, nlat, nt;
+  if (ncc_find_dim(nc, "press", &np) < 0 || np < 2 || np > CP)
+    ERRMSG("Dimension press is missing or out of range!");
+  if (ncc_find_dim(nc, "lat", &nlat) < 0 || nlat < 2 || nlat > CY)
+    ERRMSG("Dimension lat is missing or out of range!");
+  if (ncc_find_dim(nc, "time", &nt) < 0 || nt != 12)
+    ERRMSG("Dimension time is missing or out of range!");
+  const int vp = ncc_find_var(nc, "press"), vlat = ncc_find_var(nc, "lat"), var = ncc_find_var(nc, varname);
+  if (vp < 0 || vlat < 0 || var < 0)
+    ERRMSG("Cannot find the variables press, lat and %s!", varname);
+  zm->np = (int) np;
+  zm->nlat = (int) nlat;
+  if (!ncc_read_double(nc, vp, 0, 0, np, zm->p) || !ncc_read_double(nc, vlat, 0, 0, nlat, zm->lat))
+    ERRMSG("netCDF: %s", ncc_error(nc));
+  if (zm->p[0] < zm->p[1])
+    ERRMSG("Pressure data are not descending!");
+  if (zm->lat[0] > zm->lat[1])
+    ERRMSG("Latitude data are not ascending!");
+  zm->ntime = 12;
+  for (int it = 0; it < 12; it++)
+    zm->time[it] = month_mid[it];
+  double *help;
+  ALLOC(help, double, (size_t) (np * nlat));
+  const int by_record = ncc_var_is_record(nc, var);
+  for (int it = 0; it < zm->ntime; it++) {
+    if (!ncc_read_double(nc, var, by_record ? it : 0, by_record ? 0 : (long long) it * np * nlat, np * nlat, help))
+      ERRMSG("netCDF: %s", ncc_error(nc));
+    for (int iz = 0; iz < zm->np; iz++)
+      for (int iy = 0; iy < zm->nlat; iy++)
+        zm->vmr[it][iz][iy] = help[(size_t) iz * (size_t) zm->nlat + (size_t) iy];
+  }
+  free(help);
+  ncc_close(nc);
+  double lo = 1e99, hi = -1e99;
+  for (int it = 0; it < zm->ntime; it++)
+    for (int iy = 0; iy < zm->nlat; iy++)
+      for (int iz = 0; iz < zm->np; iz++) {
+        if (zm->vmr[it][iz][iy] < 0) {
+          for (int k = 0; k < zm->np; k++)
+            if (zm->vmr[it][k][iy] >= 0) {
+              zm->vmr[it][iz][iy] = zm->vmr[it][k][iy];
+              break;
+            }
+          for (int k = zm->np - 1; k >= 0; k--)
+            if (zm->vmr[it][k][iy] >= 0) {
+              zm->vmr[it][iz][iy] = zm->vmr[it][k][iy];
+              break;
+            }
+        }
+        lo = fmin(lo, zm->vmr[it][iz][iy]);
+        hi = fmax(hi, zm->vmr[it][iz][iy]);
+      }
+  LOG(2, "Number of time steps: %d", zm->ntime);
+  LOG(2, "Number of pressure levels: %d", zm->np);
+  LOG(2, "Pressure levels: %g, %g ... %g hPa", zm->p[0], zm->p[1], zm->p[zm->np - 1]);
+  LOG(2, "Number of latitudes: %d", zm->nlat);
+  LOG(2, "Latitudes: %g, %g ... %g deg", zm->lat[0], zm->lat[1], zm->lat[zm->nlat - 1]);
+  LOG(2, "%s volume mixing ratio range: %g ... %g ppv", varname, lo, hi);
+}
+
+/* clim_oh_diurnal_correction (mptrac.c:122-152): the OH table divided by the zonal mean of the day / night
+ * factor exp(-beta / cos(sza)) that clim_oh applies again per particle */
+static void clim_oh_diurnal_correction(const ctl_t *ctl, clim_t *clim) {
+  const double csza_thresh = cos(DEG2RAD(85.));
+  for (int it = 0; it < clim->oh.ntime; it++)
+    for (int iz = 0; iz < clim->oh.np; iz++)
+      for (int iy = 0; iy < clim->oh.nlat; iy++) {
+        int n = 0;
+        double sum = 0;
+        for (double lon = -180; lon < 180; lon += 1.0) {
+          const double csza = cos_sza(clim->oh.time[it], lon, clim->oh.lat[iy]);
+          sum += exp(-ctl->oh_chem_beta / (csza >= csza_thresh ? csza : csza_thresh));
+          n++;
+        }
+        clim->oh.vmr[it][iz][iy] /= (sum / (double) n);
+      }
+}
+
+/* mptrac.c:6663-6719: the tropopause climatology and the zonal means a requested module_meteo quantity needs
+ * (the reference reads all its climatologies whatever the quantities; its photolysis rates and tracer time
+ * series feed the chemistry modules, which are not part of this build) */
 void mptrac_read_clim(const ctl_t *ctl, clim_t *clim) {
-  (void) ctl;   /* the chemistry climatologies of mptrac.c:6663-6719 are not on the hot path */
   clim_tropo_init(clim);
+  if ((ctl->qnt_hno3 >= 0 || ctl->qnt_tnat >= 0) && ctl->clim_hno3_filename[0] != '-')
+    read_clim_zm(ctl->clim_hno3_filename, "HNO3", &clim->hno3);
+  if (ctl->qnt_oh >= 0 && ctl->clim_oh_filename[0] != '-') {
+    read_clim_zm(ctl->clim_oh_filename, "OH", &clim->oh);
+    if (ctl->oh_chem_beta > 0)
+      clim_oh_diurnal_correction(ctl, clim);
+  }
+  if (ctl->qnt_h2o2 >= 0 && ctl->clim_h2o2_filename[0] != '-')
+    read_clim_zm(ctl->clim_h2o2_filename, "H2O2", &clim->h2o2);
+  if (ctl->qnt_ho2 >= 0 && ctl->clim_ho2_filename[0] != '-')
+    read_clim_zm(ctl->clim_ho2_filename, "HO2", &clim->ho2);
+  if (ctl->qnt_o1d >= 0 && ctl->clim_o1d_filename[0] != '-')
+    read_clim_zm(ctl->clim_o1d_filename, "O1D", &clim->o1d);
 }
 
 /* -------------------------------------------------------------------------- */
@@ -1401,21 +1532,22 @@ static void get_met_filename(const ctl_t *ctl, const double t, const int direct,
 
 static void to_device_ctl(const ctl_t *c, mphip_ctl_t *d) {
   memset(d, 0, sizeof(*d));
-#define CP(f) d->f = c->f
-  CP(direction); CP(met_coord_type); CP(t_start); CP(t_stop); CP(dt_mod); CP(dt_met); CP(met_utm_ref_lat);
-  CP(nq); CP(qnt_m); CP(qnt_vmr); CP(qnt_rp); CP(qnt_rhop); CP(qnt_ens); CP(qnt_loss_rate);
-  CP(qnt_mloss_decay); CP(qnt_mloss_wet); CP(qnt_mloss_dry); CP(nens); CP(advect); CP(advect_vert_coord);
-  CP(rng_type); CP(diffusion); CP(turb_pbl_scheme); CP(conv_mix_pbl);
-  CP(turb_dx_pbl); CP(turb_dx_trop); CP(turb_dx_strat); CP(turb_dz_pbl); CP(turb_dz_trop); CP(turb_dz_strat);
-  CP(turb_mesox); CP(turb_mesoz); CP(turb_pbl_trans); CP(conv_pbl_trans); CP(conv_cape); CP(conv_cin);
-  CP(conv_dt); CP(sort_dt); CP(tdec_trop); CP(tdec_strat); CP(mixing_dt); CP(mixing_trop); CP(mixing_strat);
-  CP(mixing_z0); CP(mixing_z1); CP(mixing_lon0); CP(mixing_lon1); CP(mixing_lat0); CP(mixing_lat1);
-  CP(mixing_nx); CP(mixing_ny); CP(mixing_nz);
-  CP(wet_depo_ic_a); CP(wet_depo_ic_b); CP(wet_depo_bc_a); CP(wet_depo_bc_b); CP(wet_depo_so2_ph);
-  CP(wet_depo_ic_ret_ratio); CP(wet_depo_bc_ret_ratio); CP(dry_depo_vdep); CP(dry_depo_dp);
-  CP(grid_z0); CP(grid_z1); CP(grid_lon0); CP(grid_lon1); CP(grid_lat0); CP(grid_lat1);
-  CP(grid_nx); CP(grid_ny); CP(grid_nz);
-#undef CP
+#define TAKE(f) d->f = c->f
+  TAKE(direction); TAKE(met_coord_type); TAKE(t_start); TAKE(t_stop); TAKE(dt_mod); TAKE(dt_met); TAKE(met_utm_ref_lat);
+  TAKE(met_utm_ref_lon); TAKE(oh_chem_beta);
+  TAKE(nq); TAKE(qnt_m); TAKE(qnt_vmr); TAKE(qnt_rp); TAKE(qnt_rhop); TAKE(qnt_ens); TAKE(qnt_loss_rate);
+  TAKE(qnt_mloss_decay); TAKE(qnt_mloss_wet); TAKE(qnt_mloss_dry); TAKE(nens); TAKE(advect); TAKE(advect_vert_coord);
+  TAKE(rng_type); TAKE(diffusion); TAKE(turb_pbl_scheme); TAKE(conv_mix_pbl);
+  TAKE(turb_dx_pbl); TAKE(turb_dx_trop); TAKE(turb_dx_strat); TAKE(turb_dz_pbl); TAKE(turb_dz_trop); TAKE(turb_dz_strat);
+  TAKE(turb_mesox); TAKE(turb_mesoz); TAKE(turb_pbl_trans); TAKE(conv_pbl_trans); TAKE(conv_cape); TAKE(conv_cin);
+  TAKE(conv_dt); TAKE(sort_dt); TAKE(tdec_trop); TAKE(tdec_strat); TAKE(mixing_dt); TAKE(mixing_trop); TAKE(mixing_strat);
+  TAKE(mixing_z0); TAKE(mixing_z1); TAKE(mixing_lon0); TAKE(mixing_lon1); TAKE(mixing_lat0); TAKE(mixing_lat1);
+  TAKE(mixing_nx); TAKE(mixing_ny); TAKE(mixing_nz);
+  TAKE(wet_depo_ic_a); TAKE(wet_depo_ic_b); TAKE(wet_depo_bc_a); TAKE(wet_depo_bc_b); TAKE(wet_depo_so2_ph);
+  TAKE(wet_depo_ic_ret_ratio); TAKE(wet_depo_bc_ret_ratio); TAKE(dry_depo_vdep); TAKE(dry_depo_dp);
+  TAKE(grid_z0); TAKE(grid_z1); TAKE(grid_lon0); TAKE(grid_lon1); TAKE(grid_lat0); TAKE(grid_lat1);
+  TAKE(grid_nx); TAKE(grid_ny); TAKE(grid_nz);
+#undef TAKE
   d->qnt_zeta = c->qnt_zeta;
   d->qnt_eta = c->qnt_eta;
   d->met_dt_out = c->met_dt_out;
@@ -1645,9 +1777,24 @@ void mptrac_update_device(const ctl_t *ctl, const cache_t *cache, const clim_t *
     HIP(mphip_update_ctl(g_ctx, &d));
     g_nq = ctl->nq;
   }
-  if (clim)
+  if (clim) {
     HIP(mphip_update_clim(g_ctx, clim->tropo_ntime, clim->tropo_nlat, clim->tropo_time, clim->tropo_lat,
                           &clim->tropo[0][0], 73));
+    const clim_zm_t *zm[MPHIP_NZM] = { &clim->hno3, &clim->oh, &clim->h2o2, &clim->ho2, &clim->o1d };
+    for (int k = 0; k < MPHIP_NZM; k++) {   /* compact copies of the tables that were read */
+      double *v = NULL;
+      if (zm[k]->ntime > 0) {
+        ALLOC(v, double, (size_t) zm[k]->ntime * (size_t) zm[k]->np * (size_t) zm[k]->nlat);
+        size_t n = 0;
+        for (int it = 0; it < zm[k]->ntime; it++)
+          for (int iz = 0; iz < zm[k]->np; iz++)
+            for (int iy = 0; iy < zm[k]->nlat; iy++)
+              v[n++] = zm[k]->vmr[it][iz][iy];
+      }
+      HIP(mphip_update_clim_zm(g_ctx, k, zm[k]->ntime, zm[k]->np, zm[k]->nlat, zm[k]->time, zm[k]->p, zm[k]->lat, v));
+      free(v);
+    }
+  }
   if (met0)
     upload_met(*met0, 0);
   if (met1)

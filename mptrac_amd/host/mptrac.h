@@ -120,7 +120,8 @@ extern "C" {
   X(swc, "kg/kg") X(cc, "1") X(pct, "hPa") X(pcb, "hPa") X(cl, "kg/m^2") X(plcl, "hPa") X(plfc, "hPa")  \
   X(pel, "hPa") X(cape, "J/kg") X(cin, "J/kg") X(o3c, "DU") X(vh, "m/s") X(vz, "m/s") X(psat, "hPa")    \
   X(psice, "hPa") X(pw, "hPa") X(sh, "kg/kg") X(rh, "%") X(rhice, "%") X(theta, "K") X(zeta_d, "K")     \
-  X(tvirt, "K") X(lapse, "K/km") X(pv, "PVU") X(tdew, "K") X(tice, "K")
+  X(tvirt, "K") X(lapse, "K/km") X(pv, "PVU") X(tdew, "K") X(tice, "K")                                 \
+  X(hno3, "ppv") X(oh, "ppv") X(h2o2, "ppv") X(ho2, "ppv") X(o1d, "ppv") X(tnat, "K") X(tsts, "K")
 
 /* ---- structs -------------------------------------------------------------- */
 
@@ -139,7 +140,11 @@ typedef struct {
   /* time and meteo input */
   int direction, met_coord_type, met_type;
   int met_nc_scale, met_pbl, met_cape;   /* netCDF input (MET_TYPE 0): packed data, source of pbl / cape */
-  double t_start, t_stop, dt_mod, dt_met, met_utm_ref_lat, met_dt_out;
+  double t_start, t_stop, dt_mod, dt_met, met_utm_ref_lat, met_utm_ref_lon, met_dt_out;
+  /* zonal-mean climatologies module_meteo samples (mptrac.c:7461-7470) and the diurnal scaling of OH (mptrac.c:7394) */
+  char clim_hno3_filename[LEN], clim_oh_filename[LEN], clim_h2o2_filename[LEN], clim_ho2_filename[LEN],
+    clim_o1d_filename[LEN];
+  double oh_chem_beta;
   char metbase[LEN];
   /* modules */
   double sort_dt;
@@ -217,14 +222,38 @@ typedef struct {
   double dt[NP];
 } cache_t;
 
-/* climatological data: tropopause part of the reference's clim_t
- * (mptrac.h:3785-3800) */
+/* extents of the zonal-mean climatologies (reference: mptrac.h:599-620) */
+#ifndef CP
+#define CP 70
+#endif
+#ifndef CY
+#define CY 250
+#endif
+#ifndef CT
+#define CT 12
+#endif
+
+/* a zonal-mean climatology, as the reference (clim_zm_t, mptrac.h:3745-3776) */
+typedef struct {
+  int ntime;
+  int nlat;
+  int np;
+  double time[CT];
+  double lat[CY];
+  double p[CP];
+  double vmr[CT][CP][CY];
+} clim_zm_t;
+
+/* climatological data: the tropopause part of the reference's clim_t (mptrac.h:3785-3800) and the zonal means
+ * module_meteo samples (mptrac.h:3805-3817); photolysis rates and the tracer time series belong to the
+ * chemistry modules and are absent */
 typedef struct {
   int tropo_ntime;
   int tropo_nlat;
   double tropo_time[12];
   double tropo_lat[73];
   double tropo[12][73];
+  clim_zm_t hno3, oh, h2o2, ho2, o1d;
 } clim_t;
 
 /* meteo snapshot: the fields of the reference's met_t (mptrac.h:3844-4014)

@@ -342,6 +342,10 @@ int ncc_var_is_packed(const ncc_file *nc, int var) {
   return nc->var[var].type == T_SHORT || nc->var[var].type == T_BYTE;
 }
 
+int ncc_var_is_record(const ncc_file *nc, int var) {
+  return nc->var[var].is_record;
+}
+
 int ncc_get_att(const ncc_file *nc, int var, const char *name, double *value) {
   const int n = var < 0 ? nc->natt : nc->var[var].natt;
   const ncc_att *a = var < 0 ? nc->att : nc->var[var].att;

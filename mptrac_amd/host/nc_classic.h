@@ -16,6 +16,7 @@ int ncc_find_var(const ncc_file *nc, const char *name);
 int ncc_var_ndims(const ncc_file *nc, int var);
 long long ncc_var_dim(const ncc_file *nc, int var, int d, const char **name);
 int ncc_var_is_packed(const ncc_file *nc, int var);                /* stored as short / byte */
+int ncc_var_is_record(const ncc_file *nc, int var);                /* leading dimension is the record dimension */
 /* first value of a numeric attribute of variable `var` (-1: global); 0 if absent */
 int ncc_get_att(const ncc_file *nc, int var, const char *name, double *value);
 /* `count` elements from element `first` of record `rec` of a record variable (leading dimension unlimited)

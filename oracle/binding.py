@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from mptrac_amd.ctl import make_ctl_struct, fill_ctl
+from mptrac_amd.ctl import ZONAL_MEANS, make_ctl_struct, fill_ctl
 from mptrac_amd.synth import FIELDS_2D, FIELDS_3D
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -37,9 +37,14 @@ class OrcCache(C.Structure):
                 ("iso_var", _dp), ("iso_ts", _dp), ("iso_ps", _dp), ("iso_n", C.c_int)]
 
 
+class OrcZm(C.Structure):
+    _fields_ = [("ntime", C.c_int), ("np", C.c_int), ("nlat", C.c_int), ("pad", C.c_int),
+                ("time", _dp), ("p", _dp), ("lat", _dp), ("vmr", _dp)]
+
+
 class OrcClim(C.Structure):
     _fields_ = [("tropo_ntime", C.c_int), ("tropo_nlat", C.c_int), ("tropo_time", C.c_double * 12),
-                ("tropo_lat", C.c_double * 73), ("tropo", (C.c_double * 73) * 12)]
+                ("tropo_lat", C.c_double * 73), ("tropo", (C.c_double * 73) * 12), ("zm", OrcZm * len(ZONAL_MEANS))]
 
 
 def build(force=False):
@@ -98,8 +103,12 @@ def lib():
                                               C.POINTER(C.c_int), _dp, _dp]
         _lib.orc_intpol_met_time_3d.argtypes = [C.POINTER(OrcMet), C.POINTER(OrcMet), C.c_int] + \
             [C.c_double] * 4 + [_dp]
+        _lib.orc_clim_zm.restype = C.c_double
+        _lib.orc_clim_zm.argtypes = [C.POINTER(OrcZm)] + [C.c_double] * 3
+        _lib.orc_clim_oh.restype = C.c_double
+        _lib.orc_clim_oh.argtypes = [C.POINTER(OrcCtl), C.POINTER(OrcClim)] + [C.c_double] * 4
         for fn, nargs in (("orc_rh", 3), ("orc_rhice", 3), ("orc_tdew", 2), ("orc_tice", 2), ("orc_theta", 2),
-                          ("orc_zeta", 3), ("orc_lapse_rate", 2)):
+                          ("orc_zeta", 3), ("orc_lapse_rate", 2), ("orc_cos_sza", 3), ("orc_nat_temperature", 3)):
             getattr(_lib, fn).restype = C.c_double
             getattr(_lib, fn).argtypes = [C.c_double] * nargs
         _lib.orc_intpol_met_time_2d.argtypes = [C.POINTER(OrcMet), C.POINTER(OrcMet), C.c_int] + \
@@ -118,8 +127,17 @@ class Oracle:
     def __init__(self, ctl_kw, clim, met0, met1, atm, rng_ctr=0):
         self.lib = lib()
         self.ctl = fill_ctl(OrcCtl(), **ctl_kw)
-        time, lat, tropo = clim
+        time, lat, tropo = clim[:3]
         self.clim = OrcClim()
+        # zonal-mean climatologies: optional fourth element {name: (time, p, lat, vmr[ntime][np][nlat])}
+        self._zm = {}
+        for name, tab in (clim[3] if len(clim) > 3 else {}).items():
+            arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in tab]
+            assert arrs[3].shape == (len(arrs[0]), len(arrs[1]), len(arrs[2])), name
+            self._zm[name] = arrs
+            z = self.clim.zm[ZONAL_MEANS.index(name)]
+            z.ntime, z.np, z.nlat = (len(a) for a in arrs[:3])
+            z.time, z.p, z.lat, z.vmr = (_ptr(a, _dp) for a in arrs)
         self.clim.tropo_ntime, self.clim.tropo_nlat = len(time), len(lat)
         for i, v in enumerate(time):
             self.clim.tropo_time[i] = v
@@ -215,7 +233,7 @@ class Oracle:
         elif name == "dry_depo":
             L.orc_module_dry_depo(ctl, cache, m0, m1, atm)
         elif name == "meteo":
-            L.orc_module_meteo(ctl, m0, m1, atm)
+            L.orc_module_meteo(ctl, clim, m0, m1, atm)
         elif name == "isosurf_init":
             L.orc_module_isosurf_init(ctl, cache, m0, m1, atm)
         elif name == "isosurf":

@@ -1400,14 +1400,95 @@ double orc_lapse_rate(double t, double h2o) {   /* lapse_rate, mptrac.c:3324-333
   return 1e3 * C_G0 * (a + C_LV * r * t) / (C_CPD * a + SQ(C_LV) * r * C_EPS);
 }
 
+/* clim_zm, mptrac.c:414-466: a zonal-mean climatology at (time of year, latitude, pressure), clamped to the
+ * table in pressure and latitude, linear in pressure, latitude and time, never negative */
+double orc_clim_zm(const orc_zm_t *zm, double t, double lat, double p) {
+  double sec = fmod_trunc(t, 365.25 * 86400.);
+  while (sec < 0)
+    sec += 365.25 * 86400.;
+  double p_help = p;
+  if (p < zm->p[zm->np - 1])
+    p_help = zm->p[zm->np - 1];
+  else if (p > zm->p[0])
+    p_help = zm->p[0];
+  double lat_help = lat;
+  if (lat < zm->lat[0])
+    lat_help = zm->lat[0];
+  else if (lat > zm->lat[zm->nlat - 1])
+    lat_help = zm->lat[zm->nlat - 1];
+  const int isec = orc_locate_irr(zm->time, zm->ntime, sec);
+  const int ilat = orc_locate_reg(zm->lat, zm->nlat, lat_help);
+  const int ip = orc_locate_irr(zm->p, zm->np, p_help);
+#define VMR(it, iz, iy) zm->vmr[((size_t) (it) * (size_t) zm->np + (size_t) (iz)) * (size_t) zm->nlat + (size_t) (iy)]
+  const double aux00 = lin(zm->p[ip], VMR(isec, ip, ilat), zm->p[ip + 1], VMR(isec, ip + 1, ilat), p_help);
+  const double aux01 = lin(zm->p[ip], VMR(isec, ip, ilat + 1), zm->p[ip + 1], VMR(isec, ip + 1, ilat + 1), p_help);
+  const double aux10 = lin(zm->p[ip], VMR(isec + 1, ip, ilat), zm->p[ip + 1], VMR(isec + 1, ip + 1, ilat), p_help);
+  const double aux11 =
+    lin(zm->p[ip], VMR(isec + 1, ip, ilat + 1), zm->p[ip + 1], VMR(isec + 1, ip + 1, ilat + 1), p_help);
+#undef VMR
+  const double aux0 = lin(zm->lat[ilat], aux00, zm->lat[ilat + 1], aux01, lat_help);
+  const double aux1 = lin(zm->lat[ilat], aux10, zm->lat[ilat + 1], aux11, lat_help);
+  const double aux = lin(zm->time[isec], aux0, zm->time[isec + 1], aux1, sec);
+  return aux > 0.0 ? aux : 0.0;
+}
+
+/* cos_sza, mptrac.c:1857-1897: cosine of the solar zenith angle (low-precision almanac formulas) */
+double orc_cos_sza(double sec, double lon, double lat) {
+  const double D = sec / 86400 - 0.5;
+  const double g = deg2rad(357.529 + 0.98560028 * D);
+  const double q = 280.459 + 0.98564736 * D;
+  const double L = deg2rad(q + 1.915 * sin(g) + 0.020 * sin(2 * g));
+  const double e = deg2rad(23.439 - 0.00000036 * D);
+  const double sindec = sin(e) * sin(L);
+  const double ra = atan2(cos(e) * sin(L), cos(L));
+  const double GMST = 18.697374558 + 24.06570982441908 * D;
+  const double LST = GMST + lon / 15;
+  const double h = LST / 12 * M_PI - ra;
+  const double lat_help = deg2rad(lat);
+  return sin(lat_help) * sindec + cos(lat_help) * sqrt(1 - SQ(sindec)) * cos(h);
+}
+
+/* clim_oh, mptrac.c:89-120: the OH climatology with the optional diurnal scaling exp(-beta / cos(sza)) */
+double orc_clim_oh(const orc_ctl_t *ctl, const orc_clim_t *clim, double t, double lon, double lat, double p) {
+  const double csza_thresh = cos(deg2rad(85.));
+  const double lat_ref = ctl->met_coord_type == 0 ? lat : ctl->met_utm_ref_lat;
+  double lon_ref = ctl->met_coord_type == 0 ? lon : ctl->met_utm_ref_lon;
+  while (lon_ref < -180.0)
+    lon_ref += 360.0;
+  while (lon_ref >= 180.0)
+    lon_ref -= 360.0;
+  const double oh = orc_clim_zm(&clim->zm[ORC_ZM_OH], t, lat_ref, p);
+  if (ctl->oh_chem_beta <= 0)
+    return oh;
+  const double csza = orc_cos_sza(t, lon_ref, lat_ref);
+  const double denom = (csza >= csza_thresh) ? csza : csza_thresh;
+  return oh * exp(-ctl->oh_chem_beta / denom);
+}
+
+/* nat_temperature, mptrac.c:8334-8355: existence temperature of nitric acid trihydrate (Hanson and Mauersberger) */
+double orc_nat_temperature(double p, double h2o, double hno3) {
+  const double h2o_help = h2o > 0.1e-6 ? h2o : 0.1e-6;
+  const double p_hno3 = hno3 * p / 1.333224;
+  const double p_h2o = h2o_help * p / 1.333224;
+  const double a = 0.009179 - 0.00088 * log10(p_h2o);
+  const double b = (38.9855 - log10(p_hno3) - 2.7836 * log10(p_h2o)) / a;
+  const double c = -11397.0 / a;
+  double tnat = (-b + sqrt(b * b - 4. * c)) / 2.;
+  const double x2 = (-b - sqrt(b * b - 4. * c)) / 2.;
+  if (x2 > 0)
+    tnat = x2;
+  return tnat;
+}
+
 /* A field the caller did not provide reads as the zero-initialised met_t array
  * of the reference (mptrac_alloc uses calloc) and interpolates to exactly 0. */
 #define M3(f, init) ((met0->f3[f] && met1->f3[f]) ? time_3d(met0, met1, f, tm, p, lon, lat, &s, init) : 0.0)
 #define M2(f) ((met0->f2[f] && met1->f2[f]) ? time_2d(met0, met1, f, tm, lon, lat, &s, 0) : 0.0)
 #define SETQ(k, val) if (ctl->qnt_met[k] >= 0) atm->q[ctl->qnt_met[k]][ip] = (val)
 
-void orc_module_meteo(const orc_ctl_t *ctl, const orc_met_t *met0, const orc_met_t *met1,
+void orc_module_meteo(const orc_ctl_t *ctl, const orc_clim_t *clim, const orc_met_t *met0, const orc_met_t *met1,
                       orc_atm_t *atm) {
+  /* mptrac.c:5074-5076 ("Need T_ice and T_NAT to calculate T_STS!"): the caller's business here */
 #pragma omp parallel for schedule(static)
   for (int ip = 0; ip < atm->np; ip++) {   /* PARTICLE_LOOP with check_dt = 0 */
     const double tm = atm->time[ip], p = atm->p[ip], lon = atm->lon[ip], lat = atm->lat[ip];
@@ -1480,6 +1561,18 @@ void orc_module_meteo(const orc_ctl_t *ctl, const orc_met_t *met0, const orc_met
     SETQ(ORC_MQ_PV, pv);
     SETQ(ORC_MQ_TDEW, orc_tdew(p, h2o));
     SETQ(ORC_MQ_TICE, orc_tice(p, h2o));
+    /* the climatology part of the list (mptrac.c:5129-5141, 5158-5163); a table is only touched for a
+     * requested quantity */
+    const double lat_ref = ctl->met_coord_type == 0 ? lat : ctl->met_utm_ref_lat;
+    SETQ(ORC_MQ_HNO3, orc_clim_zm(&clim->zm[ORC_ZM_HNO3], tm, lat_ref, p));
+    SETQ(ORC_MQ_OH, orc_clim_oh(ctl, clim, tm, lon, lat, p));
+    SETQ(ORC_MQ_H2O2, orc_clim_zm(&clim->zm[ORC_ZM_H2O2], tm, lat_ref, p));
+    SETQ(ORC_MQ_HO2, orc_clim_zm(&clim->zm[ORC_ZM_HO2], tm, lat_ref, p));
+    SETQ(ORC_MQ_O1D, orc_clim_zm(&clim->zm[ORC_ZM_O1D], tm, lat_ref, p));
+    SETQ(ORC_MQ_TNAT, orc_nat_temperature(p, h2o, orc_clim_zm(&clim->zm[ORC_ZM_HNO3], tm, lat, p)));
+    if (ctl->qnt_met[ORC_MQ_TSTS] >= 0)   /* from the two quantities as stored */
+      atm->q[ctl->qnt_met[ORC_MQ_TSTS]][ip] =
+        0.5 * (atm->q[ctl->qnt_met[ORC_MQ_TICE]][ip] + atm->q[ctl->qnt_met[ORC_MQ_TNAT]][ip]);
   }
 }
 
@@ -1606,7 +1699,7 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
     orc_module_isosurf(ctl, cache, met0, met1, atm);   /* mptrac.c:7914-7916 */
   orc_module_position(cache, met0, met1, atm);
   if (ctl->met_dt_out > 0 && (ctl->met_dt_out < ctl->dt_mod || fmod(t, ctl->met_dt_out) == 0))
-    orc_module_meteo(ctl, met0, met1, atm);   /* mptrac.c:7921-7924 */
+    orc_module_meteo(ctl, clim, met0, met1, atm);   /* mptrac.c:7921-7924 */
   if (ctl->bound_lat0 < ctl->bound_lat1 && ctl->bound_p0 > ctl->bound_p1)
     orc_module_bound_cond(ctl, cache, met0, met1, atm);   /* mptrac.c:7926-7929 */
   /* zero the total loss rate, mptrac.c:7932-7936 */

@@ -49,7 +49,10 @@ enum { ORC_MQ_PS = 0, ORC_MQ_TS, ORC_MQ_ZS, ORC_MQ_US, ORC_MQ_VS, ORC_MQ_ESS, OR
        ORC_MQ_IWC, ORC_MQ_SWC, ORC_MQ_CC, ORC_MQ_PCT, ORC_MQ_PCB, ORC_MQ_CL, ORC_MQ_PLCL, ORC_MQ_PLFC,
        ORC_MQ_PEL, ORC_MQ_CAPE, ORC_MQ_CIN, ORC_MQ_O3C, ORC_MQ_VH, ORC_MQ_VZ, ORC_MQ_PSAT, ORC_MQ_PSICE,
        ORC_MQ_PW, ORC_MQ_SH, ORC_MQ_RH, ORC_MQ_RHICE, ORC_MQ_THETA, ORC_MQ_ZETA_D, ORC_MQ_TVIRT, ORC_MQ_LAPSE,
-       ORC_MQ_PV, ORC_MQ_TDEW, ORC_MQ_TICE, ORC_NMQ };
+       ORC_MQ_PV, ORC_MQ_TDEW, ORC_MQ_TICE,
+       ORC_MQ_HNO3, ORC_MQ_OH, ORC_MQ_H2O2, ORC_MQ_HO2, ORC_MQ_O1D, ORC_MQ_TNAT, ORC_MQ_TSTS, ORC_NMQ };
+/* zonal-mean climatologies of clim_t that module_meteo samples (mptrac.h:3805-3817) */
+enum { ORC_ZM_HNO3 = 0, ORC_ZM_OH, ORC_ZM_H2O2, ORC_ZM_HO2, ORC_ZM_O1D, ORC_NZM };
 
 /* Hot-path subset of ctl_t (mptrac.h:2494-3553).  Field names follow the
  * reference.  Layout is mirrored 1:1 by the Python ctypes class. */
@@ -94,7 +97,6 @@ typedef struct {
   /* module_meteo (mptrac.c:7197, 7921-7924); qnt_met[k] = ctl->qnt_<name>, -1 = not present */
   double met_dt_out;
   int qnt_met[ORC_NMQ];
-  int pad2;
   /* module_isosurf (mptrac.c:7208) and module_bound_cond (mptrac.c:7266-7289) */
   int isosurf;            /* 0 none, 1 pressure, 2 density, 3 potential temperature, 4 balloon time series */
   int bound_pbl;
@@ -102,6 +104,9 @@ typedef struct {
   int pad3;
   double bound_mass, bound_mass_trend, bound_vmr, bound_vmr_trend;
   double bound_lat0, bound_lat1, bound_p0, bound_p1, bound_dps, bound_dzs, bound_zetas;
+  /* clim_oh (mptrac.c:89-120) */
+  double oh_chem_beta;
+  double met_utm_ref_lon;
 } orc_ctl_t;
 
 /* One meteo snapshot: compact view of met_t (mptrac.h:3844-4014). */
@@ -137,12 +142,20 @@ typedef struct {
   int iso_n;
 } orc_cache_t;
 
-/* Climatological tropopause part of clim_t (mptrac.h:3785-3800). */
+/* A zonal-mean climatology, view of clim_zm_t (mptrac.h:3745-3776): vmr[ntime][np][nlat], compact. */
+typedef struct {
+  int ntime, np, nlat;
+  int pad;
+  const double *time, *p, *lat, *vmr;
+} orc_zm_t;
+
+/* Climatological tropopause part of clim_t (mptrac.h:3785-3800) and the zonal means module_meteo samples. */
 typedef struct {
   int tropo_ntime, tropo_nlat;
   double tropo_time[12];
   double tropo_lat[73];
   double tropo[12][73];
+  orc_zm_t zm[ORC_NZM];
 } orc_clim_t;
 
 size_t orc_sizeof_ctl(void);
@@ -175,6 +188,12 @@ double orc_tice(double p, double h2o);
 double orc_theta(double p, double t);
 double orc_zeta(double ps, double p, double t);
 double orc_lapse_rate(double t, double h2o);
+/* the climatology part of module_meteo: clim_zm (mptrac.c:414), cos_sza (mptrac.c:1857), clim_oh (mptrac.c:89),
+ * nat_temperature (mptrac.c:8334) */
+double orc_clim_zm(const orc_zm_t *zm, double t, double lat, double p);
+double orc_cos_sza(double sec, double lon, double lat);
+double orc_clim_oh(const orc_ctl_t *ctl, const orc_clim_t *clim, double t, double lon, double lat, double p);
+double orc_nat_temperature(double p, double h2o, double hno3);
 
 /* --- modules (mptrac.c:3598-6293) ---------------------------------------- */
 void orc_module_rng(const orc_ctl_t *ctl, orc_cache_t *cache, size_t n, int method);
@@ -210,7 +229,7 @@ void orc_module_isosurf(const orc_ctl_t *ctl, const orc_cache_t *cache, const or
                         const orc_met_t *met1, orc_atm_t *atm);              /* mptrac.c:4956 */
 void orc_module_bound_cond(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
                            const orc_met_t *met1, orc_atm_t *atm);           /* mptrac.c:3789 */
-void orc_module_meteo(const orc_ctl_t *ctl, const orc_met_t *met0, const orc_met_t *met1,
+void orc_module_meteo(const orc_ctl_t *ctl, const orc_clim_t *clim, const orc_met_t *met0, const orc_met_t *met1,
                       orc_atm_t *atm);   /* mptrac.c:5062 */
 /* keys[np] (as the reference's double keys, exact integers) and perm[np] are
  * optional outputs (may be NULL).  Ties are ordered by original index. */

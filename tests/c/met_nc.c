@@ -22,8 +22,8 @@ int main(int argc, char *argv[]) {
     return 2;
   mptrac_alloc(&ctl, &cache, &clim, &met, &back, &atm, &depo, &dd);
   char *keys[] = { argv[0], "-", "-", "-", "MET_TYPE", "0", "MET_COORD_TYPE", argv[2], "MET_UTM_REF_LAT", "50",
-    "MET_PBL", "0", "MET_CAPE", "0" };
-  mptrac_read_ctl("-", 14, keys, ctl);
+    "MET_UTM_REF_LON", "10", "MET_PBL", "0", "MET_CAPE", "0" };
+  mptrac_read_ctl("-", 16, keys, ctl);
   met->coord_type = atoi(argv[2]);
   met->nx = 7;
   met->ny = 5;

@@ -793,14 +793,19 @@ def _row_err(a, b):
 
 
 def test_module_meteo_every_quantity():
-    """All 53 quantities of module_meteo's SET_ATM list (mptrac.c:5091-5157), NQ_MAX at a time, at
-    generic and special positions (poles, date line, outside the pressure range, NaN neighbourhoods)."""
+    """All 60 quantities of module_meteo's SET_ATM list (mptrac.c:5091-5163), NQ_MAX at a time, at
+    generic and special positions (poles, date line, outside the pressure range, NaN neighbourhoods); the
+    climatology quantities from the reference's HNO3 table and synthetic tables for the other four."""
     from mptrac_amd.ctl import METEO_QUANTITIES, ctl_from_quantities
     from mptrac_amd.synth import FIELDS_METEO_ONLY
     fields = cases.PRESSURE_LEVEL_FIELDS + FIELDS_METEO_ONLY
     m0 = synthetic_met("C1", 0.0, 1.0, fields=fields)
     m1 = synthetic_met("C1", 3600.0, 1.25, fields=fields)
-    clim = cases.load_clim_tropo()
+    import refclim
+    zm = {"hno3": refclim.load_zonal_mean()}
+    zm.update({name: refclim.synthetic_zonal_mean(5 + k, scale=10.0 ** -(9 + k))
+               for k, name in enumerate(("oh", "h2o2", "ho2", "o1d"))})
+    clim = cases.load_clim_tropo() + (zm,)
     n = 20000
     for first in range(0, len(METEO_QUANTITIES), 15):
         names = ("m",) + METEO_QUANTITIES[first:first + 15]
@@ -822,6 +827,61 @@ def test_module_meteo_every_quantity():
             assert np.any(r["q"][i] != 0.0) or name in ("swc",), name
             assert _row_err(g["q"][i], r["q"][i]) <= 1e-11, (name, _row_err(g["q"][i], r["q"][i]))
         s.close()
+
+
+@pytest.mark.parametrize("coord_type", [0, 1], ids=["latlon", "cartesian"])
+def test_module_meteo_oh_with_diurnal_scaling(coord_type):
+    """clim_oh (mptrac.c:89-120) with OH_CHEM_BETA > 0: the zonal mean times exp(-beta / cos(sza)) at the
+    particle's longitude and latitude -- on a Cartesian grid at the reference point of the projection, where tnat
+    still takes the particle's own latitude coordinate (mptrac.c:5160)."""
+    import refclim
+    from mptrac_amd.ctl import ctl_from_quantities
+    names = ("oh", "hno3", "tnat", "tice", "tsts", "h2o")
+    ctl, _, m0, m1, _ = cases.make_case("meteo", n=10)
+    atm = synthetic_particles(5000, seed=4, quantities=names, time=1800.0)
+    atm["time"][::3] = 360547200.0 + 3600.0 * np.arange(len(atm["time"][::3]))     # days and nights, months
+    ctl = dict(cases.BASE, **ctl_from_quantities(names), oh_chem_beta=0.6, met_coord_type=coord_type,
+               met_utm_ref_lat=48.15, met_utm_ref_lon=371.57)
+    if coord_type == 1:
+        m0.coord_type = m1.coord_type = 1
+    clim = cases.load_clim_tropo() + ({"hno3": refclim.load_zonal_mean(), "oh": refclim.synthetic_zonal_mean(8, scale=1e-13)},)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    o.module("meteo")
+    s.module("meteo")
+    g, r = s.state(), o.state()
+    oh = r["q"][0]
+    assert oh.min() >= 0 and len(np.unique(np.round(oh / oh.max(), 6))) > (100 if coord_type == 0 else 5)
+    for i, name in enumerate(names):
+        assert _row_err(g["q"][i], r["q"][i]) <= 1e-11, (name, _row_err(g["q"][i], r["q"][i]))
+    assert np.array_equal(r["q"][4], 0.5 * (r["q"][3] + r["q"][2]), equal_nan=True)
+    s.close()
+
+
+def test_module_meteo_climatology_rules():
+    """A climatology quantity without its table and tsts without tice / tnat are refused (the second with the
+    reference's message, mptrac.c:5074-5076); removing a table takes effect."""
+    import refclim
+    from mptrac_amd.ctl import ctl_from_quantities
+    _, _, m0, m1, _ = cases.make_case("meteo", n=10)
+    hno3 = refclim.load_zonal_mean()
+    for names, zm, message in ((("hno3",), {}, "HNO3 climatology was not uploaded"),
+                               (("tnat", "h2o"), {}, "HNO3 climatology was not uploaded"),
+                               (("ho2",), {"hno3": hno3}, "HO2 climatology was not uploaded"),
+                               (("tsts", "tnat", "h2o"), {"hno3": hno3}, "Need T_ice and T_NAT to calculate T_STS!")):
+        atm = synthetic_particles(100, seed=1, quantities=names, time=100.0)
+        s = hip.Simulation(dict(cases.BASE, **ctl_from_quantities(names)), cases.load_clim_tropo() + (zm,), m0, m1, atm)
+        with pytest.raises(hip.MphipError, match=message):
+            s.module("meteo")
+        s.close()
+    atm = synthetic_particles(100, seed=1, quantities=("hno3",), time=100.0)
+    s = hip.Simulation(dict(cases.BASE, **ctl_from_quantities(("hno3",))), cases.load_clim_tropo() + ({"hno3": hno3},), m0, m1, atm)
+    s.module("meteo")
+    assert s.state()["q"][0].max() > 1e-10
+    s.update_clim_zm("hno3")
+    with pytest.raises(hip.MphipError, match="HNO3 climatology was not uploaded"):
+        s.module("meteo")
+    s.close()
 
 
 @pytest.mark.parametrize("case", ["meteo", "meteo_gated"])

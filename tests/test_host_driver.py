@@ -316,6 +316,32 @@ def test_trac_sparse_box_grid_against_the_reference_trac_test_golden(tmp_path):
 
 
 @pytest.mark.gpu
+def test_trac_nat_and_sts_temperatures_from_the_hno3_climatology(tmp_path):
+    """module_meteo's climatology quantities through the driver: CLIM_HNO3_FILENAME = the reference's HNO3 file,
+    quantities h2o, tnat, tice, tsts on the 10000 parcels of the reference's dt_test particle file.  The particle
+    file written at the start time holds T_NAT = nat_temperature(p, h2o, HNO3(t, lat, p)) -- recomputed here from
+    the printed columns with the independent reading of the table (tests/refclim.py) -- and T_STS = their mean."""
+    import refclim
+    from oracle import binding as B
+    tmp = str(tmp_path)
+    t0 = 360547200.0
+    _atm_test_run(tmp, ("MET_DT_OUT", "0.1", "CLIM_HNO3_FILENAME", refclim.HNO3_FILE), case="ref_dt_test",
+                  atm_file="atm_pl_2011_06_05_00_00_00.tab", quantities=("h2o", "tnat", "tice", "tsts"), t0=t0)
+    rows = np.loadtxt(os.path.join(tmp, "atm_2011_06_05_00_00_00.tab"))
+    assert rows.shape == (10000, 8)
+    L = B.lib()
+    table = refclim.load_zonal_mean()
+    press = 1013.25 * np.exp(-rows[:, 1] / 7.0)
+    h2o, tnat, tice, tsts = rows[:, 4], rows[:, 5], rows[:, 6], rows[:, 7]
+    assert h2o.min() > 0 and 150 < tnat.min() and tnat.max() < 260
+    assert np.allclose(tsts, 0.5 * (tice + tnat), rtol=0, atol=1.1e-3)       # six printed digits each
+    for ip in range(0, 10000, 97):
+        hno3 = refclim.clim_zm(table, rows[ip, 0], rows[ip, 3], press[ip])
+        assert abs(L.orc_nat_temperature(press[ip], h2o[ip], hno3) - tnat[ip]) <= 2e-4 * tnat[ip]
+        assert abs(L.orc_tice(press[ip], h2o[ip]) - tice[ip]) <= 2e-4 * tice[ip]
+
+
+@pytest.mark.gpu
 def test_trac_grid_implicit_volume_mixing_ratio(tmp_path):
     """MOLMASS set: column 8 of the grid file = MA / MOLMASS * column density / (rho(p, T) * dz), T interpolated
     to the cell centre from the two snapshots (mptrac.c:13885-13900)."""

@@ -286,3 +286,81 @@ def test_clams_init_file_of_the_reference_interoper_test(tmp_path):
     assert mine.shape == gold.shape == (5662, 4 + len(quantities))
     for col in (0, 2, 3, 4 + quantities.index("m"), 4 + quantities.index("zeta")):
         assert np.array_equal(mine[:, col], gold[:, col]), col
+
+
+@pytest.mark.parametrize("atm_type", [1, 2], ids=["binary", "netcdf"])
+def test_particle_file_conversions_of_the_reference_atm_test(tmp_path, atm_type):
+    """tests/atm_test/run.sh:37-43 of the reference: its particle file (10000 parcels: aoa, m, vmr) converted to the
+    binary / netCDF format and back to text is the file itself, byte for byte."""
+    gold = os.path.join(HERE, "golden", "ref_atm_test", "atm_2000_01_01_00_00_00.tab")
+    qnt = ["NQ", 3, "QNT_NAME[0]", "aoa", "QNT_NAME[1]", "m", "QNT_NAME[2]", "vmr"]
+    packed = tmp_path / ("atm.bin" if atm_type == 1 else "atm.nc")
+    _atm_conv([gold, 0, packed, atm_type] + qnt)
+    _atm_conv([packed, atm_type, tmp_path / "back.tab", 0] + qnt)
+    with open(tmp_path / "back.tab", "rb") as a, open(gold, "rb") as b:
+        assert a.read() == b.read()
+
+
+def _clim_tables(tmp_path, keys):
+    exe = compile_c_test("clim_zm")
+    args = [exe, str(tmp_path / "clim.txt")]
+    for k, v in keys.items():
+        args += [k, str(v)]
+    res = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "RESULT done" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+    lines = open(tmp_path / "clim.txt").read().splitlines()
+    out = {}
+    for k in range(0, len(lines), 5):
+        name, nt, npr, nlat = lines[k].split()
+        nt, npr, nlat = int(nt), int(npr), int(nlat)
+        axes = [np.array(lines[k + 1 + j].split(), dtype=np.float64) for j in range(3)]
+        out[name] = (axes[0], axes[1], axes[2], np.array(lines[k + 4].split(), dtype=np.float64).reshape(nt, npr, nlat))
+    return out, res.stdout
+
+
+def test_zonal_mean_climatology_reader_on_the_reference_hno3_file(tmp_path):
+    """mptrac_read_clim with a quantity that needs the HNO3 climatology: the reference's data/gozcards_HNO3.nc
+    (classic netCDF, single precision, 2164 gaps) gives the table an independent reading of the file gives
+    (tests/refclim.py: monthly mid-points, gaps filled from the highest valid level of their column); tables no
+    quantity asks for are not read, a missing file is a warning."""
+    import refclim
+    keys = {"NQ": 2, "QNT_NAME[0]": "tnat", "QNT_NAME[1]": "h2o", "CLIM_HNO3_FILENAME": refclim.HNO3_FILE}
+    tabs, _ = _clim_tables(tmp_path, keys)
+    want = refclim.load_zonal_mean()
+    for got, ref in zip(tabs["hno3"], want):
+        assert np.array_equal(got, ref)
+    assert all(tabs[k][3].size == 0 for k in ("oh", "h2o2", "ho2", "o1d"))
+    keys.update({"NQ": 3, "QNT_NAME[2]": "ho2", "CLIM_HO2_FILENAME": str(tmp_path / "nothing.nc")})
+    tabs, log = _clim_tables(tmp_path, keys)
+    assert "HO2 climatology data are missing" in log and tabs["ho2"][3].size == 0 and tabs["hno3"][3].size == 12 * 25 * 18
+
+
+def test_oh_climatology_with_diurnal_correction(tmp_path):
+    """OH_CHEM_BETA > 0 (clim_oh_diurnal_correction, mptrac.c:122-152): the table is divided by the mean over 360
+    longitudes of exp(-beta / max(cos(sza), cos 85 deg)) at each month and latitude.  Table: a classic netCDF file
+    made here with the variable names of the reference's radical climatology."""
+    from scipy.io import netcdf_file
+    import refclim
+    _, p, lat, vmr = refclim.synthetic_zonal_mean(21, scale=1e-13)
+    path = str(tmp_path / "radicals.nc")
+    f = netcdf_file(path, "w")
+    for name, n in (("time", 12), ("press", len(p)), ("lat", len(lat))):
+        f.createDimension(name, n)
+    f.createVariable("press", "f", ("press",))[:] = p
+    f.createVariable("lat", "i", ("lat",))[:] = lat.astype(np.int32)
+    f.createVariable("OH", "f", ("time", "press", "lat"))[:] = vmr
+    f.close()
+    keys = {"NQ": 1, "QNT_NAME[0]": "oh", "CLIM_OH_FILENAME": path}
+    plain, _ = _clim_tables(tmp_path, keys)
+    assert np.array_equal(plain["oh"][3], vmr.astype(np.float32).astype(np.float64))
+    assert np.array_equal(plain["oh"][1], p.astype(np.float32).astype(np.float64)) and np.array_equal(plain["oh"][2], lat)
+    beta = 0.6
+    scaled, _ = _clim_tables(tmp_path, dict(keys, OH_CHEM_BETA=beta))
+    from oracle import binding as B
+    L = B.lib()
+    thresh = np.cos(np.deg2rad(85.0))
+    for it in (0, 5, 11):
+        for iy in (0, 4, 8):
+            c = np.array([L.orc_cos_sza(refclim.MONTH_MID[it], float(lon), float(lat[iy])) for lon in range(-180, 180)])
+            factor = np.mean(np.exp(-beta / np.maximum(c, thresh)))
+            assert np.allclose(scaled["oh"][3][it, :, iy], plain["oh"][3][it, :, iy] / factor, rtol=1e-13, atol=0)

@@ -179,3 +179,48 @@ def test_coord_test_golden_of_the_reference():
     worst = R.run_against_golden(o, mets)
     assert worst["x"] <= R.TOL_XY and worst["y"] <= R.TOL_XY, worst
     assert worst["z"] <= R.TOL_REL and worst["q"] <= R.TOL_REL, worst
+
+
+def test_nat_temperature_matches_reference_tools_test_table():
+    """tests/tools_test of the reference (run.sh:39-47): 36 calls of its `tnat` tool -- dew point, frost point and
+    NAT existence temperature at (p, H2O, HNO3); every printed digit."""
+    L = B.lib()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tools_test", "tnat.tab")
+    vals = {}
+    seen = 0
+    for ln in open(path):
+        if "=" not in ln:
+            continue
+        key, rest = ln.split("=")
+        vals[key.strip()] = rest.split()[0]
+        if key.strip() == "T_NAT":
+            p, h2o, hno3 = float(vals["p"]), float(vals["q_H2O"]), float(vals["q_HNO3"])
+            assert "%g" % L.orc_tdew(p, h2o) == vals["T_dew"]
+            assert "%g" % L.orc_tice(p, h2o) == vals["T_ice"]
+            assert "%g" % L.orc_nat_temperature(p, h2o, hno3) == vals["T_NAT"]
+            seen += 1
+    assert seen == 36
+
+
+def test_zonal_mean_climatology_against_an_independent_restatement():
+    """orc_clim_zm on the reference's HNO3 climatology (gap-filled as read_clim_zm does) and on a synthetic table,
+    against the numpy statement of the same interpolation in tests/refclim.py -- inside the table, beyond its
+    edges (clamped), across the turn of the year's last node."""
+    import refclim
+    L = B.lib()
+    rng = np.random.default_rng(11)
+    for table in (refclim.load_zonal_mean(), refclim.synthetic_zonal_mean(3)):
+        time, p, lat, vmr = (np.ascontiguousarray(a) for a in table)
+        assert (vmr >= 0).all()
+        z = B.OrcZm()
+        z.ntime, z.np, z.nlat = len(time), len(p), len(lat)
+        z.time, z.p, z.lat, z.vmr = (a.ctypes.data_as(C.POINTER(C.c_double)) for a in (time, p, lat, vmr))
+        worst = 0.0
+        for _ in range(4000):
+            t = rng.uniform(-4e7, 9e8)
+            la = rng.uniform(-95.0, 95.0)
+            pr = float(np.exp(rng.uniform(np.log(0.05), np.log(1100.0))))
+            want = refclim.clim_zm(table, t, la, pr)
+            got = L.orc_clim_zm(C.byref(z), t, la, pr)
+            worst = max(worst, abs(got - want) / max(abs(want), 1e-30))
+        assert worst <= 1e-12, worst
