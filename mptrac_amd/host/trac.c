@@ -36,10 +36,25 @@ int main(int argc, char *argv[]) {
   FILE *dirlist;
   char dirname[LEN], filename[2 * LEN];
 
-  if (argc < 4) {
-    printf("\nMPTRAC trac tool (MI355X build).\n\nUsage:\n  trac <dirlist> <ctl> <atm_in> [KEY VALUE ...]\n\n");
-    return EXIT_FAILURE;
-  }
+  /* the command-line conventions of the reference's tools (USAGE, mptrac.h:2213-2222; tests/cli_test): -h or
+   * --help anywhere prints the usage and succeeds, too few arguments are the standard diagnostic */
+  for (int i = 1; i < argc; i++)
+    if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) {
+      printf("\nMPTRAC trac tool (MI355X build).\n\n"
+             "Runs the trajectory calculations of the directories listed in <dirlist> on the GPU.\n\n"
+             "Usage:\n  trac <dirlist> <ctl> <atm_in> [KEY VALUE ...]\n\n"
+             "Arguments:\n"
+             "  <dirlist>  File with one working directory per line.\n"
+             "  <ctl>      Control parameter file, relative to each directory.\n"
+             "  <atm_in>   Initial particle file, relative to each directory.\n"
+             "  [KEY VALUE ...]  Control parameters that override the file.\n\n"
+             "Started N times by a launcher that exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /\n"
+             "MASTER_PORT, the N processes share every simulation, one GPU each.\n\n");
+      return EXIT_SUCCESS;
+    }
+  if (argc < 4)
+    ERRMSG("Missing or invalid command-line arguments.\n\n"
+           "Usage: trac <dirlist> <ctl> <atm_in> [KEY VALUE ...]\n\n" "Use -h for full help.");
   if (!(dirlist = fopen(argv[1], "r")))
     ERRMSG("Cannot open directory list!");
   mptrac_amd_job_t job;

@@ -462,3 +462,16 @@ def test_rank_rendezvous_gives_up_when_a_peer_never_comes():
         assert time.time() - t0 < 10.0
     finally:
         del os.environ["MPTRAC_RENDEZVOUS_TIMEOUT"]
+
+
+def test_trac_command_line_conventions_of_the_reference_cli_test():
+    """tests/cli_test/run.sh of the reference, for the driver: no arguments fail with the standard diagnostic;
+    -h and --help succeed and print a usage section, with extra arguments too."""
+    import subprocess
+    _, trac = build.build_host()
+    r = subprocess.run([trac], capture_output=True, text=True)
+    assert r.returncode != 0 and "Missing or invalid command-line arguments." in r.stdout + r.stderr
+    for flag in ("-h", "--help"):
+        for extra in ([], ["extra-arg"]):
+            r = subprocess.run([trac, flag] + extra, capture_output=True, text=True)
+            assert r.returncode == 0 and "Usage:" in r.stdout
