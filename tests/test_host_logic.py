@@ -468,6 +468,7 @@ def test_trac_command_line_conventions_of_the_reference_cli_test():
     """tests/cli_test/run.sh of the reference, for the driver: no arguments fail with the standard diagnostic;
     -h and --help succeed and print a usage section, with extra arguments too."""
     import subprocess
+    from mptrac_amd import build
     _, trac = build.build_host()
     r = subprocess.run([trac], capture_output=True, text=True)
     assert r.returncode != 0 and "Missing or invalid command-line arguments." in r.stdout + r.stderr
