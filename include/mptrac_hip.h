@@ -68,6 +68,10 @@ enum { MPHIP_MQ_PS = 0, MPHIP_MQ_TS, MPHIP_MQ_ZS, MPHIP_MQ_US, MPHIP_MQ_VS, MPHI
  * mptrac.h:3745-3776, 3805-3817) */
 enum { MPHIP_ZM_HNO3 = 0, MPHIP_ZM_OH, MPHIP_ZM_H2O2, MPHIP_ZM_HO2, MPHIP_ZM_O1D, MPHIP_NZM };
 
+/* Trace gases module_bound_cond sets from a surface time series and module_mixing mixes (clim_ts_t members ccl4,
+ * ccl3f, ccl2f2, n2o, sf6 of clim_t, mptrac.h:3820-3832; quantities Cccl4, Cccl3f, Cccl2f2, Cn2o, Csf6) */
+enum { MPHIP_TR_CCL4 = 0, MPHIP_TR_CCL3F, MPHIP_TR_CCL2F2, MPHIP_TR_N2O, MPHIP_TR_SF6, MPHIP_NTR };
+
 /* Module bits for mphip_module(); one bit per reference module_* function
  * (declarations mptrac.h:6140-7205). */
 enum {
@@ -146,6 +150,11 @@ typedef struct {
    * and the reference longitude a Cartesian grid is centred on (MET_UTM_REF_LON) */
   double oh_chem_beta;
   double met_utm_ref_lon;
+  /* ctl->qnt_Cccl4, qnt_Cccl3f, qnt_Cccl2f2, qnt_Cn2o, qnt_Csf6 (MPHIP_TR_* order; -1 = not present): mixed by
+   * module_mixing (mptrac.c:5223-5230), set by module_bound_cond where a time series was uploaded
+   * (mphip_update_clim_ts; mptrac.c:3857-3875) */
+  int qnt_tracer[MPHIP_NTR];
+  int pad4;
 } mphip_ctl_t;
 
 /* View of one met_t snapshot (mptrac.h:3844-4014).  The arrays stay where the
@@ -195,6 +204,11 @@ int mphip_update_clim(mphip_ctx *ctx, int ntime, int nlat, const double *tropo_t
  * every climatology quantity that is requested (hno3: also for tnat); ntime = 0 removes a table. */
 int mphip_update_clim_zm(mphip_ctx *ctx, int which, int ntime, int np, int nlat, const double *time,
                          const double *p, const double *lat, const double *vmr);
+/* ... and one of its trace-gas time series (clim_ts_t, mptrac.h:3729-3743; `which` = MPHIP_TR_*): ascending times
+ * [s] and volume mixing ratios; module_bound_cond sets the quantity of a series that is present to clim_ts at the
+ * particle's time (constant beyond the ends of the series), ntime = 0 removes it -- the reference's
+ * CLIM_*_TIMESERIES = "-". */
+int mphip_update_clim_ts(mphip_ctx *ctx, int which, int ntime, const double *time, const double *vmr);
 /* mptrac_update_device(..., met0, met1, ...), mptrac.c:8034-8048; slot 0 = met0,
  * slot 1 = met1. */
 int mphip_update_met(mphip_ctx *ctx, int slot, const mphip_met_t *met);

@@ -77,8 +77,10 @@ def main():
     # the other direction: every member of mphip_ctl_t is filled by hip_ctl
     dev = struct_members(abi, "mphip_ctl_t")
     filled = set(same) | {"qnt_met", "wet_depo_pre", "wet_depo_ic_h", "wet_depo_bc_h"}
+    if len(re.findall(r"d->qnt_tracer\[MPHIP_TR_\w+\] = c->qnt_C\w+;", glue)) == 5:
+        filled.add("qnt_tracer")
     unfilled = sorted(f for f in dev if f not in filled and not f.startswith("pad"))
-    # the 53 module_meteo quantities in ABI order
+    # the module_meteo quantities in ABI order
     order = [e.lower() for e in re.findall(r"MPHIP_MQ_(\w+)", abi.split("MPHIP_NMQ")[0])]
     glue_order = [x.split(",")[0].strip().lower() for x in macro_list(glue, "HIP_CTL_METEO_QNT")]
     problems = sorted(set(missing))

@@ -32,6 +32,7 @@
 
 static mphip_ctx *hip_ctx;     /* process-global like rng_ctr (mptrac.c:32-40): the interface is not re-entrant */
 static int hip_nq;
+static int hip_ts_on[MPHIP_NTR] = { 1, 1, 1, 1, 1 };   /* CLIM_*_TIMESERIES is not "-" (mptrac.c:3858 ...) */
 
 #define HIPCALL(x) {                                    \
     if ((x) != 0)                                       \
@@ -75,6 +76,11 @@ static void hip_ctl(const ctl_t *c, mphip_ctl_t *d) {
 #define X(E, f) d->qnt_met[MPHIP_MQ_##E] = c->qnt_##f;
   HIP_CTL_METEO_QNT(X)
 #undef X
+  d->qnt_tracer[MPHIP_TR_CCL4] = c->qnt_Cccl4;
+  d->qnt_tracer[MPHIP_TR_CCL3F] = c->qnt_Cccl3f;
+  d->qnt_tracer[MPHIP_TR_CCL2F2] = c->qnt_Cccl2f2;
+  d->qnt_tracer[MPHIP_TR_N2O] = c->qnt_Cn2o;
+  d->qnt_tracer[MPHIP_TR_SF6] = c->qnt_Csf6;
   for (int k = 0; k < 2; k++) {
     d->wet_depo_pre[k] = c->wet_depo_pre[k];
     d->wet_depo_ic_h[k] = c->wet_depo_ic_h[k];
@@ -166,6 +172,11 @@ void mptrac_hip_update_device(const ctl_t *ctl, const cache_t *cache, const clim
     hip_ctl(ctl, &d);
     HIPCALL(mphip_update_ctl(hip_ctx, &d));
     hip_nq = ctl->nq;
+    hip_ts_on[MPHIP_TR_CCL4] = ctl->clim_ccl4_timeseries[0] != '-';
+    hip_ts_on[MPHIP_TR_CCL3F] = ctl->clim_ccl3f_timeseries[0] != '-';
+    hip_ts_on[MPHIP_TR_CCL2F2] = ctl->clim_ccl2f2_timeseries[0] != '-';
+    hip_ts_on[MPHIP_TR_N2O] = ctl->clim_n2o_timeseries[0] != '-';
+    hip_ts_on[MPHIP_TR_SF6] = ctl->clim_sf6_timeseries[0] != '-';
   }
   if (clim != NULL) {
     HIPCALL(mphip_update_clim(hip_ctx, clim->tropo_ntime, clim->tropo_nlat, clim->tropo_time, clim->tropo_lat,
@@ -186,6 +197,10 @@ void mptrac_hip_update_device(const ctl_t *ctl, const cache_t *cache, const clim
                                    zm[k]->lat, v));
       free(v);
     }
+    /* the surface time series of module_bound_cond's trace gases ("-" as file name: no boundary condition) */
+    const clim_ts_t *ts[MPHIP_NTR] = { &clim->ccl4, &clim->ccl3f, &clim->ccl2f2, &clim->n2o, &clim->sf6 };
+    for (int k = 0; k < MPHIP_NTR; k++)
+      HIPCALL(mphip_update_clim_ts(hip_ctx, k, hip_ts_on[k] ? ts[k]->ntime : 0, ts[k]->time, ts[k]->vmr));
   }
   mphip_met_t v;
   if (met0 != NULL) {

@@ -58,6 +58,9 @@ struct mphip_ctx {
   bool have_clim = false;
   double *d_zm[MPHIP_NZM] = {};      // zonal-mean climatologies: [time | p | lat | vmr] each
   DevZm zm[MPHIP_NZM] = {};
+  double *d_ts[MPHIP_NTR] = {};      // trace-gas time series: [time | vmr] each
+  DevTracerSeries h_tracers = {};    // host copy of *d_tracers
+  DevTracerSeries *d_tracers = nullptr;
   double *d_logtab = nullptr;         // table of the lean kernels' logarithm (mphip_logtab.hpp)
 
   // meteo
@@ -677,6 +680,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   S.met = dev_met(ctx);
   S.atm = dev_atm(ctx);
   S.clim = ctx->d_clim;
+  S.tracers = ctx->d_tracers;
   S.t = t;
   S.mask = mask;
   // every block walks a whole number of 256-particle rounds (no half-empty last round)
@@ -1569,7 +1573,8 @@ int mixing_plan(mphip_ctx *ctx, double t, MixPlan *P, bool *active) {
   memset(P, 0, sizeof(*P));
   // the mixed quantities (hot-path subset of mptrac.c:5223-5230), all in one pass
   MixSet &mq = P->mq;
-  for (int iq : { c.qnt_m, c.qnt_vmr, c.qnt_aoa })
+  for (int iq : { c.qnt_m, c.qnt_vmr, c.qnt_tracer[MPHIP_TR_CCL4], c.qnt_tracer[MPHIP_TR_CCL3F], c.qnt_tracer[MPHIP_TR_CCL2F2],
+                  c.qnt_tracer[MPHIP_TR_N2O], c.qnt_tracer[MPHIP_TR_SF6], c.qnt_aoa })
     if (iq >= 0)
       mq.q[mq.n++] = a.q[iq];
   if (mq.n == 0)
@@ -1804,6 +1809,9 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_clim);
   for (auto p : ctx->d_zm)
     dev_free(p);
+  for (auto p : ctx->d_ts)
+    dev_free(p);
+  dev_free(ctx->d_tracers);
   dev_free(ctx->d_logtab);
   dev_free(ctx->d_axes);
   ctx->pk.release();
@@ -1880,7 +1888,8 @@ int mphip_update_ctl(mphip_ctx *ctx, const mphip_ctl_t *ctl) {
     if (ctl->qnt_met[k] >= 0)
       for (int other : { ctl->qnt_m, ctl->qnt_vmr, ctl->qnt_aoa, ctl->qnt_loss_rate, ctl->qnt_mloss_decay,
                          ctl->qnt_mloss_wet, ctl->qnt_mloss_dry, ctl->qnt_rp, ctl->qnt_rhop, ctl->qnt_ens,
-                         ctl->qnt_zeta, ctl->qnt_eta })
+                         ctl->qnt_zeta, ctl->qnt_eta, ctl->qnt_tracer[0], ctl->qnt_tracer[1], ctl->qnt_tracer[2],
+                         ctl->qnt_tracer[3], ctl->qnt_tracer[4] })
         if (ctl->qnt_met[k] == other)
           return fail(ctx, "a module_meteo quantity shares its index with a mass / mixing-ratio / loss / particle quantity");
   if (ctx->have_ctl && flush_meteo(ctx))   // a deferred module_meteo belongs to the old parameters
@@ -1960,6 +1969,42 @@ int mphip_update_clim_zm(mphip_ctx *ctx, int which, int ntime, int np, int nlat,
   z.ntime = ntime;
   z.np = np;
   z.nlat = nlat;
+  return 0;
+}
+
+int mphip_update_clim_ts(mphip_ctx *ctx, int which, int ntime, const double *time, const double *vmr) {
+  if (!ctx || which < 0 || which >= MPHIP_NTR)
+    return fail(ctx, "bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ahead_drop(ctx))
+    return 1;
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // kernels in flight may read the old series
+  dev_free(ctx->d_ts[which]);
+  ctx->d_ts[which] = nullptr;
+  DevTracerSeries &h = ctx->h_tracers;
+  h.time[which] = h.vmr[which] = nullptr;
+  h.ntime[which] = 0;
+  if (ntime != 0) {
+    if (!time || !vmr)
+      return fail(ctx, "null argument");
+    if (ntime < 2)
+      return fail(ctx, "Not enough data points!");                 // messages of read_clim_ts, mptrac.c:8712-8730
+    for (int i = 1; i < ntime; i++)
+      if (!(time[i] > time[i - 1]))
+        return fail(ctx, "Time series must be ascending!");
+    double *d = nullptr;
+    if (dev_alloc(ctx, &d, 2 * (size_t) ntime))
+      return 1;
+    ctx->d_ts[which] = d;
+    HIPCHK(hipMemcpy(d, time, (size_t) ntime * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d + ntime, vmr, (size_t) ntime * sizeof(double), hipMemcpyHostToDevice));
+    h.time[which] = d;
+    h.vmr[which] = d + ntime;
+    h.ntime[which] = ntime;
+  }
+  if (!ctx->d_tracers)
+    HIPCHK(hipMalloc((void **) &ctx->d_tracers, sizeof(DevTracerSeries)));
+  HIPCHK(hipMemcpy(ctx->d_tracers, &h, sizeof(DevTracerSeries), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -2933,6 +2978,7 @@ int mphip_test_piece(mphip_ctx *ctx, int piece, int reps, double *checksum) {
   S.met = dev_met(ctx);
   S.atm = dev_atm(ctx);
   S.clim = ctx->d_clim;
+  S.tracers = ctx->d_tracers;
   S.t = 0;
   S.mask = 0;
   long long per_block = (ctx->np + ctx->step_blocks - 1) / ctx->step_blocks;

@@ -1038,6 +1038,24 @@ __device__ inline double clim_zm(const DevZm &Z, double t, double lat, double p)
   return aux > 0.0 ? aux : 0.0;
 }
 
+// the time series of module_bound_cond's trace gases (clim_ts_t members of clim_t), in device memory
+struct DevTracerSeries {
+  const double *time[MPHIP_NTR], *vmr[MPHIP_NTR];
+  int ntime[MPHIP_NTR];   // 0: not present
+};
+
+// clim_ts, mptrac.c:394-410
+__device__ inline double clim_ts(const DevTracerSeries &T, int k, double t) {
+  const double *time = T.time[k], *vmr = T.vmr[k];
+  const int n = T.ntime[k];
+  if (t <= time[0])
+    return vmr[0];
+  if (t >= time[n - 1])
+    return vmr[n - 1];
+  const int idx = locate_irr(time, n, t, 1);
+  return lin_nodes(time[idx], vmr[idx], time[idx + 1], vmr[idx + 1], t);
+}
+
 // cos_sza, mptrac.c:1857-1897
 __device__ inline double cos_sza(double sec, double lon, double lat) {
   // (the hour angle is ~1e4 rad years after 2000: no contraction, so that its roundings are the host's)

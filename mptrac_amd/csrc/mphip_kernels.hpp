@@ -28,7 +28,7 @@ struct BoxGrid {
   int nx, ny, nz;
 };
 
-constexpr int kMixMax = 3;   // mass, volume mixing ratio, age of air (the hot-path subset of the reference's list)
+constexpr int kMixMax = 8;   // mass, volume mixing ratio, five trace gases, age of air (of the reference's list, mptrac.c:5223-5230)
 struct MixSet {
   double *q[kMixMax];
   int n;
@@ -105,6 +105,7 @@ struct StepParams {
   DevMet met;
   DevAtm atm;
   const DevClim *clim;
+  const DevTracerSeries *tracers;   // time series of module_bound_cond's trace gases (NULL: none uploaded)
   double t;
   unsigned mask;          // MPHIP_MOD_* bits to run (when the kernel is the generic instantiation)
   int nblocks_logical;    // multiple of 8
@@ -139,10 +140,13 @@ constexpr unsigned kTailModules = MPHIP_MOD_LOSS_ZERO | MPHIP_MOD_DECAY | MPHIP_
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI | MPHIP_MOD_ISOSURF | MPHIP_MOD_POSITION2;
 
-// module_bound_cond, mptrac.c:3848-3879 (mass, volume mixing ratio, age of air)
+// module_bound_cond, mptrac.c:3800-3879 (mass, volume mixing ratio, trace gases with a surface time series, age of air)
 __device__ __forceinline__ void bound_cond(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
-                                           long long i, const Particle &P) {
-  if (ctl.qnt_m < 0 && ctl.qnt_vmr < 0 && ctl.qnt_aoa < 0)
+                                           long long i, const Particle &P, const DevTracerSeries *tracers) {
+  // (mptrac.c:3800-3804 as written there: the CFC-10 index is tested for "non-zero", not for "absent")
+  const int *tr = ctl.qnt_tracer;
+  if (ctl.qnt_m < 0 && ctl.qnt_vmr < 0 && tr[MPHIP_TR_CCL4] && tr[MPHIP_TR_CCL3F] < 0 && tr[MPHIP_TR_CCL2F2] < 0
+      && tr[MPHIP_TR_N2O] < 0 && tr[MPHIP_TR_SF6] < 0 && ctl.qnt_aoa < 0)
     return;
   if (!in_boundary_region(ctl, M, A, P))
     return;
@@ -150,6 +154,10 @@ __device__ __forceinline__ void bound_cond(const mphip_ctl_t &ctl, const DevMet 
     a.q[ctl.qnt_m][i] = ctl.bound_mass + ctl.bound_mass_trend * P.time;
   if (ctl.qnt_vmr >= 0 && ctl.bound_vmr >= 0)
     a.q[ctl.qnt_vmr][i] = ctl.bound_vmr + ctl.bound_vmr_trend * P.time;
+  if (tracers)
+    for (int k = 0; k < MPHIP_NTR; k++)
+      if (tr[k] >= 0 && tracers->ntime[k] > 0)
+        a.q[tr[k]][i] = clim_ts(*tracers, k, P.time);
   if (ctl.qnt_aoa >= 0)
     a.q[ctl.qnt_aoa][i] = P.time;
 }
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
     constexpr bool bound_rt = lean && ((CT & kGated) || (CT & ~(kTwoStage | kGated)) == MPHIP_MOD_TIMESTEPS);
     const unsigned bmask = bound_rt ? S.mask : (CT == kMaskGeneric ? mask : 0u);
     if (bmask & MPHIP_MOD_BOUND_COND)
-      bound_cond(ctl, M, A, a, i, P);
+      bound_cond(ctl, M, A, a, i, P, S.tracers);
     // the loss / decay / deposition modules behind the movers: in the lean instantiations a run-time choice
     // too (their template mask names the movers), so that they serve every combination of these modules
     const unsigned tmask = lean ? (S.mask & kTailModules) : mask;
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
         dry_depo(ctl, M, A, a, i, P);
     }
     if (bmask & MPHIP_MOD_BOUND_COND2)
-      bound_cond(ctl, M, A, a, i, P);
+      bound_cond(ctl, M, A, a, i, P, S.tracers);
   }
 }
 

@@ -114,6 +114,9 @@ CTL_FIELDS = [
     # module_meteo's OH climatology (clim_oh, mptrac.c:89-120): diurnal scaling, reference longitude of a Cartesian grid
     ("oh_chem_beta", C.c_double, 0.0),
     ("met_utm_ref_lon", C.c_double, 0.0),
+    # trace gases of module_bound_cond / module_mixing: qnt_Cccl4, qnt_Cccl3f, qnt_Cccl2f2, qnt_Cn2o, qnt_Csf6 (TRACERS)
+    ("qnt_tracer", C.c_int * 5, (-1,) * 5),
+    ("pad4", C.c_int, 0),
 ]
 
 # quantities module_meteo fills, in the order of its SET_ATM list (mptrac.c:5091-5157) = MPHIP_MQ_*
@@ -128,6 +131,11 @@ assert len(METEO_QUANTITIES) == 60
 
 # zonal-mean climatologies module_meteo samples (clim_zm_t members of clim_t, mptrac.h:3805-3817) = MPHIP_ZM_*
 ZONAL_MEANS = ("hno3", "oh", "h2o2", "ho2", "o1d")
+
+# trace gases with a surface time series (clim_ts_t members ccl4, ccl3f, ccl2f2, n2o, sf6 of clim_t,
+# mptrac.h:3820-3832) = MPHIP_TR_*: quantity names and names of the tables
+TRACERS = ("Cccl4", "Cccl3f", "Cccl2f2", "Cn2o", "Csf6")
+TRACER_SERIES = ("ccl4", "ccl3f", "ccl2f2", "n2o", "sf6")
 
 
 def make_ctl_struct(name):
@@ -161,11 +169,16 @@ def ctl_from_quantities(names):
              "mloss_wet": "qnt_mloss_wet", "mloss_dry": "qnt_mloss_dry", "zeta": "qnt_zeta", "eta": "qnt_eta",
              "aoa": "qnt_aoa"}
     met = [-1] * len(METEO_QUANTITIES)
+    tracer = [-1] * len(TRACERS)
     for i, n in enumerate(names):
         if n in table:
             out[table[n]] = i
         elif n in METEO_QUANTITIES:
             met[METEO_QUANTITIES.index(n)] = i
+        elif n in TRACERS:
+            tracer[TRACERS.index(n)] = i
     if any(v >= 0 for v in met):
         out["qnt_met"] = tuple(met)
+    if any(v >= 0 for v in tracer):
+        out["qnt_tracer"] = tuple(tracer)
     return out

@@ -14,7 +14,7 @@ import weakref
 import numpy as np
 
 from . import build as _build
-from .ctl import ZONAL_MEANS, fill_ctl, make_ctl_struct
+from .ctl import TRACER_SERIES, ZONAL_MEANS, fill_ctl, make_ctl_struct
 from .synth import FIELDS_2D, FIELDS_3D, FIELDS_ML
 
 NQ_MAX = 16
@@ -84,6 +84,7 @@ def load(build=True):
     L.mphip_update_ctl.argtypes = [C.c_void_p, C.POINTER(MphipCtl)]
     L.mphip_update_clim.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]
     L.mphip_update_clim_zm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp]
+    L.mphip_update_clim_ts.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp]
     L.mphip_update_met.argtypes = [C.c_void_p, C.c_int, C.POINTER(MphipMet)]
     L.mphip_swap_met.argtypes = [C.c_void_p]
     L.mphip_prefetch_met.argtypes = [C.c_void_p, C.POINTER(MphipMet)]
@@ -157,8 +158,12 @@ class Simulation:
                                            _ptr(np.ascontiguousarray(lat, dtype=np.float64), _dp),
                                            _ptr(tropo, _dp), tropo.shape[1]))
         # zonal-mean climatologies: optional fourth element {name: (time, p, lat, vmr[ntime][np][nlat])}
+        # ... and trace-gas time series {name: (time, vmr)}
         for name, tab in (clim[3] if len(clim) > 3 else {}).items():
-            self.update_clim_zm(name, *tab)
+            if name in TRACER_SERIES:
+                self.update_clim_ts(name, *tab)
+            else:
+                self.update_clim_zm(name, *tab)
         self.update_ctl()
         self.set_met(0, met0)
         self.set_met(1, met1)
@@ -180,6 +185,12 @@ class Simulation:
             assert vmr.shape == (len(time), len(p), len(lat))
         self._chk(self.L.mphip_update_clim_zm(self.h, ZONAL_MEANS.index(name), len(time), len(p), len(lat),
                                               _ptr(time, _dp), _ptr(p, _dp), _ptr(lat, _dp), _ptr(vmr, _dp)))
+
+    def update_clim_ts(self, name, time=(), vmr=()):
+        """Surface time series of a trace gas for module_bound_cond (ccl4, ccl3f, ccl2f2, n2o, sf6); no nodes: removed."""
+        time, vmr = (np.ascontiguousarray(a, dtype=np.float64) for a in (time, vmr))
+        assert time.shape == vmr.shape
+        self._chk(self.L.mphip_update_clim_ts(self.h, TRACER_SERIES.index(name), len(time), _ptr(time, _dp), _ptr(vmr, _dp)))
 
     # -- plumbing -----------------------------------------------------------
     def _chk(self, rc):

@@ -139,13 +139,16 @@ static const struct {
   { "hno3", "nitric acid", "ppv" }, { "oh", "hydroxyl radical", "ppv" }, { "h2o2", "hydrogen peroxide", "ppv" },
   { "ho2", "hydroperoxyl radical", "ppv" }, { "o1d", "atomic oxygen", "ppv" },
   { "tsts", "STS existence temperature", "K" }, { "tnat", "NAT existence temperature", "K" },
+  { "Cccl4", "CCl4 (CFC-10) volume mixing ratio", "ppv" }, { "Cccl3f", "CCl3F (CFC-11) volume mixing ratio", "ppv" },
+  { "Cccl2f2", "CCl2F2 (CFC-12) volume mixing ratio", "ppv" }, { "Cn2o", "N2O volume mixing ratio", "ppv" },
+  { "Csf6", "SF6 volume mixing ratio", "ppv" },
 };
 
 static const char *unsupported_qnt[] = {
   /* quantities only the chemistry, radioactive-decay and domain-decomposition code of the reference fills or
    * mixes (SET_QNT table, mptrac.c:6905-6969): they would be carried along unchanged here */
   "mloss_oh", "mloss_h2o2", "mloss_kpp", "Cx", "Ch2o", "Co3", "Cco", "Coh", "Ch", "Cho2", "Ch2o2", "Co1d", "Co3p",
-  "Cccl4", "Cccl3f", "Cccl2f2", "Cn2o", "Csf6", "Arn222", "Apb210", "Abe7", "Acs137", "Ai131", "Axe133",
+  "Arn222", "Apb210", "Abe7", "Acs137", "Ai131", "Axe133",
   "current_subdomain", "target_subdomain", NULL
 };
 
@@ -164,6 +167,11 @@ static const char *unsupported_qnt[] = {
   S(clim_ho2_filename, "CLIM_HO2_FILENAME", "../../data/clams_radical_species_vmr.nc") \
   S(clim_o1d_filename, "CLIM_O1D_FILENAME", "../../data/clams_radical_species_vmr.nc") \
   D(oh_chem_beta, "OH_CHEM_BETA", "0") \
+  S(clim_ccl4_timeseries, "CLIM_CCL4_TIMESERIES", "../../data/noaa_gml_ccl4.tab") \
+  S(clim_ccl3f_timeseries, "CLIM_CCL3F_TIMESERIES", "../../data/noaa_gml_cfc11.tab") \
+  S(clim_ccl2f2_timeseries, "CLIM_CCL2F2_TIMESERIES", "../../data/noaa_gml_cfc12.tab") \
+  S(clim_n2o_timeseries, "CLIM_N2O_TIMESERIES", "../../data/noaa_gml_n2o.tab") \
+  S(clim_sf6_timeseries, "CLIM_SF6_TIMESERIES", "../../data/noaa_gml_sf6.tab") \
   D(dt_met, "DT_MET", "3600") \
   I(met_type, "MET_TYPE", "0") \
   D(met_dt_out, "MET_DT_OUT", "0.1") \
@@ -307,6 +315,7 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
   ctl->qnt_m = ctl->qnt_vmr = ctl->qnt_rp = ctl->qnt_rhop = ctl->qnt_ens = ctl->qnt_loss_rate = -1;
   ctl->qnt_mloss_decay = ctl->qnt_mloss_wet = ctl->qnt_mloss_dry = ctl->qnt_zeta = ctl->qnt_eta = -1;
   ctl->qnt_aoa = ctl->qnt_stat = -1;
+  ctl->qnt_Cccl4 = ctl->qnt_Cccl3f = ctl->qnt_Cccl2f2 = ctl->qnt_Cn2o = ctl->qnt_Csf6 = -1;
 #define X(n, u) ctl->qnt_##n = -1;
   MPTRAC_METEO_QNT(X)
 #undef X
@@ -346,6 +355,11 @@ void mptrac_read_ctl(const char *filename, int argc, char *argv[], ctl_t *ctl) {
     else if (!strcasecmp(n, "zeta")) ctl->qnt_zeta = iq;
     else if (!strcasecmp(n, "eta")) ctl->qnt_eta = iq;
     else if (!strcasecmp(n, "aoa")) ctl->qnt_aoa = iq;
+    else if (!strcasecmp(n, "Cccl4")) ctl->qnt_Cccl4 = iq;
+    else if (!strcasecmp(n, "Cccl3f")) ctl->qnt_Cccl3f = iq;
+    else if (!strcasecmp(n, "Cccl2f2")) ctl->qnt_Cccl2f2 = iq;
+    else if (!strcasecmp(n, "Cn2o")) ctl->qnt_Cn2o = iq;
+    else if (!strcasecmp(n, "Csf6")) ctl->qnt_Csf6 = iq;
 #define X(nm, u) else if (!strcasecmp(n, #nm)) ctl->qnt_##nm = iq;
     MPTRAC_METEO_QNT(X)
 #undef X
@@ -647,6 +661,40 @@ static void clim_oh_diurnal_correction(const ctl_t *ctl, clim_t *clim) {
       }
 }
 
+/* A trace-gas time series: text lines "year vmr" (read_clim_ts, mptrac.c:8693-8743); years become seconds since
+ * 2000-01-01.  A file that cannot be opened is a warning: the gas then has no boundary condition. */
+static int read_clim_ts(const char *filename, clim_ts_t *ts) {
+  LOG(1, "Read climatological time series: %s", filename);
+  FILE *in = fopen(filename, "r");
+  if (!in) {
+    WARN("Cannot open file!");
+    return 0;
+  }
+  char line[LEN];
+  int nh = 0;
+  while (fgets(line, LEN, in))
+    if (sscanf(line, "%lg %lg", &ts->time[nh], &ts->vmr[nh]) == 2) {
+      ts->time[nh] = (ts->time[nh] - 2000.0) * 365.25 * 86400.;
+      if (nh > 0 && ts->time[nh] <= ts->time[nh - 1])
+        ERRMSG("Time series must be ascending!");
+      if ((++nh) >= CTS)
+        ERRMSG("Too many data points!");
+    }
+  fclose(in);
+  ts->ntime = nh;
+  if (nh < 2)
+    ERRMSG("Not enough data points!");
+  LOG(2, "Number of time steps: %d", ts->ntime);
+  LOG(2, "Time steps: %.2f, %.2f ... %.2f s", ts->time[0], ts->time[1], ts->time[nh - 1]);
+  double lo = ts->vmr[0], hi = ts->vmr[0];
+  for (int i = 1; i < nh; i++) {
+    lo = fmin(lo, ts->vmr[i]);
+    hi = fmax(hi, ts->vmr[i]);
+  }
+  LOG(2, "Volume mixing ratio range: %g ... %g ppv", lo, hi);
+  return 1;
+}
+
 /* mptrac.c:6663-6719: the tropopause climatology and the zonal means a requested module_meteo quantity needs
  * (the reference reads all its climatologies whatever the quantities; its photolysis rates and tracer time
  * series feed the chemistry modules, which are not part of this build) */
@@ -665,6 +713,17 @@ void mptrac_read_clim(const ctl_t *ctl, clim_t *clim) {
     read_clim_zm(ctl->clim_ho2_filename, "HO2", &clim->ho2);
   if (ctl->qnt_o1d >= 0 && ctl->clim_o1d_filename[0] != '-')
     read_clim_zm(ctl->clim_o1d_filename, "O1D", &clim->o1d);
+  /* the time series of the trace gases that are carried (module_bound_cond, mptrac.c:3857-3875) */
+  if (ctl->qnt_Cccl4 >= 0 && ctl->clim_ccl4_timeseries[0] != '-')
+    read_clim_ts(ctl->clim_ccl4_timeseries, &clim->ccl4);
+  if (ctl->qnt_Cccl3f >= 0 && ctl->clim_ccl3f_timeseries[0] != '-')
+    read_clim_ts(ctl->clim_ccl3f_timeseries, &clim->ccl3f);
+  if (ctl->qnt_Cccl2f2 >= 0 && ctl->clim_ccl2f2_timeseries[0] != '-')
+    read_clim_ts(ctl->clim_ccl2f2_timeseries, &clim->ccl2f2);
+  if (ctl->qnt_Cn2o >= 0 && ctl->clim_n2o_timeseries[0] != '-')
+    read_clim_ts(ctl->clim_n2o_timeseries, &clim->n2o);
+  if (ctl->qnt_Csf6 >= 0 && ctl->clim_sf6_timeseries[0] != '-')
+    read_clim_ts(ctl->clim_sf6_timeseries, &clim->sf6);
 }
 
 /* -------------------------------------------------------------------------- */
@@ -1552,6 +1611,11 @@ static void to_device_ctl(const ctl_t *c, mphip_ctl_t *d) {
   d->qnt_eta = c->qnt_eta;
   d->met_dt_out = c->met_dt_out;
   d->qnt_aoa = c->qnt_aoa;
+  d->qnt_tracer[MPHIP_TR_CCL4] = c->qnt_Cccl4;
+  d->qnt_tracer[MPHIP_TR_CCL3F] = c->qnt_Cccl3f;
+  d->qnt_tracer[MPHIP_TR_CCL2F2] = c->qnt_Cccl2f2;
+  d->qnt_tracer[MPHIP_TR_N2O] = c->qnt_Cn2o;
+  d->qnt_tracer[MPHIP_TR_SF6] = c->qnt_Csf6;
   d->isosurf = c->isosurf;
   d->bound_pbl = c->bound_pbl;
   d->bound_mass = c->bound_mass;
@@ -1794,6 +1858,9 @@ void mptrac_update_device(const ctl_t *ctl, const cache_t *cache, const clim_t *
       HIP(mphip_update_clim_zm(g_ctx, k, zm[k]->ntime, zm[k]->np, zm[k]->nlat, zm[k]->time, zm[k]->p, zm[k]->lat, v));
       free(v);
     }
+    const clim_ts_t *ts[MPHIP_NTR] = { &clim->ccl4, &clim->ccl3f, &clim->ccl2f2, &clim->n2o, &clim->sf6 };
+    for (int k = 0; k < MPHIP_NTR; k++)
+      HIP(mphip_update_clim_ts(g_ctx, k, ts[k]->ntime, ts[k]->time, ts[k]->vmr));
   }
   if (met0)
     upload_met(*met0, 0);

@@ -133,6 +133,7 @@ typedef struct {
   char qnt_name[NQ][LEN], qnt_longname[NQ][LEN], qnt_unit[NQ][LEN], qnt_format[NQ][LEN];
   int qnt_m, qnt_vmr, qnt_rp, qnt_rhop, qnt_ens, qnt_stat, qnt_loss_rate;
   int qnt_mloss_decay, qnt_mloss_wet, qnt_mloss_dry, qnt_zeta, qnt_eta, qnt_aoa;
+  int qnt_Cccl4, qnt_Cccl3f, qnt_Cccl2f2, qnt_Cn2o, qnt_Csf6;   /* trace gases: boundary condition from a time series, mixing */
   /* module_meteo outputs: qnt_ps, qnt_ts, ..., qnt_tice (mptrac.h:2518-2740) */
 #define X(n, u) int qnt_##n;
   MPTRAC_METEO_QNT(X)
@@ -145,6 +146,9 @@ typedef struct {
   char clim_hno3_filename[LEN], clim_oh_filename[LEN], clim_h2o2_filename[LEN], clim_ho2_filename[LEN],
     clim_o1d_filename[LEN];
   double oh_chem_beta;
+  /* surface time series of the trace gases (mptrac.c:7471-7480) */
+  char clim_ccl4_timeseries[LEN], clim_ccl3f_timeseries[LEN], clim_ccl2f2_timeseries[LEN], clim_n2o_timeseries[LEN],
+    clim_sf6_timeseries[LEN];
   char metbase[LEN];
   /* modules */
   double sort_dt;
@@ -233,6 +237,17 @@ typedef struct {
 #define CT 12
 #endif
 
+#ifndef CTS
+#define CTS 1000
+#endif
+
+/* a climatological time series, as the reference (clim_ts_t, mptrac.h:3733-3744) */
+typedef struct {
+  int ntime;
+  double time[CTS];
+  double vmr[CTS];
+} clim_ts_t;
+
 /* a zonal-mean climatology, as the reference (clim_zm_t, mptrac.h:3745-3776) */
 typedef struct {
   int ntime;
@@ -254,6 +269,7 @@ typedef struct {
   double tropo_lat[73];
   double tropo[12][73];
   clim_zm_t hno3, oh, h2o2, ho2, o1d;
+  clim_ts_t ccl4, ccl3f, ccl2f2, n2o, sf6;   /* surface time series of module_bound_cond's trace gases */
 } clim_t;
 
 /* meteo snapshot: the fields of the reference's met_t (mptrac.h:3844-4014)

@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from mptrac_amd.ctl import ZONAL_MEANS, make_ctl_struct, fill_ctl
+from mptrac_amd.ctl import TRACER_SERIES, ZONAL_MEANS, make_ctl_struct, fill_ctl
 from mptrac_amd.synth import FIELDS_2D, FIELDS_3D
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -42,9 +42,14 @@ class OrcZm(C.Structure):
                 ("time", _dp), ("p", _dp), ("lat", _dp), ("vmr", _dp)]
 
 
+class OrcTs(C.Structure):
+    _fields_ = [("ntime", C.c_int), ("pad", C.c_int), ("time", _dp), ("vmr", _dp)]
+
+
 class OrcClim(C.Structure):
     _fields_ = [("tropo_ntime", C.c_int), ("tropo_nlat", C.c_int), ("tropo_time", C.c_double * 12),
-                ("tropo_lat", C.c_double * 73), ("tropo", (C.c_double * 73) * 12), ("zm", OrcZm * len(ZONAL_MEANS))]
+                ("tropo_lat", C.c_double * 73), ("tropo", (C.c_double * 73) * 12), ("zm", OrcZm * len(ZONAL_MEANS)),
+                ("ts", OrcTs * len(TRACER_SERIES))]
 
 
 def build(force=False):
@@ -103,6 +108,8 @@ def lib():
                                               C.POINTER(C.c_int), _dp, _dp]
         _lib.orc_intpol_met_time_3d.argtypes = [C.POINTER(OrcMet), C.POINTER(OrcMet), C.c_int] + \
             [C.c_double] * 4 + [_dp]
+        _lib.orc_clim_ts.restype = C.c_double
+        _lib.orc_clim_ts.argtypes = [C.POINTER(OrcTs), C.c_double]
         _lib.orc_clim_zm.restype = C.c_double
         _lib.orc_clim_zm.argtypes = [C.POINTER(OrcZm)] + [C.c_double] * 3
         _lib.orc_clim_oh.restype = C.c_double
@@ -132,6 +139,14 @@ class Oracle:
         # zonal-mean climatologies: optional fourth element {name: (time, p, lat, vmr[ntime][np][nlat])}
         self._zm = {}
         for name, tab in (clim[3] if len(clim) > 3 else {}).items():
+            if name in TRACER_SERIES:      # a trace-gas time series (time, vmr)
+                arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in tab]
+                assert len(arrs) == 2 and arrs[0].shape == arrs[1].shape and len(arrs[0]) >= 2, name
+                self._zm[name] = arrs
+                z = self.clim.ts[TRACER_SERIES.index(name)]
+                z.ntime = len(arrs[0])
+                z.time, z.vmr = (_ptr(a, _dp) for a in arrs)
+                continue
             arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in tab]
             assert arrs[3].shape == (len(arrs[0]), len(arrs[1]), len(arrs[2])), name
             self._zm[name] = arrs
@@ -239,7 +254,7 @@ class Oracle:
         elif name == "isosurf":
             L.orc_module_isosurf(ctl, cache, m0, m1, atm)
         elif name in ("bound_cond", "bound_cond2"):
-            L.orc_module_bound_cond(ctl, cache, m0, m1, atm)
+            L.orc_module_bound_cond(ctl, cache, clim, m0, m1, atm)
         else:
             raise KeyError(name)
 

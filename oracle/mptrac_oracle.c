@@ -1181,10 +1181,12 @@ void orc_module_mixing(const orc_ctl_t *ctl, const orc_clim_t *clim, orc_atm_t *
     if (ixs[ip] >= ctl->mixing_nx || iys[ip] >= ctl->mixing_ny || izs[ip] >= ctl->mixing_nz)
       izs[ip] = -1;
   }
-  /* of the reference's quantity list (mptrac.c:5223-5230) the hot-path subset
-   * carries mass and volume mixing ratio, in this order */
-  const int quantities[3] = { ctl->qnt_m, ctl->qnt_vmr, ctl->qnt_aoa };   /* of the list at mptrac.c:5223-5230 */
-  for (int i = 0; i < 3; i++)
+  /* of the reference's quantity list (mptrac.c:5223-5230): mass, volume mixing ratio, the five trace gases and
+   * age of air -- the chemistry species and radionuclides of the list are not carried (every quantity is
+   * mixed on its own, so the order does not matter) */
+  const int quantities[8] = { ctl->qnt_m, ctl->qnt_vmr, ctl->qnt_tracer[ORC_TR_CCL4], ctl->qnt_tracer[ORC_TR_CCL3F],
+    ctl->qnt_tracer[ORC_TR_CCL2F2], ctl->qnt_tracer[ORC_TR_N2O], ctl->qnt_tracer[ORC_TR_SF6], ctl->qnt_aoa };
+  for (int i = 0; i < 8; i++)
     if (quantities[i] >= 0)
       mixing_one(ctl, clim, atm, ixs, iys, izs, quantities[i]);
   free(ixs);
@@ -1627,12 +1629,26 @@ void orc_module_isosurf(const orc_ctl_t *ctl, const orc_cache_t *cache, const or
   }
 }
 
-/* ---- module_bound_cond (mptrac.c:3789-3881): mass, volume mixing ratio and age
- * of air; the trace-gas time series belong to the chemistry part ------------- */
+/* clim_ts, mptrac.c:394-410: a time series at time t, constant beyond its ends */
+double orc_clim_ts(const orc_ts_t *ts, double t) {
+  if (t <= ts->time[0])
+    return ts->vmr[0];
+  else if (t >= ts->time[ts->ntime - 1])
+    return ts->vmr[ts->ntime - 1];
+  const int idx = orc_locate_irr(ts->time, ts->ntime, t);
+  return lin(ts->time[idx], ts->vmr[idx], ts->time[idx + 1], ts->vmr[idx + 1], t);
+}
 
-void orc_module_bound_cond(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
-                           const orc_met_t *met1, orc_atm_t *atm) {
-  if (ctl->qnt_m < 0 && ctl->qnt_vmr < 0 && ctl->qnt_aoa < 0)
+/* ---- module_bound_cond (mptrac.c:3789-3881): mass, volume mixing ratio, the trace gases with a surface time
+ * series and age of air ------------------------------------------------------------------------------------- */
+
+void orc_module_bound_cond(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_clim_t *clim,
+                           const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm) {
+  /* mptrac.c:3800-3804, as written there: the CFC-10 index is tested for "non-zero", not for "absent" -- with
+   * Cccl4 as the only quantity of the list the module runs if and only if it is quantity 0 */
+  const int *tr = ctl->qnt_tracer;
+  if (ctl->qnt_m < 0 && ctl->qnt_vmr < 0 && tr[ORC_TR_CCL4] && tr[ORC_TR_CCL3F] < 0 && tr[ORC_TR_CCL2F2] < 0
+      && tr[ORC_TR_N2O] < 0 && tr[ORC_TR_SF6] < 0 && ctl->qnt_aoa < 0)
     return;
 #pragma omp parallel for schedule(static)
   for (int ip = 0; ip < atm->np; ip++) {
@@ -1663,6 +1679,9 @@ void orc_module_bound_cond(const orc_ctl_t *ctl, const orc_cache_t *cache, const
       atm->q[ctl->qnt_m][ip] = ctl->bound_mass + ctl->bound_mass_trend * atm->time[ip];
     if (ctl->qnt_vmr >= 0 && ctl->bound_vmr >= 0)
       atm->q[ctl->qnt_vmr][ip] = ctl->bound_vmr + ctl->bound_vmr_trend * atm->time[ip];
+    for (int k = 0; k < ORC_NTR; k++)   /* mptrac.c:3857-3875 */
+      if (tr[k] >= 0 && clim->ts[k].ntime > 0)
+        atm->q[tr[k]][ip] = orc_clim_ts(&clim->ts[k], atm->time[ip]);
     if (ctl->qnt_aoa >= 0)
       atm->q[ctl->qnt_aoa][ip] = atm->time[ip];
   }
@@ -1701,7 +1720,7 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
   if (ctl->met_dt_out > 0 && (ctl->met_dt_out < ctl->dt_mod || fmod(t, ctl->met_dt_out) == 0))
     orc_module_meteo(ctl, clim, met0, met1, atm);   /* mptrac.c:7921-7924 */
   if (ctl->bound_lat0 < ctl->bound_lat1 && ctl->bound_p0 > ctl->bound_p1)
-    orc_module_bound_cond(ctl, cache, met0, met1, atm);   /* mptrac.c:7926-7929 */
+    orc_module_bound_cond(ctl, cache, clim, met0, met1, atm);   /* mptrac.c:7926-7929 */
   /* zero the total loss rate, mptrac.c:7932-7936 */
   if (ctl->qnt_loss_rate >= 0)
     for (int ip = 0; ip < atm->np; ip++)
@@ -1718,7 +1737,7 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
   if (ctl->dry_depo_vdep > 0)
     orc_module_dry_depo(ctl, cache, met0, met1, atm);
   if (ctl->bound_lat0 < ctl->bound_lat1 && ctl->bound_p0 > ctl->bound_p1)
-    orc_module_bound_cond(ctl, cache, met0, met1, atm);   /* mptrac.c:7997-8000 */
+    orc_module_bound_cond(ctl, cache, clim, met0, met1, atm);   /* mptrac.c:7997-8000 */
 }
 
 /* ---- write_grid binning (mptrac.c:13815-13872) -------------------------- */

@@ -53,6 +53,8 @@ enum { ORC_MQ_PS = 0, ORC_MQ_TS, ORC_MQ_ZS, ORC_MQ_US, ORC_MQ_VS, ORC_MQ_ESS, OR
        ORC_MQ_HNO3, ORC_MQ_OH, ORC_MQ_H2O2, ORC_MQ_HO2, ORC_MQ_O1D, ORC_MQ_TNAT, ORC_MQ_TSTS, ORC_NMQ };
 /* zonal-mean climatologies of clim_t that module_meteo samples (mptrac.h:3805-3817) */
 enum { ORC_ZM_HNO3 = 0, ORC_ZM_OH, ORC_ZM_H2O2, ORC_ZM_HO2, ORC_ZM_O1D, ORC_NZM };
+/* trace gases with a surface time series (clim_ts_t members ccl4, ccl3f, ccl2f2, n2o, sf6, mptrac.h:3820-3832) */
+enum { ORC_TR_CCL4 = 0, ORC_TR_CCL3F, ORC_TR_CCL2F2, ORC_TR_N2O, ORC_TR_SF6, ORC_NTR };
 
 /* Hot-path subset of ctl_t (mptrac.h:2494-3553).  Field names follow the
  * reference.  Layout is mirrored 1:1 by the Python ctypes class. */
@@ -107,6 +109,9 @@ typedef struct {
   /* clim_oh (mptrac.c:89-120) */
   double oh_chem_beta;
   double met_utm_ref_lon;
+  /* qnt_Cccl4, qnt_Cccl3f, qnt_Cccl2f2, qnt_Cn2o, qnt_Csf6 */
+  int qnt_tracer[ORC_NTR];
+  int pad4;
 } orc_ctl_t;
 
 /* One meteo snapshot: compact view of met_t (mptrac.h:3844-4014). */
@@ -149,13 +154,22 @@ typedef struct {
   const double *time, *p, *lat, *vmr;
 } orc_zm_t;
 
-/* Climatological tropopause part of clim_t (mptrac.h:3785-3800) and the zonal means module_meteo samples. */
+/* A trace-gas time series, view of clim_ts_t (mptrac.h:3729-3743). */
+typedef struct {
+  int ntime;
+  int pad;
+  const double *time, *vmr;
+} orc_ts_t;
+
+/* Climatological tropopause part of clim_t (mptrac.h:3785-3800), the zonal means module_meteo samples and the
+ * time series module_bound_cond applies. */
 typedef struct {
   int tropo_ntime, tropo_nlat;
   double tropo_time[12];
   double tropo_lat[73];
   double tropo[12][73];
   orc_zm_t zm[ORC_NZM];
+  orc_ts_t ts[ORC_NTR];   /* ntime = 0: the reference's CLIM_*_TIMESERIES = "-" */
 } orc_clim_t;
 
 size_t orc_sizeof_ctl(void);
@@ -194,6 +208,7 @@ double orc_clim_zm(const orc_zm_t *zm, double t, double lat, double p);
 double orc_cos_sza(double sec, double lon, double lat);
 double orc_clim_oh(const orc_ctl_t *ctl, const orc_clim_t *clim, double t, double lon, double lat, double p);
 double orc_nat_temperature(double p, double h2o, double hno3);
+double orc_clim_ts(const orc_ts_t *ts, double t);   /* mptrac.c:394-410 */
 
 /* --- modules (mptrac.c:3598-6293) ---------------------------------------- */
 void orc_module_rng(const orc_ctl_t *ctl, orc_cache_t *cache, size_t n, int method);
@@ -227,8 +242,8 @@ void orc_module_isosurf_init(const orc_ctl_t *ctl, orc_cache_t *cache, const orc
                              const orc_met_t *met1, const orc_atm_t *atm);   /* mptrac.c:4886 (modes 1-3) */
 void orc_module_isosurf(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
                         const orc_met_t *met1, orc_atm_t *atm);              /* mptrac.c:4956 */
-void orc_module_bound_cond(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_met_t *met0,
-                           const orc_met_t *met1, orc_atm_t *atm);           /* mptrac.c:3789 */
+void orc_module_bound_cond(const orc_ctl_t *ctl, const orc_cache_t *cache, const orc_clim_t *clim,
+                           const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm);   /* mptrac.c:3789 */
 void orc_module_meteo(const orc_ctl_t *ctl, const orc_clim_t *clim, const orc_met_t *met0, const orc_met_t *met1,
                       orc_atm_t *atm);   /* mptrac.c:5062 */
 /* keys[np] (as the reference's double keys, exact integers) and perm[np] are

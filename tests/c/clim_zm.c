@@ -2,7 +2,8 @@
  *   clim_zm <out file> [KEY VALUE ...]
  * reads the control parameters and the climatologies the requested quantities need, and writes for each of the
  * five tables "name ntime np nlat" followed by its time, pressure and latitude axes and the mixing ratios in
- * index order [time][p][lat], 17 significant digits.  No device involved. */
+ * index order [time][p][lat], then for each of the five trace-gas time series "name ntime", its times and its
+ * mixing ratios; 17 significant digits.  No device involved. */
 #include "mptrac.h"
 
 static void dump(FILE *out, const char *name, const clim_zm_t *zm) {
@@ -23,6 +24,16 @@ static void dump(FILE *out, const char *name, const clim_zm_t *zm) {
   fputc('\n', out);
 }
 
+static void dump_ts(FILE *out, const char *name, const clim_ts_t *ts) {
+  fprintf(out, "%s %d\n", name, ts->ntime);
+  for (int i = 0; i < ts->ntime; i++)
+    fprintf(out, "%.17g ", ts->time[i]);
+  fputc('\n', out);
+  for (int i = 0; i < ts->ntime; i++)
+    fprintf(out, "%.17g ", ts->vmr[i]);
+  fputc('\n', out);
+}
+
 int main(int argc, char *argv[]) {
   static ctl_t ctl;
   clim_t *clim;
@@ -39,6 +50,11 @@ int main(int argc, char *argv[]) {
   dump(out, "h2o2", &clim->h2o2);
   dump(out, "ho2", &clim->ho2);
   dump(out, "o1d", &clim->o1d);
+  dump_ts(out, "ccl4", &clim->ccl4);
+  dump_ts(out, "ccl3f", &clim->ccl3f);
+  dump_ts(out, "ccl2f2", &clim->ccl2f2);
+  dump_ts(out, "n2o", &clim->n2o);
+  dump_ts(out, "sf6", &clim->sf6);
   fclose(out);
   printf("RESULT done\n");
   free(clim);

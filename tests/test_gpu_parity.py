@@ -147,6 +147,77 @@ def test_run_timestep_20_steps(case):
     s.close()
 
 
+def _tracer_series(t_mid):
+    """Surface time series around the run (the reference's SF6 and N2O files shifted to it, a synthetic third)."""
+    import os
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data")
+    out = {}
+    for name, fn in (("sf6", "noaa_gml_sf6.tab"), ("n2o", "noaa_gml_n2o.tab")):
+        raw = np.loadtxt(os.path.join(ref, fn))
+        time = (raw[:, 0] - 2000.0) * 365.25 * 86400.0
+        # one node per 100 s around the run instead of one per month: every step sees another segment
+        out[name] = (t_mid + (time - time[len(time) // 2]) / 26298.0, raw[:, 1])
+    out["ccl3f"] = (np.array([t_mid - 500.0, t_mid, t_mid + 700.0]), np.array([2.4e-10, 2.6e-10, 2.5e-10]))
+    return out
+
+
+@pytest.mark.parametrize("with_mass", [True, False], ids=["with_mass", "tracers_only"])
+def test_trace_gas_boundary_conditions_and_mixing(with_mass):
+    """module_bound_cond sets Csf6, Cn2o, Cccl3f from their surface time series at the particle's time inside the
+    boundary region (mptrac.c:3857-3875; Cccl2f2 is carried without a series -- CLIM_CCL2F2_TIMESERIES "-" -- and
+    keeps its values there) and module_mixing relaxes all of them towards the cell means (mptrac.c:5223-5230): 20
+    steps of the boundary-condition case with mixing (and decay, when mass is carried) against the oracle."""
+    quantities = (("m", "vmr") if with_mass else ()) + ("Csf6", "Cn2o", "Cccl3f", "Cccl2f2", "aoa")
+    ctl, clim, m0, m1, atm = cases.make_case("bound", n=10000, quantities=quantities)
+    if not with_mass:      # module_decay needs mass or volume mixing ratio (mptrac.c:4235)
+        ctl = dict(ctl, tdec_trop=0.0, tdec_strat=0.0)
+    rng = np.random.default_rng(3)
+    for k, name in enumerate(quantities):
+        if name.startswith("C"):
+            atm["q"][k][:] = rng.uniform(1e-12, 5e-10, len(atm["time"]))
+    before = [q.copy() for q in atm["q"]]
+    clim = clim + (_tracer_series(1800.0),)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(atm["time"].min(), atm["time"].max())
+    for t in cases.step_times(o.ctl):
+        o.run_timestep(t)
+        s.run_timestep(t)
+    _compare(o, s)
+    r = o.state()
+    for name in ("Csf6", "Cn2o", "Cccl3f", "Cccl2f2"):
+        k = quantities.index(name)
+        assert np.abs(r["q"][k] - before[k]).max() > 1e-13, name        # the boundary condition and / or the mixing acted
+    # inside the boundary region the three gases carry values of their series, the fourth does not
+    sf6 = r["q"][quantities.index("Csf6")]
+    lo, hi = clim[3]["sf6"][1].min(), clim[3]["sf6"][1].max()
+    assert ((sf6 >= lo) & (sf6 <= hi)).sum() > 100
+    s.close()
+
+
+def test_bound_cond_cfc10_quirk_of_the_reference():
+    """mptrac.c:3800-3804 tests the CFC-10 index for "non-zero" instead of "absent": with Cccl4 as the only
+    quantity of the module's list, the module runs if and only if it is quantity 0.  Reproduced, not repaired."""
+    for quantities, acts in ((("Cccl4", "rp"), True), (("rp", "Cccl4"), False)):
+        ctl, clim, m0, m1, atm = cases.make_case("bound", n=3000, quantities=quantities)
+        ctl = dict(ctl, mixing_dt=0.0, tdec_trop=0.0, tdec_strat=0.0)
+        k = quantities.index("Cccl4")
+        atm["q"][k][:] = 7e-11
+        clim = clim + ({"ccl4": (np.array([0.0, 4000.0]), np.array([9e-11, 9.5e-11]))},)
+        o = B.Oracle(ctl, clim, m0, m1, atm)
+        o.timesteps_init()
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.timesteps_init(atm["time"].min(), atm["time"].max())
+        for t in cases.step_times(o.ctl)[:4]:
+            o.run_timestep(t)
+            s.run_timestep(t)
+        g, r = s.state(), o.state()
+        assert np.array_equal(g["q"][k], r["q"][k])
+        assert (np.abs(r["q"][k] - 7e-11).max() > 1e-11) == acts
+        s.close()
+
+
 def test_fused_step_equals_module_sequence():
     """mphip_run_timestep (one launch) and the module-by-module sequence
     (one launch each, cache->dt handed over in memory) give identical bits."""

@@ -310,7 +310,10 @@ def _clim_tables(tmp_path, keys):
     assert res.returncode == 0 and "RESULT done" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
     lines = open(tmp_path / "clim.txt").read().splitlines()
     out = {}
-    for k in range(0, len(lines), 5):
+    for k in range(25, len(lines), 3):      # the five time series behind the five tables
+        out[lines[k].split()[0]] = (np.array(lines[k + 1].split(), dtype=np.float64),
+                                    np.array(lines[k + 2].split(), dtype=np.float64))
+    for k in range(0, 25, 5):
         name, nt, npr, nlat = lines[k].split()
         nt, npr, nlat = int(nt), int(npr), int(nlat)
         axes = [np.array(lines[k + 1 + j].split(), dtype=np.float64) for j in range(3)]
@@ -364,3 +367,20 @@ def test_oh_climatology_with_diurnal_correction(tmp_path):
             c = np.array([L.orc_cos_sza(refclim.MONTH_MID[it], float(lon), float(lat[iy])) for lon in range(-180, 180)])
             factor = np.mean(np.exp(-beta / np.maximum(c, thresh)))
             assert np.allclose(scaled["oh"][3][it, :, iy], plain["oh"][3][it, :, iy] / factor, rtol=1e-13, atol=0)
+
+
+def test_trace_gas_time_series_reader_on_the_reference_files(tmp_path):
+    """mptrac_read_clim with trace-gas quantities: the reference's data/noaa_gml_sf6.tab and noaa_gml_n2o.tab
+    (text, "year vmr") become (seconds since 2000, vmr) series; a series whose gas is not carried is not read, "-"
+    switches one off."""
+    ref = os.path.join(HERE, "golden", "ref_data")
+    keys = {"NQ": 2, "QNT_NAME[0]": "Csf6", "QNT_NAME[1]": "Cn2o", "CLIM_SF6_TIMESERIES": os.path.join(ref, "noaa_gml_sf6.tab"),
+            "CLIM_N2O_TIMESERIES": os.path.join(ref, "noaa_gml_n2o.tab")}
+    tabs, _ = _clim_tables(tmp_path, keys)
+    for name, fn in (("sf6", "noaa_gml_sf6.tab"), ("n2o", "noaa_gml_n2o.tab")):
+        raw = np.loadtxt(os.path.join(ref, fn))
+        assert np.array_equal(tabs[name][0], (raw[:, 0] - 2000.0) * 365.25 * 86400.0) and np.array_equal(tabs[name][1], raw[:, 1])
+        assert len(raw) > 100
+    assert all(len(tabs[k][0]) == 0 for k in ("ccl4", "ccl3f", "ccl2f2"))
+    tabs, _ = _clim_tables(tmp_path, dict(keys, CLIM_N2O_TIMESERIES="-"))
+    assert len(tabs["n2o"][0]) == 0 and len(tabs["sf6"][0]) > 100

@@ -224,3 +224,21 @@ def test_zonal_mean_climatology_against_an_independent_restatement():
             got = L.orc_clim_zm(C.byref(z), t, la, pr)
             worst = max(worst, abs(got - want) / max(abs(want), 1e-30))
         assert worst <= 1e-12, worst
+
+
+def test_trace_gas_time_series_interpolation():
+    """orc_clim_ts (clim_ts, mptrac.c:394-410) on the reference's SF6 series against numpy's clamped linear
+    interpolation: inside, at the nodes, before the first and after the last entry."""
+    L = B.lib()
+    raw = np.loadtxt(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data", "noaa_gml_sf6.tab"))
+    time = np.ascontiguousarray((raw[:, 0] - 2000.0) * 365.25 * 86400.0)
+    vmr = np.ascontiguousarray(raw[:, 1])
+    ts = B.OrcTs()
+    ts.ntime = len(time)
+    ts.time, ts.vmr = (a.ctypes.data_as(C.POINTER(C.c_double)) for a in (time, vmr))
+    rng = np.random.default_rng(2)
+    probes = np.concatenate([rng.uniform(time[0] - 1e8, time[-1] + 1e8, 3000), time[::7], [time[0], time[-1]]])
+    got = np.array([L.orc_clim_ts(C.byref(ts), float(t)) for t in probes])
+    want = np.interp(probes, time, vmr)
+    assert np.allclose(got, want, rtol=1e-13, atol=0)
+    assert got[-2] == vmr[0] and got[-1] == vmr[-1]
