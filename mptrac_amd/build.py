@@ -81,15 +81,15 @@ def build_host(force=False, verbose=False, dims=None):
     os.makedirs(LIBDIR, exist_ok=True)
     dims = dict(HOST_DIMS, **(dims or {}))
     src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "mptrac.h", "trac.c", "ctlfile.c", "nc_classic.c",
-                                               "nc_classic.h", "rendezvous.c", "output.c")]
-    lib_src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "ctlfile.c", "nc_classic.c", "rendezvous.c", "output.c")]
+                                               "nc_classic.h", "nc_internal.h", "nc_hdf5.c", "rendezvous.c", "output.c")]
+    lib_src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "ctlfile.c", "nc_classic.c", "nc_hdf5.c", "rendezvous.c", "output.c")]
     if not (force or _stale(HOST_LIB, src) or _stale(TRAC_BIN, src)):
         return HOST_LIB, TRAC_BIN
     defs = [f"-D{k}={v}" for k, v in dims.items()]
     defs.append('-DMPTRAC_AMD_DATA_DIR="%s"' % os.path.join(HERE, "data"))
     common = ["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-W", "-Wno-format-security", "-fPIC", "-mcmodel=medium",
               *defs]
-    rpath = ["-L" + LIBDIR, "-lmptrac_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread"]
+    rpath = ["-L" + LIBDIR, "-lmptrac_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread", "-lz"]
     cmds = [common + ["-shared", "-o", HOST_LIB] + lib_src + rpath,
             common + ["-o", TRAC_BIN, os.path.join(HOST_DIR, "trac.c")] + lib_src + rpath]
     for cmd in cmds:

@@ -11,54 +11,19 @@
  *   var      = name ndims dimid... vatt_list type vsize begin
  *   data     = fixed-size variables at `begin`; record r of a record variable at begin + r * recsize
  */
-#include "nc_classic.h"
+#include "nc_internal.h"
 
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-enum { TAG_DIM = 10, TAG_VAR = 11, TAG_ATT = 12 };
-enum { T_BYTE = 1, T_CHAR = 2, T_SHORT = 3, T_INT = 4, T_FLOAT = 5, T_DOUBLE = 6 };
-
-typedef struct {
-  char *name;
-  int type;
-  size_t n;
-  unsigned char *raw;   /* big-endian values as stored */
-} ncc_att;
-
-typedef struct {
-  char *name;
-  int ndims, dimid[8];
-  int natt;
-  ncc_att *att;
-  int type;
-  long long vsize, begin;
-  int is_record;
-  long long nelem;      /* elements of one record (record variables) or of the whole variable */
-} ncc_var;
-
-struct ncc_file {
-  FILE *f;
-  int version;
-  long long numrecs, recsize;
-  int ndim;
-  char **dim_name;
-  long long *dim_len;
-  int natt;
-  ncc_att *att;
-  int nvar;
-  ncc_var *var;
-  char err[256];
-};
-
 static int type_size(int t) {
   switch (t) {
   case T_BYTE: case T_CHAR: return 1;
   case T_SHORT: return 2;
   case T_INT: case T_FLOAT: return 4;
-  case T_DOUBLE: return 8;
+  case T_DOUBLE: case T_INT64: return 8;
   }
   return 0;
 }
@@ -150,6 +115,12 @@ static double decode(const unsigned char *p, int type) {
     memcpy(&d, &u, 8);
     return d;
   }
+  case T_INT64: {
+    uint64_t u = 0;
+    for (int k = 0; k < 8; k++)
+      u = (u << 8) | p[k];
+    return (double) (int64_t) u;
+  }
   }
   return 0.0;
 }
@@ -165,8 +136,10 @@ ncc_file *ncc_open(const char *path, char *err, size_t errlen) {
     fail(nc, "cannot open file");
   else if (fread(magic, 1, 4, nc->f) != 4)
     fail(nc, "file too short");
-  else if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F')
-    fail(nc, "netCDF-4 / HDF5 file: only the classic formats (CDF-1, CDF-2) are read by this build");
+  else if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F') {
+    nc->is_hdf5 = 1;
+    ok = h5_load(nc);
+  }
   else if (magic[0] != 'C' || magic[1] != 'D' || magic[2] != 'F' || (magic[3] != 1 && magic[3] != 2))
     fail(nc, "not a classic netCDF file (CDF-1 / CDF-2)");
   else {
@@ -216,7 +189,7 @@ ncc_file *ncc_open(const char *path, char *err, size_t errlen) {
         v->nelem = 1;
         for (uint32_t d = 0; d < nd && !bad; d++) {
           uint32_t id;
-          if (!get_u32(nc, &id) || (int) id >= nc->ndim)
+          if (!get_u32(nc, &id) || id >= (uint32_t) nc->ndim)
             bad = 1;
           else {
             v->dimid[d] = (int) id;
@@ -301,8 +274,10 @@ void ncc_close(ncc_file *nc) {
   for (int i = 0; i < nc->nvar; i++) {
     free(nc->var[i].name);
     free_atts(nc->var[i].natt, nc->var[i].att);
+    h5_free_dataset(nc->var[i].h5);
   }
   free(nc->var);
+  h5_free(nc);
   free(nc);
 }
 
@@ -362,6 +337,8 @@ static int read_raw(ncc_file *nc, int var, long long rec, long long first, long 
   ncc_var *v = &nc->var[var];
   if (first < 0 || count < 0 || first + count > v->nelem)
     return fail(nc, "read beyond the end of a netCDF variable");
+  if (nc->is_hdf5)
+    return h5_read_raw(nc, var, first, count, buf);
   if (v->is_record && (rec < 0 || rec >= nc->numrecs))
     return fail(nc, "record index out of range");
   const int ts = type_size(v->type);

@@ -79,15 +79,15 @@ def compile_c_test(name):
     if os.environ.get("MPTRAC_TEST_SANITIZE"):
         # the test and the host layer's sources as one program under the address and undefined-behaviour sanitizers
         exe += "_san"
-        host = [os.path.join(build.HOST_DIR, f) for f in ("mptrac.c", "ctlfile.c", "nc_classic.c", "rendezvous.c",
-                                                           "output.c")]
+        host = [os.path.join(build.HOST_DIR, f) for f in ("mptrac.c", "ctlfile.c", "nc_classic.c", "nc_hdf5.c",
+                                                           "rendezvous.c", "output.c")]
         defs = [f"-D{k}={v}" for k, v in build.HOST_DIMS.items()]
         defs.append('-DMPTRAC_AMD_DATA_DIR="%s"' % os.path.join(os.path.dirname(build.HOST_DIR), "data"))
         subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu99", "-Wall", "-fsanitize=address,undefined",
                                "-fno-omit-frame-pointer", "-mcmodel=medium", *defs, "-I", build.HOST_DIR,
                                "-I", os.path.join(os.path.dirname(here), "include"), "-o", exe, src, *host,
                                "-L" + build.LIBDIR, "-lmptrac_hip", "-Wl,-rpath," + build.LIBDIR,
-                               "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread"])
+                               "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread", "-lz"])
         return exe
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
         defs = [f"-D{k}={v}" for k, v in build.HOST_DIMS.items()]

@@ -476,3 +476,41 @@ def test_trac_command_line_conventions_of_the_reference_cli_test():
         for extra in ([], ["extra-arg"]):
             r = subprocess.run([trac, flag] + extra, capture_output=True, text=True)
             assert r.returncode == 0 and "Usage:" in r.stdout
+
+
+def test_hdf5_reader_on_old_style_chunked_compressed_files(tmp_path):
+    """nc_hdf5.c on the on-disk style of HDF5-1.8-era netCDF-4 files, which none of the reference's files has:
+    version-0 superblock, version-1 object headers, symbol-table group, chunked datasets with a version-1 B-tree,
+    shuffle + deflate, edge chunks that overhang the array, a chunk that was never written (fill value), packed
+    shorts with scale / offset attributes, big-endian storage.  The file is made by tests/h5write.py from the format
+    specification (no HDF5 library in the image)."""
+    import subprocess
+    import h5write
+    from hostfiles import compile_c_test
+    rng = np.random.default_rng(12)
+    t3 = rng.normal(250.0, 20.0, (5, 13, 17)).astype("<f4")
+    packed = rng.integers(-30000, 30000, (7, 10)).astype("<i2")
+    big = rng.normal(0.0, 1.0, (4, 6)).astype(">f8")
+    lev = np.array([1000.0, 850.0, 500.0, 250.0, 100.0])
+    holes = np.arange(6 * 8, dtype="<f4").reshape(6, 8)
+    w = h5write.Writer()
+    w.dataset("t", t3, chunks=(2, 5, 8), shuffle=True, deflate=4)
+    w.dataset("q", packed, chunks=(4, 4), deflate=1, attrs=(("scale_factor", np.float64(0.25)), ("add_offset", np.float64(-3.0))))
+    w.dataset("b", big)
+    w.dataset("lev", lev)
+    w.dataset("holes", holes, chunks=(3, 4), shuffle=True, fill=np.float32(-7.5), skip_chunks=((1, 0),))
+    path = str(tmp_path / "old_style.nc")
+    w.close(path)
+    exe = compile_c_test("nc_dump")
+    res = subprocess.run([exe, path, "t", "q", "b", "lev", "holes"], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0 and "RESULT done" in res.stdout, res.stdout[-2000:]
+    vals = {ln.split()[1]: np.array(ln.split()[2:], dtype=np.float64) for ln in res.stdout.splitlines() if ln.startswith("values ")}
+    assert np.array_equal(vals["t"], t3.astype(np.float64).ravel())
+    assert np.array_equal(vals["q"], packed.astype(np.float64).ravel())
+    assert np.array_equal(vals["b"], big.astype(np.float64).ravel())
+    assert np.array_equal(vals["lev"], lev)
+    want = holes.astype(np.float64).copy()
+    want[3:6, 0:4] = -7.5
+    assert np.array_equal(vals["holes"], want.ravel())
+    assert "att q scale_factor 0.25" in res.stdout and "att q add_offset -3" in res.stdout
+    assert "var t 3" in res.stdout

@@ -384,3 +384,38 @@ def test_trace_gas_time_series_reader_on_the_reference_files(tmp_path):
     assert all(len(tabs[k][0]) == 0 for k in ("ccl4", "ccl3f", "ccl2f2"))
     tabs, _ = _clim_tables(tmp_path, dict(keys, CLIM_N2O_TIMESERIES="-"))
     assert len(tabs["n2o"][0]) == 0 and len(tabs["sf6"][0]) > 100
+
+
+def test_netcdf4_particle_files_of_the_reference_dd_test(tmp_path):
+    """The nine init.nc files of the reference's tests/dd_test (netCDF-4 / HDF5: superblock version 2, links and
+    attributes in the object headers, contiguous little-endian doubles -- written by the reference's CLaMS
+    writer) read with ATM_TYPE 4 by the host layer's own HDF5 reader: converted to text, the 144 parcels are the
+    rows of the golden particle file of the start time (the run has not moved them yet; columns time, altitude,
+    longitude, latitude, idx, zeta -- absent from the file under that name, hence 0 as in the golden -- and m)."""
+    gold = np.loadtxt(os.path.join(HERE, "golden", "ref_dd_test", "atm_2022_06_02_00_00_00.tab"))
+    rows = []
+    for k in range(9):
+        out = tmp_path / f"atm_{k}.tab"
+        _atm_conv([os.path.join(HERE, "golden", "ref_dd_test", "init", f"data.{k}.nc"), 4, out, 0, "NQ", 3,
+                   "QNT_NAME[0]", "idx", "QNT_UNIT[0]", "-", "QNT_NAME[1]", "zeta", "QNT_NAME[2]", "m"])
+        rows.append(np.loadtxt(out).reshape(-1, 7))
+    mine = np.concatenate(rows)
+    assert mine.shape == (144, 7) and gold.shape[0] == 144
+    mine = mine[np.argsort(mine[:, 4])]
+    gold = gold[np.argsort(gold[:, 4])]
+    assert np.array_equal(mine, gold[:, :7])
+
+
+def test_netcdf4_climatology_file_of_the_reference(tmp_path):
+    """data/cams_H2O2.nc of the reference (netCDF-4 / HDF5 with a version-0 superblock; the default of
+    CLIM_H2O2_FILENAME) through mptrac_read_clim: 12 months x 25 levels x 241 latitudes of mixing ratios on
+    the axes the file declares (1000 ... 1 hPa, -90 ... 90 degrees in steps of 0.75)."""
+    keys = {"NQ": 1, "QNT_NAME[0]": "h2o2", "CLIM_H2O2_FILENAME": os.path.join(HERE, "golden", "ref_data", "cams_H2O2.nc")}
+    tabs, _ = _clim_tables(tmp_path, keys)
+    time, p, lat, vmr = tabs["h2o2"]
+    assert vmr.shape == (12, 25, 241) and p[0] == 1000.0 and p[-1] == 1.0 and np.all(np.diff(p) < 0)
+    assert np.array_equal(lat, -90.0 + 0.75 * np.arange(241))
+    assert vmr.min() >= 0 and (vmr == 0).sum() < 50 and vmr.max() < 1e-8 and np.isfinite(vmr).all()   # (zeros: polar night)
+    # (double precision in the file: 12 * 25 * 241 * 8 bytes of its 588720 are this array)
+    # smooth in latitude: neighbouring columns differ by far less than the field varies
+    assert np.abs(np.diff(vmr, axis=2)).max() < 0.2 * vmr.max()
