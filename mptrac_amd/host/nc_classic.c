@@ -3,7 +3,7 @@
  *
  * The image has no netCDF library; the classic format is a flat big-endian header followed by the arrays
  * ("The NetCDF Classic Format Specification", Unidata), which is all the reference's own test meteo files
- * (tests/data/era5_utm32_*.nc) use.  Written from that specification.  netCDF-4 / HDF5 files are rejected.
+ * (tests/data/era5_utm32_*.nc) use.  Written from that specification.  netCDF-4 / HDF5 files go to nc_hdf5.c.
  *
  *   header   = magic numrecs dim_list gatt_list var_list
  *   dim      = name length                      (length 0: the record dimension)
