@@ -1,6 +1,6 @@
 """Randomised module combinations against the oracle (GPU): every seed draws a control set (integrator,
 stochastic modules, convection, sedimentation, sort, mixing, decay, wet / dry deposition, boundary conditions,
-isosurface mode, meteo quantities, direction, grid orientation, vertical coordinate of the advection) and runs 12 steps through
+isosurface mode, meteo quantities (climatology ones included), trace gases with surface time series, direction, grid orientation, vertical coordinate of the advection) and runs 12 steps through
 mphip_run_timestep.  Catches interactions between modules and between the kernel instantiations that the
 named cases do not cover."""
 import numpy as np
@@ -53,6 +53,33 @@ def draw(seed):
     if vert:
         names += ["zeta", "eta"]
         ctl.pop("isosurf", None)
+    # a second stream for what came later (the draws above stay what they were for every seed): trace gases of
+    # module_bound_cond / module_mixing with and without a surface time series, climatology quantities of module_meteo
+    r2 = np.random.default_rng(seed + 1000003)
+    tables = {}
+    if r2.random() < 0.35:
+        gases = list(r2.choice(["Cccl4", "Cccl3f", "Cccl2f2", "Cn2o", "Csf6"], size=int(r2.integers(1, 4)), replace=False))
+        for gname in gases[:max(0, 16 - len(names))]:
+            names.append(gname)
+            if r2.random() < 0.75:
+                tt = np.sort(r2.uniform(-8000.0, 8000.0, int(r2.integers(2, 40))))
+                tables[{"Cccl4": "ccl4", "Cccl3f": "ccl3f", "Cccl2f2": "ccl2f2", "Cn2o": "n2o", "Csf6": "sf6"}[gname]] = \
+                    (tt + np.arange(len(tt)) * 1e-3, r2.uniform(1e-12, 4e-10, len(tt)))
+    if r2.random() < 0.3 and len(names) <= 12:
+        import refclim
+        want = list(r2.choice(["hno3", "oh", "ho2", "tnat"], size=2, replace=False))
+        if "tnat" in want and len(names) <= 10 and r2.random() < 0.5:
+            want += ["tice", "tsts"]
+        for q in want:
+            if q not in names:
+                names.append(q)
+        if "met_dt_out" not in ctl:
+            ctl.update(met_dt_out=pick(0.1, 1200.0))
+        tables["hno3"] = refclim.load_zonal_mean()
+        tables["oh"] = refclim.synthetic_zonal_mean(seed, scale=1e-13)
+        tables["ho2"] = refclim.synthetic_zonal_mean(seed + 1, np_=7, nlat=13, scale=1e-12)
+        ctl.update(oh_chem_beta=float(r2.choice([0.0, 0.6])))
+    ctl["_tables"] = tables
     ctl.update(ctl_from_quantities(names), advect_vert_coord=vert)
     if not sedi:
         ctl["qnt_rp"] = ctl["qnt_rhop"] = -1
@@ -75,6 +102,7 @@ def _seeds():
 @pytest.mark.parametrize("seed", _seeds())
 def test_random_module_combination(seed):
     ctl, names, geom = draw(seed)
+    tables = ctl.pop("_tables")
     fields = cases.PRESSURE_LEVEL_FIELDS + FIELDS_METEO_ONLY
     if ctl["advect_vert_coord"]:
         fields = fields + FIELDS_ML
@@ -88,7 +116,10 @@ def test_random_module_combination(seed):
             atm["q"][list(names).index(nq)] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
     if ctl.get("turb_pbl_scheme", 0):
         atm["p"][::2] = 1013.25 * np.exp(-(0.02 + 0.9 * (atm["lon"][::2] - geom["lon0"]) / 360.0) / 7.0)
-    clim = cases.load_clim_tropo()
+    clim = cases.load_clim_tropo() + (tables,)
+    for k, name in enumerate(names):
+        if name.startswith("C"):     # trace gases: mixing ratios of their own
+            atm["q"][k] = np.random.default_rng(seed + k).uniform(1e-12, 4e-10, len(atm["time"]))
     o = B.Oracle(ctl, clim, m0, m1, atm)
     o.timesteps_init()
     s = hip.Simulation(ctl, clim, m0, m1, atm)
