@@ -1437,6 +1437,54 @@ static int nc_field(const nc_reader *r, const char *const *names, const int nlev
 #define NC_3D(field, scl, ...) nc_field(&r, NAMES(__VA_ARGS__), met->np, scl, &met->field[0][0][0], EP)
 #define NC_2D(field, scl, ...) nc_field(&r, NAMES(__VA_ARGS__), 0, scl, &met->field[0][0], 1)
 
+/* read_met_polar_winds (mptrac.c:11775-11833): on a grid that reaches both poles the winds of the pole rows are
+ * replaced by the mean wind vector of the neighbouring row, turned into each longitude's local directions */
+static void met_polar_winds(met_t *met) {
+  if (fabs(met->lat[0]) < 89.999 || fabs(met->lat[met->ny - 1]) < 89.999)
+    return;
+  double *clon, *slon;
+  ALLOC(clon, double, met->nx);
+  ALLOC(slon, double, met->nx);
+  for (int ihem = 0; ihem < 2; ihem++) {
+    const int i89 = ihem ? met->ny - 2 : 1, i90 = ihem ? met->ny - 1 : 0, sign = met->lat[i90] < 0 ? -1 : 1;
+    for (int ix = 0; ix < met->nx; ix++) {
+      clon[ix] = cos(sign * DEG2RAD(met->lon[ix]));
+      slon[ix] = sin(sign * DEG2RAD(met->lon[ix]));
+    }
+    for (int ip = 0; ip < met->np; ip++) {
+      double vel89x = 0, vel89y = 0;
+      for (int ix = 0; ix < met->nx; ix++) {
+        vel89x += (met->u[ix][i89][ip] * clon[ix] - met->v[ix][i89][ip] * slon[ix]) / met->nx;
+        vel89y += (met->u[ix][i89][ip] * slon[ix] + met->v[ix][i89][ip] * clon[ix]) / met->nx;
+      }
+      for (int ix = 0; ix < met->nx; ix++) {
+        met->u[ix][i90][ip] = (float) (vel89x * clon[ix] + vel89y * slon[ix]);
+        met->v[ix][i90][ip] = (float) (-vel89x * slon[ix] + vel89y * clon[ix]);
+      }
+    }
+  }
+  free(clon);
+  free(slon);
+}
+
+/* read_met_periodic (mptrac.c:11714-11771): a global grid gets one more longitude, a copy of the first column */
+static void met_periodic(met_t *met) {
+  if (!(fabs(met->lon[met->nx - 1] - met->lon[0] + met->lon[1] - met->lon[0] - 360) < 0.01))
+    return;
+  if ((++met->nx) >= EX)
+    ERRMSG("Cannot create periodic boundary conditions!");
+  const int last = met->nx - 1;
+  met->lon[last] = met->lon[last - 1] + met->lon[1] - met->lon[0];
+  float (*f2[])[EY] = { met->ps, met->zs, met->ts, met->us, met->vs, met->ess, met->nss, met->shf, met->lsm, met->sst,
+    met->pbl, met->cape, met->cin };
+  float (*f3[])[EY][EP] = { met->t, met->u, met->v, met->w, met->h2o, met->o3, met->lwc, met->rwc, met->iwc, met->swc,
+    met->cc };
+  for (size_t f = 0; f < sizeof(f2) / sizeof(f2[0]); f++)
+    memcpy(f2[f][last], f2[f][0], sizeof(f2[f][0]));
+  for (size_t f = 0; f < sizeof(f3) / sizeof(f3[0]); f++)
+    memcpy(f3[f][last], f3[f][0], sizeof(f3[f][0]));
+}
+
 static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
   char err[256];
   ncc_file *nc = ncc_open(filename, err, sizeof(err));
@@ -1447,9 +1495,6 @@ static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
     }
     ERRMSG("%s: %s", filename, err);
   }
-  if (ctl->met_coord_type == 0)
-    ERRMSG("netCDF meteo files on a longitude / latitude grid need the reference's meteo preprocessing, which this "
-           "build does not provide: convert them to MET_TYPE 1 with the reference's met_conv tool!");
   met->coord_type = ctl->met_coord_type;
   nc_reader r = { nc, ctl, met, ctl->met_nc_scale };
 
@@ -1463,15 +1508,16 @@ static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
 
   /* axes */
   long long nx, ny;
-  if (ncc_find_dim(nc, "x", &nx) < 0 || ncc_find_dim(nc, "y", &ny) < 0)
-    ERRMSG("Cannot read netCDF dimension x / y!");
-  if (nx < 2 || nx > EX || ny < 2 || ny > EY)
-    ERRMSG("Dimension x / y is out of range!");
+  const char *xname = ctl->met_coord_type == 0 ? "lon" : "x", *yname = ctl->met_coord_type == 0 ? "lat" : "y";
+  if (ncc_find_dim(nc, xname, &nx) < 0 || ncc_find_dim(nc, yname, &ny) < 0)
+    ERRMSG("Cannot read netCDF dimension %s / %s!", xname, yname);
+  if (nx < 2 || nx >= EX || ny < 2 || ny > EY)      /* (one column is kept for the periodic boundary) */
+    ERRMSG("Dimension %s / %s is out of range!", xname, yname);
   met->nx = (int) nx;
   met->ny = (int) ny;
-  const int vx = ncc_find_var(nc, "x"), vy = ncc_find_var(nc, "y");
+  const int vx = ncc_find_var(nc, xname), vy = ncc_find_var(nc, yname);
   if (vx < 0 || vy < 0 || !ncc_read_double(nc, vx, 0, 0, nx, met->lon) || !ncc_read_double(nc, vy, 0, 0, ny, met->lat))
-    ERRMSG("Cannot read the x / y coordinates!");
+    ERRMSG("Cannot read the %s / %s coordinates!", xname, yname);
   const int vu = nc_lookup(&r, NAMES("u", "U"));
   if (vu < 0)
     ERRMSG("Variable 'u' or 'U' not found, cannot determine vertical dimension!");
@@ -1545,14 +1591,20 @@ static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
         f3[f][i][j][k] = k + 1 < EP ? f3[f][i][j][k + 1] : 0.f;
   }
 
+  if (met->coord_type == 0) {
+    met_polar_winds(met);
+    met_periodic(met);
+  }
+
   /* Fields the reference derives in its preprocessing.  The boundary-layer pressure enters module_diff_turb
    * only through weights that multiply TURB_DX_PBL / TURB_DZ_PBL against TURB_DX_TROP / TURB_DZ_TROP: with
    * equal values (the defaults) and none of the other consumers active any finite value below the
    * tropopause gives the reference's result, and surface pressure - 100 hPa is used.  Everything else that
    * would need a derived field is refused. */
   if (!have_pbl) {
-    if (ctl->turb_dx_pbl != ctl->turb_dx_trop || ctl->turb_dz_pbl != ctl->turb_dz_trop || ctl->conv_mix_pbl
-        || ctl->turb_pbl_scheme != 0 || ctl->bound_pbl || ctl->qnt_pbl >= 0)
+    if ((ctl->diffusion && (ctl->turb_dx_pbl != ctl->turb_dx_trop || ctl->turb_dz_pbl != ctl->turb_dz_trop
+                            || ctl->turb_pbl_scheme != 0))
+        || ctl->conv_mix_pbl || ctl->bound_pbl || ctl->qnt_pbl >= 0)
       ERRMSG("This configuration uses the boundary-layer pressure, which the reference derives in its meteo "
              "preprocessing (not provided): supply it in the file (MET_PBL 0, variable blp) or use MET_TYPE 1 files!");
     EACH_COLUMN(met, i, j)

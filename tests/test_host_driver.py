@@ -252,6 +252,45 @@ def test_trac_runs_the_reference_coord_test_command_line_on_its_netcdf_files(tmp
                 name, len(bad) + abs(len(gl) - len(rl)), len(rl), gl[bad[0]] if bad else None, rl[bad[0]] if bad else None))
 
 
+@pytest.mark.gpu
+def test_trac_runs_the_reference_dd_test_on_global_netcdf_meteo_files(tmp_path):
+    """tests/dd_test of the reference through the drop-in driver with MET_TYPE 0 files on a global longitude /
+    latitude grid: the wind tool's solid-body rotation written as netCDF (tests/c/wind_met.c -> mptrac_write_met),
+    read back by the host layer's reader -- latitudes from north to south, polar-wind fix, periodic longitude column
+    (read_met_polar_winds, read_met_periodic) --, six hours of midpoint advection of the 144 golden parcels: the seven
+    hourly particle files carry the golden rows (time, altitude, longitude, latitude, idx, zeta, m), every printed digit."""
+    tmp = str(tmp_path)
+    _, trac = build.build_host()
+    exe = hf.compile_c_test("wind_met")
+    metbase = os.path.join(tmp, "wind")
+    r = subprocess.run([exe, metbase, repr(T0), "8"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RESULT done" in r.stdout, r.stdout[-2000:]
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_dd_test")
+    gold = {h: [ln.strip() for ln in open(os.path.join(gold_dir, "atm_2022_06_02_%02d_00_00.tab" % h)) if ln.strip()]
+            for h in range(7)}
+    open(os.path.join(tmp, "init.tab"), "w").write("\n".join(gold[0]) + "\n")
+    # tests/dd_test/data.ref/config.ctl (the two domain-decomposition quantities under neutral names)
+    keys = {"NQ": 5, "QNT_NAME[0]": "idx", "QNT_UNIT[0]": "-", "QNT_NAME[1]": "zeta", "QNT_NAME[2]": "m",
+            "QNT_NAME[3]": "sub_a", "QNT_UNIT[3]": "-", "QNT_NAME[4]": "sub_b", "QNT_UNIT[4]": "-",
+            "METBASE": metbase, "MET_TYPE": 0, "MET_DT_OUT": 0, "ADVECT": 2, "ADVECT_VERT_COORD": 0,
+            "TURB_DX_TROP": 0, "TURB_DX_STRAT": 0, "TURB_DZ_TROP": 0, "TURB_DZ_STRAT": 0.0, "TURB_MESOX": 0.0,
+            "TURB_MESOZ": 0.0, "DIRECTION": 1, "TDEC_TROP": 259200, "TDEC_STRAT": 259200, "DT_MOD": 600, "DT_MET": 3600,
+            "T_START": repr(T0), "T_STOP": repr(T0 + 6 * 3600.0), "ATM_DT_OUT": 3600, "ATM_BASENAME": "atm"}
+    hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
+    open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
+    r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "init.tab"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    for h in range(7):
+        rows = [ln.strip() for ln in open(os.path.join(tmp, "atm_2022_06_02_%02d_00_00.tab" % h))
+                if ln.strip() and not ln.startswith("#")]
+        # (the last two columns are the subdomain bookkeeping of the reference's domain decomposition, which moves
+        # parcels between ranks: not part of this build)
+        bad = [i for i in range(144) if rows[i].split()[:7] != gold[h][i].split()[:7]]
+        assert len(rows) == 144 and not bad, (h, len(bad), rows[bad[0]], gold[h][bad[0]])
+
+
 def _atm_test_run(tmp, extra_args=(), case="ref_atm_test", atm_file="atm_2000_01_01_00_00_00.tab",
                   quantities=("aoa", "m", "vmr"), t0=0.0):
     """`trac` on a golden particle file of the reference (default: tests/atm_test, 10000 parcels with aoa, m, vmr); the
