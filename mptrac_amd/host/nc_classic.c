@@ -302,6 +302,14 @@ int ncc_find_var(const ncc_file *nc, const char *name) {
   return -1;
 }
 
+int ncc_num_vars(const ncc_file *nc) {
+  return nc->nvar;
+}
+
+const char *ncc_var_name(const ncc_file *nc, int var) {
+  return nc->var[var].name;
+}
+
 int ncc_var_ndims(const ncc_file *nc, int var) {
   return nc->var[var].ndims;
 }

@@ -13,6 +13,8 @@ const char *ncc_error(const ncc_file *nc);
 /* index of a dimension / variable, -1 if absent; *len = current length (record dimension: number of records) */
 int ncc_find_dim(const ncc_file *nc, const char *name, long long *len);
 int ncc_find_var(const ncc_file *nc, const char *name);
+int ncc_num_vars(const ncc_file *nc);
+const char *ncc_var_name(const ncc_file *nc, int var);
 int ncc_var_ndims(const ncc_file *nc, int var);
 long long ncc_var_dim(const ncc_file *nc, int var, int d, const char **name);
 int ncc_var_is_packed(const ncc_file *nc, int var);                /* stored as short / byte */

@@ -9,8 +9,9 @@
  * contiguous, chunked with a version-1 B-tree (layout version 3) or as a single chunk / implicit / fixed-array
  * index (layout version 4) -- and attributes in the object header or in a fractal heap.  Only the root group is
  * read (netCDF classic data model).  What is not read is refused with a message, never guessed: variable-length
- * and compound types (the DIMENSION_LIST attributes of netCDF-4 are skipped: axis lengths come from each
- * variable's dataspace, and an axis gets the name of the dimension scale of that length), extensible-array and
+ * and compound types (except the DIMENSION_LIST attributes of netCDF-4, which name the dimension of every axis
+ * through references in a global heap; files without them get axis names from the dimension scale of the
+ * axis' length), extensible-array and
  * version-2 B-tree chunk indices, external storage, other filters.
  *
  * A variable's values are produced as the classic format stores them (big-endian, row-major), so everything
@@ -603,6 +604,8 @@ static int parse_attribute(ncc_file *nc, att_list *A, const unsigned char *p, si
   int type = nc_type_of(&t);
   if (t.cls == 3)
     type = T_CHAR;
+  if (t.cls == 9 && name_size >= 14 && strncmp(name, "DIMENSION_LIST", 14) == 0)
+    type = T_BYTE;   /* kept as stored: one (length, global heap address, index) entry per axis -- axis_scale() */
   if (!type)
     return 1;   /* variable-length, reference, compound ...: not an attribute the classic model has */
   if (A->n == A->cap) {
@@ -622,8 +625,8 @@ static int parse_attribute(ncc_file *nc, att_list *A, const unsigned char *p, si
   memcpy(a->raw, p + at, (size_t) bytes);
   memset(a->raw + bytes, 0, 8);
   a->type = type;
-  a->n = type == T_CHAR ? (size_t) bytes : (size_t) count;
-  if (type != T_CHAR)
+  a->n = (type == T_CHAR || t.cls == 9) ? (size_t) bytes : (size_t) count;
+  if (type != T_CHAR && t.cls != 9)
     to_big_endian(a->raw, (size_t) count, t.size, t.little_endian);
   A->n++;
   return 1;
@@ -665,6 +668,48 @@ static const ncc_att *find_att(const att_list *A, const char *name) {
     if (strcmp(A->a[i].name, name) == 0)
       return &A->a[i];
   return NULL;
+}
+
+/* Object header address of the dimension scale attached to axis k of a variable: entry k of its DIMENSION_LIST
+ * attribute names an object of a global heap collection that holds the references.  UNDEF: none / not readable. */
+static uint64_t axis_scale(ncc_file *nc, const att_list *A, int k) {
+  const int so = nc->h5->so, sl = nc->h5->sl;
+  const ncc_att *a = find_att(A, "DIMENSION_LIST");
+  const size_t entry = 8 + (size_t) so;
+  if (!a || a->type != T_BYTE || (size_t) (k + 1) * entry > a->n)
+    return UNDEF;
+  const unsigned char *e = a->raw + (size_t) k * entry;
+  const uint64_t count = le(e, 4), heap = la(e + 4, so), index = le(e + 4 + so, 4);
+  if (count < 1 || heap == UNDEF || index == 0)
+    return UNDEF;
+  unsigned char head[32];
+  if (!rd(nc, heap, head, 8 + (size_t) sl) || memcmp(head, "GCOL", 4) != 0) {
+    nc->err[0] = '\0';
+    return UNDEF;
+  }
+  const uint64_t size = le(head + 8, sl);
+  if (size < 16 || size > (1u << 26))
+    return UNDEF;
+  unsigned char *col = malloc((size_t) size + 16);
+  uint64_t found = UNDEF;
+  if (col && rd(nc, heap, col, (size_t) size)) {
+    size_t at = 8 + (size_t) sl;
+    while (at + 8 + (size_t) sl <= size) {
+      const uint64_t id = le(col + at, 2), osize = le(col + at + 8, sl);
+      const size_t data = at + 8 + (size_t) sl;
+      if (id == 0 || osize > size - data)
+        break;   /* object 0 is the free space at the end */
+      if (id == index) {
+        if (osize >= (uint64_t) so)
+          found = la(col + data, so);
+        break;
+      }
+      at = data + (((size_t) osize + 7) & ~(size_t) 7);
+    }
+  } else
+    nc->err[0] = '\0';
+  free(col);
+  return found;
 }
 
 /* ---- datasets --------------------------------------------------------------------------------------------- */
@@ -1176,7 +1221,7 @@ int h5_load(ncc_file *nc) {
     struct h5_dataset d;
     h5_type t;
     att_list A;
-    int is_dataset, is_scale, no_variable;
+    int is_dataset, is_scale, no_variable, dim;
   } obj;
   obj *o = ok ? calloc((size_t) (L.n ? L.n : 1), sizeof(obj)) : NULL;
   if (ok && !o)
@@ -1192,7 +1237,8 @@ int h5_load(ncc_file *nc) {
     if (cls && cls->type == T_CHAR && strncmp((const char *) cls->raw, "DIMENSION_SCALE", 15) == 0 && o[i].d.rank == 1) {
       o[i].is_scale = 1;
       o[i].no_variable = nm && nm->type == T_CHAR && strncmp((const char *) nm->raw, "This is a netCDF dimension but not a netCDF variable", 52) == 0;
-      if (find_or_add_dim(nc, L.name[i], o[i].d.dims[0], &dim_cap) < 0)
+      o[i].dim = find_or_add_dim(nc, L.name[i], o[i].d.dims[0], &dim_cap);
+      if (o[i].dim < 0)
         ok = h5fail(nc, "out of memory");
     }
   }
@@ -1213,10 +1259,18 @@ int h5_load(ncc_file *nc) {
     v->nelem = 1;
     for (int k = 0; ok && k < v->ndims; k++) {
       v->nelem *= (long long) o[i].d.dims[k];
-      /* the axis is named after the dimension of that length: its own scale first (coordinate variables) */
+      /* the axis belongs to the dimension scale its DIMENSION_LIST entry refers to; a coordinate variable is its
+       * own scale; without the list (files not written by netCDF-4) the dimension of that length gives the name */
       int id = -1;
       if (o[i].is_scale && v->ndims == 1)
-        id = ncc_find_dim(nc, L.name[i], NULL);
+        id = o[i].dim;
+      if (id < 0) {
+        const uint64_t scale = axis_scale(nc, &o[i].A, k);
+        for (int j = 0; scale != UNDEF && id < 0 && j < L.n; j++)
+          if (L.addr[j] == scale && o[j].is_scale && o[j].d.dims[0] == o[i].d.dims[k])
+            id = o[j].dim;
+      }
+#ifndef NC_HDF5_NO_LENGTH_FALLBACK   /* (defined by a test that wants to see the DIMENSION_LIST path alone) */
       for (int j = 0; id < 0 && j < nc->ndim; j++)
         if (nc->dim_len[j] == (long long) o[i].d.dims[k]) {
           int taken = 0;   /* (an axis of equal length earlier in this variable took that name) */
@@ -1225,6 +1279,7 @@ int h5_load(ncc_file *nc) {
           if (!taken)
             id = j;
         }
+#endif
       if (id < 0) {
         char anon[64];
         snprintf(anon, sizeof(anon), "phony_dim_%d", nc->ndim);

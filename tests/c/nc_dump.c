@@ -1,7 +1,7 @@
 /* Test program (tests/test_host_logic.py): header and values of a netCDF file as the host layer's reader sees it
  * (classic formats and netCDF-4 / HDF5).
  *   nc_dump <file> [variable ...]
- * prints "dim <name> <length>", "var <name> <ndims> <dim names...> <nelem>", "att <var|-> <name> <first value>", and for
+ * prints "header <name> <axis>=<length> ..." for every variable, "dim <name> <length>", "var <name> <ndims> <dim names...> <nelem>", "att <var|-> <name> <first value>", and for
  * each named variable "values <name>" followed by all its values (17 significant digits). */
 #include "nc_classic.h"
 
@@ -17,6 +17,15 @@ int main(int argc, char *argv[]) {
   if (!nc) {
     printf("ERROR %s\n", why);
     return 1;
+  }
+  for (int v = 0; v < ncc_num_vars(nc); v++) {   /* every variable with its axes */
+    printf("header %s", ncc_var_name(nc, v));
+    for (int d = 0; d < ncc_var_ndims(nc, v); d++) {
+      const char *name;
+      const long long len = ncc_var_dim(nc, v, d, &name);
+      printf(" %s=%lld", name, len);
+    }
+    printf("\n");
   }
   for (int a = 2; a < argc; a++) {
     const int var = ncc_find_var(nc, argv[a]);

@@ -514,3 +514,22 @@ def test_hdf5_reader_on_old_style_chunked_compressed_files(tmp_path):
     assert np.array_equal(vals["holes"], want.ravel())
     assert "att q scale_factor 0.25" in res.stdout and "att q add_offset -3" in res.stdout
     assert "var t 3" in res.stdout
+
+
+def test_netcdf4_axis_names_come_from_the_dimension_lists(tmp_path):
+    """The HDF5 reader names a variable's axes through its DIMENSION_LIST attribute (variable-length lists of
+    object references in a global heap), as netCDF-4 does; naming by length is only the fall-back for files
+    without the lists.  Built without the fall-back, the reader still names every axis of the reference's own
+    netCDF-4 files (both superblock versions)."""
+    import subprocess
+    from mptrac_amd import build
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "nc_dump_lists")
+    src = [os.path.join(here, "c", "nc_dump.c")] + [os.path.join(build.HOST_DIR, f) for f in ("nc_classic.c", "nc_hdf5.c")]
+    subprocess.check_call(["gcc", "-O1", "-std=gnu99", "-DNC_HDF5_NO_LENGTH_FALLBACK", "-I", build.HOST_DIR, "-o", exe, *src,
+                           "-lz", "-lm"])
+    want = {os.path.join(here, "golden", "ref_data", "cams_H2O2.nc"): "header H2O2 time=12 press=25 lat=241",
+            os.path.join(here, "golden", "ref_dd_test", "init", "data.3.nc"): "header m time=1 NPARTS=16"}
+    for path, line in want.items():
+        out = subprocess.run([exe, path], capture_output=True, text=True, timeout=60).stdout
+        assert line in out.splitlines() and "phony_dim" not in out, out
