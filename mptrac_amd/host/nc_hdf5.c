@@ -243,7 +243,7 @@ static int heap_direct(ncc_file *nc, frheap *h, uint64_t addr, uint64_t size) {
     ok = h5fail(nc, "fractal heap direct block without signature");
   if (ok) {
     const size_t head = 5 + (size_t) h->so + (size_t) ((h->max_bits + 7) / 8) + (h->has_checksum ? 4 : 0);
-    ok = h->visit(nc, h->user, blk + head, (size_t) size - head);
+    ok = head < size ? h->visit(nc, h->user, blk + head, (size_t) size - head) : h5fail(nc, "implausible fractal heap block");
   }
   free(blk);
   return ok;
@@ -332,7 +332,8 @@ static int walk_heap(ncc_file *nc, uint64_t addr, heap_visit visit, void *user) 
   h.user = user;
   if (h.filtered)
     return h5fail(nc, "filtered fractal heaps are not read");
-  if (h.width < 1 || h.width > 1024 || h.start_size < 16 || h.start_size > (1u << 24))
+  if (h.width < 1 || h.width > 1024 || h.start_size < 16 || h.start_size > (1u << 24) || h.max_bits < 8 || h.max_bits > 64
+      || h.max_direct < h.start_size || h.max_direct > ((uint64_t) 1 << 32) || cur_rows > 64)
     return h5fail(nc, "implausible fractal heap");
   if (cur_rows == 0)
     return heap_direct(nc, &h, root, h.start_size);

@@ -3,7 +3,12 @@ root group as a symbol table, chunked datasets indexed by a version-1 B-tree, fi
 layout netCDF-4 files written by HDF5 1.8-era libraries have, e.g. compressed reanalysis files.  Written from the
 HDF5 File Format Specification for the tests of mptrac_amd/host/nc_hdf5.c: the image has no HDF5 library, and
 the reference's own netCDF-4 files are all contiguous and new-style.  (A file made here is laid out by this
-module's reading of the specification, not by the HDF5 library.)"""
+module's reading of the specification, not by the HDF5 library.)
+
+Writer(style="new") writes the other common combination instead -- what netCDF-4 produces with the "1.8" format
+bounds: superblock version 2, version-2 object headers, the root group as compact link messages, version-2
+dataspace / filter pipeline / version-3 attribute messages, and still the version-3 layout with a version-1 chunk
+B-tree.  (Checksums are written as zero: the reader under test does not verify them.)"""
 import struct
 import zlib
 
@@ -62,8 +67,31 @@ def _shuffle(raw, itemsize):
     return a.T.copy().tobytes()
 
 
+def _msg2(mtype, body):
+    return struct.pack("<BHB", mtype, len(body), 0) + body
+
+
+def _dataspace2(shape):
+    return struct.pack("<BBBB", 2, len(shape), 0, 1) + b"".join(struct.pack("<Q", n) for n in shape)
+
+
+def _attribute3(name, value):
+    nm = name.encode() + b"\0"
+    ds = struct.pack("<BBBB", 2, 0, 0, 0)
+    if isinstance(value, (str, bytes)):
+        raw = (value.encode() if isinstance(value, str) else value) + b"\0"
+        dt = struct.pack("<BBBBI", 0x13, 0, 0, 0, len(raw))
+    else:
+        value = np.asarray(value)
+        raw = value.tobytes()
+        dt = _datatype(value.dtype)
+    return struct.pack("<BBHHHB", 3, 0, len(nm), len(dt), len(ds), 0) + nm + dt + ds + raw
+
+
 class Writer:
-    def __init__(self):
+    def __init__(self, style="old"):
+        assert style in ("old", "new")
+        self.new = style == "new"
         self.buf = bytearray(96)      # the superblock is written last
         self.entries = []             # (name, object header address)
 
@@ -76,27 +104,36 @@ class Writer:
 
     def _object_header(self, messages):
         body = b"".join(messages)
+        if self.new:   # "OHDR", version 2, flags (size of chunk 0 in 4 bytes), size, messages, checksum
+            return self._append(b"OHDR" + struct.pack("<BBI", 2, 0x02, len(body)) + body + b"\0\0\0\0")
         return self._append(struct.pack("<BxHII4x", 1, len(messages), 1, len(body)) + body)
 
     def dataset(self, name, array, chunks=None, shuffle=False, deflate=None, attrs=(), fill=None, skip_chunks=()):
         """array: numpy array (its dtype and byte order are stored as they are); chunks: chunk shape or None for
         contiguous storage; skip_chunks: chunk indices (tuples) that are not written (they read as `fill`)"""
         array = np.ascontiguousarray(array)
-        msgs = [_msg(0x01, _dataspace(array.shape)), _msg(0x03, _datatype(array.dtype))]
+        _msg = _msg2 if self.new else globals()["_msg"]
+        msgs = [_msg(0x01, (_dataspace2 if self.new else _dataspace)(array.shape)), _msg(0x03, _datatype(array.dtype))]
         if fill is not None:
             fv = np.asarray(fill, dtype=array.dtype).tobytes()
-            msgs.append(_msg(0x05, struct.pack("<BBBBI", 2, 2, 0, 1, len(fv)) + fv))
+            if self.new:   # version 3: flags (allocation time 2, write time 0, defined), size, value
+                msgs.append(_msg(0x05, struct.pack("<BBI", 3, 0x02 | 0x20, len(fv)) + fv))
+            else:
+                msgs.append(_msg(0x05, struct.pack("<BBBBI", 2, 2, 0, 1, len(fv)) + fv))
         if chunks is None:
             at = self._append(array.tobytes())
             msgs.append(_msg(0x08, struct.pack("<BBQQ", 3, 1, at, array.nbytes)))
         else:
             filters = []
             if shuffle:
-                filters.append(struct.pack("<HHHHI4x", 2, 0, 0, 1, array.itemsize))
+                filters.append(struct.pack("<HHHI", 2, 0, 1, array.itemsize) if self.new
+                               else struct.pack("<HHHHI4x", 2, 0, 0, 1, array.itemsize))
             if deflate is not None:
-                filters.append(struct.pack("<HHHHI4x", 1, 0, 0, 1, deflate))
+                filters.append(struct.pack("<HHHI", 1, 0, 1, deflate) if self.new
+                               else struct.pack("<HHHHI4x", 1, 0, 0, 1, deflate))
             if filters:
-                msgs.append(_msg(0x0B, struct.pack("<BB6x", 1, len(filters)) + b"".join(filters)))
+                msgs.append(_msg(0x0B, (struct.pack("<BB", 2, len(filters)) if self.new else struct.pack("<BB6x", 1, len(filters)))
+                                 + b"".join(filters)))
             rank = array.ndim
             keys = []
             counts = [-(-array.shape[k] // chunks[k]) for k in range(rank)]
@@ -124,10 +161,20 @@ class Writer:
             msgs.append(_msg(0x08, struct.pack("<BBBQ", 3, 2, rank + 1, tree)
                              + b"".join(struct.pack("<I", c) for c in list(chunks) + [array.itemsize])))
         for aname, value in attrs:
-            msgs.append(_msg(0x0C, _attribute(aname, value)))
+            msgs.append(_msg(0x0C, (_attribute3 if self.new else _attribute)(aname, value)))
         self.entries.append((name, self._object_header(msgs)))
 
     def close(self, path):
+        if self.new:
+            links = [_msg2(0x06, struct.pack("<BBB", 1, 0, len(name.encode())) + name.encode() + struct.pack("<Q", addr))
+                     for name, addr in self.entries]
+            root = self._object_header(links)
+            eof = len(self.buf)
+            sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBB", 2, 8, 8, 0) + struct.pack("<QQQQ", 0, UNDEF, eof, root) + b"\0\0\0\0"
+            self.buf[:len(sb)] = sb
+            with open(path, "wb") as f:
+                f.write(self.buf)
+            return
         # local heap: the empty name of the root at offset 0, then the link names (sorted, as the B-tree keys need)
         self.entries.sort()
         heap = bytearray(b"\0" * 8)

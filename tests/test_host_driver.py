@@ -187,13 +187,13 @@ def test_trac_writes_the_reference_coord_test_files_byte_for_byte(tmp_path):
                 name, len(bad) + abs(len(gl) - len(rl)), len(rl), gl[bad[0]] if bad else None, rl[bad[0]] if bad else None))
 
 
-def _as_netcdf4(src, dst):
+def _as_netcdf4(src, dst, style="old"):
     """the variables of a classic netCDF file in an HDF5 file of the old on-disk style (tests/h5write.py): the
     dimensions as dimension scales, everything with more than one axis chunked, shuffled and deflated"""
     from scipy.io import netcdf_file
     import h5write
     f = netcdf_file(src, "r", mmap=False)
-    w = h5write.Writer()
+    w = h5write.Writer(style)
     for name, var in f.variables.items():
         if not var.shape:      # (a scalar variable: nothing the reader of the meteo files needs)
             continue
@@ -211,24 +211,24 @@ def _as_netcdf4(src, dst):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("container", ["classic", "netcdf4"])
+@pytest.mark.parametrize("container", ["classic", "netcdf4", "netcdf4_new_style"])
 def test_trac_runs_the_reference_coord_test_command_line_on_its_netcdf_files(tmp_path, container):
     """tests/coord_test/run.sh of the reference as it stands: control file, command line (MET_TYPE left at its
     default 0 = netCDF) and the three classic-netCDF meteo files -- read by the host layer's own reader, no
     conversion step -- give the thirteen golden particle files byte for byte.  `netcdf4`: the same variables
-    repacked into HDF5 files (chunked, shuffled, deflated; old on-disk style, tests/h5write.py) and read by the host
-    layer's HDF5 reader: the same bytes come out."""
+    repacked into HDF5 files (chunked, shuffled, deflated; old and new on-disk style, tests/h5write.py) and read by
+    the host layer's HDF5 reader: the same bytes come out."""
     import shutil
     import ref_coord as R
     tmp = str(tmp_path)
     _, trac = build.build_host()
     shutil.copy(os.path.join(R.HERE, R.OUTPUTS[0]), os.path.join(tmp, "atm_split.tab"))
     metbase = os.path.join(R.HERE, "era5_utm32")
-    if container == "netcdf4":
+    if container != "classic":
         metbase = os.path.join(tmp, "era5_utm32")
         for h in range(3):
             name = "era5_utm32_2025_05_01_%02d.nc" % h
-            _as_netcdf4(os.path.join(R.HERE, name), os.path.join(tmp, name))
+            _as_netcdf4(os.path.join(R.HERE, name), os.path.join(tmp, name), "new" if container.endswith("new_style") else "old")
             assert open(os.path.join(tmp, name), "rb").read(4) == b"\x89HDF"
     keys = {"NQ": 4, "QNT_NAME[0]": "t", "QNT_NAME[1]": "u", "QNT_NAME[2]": "v", "QNT_NAME[3]": "w",
             "METBASE": metbase, "TRACER_CHEM": 0, "DIFFUSION": 1, "DT_MET": 3600.0,

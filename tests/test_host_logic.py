@@ -478,12 +478,14 @@ def test_trac_command_line_conventions_of_the_reference_cli_test():
             assert r.returncode == 0 and "Usage:" in r.stdout
 
 
-def test_hdf5_reader_on_old_style_chunked_compressed_files(tmp_path):
-    """nc_hdf5.c on the on-disk style of HDF5-1.8-era netCDF-4 files, which none of the reference's files has:
-    version-0 superblock, version-1 object headers, symbol-table group, chunked datasets with a version-1 B-tree,
-    shuffle + deflate, edge chunks that overhang the array, a chunk that was never written (fill value), packed
-    shorts with scale / offset attributes, big-endian storage.  The file is made by tests/h5write.py from the format
-    specification (no HDF5 library in the image)."""
+@pytest.mark.parametrize("style", ["old", "new"])
+def test_hdf5_reader_on_chunked_compressed_files(tmp_path, style):
+    """nc_hdf5.c on chunked, filtered data, which none of the reference's files has -- in the two on-disk styles
+    netCDF-4 files come in: `old` = version-0 superblock, version-1 object headers, symbol-table group, version-1
+    filter pipeline; `new` = version-2 superblock and object headers, link messages, version-2 dataspace / pipeline,
+    version-3 attributes; both with version-1 chunk B-trees.  Shuffle + deflate, edge chunks that overhang the
+    array, a chunk that was never written (fill value), packed shorts with scale / offset attributes, big-endian
+    storage.  The files are made by tests/h5write.py from the format specification (no HDF5 library in the image)."""
     import subprocess
     import h5write
     from hostfiles import compile_c_test
@@ -493,7 +495,7 @@ def test_hdf5_reader_on_old_style_chunked_compressed_files(tmp_path):
     big = rng.normal(0.0, 1.0, (4, 6)).astype(">f8")
     lev = np.array([1000.0, 850.0, 500.0, 250.0, 100.0])
     holes = np.arange(6 * 8, dtype="<f4").reshape(6, 8)
-    w = h5write.Writer()
+    w = h5write.Writer(style)
     w.dataset("t", t3, chunks=(2, 5, 8), shuffle=True, deflate=4)
     w.dataset("q", packed, chunks=(4, 4), deflate=1, attrs=(("scale_factor", np.float64(0.25)), ("add_offset", np.float64(-3.0))))
     w.dataset("b", big)

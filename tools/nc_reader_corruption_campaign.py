@@ -24,8 +24,16 @@ def sample_files(tmp="/tmp"):
               attrs=(("scale_factor", np.float64(0.25)),))
     w.dataset("lev", np.arange(5.0))
     w.close(os.path.join(tmp, "old_style.nc"))
+    w = h5write.Writer("new")
+    w.dataset("t", rng.normal(250.0, 20.0, (5, 13, 17)).astype("<f4"), chunks=(2, 5, 8), shuffle=True, deflate=4)
+    w.dataset("q", rng.integers(-30000, 30000, (7, 10)).astype("<i2"), chunks=(4, 4), deflate=1,
+              attrs=(("scale_factor", np.float64(0.25)),))
+    w.dataset("lev", np.arange(5.0))
+    w.close(os.path.join(tmp, "new_style.nc"))
     g = os.path.join(os.path.dirname(HERE), "tests", "golden")
     return {os.path.join(tmp, "old_style.nc"): ["t", "q", "lev"],
+            os.path.join(tmp, "new_style.nc"): ["t", "q", "lev"],
+            "/root/reference/data/tuv_photolysis_rates.nc": ["press", "o2"],
             os.path.join(g, "ref_dd_test", "init", "data.0.nc"): ["LON", "LAT", "idx", "time"],
             os.path.join(g, "ref_data", "cams_H2O2.nc"): ["H2O2", "press"],
             os.path.join(g, "ref_data", "gozcards_HNO3.nc"): ["HNO3", "press"],
@@ -37,9 +45,11 @@ def main():
     trials = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1", UBSAN_OPTIONS="halt_on_error=1")
     bad = total = 0
-    for seed in (7, 21, 99):
+    for seed in (7, 21, 99, 1234, 4321):
         random.seed(seed)
         for path, names in sample_files().items():
+            if not os.path.exists(path):      # (the reference's dense-group file: this container only)
+                continue
             data = bytearray(open(path, "rb").read())
             hdr = min(len(data), 16000)
             for trial in range(trials):
