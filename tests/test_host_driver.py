@@ -414,6 +414,33 @@ def test_trac_nat_and_sts_temperatures_from_the_hno3_climatology(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["atm_test", "dt_test"])
+def test_atm2grid_commands_of_the_reference_tests(tmp_path, case):
+    """The `atm2grid` tool of this build (host/atm2grid.c: binning on the device, write_grid on the host) with the
+    command lines of the reference's tests/atm_test/run.sh:86-87 and tests/dt_test/run.sh:47-48 on their golden
+    particle files: the golden gridded files, byte for byte."""
+    import shutil
+    from mptrac_amd.build import ATM2GRID_BIN
+    build.build_host()
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if case == "atm_test":
+        atm, grid, stamp = os.path.join(gold, "ref_atm_test", "atm_2000_01_01_00_00_00.tab"), "grid_2000_01_01_00_00_00.tab", "ref_atm_test"
+        args = ["-", None, "GRID_BASENAME", None, "GRID_NX", "72", "GRID_NY", "36", "NQ", "3", "QNT_NAME[0]", "aoa",
+                "QNT_NAME[1]", "m", "QNT_NAME[2]", "vmr", "MOLMASS", "64.066"]
+    else:
+        atm, grid, stamp = os.path.join(gold, "ref_dt_test", "atm_pl_2011_06_05_00_00_00.tab"), "grid_2011_06_05_00_00_00.tab", "ref_dt_test"
+        hf.write_ctl(str(tmp_path / "trac.ctl"), {"NQ": 4, "QNT_NAME[0]": "t", "QNT_NAME[1]": "u", "QNT_NAME[2]": "v",
+                                                  "QNT_NAME[3]": "w", "DT_MOD": 10.0, "DIFFUSION": 1})
+        args = [str(tmp_path / "trac.ctl"), None, "GRID_BASENAME", None, "GRID_NX", "72", "GRID_NY", "36", "MOLMASS", "64.066"]
+    local = str(tmp_path / os.path.basename(atm))
+    shutil.copy(atm, local)
+    args[1], args[3] = local, str(tmp_path / "grid")
+    r = subprocess.run([ATM2GRID_BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    _same_text(str(tmp_path / grid), os.path.join(gold, stamp, grid))
+
+
+@pytest.mark.gpu
 def test_trac_grid_implicit_volume_mixing_ratio(tmp_path):
     """MOLMASS set: column 8 of the grid file = MA / MOLMASS * column density / (rho(p, T) * dz), T interpolated
     to the cell centre from the two snapshots (mptrac.c:13885-13900)."""

@@ -535,3 +535,15 @@ def test_netcdf4_axis_names_come_from_the_dimension_lists(tmp_path):
     for path, line in want.items():
         out = subprocess.run([exe, path], capture_output=True, text=True, timeout=60).stdout
         assert line in out.splitlines() and "phony_dim" not in out, out
+
+
+def test_atm2grid_command_line_conventions():
+    """atm2grid follows the reference's tool conventions (tests/cli_test) like the driver."""
+    import subprocess
+    from mptrac_amd import build
+    build.build_host()
+    r = subprocess.run([build.ATM2GRID_BIN], capture_output=True, text=True)
+    assert r.returncode != 0 and "Missing or invalid command-line arguments." in r.stdout + r.stderr
+    for flag in ("-h", "--help"):
+        r = subprocess.run([build.ATM2GRID_BIN, flag, "extra-arg"], capture_output=True, text=True)
+        assert r.returncode == 0 and "Usage:" in r.stdout
