@@ -72,6 +72,8 @@ HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(LIBDIR, "libmptrac.so")
 TRAC_BIN = os.path.join(LIBDIR, "trac")
 ATM2GRID_BIN = os.path.join(LIBDIR, "atm2grid")
+ATM_CONV_BIN = os.path.join(LIBDIR, "atm_conv")
+MET_CONV_BIN = os.path.join(LIBDIR, "met_conv")
 # small test extents by default; production builds pass the reference's -DNP=... -DEX=... values
 HOST_DIMS = {"NP": 200000, "NQ": 15, "EX": 364, "EY": 186, "EP": 64}
 
@@ -81,7 +83,7 @@ def build_host(force=False, verbose=False, dims=None):
     and the trac driver.  Plain gcc; links against libmptrac_hip.so."""
     os.makedirs(LIBDIR, exist_ok=True)
     dims = dict(HOST_DIMS, **(dims or {}))
-    src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "mptrac.h", "trac.c", "atm2grid.c", "ctlfile.c", "nc_classic.c",
+    src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "mptrac.h", "trac.c", "atm2grid.c", "atm_conv.c", "met_conv.c", "ctlfile.c", "nc_classic.c",
                                                "nc_classic.h", "nc_internal.h", "nc_hdf5.c", "rendezvous.c", "output.c")]
     lib_src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "ctlfile.c", "nc_classic.c", "nc_hdf5.c", "rendezvous.c", "output.c")]
     if not (force or _stale(HOST_LIB, src) or _stale(TRAC_BIN, src)):
@@ -93,7 +95,9 @@ def build_host(force=False, verbose=False, dims=None):
     rpath = ["-L" + LIBDIR, "-lmptrac_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread", "-lz"]
     cmds = [common + ["-shared", "-o", HOST_LIB] + lib_src + rpath,
             common + ["-o", TRAC_BIN, os.path.join(HOST_DIR, "trac.c")] + lib_src + rpath,
-            common + ["-o", ATM2GRID_BIN, os.path.join(HOST_DIR, "atm2grid.c")] + lib_src + rpath]
+            common + ["-o", ATM2GRID_BIN, os.path.join(HOST_DIR, "atm2grid.c")] + lib_src + rpath,
+            common + ["-o", ATM_CONV_BIN, os.path.join(HOST_DIR, "atm_conv.c")] + lib_src + rpath,
+            common + ["-o", MET_CONV_BIN, os.path.join(HOST_DIR, "met_conv.c")] + lib_src + rpath]
     for cmd in cmds:
         if verbose:
             print(" ".join(cmd))

@@ -547,3 +547,16 @@ def test_atm2grid_command_line_conventions():
     for flag in ("-h", "--help"):
         r = subprocess.run([build.ATM2GRID_BIN, flag, "extra-arg"], capture_output=True, text=True)
         assert r.returncode == 0 and "Usage:" in r.stdout
+
+
+def test_conversion_tools_command_line_conventions():
+    """atm_conv and met_conv follow the reference's tool conventions (tests/cli_test)."""
+    import subprocess
+    from mptrac_amd import build
+    build.build_host()
+    for exe in (build.ATM_CONV_BIN, build.MET_CONV_BIN):
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode != 0 and "Missing or invalid command-line arguments." in r.stdout + r.stderr
+        for flag in ("-h", "--help"):
+            r = subprocess.run([exe, flag], capture_output=True, text=True)
+            assert r.returncode == 0 and "Usage:" in r.stdout
