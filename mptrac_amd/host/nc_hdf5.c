@@ -90,10 +90,12 @@ typedef struct {
 
 static int add_msg(ncc_file *nc, h5_msgs *ms, int type, const unsigned char *data, size_t size) {
   if (ms->n == ms->cap) {
-    ms->cap = ms->cap ? 2 * ms->cap : 32;
-    ms->m = realloc(ms->m, (size_t) ms->cap * sizeof(h5_msg));
-    if (!ms->m)
+    const int want = ms->cap ? 2 * ms->cap : 32;
+    h5_msg *grown = realloc(ms->m, (size_t) want * sizeof(h5_msg));
+    if (!grown)
       return h5fail(nc, "out of memory");
+    ms->m = grown;
+    ms->cap = want;
   }
   h5_msg *m = &ms->m[ms->n++];
   m->type = type;
@@ -350,11 +352,16 @@ typedef struct {
 
 static int add_link(ncc_file *nc, h5_links *L, const char *name, size_t len, uint64_t addr) {
   if (L->n == L->cap) {
-    L->cap = L->cap ? 2 * L->cap : 64;
-    L->name = realloc(L->name, (size_t) L->cap * sizeof(char *));
-    L->addr = realloc(L->addr, (size_t) L->cap * sizeof(uint64_t));
-    if (!L->name || !L->addr)
+    const int want = L->cap ? 2 * L->cap : 64;
+    char **names = realloc(L->name, (size_t) want * sizeof(char *));
+    if (names)
+      L->name = names;
+    uint64_t *addrs = realloc(L->addr, (size_t) want * sizeof(uint64_t));
+    if (addrs)
+      L->addr = addrs;
+    if (!names || !addrs)
       return h5fail(nc, "out of memory");
+    L->cap = want;
   }
   L->name[L->n] = malloc(len + 1);
   if (!L->name[L->n])
@@ -610,10 +617,12 @@ static int parse_attribute(ncc_file *nc, att_list *A, const unsigned char *p, si
   if (!type)
     return 1;   /* variable-length, reference, compound ...: not an attribute the classic model has */
   if (A->n == A->cap) {
-    A->cap = A->cap ? 2 * A->cap : 16;
-    A->a = realloc(A->a, (size_t) A->cap * sizeof(ncc_att));
-    if (!A->a)
+    const int want = A->cap ? 2 * A->cap : 16;
+    ncc_att *grown = realloc(A->a, (size_t) want * sizeof(ncc_att));
+    if (!grown)
       return h5fail(nc, "out of memory");
+    A->a = grown;
+    A->cap = want;
   }
   ncc_att *a = &A->a[A->n];
   memset(a, 0, sizeof(*a));
@@ -1151,13 +1160,21 @@ void h5_free(ncc_file *nc) {
 
 static int find_or_add_dim(ncc_file *nc, const char *name, uint64_t len, int *cap) {
   if (nc->ndim == *cap) {
-    *cap = *cap ? 2 * *cap : 32;
-    nc->dim_name = realloc(nc->dim_name, (size_t) *cap * sizeof(char *));
-    nc->dim_len = realloc(nc->dim_len, (size_t) *cap * sizeof(long long));
-    if (!nc->dim_name || !nc->dim_len)
+    const int want = *cap ? 2 * *cap : 32;
+    char **names = realloc(nc->dim_name, (size_t) want * sizeof(char *));
+    if (names)
+      nc->dim_name = names;
+    long long *lens = realloc(nc->dim_len, (size_t) want * sizeof(long long));
+    if (lens)
+      nc->dim_len = lens;
+    if (!names || !lens)
       return -1;
+    *cap = want;
   }
-  nc->dim_name[nc->ndim] = strdup(name);
+  char *copy = strdup(name);
+  if (!copy)
+    return -1;
+  nc->dim_name[nc->ndim] = copy;
   nc->dim_len[nc->ndim] = (long long) len;
   return nc->ndim++;
 }
@@ -1253,8 +1270,12 @@ int h5_load(ncc_file *nc) {
     const int type = nc_type_of(&o[i].t);
     if (!type)
       continue;   /* strings, compounds ...: not in the classic data model the host layer reads */
-    ncc_var *v = &nc->var[nc->nvar];
+    ncc_var *v = &nc->var[nc->nvar++];   /* (counted at once: ncc_close releases it if what follows fails) */
     v->name = strdup(L.name[i]);
+    if (!v->name) {
+      ok = h5fail(nc, "out of memory");
+      break;
+    }
     v->ndims = o[i].d.rank;
     v->type = type;
     v->nelem = 1;
@@ -1305,7 +1326,6 @@ int h5_load(ncc_file *nc) {
     v->natt = o[i].A.n;
     o[i].A.a = NULL;
     o[i].A.n = 0;
-    nc->nvar++;
   }
   for (int i = 0; o && i < L.n; i++) {
     free(o[i].d.compact);
