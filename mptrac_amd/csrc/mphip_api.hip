@@ -42,6 +42,9 @@ struct MetSlot {
   // smallest surface pressure of the snapshot (-inf if a value is not finite: no shortcut then) and smallest
   // finite cloud-top pressure: lower bounds of what the deposition modules interpolate (DevMet::ps_skip, pct_skip)
   double ps_min = -HUGE_VAL, pct_min = -HUGE_VAL;
+  // extremes of ps / pbl (all values finite, else unknown = the defaults) and the smallest pel that is not a NaN:
+  // bounds of what module_diff_turb and module_convection interpolate (DevMet::turb_skip, conv_skip)
+  double ps_max = HUGE_VAL, pbl_min = -HUGE_VAL, pbl_max = HUGE_VAL, pel_min = -HUGE_VAL;
 };
 
 }   // namespace
@@ -334,6 +337,35 @@ DevMet dev_met(const mphip_ctx *c) {
   // a little below the smallest value of either snapshot: what lies below that is below every interpolated value
   M.ps_skip = std::min(c->slot[0].ps_min, c->slot[1].ps_min) - 1e-6;
   M.pct_skip = std::min(c->slot[0].pct_min, c->slot[1].pct_min) - 1e-6;
+  // module_diff_turb / module_convection: bounds below which the boundary layer / the convective column cannot
+  // reach, from the extremes of ps and pbl over both snapshots (p1 = pbl - trans (ps - pbl) is linear in both:
+  // its smallest value is at a corner of the box of extremes) and the smallest pel
+  {
+    const double ps_lo = std::min(c->slot[0].ps_min, c->slot[1].ps_min), ps_hi = std::max(c->slot[0].ps_max, c->slot[1].ps_max);
+    const double pbl_lo = std::min(c->slot[0].pbl_min, c->slot[1].pbl_min),
+                 pbl_hi = std::max(c->slot[0].pbl_max, c->slot[1].pbl_max);
+    auto p1_min = [&](double trans) {
+      double lo = HUGE_VAL;
+      for (double pbl : { pbl_lo, pbl_hi })
+        for (double ps : { ps_lo, ps_hi })
+          lo = std::min(lo, pbl - trans * (ps - pbl));
+      return lo;
+    };
+    const bool known = std::isfinite(ps_lo) && std::isfinite(ps_hi) && std::isfinite(pbl_lo) && std::isfinite(pbl_hi);
+    M.turb_skip = -HUGE_VAL;
+    M.conv_skip = -HUGE_VAL;
+    if (known && c->have_ctl) {
+      const double b = std::min({ ps_lo, pbl_lo, p1_min(c->ctl.turb_pbl_trans) });
+      M.turb_skip = b - 1e-6 * std::fabs(b) - 1e-6;
+      double lo = ps_lo;
+      if (c->ctl.conv_mix_pbl)
+        lo = std::min(lo, p1_min(c->ctl.conv_pbl_trans));
+      if (c->ctl.conv_cape >= 0)
+        lo = std::min(lo, std::min(c->slot[0].pel_min, c->slot[1].pel_min));
+      if (lo == lo)
+        M.conv_skip = lo - 1e-6 * std::fabs(lo) - 1e-6;
+    }
+  }
   M.logtab = c->d_logtab;
   return M;
 }
@@ -1685,21 +1717,35 @@ int upload_fields(mphip_ctx *ctx, MetSlot &S, const mphip_met_t *met, bool new_g
     }
   }
   S.ps11 = met->f2[MPHIP_PS] ? met->f2[MPHIP_PS][(size_t) met->sx2 + 1] : 0.f;
-  S.ps_min = S.pct_min = -HUGE_VAL;
-  if (met->f2[MPHIP_PS]) {
-    double lo = HUGE_VAL;
-    bool finite = true;
-    for (int ix = 0; ix < met->nx && finite; ix++)
+  S.ps_min = S.pct_min = S.pbl_min = S.pel_min = -HUGE_VAL;
+  S.ps_max = S.pbl_max = HUGE_VAL;
+  // smallest and largest value of a surface field if every value is finite
+  auto extremes = [&](int f, double &lo_out, double &hi_out) {
+    if (!met->f2[f])
+      return;
+    double lo = HUGE_VAL, hi = -HUGE_VAL;
+    for (int ix = 0; ix < met->nx; ix++)
       for (int iy = 0; iy < met->ny; iy++) {
-        const float v = met->f2[MPHIP_PS][(size_t) ix * (size_t) met->sx2 + iy];
-        if (!std::isfinite(v)) {
-          finite = false;
-          break;
-        }
+        const float v = met->f2[f][(size_t) ix * (size_t) met->sx2 + iy];
+        if (!std::isfinite(v))
+          return;
         lo = std::min(lo, (double) v);
+        hi = std::max(hi, (double) v);
       }
-    if (finite)
-      S.ps_min = lo;
+    lo_out = lo;
+    hi_out = hi;
+  };
+  extremes(MPHIP_PS, S.ps_min, S.ps_max);
+  extremes(MPHIP_PBL, S.pbl_min, S.pbl_max);
+  if (met->f2[MPHIP_PEL]) {
+    double lo = HUGE_VAL;
+    for (int ix = 0; ix < met->nx; ix++)
+      for (int iy = 0; iy < met->ny; iy++) {
+        const float v = met->f2[MPHIP_PEL][(size_t) ix * (size_t) met->sx2 + iy];
+        if (v == v)   // (a NaN never starts convection: dmin(ptop, NaN) is a NaN and p >= NaN is false)
+          lo = std::min(lo, (double) v);
+      }
+    S.pel_min = lo;
   }
   if (met->f2[MPHIP_PCT]) {
     double lo = HUGE_VAL;

@@ -83,6 +83,10 @@ struct DevMet {
   // of module_dry_depo wherever it is, one with p <= pct_skip above every cloud top of module_wet_depo -- both
   // modules return for it before they gather anything, with the result the gathers would have led to
   double ps_skip, pct_skip;
+  // module_diff_turb: a particle between the snapshots with 1.01 p < turb_skip lies above the boundary layer and
+  // its transition zone wherever it is (weight 0) and more than its +-10 m probes below the surface;
+  // module_convection: one with p < conv_skip lies above every top the convective column can have (-inf = unknown)
+  double turb_skip, conv_skip;
   const double *logtab;          // table of log_tab() (kLogTabN x 3 doubles), copied to LDS by the step kernel
 };
 
@@ -1112,6 +1116,38 @@ __device__ inline double nat_temperature(double p, double h2o, double hno3) {
 // for several pressures
 __device__ __forceinline__ double tropo_pressure(const mphip_ctl_t &ctl, const DevClim &C, double time, double lat) {
   return clim_tropo(C, time, ctl.met_coord_type == 0 ? lat : ctl.met_utm_ref_lat);
+}
+
+// clim_tropo with its time part (second of the year, month interval) evaluated once: module_diff_turb asks for the
+// tropopause at two latitudes of the same time.  Same operations as clim_tropo, same bits.
+struct TropoTime {
+  double sec;
+  int it;
+};
+
+__device__ __forceinline__ TropoTime tropo_time(const DevClim &C, double t) {
+  TropoTime tt;
+  tt.sec = fmod_trunc(t, 365.25 * 86400.);
+  while (tt.sec < 0)
+    tt.sec += 365.25 * 86400.;
+  tt.it = locate_irr(C.time, C.ntime, tt.sec, 1);
+  return tt;
+}
+
+__device__ __forceinline__ double clim_tropo_at(const DevClim &C, const TropoTime &tt, double lat) {
+  const int it = tt.it;
+  const int il = locate_reg(C.lat, C.nlat, lat);
+  const double dlat = lat - C.lat[il];
+  const double pa = C.tropo[it][il] + div_const(C.tropo[it][il + 1] - C.tropo[it][il], C.lat[il + 1] - C.lat[il],
+                                                C.inv_dlat[il]) * dlat;
+  const double pb = C.tropo[it + 1][il] + div_const(C.tropo[it + 1][il + 1] - C.tropo[it + 1][il],
+                                                    C.lat[il + 1] - C.lat[il], C.inv_dlat[il]) * dlat;
+  return pa + div_const(pb - pa, C.time[it + 1] - C.time[it], C.inv_dtime[it]) * (tt.sec - C.time[it]);
+}
+
+__device__ __forceinline__ double tropo_pressure_at(const mphip_ctl_t &ctl, const DevClim &C, const TropoTime &tt,
+                                                    double lat) {
+  return clim_tropo_at(C, tt, ctl.met_coord_type == 0 ? lat : ctl.met_utm_ref_lat);
 }
 
 __device__ __forceinline__ double tropo_weight_pt(double pt, double p) {
@@ -2701,23 +2737,34 @@ __device__ __forceinline__ void advect_rk4_fast(const DevMet &M, const Axes &A, 
   advect_fast<4>(M, A, P, hook, wc);
 }
 
-// module_diff_turb (mptrac.c:4603-4733)
+// module_diff_turb (mptrac.c:4603-4733).  The surface pressure and the boundary-layer top only matter near the
+// ground: for a particle whose pressure (with a 1 % margin for the +-10 m probes of the Kz gradient) is below
+// DevMet::turb_skip the boundary-layer weight is 0 wherever it is, and the surface can only come into play if the
+// vertical displacement reaches it.  Such a particle runs with ps = pbl = the bound -- every expression below then
+// evaluates exactly as with the interpolated values -- and gathers nothing; if its trial pressure does reach the
+// bound, the reflection is redone with the interpolated surface pressure.
 __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevClim &C,
                                                Particle &P, uint64_t ctr, uint64_t g, const double *pre,
                                                const double *ltab) {
-  Stencil s = stencil_zero();
-  horiz_fast(M, A, P.lon, P.lat, s);
-  SurfA c;
-  load_pair_2d32(M.sfa, M, s, c);
   const double wt = time_weight(M, P.time);
-  const double pbl = pair_time_2d_fast(c, s, wt, 1);
-  if (ctl.turb_pbl_scheme > 0 && P.p >= pbl)
-    return;
-  const double ps = pair_time_2d_fast(c, s, wt, 0);
+  const bool far = (P.p * 1.01 < M.turb_skip) & (wt >= 0.0) & (wt <= 1.0);
+  double pbl = M.turb_skip, ps = M.turb_skip;
+  const double lon0 = P.lon, lat0 = P.lat;
+  if (!far) {
+    Stencil s = stencil_zero();
+    horiz_fast(M, A, P.lon, P.lat, s);
+    SurfA c;
+    load_pair_2d32(M.sfa, M, s, c);
+    pbl = pair_time_2d_fast(c, s, wt, 1);
+    if (ctl.turb_pbl_scheme > 0 && P.p >= pbl)
+      return;
+    ps = pair_time_2d_fast(c, s, wt, 0);
+  }
   const double ptop = A.p[M.np - 1];
 
+  const TropoTime tt = tropo_time(C, P.time);
   const double wpbl = pbl_weight(ctl, P.p, pbl, ps);
-  const double wtrop = tropo_weight(ctl, C, P.time, P.lat, P.p) * (1.0 - wpbl);
+  const double wtrop = tropo_weight_pt(tropo_pressure_at(ctl, C, tt, P.lat), P.p) * (1.0 - wpbl);
   const double wstrat = 1.0 - wpbl - wtrop;
   const double Kx = wpbl * ctl.turb_dx_pbl + wtrop * ctl.turb_dx_trop + wstrat * ctl.turb_dx_strat;
   const double Kz = wpbl * ctl.turb_dz_pbl + wtrop * ctl.turb_dz_trop + wstrat * ctl.turb_dz_strat;
@@ -2743,7 +2790,7 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
     const double eps_km = 0.01;
     const double p_up = p_save + dz2dp(eps_km, p_save);
     const double p_dn = p_save + dz2dp(-eps_km, p_save);
-    const double pt = tropo_pressure(ctl, C, P.time, P.lat);   // latitude already displaced above
+    const double pt = tropo_pressure_at(ctl, C, tt, P.lat);   // latitude already displaced above
     const double Kz_up = kz_blend(ctl, pt, vmax(ptop, vmin(ps, p_up)), pbl, ps);
     const double Kz_dn = kz_blend(ctl, pt, vmax(ptop, vmin(ps, p_dn)), pbl, ps);
     const double dKz_dz = (Kz_up - Kz_dn) * (1.0 / (2.0 * eps_km * 1e3));
@@ -2751,14 +2798,33 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
     const double w_drift = dKz_dz + Kz * dlnrho_dz;
     const double dz_drift = w_drift * dt_abs * 1e-3;
     const double dz_tot = rs2 * sigma_z + dz_drift;
-    double ptrial = p_save + dz2dp(dz_tot, p_save);
+    const double ptrial0 = p_save + dz2dp(dz_tot, p_save);
+    double ptrial = ptrial0;
+    bool at_surface = false;
     for (int iter = 0; iter < 10; iter++) {
-      if (ptrial > ps)
+      if (ptrial > ps) {
+        at_surface = true;
         ptrial = ps * ps / ptrial;
-      else if (ptrial < ptop)
+      } else if (ptrial < ptop)
         ptrial = ptop * ptop / ptrial;
       else
         break;
+    }
+    if (far & (at_surface | !(ptrial <= ps))) {   // (rare: a displacement of kilometres) -- now the surface pressure is needed
+      Stencil s = stencil_zero();
+      horiz_fast(M, A, lon0, lat0, s);
+      SurfA c;
+      load_pair_2d32(M.sfa, M, s, c);
+      ps = pair_time_2d_fast(c, s, wt, 0);
+      ptrial = ptrial0;
+      for (int iter = 0; iter < 10; iter++) {
+        if (ptrial > ps)
+          ptrial = ps * ps / ptrial;
+        else if (ptrial < ptop)
+          ptrial = ptop * ptop / ptrial;
+        else
+          break;
+      }
     }
     P.p = dmax(ptop, dmin(ps, ptrial));
   }
@@ -2839,7 +2905,8 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
   Stencil s = stencil_zero();
   horiz_fast(M, A, P.lon, P.lat, s);
   const double wt = time_weight(M, P.time);
-  if (mask & MPHIP_MOD_CONVECTION) {
+  // (a particle with p < DevMet::conv_skip lies above every top the convective column can have: nothing to do)
+  if ((mask & MPHIP_MOD_CONVECTION) && !((P.p < M.conv_skip) & (wt >= 0.0) & (wt <= 1.0))) {
     SurfA c;
     load_pair_2d32(M.sfa, M, s, c);
     const double ps = pair_time_2d_fast(c, s, wt, 0);
