@@ -26,6 +26,9 @@ constexpr unsigned kAdvTurb = kAdv | MPHIP_MOD_DIFF_TURB;
 constexpr unsigned kAdvDiff = kAdvTurb | MPHIP_MOD_DIFF_MESO;
 constexpr unsigned kAdvTurbConvSedi = kAdvTurb | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kAdvDiffConvSedi = kAdvDiff | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
+// second launch of a split time step (option split_step): everything behind module_advect, dt from memory
+constexpr unsigned kDiffConvSediOnly = MPHIP_MOD_TIMESTEPS | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_CONVECTION
+  | MPHIP_MOD_SEDI | MPHIP_MOD_POSITION2;
 constexpr unsigned kTailOnly = MPHIP_MOD_TIMESTEPS;   // no mover: a launch of loss / decay / deposition modules only
 constexpr unsigned kParticleBits = 0x3fffu | MPHIP_MOD_ISOSURF | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2
   | MPHIP_MOD_ISOSURF_INIT;
@@ -152,6 +155,7 @@ struct mphip_ctx {
   int locality_tile = 0;              // horizontal tile edge of the locality key (columns); 0 = 4, or 8 with model-level winds
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;
+  int split_step = 0;                 // experiment: advection and the modules behind it as two launches
   bool force_generic = false;
   bool compact_depo = true;           // deposition-only launches through depo_kernel (0: the fused kernel's tail)
   int sort_bits = 0;                  // digit width of the radix sort (0 = fewest passes; 8, 9, 10: tuning / tests)
@@ -764,6 +768,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     const bool exact = req == kAdv || req == kAdvTurb || req == kAdvDiff || req == kAdvTurbConvSedi || req == kAdvDiffConvSedi;
     if (req == kTailOnly)
       sel = kTailOnly;
+    else if (req == kDiffConvSediOnly && !(mask & kBound))
+      sel = kDiffConvSediOnly;
     else if (exact && !(mask & kBound))
       sel = req | scheme;
     else if ((req & ~kOptionalModules) == kAdv)
@@ -800,6 +806,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiffConvSedi | kGated)
     STEP_CASE(kAdvDiffConvSedi | kGated | kTwoStage)
     STEP_CASE(kTailOnly)
+    STEP_CASE(kDiffConvSediOnly)
 #undef STEP_CASE
   default:
     if (rare || ctx->force_generic)
@@ -2613,7 +2620,13 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   const bool sort_next = ctx->sort_ahead && ctx->np > 0 && ctx->ext_identity && c.sort_dt > 0
     && fmod(t_next, c.sort_dt) == 0 && c.direction * (t_next - c.t_stop) <= 0;
   if (!mixing_now) {
-    if (launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
+    constexpr unsigned kFirst = MPHIP_MOD_TIMESTEPS | MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT;
+    if (ctx->split_step && (mask & ~kFirst & ~kTailModules) == (kDiffConvSediOnly & ~MPHIP_MOD_TIMESTEPS)
+        && (mask & kFirst) == kFirst) {
+      if (launch_step(ctx, (mask & kFirst) | MPHIP_MOD_POSITION2 | kStoreDt, t, 0, 0, 0)
+          || launch_step(ctx, (mask & ~kFirst) | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
+        return 1;
+    } else if (launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
       return 1;
     if (sort_next && ahead_launch(ctx, t_next))
       return 1;
@@ -2892,6 +2905,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
   }
   if (strcmp(name, "pin_host_atm") == 0) {   // page-lock the arrays handed to mphip_update_atm / mphip_get_atm
     ctx->pin_host_atm = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "split_step") == 0) {
+    ctx->split_step = value != 0;
     return 0;
   }
   if (strcmp(name, "xcd_map") == 0) {

@@ -2831,14 +2831,17 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
 }
 
 // module_diff_meso (mptrac.c:4280-4338) on the {u0,v0,u1,v1,w0,w1} records
+template <bool STREAM = false>
 __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                                float &up, float &vp, float &wp, uint64_t ctr, uint64_t g,
                                                const double *pre, WindCache &wc, const double *ltab) {
 #pragma clang fp contract(off)
   Stencil s;
   raw_cell_fast(M, A, P.lon, P.lat, P.p, s);
-  load_wind_cached32(M, s, wc);
-  wind_cache_wait(wc);
+  if (!STREAM) {
+    load_wind_cached32(M, s, wc);
+    wind_cache_wait(wc);
+  }
   const WindCorners &c = wc.c;
 
   // single-precision sums in the reference's order -- i (lon), j (lat), k (level), met0 before met1 --,
@@ -2849,7 +2852,17 @@ __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const Dev
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      const f32x4u r0 = c.r[i][j][0], r1 = c.r[i][j][1], r2 = c.r[i][j][2];
+      f32x4u r0, r1, r2;
+      if (STREAM) {   // (no corner cache in this instantiation: a corner is summed as it arrives)
+        const unsigned off = 24u * cell32(M, s, i, j);
+        r0 = load_at<f32x4u>(M.wind, off);
+        r1 = load_at<f32x4u>(M.wind, off + 16u);
+        r2 = load_at<f32x4u>(M.wind, off + 32u);
+      } else {
+        r0 = c.r[i][j][0];
+        r1 = c.r[i][j][1];
+        r2 = c.r[i][j][2];
+      }
       // level ip: uv0 = r0[0,1], uv1 = r0[2,3], w0 w1 = r1[0,1]; level ip + 1: uv0 = r1[2,3], uv1 = r2[0,1], w0 w1 = r2[2,3]
       const f32x2 uv[2][2] = { { __builtin_shufflevector(r0, r0, 0, 1), __builtin_shufflevector(r0, r0, 2, 3) },
                                { __builtin_shufflevector(r1, r1, 2, 3), __builtin_shufflevector(r2, r2, 0, 1) } };

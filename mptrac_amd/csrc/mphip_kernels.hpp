@@ -488,8 +488,11 @@ struct RngEarly {
 #endif
   }
 };
+#ifndef MPHIP_SPLITB_WAVES_PER_SIMD
+#define MPHIP_SPLITB_WAVES_PER_SIMD 4
+#endif
 template <unsigned CT>
-__global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
+__global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & MPHIP_MOD_ADVECT) || CT == MPHIP_MOD_TIMESTEPS ? MPHIP_LEAN_WAVES_PER_SIMD : MPHIP_SPLITB_WAVES_PER_SIMD)
                                    : (CT == kMaskGenericPL ? MPHIP_STEP_WAVES_PER_SIMD : MPHIP_GENERIC_WAVES_PER_SIMD)) void step_kernel(
   const StepParams S) {
   extern __shared__ double s_axes[];
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? MPHIP_LEAN_WAVES_PER_SIMD
       if (CT == kMaskGenericML)
         wind_cache_reset(wc, true);
       if (lean)
-        diff_meso_fast(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc, ltab);
+        diff_meso_fast<!(CT & MPHIP_MOD_ADVECT)>(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc, ltab);
       else
         diff_meso(ctl, M, A, P, up, vp, wp, S.ctr_meso, g, early ? pre.meso : nullptr, wc, ltab);
       st_state(&a.up[i], up);
