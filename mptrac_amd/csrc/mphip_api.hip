@@ -370,6 +370,11 @@ DevMet dev_met(const mphip_ctx *c) {
         M.conv_skip = lo - 1e-6 * std::fabs(lo) - 1e-6;
     }
   }
+  M.meso_dt = std::fabs(c->ctl.dt_mod);
+  M.meso_r = 1 - 2 * M.meso_dt / c->ctl.dt_met;
+  M.meso_r2 = std::sqrt(1 - M.meso_r * M.meso_r);
+  if (!c->have_ctl || !(M.meso_dt > 0) || !std::isfinite(M.meso_r2))
+    M.meso_dt = -1;    // never equal to |dt|: the kernels compute the coefficients themselves
   M.logtab = c->d_logtab;
   return M;
 }

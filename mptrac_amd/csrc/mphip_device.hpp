@@ -87,6 +87,9 @@ struct DevMet {
   // its transition zone wherever it is (weight 0) and more than its +-10 m probes below the surface;
   // module_convection: one with p < conv_skip lies above every top the convective column can have (-inf = unknown)
   double turb_skip, conv_skip;
+  // module_diff_meso: r = 1 - 2 |dt| / DT_MET and sqrt(1 - r^2) for |dt| = meso_dt = |DT_MOD| (every particle of a
+  // step but the last, shortened one), from the host -- IEEE division and square root as the reference's
+  double meso_dt, meso_r, meso_r2;
   const double *logtab;          // table of log_tab() (kLogTabN x 3 doubles), copied to LDS by the step kernel
 };
 
@@ -191,8 +194,9 @@ __device__ __forceinline__ double fdiv(double a, double b) {
 #if MPHIP_EXACT_DIV
   return a / b;
 #else
-  double r = __builtin_amdgcn_rcp(b);             // two Newton steps, then one residual correction
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  // v_rcp_f64 is good to ~2^-26; one Newton step squares that, and the residual correction of the quotient
+  // multiplies the two errors: the result is the correctly rounded quotient or its neighbour
+  double r = __builtin_amdgcn_rcp(b);
   r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
   const double q = a * r;
   return __builtin_fma(__builtin_fma(-b, q, a), r, q);
@@ -1176,21 +1180,36 @@ __device__ __forceinline__ double pbl_weight(const mphip_ctl_t &ctl, double p, d
   return lin(p0, 1.0, p1, 0.0, p);
 }
 
-// sedi, mptrac.c:12506-12535
+// sedi, mptrac.c:12506-12535.  The default build forms the six quotients of the formula from two reciprocals,
+// 1 / (s T) and 1 / ((T + 120) rho v r) with s = (T / 296.16)^1.5: eta = c s / (T + 120), rho = 100 p / (RA T),
+// K = 2 eta / (rho v r), and 1 / K, 1 / eta follow by products -- a few ulp from the reference's operation order
+// on a velocity that moves the pressure by parts per million.
 __device__ __forceinline__ double sedi(double p, double T, double rp, double rhop) {
   const double r = rp * 1e-6;
-  const double rho = rho_air(p, T);
 #if MPHIP_EXACT_DIV
+  const double rho = rho_air(p, T);
   const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * pow(T / 296.16, 1.5);
-#else
-  const double tr = T * (1.0 / 296.16);   // x^1.5 = x sqrt(x): within 2 ulp of pow()
-  const double eta = 1.8325e-5 * fdiv(416.16, T + 120.) * (tr * fsqrt(tr));
-#endif
   const double v = fsqrt(div_const(8. * kKB * T, kPi * kMAir, 1.0 / (kPi * kMAir)));
   const double lambda = fdiv(2. * eta, rho * v);
   const double K = fdiv(lambda, r);
   const double G = 1. + K * (1.249 + 0.42 * exp(fdiv(-0.87, K)));
   return fdiv(2. * (r * r) * (rhop - rho) * kG0, 9. * eta) * G;
+#else
+  const double tr = T * (1.0 / 296.16);   // x^1.5 = x sqrt(x): within 2 ulp of pow()
+  const double s = tr * fsqrt(tr);
+  const double a = T + 120.;
+  const double d = frcp(s * T);
+  const double inv_t = d * s, inv_s = d * T;
+  const double rho = (100. / kRA) * p * inv_t;
+  const double v = fsqrt((8. * kKB / (kPi * kMAir)) * T);
+  const double c = 1.8325e-5 * 416.16;    // eta = c s / a
+  const double arvr = a * rho * v * r;
+  const double K = (2. * c) * s * frcp(arvr);
+  const double inv_K = (0.5 / c) * arvr * inv_s;
+  const double G = 1. + K * (1.249 + 0.42 * exp(-0.87 * inv_K));
+  // 2 r^2 (rhop - rho) g / (9 eta) with 1 / eta = a / (c s)
+  return (2. * kG0 / (9. * c)) * (r * r) * (rhop - rho) * (a * inv_s) * G;
+#endif
 }
 
 // ---- random numbers (mptrac.c:5784-5828) -----------------------------------
@@ -2134,6 +2153,17 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   P.p = clampd(P.p, pbl, ps);
 }
 
+// temporal correlation of module_diff_meso (mptrac.c:4310-4311): from the host for the regular time step
+__device__ __forceinline__ void meso_coeffs(const mphip_ctl_t &ctl, const DevMet &M, double dt, double &r, double &r2) {
+  if (fabs(dt) == M.meso_dt) {
+    r = M.meso_r;
+    r2 = M.meso_r2;
+  } else {
+    r = 1 - fdiv(2 * fabs(dt), ctl.dt_met);
+    r2 = fsqrt(1 - r * r);
+  }
+}
+
 // module_diff_meso, mptrac.c:4280-4338
 __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                           float &up, float &vp, float &wp, uint64_t ctr, uint64_t g,
@@ -2181,8 +2211,8 @@ __device__ __forceinline__ void diff_meso(const mphip_ctl_t &ctl, const DevMet &
     sd[q] = (var > 0 ? sqrtf(var) : 0.f);
   }
 
-  const double r = 1 - fdiv(2 * fabs(P.dt), ctl.dt_met);
-  const double r2 = fsqrt(1 - r * r);
+  double r, r2;
+  meso_coeffs(ctl, M, P.dt, r, r2);
   double rs0, rs1, rs2;
   if (pre) {
     rs0 = pre[0];
@@ -2886,8 +2916,8 @@ __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const Dev
     sd[q] = (var > 0 ? sqrtf(var) : 0.f);
   }
 
-  const double r = 1 - fdiv(2 * fabs(P.dt), ctl.dt_met);
-  const double r2 = fsqrt(1 - r * r);
+  double r, r2;
+  meso_coeffs(ctl, M, P.dt, r, r2);
   double rs0, rs1, rs2;
   if (pre) {
     rs0 = pre[0];
