@@ -14,7 +14,8 @@
  *
  * Every member of ctl_t / met_t / clim_t / cache_t / atm_t named here exists in the reference's mptrac.h:
  * integration/check_glue_fields.py verifies that against /root/reference (tests/test_abi.py runs it).  The
- * file cannot be compiled in this repository's image (the reference's header needs GSL and netCDF).
+ * file is type-checked against the reference header by integration/typecheck_glue.py (gcc -fsyntax-only; the
+ * reference itself cannot be built in this image: its header needs GSL and netCDF).
  *
  * Call sites (reference file:line -> what replaces the OpenACC region there):
  *   mptrac_alloc          mptrac.c:6336-6372   mptrac_hip_alloc(rank)            instead of `acc enter data create`

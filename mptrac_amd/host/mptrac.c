@@ -553,19 +553,32 @@ void clim_tropo_init(clim_t *clim) {
     ERRMSG("Error while reading tropopause climatology!");
 }
 
-/* cos_sza (mptrac.c:1857-1897): cosine of the solar zenith angle at `sec` seconds since 2000-01-01 00:00 UTC */
-static double cos_sza(const double sec, const double lon, const double lat) {
-  const double D = sec / 86400 - 0.5;
-  const double g = DEG2RAD(357.529 + 0.98560028 * D);
-  const double q = 280.459 + 0.98564736 * D;
-  const double L = DEG2RAD(q + 1.915 * sin(g) + 0.020 * sin(2 * g));
-  const double e = DEG2RAD(23.439 - 0.00000036 * D);
-  const double sindec = sin(e) * sin(L);
-  const double ra = atan2(cos(e) * sin(L), cos(L));
-  const double GMST = 18.697374558 + 24.06570982441908 * D;
-  const double LST = GMST + lon / 15;
-  const double h = LST / 12 * M_PI - ra;
-  return sin(DEG2RAD(lat)) * sindec + cos(DEG2RAD(lat)) * sqrt(1 - SQR(sindec)) * cos(h);
+/* Position of the sun at `sec` seconds since 2000-01-01 00:00 UTC -- the low-precision almanac formulae the
+ * reference's cos_sza evaluates (mptrac.c:1857-1897) --, split into what depends on the time only and what depends
+ * on the observer: the day / night correction below asks for 360 longitudes per (month, latitude). */
+typedef struct {
+  double sin_dec, cos_dec;   /* declination of the sun */
+  double ra;                 /* right ascension [rad] */
+  double gmst;               /* Greenwich mean sidereal time [h] */
+} sun_t;
+
+static sun_t sun_at(const double sec) {
+  sun_t sun;
+  const double days = sec / 86400 - 0.5;   /* since 2000-01-01 12:00 UTC */
+  const double anomaly = DEG2RAD(357.529 + 0.98560028 * days);
+  const double ecl_lon = DEG2RAD(280.459 + 0.98564736 * days + 1.915 * sin(anomaly) + 0.020 * sin(2 * anomaly));
+  const double obliquity = DEG2RAD(23.439 - 0.00000036 * days);
+  sun.sin_dec = sin(obliquity) * sin(ecl_lon);
+  sun.cos_dec = sqrt(1 - SQR(sun.sin_dec));
+  sun.ra = atan2(cos(obliquity) * sin(ecl_lon), cos(ecl_lon));
+  sun.gmst = 18.697374558 + 24.06570982441908 * days;
+  return sun;
+}
+
+/* cosine of the solar zenith angle for an observer at (lon, lat) */
+static double cos_zenith(const sun_t *sun, const double lon, const double sin_lat, const double cos_lat) {
+  const double hour_angle = (sun->gmst + lon / 15) / 12 * M_PI - sun->ra;
+  return sin_lat * sun->sin_dec + cos_lat * sun->cos_dec * cos(hour_angle);
 }
 
 /* One zonal-mean climatology (monthly means) from a netCDF file with the dimensions time (12), press, lat and
@@ -644,53 +657,77 @@ static void read_clim_zm(const char *filename, const char *varname, clim_zm_t *z
 }
 
 /* clim_oh_diurnal_correction (mptrac.c:122-152): the OH table divided by the zonal mean of the day / night
- * factor exp(-beta / cos(sza)) that clim_oh applies again per particle */
+ * factor exp(-beta / cos(sza)) that clim_oh applies again per particle.  The mean depends on month and latitude
+ * only: one row of factors per month, applied to every level. */
 static void clim_oh_diurnal_correction(const ctl_t *ctl, clim_t *clim) {
-  const double csza_thresh = cos(DEG2RAD(85.));
-  for (int it = 0; it < clim->oh.ntime; it++)
-    for (int iz = 0; iz < clim->oh.np; iz++)
-      for (int iy = 0; iy < clim->oh.nlat; iy++) {
-        int n = 0;
-        double sum = 0;
-        for (double lon = -180; lon < 180; lon += 1.0) {
-          const double csza = cos_sza(clim->oh.time[it], lon, clim->oh.lat[iy]);
-          sum += exp(-ctl->oh_chem_beta / (csza >= csza_thresh ? csza : csza_thresh));
-          n++;
-        }
-        clim->oh.vmr[it][iz][iy] /= (sum / (double) n);
+  const double floor_csza = cos(DEG2RAD(85.));
+  for (int it = 0; it < clim->oh.ntime; it++) {
+    const sun_t sun = sun_at(clim->oh.time[it]);
+    for (int iy = 0; iy < clim->oh.nlat; iy++) {
+      const double sin_lat = sin(DEG2RAD(clim->oh.lat[iy])), cos_lat = cos(DEG2RAD(clim->oh.lat[iy]));
+      double sum = 0;
+      for (int k = 0; k < 360; k++) {
+        const double csza = cos_zenith(&sun, -180.0 + k, sin_lat, cos_lat);
+        sum += exp(-ctl->oh_chem_beta / fmax(csza, floor_csza));
       }
+      const double zonal_mean = sum / 360.0;
+      for (int iz = 0; iz < clim->oh.np; iz++)
+        clim->oh.vmr[it][iz][iy] /= zonal_mean;
+    }
+  }
 }
 
-/* A trace-gas time series: text lines "year vmr" (read_clim_ts, mptrac.c:8693-8743); years become seconds since
- * 2000-01-01.  A file that cannot be opened is a warning: the gas then has no boundary condition. */
+/* Text table of two numeric columns; lines that do not start with two numbers (headers, comments) are skipped.
+ * Returns the number of rows stored (at most `max`; one more row is an error), or -1 if the file cannot be opened. */
+static int read_two_columns(const char *filename, double *x, double *y, const int max) {
+  FILE *in = fopen(filename, "r");
+  if (!in)
+    return -1;
+  int n = 0;
+  char line[LEN];
+  while (fgets(line, LEN, in)) {
+    char *end;
+    const double a = strtod(line, &end);
+    if (end == line)
+      continue;
+    char *end2;
+    const double b = strtod(end, &end2);
+    if (end2 == end)
+      continue;
+    if (n >= max) {
+      fclose(in);
+      ERRMSG("Too many data points!");
+    }
+    x[n] = a;
+    y[n] = b;
+    n++;
+  }
+  fclose(in);
+  return n;
+}
+
+/* A trace-gas time series "year vmr" (read_clim_ts, mptrac.c:8693-8743); years become seconds since 2000-01-01.
+ * A file that cannot be opened is a warning: the gas then has no boundary condition. */
 static int read_clim_ts(const char *filename, clim_ts_t *ts) {
   LOG(1, "Read climatological time series: %s", filename);
-  FILE *in = fopen(filename, "r");
-  if (!in) {
+  const int n = read_two_columns(filename, ts->time, ts->vmr, CTS - 1);
+  if (n < 0) {
     WARN("Cannot open file!");
     return 0;
   }
-  char line[LEN];
-  int nh = 0;
-  while (fgets(line, LEN, in))
-    if (sscanf(line, "%lg %lg", &ts->time[nh], &ts->vmr[nh]) == 2) {
-      ts->time[nh] = (ts->time[nh] - 2000.0) * 365.25 * 86400.;
-      if (nh > 0 && ts->time[nh] <= ts->time[nh - 1])
-        ERRMSG("Time series must be ascending!");
-      if ((++nh) >= CTS)
-        ERRMSG("Too many data points!");
-    }
-  fclose(in);
-  ts->ntime = nh;
-  if (nh < 2)
+  if (n < 2)
     ERRMSG("Not enough data points!");
-  LOG(2, "Number of time steps: %d", ts->ntime);
-  LOG(2, "Time steps: %.2f, %.2f ... %.2f s", ts->time[0], ts->time[1], ts->time[nh - 1]);
   double lo = ts->vmr[0], hi = ts->vmr[0];
-  for (int i = 1; i < nh; i++) {
+  for (int i = 0; i < n; i++) {
+    ts->time[i] = (ts->time[i] - 2000.0) * 365.25 * 86400.;
+    if (i > 0 && ts->time[i] <= ts->time[i - 1])
+      ERRMSG("Time series must be ascending!");
     lo = fmin(lo, ts->vmr[i]);
     hi = fmax(hi, ts->vmr[i]);
   }
+  ts->ntime = n;
+  LOG(2, "Number of time steps: %d", ts->ntime);
+  LOG(2, "Time steps: %.2f, %.2f ... %.2f s", ts->time[0], ts->time[1], ts->time[n - 1]);
   LOG(2, "Volume mixing ratio range: %g ... %g ppv", lo, hi);
   return 1;
 }
@@ -700,30 +737,37 @@ static int read_clim_ts(const char *filename, clim_ts_t *ts) {
  * series feed the chemistry modules, which are not part of this build) */
 void mptrac_read_clim(const ctl_t *ctl, clim_t *clim) {
   clim_tropo_init(clim);
-  if ((ctl->qnt_hno3 >= 0 || ctl->qnt_tnat >= 0) && ctl->clim_hno3_filename[0] != '-')
-    read_clim_zm(ctl->clim_hno3_filename, "HNO3", &clim->hno3);
-  if (ctl->qnt_oh >= 0 && ctl->clim_oh_filename[0] != '-') {
-    read_clim_zm(ctl->clim_oh_filename, "OH", &clim->oh);
-    if (ctl->oh_chem_beta > 0)
-      clim_oh_diurnal_correction(ctl, clim);
-  }
-  if (ctl->qnt_h2o2 >= 0 && ctl->clim_h2o2_filename[0] != '-')
-    read_clim_zm(ctl->clim_h2o2_filename, "H2O2", &clim->h2o2);
-  if (ctl->qnt_ho2 >= 0 && ctl->clim_ho2_filename[0] != '-')
-    read_clim_zm(ctl->clim_ho2_filename, "HO2", &clim->ho2);
-  if (ctl->qnt_o1d >= 0 && ctl->clim_o1d_filename[0] != '-')
-    read_clim_zm(ctl->clim_o1d_filename, "O1D", &clim->o1d);
-  /* the time series of the trace gases that are carried (module_bound_cond, mptrac.c:3857-3875) */
-  if (ctl->qnt_Cccl4 >= 0 && ctl->clim_ccl4_timeseries[0] != '-')
-    read_clim_ts(ctl->clim_ccl4_timeseries, &clim->ccl4);
-  if (ctl->qnt_Cccl3f >= 0 && ctl->clim_ccl3f_timeseries[0] != '-')
-    read_clim_ts(ctl->clim_ccl3f_timeseries, &clim->ccl3f);
-  if (ctl->qnt_Cccl2f2 >= 0 && ctl->clim_ccl2f2_timeseries[0] != '-')
-    read_clim_ts(ctl->clim_ccl2f2_timeseries, &clim->ccl2f2);
-  if (ctl->qnt_Cn2o >= 0 && ctl->clim_n2o_timeseries[0] != '-')
-    read_clim_ts(ctl->clim_n2o_timeseries, &clim->n2o);
-  if (ctl->qnt_Csf6 >= 0 && ctl->clim_sf6_timeseries[0] != '-')
-    read_clim_ts(ctl->clim_sf6_timeseries, &clim->sf6);
+  /* zonal means: read when a module_meteo quantity needs the table and a file is named */
+  const struct {
+    int wanted;
+    const char *file, *var;
+    clim_zm_t *zm;
+  } zonal[] = {
+    { ctl->qnt_hno3 >= 0 || ctl->qnt_tnat >= 0, ctl->clim_hno3_filename, "HNO3", &clim->hno3 },
+    { ctl->qnt_oh >= 0, ctl->clim_oh_filename, "OH", &clim->oh },
+    { ctl->qnt_h2o2 >= 0, ctl->clim_h2o2_filename, "H2O2", &clim->h2o2 },
+    { ctl->qnt_ho2 >= 0, ctl->clim_ho2_filename, "HO2", &clim->ho2 },
+    { ctl->qnt_o1d >= 0, ctl->clim_o1d_filename, "O1D", &clim->o1d },
+  };
+  for (size_t k = 0; k < sizeof(zonal) / sizeof(zonal[0]); k++)
+    if (zonal[k].wanted && zonal[k].file[0] != '-') {
+      read_clim_zm(zonal[k].file, zonal[k].var, zonal[k].zm);
+      if (zonal[k].zm == &clim->oh && ctl->oh_chem_beta > 0)
+        clim_oh_diurnal_correction(ctl, clim);
+    }
+  /* surface time series of the trace gases that are carried (module_bound_cond, mptrac.c:3857-3875) */
+  const struct {
+    int qnt;
+    const char *file;
+    clim_ts_t *ts;
+  } series[] = {
+    { ctl->qnt_Cccl4, ctl->clim_ccl4_timeseries, &clim->ccl4 },     { ctl->qnt_Cccl3f, ctl->clim_ccl3f_timeseries, &clim->ccl3f },
+    { ctl->qnt_Cccl2f2, ctl->clim_ccl2f2_timeseries, &clim->ccl2f2 }, { ctl->qnt_Cn2o, ctl->clim_n2o_timeseries, &clim->n2o },
+    { ctl->qnt_Csf6, ctl->clim_sf6_timeseries, &clim->sf6 },
+  };
+  for (size_t k = 0; k < sizeof(series) / sizeof(series[0]); k++)
+    if (series[k].qnt >= 0 && series[k].file[0] != '-')
+      read_clim_ts(series[k].file, series[k].ts);
 }
 
 /* -------------------------------------------------------------------------- */
@@ -1122,18 +1166,14 @@ static void write_atm_bin(const char *filename, const ctl_t *ctl, const atm_t *a
 
 void mptrac_write_atm(const char *filename, const ctl_t *ctl, const atm_t *atm, const double t) {
   LOG(1, "Write atmospheric data: %s", filename);
-  if (ctl->atm_type_out == 0)
-    write_atm_asc(filename, ctl, atm, t);
-  else if (ctl->atm_type_out == 1)
-    write_atm_bin(filename, ctl, atm);
-  else if (ctl->atm_type_out == 2)
-    write_atm_nc(filename, ctl, atm);
-  else if (ctl->atm_type_out == 3)
-    write_atm_clams_traj(filename, ctl, atm, t);
-  else if (ctl->atm_type_out == 4)
-    write_atm_clams(filename, ctl, atm);
-  else
-    ERRMSG("Atmospheric data type not supported!");
+  switch (ctl->atm_type_out) {   /* ATM_TYPE_OUT: 0 ASCII, 1 binary, 2 netCDF, 3 CLaMS trajectories, 4 CLaMS positions */
+  case 0: write_atm_asc(filename, ctl, atm, t); break;
+  case 1: write_atm_bin(filename, ctl, atm); break;
+  case 2: write_atm_nc(filename, ctl, atm); break;
+  case 3: write_atm_clams_traj(filename, ctl, atm, t); break;
+  case 4: write_atm_clams(filename, ctl, atm); break;
+  default: ERRMSG("Atmospheric data type not supported!");
+  }
 }
 
 /* every column (i, j) of the grid */
@@ -1437,34 +1477,44 @@ static int nc_field(const nc_reader *r, const char *const *names, const int nlev
 #define NC_3D(field, scl, ...) nc_field(&r, NAMES(__VA_ARGS__), met->np, scl, &met->field[0][0][0], EP)
 #define NC_2D(field, scl, ...) nc_field(&r, NAMES(__VA_ARGS__), 0, scl, &met->field[0][0], 1)
 
-/* read_met_polar_winds (mptrac.c:11775-11833): on a grid that reaches both poles the winds of the pole rows are
- * replaced by the mean wind vector of the neighbouring row, turned into each longitude's local directions */
-static void met_polar_winds(met_t *met) {
-  if (fabs(met->lat[0]) < 89.999 || fabs(met->lat[met->ny - 1]) < 89.999)
-    return;
-  double *clon, *slon;
-  ALLOC(clon, double, met->nx);
-  ALLOC(slon, double, met->nx);
-  for (int ihem = 0; ihem < 2; ihem++) {
-    const int i89 = ihem ? met->ny - 2 : 1, i90 = ihem ? met->ny - 1 : 0, sign = met->lat[i90] < 0 ? -1 : 1;
-    for (int ix = 0; ix < met->nx; ix++) {
-      clon[ix] = cos(sign * DEG2RAD(met->lon[ix]));
-      slon[ix] = sin(sign * DEG2RAD(met->lon[ix]));
+/* The wind at a pole has no direction of its own.  On a grid that reaches both poles (read_met_polar_winds,
+ * mptrac.c:11775-11833) each pole row gets the mean wind vector of the row next to it: averaged in a frame fixed
+ * at the pole (every longitude's (u, v) turned by its longitude), then turned back into the local directions. */
+static void pole_row_from_neighbour(met_t *met, const int pole, const int next, const double *c, const double *s) {
+  const int nx = met->nx;
+  for (int ip = 0; ip < met->np; ip++) {
+    double mx = 0, my = 0;   /* mean vector in the polar frame */
+    for (int ix = 0; ix < nx; ix++) {
+      const double u = met->u[ix][next][ip], v = met->v[ix][next][ip];
+      mx += (u * c[ix] - v * s[ix]) / nx;
+      my += (u * s[ix] + v * c[ix]) / nx;
     }
-    for (int ip = 0; ip < met->np; ip++) {
-      double vel89x = 0, vel89y = 0;
-      for (int ix = 0; ix < met->nx; ix++) {
-        vel89x += (met->u[ix][i89][ip] * clon[ix] - met->v[ix][i89][ip] * slon[ix]) / met->nx;
-        vel89y += (met->u[ix][i89][ip] * slon[ix] + met->v[ix][i89][ip] * clon[ix]) / met->nx;
-      }
-      for (int ix = 0; ix < met->nx; ix++) {
-        met->u[ix][i90][ip] = (float) (vel89x * clon[ix] + vel89y * slon[ix]);
-        met->v[ix][i90][ip] = (float) (-vel89x * slon[ix] + vel89y * clon[ix]);
-      }
+    for (int ix = 0; ix < nx; ix++) {
+      met->u[ix][pole][ip] = (float) (mx * c[ix] + my * s[ix]);
+      met->v[ix][pole][ip] = (float) (my * c[ix] - mx * s[ix]);
     }
   }
-  free(clon);
-  free(slon);
+}
+
+static void met_polar_winds(met_t *met) {
+  const int last = met->ny - 1;
+  if (fabs(met->lat[0]) < 89.999 || fabs(met->lat[last]) < 89.999)
+    return;
+  double *c, *s;
+  ALLOC(c, double, met->nx);
+  ALLOC(s, double, met->nx);
+  const int rows[2][2] = { { 0, 1 }, { last, last - 1 } };   /* { pole row, its neighbour } */
+  for (int k = 0; k < 2; k++) {
+    /* the frame turns with the longitude at the north pole, against it at the south pole */
+    const double turn = met->lat[rows[k][0]] < 0 ? -1 : 1;
+    for (int ix = 0; ix < met->nx; ix++) {
+      c[ix] = cos(turn * DEG2RAD(met->lon[ix]));
+      s[ix] = sin(turn * DEG2RAD(met->lon[ix]));
+    }
+    pole_row_from_neighbour(met, rows[k][0], rows[k][1], c, s);
+  }
+  free(c);
+  free(s);
 }
 
 /* read_met_periodic (mptrac.c:11714-11771): a global grid gets one more longitude, a copy of the first column */
@@ -2086,17 +2136,11 @@ void mptrac_run_timestep(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t **met0,
    * modes 1-3 are evaluated on the device */
   if (t == ctl->t_start && ctl->isosurf == 4) {
     LOG(1, "Read balloon pressure data: %s", ctl->balloon);
-    FILE *in;
-    if (!(in = fopen(ctl->balloon, "r")))
+    cache->iso_n = read_two_columns(ctl->balloon, cache->iso_ts, cache->iso_ps, NP);
+    if (cache->iso_n < 0)
       ERRMSG("Cannot open file!");
-    char line[LEN];
-    while (fgets(line, LEN, in))
-      if (sscanf(line, "%lg %lg", &(cache->iso_ts[cache->iso_n]), &(cache->iso_ps[cache->iso_n])) == 2)
-        if ((++cache->iso_n) > NP)
-          ERRMSG("Too many data points!");
     if (cache->iso_n < 1)
       ERRMSG("Could not read any data!");
-    fclose(in);
     HIP(mphip_update_iso(g_ctx, NULL, cache->iso_ts, cache->iso_ps, cache->iso_n));
   }
   HIP(mphip_run_timestep(g_ctx, t));

@@ -35,6 +35,7 @@ struct h5_dataset {
   int elsize, little_endian;
   /* chunked */
   uint64_t chunk[9];          /* chunk extent per axis (+ element size) */
+  int chunk_nd;               /* dimensionality the layout message states (rank + 1) */
   int chunk_index;            /* 0 B-tree v1, 1 single chunk, 2 implicit, 3 fixed array */
   uint64_t index_addr, single_size;
   uint32_t single_mask;
@@ -130,6 +131,8 @@ static int parse_block_v1(ncc_file *nc, h5_msgs *ms, const unsigned char *p, siz
     if (at + size > n)
       return h5fail(nc, "object header message runs past its block");
     if (type == 0x10) {   /* continuation */
+      if (size < (size_t) (so + sl))
+        return h5fail(nc, "malformed continuation message");
       const uint64_t addr = la(p + at, so), len = le(p + at + so, sl);
       if (depth > 64 || len > (1u << 26))
         return h5fail(nc, "implausible object header continuation");
@@ -158,6 +161,8 @@ static int parse_block_v2(ncc_file *nc, h5_msgs *ms, const unsigned char *p, siz
     if (at + size > n)
       return h5fail(nc, "object header message runs past its chunk");
     if (type == 0x10) {
+      if (size < (size_t) (so + sl))
+        return h5fail(nc, "malformed continuation message");
       const uint64_t addr = la(p + at, so), len = le(p + at + so, sl);
       if (depth > 64 || len < 8 || len > (1u << 26))
         return h5fail(nc, "implausible object header continuation");
@@ -230,6 +235,7 @@ typedef struct {
   uint64_t self;
   heap_visit visit;
   void *user;
+  long blocks;                /* indirect blocks visited so far (a crafted file may point every child at one block) */
 } frheap;
 
 static int heap_direct(ncc_file *nc, frheap *h, uint64_t addr, uint64_t size) {
@@ -256,6 +262,8 @@ static int heap_indirect(ncc_file *nc, frheap *h, uint64_t addr, int nrows, int 
     return 1;
   if (depth > 8)
     return h5fail(nc, "fractal heap nested too deeply");
+  if (++h->blocks > 100000)
+    return h5fail(nc, "implausible number of fractal heap blocks");
   /* rows 0, 1: start_size; row r: start_size * 2^(r-1); rows whose blocks exceed max_direct hold indirect blocks */
   int max_direct_rows = 2;
   for (uint64_t s = h->start_size; s < h->max_direct; s *= 2)
@@ -779,11 +787,19 @@ static int parse_dataset(ncc_file *nc, const h5_msgs *ms, struct h5_dataset *d, 
         d->filter[d->nfilter++] = id;
       }
     } else if (m->type == 0x08) {   /* data layout */
+      /* every fixed-offset read below is checked against the message's length first */
+#define NEED(n)                                                      \
+  do {                                                               \
+    if ((size_t) (n) > m->size)                                      \
+      return h5fail(nc, "malformed data layout message");            \
+  } while (0)
+      NEED(2);
       const int version = p[0];
       have_layout = 1;
       if (version == 3 || version == 4) {
         d->layout = p[1];
         if (d->layout == 0) {
+          NEED(4);
           d->size = le(p + 2, 2);
           if (4 + d->size > m->size)
             return h5fail(nc, "compact data run past their message");
@@ -792,26 +808,34 @@ static int parse_dataset(ncc_file *nc, const h5_msgs *ms, struct h5_dataset *d, 
             return h5fail(nc, "out of memory");
           memcpy(d->compact, p + 4, (size_t) d->size);
         } else if (d->layout == 1) {
+          NEED(2 + so + sl);
           d->addr = la(p + 2, so);
           d->size = le(p + 2 + so, sl);
         } else if (d->layout == 2 && version == 3) {
+          NEED(3);
           const int nd = p[2];
           if (nd < 2 || nd > 9)
             return h5fail(nc, "chunk dimensionality out of range");
+          NEED(3 + so + 4 * nd);
+          d->chunk_nd = nd;
           d->index_addr = la(p + 3, so);
           for (int k = 0; k < nd; k++)
             d->chunk[k] = le(p + 3 + (size_t) so + 4 * (size_t) k, 4);
           d->chunk_index = 0;
         } else if (d->layout == 2) {
+          NEED(5);
           const int flags = p[2], nd = p[3], enc = p[4];
           if (nd < 2 || nd > 9 || enc < 1 || enc > 8)
             return h5fail(nc, "chunk dimensionality out of range");
+          NEED(5 + nd * enc + 1);
+          d->chunk_nd = nd;
           size_t at = 5;
           for (int k = 0; k < nd; k++, at += (size_t) enc)
             d->chunk[k] = le(p + at, enc);
           const int index = p[at++];
           if (index == 1) {   /* single chunk */
             if (flags & 2) {
+              NEED(at + (size_t) sl + 4);
               d->single_size = le(p + at, sl);
               at += (size_t) sl;
               d->single_mask = (uint32_t) le(p + at, 4);
@@ -826,26 +850,33 @@ static int parse_dataset(ncc_file *nc, const h5_msgs *ms, struct h5_dataset *d, 
           } else
             return h5fail(nc, "chunk index of this kind (extensible array / B-tree v2: datasets with unlimited dimensions "
                               "written with the latest file format) is not read");
+          NEED(at + (size_t) so);
           d->index_addr = la(p + at, so);
         } else
           return h5fail(nc, "virtual or unknown data layout");
       } else if (version == 1 || version == 2) {
+        NEED(8);
         const int nd = p[1];
         d->layout = p[2];
+        if (nd < 1 || nd > 8)
+          return h5fail(nc, "data layout dimensionality out of range");
         size_t at = 8;
         if (d->layout != 0) {
+          NEED(at + (size_t) so);
           d->addr = d->index_addr = la(p + at, so);
           at += (size_t) so;
         }
+        NEED(at + 4 * (size_t) nd + (d->layout == 1 ? 0 : 4));
         uint64_t total = 1;
-        for (int k = 0; k < nd && k < 9; k++) {
+        for (int k = 0; k < nd; k++) {
           d->chunk[k] = le(p + at + 4 * (size_t) k, 4);
           total *= d->chunk[k];
         }
         at += 4 * (size_t) nd;
-        if (d->layout == 2)
+        if (d->layout == 2) {
           d->chunk[nd] = le(p + at, 4);
-        else if (d->layout == 0) {
+          d->chunk_nd = nd + 1;
+        } else if (d->layout == 0) {
           d->size = le(p + at, 4);
           if (at + 4 + d->size > m->size)
             return h5fail(nc, "compact data run past their message");
@@ -858,8 +889,11 @@ static int parse_dataset(ncc_file *nc, const h5_msgs *ms, struct h5_dataset *d, 
         d->chunk_index = 0;
       } else
         return h5fail(nc, "unknown data layout version");
+#undef NEED
     }
   }
+  if (have_layout && have_space && d->layout == 2 && d->chunk_nd != d->rank + 1)
+    return h5fail(nc, "chunk dimensionality does not match the dataspace");
   *is_dataset = have_space && have_type && have_layout;
   if (*is_dataset && (t->size < 1 || t->size > 8) && nc_type_of(t))
     return h5fail(nc, "implausible element size");
@@ -1055,6 +1089,8 @@ static int assemble(ncc_file *nc, const struct h5_dataset *d, unsigned char *who
     const uint64_t nent = le(h + 8, nc->h5->sl), data = la(h + 8 + (size_t) nc->h5->sl, so);
     if (nent < total_chunks)
       return h5fail(nc, "fixed array chunk index is too short");
+    if (page_bits < 1 || page_bits > 63)
+      return h5fail(nc, "implausible fixed array page size");
     if (nent > ((uint64_t) 1 << page_bits))
       return h5fail(nc, "paged fixed array chunk indices are not read");
     if (data == UNDEF)
