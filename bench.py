@@ -257,26 +257,18 @@ def main():
     elif use_dist or args.rccl_single:
         # the library's own RCCL communicator: all-reduces on the simulation's stream, no Python in the data path
         from mptrac_amd import dist as mdist
-        ok = 1
+        # No silent fall-back: a run that was asked to reduce through RCCL and cannot, stops (every rank raises:
+        # the identifier broadcast has happened or failed on all of them alike).  --torch-allreduce is the
+        # explicit way to reduce through torch.distributed instead.
         try:
             mdist.init_rccl(sim, dist)
-        except Exception as exc:      # e.g. no librccl the loader can find: say so and keep the run alive
-            sys.stderr.write(f"rank {rank}: native RCCL communicator unavailable ({exc}); "
-                             "reducing through torch.distributed instead\n")
-            ok = 0
-        if use_dist and world > 1:    # every rank takes the same path
-            import torch
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        if not ok:
-            try:
-                sim.comm_destroy()
-            except Exception:
-                pass
-            if use_dist:
-                sim.set_allreduce(mdist.make_allreduce_hook("cuda"))
-        reduction = "rccl (native, on the step stream)" if ok else "torch.distributed callback"
+        except Exception as exc:
+            raise SystemExit(f"rank {rank}: native RCCL communicator unavailable ({exc}); "
+                             "pass --torch-allreduce to reduce through torch.distributed instead")
+        reduction = "rccl (native, on the step stream)"
+    rccl_ranks, rccl_rank = sim.comm_query()
+    if (use_dist and world > 1 and not args.torch_allreduce) and (rccl_ranks != world or rccl_rank != rank):
+        raise SystemExit(f"rank {rank}: the RCCL communicator reports rank {rccl_rank} of {rccl_ranks}, expected {rank} of {world}")
     if args.eager_meteo:
         sim.set_option("lazy_meteo", 0)
     if args.atomic_sums:
@@ -337,16 +329,20 @@ def main():
     wall = time.perf_counter() - t0
     launches, kernel_ms = (0, float("nan")) if args.no_kernel_events else sim.profile_end()
 
+    # launches of the step kernel family bracketed per time step (one; two where module_mixing splits the step)
+    launches_per_step = launches / max(args.steps, 1)
+    kernel_ms_per_step = kernel_ms / max(args.steps, 1)       # their SUM per step, not a mean over unlike kernels
+    per_rank_kernel_ms = [kernel_ms_per_step]
     if use_dist:
         import torch
         tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = tw.item()
-        km = torch.tensor([kernel_ms / max(launches, 1)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kernel_ms_per_launch = km.item()
-    else:
-        kernel_ms_per_launch = kernel_ms / max(launches, 1)
+        km = torch.zeros(world, dtype=torch.float64, device="cuda")
+        km[rank] = kernel_ms_per_step
+        dist.all_reduce(km, op=dist.ReduceOp.SUM)
+        per_rank_kernel_ms = [float(x) for x in km.tolist()]
+        kernel_ms_per_step = max(per_rank_kernel_ms)
 
     # sanity: every particle took every step and the output grid saw all of them
     g = sim.get_atm()
@@ -358,7 +354,12 @@ def main():
         value = n_total * args.steps / wall
         a_per, a_state, a_met = algorithmic_bytes_per_pstep(args.workload, met0, n_local)
         bytes_per_launch = a_per * n_local
-        achieved = bytes_per_launch / (kernel_ms_per_launch * 1e-3) / 1e9
+        # One fused launch per step: the roofline of that kernel.  A step of several unlike kernels (module_sort,
+        # module_mixing, the deposition launch: C5, C3x ...) has no single dominant launch to price -- its
+        # algorithmic bytes are set against the whole step's wall time.
+        one_launch = abs(launches_per_step - 1.0) < 1e-9 and not (ctl.get("sort_dt", 0) > 0 or "mixing_dt" in ctl)
+        roof_ms = kernel_ms_per_step if one_launch else wall / args.steps * 1e3
+        achieved = bytes_per_launch / (roof_ms * 1e-3) / 1e9
         traffic = valu_busy = fp64_frac = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -388,15 +389,20 @@ def main():
                        **({"particles_override": True} if args.particles else {}),
                        "grid": [met0.nx, met0.ny, met0.np], "dt_mod": dt,
                        "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce",
-                       "reduction": reduction,
+                       "reduction": reduction, "rccl_ranks": rccl_ranks,
                        "device_warmup": (f"{warm_steps} untimed steps of a scratch copy ({warm_ms:.0f} ms) before "
                                          "the timed region: settled clocks" if scratch is not None else "none")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "step_kernel (fused time step)", "kernel_ms": kernel_ms_per_launch,
+                         "kernel": ("step_kernel (fused time step)" if one_launch else
+                                    "whole time step (step kernel, module_sort, module_mixing, deposition launch ...): "
+                                    "wall time per step"),
+                         "kernel_ms": roof_ms, "step_kernel_ms_per_step": kernel_ms_per_step,
+                         "step_kernel_launches_per_step": launches_per_step,
+                         "kernel_ms_per_rank": per_rank_kernel_ms,
                          # the same kernel over the W warm-up launches, i.e. on a device that comes from idle
                          # (clock ramp, profiles/r03_clock_ramp.txt); not part of `achieved`
-                         "kernel_ms_from_idle": (cold_ms / cold_launches) if cold_launches else None,
+                         "kernel_ms_from_idle": (cold_ms / max(args.warmup, 1)) if cold_launches else None,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_particle_step": a_per,
                          # SURVEY 8(d) caveat: the fused step is fp64-VALU-bound, not HBM-bound; share of SIMD

@@ -303,6 +303,10 @@ int mphip_set_allreduce(mphip_ctx *ctx, mphip_allreduce_fn fn, void *user);
 int mphip_comm_unique_id(void *id128);
 int mphip_comm_init(mphip_ctx *ctx, int nranks, int rank, const void *id128);
 int mphip_comm_destroy(mphip_ctx *ctx);
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank): *nranks = 0 without a communicator.
+ * A launcher prints it next to its results so that a run that was meant to span N GPUs can be told from N
+ * independent ones (the reference prints its MPI rank / size the same way, trac.c:70-81). */
+int mphip_comm_query(mphip_ctx *ctx, int *nranks, int *rank);
 
 /* Tuning knobs without a reference counterpart.
  *   "locality_sort_interval" (default 60): the device keeps the particles stored

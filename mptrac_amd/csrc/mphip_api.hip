@@ -1312,6 +1312,8 @@ struct Rccl {
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;
+  int (*CommUserRank)(void *, int *) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   bool ok = false;
   std::string why;
@@ -1342,6 +1344,8 @@ Rccl &rccl() {
     r.AllReduce = (decltype(r.AllReduce)) sym("ncclAllReduce");
     r.GroupStart = (decltype(r.GroupStart)) sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd)) sym("ncclGroupEnd");
+    r.CommCount = (decltype(r.CommCount)) sym("ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank)) sym("ncclCommUserRank");
     r.GetErrorString = (decltype(r.GetErrorString)) sym("ncclGetErrorString");
     r.ok = r.why.empty();
   });
@@ -2880,6 +2884,19 @@ int mphip_comm_destroy(mphip_ctx *ctx) {
   }
   ctx->comm_ranks = 1;
   ctx->comm_rank = 0;
+  return 0;
+}
+
+int mphip_comm_query(mphip_ctx *ctx, int *nranks, int *rank) {
+  if (!ctx || !nranks || !rank)
+    return 1;
+  *nranks = 0;
+  *rank = 0;
+  if (!ctx->comm)
+    return 0;
+  Rccl &R = rccl();
+  RCCLCHK(R.CommCount(ctx->comm, nranks));
+  RCCLCHK(R.CommUserRank(ctx->comm, rank));
   return 0;
 }
 

@@ -108,6 +108,7 @@ def load(build=True):
     L.mphip_comm_unique_id.argtypes = [C.c_void_p]
     L.mphip_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.mphip_comm_destroy.argtypes = [C.c_void_p]
+    L.mphip_comm_query.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mphip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
     L.mphip_synchronize.argtypes = [C.c_void_p]
     L.mphip_profile_begin.argtypes = [C.c_void_p]
@@ -411,6 +412,12 @@ class Simulation:
 
     def comm_destroy(self):
         self._chk(self.L.mphip_comm_destroy(self.h))
+
+    def comm_query(self):
+        """(ranks, rank) as the RCCL communicator reports them; (0, 0) without one."""
+        n, r = C.c_int(), C.c_int()
+        self._chk(self.L.mphip_comm_query(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
 
     def profile_begin(self):
         self._chk(self.L.mphip_profile_begin(self.h))

@@ -32,6 +32,13 @@ def test_bench_prints_the_contract_line(extra):
     assert r["kernel_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-9 * r["achieved"]
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.02 and "traffic" in r
+    # one rank: no communicator; the per-rank kernel times the driver reads are there
+    assert cfg["rccl_ranks"] == 0 and len(r["kernel_ms_per_rank"]) == 1
+    if "C5" in extra:   # a step of several unlike kernels is priced as a whole (wall time per step)
+        assert r["step_kernel_launches_per_step"] == 2 and abs(r["kernel_ms"] - d["ms_per_step"]) <= 1e-9 * r["kernel_ms"]
+        assert r["step_kernel_ms_per_step"] < r["kernel_ms"]
+    else:
+        assert r["step_kernel_launches_per_step"] == 1 and r["kernel_ms"] == r["step_kernel_ms_per_step"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "particle-steps/s" and c["cores"] >= 1 and c["value"] > 1e4
     assert "sample" in c and c["value_1_thread"] > 0
