@@ -199,6 +199,13 @@ def main():
                          "10-25 %% slower for its first ~30 ms under load (power management: 0.99 -> 1.13 -> 0.88 ms, "
                          "profiles/r03_clock_ramp.txt); a production run is thousands of steps long, so the timed "
                          "steps are taken at the settled clocks")
+    ap.add_argument("--multi-step", choices=("on", "off"), default="on",
+                    help="on: the K timed steps go to the library as ONE call (mphip_run_timesteps: the reference's time "
+                         "loop, trac.c:204-226; steps with nothing scheduled between them -- no module_sort, mixing, "
+                         "output -- share a kernel launch in which every particle takes its steps one after the other: "
+                         "same bits, the particle state and the meteo lines it uses stay in the caches from step to "
+                         "step).  off: K mphip_run_timestep calls, one launch per step.  The line reports the step "
+                         "kernel's time under both")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="(diagnostic) do not bracket the step kernel with HIP events; roofline is then not reported")
     args = ap.parse_args()
@@ -226,7 +233,7 @@ def main():
             hip.load()
         dist.barrier()
 
-    steps_total = args.warmup + args.steps + 1
+    steps_total = args.warmup + args.steps + 1 + 10     # (+ the ten single-launch steps behind the timed region)
     ctl, clim, met0, met1, atm, n_local, n_total = build_inputs(args.workload, rank, world, steps_total, particles=args.particles)
     sim = hip.Simulation(ctl, clim, met0, met1, atm, device=local_rank,
                          shard=(rank * n_local, (rank + 1) * n_local), n_total=n_total)
@@ -320,10 +327,15 @@ def main():
 
     if not args.no_kernel_events:
         sim.profile_begin()
+    batched = args.multi_step == "on"
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.run_timestep(k * dt)
-        k += 1
+    if batched:
+        sim.run_timesteps(k * dt, args.steps)      # exactly K steps: t = k dt, (k + 1) dt, ...
+        k += args.steps
+    else:
+        for _ in range(args.steps):
+            sim.run_timestep(k * dt)
+            k += 1
     cnt, mean, _sig = sim.grid_sums((k - 1) * dt)    # gridded output + all-reduce
     barrier()
     wall = time.perf_counter() - t0
@@ -344,6 +356,18 @@ def main():
         per_rank_kernel_ms = [float(x) for x in km.tolist()]
         kernel_ms_per_step = max(per_rank_kernel_ms)
 
+    # outside the timed region: the step kernel with one launch per time step (what --multi-step off times)
+    single_ms = None
+    if not args.no_kernel_events:
+        sim.set_option("multi_step", 0)
+        sim.profile_begin()
+        for _ in range(min(10, args.steps)):
+            sim.run_timestep(k * dt)
+            k += 1
+        sim.synchronize()
+        n1, ms1 = sim.profile_end()
+        single_ms = ms1 / max(1, min(10, args.steps))
+
     # sanity: every particle took every step and the output grid saw all of them
     g = sim.get_atm()
     assert np.all(g["time"] == (k - 1) * dt), "not all particles advanced"
@@ -357,7 +381,7 @@ def main():
         # One fused launch per step: the roofline of that kernel.  A step of several unlike kernels (module_sort,
         # module_mixing, the deposition launch: C5, C3x ...) has no single dominant launch to price -- its
         # algorithmic bytes are set against the whole step's wall time.
-        one_launch = abs(launches_per_step - 1.0) < 1e-9 and not (ctl.get("sort_dt", 0) > 0 or "mixing_dt" in ctl)
+        one_launch = launches_per_step <= 1.0 + 1e-9 and not (ctl.get("sort_dt", 0) > 0 or "mixing_dt" in ctl)
         roof_ms = kernel_ms_per_step if one_launch else wall / args.steps * 1e3
         achieved = bytes_per_launch / (roof_ms * 1e-3) / 1e9
         traffic = valu_busy = fp64_frac = None
@@ -390,6 +414,8 @@ def main():
                        "grid": [met0.nx, met0.ny, met0.np], "dt_mod": dt,
                        "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce",
                        "reduction": reduction, "rccl_ranks": rccl_ranks,
+                       "time_loop": ("one mphip_run_timesteps call for the K steps (steps with nothing between them "
+                                     "share a launch)" if batched else "K mphip_run_timestep calls"),
                        "device_warmup": (f"{warm_steps} untimed steps of a scratch copy ({warm_ms:.0f} ms) before "
                                          "the timed region: settled clocks" if scratch is not None else "none")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -400,6 +426,8 @@ def main():
                          "kernel_ms": roof_ms, "step_kernel_ms_per_step": kernel_ms_per_step,
                          "step_kernel_launches_per_step": launches_per_step,
                          "kernel_ms_per_rank": per_rank_kernel_ms,
+                         # the same steps as one launch per time step (rank 0, ten steps behind the timed region)
+                         "kernel_ms_one_launch_per_step": single_ms,
                          # the same kernel over the W warm-up launches, i.e. on a device that comes from idle
                          # (clock ramp, profiles/r03_clock_ramp.txt); not part of `achieved`
                          "kernel_ms_from_idle": (cold_ms / max(args.warmup, 1)) if cold_launches else None,

@@ -267,6 +267,12 @@ int mphip_get_iso(mphip_ctx *ctx, double *iso_var);
  * of air (qnt_m, qnt_vmr, qnt_aoa) -- in one pass; the chemistry and radionuclide quantities of the
  * reference's list (mptrac.c:5223-5230) are not part of this back end and are left untouched. */
 int mphip_run_timestep(mphip_ctx *ctx, double t);
+/* The time loop of the reference's driver (trac.c:204-226: `for (t = t_start; ...; t += direction * dt_mod)
+ * mptrac_run_timestep(...)`) for `nsteps` consecutive steps starting at t_first: same results as nsteps calls of
+ * mphip_run_timestep.  Steps with nothing scheduled between them may share one kernel launch (option
+ * "multi_step" = most steps per launch, default 64; 0 = never) -- what small particle counts need, where a time
+ * step is shorter than a launch.  A driver calls it for the steps up to its next output. */
+int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps);
 /* One reference module_* on its own (same state hand-over through the device
  * copy of cache->dt); `modules` is one MPHIP_MOD_* bit or an OR of the
  * per-particle bits in reference order. */

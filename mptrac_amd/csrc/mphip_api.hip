@@ -156,6 +156,7 @@ struct mphip_ctx {
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;
   int split_step = 0;                 // experiment: advection and the modules behind it as two launches
+  int multi_step = 64;                // mphip_run_timesteps: most time steps per launch (0 = always one by one)
   bool force_generic = false;
   bool compact_depo = true;           // deposition-only launches through depo_kernel (0: the fused kernel's tail)
   int sort_bits = 0;                  // digit width of the radix sort (0 = fewest passes; 8, 9, 10: tuning / tests)
@@ -702,8 +703,10 @@ int check_fields(mphip_ctx *ctx, unsigned mask) {
   return 0;
 }
 
+// nsteps > 1: that many consecutive time steps in one launch (kMultiStep instantiations; the caller has checked that
+// one exists for this module set, multi_step_mask)
 int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint64_t ctr_meso, uint64_t ctr_conv,
-                uint64_t ctr_pbl = 0) {
+                uint64_t ctr_pbl = 0, int nsteps = 1, double t_stride = 0, uint64_t ctr_stride = 0) {
   if (ctx->np == 0)
     return 0;
   if (ensure_packed(ctx) || check_fields(ctx, mask))
@@ -736,6 +739,9 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   S.ctr_meso = ctr_meso;
   S.ctr_conv = ctr_conv;
   S.ctr_pbl = ctr_pbl;
+  S.nsteps = nsteps;
+  S.t_stride = t_stride;
+  S.ctr_stride = ctr_stride;
   const size_t lds = axes_lds_bytes(ctx) + sizeof(DevClim) + sizeof(kLogTabHost);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->prof) {
@@ -776,7 +782,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     else if (req == kDiffConvSediOnly && !(mask & kBound))
       sel = kDiffConvSediOnly;
     else if (exact && !(mask & kBound))
-      sel = req | scheme;
+      sel = req | scheme | (nsteps > 1 ? kMultiStep : 0u);
     else if ((req & ~kOptionalModules) == kAdv)
       sel = kAdvDiffConvSedi | kGated | scheme;
   }
@@ -812,8 +818,14 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiffConvSedi | kGated | kTwoStage)
     STEP_CASE(kTailOnly)
     STEP_CASE(kDiffConvSediOnly)
+    STEP_CASE(kAdv | kMultiStep)
+    STEP_CASE(kAdvTurb | kMultiStep)
+    STEP_CASE(kAdvDiff | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kMultiStep)
 #undef STEP_CASE
   default:
+    if (nsteps > 1)
+      return fail(ctx, "internal: no multi-step instantiation for this module set");
     if (rare || ctx->force_generic)
       hipLaunchKernelGGL(step_kernel<kMaskGeneric>, dim3(nb), dim3(256), lds, ctx->stream, S);
     else if (ml_fast)
@@ -2663,6 +2675,102 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   return meteo_now ? schedule_meteo(ctx) : 0;
 }
 
+// mphip_run_timesteps: n calls of mphip_run_timestep at t_first, t_first + stride, ... (stride = direction * DT_MOD,
+// accumulated as the loop of trac.c:208 accumulates it).  Runs of steps with nothing between them -- no module_sort,
+// no mixing, no module_meteo, no rarely used module, convection (if any) in every step, the internal re-sort not
+// due -- and a lean instantiation of their module set go to the device as ONE launch in which every particle takes
+// its steps one after the other: at small particle counts a step is shorter than a kernel launch.  Everything else
+// takes the steps one by one; the results are the same either way (tests/test_gpu_parity.py).
+int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
+  if (!ctx)
+    return 1;
+  if (!ctx->have_ctl)
+    return fail(ctx, "control parameters were not uploaded");
+  if (nsteps < 0)
+    return fail(ctx, "mphip_run_timesteps: negative step count");
+  const mphip_ctl_t &c = ctx->ctl;
+  const double stride = c.direction * c.dt_mod;
+  double t = t_first;
+  int done = 0;
+  while (done < nsteps) {
+    // how many steps from here on can share a launch?
+    int batch = 0;
+    const bool meteo = meteo_requested(c);   // (module_meteo without a quantity to fill does nothing)
+    const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !(c.sort_dt > 0) && !(meteo && c.met_dt_out > 0)
+      && !(c.mixing_trop >= 0 && c.mixing_strat >= 0) && !(c.isosurf >= 1 && c.isosurf <= 4)
+      && !(c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1) && !(c.diffusion && c.turb_pbl_scheme == 1)
+      && !((c.conv_mix_pbl || c.conv_cape >= 0) && c.conv_dt > 0) && c.advect == 4
+      && !(c.advect_vert_coord >= 1 && c.advect_vert_coord <= 3) && !(meteo && ctx->meteo_pending) && !ctx->fused_perm
+      && !ctx->force_generic && !ctx->split_step;
+    if (quiet) {
+      batch = nsteps - done;
+      if (ctx->locality_interval > 0)
+        batch = std::min(batch, ctx->locality_interval - ctx->steps_since_resort);
+      batch = std::min(batch, ctx->multi_step);
+    }
+    if (batch < 2) {
+      if (mphip_run_timestep(ctx, t))
+        return 1;
+      t += stride;
+      done++;
+      continue;
+    }
+    // the module set and the counters of mphip_run_timestep, for `batch` steps at once
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t n = (uint64_t) ctx->np_total;
+    unsigned mask = MPHIP_MOD_TIMESTEPS | MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_POSITION2;
+    uint64_t per_step = 0, off_turb = 0, off_meso = 0, off_conv = 0;
+    if (c.diffusion
+        && (c.turb_dx_pbl > 0 || c.turb_dz_pbl > 0 || c.turb_dx_trop > 0 || c.turb_dz_trop > 0 || c.turb_dx_strat > 0
+            || c.turb_dz_strat > 0)) {
+      mask |= MPHIP_MOD_DIFF_TURB;
+      off_turb = per_step;
+      per_step += 3 * n + 1;
+    }
+    if (c.diffusion && (c.turb_mesox > 0 || c.turb_mesoz > 0)) {
+      mask |= MPHIP_MOD_DIFF_MESO;
+      off_meso = per_step;
+      per_step += 3 * n + 1;
+    }
+    if (c.conv_mix_pbl || c.conv_cape >= 0) {
+      mask |= MPHIP_MOD_CONVECTION;
+      off_conv = per_step;
+      per_step += n + 1;
+    }
+    if (c.qnt_rp >= 0 && c.qnt_rhop >= 0)
+      mask |= MPHIP_MOD_SEDI;
+    const unsigned movers = mask;
+    const bool exact = movers == kAdv || movers == kAdvTurb || movers == kAdvDiff || movers == kAdvDiffConvSedi;
+    if (c.qnt_loss_rate >= 0)
+      mask |= MPHIP_MOD_LOSS_ZERO;
+    if (c.tdec_trop > 0 && c.tdec_strat > 0)
+      mask |= MPHIP_MOD_DECAY;
+    if ((c.wet_depo_ic_a > 0 || c.wet_depo_ic_h[0] > 0) && (c.wet_depo_bc_a > 0 || c.wet_depo_bc_h[0] > 0))
+      mask |= MPHIP_MOD_WET_DEPO;
+    if (c.dry_depo_vdep > 0)
+      mask |= MPHIP_MOD_DRY_DEPO;
+    if (!exact) {     // no multi-step instantiation of this module set
+      if (mphip_run_timestep(ctx, t))
+        return 1;
+      t += stride;
+      done++;
+      continue;
+    }
+    if (flush_meteo(ctx))
+      return 1;
+    if (launch_step(ctx, mask, t, ctx->rng_ctr + off_turb, ctx->rng_ctr + off_meso, ctx->rng_ctr + off_conv, 0, batch, stride,
+                    per_step))
+      return 1;
+    ctx->rng_ctr += per_step * (uint64_t) batch;
+    if (ctx->steps_since_resort < (1 << 29))
+      ctx->steps_since_resort += batch;
+    for (int k = 0; k < batch; k++)
+      t += stride;
+    done += batch;
+  }
+  return 0;
+}
+
 int mphip_module(mphip_ctx *ctx, unsigned modules, double t) {
   if (ctx && ahead_drop(ctx))
     return 1;
@@ -2927,6 +3035,12 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
   }
   if (strcmp(name, "pin_host_atm") == 0) {   // page-lock the arrays handed to mphip_update_atm / mphip_get_atm
     ctx->pin_host_atm = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "multi_step") == 0) {   // mphip_run_timesteps: most steps per launch, 0 = one launch per step
+    if (value < 0 || value > 4096)
+      return fail(ctx, "multi_step must be in 0 ... 4096");
+    ctx->multi_step = (int) value;
     return 0;
   }
   if (strcmp(name, "split_step") == 0) {

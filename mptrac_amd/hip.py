@@ -100,6 +100,7 @@ def load(build=True):
     L.mphip_update_iso.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int]
     L.mphip_get_iso.argtypes = [C.c_void_p, _dp]
     L.mphip_run_timestep.argtypes = [C.c_void_p, C.c_double]
+    L.mphip_run_timesteps.argtypes = [C.c_void_p, C.c_double, C.c_int]
     L.mphip_module.argtypes = [C.c_void_p, C.c_uint, C.c_double]
     L.mphip_get_sort.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
     L.mphip_grid_sums.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int), _dp, _dp]
@@ -381,6 +382,10 @@ class Simulation:
 
     def synchronize(self):
         self._chk(self.L.mphip_synchronize(self.h))
+
+    def run_timesteps(self, t_first, nsteps):
+        """nsteps consecutive time steps starting at t_first (mphip_run_timesteps)."""
+        self._chk(self.L.mphip_run_timesteps(self.h, float(t_first), int(nsteps)))
 
     def set_option(self, name, value):
         self._chk(self.L.mphip_set_option(self.h, name.encode(), float(value)))

@@ -42,7 +42,27 @@ static int g_nq;                        /* ctl->nq of the last control upload */
 static int g_isosurf;                   /* ctl->isosurf of the last control upload */
 static int g_meteo_fields;              /* a module_meteo quantity is requested: upload the fields only it reads */
 
+/* Time steps handed over by mptrac_run_timestep wait here while they follow each other at the model's stride;
+ * they go to the device as one mphip_run_timesteps call -- steps with nothing scheduled between them share a kernel
+ * launch there -- as soon as anything else needs the device (every other call of this layer goes through HIP()),
+ * the run of steps breaks, or the list is full.  The caller's loop stays the reference's: one call per step.
+ * HIP_STEP_BATCH in the environment sets the most steps held back (default 64; 0 or 1: every step at once). */
+static struct {
+  int n, cap;
+  double t_first, t_next;
+} g_steps = { 0, -1, 0, 0 };
+
+static void flush_steps(void) {
+  if (!g_steps.n)
+    return;
+  const int n = g_steps.n;
+  g_steps.n = 0;
+  if (mphip_run_timesteps(g_ctx, g_steps.t_first, n) != 0)
+    ERRMSG("HIP back end: %s", mphip_last_error(g_ctx));
+}
+
 #define HIP(call) {                                                     \
+    flush_steps();                                                      \
     if ((call) != 0)                                                    \
       ERRMSG("HIP back end: %s", mphip_last_error(g_ctx));              \
   }
@@ -79,6 +99,7 @@ void mptrac_free(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t *met0, met_t *m
     pthread_join(g_ahead.thread, NULL);
   g_ahead.active = g_ahead.joined = 0;
   if (g_ctx) {
+    flush_steps();
     mphip_destroy(g_ctx);
     g_ctx = NULL;
   }
@@ -1894,6 +1915,7 @@ static void poll_read_ahead(int wait) {
   if (g_ahead.file_ok) {
     mphip_met_t m;
     describe_met(g_ahead.met, &m);
+    flush_steps();
     if (mphip_prefetch_met(g_ctx, &m) != 0) {
       WARN("Meteo read-ahead: %s", mphip_last_error(g_ctx));
     } else
@@ -2143,7 +2165,19 @@ void mptrac_run_timestep(ctl_t *ctl, cache_t *cache, clim_t *clim, met_t **met0,
       ERRMSG("Could not read any data!");
     HIP(mphip_update_iso(g_ctx, NULL, cache->iso_ts, cache->iso_ps, cache->iso_n));
   }
-  HIP(mphip_run_timestep(g_ctx, t));
+  /* queue the step (see g_steps) */
+  if (g_steps.cap < 0) {
+    const char *e = getenv("HIP_STEP_BATCH");
+    g_steps.cap = e ? atoi(e) : 64;
+  }
+  if (g_steps.n && (t != g_steps.t_next || g_steps.n >= g_steps.cap))
+    flush_steps();
+  if (!g_steps.n)
+    g_steps.t_first = t;
+  g_steps.n++;
+  g_steps.t_next = t + ctl->direction * ctl->dt_mod;
+  if (g_steps.cap <= 1)
+    flush_steps();
 }
 
 /* -------------------------------------------------------------------------- */

@@ -38,7 +38,9 @@ def test_bench_prints_the_contract_line(extra):
         assert r["step_kernel_launches_per_step"] == 2 and abs(r["kernel_ms"] - d["ms_per_step"]) <= 1e-9 * r["kernel_ms"]
         assert r["step_kernel_ms_per_step"] < r["kernel_ms"]
     else:
-        assert r["step_kernel_launches_per_step"] == 1 and r["kernel_ms"] == r["step_kernel_ms_per_step"]
+        # (2e5 particles: the K steps go to the library as one call and share launches)
+        assert r["step_kernel_launches_per_step"] <= 1 and r["kernel_ms"] == r["step_kernel_ms_per_step"]
+        assert "mphip_run_timesteps" in cfg["time_loop"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "particle-steps/s" and c["cores"] >= 1 and c["value"] > 1e4
     assert "sample" in c and c["value_1_thread"] > 0

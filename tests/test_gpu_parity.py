@@ -1566,3 +1566,43 @@ def test_long_run_400_steps_with_prefetched_handovers():
     assert imet == 3
     _compare(o, s)
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["advect", "turb", "diff", "conv_sedi", "full"])
+def test_run_timesteps_equals_the_step_by_step_loop(case):
+    """mphip_run_timesteps (the reference's time loop, trac.c:204-226, as one call): runs of steps with nothing
+    scheduled between them share a kernel launch in which every particle takes its steps one after the other;
+    same bits as one mphip_run_timestep per step -- state, uvwp and the counter of the random numbers --,
+    whether the batches are long, short, cut by the internal re-sort, or (module sets with module_sort / mixing:
+    "full") not possible at all."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=5003)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    times = cases.step_times(o.ctl)
+    runs = {}
+    for name, multi, interval in (("loop", None, 4), ("batched", 64, 4), ("pairs", 2, 4), ("no_resort", 64, 0), ("off", 0, 4)):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("locality_sort_interval", interval)
+        s.timesteps_init(0.0, 0.0)
+        if multi is None:
+            for t in times[:12]:
+                s.run_timestep(t)
+        else:
+            s.set_option("multi_step", multi)
+            s.run_timestep(times[0])
+            s.run_timesteps(times[1], 7)
+            s.run_timesteps(times[8], 4)
+        runs[name] = s.state()
+        runs[name]["ctr"] = s.get_cache()["rng_ctr"]
+        s.close()
+    for name in ("batched", "pairs", "no_resort", "off"):
+        for k in ("time", "lon", "lat", "p", "uvwp", "q"):
+            assert np.array_equal(runs[name][k], runs["loop"][k], equal_nan=True), (name, k)
+        assert runs[name]["ctr"] == runs["loop"]["ctr"], name
+    for t in times[:12]:
+        o.run_timestep(t)
+    r = o.state()
+    assert np.array_equal(runs["batched"]["time"], r["time"])
+    for k in ("lon", "lat", "p"):
+        assert cases.rel_err(runs["batched"][k], r[k]) <= TOL, k
