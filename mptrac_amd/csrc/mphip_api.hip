@@ -82,6 +82,8 @@ struct mphip_ctx {
   // launch that the next time step would overwrite unseen is dropped
   bool fuse_sort = true;              // module_sort's gather of time, p, lon, lat inside the following step launch
   const int *fused_perm = nullptr;    // set by do_sort, consumed by the next launch_step
+  bool fuse_quantities = true;        // ... which then moves the quantity arrays too (option fuse_sort_quantities)
+  bool fused_quantities = false;
   bool lazy_meteo = true;
   bool meteo_pending = false;
   bool pin_host_atm = false;          // page-lock the caller's particle arrays (persistent atm_t of a C caller only)
@@ -277,6 +279,9 @@ DevAtm dev_atm(const mphip_ctx *c) {
   a.s_p = c->d_alt[1];
   a.s_lon = c->d_alt[2];
   a.s_lat = c->d_alt[3];
+  a.nq_perm = c->fused_perm && c->fused_quantities ? c->nq : 0;
+  for (int iq = 0; iq < MPHIP_NQ_MAX; iq++)
+    a.s_q[iq] = iq < c->nq ? c->d_alt[4 + iq] : nullptr;
   a.np = c->np;
   a.ip0 = c->ip0;
   a.np_total = c->np_total;
@@ -1131,8 +1136,15 @@ int sort_keys(mphip_ctx *ctx, int tile, const double *timestep_t, const BoxArgs 
   TimestepArgs ts = { (double) ctx->ctl.direction, ctx->ctl.t_start, ctx->ctl.t_stop, timestep_t ? *timestep_t : 0.0 };
   BoxArgs none;
   memset(&none, 0, sizeof(none));
-  hipLaunchKernelGGL(sort_key_kernel, dim3(grid_for(ctx->np)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
-                     tile_zbits(ctx, tile), ctx->d_keys[0], (int *) nullptr, ts, timestep_t ? ctx->d_dt : nullptr, box ? *box : none);
+  const bool lean = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV && !ctx->force_generic;
+  if (lean)
+    hipLaunchKernelGGL(sort_key_kernel<true>, dim3(grid_for(ctx->np)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
+                       tile_zbits(ctx, tile), ctx->d_keys[0], (int *) nullptr, ts, timestep_t ? ctx->d_dt : nullptr,
+                       box ? *box : none);
+  else
+    hipLaunchKernelGGL(sort_key_kernel<false>, dim3(grid_for(ctx->np)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
+                       tile_zbits(ctx, tile), ctx->d_keys[0], (int *) nullptr, ts, timestep_t ? ctx->d_dt : nullptr,
+                       box ? *box : none);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1288,7 +1300,9 @@ int do_sort(mphip_ctx *ctx, const double *timestep_t = nullptr) {
       g.in8[k] = ctx->d_arr[4 + k];
       g.out8[k] = ctx->d_alt[4 + k];
     }
-    if (ctx->nq > 0) {
+    // ... or not even those: option fuse_sort_quantities (default) lets the step launch move them as well
+    ctx->fused_quantities = ctx->fuse_quantities;
+    if (ctx->nq > 0 && !ctx->fused_quantities) {
       hipLaunchKernelGGL(perm_gather_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], n, pg);
       HIPCHK(hipGetLastError());
     }
@@ -3041,6 +3055,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (value < 0 || value > 4096)
       return fail(ctx, "multi_step must be in 0 ... 4096");
     ctx->multi_step = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "fuse_sort_quantities") == 0) {   // 0: module_sort moves the quantity arrays in a pass of its own
+    ctx->fuse_quantities = value != 0;
     return 0;
   }
   if (strcmp(name, "split_step") == 0) {

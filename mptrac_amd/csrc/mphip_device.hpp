@@ -107,6 +107,8 @@ struct DevAtm {
   // of the arrays below and written to slot i of time / p / lon / lat (NULL = read where it is written)
   const int *perm;
   const double *s_time, *s_p, *s_lon, *s_lat;
+  const double *s_q[MPHIP_NQ_MAX];   // ... and the quantity arrays (nq_perm of them: 0 = they were moved by a pass of their own)
+  int nq_perm;
   long long np;                  // particles owned by this context
   long long ip0;                 // global index of the first one
   long long np_total;            // particles of the whole simulation

@@ -579,6 +579,8 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & MPHIP_MOD_ADVECT) |
       P.lon = a.s_lon[src];
       P.lat = a.s_lat[src];
       P.p = a.s_p[src];
+      for (int k = 0; k < a.nq_perm; k++)   // the quantities move here too (what follows reads them at slot i)
+        a.q[k][i] = a.s_q[k][src];
     } else {
       P.time = ld_state(&a.time[i]);
       P.lon = ld_state(&a.lon[i]);
@@ -1029,6 +1031,9 @@ __host__ __device__ __forceinline__ uint32_t tile_z_order(uint32_t tx, uint32_t 
   return z | ((tx >> m) | (ty >> m)) << (2 * m);   // (only one of the two has bits left)
 }
 
+// LEAN: lat/lon grid with the pressure look-up table (launch_step's condition): the indices come from
+// raw_cell_fast -- first guess, verified, general search for the rare miss -- instead of three bisections
+template <bool LEAN>
 __global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, int zbits, uint32_t *__restrict__ keys,
                                 int *__restrict__ idx, const TimestepArgs ts, double *__restrict__ dt_out,
                                 const BoxArgs box) {
@@ -1058,9 +1063,18 @@ __global__ void sort_key_kernel(DevMet M, DevAtm a, int tile, int zbits, uint32_
       lon = lon2;
       lat = lat2;
     }
-    const int ix = locate_reg(A.lon, M.nx, lon);
-    const int iy = locate_lat(M, A, lat);
-    const int iz = locate_p(M, A, a.p[i]);
+    int ix, iy, iz;
+    if (LEAN) {
+      Stencil s;
+      raw_cell_fast(M, A, lon, lat, a.p[i], s);
+      ix = s.ix;
+      iy = s.iy;
+      iz = s.ip;
+    } else {
+      ix = locate_reg(A.lon, M.nx, lon);
+      iy = locate_lat(M, A, lat);
+      iz = locate_p(M, A, a.p[i]);
+    }
     if (tile == 0)
       keys[i] = (uint32_t) ((ix * M.ny + iy) * M.np + iz);
     else {
