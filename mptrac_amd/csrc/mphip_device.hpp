@@ -320,7 +320,7 @@ __device__ __forceinline__ double dx2deg(double dx, double lat) {   // mptrac.h:
 #if MPHIP_EXACT_DIV
   return dx * 180. / (kPi * kRE * cos(deg2rad(lat)));
 #else
-  return (dx * 180.) * frcp(kPi * kRE * cos_latitude(deg2rad(lat)));   // (as DegPerMetre of the lean kernels: same bits)
+  return (dx * 180.) * frcp(kPi * kRE * cos_latitude(deg2rad(lat)));
 #endif
 }
 
@@ -333,12 +333,32 @@ __device__ __forceinline__ double dy2deg(double dy) {   // mptrac.h:922
 #endif
 }
 
-__device__ __forceinline__ double dx2coord(int coord_type, double dx, double lat) {   // mptrac.h:966
+// DX2COORD / DY2COORD (mptrac.h:966, 989) of a distance in metres.  The default build folds the constant factors of
+// dx / 1000 * 180 / (pi RE cos(lat)) into one (kMetresToDeg = 180e-3, kDegPerMetreY = 180e-3 / (pi RE)): one
+// rounding instead of three on a displacement of metres -- the lean kernels (DegPerMetre) form the same products
+constexpr double kMetresToDeg = 1e-3 * 180.;
+constexpr double kDegPerMetreY = 1e-3 * 180. / (kPi * kRE);
+
+__device__ __forceinline__ double dx2coord(int coord_type, double dx, double lat) {
+#pragma clang fp contract(off)
+#if MPHIP_EXACT_DIV
   return coord_type == 0 ? dx2deg(div_const(dx, 1000.0, 1e-3), lat) : dx;
+#else
+  if (coord_type != 0)
+    return dx;
+  if (lat < -89.999 || lat > 89.999)
+    return 0;
+  return dx * (kMetresToDeg * frcp(kPi * kRE * cos_latitude(deg2rad(lat))));
+#endif
 }
 
-__device__ __forceinline__ double dy2coord(int coord_type, double dy) {   // mptrac.h:989
+__device__ __forceinline__ double dy2coord(int coord_type, double dy) {
+#pragma clang fp contract(off)
+#if MPHIP_EXACT_DIV
   return coord_type == 0 ? dy2deg(div_const(dy, 1000.0, 1e-3)) : dy;
+#else
+  return coord_type == 0 ? dy * kDegPerMetreY : dy;
+#endif
 }
 
 __device__ __forceinline__ double dz2dp(double dz, double p) {   // mptrac.h:941
@@ -1370,6 +1390,15 @@ __device__ __forceinline__ void normal_triple(const double *__restrict__ ltab, u
   r0 = odd ? oa : ea;
   r1 = odd ? eb : oa;
   r2 = odd ? ob : eb;
+}
+
+// rs[3g + 2] alone: the second Box-Muller pair of the triple
+__device__ __forceinline__ double normal_third(const double *__restrict__ ltab, uint64_t c0, uint64_t g) {
+  const uint64_t i0 = 3 * g;
+  const uint64_t y = (c0 + (i0 & ~1ull)) * kSquaresKey;
+  double eb, ob;
+  normal_pair_from(ltab, y + 2 * kSquaresKey, eb, ob);
+  return (i0 & 1) ? ob : eb;
 }
 
 // ---- per-particle state -----------------------------------------------------
@@ -2416,20 +2445,22 @@ struct DegPerMetre {
 };
 
 __device__ __forceinline__ DegPerMetre deg_per_metre(double lat) {
+#pragma clang fp contract(off)
   DegPerMetre d;
   const double c = kPi * kRE * cos_latitude_k(deg2rad(lat));
-  d.kx = (lat < -89.999 || lat > 89.999) ? 0.0 : frcp(c);
+  d.kx = (lat < -89.999 || lat > 89.999) ? 0.0 : kMetresToDeg * frcp(c);
   return d;
 }
 
+// (contraction off: the product is rounded before the caller adds it, as in dx2coord / dy2coord of the general code)
 __device__ __forceinline__ double dx2deg_k(const DegPerMetre &d, double dx_metres) {
 #pragma clang fp contract(off)
-  return ((dx_metres * 1e-3) * 180.) * d.kx;
+  return dx_metres * d.kx;
 }
 
 __device__ __forceinline__ double dy2deg_k(double dy_metres) {
 #pragma clang fp contract(off)
-  return ((dy_metres * 1e-3) * 180.) * (1.0 / (kPi * kRE));
+  return dy_metres * kDegPerMetreY;
 }
 
 // ---- stencil set-up ---------------------------------------------------------
@@ -2796,25 +2827,31 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
 
   const TropoTime tt = tropo_time(C, P.time);
   const double wpbl = pbl_weight(ctl, P.p, pbl, ps);
-  const double wtrop = tropo_weight_pt(tropo_pressure_at(ctl, C, tt, P.lat), P.p) * (1.0 - wpbl);
+  double pt = tropo_pressure_at(ctl, C, tt, P.lat);
+  const double wtrop = tropo_weight_pt(pt, P.p) * (1.0 - wpbl);
   const double wstrat = 1.0 - wpbl - wtrop;
   const double Kx = wpbl * ctl.turb_dx_pbl + wtrop * ctl.turb_dx_trop + wstrat * ctl.turb_dx_strat;
   const double Kz = wpbl * ctl.turb_dz_pbl + wtrop * ctl.turb_dz_trop + wstrat * ctl.turb_dz_strat;
   const double dt_abs = fabs(P.dt);
 
-  double rs0, rs1, rs2;
+  // Without horizontal diffusion (Kx = 0: the stratosphere of the default parameters) only rs[3 g + 2] is used --
+  // one Box-Muller pair instead of two -- and the latitude keeps the tropopause pressure found above
+  double rs0 = 0, rs1 = 0, rs2;
   if (pre) {
     rs0 = pre[0];
     rs1 = pre[1];
     rs2 = pre[2];
-  } else
+  } else if (Kx > 0)
     normal_triple(ltab, ctr, g, rs0, rs1, rs2);
+  else
+    rs2 = normal_third(ltab, ctr, g);
 
   if (Kx > 0) {
     const double sigma_h = fsqrt(2.0 * Kx * dt_abs);
     const DegPerMetre dm = deg_per_metre(P.lat);
     P.lon += dx2deg_k(dm, rs0 * sigma_h);
     P.lat += dy2deg_k(rs1 * sigma_h);
+    pt = tropo_pressure_at(ctl, C, tt, P.lat);   // (mptrac.c:4669: at the displaced latitude)
   }
   if (Kz > 0) {
     const double sigma_z = fsqrt(2.0 * Kz * dt_abs) * 1e-3;
@@ -2822,7 +2859,6 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
     const double eps_km = 0.01;
     const double p_up = p_save + dz2dp(eps_km, p_save);
     const double p_dn = p_save + dz2dp(-eps_km, p_save);
-    const double pt = tropo_pressure_at(ctl, C, tt, P.lat);   // latitude already displaced above
     const double Kz_up = kz_blend(ctl, pt, vmax(ptop, vmin(ps, p_up)), pbl, ps);
     const double Kz_dn = kz_blend(ctl, pt, vmax(ptop, vmin(ps, p_dn)), pbl, ps);
     const double dKz_dz = (Kz_up - Kz_dn) * (1.0 / (2.0 * eps_km * 1e3));
