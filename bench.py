@@ -425,6 +425,9 @@ def main():
                                     "wall time per step"),
                          "kernel_ms": roof_ms, "step_kernel_ms_per_step": kernel_ms_per_step,
                          "step_kernel_launches_per_step": launches_per_step,
+                         # what a kernel trace of this command shows for the timed launches: `launch_ms` each
+                         "steps_per_launch": (args.steps / launches) if launches else None,
+                         "launch_ms": (kernel_ms / launches) if launches else None,
                          "kernel_ms_per_rank": per_rank_kernel_ms,
                          # the same steps as one launch per time step (rank 0, ten steps behind the timed region)
                          "kernel_ms_one_launch_per_step": single_ms,

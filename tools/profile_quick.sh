@@ -28,6 +28,7 @@ if "GRBM_GUI_ACTIVE" in m:
     cyc = m["GRBM_GUI_ACTIVE"] / 8.0
     print("kernel cycles %.4g  TD busy %.2f  TA busy %.2f" % (cyc, m["TD_TD_BUSY_sum"] / 256 / cyc, m["TA_TA_BUSY_sum"] / 256 / cyc))
     if "SQ_ACTIVE_INST_VALU" in m:
-        print("VALU busy %.2f   VALU per batch %.0f  VMEM_RD per batch %.1f  SALU per batch %.0f" % (
-            m["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc), m["SQ_INSTS_VALU"] / 156250, m["SQ_INSTS_VMEM_RD"] / 156250, m["SQ_INSTS_SALU"] / 156250))
+        # (the 6-step launch of mphip_run_timesteps: per time step)
+    print("VALU busy %.2f   VALU per 64 particle-steps %.0f  VMEM_RD %.1f  SALU %.0f" % (
+            m["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc), m["SQ_INSTS_VALU"] / 156250 / 6, m["SQ_INSTS_VMEM_RD"] / 156250 / 6, m["SQ_INSTS_SALU"] / 156250 / 6))
 PY

@@ -42,10 +42,23 @@ print("\n".join(out))
 
 # HBM traffic of the step kernel per launch (MI355X_MICROARCH.md, HBM section):
 # FETCH_SIZE / WRITE_SIZE are in KiB; calibrate on pack_kernel (known bytes).
+# The timed steps of bench.py go to the device as one multi-step launch (step_kernel<6710....u>: the kMultiStep
+# instantiations, K time steps per particle): its counters divided by K are the per-step figures everything below
+# works with.  Runs without such a launch (--multi-step off, older builds): every dispatch is one step.
+try:
+    _steps = int(json.loads(open(bj).read().strip().splitlines()[-1])["steps"])
+except Exception:
+    _steps = 1
+_pmc_steps = 10      # tools/profile.sh: the PMC passes run `bench.py --steps 10`
+
+
 def one(d, name):
     for f in glob.glob(os.path.join(src, d, "**/*counter_collection.csv"), recursive=True):
-        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == name]
-        return v
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == name]
+        multi = [float(r["Counter_Value"]) / _pmc_steps for r in rows if "step_kernel<6710" in r.get("Kernel_Name", "")]
+        if multi:
+            return multi
+        return [float(r["Counter_Value"]) for r in rows]
     return []
 
 
@@ -89,6 +102,6 @@ if fs and ws:
             info["valu_insts_per_64_particle_steps"] = max(iv) / (cfg["config"]["particles_per_gpu"] / 64.0)
         except Exception:
             pass
-    print("== HBM traffic of step_kernel per launch ==")
+    print("== HBM traffic of step_kernel per time step (multi-step launch / its steps) ==")
     print("  " + json.dumps(info))
     json.dump(info, open(os.path.join(src, "traffic.json"), "w"))
