@@ -158,6 +158,9 @@ struct mphip_ctx {
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int xcd_map = 1;
   int split_step = 0;                 // experiment: advection and the modules behind it as two launches
+  int perm_records = 1;               // random permutations of the particle arrays through records (permute_random)
+  void *d_prec = nullptr;             // ... their buffer
+  size_t prec_cap = 0;
   int multi_step = 64;                // mphip_run_timesteps: most time steps per launch (0 = always one by one)
   bool force_generic = false;
   bool compact_depo = true;           // deposition-only launches through depo_kernel (0: the fused kernel's tail)
@@ -1224,6 +1227,47 @@ int ahead_launch(mphip_ctx *ctx, double t_next, const BoxArgs *box = nullptr) {
 }
 
 // put every per-particle array back into the external slot order
+// The particle arrays of `g` moved by a RANDOM permutation: out[i] = in[index[i]] (gather) or out[index[i]] = in[i]
+// (scatter), through one record per particle (perm_pack_kernel / perm_unpack_kernel).  Falls back to the
+// array-by-array kernels if the record buffer cannot be had (option perm_records 0 does so always).
+int permute_random(mphip_ctx *ctx, const PermArgs &g, const int *index, long long n, bool scatter) {
+  const PermGeom pg = perm_geom(n);
+  RecordGeom rg;
+  rg.n8 = g.n8;
+  rg.n4 = g.n4;
+  const int words4 = g.n4 + (g.ext_out ? 1 : 0);
+  rg.chunks = (g.n8 + 1) / 2 + (words4 + 3) / 4;
+  const size_t need = (size_t) n * (size_t) rg.chunks * 16;
+  bool records = ctx->perm_records && n >= 65536;
+  if (records && need > ctx->prec_cap) {
+    if (ctx->d_prec)
+      (void) hipFree(ctx->d_prec);
+    ctx->d_prec = nullptr;
+    ctx->prec_cap = 0;
+    if (hipMalloc(&ctx->d_prec, need) == hipSuccess)
+      ctx->prec_cap = need;
+    else {
+      (void) hipGetLastError();
+      records = false;
+    }
+  }
+  if (!records) {
+    if (scatter)
+      hipLaunchKernelGGL(perm_scatter_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, index, n, pg);
+    else
+      hipLaunchKernelGGL(perm_gather_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, index, n, pg);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  f32x4u *rec = (f32x4u *) ctx->d_prec;
+  hipLaunchKernelGGL(perm_pack_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, rg, scatter ? index : (const int *) nullptr,
+                     rec, n, pg);
+  hipLaunchKernelGGL(perm_unpack_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, rg,
+                     scatter ? (const int *) nullptr : index, (const f32x4u *) rec, n, pg);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int restore_external_order(mphip_ctx *ctx) {
   if (ctx->ext_identity || ctx->np == 0) {
     ctx->ext_identity = true;
@@ -1232,9 +1276,8 @@ int restore_external_order(mphip_ctx *ctx) {
   if (ahead_drop(ctx))
     return 1;
   PermArgs g = perm_args(ctx, true);
-  const PermGeom pg = perm_geom(ctx->np);
-  hipLaunchKernelGGL(perm_scatter_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_ext, ctx->np, pg);
-  HIPCHK(hipGetLastError());
+  if (permute_random(ctx, g, ctx->d_ext, ctx->np, true))
+    return 1;
   perm_swap(ctx, true);
   ctx->ext_identity = true;
   ctx->steps_since_resort = 1 << 30;
@@ -1258,9 +1301,14 @@ int locality_sort(mphip_ctx *ctx) {
   PermArgs g = perm_args(ctx, true);
   g.ext_in = ctx->ext_identity ? nullptr : ctx->d_ext;
   g.ext_out = ctx->d_ext_alt;
-  const PermGeom pg = perm_geom(ctx->np);
-  hipLaunchKernelGGL(perm_gather_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], ctx->np, pg);
-  HIPCHK(hipGetLastError());
+  if (ctx->ext_identity) {   // out of the caller's order: a random permutation
+    if (permute_random(ctx, g, ctx->d_vals[cur], ctx->np, false))
+      return 1;
+  } else {                   // a re-sort: most particles stay where they are, the gathers hit the caches
+    const PermGeom pg = perm_geom(ctx->np);
+    hipLaunchKernelGGL(perm_gather_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_vals[cur], ctx->np, pg);
+    HIPCHK(hipGetLastError());
+  }
   perm_swap(ctx, true);
   std::swap(ctx->d_ext, ctx->d_ext_alt);
   ctx->ext_identity = false;
@@ -1939,6 +1987,7 @@ void mphip_destroy(mphip_ctx *ctx) {
     dev_free(ctx->d_vals[k]);
   }
   dev_free(ctx->d_counts);
+  dev_free(ctx->d_prec);
   dev_free(ctx->d_cell);
   dev_free(ctx->d_sums);
   dev_free(ctx->d_cnt);
@@ -2451,9 +2500,8 @@ int mphip_get_atm(mphip_ctx *ctx, double *time, double *p, double *lon, double *
   double *const *srcs = ctx->d_arr;
   if (!ctx->ext_identity && ctx->np) {
     PermArgs g = perm_args(ctx, false);
-    const PermGeom pg = perm_geom(ctx->np);
-    hipLaunchKernelGGL(perm_scatter_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, ctx->d_ext, ctx->np, pg);
-    HIPCHK(hipGetLastError());
+    if (permute_random(ctx, g, ctx->d_ext, ctx->np, true))
+      return 1;
     srcs = ctx->d_alt;
   }
   double *dst[4] = { time, p, lon, lat };
@@ -3059,6 +3107,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
   }
   if (strcmp(name, "fuse_sort_quantities") == 0) {   // 0: module_sort moves the quantity arrays in a pass of its own
     ctx->fuse_quantities = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "perm_records") == 0) {
+    ctx->perm_records = value != 0;
     return 0;
   }
   if (strcmp(name, "split_step") == 0) {

@@ -1375,6 +1375,89 @@ __global__ void perm_scatter_kernel(PermArgs g, const int *__restrict__ ext, lon
   }
 }
 
+// Random permutations (the first sort out of the caller's order, the way back at a download) through records.
+// A structure-of-arrays element moved to a random place costs a memory transaction of its own whatever its size --
+// ten of them per particle in the kernels above, 1.3-2.1 ms for 1e7 particles of C3.  Two passes instead:
+//   pack    the arrays -> one record per particle (8-byte fields, then 4-byte ones, padded to 16 bytes), written in
+//           16-byte pieces either where the particle is (gather) or where it goes (scatter: dst = ext[i]);
+//   unpack  records -> arrays, every store coalesced; the gather reads record perm[i] here.
+// One random transaction of a record (one or two lines) per particle instead of ten.
+struct RecordGeom {
+  int n8, n4;        // fields (the slot ids of a gather travel as one more 4-byte field)
+  int chunks;        // 16-byte pieces per record
+};
+
+__device__ __forceinline__ void record_fields(const PermArgs &g, const RecordGeom &rg, int c, long long src, bool ids,
+                                              f32x4u &v) {
+  // piece c: doubles 2c, 2c + 1 while they last, then four 4-byte fields per piece
+  const int d8 = (rg.n8 + 1) / 2;
+  if (c < d8) {
+    const double a = g.in8[2 * c][src];
+    const double b = 2 * c + 1 < rg.n8 ? g.in8[2 * c + 1][src] : 0.0;
+    v[0] = __uint_as_float((uint32_t) __double2loint(a));
+    v[1] = __uint_as_float((uint32_t) __double2hiint(a));
+    v[2] = __uint_as_float((uint32_t) __double2loint(b));
+    v[3] = __uint_as_float((uint32_t) __double2hiint(b));
+  } else {
+    const int f0 = 4 * (c - d8);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int f = f0 + k;
+      float x = 0.f;
+      if (f < g.n4)
+        x = g.in4[f][src];
+      else if (f == g.n4 && ids)
+        x = __int_as_float(g.ext_in ? g.ext_in[src] : (int) src);
+      v[k] = x;
+    }
+  }
+}
+
+// records[dst] <- particle i; dst = i (gather: the unpack pass follows the permutation) or ext[i] (scatter)
+__global__ __launch_bounds__(256) void perm_pack_kernel(PermArgs g, RecordGeom rg, const int *__restrict__ dst_of,
+                                                        f32x4u *__restrict__ rec, long long n, PermGeom pg) {
+  long long first, last;
+  perm_range(pg, n, first, last);
+  const bool ids = g.ext_out != nullptr;
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
+    const long long dst = dst_of ? (long long) dst_of[i] : i;
+    for (int c = 0; c < rg.chunks; c++) {
+      f32x4u v;
+      record_fields(g, rg, c, i, ids, v);
+      rec[dst * rg.chunks + c] = v;
+    }
+  }
+}
+
+// arrays[i] <- records[src]; src = src_of[i] (gather) or i (scatter)
+__global__ __launch_bounds__(256) void perm_unpack_kernel(PermArgs g, RecordGeom rg, const int *__restrict__ src_of,
+                                                          const f32x4u *__restrict__ rec, long long n, PermGeom pg) {
+  long long first, last;
+  perm_range(pg, n, first, last);
+  const int d8 = (rg.n8 + 1) / 2;
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
+    const long long src = src_of ? (long long) src_of[i] : i;
+    for (int c = 0; c < rg.chunks; c++) {
+      const f32x4u v = rec[src * rg.chunks + c];
+      if (c < d8) {
+        g.out8[2 * c][i] = __hiloint2double((int) __float_as_uint(v[1]), (int) __float_as_uint(v[0]));
+        if (2 * c + 1 < rg.n8)
+          g.out8[2 * c + 1][i] = __hiloint2double((int) __float_as_uint(v[3]), (int) __float_as_uint(v[2]));
+      } else {
+        const int f0 = 4 * (c - d8);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int f = f0 + k;
+          if (f < g.n4)
+            g.out4[f][i] = v[k];
+          else if (f == g.n4 && g.ext_out)
+            g.ext_out[i] = __float_as_int(v[k]);
+        }
+      }
+    }
+  }
+}
+
 // out[i] = in[ext[i]]: one array handed over in the caller's order into the stored order
 __global__ void gather_by_ext_kernel(const double *__restrict__ in, const int *__restrict__ ext, double *__restrict__ out,
                                      long long n) {
