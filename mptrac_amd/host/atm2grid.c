@@ -52,8 +52,8 @@ int main(int argc, char *argv[]) {
   char filename[3 * LEN];
   sprintf(filename, "%s_%04d_%02d_%02d_%02d_%02d_%02d.%s", ctl->grid_basename, year, mon, day, hour, min, sec,
           ctl->grid_type == 0 ? "tab" : "nc");
-  /* the particles go to the device; start = stop = output time, so that a GRID_KERNEL is read */
-  ctl->t_start = ctl->t_stop = t;
+  /* the particles go to the device.  (T_START keeps its default, as in the reference's tool: write_grid reads a
+   * GRID_KERNEL only at t == T_START, so the tool never applies one -- atm2grid.c:68-92) */
   mptrac_update_device(ctl, NULL, NULL, NULL, NULL, atm);
   write_grid(filename, ctl, NULL, NULL, atm, t);
   mptrac_free(ctl, cache, clim, met0, met1, atm, depo, dd);

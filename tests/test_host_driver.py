@@ -130,6 +130,30 @@ def test_trac_end_to_end_matches_oracle(tmp_path, atm_type, pbl, meteo):
 
 
 @pytest.mark.gpu
+def test_trac_step_queue_is_not_observable(tmp_path):
+    """The host layer holds back the time steps mptrac_run_timestep is given while they follow each other and hands
+    them to the device as one mphip_run_timesteps call when anything else needs it (output, a new meteo file, the
+    end of the run): the driver's loop stays the reference's, one call per step.  Every output file is the same,
+    byte for byte, with the queue (default), with short queues and without it (HIP_STEP_BATCH 1)."""
+    import hashlib
+    digests = {}
+    for batch in ("default", "4", "1"):
+        tmp = str(tmp_path / ("batch_" + batch))
+        os.makedirs(tmp)
+        trac, mets, atm = _setup(tmp, n=3000, hours=2, extra={"ATM_DT_OUT": 1800})
+        env = dict(os.environ)
+        if batch != "default":
+            env["HIP_STEP_BATCH"] = batch
+        r = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, env=env)
+        assert r.returncode == 0, r.stdout.decode()[-3000:]
+        files = sorted(f for f in os.listdir(tmp) if f.startswith(("atm_2022", "grid_2022")))
+        assert len(files) == 5 + 3, files      # particles every half hour, the grid every hour
+        digests[batch] = [(f, hashlib.sha1(open(os.path.join(tmp, f), "rb").read()).hexdigest()) for f in files]
+    assert digests["4"] == digests["default"] and digests["1"] == digests["default"]
+
+
+@pytest.mark.gpu
 def test_trac_with_meteo_read_ahead(tmp_path):
     """HIP_MET_PREFETCH 1: the next meteo file is read by a thread and uploaded on the copy stream while
     the interval's time steps run; results as without it (3 h, 4 files, two hand-overs from the read-ahead)."""

@@ -286,7 +286,8 @@ def test_sharded_run_steps_through_the_times_of_the_whole_particle_file():
     gets it too.  (tests/c/shard_times.c)"""
     from hostfiles import compile_c_test
     exe = compile_c_test("shard_times")
-    for n, world in ((10, 4), (2, 4), (7, 1)):
+    from mptrac_amd import hip
+    for n, world in ((10, 4), (2, 4), (7, 1), (1003, 8), (5, 8)):   # (8 ranks: one node of the baseline's configs[3] / [4])
         seen = []
         for rank in range(world):
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
@@ -297,6 +298,8 @@ def test_sharded_run_steps_through_the_times_of_the_whole_particle_file():
             line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
             seen.append((int(line[1]), float(line[2]), float(line[3])))
         assert sum(d[0] for d in seen) == n
+        # ... the index ranges of the C driver are the ones of the Python harness (bench.py, tests)
+        assert [d[0] for d in seen] == [hip.shard_range(n, r, world)[1] - hip.shard_range(n, r, world)[0] for r in range(world)]
         assert all(d[1:] == (900.0, 1000.0 + 900.0 * (n - 1)) for d in seen), seen
         if n < world:
             assert any(d[0] == 0 for d in seen)
