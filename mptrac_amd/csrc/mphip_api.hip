@@ -832,10 +832,12 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiffConvSedi | kMultiStep)
 #undef STEP_CASE
   default:
-    if (nsteps > 1)
+    if (nsteps > 1 && !(ml_fast && !rare && !ctx->force_generic))
       return fail(ctx, "internal: no multi-step instantiation for this module set");
     if (rare || ctx->force_generic)
       hipLaunchKernelGGL(step_kernel<kMaskGeneric>, dim3(nb), dim3(256), lds, ctx->stream, S);
+    else if (ml_fast && nsteps > 1)
+      hipLaunchKernelGGL(step_kernel<kMaskGenericMLMulti>, dim3(nb), dim3(256), lds, ctx->stream, S);
     else if (ml_fast)
       hipLaunchKernelGGL(step_kernel<kMaskGenericML>, dim3(nb), dim3(256), lds, ctx->stream, S);
     else
@@ -2762,7 +2764,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
       && !(c.mixing_trop >= 0 && c.mixing_strat >= 0) && !(c.isosurf >= 1 && c.isosurf <= 4)
       && !(c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1) && !(c.diffusion && c.turb_pbl_scheme == 1)
       && !((c.conv_mix_pbl || c.conv_cape >= 0) && c.conv_dt > 0) && c.advect == 4
-      && !(c.advect_vert_coord >= 1 && c.advect_vert_coord <= 3) && !(meteo && ctx->meteo_pending) && !ctx->fused_perm
+      && !(meteo && ctx->meteo_pending) && !ctx->fused_perm
       && !ctx->force_generic && !ctx->split_step;
     if (quiet) {
       batch = nsteps - done;
@@ -2802,7 +2804,15 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     if (c.qnt_rp >= 0 && c.qnt_rhop >= 0)
       mask |= MPHIP_MOD_SEDI;
     const unsigned movers = mask;
-    const bool exact = movers == kAdv || movers == kAdvTurb || movers == kAdvDiff || movers == kAdvDiffConvSedi;
+    // winds from the model levels: the model-level instantiation (any of these module sets), if the height columns
+    // are monotonic; pressure levels: the exact lean instantiations
+    const bool ml_winds = c.advect_vert_coord >= 1 && c.advect_vert_coord <= 3;
+    if (ml_winds && ensure_packed(ctx))
+      return 1;
+    const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
+      && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // (launch_step's condition)
+    const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->d_kz != nullptr
+                                : lean_ok && (movers == kAdv || movers == kAdvTurb || movers == kAdvDiff || movers == kAdvDiffConvSedi);
     if (c.qnt_loss_rate >= 0)
       mask |= MPHIP_MOD_LOSS_ZERO;
     if (c.tdec_trop > 0 && c.tdec_strat > 0)

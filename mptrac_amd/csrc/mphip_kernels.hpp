@@ -127,8 +127,12 @@ constexpr unsigned kMaskGenericPL = 0xfffffffeu;
 // as kMaskGenericPL, with model-level (zeta / eta) advection on the packed height fields instead of the
 // pressure-level integrator (needs monotonic height columns: DevMet::ml_monotonic)
 constexpr unsigned kMaskGenericML = 0xfffffffdu;
+// ... and the same with StepParams::nsteps time steps per particle and launch (see kMultiStep)
+constexpr unsigned kMaskGenericMLMulti = 0xfffffffbu;
 template <unsigned CT>
-constexpr bool kRuntimeMask = (CT == kMaskGeneric || CT == kMaskGenericPL || CT == kMaskGenericML);
+constexpr bool kModelLevels = (CT == kMaskGenericML || CT == kMaskGenericMLMulti);
+template <unsigned CT>
+constexpr bool kRuntimeMask = (CT == kMaskGeneric || CT == kMaskGenericPL || kModelLevels<CT>);
 constexpr unsigned kRareModules = MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT | MPHIP_MOD_ISOSURF | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
 constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a later launch reads it)
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & MPHIP_MOD_ADVECT) |
     const DevAtm &a = S.atm;
     const mphip_ctl_t &ctl = S.ctl;
 #endif
-    constexpr bool multi = !kRuntimeMask<CT> && (CT & kMultiStep) != 0;
+    constexpr bool multi = (!kRuntimeMask<CT> && (CT & kMultiStep) != 0) || CT == kMaskGenericMLMulti;
     const int nsteps = multi ? S.nsteps : 1;
     double t_now = S.t;
     uint64_t c_turb = S.ctr_turb, c_meso = S.ctr_meso, c_conv = S.ctr_conv;
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & MPHIP_MOD_ADVECT) |
         a.p[i] = pressure_from_zeta(M, A, P.time, a.q[ctl.qnt_zeta][i], P.lon, P.lat);
       continue;
     }
-    if (CT == kMaskGenericML && (mask & MPHIP_MOD_ADVECT_INIT)) {
+    if (kModelLevels<CT> && (mask & MPHIP_MOD_ADVECT_INIT)) {
       a.p[i] = pressure_from_zeta_fast(M, A, P.time, a.q[ctl.qnt_zeta][i], P.lon, P.lat);
       continue;
     }
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & MPHIP_MOD_ADVECT) |
 
     // the specialised instantiations run the lean versions (lat/lon grid, pressure table: launch_step)
     constexpr bool lean = !kRuntimeMask<CT>;
-    if (CT != kMaskGenericML && !(multi && MPHIP_MULTI_KEEP_WIND))   // (model-level winds: the corners are first needed by module_diff_meso -- defined there,
+    if (!kModelLevels<CT> && !(multi && MPHIP_MULTI_KEEP_WIND))   // (model-level winds: the corners are first needed by module_diff_meso -- defined there,
       wind_cache_reset(wc, CT != kMaskGeneric);   //  or 48 registers would be held through the whole advection)
     if (mask & MPHIP_MOD_POSITION) {
       if (lean)
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & MPHIP_MOD_ADVECT) |
       // model-level advection (ADVECT_VERT_COORD 1 / 3) runs in the generic instantiation only
       if (CT == kMaskGeneric && ctl.advect_vert_coord == 2) {
         advect_mlp(ctl, M, A, P);      // pressure advection, winds from the model levels
-      } else if (CT == kMaskGenericML && ctl.advect_vert_coord == 2) {
+      } else if (kModelLevels<CT> && ctl.advect_vert_coord == 2) {
         int kz = a.kz[i];
         advect_mlp_fast(ctl, M, A, P, kz);
         a.kz[i] = kz;
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & MPHIP_MOD_ADVECT) |
         double zeta;
         advect_ml(ctl, M, A, P, zeta);
         a.q[qnt][i] = zeta;
-      } else if (CT == kMaskGenericML) {
+      } else if (kModelLevels<CT>) {
         const int qnt = ctl.advect_vert_coord == 1 ? ctl.qnt_zeta : ctl.qnt_eta;
         double zeta;
         int kz = a.kz[i];     // vertical index of the last step: first guess of this step's searches
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & MPHIP_MOD_ADVECT) |
         vp = ld_state(&a.vp[i]);
         wp = ld_state(&a.wp[i]);
       }
-      if (CT == kMaskGenericML)
+      if (kModelLevels<CT>)
         wind_cache_reset(wc, true);
       if (lean)
         diff_meso_fast<!(CT & MPHIP_MOD_ADVECT)>(ctl, M, A, P, up, vp, wp, c_meso, g, early ? pre.meso : nullptr, wc, ltab);

@@ -1569,13 +1569,13 @@ def test_long_run_400_steps_with_prefetched_handovers():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["advect", "turb", "diff", "conv_sedi", "full"])
+@pytest.mark.parametrize("case", ["advect", "turb", "diff", "conv_sedi", "full", "zeta_full", "mlp_full"])
 def test_run_timesteps_equals_the_step_by_step_loop(case):
     """mphip_run_timesteps (the reference's time loop, trac.c:204-226, as one call): runs of steps with nothing
     scheduled between them share a kernel launch in which every particle takes its steps one after the other;
     same bits as one mphip_run_timestep per step -- state, uvwp and the counter of the random numbers --,
     whether the batches are long, short, cut by the internal re-sort, or (module sets with module_sort / mixing:
-    "full") not possible at all."""
+    "full") not possible at all; winds from the model levels (zeta / pressure advection) share launches too."""
     ctl, clim, m0, m1, atm = cases.make_case(case, n=5003)
     o = B.Oracle(ctl, clim, m0, m1, atm)
     o.timesteps_init()
