@@ -27,7 +27,7 @@ pmc write WRITE_SIZE
 # pack_kernel reads 32 B and writes 32 B per grid point, fully coalesced
 calib() {
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "pack_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -f csv -d "$OUT/pmc_$name" -o pmc --kernel-include-regex "mphip::pack_kernel" -- $BENCH > "$OUT/pmc_$name.log" 2>&1
 }
 calib calib_fetch FETCH_SIZE
 calib calib_write WRITE_SIZE

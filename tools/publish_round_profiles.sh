@@ -13,7 +13,7 @@ cp $G/prof_${T}mem/summary.txt $P/${T}_c3_mempipe_summary.txt
 for w in C5 C3z C3m C2; do
   cp $(ls $G/prof_${T}_$w/*kernel_stats.csv $G/prof_${T}_$w/*/*kernel_stats.csv 2>/dev/null | head -1) $P/${T}_$(echo $w | tr A-Z a-z)_kernel_stats.csv
 done
-for w in C1 C2 C3 C3_1e8 C3_driver_args C3m C3x C3z C5; do
+for w in C1 C2 C3 C3_1e5 C3_1e6 C3_1e8 C3_driver_args C3_one_launch_per_step C3m C3x C3z C5; do
   [ -s $G/${T}_bench_$w.json ] && tail -1 $G/${T}_bench_$w.json > $P/${T}_bench_$(echo $w | tr A-Z a-z).json
 done
 cp $G/${T}_config_matrix.txt $P/${T}_config_matrix.txt

@@ -52,9 +52,10 @@ except Exception:
 _pmc_steps = 10      # tools/profile.sh: the PMC passes run `bench.py --steps 10`
 
 
-def one(d, name):
+def one(d, name, kernel=None):
     for f in glob.glob(os.path.join(src, d, "**/*counter_collection.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == name]
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == name
+                and (kernel is None or kernel in r.get("Kernel_Name", ""))]
         multi = [float(r["Counter_Value"]) / _pmc_steps for r in rows if "step_kernel<6710" in r.get("Kernel_Name", "")]
         if multi:
             return multi
@@ -63,7 +64,8 @@ def one(d, name):
 
 
 fs, ws = one("pmc_fetch", "FETCH_SIZE"), one("pmc_write", "WRITE_SIZE")
-cf, cw = one("pmc_calib_fetch", "FETCH_SIZE"), one("pmc_calib_write", "WRITE_SIZE")
+# (the meteo pack kernel only: the regex of the calibration passes also matches perm_pack / perm_unpack)
+cf, cw = one("pmc_calib_fetch", "FETCH_SIZE", "mphip::pack_kernel("), one("pmc_calib_write", "WRITE_SIZE", "mphip::pack_kernel(")
 if fs and ws:
     steady_f = sorted(fs)[len(fs) // 2] * 1024.0      # median dispatch (the dt = 0 first call is smaller)
     steady_w = sorted(ws)[len(ws) // 2] * 1024.0

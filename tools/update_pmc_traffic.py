@@ -38,7 +38,7 @@ if os.path.exists(mix_file):
     for line in open(mix_file):
         f = line.split()
         if len(f) >= 4 and f[0].startswith("SQ_"):
-            mix[f[0]] = float(f[3])
+            mix[f[0]] = float(f[-1])      # (per 64 particle-steps: the last column)
     fp64 = sum(mix.get("SQ_INSTS_VALU_%s_F64" % k, 0.0) for k in ("ADD", "MUL", "FMA", "TRANS"))
     if mix.get("SQ_INSTS_VALU"):
         out["_fp64_valu_frac"] = {
