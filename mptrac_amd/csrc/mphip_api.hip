@@ -1239,6 +1239,10 @@ int permute_random(mphip_ctx *ctx, const PermArgs &g, const int *index, long lon
   rg.n4 = g.n4;
   const int words4 = g.n4 + (g.ext_out ? 1 : 0);
   rg.chunks = (g.n8 + 1) / 2 + (words4 + 3) / 4;
+  rg.inv = 65536 / rg.chunks + 1;
+  for (int p = 0; p < 64 * rg.chunks; p++)
+    if ((int) (((unsigned) p * (unsigned) rg.inv) >> 16) != p / rg.chunks)
+      return fail(ctx, "internal: record piece index");
   const size_t need = (size_t) n * (size_t) rg.chunks * 16;
   bool records = ctx->perm_records && n >= 65536;
   if (records && need > ctx->prec_cap) {
@@ -1262,9 +1266,10 @@ int permute_random(mphip_ctx *ctx, const PermArgs &g, const int *index, long lon
     return 0;
   }
   f32x4u *rec = (f32x4u *) ctx->d_prec;
-  hipLaunchKernelGGL(perm_pack_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, rg, scatter ? index : (const int *) nullptr,
-                     rec, n, pg);
-  hipLaunchKernelGGL(perm_unpack_kernel, dim3(pg.nblocks), dim3(256), 0, ctx->stream, g, rg,
+  const size_t lds = (size_t) kRecordWaves * 64 * (size_t) rg.chunks * 16;
+  hipLaunchKernelGGL(perm_pack_kernel, dim3(pg.nblocks), dim3(64 * kRecordWaves), lds, ctx->stream, g, rg,
+                     scatter ? index : (const int *) nullptr, rec, n, pg);
+  hipLaunchKernelGGL(perm_unpack_kernel, dim3(pg.nblocks), dim3(64 * kRecordWaves), lds, ctx->stream, g, rg,
                      scatter ? (const int *) nullptr : index, (const f32x4u *) rec, n, pg);
   HIPCHK(hipGetLastError());
   return 0;

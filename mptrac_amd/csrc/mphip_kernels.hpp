@@ -1389,6 +1389,7 @@ __global__ void perm_scatter_kernel(PermArgs g, const int *__restrict__ ext, lon
 struct RecordGeom {
   int n8, n4;        // fields (the slot ids of a gather travel as one more 4-byte field)
   int chunks;        // 16-byte pieces per record
+  int inv;           // p / chunks = (p * inv) >> 16 for p < 64 * chunks
 };
 
 __device__ __forceinline__ void record_fields(const PermArgs &g, const RecordGeom &rg, int c, long long src, bool ids,
@@ -1417,48 +1418,87 @@ __device__ __forceinline__ void record_fields(const PermArgs &g, const RecordGeo
   }
 }
 
+// Both kernels move the records between memory and LDS as a wave: piece p of the wave's 64 records is handled by
+// lane p % 64 (record p / chunks, piece p % chunks), so the `chunks` lanes of one record touch its bytes side by side --
+// one or two memory transactions per record instead of one per 16-byte piece and lane -- and the sequential side
+// (pack of a gather, unpack of a scatter) is fully coalesced.  Every lane then reads / has written its own record in
+// LDS.  (p / chunks by a multiplication: RecordGeom::inv, exact for p < 64 * chunks, checked by the host.)
+constexpr int kRecordWaves = 4;
+
 // records[dst] <- particle i; dst = i (gather: the unpack pass follows the permutation) or ext[i] (scatter)
-__global__ __launch_bounds__(256) void perm_pack_kernel(PermArgs g, RecordGeom rg, const int *__restrict__ dst_of,
-                                                        f32x4u *__restrict__ rec, long long n, PermGeom pg) {
+__global__ __launch_bounds__(64 * kRecordWaves) void perm_pack_kernel(PermArgs g, RecordGeom rg, const int *__restrict__ dst_of,
+                                                                      f32x4u *__restrict__ rec, long long n, PermGeom pg) {
+  extern __shared__ f32x4u s_rec[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4u *tile = s_rec + (size_t) wave * 64 * (size_t) rg.chunks;
   long long first, last;
   perm_range(pg, n, first, last);
   const bool ids = g.ext_out != nullptr;
-  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
-    const long long dst = dst_of ? (long long) dst_of[i] : i;
-    for (int c = 0; c < rg.chunks; c++) {
-      f32x4u v;
-      record_fields(g, rg, c, i, ids, v);
-      rec[dst * rg.chunks + c] = v;
+  for (long long base = first + 64 * wave; base < last; base += 64 * kRecordWaves) {
+    const long long i = base + lane;
+    const bool live = i < last;
+    const int dst = live ? (dst_of ? dst_of[i] : (int) i) : 0;
+    if (live)
+      for (int c = 0; c < rg.chunks; c++) {
+        f32x4u v;
+        record_fields(g, rg, c, i, ids, v);
+        tile[lane * rg.chunks + c] = v;
+      }
+    __builtin_amdgcn_wave_barrier();
+    const int nrec = last - base < 64 ? (int) (last - base) : 64;
+    for (int p0 = 0; p0 < nrec * rg.chunks; p0 += 64) {   // (every lane takes part in the shuffle)
+      const int p = p0 + lane;
+      const int r = (int) (((unsigned) p * (unsigned) rg.inv) >> 16) & 63, c = p - r * rg.chunks;
+      const int d = __shfl(dst, r);
+      if (p < nrec * rg.chunks)
+        rec[(size_t) d * (size_t) rg.chunks + (size_t) c] = tile[p];
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 // arrays[i] <- records[src]; src = src_of[i] (gather) or i (scatter)
-__global__ __launch_bounds__(256) void perm_unpack_kernel(PermArgs g, RecordGeom rg, const int *__restrict__ src_of,
-                                                          const f32x4u *__restrict__ rec, long long n, PermGeom pg) {
+__global__ __launch_bounds__(64 * kRecordWaves) void perm_unpack_kernel(PermArgs g, RecordGeom rg, const int *__restrict__ src_of,
+                                                                        const f32x4u *__restrict__ rec, long long n, PermGeom pg) {
+  extern __shared__ f32x4u s_rec[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4u *tile = s_rec + (size_t) wave * 64 * (size_t) rg.chunks;
   long long first, last;
   perm_range(pg, n, first, last);
   const int d8 = (rg.n8 + 1) / 2;
-  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
-    const long long src = src_of ? (long long) src_of[i] : i;
-    for (int c = 0; c < rg.chunks; c++) {
-      const f32x4u v = rec[src * rg.chunks + c];
-      if (c < d8) {
-        g.out8[2 * c][i] = __hiloint2double((int) __float_as_uint(v[1]), (int) __float_as_uint(v[0]));
-        if (2 * c + 1 < rg.n8)
-          g.out8[2 * c + 1][i] = __hiloint2double((int) __float_as_uint(v[3]), (int) __float_as_uint(v[2]));
-      } else {
-        const int f0 = 4 * (c - d8);
+  for (long long base = first + 64 * wave; base < last; base += 64 * kRecordWaves) {
+    const long long i = base + lane;
+    const bool live = i < last;
+    const int src = live ? (src_of ? src_of[i] : (int) i) : 0;
+    const int nrec = last - base < 64 ? (int) (last - base) : 64;
+    for (int p0 = 0; p0 < nrec * rg.chunks; p0 += 64) {   // (every lane takes part in the shuffle)
+      const int p = p0 + lane;
+      const int r = (int) (((unsigned) p * (unsigned) rg.inv) >> 16) & 63, c = p - r * rg.chunks;
+      const int sr = __shfl(src, r);
+      if (p < nrec * rg.chunks)
+        tile[p] = rec[(size_t) sr * (size_t) rg.chunks + (size_t) c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (live)
+      for (int c = 0; c < rg.chunks; c++) {
+        const f32x4u v = tile[lane * rg.chunks + c];
+        if (c < d8) {
+          g.out8[2 * c][i] = __hiloint2double((int) __float_as_uint(v[1]), (int) __float_as_uint(v[0]));
+          if (2 * c + 1 < rg.n8)
+            g.out8[2 * c + 1][i] = __hiloint2double((int) __float_as_uint(v[3]), (int) __float_as_uint(v[2]));
+        } else {
+          const int f0 = 4 * (c - d8);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int f = f0 + k;
-          if (f < g.n4)
-            g.out4[f][i] = v[k];
-          else if (f == g.n4 && g.ext_out)
-            g.ext_out[i] = __float_as_int(v[k]);
+          for (int k = 0; k < 4; k++) {
+            const int f = f0 + k;
+            if (f < g.n4)
+              g.out4[f][i] = v[k];
+            else if (f == g.n4 && g.ext_out)
+              g.ext_out[i] = __float_as_int(v[k]);
+          }
         }
       }
-    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
