@@ -156,6 +156,7 @@ struct mphip_ctx {
   bool locality_zorder = false;       // tiles of the locality key numbered along a Z-order curve instead of row by row
   int locality_tile = 0;              // horizontal tile edge of the locality key (columns); 0 = 4, or 8 with model-level winds
   int step_blocks = 8192;             // upper bound of the step kernel's grid
+  int step_blocks_multi = 32768;       // ... of a multi-step launch (mphip_run_timesteps)
   int xcd_map = 1;
   int split_step = 0;                 // experiment: advection and the modules behind it as two launches
   int perm_records = 1;               // random permutations of the particle arrays through records (permute_random)
@@ -736,7 +737,11 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   S.t = t;
   S.mask = mask;
   // every block walks a whole number of 256-particle rounds (no half-empty last round)
-  long long per_block = (ctx->np + ctx->step_blocks - 1) / ctx->step_blocks;
+  // (multi-step launches: more, shorter blocks -- a thread that takes 20 steps per particle should not also walk
+  // five particles; measured on C3, alternating in one process: 0.744-0.781 / 0.738-0.757 / 0.729-0.747 ms per step
+  // with 8 192 / 16 384 / 32 768 logical blocks)
+  const int blocks = nsteps > 1 ? ctx->step_blocks_multi : ctx->step_blocks;
+  long long per_block = (ctx->np + blocks - 1) / blocks;
   per_block = std::max<long long>(256, (per_block + 255) / 256 * 256);
   int nb = (int) ((ctx->np + per_block - 1) / per_block);
   nb = (nb + 7) & ~7;
@@ -3094,10 +3099,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     ctx->locality_interval = (int) value;
     return 0;
   }
-  if (strcmp(name, "step_blocks") == 0) {
+  if (strcmp(name, "step_blocks") == 0 || strcmp(name, "step_blocks_multi") == 0) {
     if (value < 8 || value > 1048576)
       return fail(ctx, "step_blocks must be in 8 ... 1048576");
-    ctx->step_blocks = (int) value;
+    (strcmp(name, "step_blocks") == 0 ? ctx->step_blocks : ctx->step_blocks_multi) = (int) value;
     return 0;
   }
   if (strcmp(name, "fuse_sort") == 0) {    // 0: module_sort re-orders every array in its own pass

@@ -11,9 +11,13 @@ import bench  # noqa: E402
 from mptrac_amd import hip  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10 ** 7
-batches = [int(x) for x in sys.argv[2:]] or [1, 2, 5, 10, 20, 60]
+opts = [a for a in sys.argv[2:] if "=" in a]
+batches = [int(x) for x in sys.argv[2:] if "=" not in x] or [1, 2, 5, 10, 20, 60]
 ctl, clim, met0, met1, atm, n_local, n_total = bench.build_inputs("C3", 0, 1, 400, particles=n)
 sim = hip.Simulation(ctl, clim, met0, met1, atm)
+for kv in opts:
+    name, value = kv.split("=")
+    sim.set_option(name, float(value))
 sim.timesteps_init(0.0, 0.0)
 dt = sim.ctl.dt_mod
 sim.run_timestep(0.0)
