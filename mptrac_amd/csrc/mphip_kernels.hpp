@@ -508,11 +508,15 @@ struct RngEarly {
 #ifndef MPHIP_MULTI_KEEP_WIND
 #define MPHIP_MULTI_KEEP_WIND 0
 #endif
+#ifndef MPHIP_MULTI_WAVES_PER_SIMD
+#define MPHIP_MULTI_WAVES_PER_SIMD 4
+#endif
 #ifndef MPHIP_SPLITB_WAVES_PER_SIMD
 #define MPHIP_SPLITB_WAVES_PER_SIMD 4
 #endif
 template <unsigned CT>
-__global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & MPHIP_MOD_ADVECT) || CT == MPHIP_MOD_TIMESTEPS ? MPHIP_LEAN_WAVES_PER_SIMD : MPHIP_SPLITB_WAVES_PER_SIMD)
+__global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & kMultiStep) ? MPHIP_MULTI_WAVES_PER_SIMD
+                                                        : (CT & MPHIP_MOD_ADVECT) || CT == MPHIP_MOD_TIMESTEPS ? MPHIP_LEAN_WAVES_PER_SIMD : MPHIP_SPLITB_WAVES_PER_SIMD)
                                    : (CT == kMaskGenericPL ? MPHIP_STEP_WAVES_PER_SIMD : MPHIP_GENERIC_WAVES_PER_SIMD)) void step_kernel(
   const StepParams S) {
   extern __shared__ double s_axes[];
