@@ -364,11 +364,18 @@ class Simulation:
         self._chk(self.L.mphip_get_sort(self.h, _ptr(keys, _dp), _ptr(perm, C.POINTER(C.c_int))))
         return keys, perm
 
-    def grid_sums(self, t):
+    def grid_sums(self, t, out=None):
+        """Counts, sums of q and of q^2 per output cell (mphip_grid_sums).  `out` = (cnt, mean, sigma) of an
+        earlier call: the arrays are filled again instead of allocated (a caller that writes one output after the
+        other, like write_grid with its own buffers)."""
         ncell = self.ctl.grid_nx * self.ctl.grid_ny * self.ctl.grid_nz
-        cnt = np.zeros(ncell, dtype=np.int32)
-        mean = np.zeros((self.nq, ncell))
-        sigma = np.zeros((self.nq, ncell))
+        if out is not None:
+            cnt, mean, sigma = out
+            assert cnt.shape == (ncell,) and mean.shape == (self.nq, ncell) and sigma.shape == (self.nq, ncell)
+        else:
+            cnt = np.zeros(ncell, dtype=np.int32)
+            mean = np.zeros((self.nq, ncell))
+            sigma = np.zeros((self.nq, ncell))
         self._chk(self.L.mphip_grid_sums(self.h, t, _ptr(cnt, C.POINTER(C.c_int)), _ptr(mean, _dp),
                                          _ptr(sigma, _dp)))
         return cnt, mean, sigma
