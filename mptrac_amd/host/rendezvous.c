@@ -72,6 +72,14 @@ static double now_s(void) {
   return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
 }
 
+/* what a peer sends before it is given the buffer */
+typedef struct {
+  unsigned magic;
+  int rank, world;
+  unsigned long long bytes;
+} hello_t;
+#define HELLO_MAGIC 0x4d505452u   /* "MPTR" */
+
 /* rank 0 sends buf[0 .. n) to each of the world - 1 other ranks; they receive it.  1 = ok, 0 = failed or timed
  * out (a peer that died before it connected must not leave rank 0 waiting for ever). */
 int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr, int port) {
@@ -94,8 +102,15 @@ int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr,
       close(ls);
       return 0;
     }
-    int ok = 1;
-    for (int k = 1; k < world && ok; k++) {
+    /* every peer says who it is first (hello_t); a connection that does not, or a rank that has been served
+     * already, is dropped without using up a place -- until world - 1 different ranks have their copy */
+    int ok = 1, served = 0;
+    unsigned char *seen = calloc((size_t) world, 1);
+    if (!seen) {
+      close(ls);
+      return 0;
+    }
+    while (served < world - 1 && ok) {
       struct pollfd pfd = { ls, POLLIN, 0 };
       const double left = deadline - now_s();
       if (left <= 0 || poll(&pfd, 1, (int) (left * 1000.0) + 1) <= 0) {
@@ -103,10 +118,21 @@ int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr,
         break;
       }
       const int fd = accept(ls, NULL, NULL);
-      ok = fd >= 0 && send_all(fd, buf, n);
-      if (fd >= 0)
-        close(fd);
+      if (fd < 0)
+        continue;
+      struct timeval tv = { 5, 0 };
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+      hello_t hello;
+      if (recv_all(fd, (char *) &hello, sizeof(hello)) && hello.magic == HELLO_MAGIC && hello.world == world && hello.rank >= 1
+          && hello.rank < world && hello.bytes == (unsigned long long) n && !seen[hello.rank]) {
+        if (send_all(fd, buf, n)) {
+          seen[hello.rank] = 1;
+          served++;
+        }
+      }
+      close(fd);
     }
+    free(seen);
     close(ls);
     return ok;
   }
@@ -121,11 +147,14 @@ int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr,
     if (connect(fd, (struct sockaddr *) &sa, sizeof(sa)) == 0) {
       struct timeval tv = { rendezvous_timeout(), 0 };
       setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-      const int ok = recv_all(fd, buf, n);
+      const hello_t hello = { HELLO_MAGIC, rank, world, (unsigned long long) n };
+      const int ok = send_all(fd, (const char *) &hello, sizeof(hello)) && recv_all(fd, buf, n);
       close(fd);
-      return ok;
-    }
-    close(fd);
+      if (ok)
+        return 1;
+      /* (rank 0 dropped the connection -- e.g. it was still serving a run before this one -- : once more) */
+    } else
+      close(fd);
     struct timespec ts = { 0, 100 * 1000 * 1000 };
     nanosleep(&ts, NULL);
   }
