@@ -1,7 +1,7 @@
 """Randomised module combinations against the oracle (GPU): every seed draws a control set (integrator,
 stochastic modules, convection, sedimentation, sort, mixing, decay, wet / dry deposition, boundary conditions,
 isosurface mode, meteo quantities (climatology ones included), trace gases with surface time series, direction, grid orientation, vertical coordinate of the advection) and runs 12 steps through
-mphip_run_timestep.  Catches interactions between modules and between the kernel instantiations that the
+mphip_run_timestep (even seeds) or mphip_run_timesteps in pieces of one to five steps (odd seeds).  Catches interactions between modules and between the kernel instantiations that the
 named cases do not cover."""
 import numpy as np
 import pytest
@@ -124,9 +124,25 @@ def test_random_module_combination(seed):
     o.timesteps_init()
     s = hip.Simulation(ctl, clim, m0, m1, atm)
     s.timesteps_init(atm["time"].min(), atm["time"].max())
-    for t in cases.step_times(o.ctl):
+    times = cases.step_times(o.ctl)
+    for t in times:
         o.run_timestep(t)
-        s.run_timestep(t)
+    if seed % 2 == 0:
+        for t in times:
+            s.run_timestep(t)
+    else:
+        # odd seeds: the same steps handed over in pieces of one to five (mphip_run_timesteps -- pieces with
+        # nothing scheduled inside share a kernel launch; whatever the module set, the result is the loop's)
+        rr = np.random.default_rng(7000 + seed)
+        stride = o.ctl.direction * o.ctl.dt_mod
+        i = 0
+        while i < len(times):
+            k = 1
+            want = int(rr.integers(1, 6))
+            while k < want and i + k < len(times) and times[i + k] == times[i + k - 1] + stride:
+                k += 1
+            s.run_timesteps(times[i], k)
+            i += k
     g, r = s.state(), o.state()
     assert np.array_equal(g["time"], r["time"])
     for k in ("lon", "lat", "p"):
