@@ -2,7 +2,9 @@
 """Long run against the oracle (GPU box): 10^5 particles, every module of the `full` case (sort, mixing, decay,
 wet / dry deposition, convection, sedimentation, diffusion) plus module_meteo quantities, 400 time steps over
 20 h with three meteo hand-overs through mphip_prefetch_met / mphip_commit_met and downloads every 97 steps.
-Prints the relative deviations on the way; fails above the 1e-10 bar."""
+Prints the relative deviations on the way; fails above the 1e-10 bar.
+  python tools/gpu_soak.py batched     the C3 module set (`conv_sedi`: nothing scheduled between the steps) handed to
+                                       the device twenty steps at a time (mphip_run_timesteps: shared launches)"""
 import os
 import sys
 import time
@@ -18,10 +20,17 @@ from mptrac_amd.ctl import ctl_from_quantities  # noqa: E402
 from mptrac_amd.synth import FIELDS_METEO_ONLY, synthetic_met, synthetic_particles  # noqa: E402
 from oracle import binding as B  # noqa: E402
 
-names = ("m", "vmr", "rp", "rhop", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry", "aoa", "t", "u", "ps", "theta")
-ctl = dict(cases.CASES["full"])
-ctl.update(ctl_from_quantities(names))
-ctl.update(t_stop=4 * 18000.0, dt_met=18000.0, met_dt_out=0.1, sort_dt=1800.0, mixing_dt=900.0)
+batched = "batched" in sys.argv[1:]
+if batched:
+    names = ("m", "rp", "rhop")
+    ctl = dict(cases.CASES["conv_sedi"])
+    ctl.update(ctl_from_quantities(names))
+    ctl.update(t_stop=4 * 18000.0, dt_met=18000.0, met_dt_out=0.0)
+else:
+    names = ("m", "vmr", "rp", "rhop", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry", "aoa", "t", "u", "ps", "theta")
+    ctl = dict(cases.CASES["full"])
+    ctl.update(ctl_from_quantities(names))
+    ctl.update(t_stop=4 * 18000.0, dt_met=18000.0, met_dt_out=0.1, sort_dt=1800.0, mixing_dt=900.0)
 fields = tuple(cases.PRESSURE_LEVEL_FIELDS) + tuple(FIELDS_METEO_ONLY)
 mets = [synthetic_met("C1", 18000.0 * k, 1.0 + 0.1 * k, fields=fields) for k in range(6)]
 atm = synthetic_particles(100000, seed=7, quantities=names)
@@ -34,15 +43,25 @@ s.timesteps_init(0.0, 0.0)
 s.prefetch_met(mets[2])
 imet, t0 = 0, time.time()
 times = cases.step_times(o.ctl)
+pending = []          # (batched) steps the device has not been given yet
 for k, t in enumerate(times):
     if t > mets[imet + 1].time:
+        if pending:
+            s.run_timesteps(pending[0], len(pending))
+            pending = []
         imet += 1
         o.swap_met(mets[imet + 1])
         s.commit_met()
         if imet + 2 < len(mets):
             s.prefetch_met(mets[imet + 2])
     o.run_timestep(t)
-    s.run_timestep(t)
+    if batched:
+        pending.append(t)
+        if len(pending) == 20 or k % 97 == 0 or k == len(times) - 1 or (k + 1 < len(times) and times[k + 1] - t != o.ctl.dt_mod):
+            s.run_timesteps(pending[0], len(pending))
+            pending = []
+    else:
+        s.run_timestep(t)
     if k % 97 == 0:
         g, r = s.state(), o.state()
         print(k, "t = %.0f s" % t, {kk: "%.1e" % cases.rel_err(g[kk], r[kk]) for kk in ("lon", "lat", "p", "q")}, flush=True)
