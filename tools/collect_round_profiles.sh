@@ -14,7 +14,10 @@ python bench.py > gpurun_out/${T}_bench_C3.json 2> gpurun_out/${T}_bench_C3.err
 tail -c 600 gpurun_out/${T}_bench_C3.json
 python bench.py --particles 1e8 --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3_1e8.json
 python bench.py --workload C3x --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3x.json
-python bench.py --workload C1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C1.json
+python bench.py --workload C1 --steps 200 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C1.json
+python bench.py --particles 1e5 --steps 200 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3_1e5.json
+python bench.py --particles 1e6 --steps 200 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3_1e6.json
+python bench.py --steps 20 --warmup 5 --multi-step off --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3_one_launch_per_step.json
 python tools/gpu_config_matrix.py > gpurun_out/${T}_config_matrix.txt 2>&1
 python tools/gpu_config_matrix.py generic_kernel=1 > gpurun_out/${T}_config_matrix_general.txt 2>&1
 python tools/gpu_bench_sweep.py C3 > gpurun_out/${T}_sustained_480_steps.txt 2>&1
