@@ -1603,8 +1603,14 @@ static int read_met_nc(const char *filename, const ctl_t *ctl, met_t *met) {
   const int vl = ncc_find_var(nc, levname);
   if (vl < 0 || !ncc_read_double(nc, vl, 0, 0, np, met->p))
     ERRMSG("Cannot read the pressure levels!");
-  for (int k = 0; k < met->np; k++)
+  /* (the level axis is the one `u` names: a reader that had to guess axis names by their length must not have
+   * guessed a horizontal one, and what was read must look like pressures) */
+  if (strcmp(levname, xname) == 0 || strcmp(levname, yname) == 0)
+    ERRMSG("Cannot determine vertical dimension!");
+  for (int k = 0; k < met->np; k++) {
     met->p[k] /= 100.0;   /* Pa -> hPa */
+    REQUIRE(isfinite(met->p[k]) && met->p[k] > 0 && met->p[k] < 2000, "The levels of '%s' are not pressures!", levname);
+  }
   const double dx = fabs(met->lon[1] - met->lon[0]);
   for (int i = 2; i < met->nx; i++)
     REQUIRE(fabs(fabs(met->lon[i] - met->lon[i - 1]) - dx) <= 0.001, "No regular grid spacing in longitudes!");
