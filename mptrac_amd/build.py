@@ -50,6 +50,7 @@ def build_variant(name, extra_flags, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    verify_async_loads(out, verbose)
     return out
 
 
@@ -65,7 +66,22 @@ def build_hip(force=False, verbose=False, extra_flags=()):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        verify_async_loads(HIP_LIB, verbose)
     return HIP_LIB
+
+
+def verify_async_loads(lib, verbose=False):
+    """The corner caches issue gathers as inline assembly and wait for them later (csrc/mphip_device.hpp:
+    load_wind_cached / wind_cache_wait); a library in which the compiler touched such a register before
+    the wait would compute with stale data, so it is not kept."""
+    from . import check_async_loads as chk
+    hazards, kernels, nloads = chk.check(lib)
+    if hazards:
+        bad = lib + ".rejected"
+        os.replace(lib, bad)
+        raise RuntimeError(f"{len(hazards)} use-before-wait hazards in {os.path.basename(lib)} (kept as {bad}), e.g. {hazards[0]}")
+    if verbose:
+        print(f"{os.path.basename(lib)}: {kernels} kernels, {nloads} loads, no register touched before its load was waited for")
 
 
 HOST_DIR = os.path.join(HERE, "host")

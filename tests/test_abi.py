@@ -96,3 +96,34 @@ def test_integration_glue_type_checks_against_the_reference_header():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "integration", "typecheck_glue.py")],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()
+
+
+def test_async_load_check_sees_a_register_touched_before_its_wait():
+    """The checker itself: a spill of an in-flight register is a hazard, a later load into it is not."""
+    from mptrac_amd import check_async_loads as chk
+    spill = [("10", "global_load_dwordx4 v[30:33], v[18:19], off offset:32"),
+             ("18", "scratch_store_dwordx4 off, v[30:33], off offset:240"),
+             ("20", "s_waitcnt vmcnt(0)")]
+    assert len(chk.check_kernel("k", spill)) == 1
+    fine = [("10", "global_load_dwordx4 v[30:33], v[18:19], off"),
+            ("14", "v_add_f64 v[2:3], v[4:5], v[6:7]"),
+            ("18", "global_load_dwordx2 v[30:31], v[8:9], off"),        # loads return in order
+            ("1c", "s_waitcnt vmcnt(0)"),
+            ("20", "v_mov_b32_e32 v1, v30")]
+    assert chk.check_kernel("k", fine) == []
+    partial = [("10", "global_load_dword v1, v[18:19], off"),
+               ("14", "global_load_dword v2, v[18:19], off offset:4"),
+               ("18", "s_waitcnt vmcnt(1)"),
+               ("1c", "v_mov_b32_e32 v3, v1"),          # the older load has returned
+               ("20", "v_mov_b32_e32 v4, v2")]          # the younger one has not
+    assert len(chk.check_kernel("k", partial)) == 1
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs llvm-objdump")
+def test_built_library_touches_no_register_before_its_load_was_waited_for():
+    """csrc/mphip_device.hpp issues the corner gathers as inline assembly and waits for them in a later statement;
+    the machine code of the library that ships must not touch those registers in between."""
+    from mptrac_amd import check_async_loads as chk
+    hazards, kernels, nloads = chk.check(hip.load(build=False)._name)
+    assert kernels > 50 and nloads > 1000
+    assert hazards == [], hazards[:3]
