@@ -771,7 +771,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   }
   const bool ml_ = ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3;   // winds from the model levels
   // model levels: the fast path needs monotonic height columns and none of the rarely used modules
-  const bool ml_fast = ml_ && ctx->pk.ml_monotonic && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
+  const bool ml_fast = ml_ && ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels
+    && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
   const unsigned rare_bits = mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u);
   const bool rare = (ml_ && !ml_fast) || rare_bits;
   // the specialised instantiations take module_timesteps / the dt store from the run-time mask
@@ -787,7 +788,15 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // movers).  Everything else (single-module calls, the other rarely used modules) takes a general instantiation.
   constexpr unsigned kBound = MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
   unsigned sel = kMaskGeneric;
-  if (!(rare_bits & ~kBound) && !ml_ && !ctx->force_generic && lean_ok) {
+  if (!(rare_bits & ~kBound) && ml_fast && !ctx->force_generic && lean_ok) {
+    // model-level winds: the headline module set has lean instantiations (its subsets the gated one); the rest
+    // stays with the general model-level kernels below
+    const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
+    if (req == kAdvDiffConvSedi && !(mask & kBound))
+      sel = req | kMLWinds | (nsteps > 1 ? kMultiStep : 0u);
+    else if ((req & ~kOptionalModules) == kAdv && nsteps == 1)
+      sel = kAdvDiffConvSedi | kGated | kMLWinds;
+  } else if (!(rare_bits & ~kBound) && !ml_ && !ctx->force_generic && lean_ok) {
     const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
     const bool exact = req == kAdv || req == kAdvTurb || req == kAdvDiff || req == kAdvTurbConvSedi || req == kAdvDiffConvSedi;
     if (req == kTailOnly)
@@ -835,6 +844,9 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvTurb | kMultiStep)
     STEP_CASE(kAdvDiff | kMultiStep)
     STEP_CASE(kAdvDiffConvSedi | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kMLWinds)
+    STEP_CASE(kAdvDiffConvSedi | kMLWinds | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kMLWinds)
 #undef STEP_CASE
   default:
     if (nsteps > 1 && !(ml_fast && !rare && !ctx->force_generic))
@@ -2821,7 +2833,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
       return 1;
     const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
       && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // (launch_step's condition)
-    const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->d_kz != nullptr
+    const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels && ctx->d_kz != nullptr
                                 : lean_ok && (movers == kAdv || movers == kAdvTurb || movers == kAdvDiff || movers == kAdvDiffConvSedi);
     if (c.qnt_loss_rate >= 0)
       mask |= MPHIP_MOD_LOSS_ZERO;

@@ -1673,16 +1673,29 @@ __device__ __forceinline__ f32x4u load_h4(const float *__restrict__ h2, size_t c
   return *(const f32x4u *) (h2 + 2 * (col + (size_t) k));
 }
 
+// The searches compare the (double) height x with single-precision levels v.  With xd = the largest float <= x,
+// x >= v is v <= xd and x < v is v > xd for every float v (v <= x < next float above xd), so one conversion per
+// stencil replaces a conversion and a double-precision compare per level read.  (NaN: every compare false,
+// as with the doubles.)
+__device__ __forceinline__ float float_below(double x) {
+  float f = (float) x;
+  if ((double) f > x) {   // rounded up: one float down
+    const uint32_t b = __float_as_uint(f);
+    f = __uint_as_float(f > 0.f ? b - 1u : (f < 0.f ? b + 1u : 0x80000001u));
+  }
+  return f;
+}
+
 // -1: the index must decrease, +1: increase, 0: level pair (lo, hi) brackets x (bisection semantics of
-// locate_irr_float: ascending lo <= x < hi, descending lo > x >= hi)
-__device__ __forceinline__ int bracket_dir(float lo, float hi, double x) {
+// locate_irr_float: ascending lo <= x < hi, descending lo > x >= hi); xd = float_below(x)
+__device__ __forceinline__ int bracket_dir(float lo, float hi, float xd) {
   if (lo < hi)
-    return x < lo ? -1 : (x >= hi ? 1 : 0);
-  return x >= lo ? -1 : (x < hi ? 1 : 0);
+    return lo > xd ? -1 : (hi <= xd ? 1 : 0);
+  return lo <= xd ? -1 : (hi > xd ? 1 : 0);
 }
 
 // index of snapshot t (0 / 1) in a monotonic column by bisection over the packed pairs
-__device__ __forceinline__ int bisect_pair(const float *__restrict__ h2, size_t col, int n, double x, int t) {
+__device__ __forceinline__ int bisect_pair(const float *__restrict__ h2, size_t col, int n, float xd, int t) {
   int lo = 0, hi = n - 1;
   const int mid0 = (hi + lo) >> 1;
   const f32x4u m = load_h4(h2, col, mid0);
@@ -1690,7 +1703,7 @@ __device__ __forceinline__ int bisect_pair(const float *__restrict__ h2, size_t 
   while (hi > lo + 1) {
     const int mid = (hi + lo) >> 1;
     const float v = h2[2 * (col + (size_t) mid) + t];
-    if (asc ? (v > x) : (v <= x))
+    if (asc ? (v > xd) : (v <= xd))
       hi = mid;
     else
       lo = mid;
@@ -1698,36 +1711,63 @@ __device__ __forceinline__ int bisect_pair(const float *__restrict__ h2, size_t 
   return lo;
 }
 
-// indices of both snapshots in column `col`, starting from `guess` (a few neighbouring pairs, then
-// bisection); v0 returns the pair record at k0 (the caller usually needs exactly that one again)
-__device__ __forceinline__ void locate_pair(const float *__restrict__ h2, size_t col, int n, double x, int guess,
-                                            int &k0, int &k1, f32x4u &v0) {
-  int k = guess < 0 ? 0 : (guess > n - 2 ? n - 2 : guess);
-  bool f0 = false, f1 = false;
-  k0 = k1 = k;
-#pragma unroll 1
-  for (int it = 0; it < 4 && !(f0 && f1); it++) {
-    const f32x4u v = load_h4(h2, col, k);
-    const int d0 = bracket_dir(v[0], v[2], x), d1 = bracket_dir(v[1], v[3], x);
-    // at the ends of the column the bisection returns 0 / n - 2 for values outside the profile
-    if (!f0 && (d0 == 0 || (d0 < 0 && k == 0) || (d0 > 0 && k == n - 2))) {
-      f0 = true;
-      k0 = k;
-      v0 = v;
-    }
-    if (!f1 && (d1 == 0 || (d1 < 0 && k == 0) || (d1 > 0 && k == n - 2))) {
-      f1 = true;
-      k1 = k;
-    }
-    const int d = !f0 ? d0 : d1;
-    k += (f0 && f1) ? 0 : d;
-  }
-  if (!f0) {
+// The level indices of the four columns of a stencil, searched side by side: every round probes one level pair of
+// all four columns (four independent loads in flight; a column is done when both snapshots bracket, at most four
+// rounds, then bisection).  The
+// search is exact whatever its first guess (monotonic columns), so all four start from `guess`.  The state of a
+// column is one word -- k0 | k1 << 10 | probe << 20 | found << 30 -- because the model-level kernels sit at their
+// register limit (the records at the result are loaded again by the caller: one more round, but a parallel one).
+constexpr int kLockstepMaxLevels = 1024;
+
+__device__ __forceinline__ uint32_t pair_search_step(uint32_t S, const f32x4u v, int n, float x) {
+  const int k = (int) ((S >> 20) & 1023u);
+  const uint32_t found = S >> 30;
+  const int d0 = bracket_dir(v[0], v[2], x), d1 = bracket_dir(v[1], v[3], x);
+  const bool e0 = (d0 == 0) | ((d0 < 0) & (k == 0)) | ((d0 > 0) & (k == n - 2));
+  const bool e1 = (d1 == 0) | ((d1 < 0) & (k == 0)) | ((d1 > 0) & (k == n - 2));
+  const bool t0 = e0 & !(found & 1u), t1 = e1 & !(found & 2u);
+  uint32_t k0 = S & 1023u, k1 = (S >> 10) & 1023u;
+  k0 = t0 ? (uint32_t) k : k0;
+  k1 = t1 ? (uint32_t) k : k1;
+  const uint32_t f = found | (t0 ? 1u : 0u) | (t1 ? 2u : 0u);
+  const int d = (f & 1u) ? d1 : d0;
+  const int kn = k + (f == 3u ? 0 : d);
+  return k0 | (k1 << 10) | ((uint32_t) kn << 20) | (f << 30);
+}
+
+__device__ __forceinline__ void pair_search_finish(uint32_t S, const float *__restrict__ h2, size_t col, int n, float x,
+                                                   int &k0, int &k1) {
+  k0 = (int) (S & 1023u);
+  k1 = (int) ((S >> 10) & 1023u);
+  if (!(S & (1u << 30)))
     k0 = bisect_pair(h2, col, n, x, 0);
-    v0 = load_h4(h2, col, k0);
-  }
-  if (!f1)
+  if (!(S & (2u << 30)))
     k1 = bisect_pair(h2, col, n, x, 1);
+}
+
+__device__ __forceinline__ void locate_pairs4(const float *__restrict__ h2, size_t ca, size_t cb, size_t cc, size_t cd, int n,
+                                              float x, int guess, int &kmin, int &kmax) {
+  const uint32_t k = (uint32_t) (guess < 0 ? 0 : (guess > n - 2 ? n - 2 : guess));
+  uint32_t A = k | (k << 10) | (k << 20), B = A, C = A, D = A;
+#pragma unroll 1
+  for (int it = 0; it < 4; it++) {
+    // (the whole wave leaves together: a lane whose searches are done probes the same records again)
+    const f32x4u va = load_h4(h2, ca, (int) ((A >> 20) & 1023u)), vb = load_h4(h2, cb, (int) ((B >> 20) & 1023u)),
+                 vc = load_h4(h2, cc, (int) ((C >> 20) & 1023u)), vd = load_h4(h2, cd, (int) ((D >> 20) & 1023u));
+    A = pair_search_step(A, va, n, x);
+    B = pair_search_step(B, vb, n, x);
+    C = pair_search_step(C, vc, n, x);
+    D = pair_search_step(D, vd, n, x);
+    if (__all((A & B & C & D) >> 30 == 3u))
+      break;
+  }
+  int a0, a1, b0, b1, c0, c1, d0, d1;
+  pair_search_finish(A, h2, ca, n, x, a0, a1);
+  pair_search_finish(B, h2, cb, n, x, b0, b1);
+  pair_search_finish(C, h2, cc, n, x, c0, c1);
+  pair_search_finish(D, h2, cd, n, x, d0, d1);
+  kmin = min(min(min(a0, a1), min(b0, b1)), min(min(c0, c1), min(d0, d1)));
+  kmax = max(max(max(a0, a1), max(b0, b1)), max(max(c0, c1), max(d0, d1)));
 }
 
 __device__ __forceinline__ double level_pair_value(const Stencil4 &s, const f32x4u c00, const f32x4u c01,
@@ -1742,6 +1782,45 @@ __device__ __forceinline__ double level_pair_value(const Stencil4 &s, const f32x
   return s.wx * (b - a) + a;
 }
 
+// ---- level window -----------------------------------------------------------
+// A wave waits for its slowest lane: when each of the four columns is searched by probing one level pair per
+// round, nearly every wave has a lane that needs a second probe, then the records at the lowest index, then
+// another pair for the reference's while loop -- four or five dependent gather rounds per stencil, and the
+// model-level kernels were idle 43 % of the time waiting for them.  So the first (and almost always only) round
+// reads a WINDOW of four levels around the hint from every column, two 16-byte loads each: levels b .. b + 3,
+// which hold the pairs b, b + 1, b + 2.  If all eight searches (four columns, two snapshots) end inside it, the
+// indices, the records at the lowest index and the records the while loop steps through are all in registers.
+// A lane with a search that leaves the window takes the lockstep search and loads what it needs.
+#ifndef MPHIP_LEVEL_WINDOW
+#define MPHIP_LEVEL_WINDOW 1
+#endif
+
+// index of snapshot t among the pairs b, b + 1, b + 2 (w0: levels b, b + 1; w1: b + 2, b + 3), or -1
+__device__ __forceinline__ int window_index(const f32x4u w0, const f32x4u w1, int t, int b, int n, float xd) {
+  const float l0 = w0[t], l1 = w0[2 + t], l2 = w1[t], l3 = w1[2 + t];
+  const int d0 = bracket_dir(l0, l1, xd), d1 = bracket_dir(l1, l2, xd), d2 = bracket_dir(l2, l3, xd);
+  int k = -1;
+  k = ((d2 == 0) | ((d2 > 0) & (b + 2 == n - 2))) ? b + 2 : k;   // (ends of the column: as the bisection)
+  k = (d1 == 0) ? b + 1 : k;
+  k = ((d0 == 0) | ((d0 < 0) & (b == 0))) ? b : k;
+  return k;
+}
+
+// the pair record {h0[k], h1[k], h0[k+1], h1[k+1]} of a column: from its window if it holds pair k
+__device__ __forceinline__ f32x4u window_record(const float *__restrict__ h2, size_t col, const f32x4u w0, const f32x4u w1,
+                                                int b, bool have, int k) {
+  const int j = k - b;
+  if (have && (unsigned) j <= 2u) {
+    f32x4u r;
+    r[0] = j == 0 ? w0[0] : (j == 1 ? w0[2] : w1[0]);
+    r[1] = j == 0 ? w0[1] : (j == 1 ? w0[3] : w1[1]);
+    r[2] = j == 0 ? w0[2] : (j == 1 ? w1[0] : w1[2]);
+    r[3] = j == 0 ? w0[3] : (j == 1 ? w1[1] : w1[3]);
+    return r;
+  }
+  return load_h4(h2, col, k);
+}
+
 // stencil_4d on a packed height field; `hint` is any earlier vertical index (e.g. of the previous stage)
 __device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, const float *__restrict__ h2, double ts,
                                                 double height, double lon, double lat, int hint, Stencil4 &s) {
@@ -1753,27 +1832,39 @@ __device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, 
   const int n = M.npl;
   const size_t c00 = col_ml(M, s.ix, s.iy), c10 = col_ml(M, s.ix + 1, s.iy), c01 = col_ml(M, s.ix, s.iy + 1),
                c11 = col_ml(M, s.ix + 1, s.iy + 1);
-  int a0, a1, b0, b1, c0, c1, d0, d1;   // locate_vert order: (ix,iy) (ix+1,iy) (ix,iy+1) (ix+1,iy+1)
-  f32x4u q00, q10, q01, q11;
-  locate_pair(h2, c00, n, height, hint, a0, a1, q00);
-  locate_pair(h2, c10, n, height, a0, b0, b1, q10);
-  locate_pair(h2, c01, n, height, b0, c0, c1, q01);
-  locate_pair(h2, c11, n, height, c0, d0, d1, q11);
-  const int kmin = min(min(min(a0, a1), min(b0, b1)), min(min(c0, c1), min(d0, d1)));
-  const int kmax = max(max(max(a0, a1), max(b0, b1)), max(max(c0, c1), max(d0, d1)));
+  const float hd = float_below(height);
+  int kmin, kmax;
+#if MPHIP_LEVEL_WINDOW
+  const int b = min(max(hint - 1, 0), max(n - 4, 0));
+  f32x4u a0 = {}, a1 = {}, b0 = {}, b1 = {}, e0 = {}, e1 = {}, f0 = {}, f1 = {};   // windows of c00, c10, c01, c11
+  bool have = false;
+  if (n >= 4) {
+    a0 = load_h4(h2, c00, b); a1 = load_h4(h2, c00, b + 2);
+    b0 = load_h4(h2, c10, b); b1 = load_h4(h2, c10, b + 2);
+    e0 = load_h4(h2, c01, b); e1 = load_h4(h2, c01, b + 2);
+    f0 = load_h4(h2, c11, b); f1 = load_h4(h2, c11, b + 2);
+    const int k0 = window_index(a0, a1, 0, b, n, hd), k1 = window_index(a0, a1, 1, b, n, hd);
+    const int k2 = window_index(b0, b1, 0, b, n, hd), k3 = window_index(b0, b1, 1, b, n, hd);
+    const int k4 = window_index(e0, e1, 0, b, n, hd), k5 = window_index(e0, e1, 1, b, n, hd);
+    const int k6 = window_index(f0, f1, 0, b, n, hd), k7 = window_index(f0, f1, 1, b, n, hd);
+    kmin = min(min(min(k0, k1), min(k2, k3)), min(min(k4, k5), min(k6, k7)));
+    kmax = max(max(max(k0, k1), max(k2, k3)), max(max(k4, k5), max(k6, k7)));
+    have = kmin >= 0;
+  }
+  if (!have)
+    locate_pairs4(h2, c00, c10, c01, c11, n, hd, hint, kmin, kmax);
   s.iz = kmin;
+  f32x4u q00 = window_record(h2, c00, a0, a1, b, have, s.iz), q10 = window_record(h2, c10, b0, b1, b, have, s.iz),
+         q01 = window_record(h2, c01, e0, e1, b, have, s.iz), q11 = window_record(h2, c11, f0, f1, b, have, s.iz);
+#else
+  locate_pairs4(h2, c00, c10, c01, c11, n, hd, hint, kmin, kmax);
+  s.iz = kmin;
+  f32x4u q00 = load_h4(h2, c00, s.iz), q10 = load_h4(h2, c10, s.iz), q01 = load_h4(h2, c01, s.iz),
+         q11 = load_h4(h2, c11, s.iz);
+#endif
   s.wt = div_const(ts - M.time0, M.time1 - M.time0, M.inv_dtime);
   s.wx = div_const(lon2 - A.lon[s.ix], A.lon[s.ix + 1] - A.lon[s.ix], A.inv_lon[s.ix]);
   s.wy = div_const(lat2 - hy.x0, hy.x1 - hy.x0, hy.inv);
-  // the records at the lowest index: already there for the columns whose snapshot-0 index is that one
-  if (a0 != s.iz)
-    q00 = load_h4(h2, c00, s.iz);
-  if (b0 != s.iz)
-    q10 = load_h4(h2, c10, s.iz);
-  if (c0 != s.iz)
-    q01 = load_h4(h2, c01, s.iz);
-  if (d0 != s.iz)
-    q11 = load_h4(h2, c11, s.iz);
   double bot = level_pair_value(s, q00, q01, q10, q11, 0);
   double top = level_pair_value(s, q00, q01, q10, q11, 1);
   const float g0 = h2[0], g1 = h2[2];   // heights0[0][0][0], heights0[0][0][1]
@@ -1781,10 +1872,17 @@ __device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, 
          || ((g0 < g1) && ((bot >= height) || (top < height)) && (bot <= height) && (s.iz < kmax))) {
     s.iz++;
     bot = top;
+#if MPHIP_LEVEL_WINDOW
+    q00 = window_record(h2, c00, a0, a1, b, have, s.iz);
+    q01 = window_record(h2, c01, e0, e1, b, have, s.iz);
+    q10 = window_record(h2, c10, b0, b1, b, have, s.iz);
+    q11 = window_record(h2, c11, f0, f1, b, have, s.iz);
+#else
     q00 = load_h4(h2, c00, s.iz);
     q01 = load_h4(h2, c01, s.iz);
     q10 = load_h4(h2, c10, s.iz);
     q11 = load_h4(h2, c11, s.iz);
+#endif
     top = level_pair_value(s, q00, q01, q10, q11, 1);
   }
   s.wz = (height - bot) / (top - bot);
@@ -1823,7 +1921,22 @@ __device__ __forceinline__ void ml_cache_reset(MlCache &w) {
         w.c.r[di][dj][k] = f32x4u{ 0.f, 0.f, 0.f, 0.f };
 }
 
+#ifndef MPHIP_ML_CACHE
+#define MPHIP_ML_CACHE 0
+#endif
 __device__ __forceinline__ void load_ml_cached(const DevMet &M, const Stencil4 &s, MlCache &w) {
+#if !MPHIP_ML_CACHE
+#pragma unroll
+  for (int di = 0; di < 2; di++)
+#pragma unroll
+    for (int dj = 0; dj < 2; dj++) {
+      const float *q = M.mlw + 6 * (col_ml(M, s.ix + di, s.iy + dj) + (size_t) s.iz);
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        w.c.r[di][dj][k] = *(const f32x4u *) (q + 4 * k);
+    }
+  return;
+#endif
   if (s.ix != w.ix || s.iy != w.iy || s.iz != w.iz) {
 #pragma unroll
     for (int di = 0; di < 2; di++)

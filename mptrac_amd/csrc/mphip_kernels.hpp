@@ -130,9 +130,18 @@ constexpr unsigned kMaskGenericML = 0xfffffffdu;
 // ... and the same with StepParams::nsteps time steps per particle and launch (see kMultiStep)
 constexpr unsigned kMaskGenericMLMulti = 0xfffffffbu;
 template <unsigned CT>
-constexpr bool kModelLevels = (CT == kMaskGenericML || CT == kMaskGenericMLMulti);
+constexpr bool kGenericML = (CT == kMaskGenericML || CT == kMaskGenericMLMulti);
 template <unsigned CT>
-constexpr bool kRuntimeMask = (CT == kMaskGeneric || CT == kMaskGenericPL || kModelLevels<CT>);
+constexpr bool kRuntimeMask = (CT == kMaskGeneric || CT == kMaskGenericPL || kGenericML<CT>);
+// template mask only, on a lean instantiation: the advection is the model-level one (advect_ml_fast /
+// advect_mlp_fast on the packed height fields, as in kMaskGenericML) and everything behind it the lean code of the
+// pressure-level kernels -- the model-level runs of the headline module set no longer pay for the general
+// versions of the diffusion, convection and sedimentation modules
+constexpr unsigned kMLWinds = 1u << 27;
+template <unsigned CT>
+constexpr bool kLeanML = !kRuntimeMask<CT> && (CT & kMLWinds) != 0;
+template <unsigned CT>
+constexpr bool kModelLevels = kGenericML<CT> || kLeanML<CT>;
 constexpr unsigned kRareModules = MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT | MPHIP_MOD_ISOSURF | MPHIP_MOD_DIFF_PBL
   | MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
 constexpr unsigned kStoreDt = 1u << 30;   // write cache->dt (needed when a later launch reads it)
@@ -148,7 +157,7 @@ constexpr unsigned kGated = 1u << 25;
 // of steps with nothing between them -- no module_sort, mixing, output -- at small particle counts, where a step is
 // shorter than a kernel launch).  The state goes through memory between the steps as it does between launches.
 constexpr unsigned kMultiStep = 1u << 26;
-constexpr unsigned kTemplateFlags = kTwoStage | kGated | kMultiStep;
+constexpr unsigned kTemplateFlags = kTwoStage | kGated | kMultiStep | kMLWinds;
 constexpr unsigned kOptionalModules = MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kTailModules = MPHIP_MOD_LOSS_ZERO | MPHIP_MOD_DECAY | MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & kMultiStep) ? MPHIP
     const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) ld_state(&a.ext[i]) : i));
 
     // specialised instantiations = RK4 on pressure levels (launch_step): 4 stages, all hooks run
-    constexpr bool early = MPHIP_RNG_EARLY && !kRuntimeMask<CT> && (CT & MPHIP_MOD_ADVECT);
+    constexpr bool early = MPHIP_RNG_EARLY && !kRuntimeMask<CT> && (CT & MPHIP_MOD_ADVECT) && !kLeanML<CT>;
     RngEarly pre;
     pre.mask = mask;
     pre.ctr_turb = c_turb;
@@ -711,10 +720,10 @@ __global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & kMultiStep) ? MPHIP
         vp = ld_state(&a.vp[i]);
         wp = ld_state(&a.wp[i]);
       }
-      if (kModelLevels<CT>)
+      if (kGenericML<CT>)
         wind_cache_reset(wc, true);
-      if (lean)
-        diff_meso_fast<!(CT & MPHIP_MOD_ADVECT)>(ctl, M, A, P, up, vp, wp, c_meso, g, early ? pre.meso : nullptr, wc, ltab);
+      if (lean)   // (without a pressure-level advection before it there are no cached corners: the streaming version)
+        diff_meso_fast<!(CT & MPHIP_MOD_ADVECT) || kLeanML<CT>>(ctl, M, A, P, up, vp, wp, c_meso, g, early ? pre.meso : nullptr, wc, ltab);
       else
         diff_meso(ctl, M, A, P, up, vp, wp, c_meso, g, early ? pre.meso : nullptr, wc, ltab);
       st_state(&a.up[i], up);
