@@ -523,8 +523,11 @@ struct RngEarly {
 #ifndef MPHIP_SPLITB_WAVES_PER_SIMD
 #define MPHIP_SPLITB_WAVES_PER_SIMD 4
 #endif
+#ifndef MPHIP_ML_WAVES_PER_SIMD
+#define MPHIP_ML_WAVES_PER_SIMD 3   // the lean model-level instantiations: 148-158 VGPRs without scratch; at four waves (128 VGPRs) they spill 35-56 dwords: C3z 1.98 -> 1.81 ms per step (profiles/r04_variants.txt item 11)
+#endif
 template <unsigned CT>
-__global__ __launch_bounds__(256, !kRuntimeMask<CT> ? ((CT & kMultiStep) ? MPHIP_MULTI_WAVES_PER_SIMD
+__global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRuntimeMask<CT> ? ((CT & kMultiStep) ? MPHIP_MULTI_WAVES_PER_SIMD
                                                         : (CT & MPHIP_MOD_ADVECT) || CT == MPHIP_MOD_TIMESTEPS ? MPHIP_LEAN_WAVES_PER_SIMD : MPHIP_SPLITB_WAVES_PER_SIMD)
                                    : (CT == kMaskGenericPL ? MPHIP_STEP_WAVES_PER_SIMD : MPHIP_GENERIC_WAVES_PER_SIMD)) void step_kernel(
   const StepParams S) {
