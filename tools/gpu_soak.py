@@ -4,7 +4,11 @@ wet / dry deposition, convection, sedimentation, diffusion) plus module_meteo qu
 20 h with three meteo hand-overs through mphip_prefetch_met / mphip_commit_met and downloads every 97 steps.
 Prints the relative deviations on the way; fails above the 1e-10 bar.
   python tools/gpu_soak.py batched     the C3 module set (`conv_sedi`: nothing scheduled between the steps) handed to
-                                       the device twenty steps at a time (mphip_run_timesteps: shared launches)"""
+                                       the device twenty steps at a time (mphip_run_timesteps: shared launches)
+  python tools/gpu_soak.py zeta        the same hand-over with winds from the model levels (`zeta_full`: zeta
+                                       advection, diffusion, convection, sedimentation -- the lean model-level kernels);
+                                       the level search of a step starts from the index the step before stored, which
+                                       after a meteo hand-over points into fields that have changed"""
 import os
 import sys
 import time
@@ -20,8 +24,14 @@ from mptrac_amd.ctl import ctl_from_quantities  # noqa: E402
 from mptrac_amd.synth import FIELDS_METEO_ONLY, synthetic_met, synthetic_particles  # noqa: E402
 from oracle import binding as B  # noqa: E402
 
-batched = "batched" in sys.argv[1:]
-if batched:
+zeta = "zeta" in sys.argv[1:]
+batched = "batched" in sys.argv[1:] or zeta
+if zeta:
+    names = tuple(cases.QUANTITIES_ML)
+    ctl = dict(cases.CASES["zeta_full"])
+    ctl.update(ctl_from_quantities(names))
+    ctl.update(t_stop=4 * 18000.0, dt_met=18000.0, met_dt_out=0.0)
+elif batched:
     names = ("m", "rp", "rhop")
     ctl = dict(cases.CASES["conv_sedi"])
     ctl.update(ctl_from_quantities(names))
@@ -31,9 +41,11 @@ else:
     ctl = dict(cases.CASES["full"])
     ctl.update(ctl_from_quantities(names))
     ctl.update(t_stop=4 * 18000.0, dt_met=18000.0, met_dt_out=0.1, sort_dt=1800.0, mixing_dt=900.0)
-fields = tuple(cases.PRESSURE_LEVEL_FIELDS) + tuple(FIELDS_METEO_ONLY)
+fields = None if zeta else tuple(cases.PRESSURE_LEVEL_FIELDS) + tuple(FIELDS_METEO_ONLY)   # (None: model-level fields too)
 mets = [synthetic_met("C1", 18000.0 * k, 1.0 + 0.1 * k, fields=fields) for k in range(6)]
 atm = synthetic_particles(100000, seed=7, quantities=names)
+if zeta:      # a vertical coordinate inside the range of the synthetic zetal field (as cases.make_case)
+    atm["q"][list(names).index("zeta")] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
 clim = cases.load_clim_tropo()
 B.lib().orc_set_num_threads(B.usable_cores())
 o = B.Oracle(ctl, clim, mets[0], mets[1], atm)
