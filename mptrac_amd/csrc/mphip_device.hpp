@@ -1668,9 +1668,18 @@ __device__ __forceinline__ double pressure_from_zeta(const DevMet &M, const Axes
 // from the previous result; the packed pairs {h0,h1} make one 16-byte gather return levels k and k + 1 of
 // both snapshots, where the reference-shaped code issues four dword gathers.
 
+// The column index type COL of the functions below is size_t (any grid) or uint32_t: the lean instantiations run
+// only where launch_step has checked that 24 bytes x cells fit 32 bits, and a 32-bit index lets the loads take
+// their base from SGPRs and one offset register per lane instead of a 64-bit address built per load.
+template <class COL>
+__device__ __forceinline__ COL col_ml_as(const DevMet &M, int ix, int iy) {
+  return ((COL) ix * (COL) M.ny + (COL) iy) * (COL) M.npl;
+}
+
 // levels k, k + 1 of both snapshots of column `col`: {h0[k], h1[k], h0[k+1], h1[k+1]}
-__device__ __forceinline__ f32x4u load_h4(const float *__restrict__ h2, size_t col, int k) {
-  return *(const f32x4u *) (h2 + 2 * (col + (size_t) k));
+template <class COL>
+__device__ __forceinline__ f32x4u load_h4(const float *__restrict__ h2, COL col, int k) {
+  return *(const f32x4u *) ((const char *) h2 + (COL) 8 * (col + (COL) k));
 }
 
 // The searches compare the (double) height x with single-precision levels v.  With xd = the largest float <= x,
@@ -1695,14 +1704,15 @@ __device__ __forceinline__ int bracket_dir(float lo, float hi, float xd) {
 }
 
 // index of snapshot t (0 / 1) in a monotonic column by bisection over the packed pairs
-__device__ __forceinline__ int bisect_pair(const float *__restrict__ h2, size_t col, int n, float xd, int t) {
+template <class COL>
+__device__ __forceinline__ int bisect_pair(const float *__restrict__ h2, COL col, int n, float xd, int t) {
   int lo = 0, hi = n - 1;
   const int mid0 = (hi + lo) >> 1;
   const f32x4u m = load_h4(h2, col, mid0);
   const bool asc = m[t] < m[2 + t];
   while (hi > lo + 1) {
     const int mid = (hi + lo) >> 1;
-    const float v = h2[2 * (col + (size_t) mid) + t];
+    const float v = ((const float *) ((const char *) h2 + (COL) 8 * (col + (COL) mid)))[t];
     if (asc ? (v > xd) : (v <= xd))
       hi = mid;
     else
@@ -1735,7 +1745,8 @@ __device__ __forceinline__ uint32_t pair_search_step(uint32_t S, const f32x4u v,
   return k0 | (k1 << 10) | ((uint32_t) kn << 20) | (f << 30);
 }
 
-__device__ __forceinline__ void pair_search_finish(uint32_t S, const float *__restrict__ h2, size_t col, int n, float x,
+template <class COL>
+__device__ __forceinline__ void pair_search_finish(uint32_t S, const float *__restrict__ h2, COL col, int n, float x,
                                                    int &k0, int &k1) {
   k0 = (int) (S & 1023u);
   k1 = (int) ((S >> 10) & 1023u);
@@ -1745,7 +1756,8 @@ __device__ __forceinline__ void pair_search_finish(uint32_t S, const float *__re
     k1 = bisect_pair(h2, col, n, x, 1);
 }
 
-__device__ __forceinline__ void locate_pairs4(const float *__restrict__ h2, size_t ca, size_t cb, size_t cc, size_t cd, int n,
+template <class COL>
+__device__ __forceinline__ void locate_pairs4(const float *__restrict__ h2, COL ca, COL cb, COL cc, COL cd, int n,
                                               float x, int guess, int &kmin, int &kmax) {
   const uint32_t k = (uint32_t) (guess < 0 ? 0 : (guess > n - 2 ? n - 2 : guess));
   uint32_t A = k | (k << 10) | (k << 20), B = A, C = A, D = A;
@@ -1807,7 +1819,8 @@ __device__ __forceinline__ int window_index(const f32x4u w0, const f32x4u w1, in
 }
 
 // the pair record {h0[k], h1[k], h0[k+1], h1[k+1]} of a column: from its window if it holds pair k
-__device__ __forceinline__ f32x4u window_record(const float *__restrict__ h2, size_t col, const f32x4u w0, const f32x4u w1,
+template <class COL>
+__device__ __forceinline__ f32x4u window_record(const float *__restrict__ h2, COL col, const f32x4u w0, const f32x4u w1,
                                                 int b, bool have, int k) {
   const int j = k - b;
   if (have && (unsigned) j <= 2u) {
@@ -1822,6 +1835,7 @@ __device__ __forceinline__ f32x4u window_record(const float *__restrict__ h2, si
 }
 
 // stencil_4d on a packed height field; `hint` is any earlier vertical index (e.g. of the previous stage)
+template <class COL = size_t>
 __device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, const float *__restrict__ h2, double ts,
                                                 double height, double lon, double lat, int hint, Stencil4 &s) {
   double lon2, lat2;
@@ -1830,8 +1844,8 @@ __device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, 
   s.ix = locate_lon(M, A, lon2);
   s.iy = hy.i;
   const int n = M.npl;
-  const size_t c00 = col_ml(M, s.ix, s.iy), c10 = col_ml(M, s.ix + 1, s.iy), c01 = col_ml(M, s.ix, s.iy + 1),
-               c11 = col_ml(M, s.ix + 1, s.iy + 1);
+  const COL c00 = col_ml_as<COL>(M, s.ix, s.iy), c10 = col_ml_as<COL>(M, s.ix + 1, s.iy),
+            c01 = col_ml_as<COL>(M, s.ix, s.iy + 1), c11 = col_ml_as<COL>(M, s.ix + 1, s.iy + 1);
   const float hd = float_below(height);
   int kmin, kmax;
 #if MPHIP_LEVEL_WINDOW
@@ -1889,13 +1903,14 @@ __device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, 
 }
 
 // ml_field on a packed pair array
+template <class COL = size_t>
 __device__ __forceinline__ double ml_field_fast(const DevMet &M, const float *__restrict__ a2, const Stencil4 &s) {
   double v[2][2][2];
 #pragma unroll
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++) {
-      const f32x4u q = load_h4(a2, col_ml(M, s.ix + di, s.iy + dj), s.iz);
+      const f32x4u q = load_h4(a2, col_ml_as<COL>(M, s.ix + di, s.iy + dj), s.iz);
 #pragma unroll
       for (int l = 0; l < 2; l++)
         v[di][dj][l] = s.wt * (double) (q[2 * l + 1] - q[2 * l]) + (double) q[2 * l];
@@ -1924,16 +1939,17 @@ __device__ __forceinline__ void ml_cache_reset(MlCache &w) {
 #ifndef MPHIP_ML_CACHE
 #define MPHIP_ML_CACHE 0
 #endif
+template <class COL = size_t>
 __device__ __forceinline__ void load_ml_cached(const DevMet &M, const Stencil4 &s, MlCache &w) {
 #if !MPHIP_ML_CACHE
 #pragma unroll
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++) {
-      const float *q = M.mlw + 6 * (col_ml(M, s.ix + di, s.iy + dj) + (size_t) s.iz);
+      const COL off = (COL) 24 * (col_ml_as<COL>(M, s.ix + di, s.iy + dj) + (COL) s.iz);
 #pragma unroll
       for (int k = 0; k < 3; k++)
-        w.c.r[di][dj][k] = *(const f32x4u *) (q + 4 * k);
+        w.c.r[di][dj][k] = *(const f32x4u *) ((const char *) M.mlw + off + (COL) (16 * k));
     }
   return;
 #endif
@@ -1963,13 +1979,13 @@ __device__ __forceinline__ void load_ml_cached(const DevMet &M, const Stencil4 &
 }
 
 // module_advect, zeta / eta branch, on the packed height fields (same arithmetic as advect_ml_n)
-template <int ADVECT>
+template <int ADVECT, class COL>
 __device__ __forceinline__ void advect_ml_fast_n(const DevMet &M, const Axes &A, Particle &P, double &zeta, int &kz) {
   const int ct = M.coord_type;
   const double dt = P.dt;
   Stencil4 s;
-  stencil_4d_fast(M, A, M.pl2, P.time, P.p, P.lon, P.lat, kz, s);
-  zeta = ml_field_fast(M, M.zl2, s);
+  stencil_4d_fast<COL>(M, A, M.pl2, P.time, P.p, P.lon, P.lat, kz, s);
+  zeta = ml_field_fast<COL>(M, M.zl2, s);
   double u = 0, v = 0, wdot = 0, um = 0, vm = 0, wdotm = 0, x0 = 0, x1 = 0, x2 = 0;
   MlCache mc;
   ml_cache_reset(mc);
@@ -1987,8 +2003,8 @@ __device__ __forceinline__ void advect_ml_fast_n(const DevMet &M, const Axes &A,
       x1 = P.lat + dy2coord(ct, dts * v);
       x2 = zeta + dts * wdot;
     }
-    stencil_4d_fast(M, A, M.zl2, P.time + dts, x2, x0, x1, s.iz, s);
-    load_ml_cached(M, s, mc);
+    stencil_4d_fast<COL>(M, A, M.zl2, P.time + dts, x2, x0, x1, s.iz, s);
+    load_ml_cached<COL>(M, s, mc);
     u = ml_packed(mc.c, s, 0);
     v = ml_packed(mc.c, s, 1);
     wdot = ml_packed(mc.c, s, 2);
@@ -2005,23 +2021,24 @@ __device__ __forceinline__ void advect_ml_fast_n(const DevMet &M, const Axes &A,
   P.lon += dx2coord(ct, dt * um, (ADVECT == 2 ? x1 : P.lat));
   P.lat += dy2coord(ct, dt * vm);
   zeta += dt * wdotm;
-  stencil_4d_fast(M, A, M.zl2, P.time, zeta, P.lon, P.lat, s.iz, s);
-  P.p = ml_field_fast(M, M.pl2, s);
+  stencil_4d_fast<COL>(M, A, M.zl2, P.time, zeta, P.lon, P.lat, s.iz, s);
+  P.p = ml_field_fast<COL>(M, M.pl2, s);
   kz = s.iz;
 }
 
+template <class COL = size_t>
 __device__ __forceinline__ void advect_ml_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                                double &zeta, int &kz) {
   if (ctl.advect == 4)
-    advect_ml_fast_n<4>(M, A, P, zeta, kz);
+    advect_ml_fast_n<4, COL>(M, A, P, zeta, kz);
   else if (ctl.advect == 2)
-    advect_ml_fast_n<2>(M, A, P, zeta, kz);
+    advect_ml_fast_n<2, COL>(M, A, P, zeta, kz);
   else
-    advect_ml_fast_n<1>(M, A, P, zeta, kz);
+    advect_ml_fast_n<1, COL>(M, A, P, zeta, kz);
 }
 
 // ADVECT_VERT_COORD 2 on the packed pressure field (monotonic columns), as advect_mlp_n
-template <int ADVECT>
+template <int ADVECT, class COL>
 __device__ __forceinline__ void advect_mlp_fast_n(const DevMet &M, const Axes &A, Particle &P, int &kz) {
   const int ct = M.coord_type;
   const double dt = P.dt;
@@ -2044,8 +2061,8 @@ __device__ __forceinline__ void advect_mlp_fast_n(const DevMet &M, const Axes &A
       x1 = P.lat + dy2coord(ct, dts * v);
       x2 = P.p + dts * w;
     }
-    stencil_4d_fast(M, A, M.pl2, P.time + dts, x2, x0, x1, s.iz, s);
-    load_ml_cached(M, s, mc);
+    stencil_4d_fast<COL>(M, A, M.pl2, P.time + dts, x2, x0, x1, s.iz, s);
+    load_ml_cached<COL>(M, s, mc);
     u = ml_packed(mc.c, s, 0);
     v = ml_packed(mc.c, s, 1);
     w = ml_packed(mc.c, s, 2);
@@ -2065,14 +2082,15 @@ __device__ __forceinline__ void advect_mlp_fast_n(const DevMet &M, const Axes &A
   kz = s.iz;
 }
 
+template <class COL = size_t>
 __device__ __forceinline__ void advect_mlp_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                                 int &kz) {
   if (ctl.advect == 4)
-    advect_mlp_fast_n<4>(M, A, P, kz);
+    advect_mlp_fast_n<4, COL>(M, A, P, kz);
   else if (ctl.advect == 2)
-    advect_mlp_fast_n<2>(M, A, P, kz);
+    advect_mlp_fast_n<2, COL>(M, A, P, kz);
   else
-    advect_mlp_fast_n<1>(M, A, P, kz);
+    advect_mlp_fast_n<1, COL>(M, A, P, kz);
 }
 
 __device__ __forceinline__ double pressure_from_zeta_fast(const DevMet &M, const Axes &A, double time, double zeta,

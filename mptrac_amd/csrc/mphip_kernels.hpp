@@ -7,6 +7,7 @@
 //   mix_* / grid_*   inter-parcel mixing and gridded-output sums
 #pragma once
 
+#include <type_traits>
 #include "mphip_device.hpp"
 
 namespace mphip {
@@ -523,6 +524,9 @@ struct RngEarly {
 #ifndef MPHIP_SPLITB_WAVES_PER_SIMD
 #define MPHIP_SPLITB_WAVES_PER_SIMD 4
 #endif
+#ifndef MPHIP_ML_OFF32
+#define MPHIP_ML_OFF32 1
+#endif
 #ifndef MPHIP_ML_WAVES_PER_SIMD
 #define MPHIP_ML_WAVES_PER_SIMD 3   // the lean model-level instantiations: 148-158 VGPRs without scratch; at four waves (128 VGPRs) they spill 35-56 dwords: C3z 1.98 -> 1.81 ms per step (profiles/r04_variants.txt item 11)
 #endif
@@ -533,6 +537,8 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
   const StepParams S) {
   extern __shared__ double s_axes[];
   const unsigned mask = kRuntimeMask<CT> ? S.mask : (CT & ~kTemplateFlags);
+  // column indices of the model-level fields: 32 bits in the lean instantiations (launch_step's size check)
+  using MLCol = std::conditional_t<kLeanML<CT> && MPHIP_ML_OFF32, uint32_t, size_t>;
   const DevMet &M = S.met;
   const DevAtm &a = S.atm;
   const mphip_ctl_t &ctl = S.ctl;
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
         advect_mlp(ctl, M, A, P);      // pressure advection, winds from the model levels
       } else if (kModelLevels<CT> && ctl.advect_vert_coord == 2) {
         int kz = a.kz[i];
-        advect_mlp_fast(ctl, M, A, P, kz);
+        advect_mlp_fast<MLCol>(ctl, M, A, P, kz);
         a.kz[i] = kz;
       } else if (CT == kMaskGeneric && (ctl.advect_vert_coord == 1 || ctl.advect_vert_coord == 3)) {
         const int qnt = ctl.advect_vert_coord == 1 ? ctl.qnt_zeta : ctl.qnt_eta;
@@ -688,7 +694,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
         const int qnt = ctl.advect_vert_coord == 1 ? ctl.qnt_zeta : ctl.qnt_eta;
         double zeta;
         int kz = a.kz[i];     // vertical index of the last step: first guess of this step's searches
-        advect_ml_fast(ctl, M, A, P, zeta, kz);
+        advect_ml_fast<MLCol>(ctl, M, A, P, zeta, kz);
         a.kz[i] = kz;
         a.q[qnt][i] = zeta;
       } else if (lean && early)
