@@ -794,11 +794,13 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
     if (req == kAdvDiffConvSedi && !(mask & kBound))
       sel = req | kMLWinds | (nsteps > 1 ? kMultiStep : 0u);
-    else if ((req & ~kOptionalModules) == kAdv && nsteps == 1)
-      sel = kAdvDiffConvSedi | kGated | kMLWinds;
+    else if ((req & ~kOptionalModules) == kAdv && (nsteps == 1 || !(mask & kBound)))
+      sel = kAdvDiffConvSedi | kGated | kMLWinds | (nsteps > 1 ? kMultiStep : 0u);
   } else if (!(rare_bits & ~kBound) && !ml_ && !ctx->force_generic && lean_ok) {
     const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
-    const bool exact = req == kAdv || req == kAdvTurb || req == kAdvDiff || req == kAdvTurbConvSedi || req == kAdvDiffConvSedi;
+    // (kAdvTurbConvSedi has a kernel of its own for single steps only: several steps per launch take the gated one)
+    const bool exact = req == kAdv || req == kAdvTurb || req == kAdvDiff || req == kAdvDiffConvSedi
+      || (req == kAdvTurbConvSedi && nsteps == 1);
     if (req == kTailOnly)
       sel = kTailOnly;
     else if (req == kDiffConvSediOnly && !(mask & kBound))
@@ -806,7 +808,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     else if (exact && !(mask & kBound))
       sel = req | scheme | (nsteps > 1 ? kMultiStep : 0u);
     else if ((req & ~kOptionalModules) == kAdv)
-      sel = kAdvDiffConvSedi | kGated | scheme;
+      sel = kAdvDiffConvSedi | kGated | scheme | (nsteps > 1 ? kMultiStep : 0u);
   }
   // module_wet_depo / module_dry_depo alone (the launch behind module_mixing): the kernel that packs the few
   // particles with anything to do into full waves
@@ -847,6 +849,13 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiffConvSedi | kMLWinds)
     STEP_CASE(kAdvDiffConvSedi | kMLWinds | kMultiStep)
     STEP_CASE(kAdvDiffConvSedi | kGated | kMLWinds)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kMLWinds | kMultiStep)
+    STEP_CASE(kAdv | kTwoStage | kMultiStep)
+    STEP_CASE(kAdvTurb | kTwoStage | kMultiStep)
+    STEP_CASE(kAdvDiff | kTwoStage | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kTwoStage | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kTwoStage | kMultiStep)
 #undef STEP_CASE
   default:
     if (nsteps > 1 && !(ml_fast && !rare && !ctx->force_generic))
@@ -2785,7 +2794,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !(c.sort_dt > 0) && !(meteo && c.met_dt_out > 0)
       && !(c.mixing_trop >= 0 && c.mixing_strat >= 0) && !(c.isosurf >= 1 && c.isosurf <= 4)
       && !(c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1) && !(c.diffusion && c.turb_pbl_scheme == 1)
-      && !((c.conv_mix_pbl || c.conv_cape >= 0) && c.conv_dt > 0) && c.advect == 4
+      && !((c.conv_mix_pbl || c.conv_cape >= 0) && c.conv_dt > 0)   // (every integrator has its multi-step instantiations)
       && !(meteo && ctx->meteo_pending) && !ctx->fused_perm
       && !ctx->force_generic && !ctx->split_step;
     if (quiet) {
@@ -2834,7 +2843,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
       && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // (launch_step's condition)
     const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels && ctx->d_kz != nullptr
-                                : lean_ok && (movers == kAdv || movers == kAdvTurb || movers == kAdvDiff || movers == kAdvDiffConvSedi);
+                                : lean_ok && (movers & ~kOptionalModules) == kAdv;   // (exact sets: their own kernels; subsets: the gated one)
     if (c.qnt_loss_rate >= 0)
       mask |= MPHIP_MOD_LOSS_ZERO;
     if (c.tdec_trop > 0 && c.tdec_strat > 0)

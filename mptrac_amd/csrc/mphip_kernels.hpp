@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
     const uint64_t g = (uint64_t) (a.ip0 + (a.ext ? (long long) ld_state(&a.ext[i]) : i));
 
     // specialised instantiations = RK4 on pressure levels (launch_step): 4 stages, all hooks run
-    constexpr bool early = MPHIP_RNG_EARLY && !kRuntimeMask<CT> && (CT & MPHIP_MOD_ADVECT) && !kLeanML<CT>;
+    constexpr bool early = MPHIP_RNG_EARLY && !kRuntimeMask<CT> && (CT & MPHIP_MOD_ADVECT) && !(CT & kTwoStage) && !kLeanML<CT>;   // (the hooks belong to the four-stage integrator)
     RngEarly pre;
     pre.mask = mask;
     pre.ctr_turb = c_turb;

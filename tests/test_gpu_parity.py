@@ -1568,15 +1568,34 @@ def test_long_run_400_steps_with_prefetched_handovers():
     s.close()
 
 
+_BATCH_CASES = [(c, None) for c in ("advect", "turb", "diff", "conv_sedi", "full", "zeta_full", "mlp_full")] + [
+    # the reference's default integrator (midpoint) and Euler: two-stage instantiations; trajectories with winds
+    # from the model levels: the gated lean model-level instantiation
+    ("advect", 2), ("conv_sedi", 2), ("turb", 2), ("diff", 1), ("zeta_full", 2), ("zeta_full", 1), ("mlp_full", 2),
+    ("advect_zeta", None), ("advect_zeta", 2),
+    # subsets without a kernel of their own take the gated instantiation, also several steps per launch: a gas tracer
+    # (diffusion and convection, no sedimentation), turbulent diffusion + convection + sedimentation (own kernel for
+    # single steps only), convection alone
+    ("conv_sedi", "gas"), ("conv_sedi", "gas2"), ("conv_sedi", "turb_only"), ("conv_thresh", None), ("conv_thresh", 2)]
+_BATCH_OVERRIDES = {"gas": dict(qnt_rp=-1, qnt_rhop=-1), "gas2": dict(qnt_rp=-1, qnt_rhop=-1, advect=2),
+                    "turb_only": dict(turb_mesox=0.0, turb_mesoz=0.0)}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["advect", "turb", "diff", "conv_sedi", "full", "zeta_full", "mlp_full"])
-def test_run_timesteps_equals_the_step_by_step_loop(case):
+@pytest.mark.parametrize("case,advect", _BATCH_CASES, ids=[c if a is None else f"{c}-{a if isinstance(a, str) else 'advect%d' % a}"
+                                                           for c, a in _BATCH_CASES])
+def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
     """mphip_run_timesteps (the reference's time loop, trac.c:204-226, as one call): runs of steps with nothing
     scheduled between them share a kernel launch in which every particle takes its steps one after the other;
     same bits as one mphip_run_timestep per step -- state, uvwp and the counter of the random numbers --,
     whether the batches are long, short, cut by the internal re-sort, or (module sets with module_sort / mixing:
-    "full") not possible at all; winds from the model levels (zeta / pressure advection) share launches too."""
+    "full") not possible at all; winds from the model levels (zeta / pressure advection) share launches too, and so
+    does every integrator (ADVECT 4, 2, 1).  Where sharing is possible it must happen: seven quiet steps, one launch."""
     ctl, clim, m0, m1, atm = cases.make_case(case, n=5003)
+    if isinstance(advect, str):
+        ctl = dict(ctl, **_BATCH_OVERRIDES[advect])
+    elif advect is not None:
+        ctl = dict(ctl, advect=advect)
     o = B.Oracle(ctl, clim, m0, m1, atm)
     o.timesteps_init()
     times = cases.step_times(o.ctl)
@@ -1591,7 +1610,14 @@ def test_run_timesteps_equals_the_step_by_step_loop(case):
         else:
             s.set_option("multi_step", multi)
             s.run_timestep(times[0])
+            s.synchronize()
+            s.profile_begin()
             s.run_timesteps(times[1], 7)
+            launches, _ = s.profile_end()
+            if name == "no_resort" and case != "full":
+                assert launches == 1, (case, advect, launches)
+            if name == "off" or case == "full":      # (module_mixing splits the launch of a step)
+                assert launches >= 7 if case == "full" else launches == 7, (case, advect, name, launches)
             s.run_timesteps(times[8], 4)
         runs[name] = s.state()
         runs[name]["ctr"] = s.get_cache()["rng_ctr"]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Step-kernel time of a few everyday control sets on the C3 particles and grid (GPU box; median of launches
-35-70): which instantiation of the step kernel they take shows in the time.
+"""Step-kernel time of a few everyday control sets on the C3 particles and grid (GPU box; one launch per step: median
+of launches 35-70; then twenty steps per mphip_run_timesteps call): which instantiation of the step kernel they take
+shows in the time.
   python tools/gpu_config_matrix.py [NAME=VALUE options]   e.g. generic_kernel=1 for the general instantiation"""
 import os
 import sys
@@ -11,7 +12,7 @@ import bench  # noqa: E402
 from mptrac_amd import hip  # noqa: E402
 from mptrac_amd.ctl import ctl_from_quantities  # noqa: E402
 
-ctl, clim, m0, m1, atm, n_local, n_total = bench.build_inputs("C3", 0, 1, 80)
+ctl, clim, m0, m1, atm, n_local, n_total = bench.build_inputs("C3", 0, 1, 200)
 gas = ctl_from_quantities(("m",))
 gas.update(qnt_rp=-1, qnt_rhop=-1)
 SETS = {
@@ -38,5 +39,16 @@ for name, over in SETS.items():
         n, t = s.profile_end()
         ms.append(t / max(n, 1))
     tail = sorted(ms[35:])
-    print(f"{name:52s} {tail[len(tail) // 2]:.4f} ms", flush=True)
+    single = tail[len(tail) // 2]
+    # ... and twenty steps per mphip_run_timesteps call (steps with nothing scheduled between them share a launch)
+    k = 71
+    s.run_timesteps(k * dt, 20)
+    k += 20
+    s.synchronize()
+    s.profile_begin()
+    for _ in range(3):
+        s.run_timesteps(k * dt, 20)
+        k += 20
+    n, t = s.profile_end()
+    print(f"{name:52s} {single:.4f} ms   20 steps per call: {t / 60:.4f} ms per step ({n} launches for 60 steps)", flush=True)
     s.close()
