@@ -2790,18 +2790,31 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
   while (done < nsteps) {
     // how many steps from here on can share a launch?
     int batch = 0;
-    const bool meteo = meteo_requested(c);   // (module_meteo without a quantity to fill does nothing)
-    const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !(c.sort_dt > 0) && !(meteo && c.met_dt_out > 0)
+    // module_meteo (lazy: evaluated when its values can be seen, dropped when the next step schedules it again --
+    // mphip_run_timestep) lets a batch run on, except that it must be evaluated between a step that schedules it and a
+    // step that does not: a batch ends behind such a step.  (module_meteo without a quantity to fill does nothing.)
+    const bool meteo = meteo_requested(c) && c.met_dt_out > 0;
+    auto meteo_at = [&](double tt) { return meteo && (c.met_dt_out < c.dt_mod || fmod(tt, c.met_dt_out) == 0); };
+    const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !(c.sort_dt > 0)
       && !(c.mixing_trop >= 0 && c.mixing_strat >= 0) && !(c.isosurf >= 1 && c.isosurf <= 4)
       && !(c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1) && !(c.diffusion && c.turb_pbl_scheme == 1)
       && !((c.conv_mix_pbl || c.conv_cape >= 0) && c.conv_dt > 0)   // (every integrator has its multi-step instantiations)
-      && !(meteo && ctx->meteo_pending) && !ctx->fused_perm
+      && !ctx->fused_perm
       && !ctx->force_generic && !ctx->split_step;
     if (quiet) {
       batch = nsteps - done;
       if (ctx->locality_interval > 0)
         batch = std::min(batch, ctx->locality_interval - ctx->steps_since_resort);
       batch = std::min(batch, ctx->multi_step);
+      double tt = t;
+      for (int j = 0; meteo && j < batch; j++) {
+        const double tn = tt + stride;
+        if (meteo_at(tt) && (!ctx->lazy_meteo || !meteo_at(tn))) {
+          batch = j + 1;
+          break;
+        }
+        tt = tn;
+      }
     }
     if (batch < 2) {
       if (mphip_run_timestep(ctx, t))
@@ -2859,7 +2872,11 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
       done++;
       continue;
     }
-    if (flush_meteo(ctx))
+    // a deferred module_meteo of the step before: dropped if the first step of the batch schedules it again,
+    // evaluated now -- before the particles move -- otherwise (as mphip_run_timestep)
+    if (meteo_at(t))
+      ctx->meteo_pending = false;
+    else if (flush_meteo(ctx))
       return 1;
     if (launch_step(ctx, mask, t, ctx->rng_ctr + off_turb, ctx->rng_ctr + off_meso, ctx->rng_ctr + off_conv, 0, batch, stride,
                     per_step))
@@ -2867,9 +2884,14 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     ctx->rng_ctr += per_step * (uint64_t) batch;
     if (ctx->steps_since_resort < (1 << 29))
       ctx->steps_since_resort += batch;
-    for (int k = 0; k < batch; k++)
+    double t_last = t;
+    for (int k = 0; k < batch; k++) {
+      t_last = t;
       t += stride;
+    }
     done += batch;
+    if (meteo_at(t_last) && schedule_meteo(ctx))   // (only the last step of a batch can leave one to be seen)
+      return 1;
   }
   return 0;
 }

@@ -1576,9 +1576,14 @@ _BATCH_CASES = [(c, None) for c in ("advect", "turb", "diff", "conv_sedi", "full
     # subsets without a kernel of their own take the gated instantiation, also several steps per launch: a gas tracer
     # (diffusion and convection, no sedimentation), turbulent diffusion + convection + sedimentation (own kernel for
     # single steps only), convection alone
-    ("conv_sedi", "gas"), ("conv_sedi", "gas2"), ("conv_sedi", "turb_only"), ("conv_thresh", None), ("conv_thresh", 2)]
+    ("conv_sedi", "gas"), ("conv_sedi", "gas2"), ("conv_sedi", "turb_only"), ("conv_thresh", None), ("conv_thresh", 2),
+    # module_meteo quantities: in every step (MET_DT_OUT below DT_MOD: only the last evaluation of a batch can be seen),
+    # in every third step (a batch ends behind a step that schedules it when the next one does not), and evaluated
+    # inside the step that schedules it (option lazy_meteo 0: a batch ends behind every such step)
+    ("meteo", None), ("meteo", "every_third"), ("meteo", "eager_third")]
 _BATCH_OVERRIDES = {"gas": dict(qnt_rp=-1, qnt_rhop=-1), "gas2": dict(qnt_rp=-1, qnt_rhop=-1, advect=2),
-                    "turb_only": dict(turb_mesox=0.0, turb_mesoz=0.0)}
+                    "turb_only": dict(turb_mesox=0.0, turb_mesoz=0.0), "every_third": dict(met_dt_out=540.0),
+                    "eager_third": dict(met_dt_out=540.0)}
 
 
 @pytest.mark.gpu
@@ -1603,6 +1608,8 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
     for name, multi, interval in (("loop", None, 4), ("batched", 64, 4), ("pairs", 2, 4), ("no_resort", 64, 0), ("off", 0, 4)):
         s = hip.Simulation(ctl, clim, m0, m1, atm)
         s.set_option("locality_sort_interval", interval)
+        if advect == "eager_third":
+            s.set_option("lazy_meteo", 0)
         s.timesteps_init(0.0, 0.0)
         if multi is None:
             for t in times[:12]:
@@ -1614,7 +1621,9 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
             s.profile_begin()
             s.run_timesteps(times[1], 7)
             launches, _ = s.profile_end()
-            if name == "no_resort" and case != "full":
+            if name == "no_resort" and advect in ("every_third", "eager_third"):
+                assert 1 < launches < 7, (case, advect, launches)
+            elif name == "no_resort" and case != "full":
                 assert launches == 1, (case, advect, launches)
             if name == "off" or case == "full":      # (module_mixing splits the launch of a step)
                 assert launches >= 7 if case == "full" else launches == 7, (case, advect, name, launches)
