@@ -2795,8 +2795,14 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     // step that does not: a batch ends behind such a step.  (module_meteo without a quantity to fill does nothing.)
     const bool meteo = meteo_requested(c) && c.met_dt_out > 0;
     auto meteo_at = [&](double tt) { return meteo && (c.met_dt_out < c.dt_mod || fmod(tt, c.met_dt_out) == 0); };
-    const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !(c.sort_dt > 0)
-      && !(c.mixing_trop >= 0 && c.mixing_strat >= 0) && !(c.isosurf >= 1 && c.isosurf <= 4)
+    // module_sort and module_mixing run at multiples of SORT_DT / MIXING_DT: such a step takes the single-step path
+    // (which sorts, or splits its launch around the mixing), the steps between two of them can share launches
+    auto scheduled = [&](double tt) {
+      return (c.sort_dt > 0 && fmod(tt, c.sort_dt) == 0)
+        || (c.mixing_trop >= 0 && c.mixing_strat >= 0 && (c.mixing_dt <= 0 || fmod(tt, c.mixing_dt) == 0));
+    };
+    const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !scheduled(t)
+      && !(c.isosurf >= 1 && c.isosurf <= 4)
       && !(c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1) && !(c.diffusion && c.turb_pbl_scheme == 1)
       && !((c.conv_mix_pbl || c.conv_cape >= 0) && c.conv_dt > 0)   // (every integrator has its multi-step instantiations)
       && !ctx->fused_perm
@@ -2807,9 +2813,13 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
         batch = std::min(batch, ctx->locality_interval - ctx->steps_since_resort);
       batch = std::min(batch, ctx->multi_step);
       double tt = t;
-      for (int j = 0; meteo && j < batch; j++) {
+      for (int j = 0; j < batch; j++) {
+        if (j > 0 && scheduled(tt)) {   // the batch ends before this step
+          batch = j;
+          break;
+        }
         const double tn = tt + stride;
-        if (meteo_at(tt) && (!ctx->lazy_meteo || !meteo_at(tn))) {
+        if (meteo_at(tt) && (!ctx->lazy_meteo || !meteo_at(tn))) {   // ... behind this one
           batch = j + 1;
           break;
         }

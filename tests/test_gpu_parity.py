@@ -1580,10 +1580,12 @@ _BATCH_CASES = [(c, None) for c in ("advect", "turb", "diff", "conv_sedi", "full
     # module_meteo quantities: in every step (MET_DT_OUT below DT_MOD: only the last evaluation of a batch can be seen),
     # in every third step (a batch ends behind a step that schedules it when the next one does not), and evaluated
     # inside the step that schedules it (option lazy_meteo 0: a batch ends behind every such step)
-    ("meteo", None), ("meteo", "every_third"), ("meteo", "eager_third")]
+    ("meteo", None), ("meteo", "every_third"), ("meteo", "eager_third"),
+    # module_sort and module_mixing due in every fourth step only: the steps between share launches
+    ("full", "sparse")]
 _BATCH_OVERRIDES = {"gas": dict(qnt_rp=-1, qnt_rhop=-1), "gas2": dict(qnt_rp=-1, qnt_rhop=-1, advect=2),
                     "turb_only": dict(turb_mesox=0.0, turb_mesoz=0.0), "every_third": dict(met_dt_out=540.0),
-                    "eager_third": dict(met_dt_out=540.0)}
+                    "eager_third": dict(met_dt_out=540.0), "sparse": dict(sort_dt=720.0, mixing_dt=720.0)}
 
 
 @pytest.mark.gpu
@@ -1604,7 +1606,7 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
     o = B.Oracle(ctl, clim, m0, m1, atm)
     o.timesteps_init()
     times = cases.step_times(o.ctl)
-    runs = {}
+    runs, counts = {}, {}
     for name, multi, interval in (("loop", None, 4), ("batched", 64, 4), ("pairs", 2, 4), ("no_resort", 64, 0), ("off", 0, 4)):
         s = hip.Simulation(ctl, clim, m0, m1, atm)
         s.set_option("locality_sort_interval", interval)
@@ -1612,7 +1614,13 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
             s.set_option("lazy_meteo", 0)
         s.timesteps_init(0.0, 0.0)
         if multi is None:
-            for t in times[:12]:
+            s.run_timestep(times[0])
+            s.synchronize()
+            s.profile_begin()
+            for t in times[1:8]:
+                s.run_timestep(t)
+            counts["loop7"], _ = s.profile_end()      # step-kernel launches of the same seven steps, one call each
+            for t in times[8:12]:
                 s.run_timestep(t)
         else:
             s.set_option("multi_step", multi)
@@ -1621,11 +1629,14 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
             s.profile_begin()
             s.run_timesteps(times[1], 7)
             launches, _ = s.profile_end()
+            counts[name] = launches
             if name == "no_resort" and advect in ("every_third", "eager_third"):
                 assert 1 < launches < 7, (case, advect, launches)
+            elif name == "no_resort" and advect == "sparse":
+                assert launches < counts["loop7"], (case, advect, launches, counts)
             elif name == "no_resort" and case != "full":
                 assert launches == 1, (case, advect, launches)
-            if name == "off" or case == "full":      # (module_mixing splits the launch of a step)
+            if name == "off" or (case == "full" and advect != "sparse"):      # (module_mixing splits the launch of a step)
                 assert launches >= 7 if case == "full" else launches == 7, (case, advect, name, launches)
             s.run_timesteps(times[8], 4)
         runs[name] = s.state()

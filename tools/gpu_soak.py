@@ -8,7 +8,10 @@ Prints the relative deviations on the way; fails above the 1e-10 bar.
   python tools/gpu_soak.py zeta        the same hand-over with winds from the model levels (`zeta_full`: zeta
                                        advection, diffusion, convection, sedimentation -- the lean model-level kernels);
                                        the level search of a step starts from the index the step before stored, which
-                                       after a meteo hand-over points into fields that have changed"""
+                                       after a meteo hand-over points into fields that have changed
+  python tools/gpu_soak.py fullbatched the full module set (module_sort every 1800 s, mixing every 900 s, module_meteo
+                                       quantities) handed over twenty steps at a time: launches are shared between
+                                       the steps at which the sort or the mixing is due"""
 import os
 import sys
 import time
@@ -25,8 +28,14 @@ from mptrac_amd.synth import FIELDS_METEO_ONLY, synthetic_met, synthetic_particl
 from oracle import binding as B  # noqa: E402
 
 zeta = "zeta" in sys.argv[1:]
-batched = "batched" in sys.argv[1:] or zeta
-if zeta:
+fullbatched = "fullbatched" in sys.argv[1:]
+batched = "batched" in sys.argv[1:] or zeta or fullbatched
+if fullbatched:
+    names = ("m", "vmr", "rp", "rhop", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry", "aoa", "t", "u", "ps", "theta")
+    ctl = dict(cases.CASES["full"])
+    ctl.update(ctl_from_quantities(names))
+    ctl.update(t_stop=4 * 18000.0, dt_met=18000.0, met_dt_out=0.1, sort_dt=1800.0, mixing_dt=900.0)
+elif zeta:
     names = tuple(cases.QUANTITIES_ML)
     ctl = dict(cases.CASES["zeta_full"])
     ctl.update(ctl_from_quantities(names))
