@@ -2797,14 +2797,17 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     auto meteo_at = [&](double tt) { return meteo && (c.met_dt_out < c.dt_mod || fmod(tt, c.met_dt_out) == 0); };
     // module_sort and module_mixing run at multiples of SORT_DT / MIXING_DT: such a step takes the single-step path
     // (which sorts, or splits its launch around the mixing), the steps between two of them can share launches
+    // (module_convection with CONV_DT > 0 likewise: due steps on their own, the steps between without it)
+    const bool conv_on = c.conv_mix_pbl || c.conv_cape >= 0;
     auto scheduled = [&](double tt) {
       return (c.sort_dt > 0 && fmod(tt, c.sort_dt) == 0)
-        || (c.mixing_trop >= 0 && c.mixing_strat >= 0 && (c.mixing_dt <= 0 || fmod(tt, c.mixing_dt) == 0));
+        || (c.mixing_trop >= 0 && c.mixing_strat >= 0 && (c.mixing_dt <= 0 || fmod(tt, c.mixing_dt) == 0))
+        || (conv_on && c.conv_dt > 0 && fmod(tt, c.conv_dt) == 0);
     };
     const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !scheduled(t)
       && !(c.isosurf >= 1 && c.isosurf <= 4)
       && !(c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1) && !(c.diffusion && c.turb_pbl_scheme == 1)
-      && !((c.conv_mix_pbl || c.conv_cape >= 0) && c.conv_dt > 0)   // (every integrator has its multi-step instantiations)
+      // (every integrator has its multi-step instantiations)
       && !ctx->fused_perm
       && !ctx->force_generic && !ctx->split_step;
     if (quiet) {
@@ -2850,7 +2853,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
       off_meso = per_step;
       per_step += 3 * n + 1;
     }
-    if (c.conv_mix_pbl || c.conv_cape >= 0) {
+    if (conv_on && !(c.conv_dt > 0)) {   // (CONV_DT > 0: the steps of a batch are the ones without convection)
       mask |= MPHIP_MOD_CONVECTION;
       off_conv = per_step;
       per_step += n + 1;

@@ -1582,10 +1582,13 @@ _BATCH_CASES = [(c, None) for c in ("advect", "turb", "diff", "conv_sedi", "full
     # inside the step that schedules it (option lazy_meteo 0: a batch ends behind every such step)
     ("meteo", None), ("meteo", "every_third"), ("meteo", "eager_third"),
     # module_sort and module_mixing due in every fourth step only: the steps between share launches
-    ("full", "sparse")]
+    ("full", "sparse"),
+    # convection due in every fourth step only (CONV_DT): the steps between share launches, without it
+    ("conv_sedi", "conv_sparse")]
 _BATCH_OVERRIDES = {"gas": dict(qnt_rp=-1, qnt_rhop=-1), "gas2": dict(qnt_rp=-1, qnt_rhop=-1, advect=2),
                     "turb_only": dict(turb_mesox=0.0, turb_mesoz=0.0), "every_third": dict(met_dt_out=540.0),
-                    "eager_third": dict(met_dt_out=540.0), "sparse": dict(sort_dt=720.0, mixing_dt=720.0)}
+                    "eager_third": dict(met_dt_out=540.0), "sparse": dict(sort_dt=720.0, mixing_dt=720.0),
+                    "conv_sparse": dict(conv_dt=720.0)}
 
 
 @pytest.mark.gpu
@@ -1630,7 +1633,7 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
             s.run_timesteps(times[1], 7)
             launches, _ = s.profile_end()
             counts[name] = launches
-            if name == "no_resort" and advect in ("every_third", "eager_third"):
+            if name == "no_resort" and advect in ("every_third", "eager_third", "conv_sparse"):
                 assert 1 < launches < 7, (case, advect, launches)
             elif name == "no_resort" and advect == "sparse":
                 assert launches < counts["loop7"], (case, advect, launches, counts)
