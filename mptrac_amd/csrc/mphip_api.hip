@@ -2806,7 +2806,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     };
     const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !scheduled(t)
       && !(c.isosurf >= 1 && c.isosurf <= 4)
-      && !(c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1) && !(c.diffusion && c.turb_pbl_scheme == 1)
+      && !(c.diffusion && c.turb_pbl_scheme == 1)
       // (every integrator has its multi-step instantiations)
       && !ctx->fused_perm
       && !ctx->force_generic && !ctx->split_step;
@@ -2868,8 +2868,13 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
       return 1;
     const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
       && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // (launch_step's condition)
-    const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels && ctx->d_kz != nullptr
+    // module_bound_cond (per particle: its own time, the tracer series on the device) is switched at run time in the
+    // gated instantiation; with winds from the model levels only the general kernel has it: single steps
+    const bool bound = c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1;
+    const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels && ctx->d_kz != nullptr && !bound
                                 : lean_ok && (movers & ~kOptionalModules) == kAdv;   // (exact sets: their own kernels; subsets: the gated one)
+    if (bound)
+      mask |= MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
     if (c.qnt_loss_rate >= 0)
       mask |= MPHIP_MOD_LOSS_ZERO;
     if (c.tdec_trop > 0 && c.tdec_strat > 0)

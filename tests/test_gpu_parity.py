@@ -1584,11 +1584,17 @@ _BATCH_CASES = [(c, None) for c in ("advect", "turb", "diff", "conv_sedi", "full
     # module_sort and module_mixing due in every fourth step only: the steps between share launches
     ("full", "sparse"),
     # convection due in every fourth step only (CONV_DT): the steps between share launches, without it
-    ("conv_sedi", "conv_sparse")]
+    ("conv_sedi", "conv_sparse"),
+    # boundary conditions (module_bound_cond before and after the other modules of a step): the gated instantiation
+    ("conv_sedi", "bound"), ("advect", "bound2")]
 _BATCH_OVERRIDES = {"gas": dict(qnt_rp=-1, qnt_rhop=-1), "gas2": dict(qnt_rp=-1, qnt_rhop=-1, advect=2),
                     "turb_only": dict(turb_mesox=0.0, turb_mesoz=0.0), "every_third": dict(met_dt_out=540.0),
                     "eager_third": dict(met_dt_out=540.0), "sparse": dict(sort_dt=720.0, mixing_dt=720.0),
-                    "conv_sparse": dict(conv_dt=720.0)}
+                    "conv_sparse": dict(conv_dt=720.0),
+                    "bound": dict(bound_lat0=-60.0, bound_lat1=60.0, bound_p0=1100.0, bound_p1=200.0, bound_mass=2.0,
+                                  bound_mass_trend=1e-6, bound_dps=300.0),
+                    "bound2": dict(bound_lat0=-60.0, bound_lat1=60.0, bound_p0=1100.0, bound_p1=200.0, bound_mass=2.0,
+                                   bound_pbl=1, advect=2)}
 
 
 @pytest.mark.gpu
