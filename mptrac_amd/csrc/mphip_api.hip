@@ -773,6 +773,11 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // model levels: the fast path needs monotonic height columns and none of the rarely used modules
   const bool ml_fast = ml_ && ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels
     && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
+  // ... module_bound_cond is no obstacle where the gated lean model-level instantiation can run (it switches the module
+  // at run time, as every gated instantiation does)
+  constexpr unsigned kBoundBits = MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
+  const bool ml_fast_bound = ml_ && ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels
+    && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT & ~kBoundBits)) && !ctx->force_generic;
   const unsigned rare_bits = mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u);
   const bool rare = (ml_ && !ml_fast) || rare_bits;
   // the specialised instantiations take module_timesteps / the dt store from the run-time mask
@@ -788,13 +793,13 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // movers).  Everything else (single-module calls, the other rarely used modules) takes a general instantiation.
   constexpr unsigned kBound = MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
   unsigned sel = kMaskGeneric;
-  if (!(rare_bits & ~kBound) && ml_fast && !ctx->force_generic && lean_ok) {
+  if (!(rare_bits & ~kBound) && (ml_fast || (ml_fast_bound && (mask & kBound))) && !ctx->force_generic && lean_ok) {
     // model-level winds: the headline module set has lean instantiations (its subsets the gated one); the rest
     // stays with the general model-level kernels below
     const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
     if (req == kAdvDiffConvSedi && !(mask & kBound))
       sel = req | kMLWinds | (nsteps > 1 ? kMultiStep : 0u);
-    else if ((req & ~kOptionalModules) == kAdv && (nsteps == 1 || !(mask & kBound)))
+    else if ((req & ~kOptionalModules) == kAdv)   // (subsets, and every set with module_bound_cond)
       sel = kAdvDiffConvSedi | kGated | kMLWinds | (nsteps > 1 ? kMultiStep : 0u);
   } else if (!(rare_bits & ~kBound) && !ml_ && !ctx->force_generic && lean_ok) {
     const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
@@ -2869,9 +2874,9 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
       && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // (launch_step's condition)
     // module_bound_cond (per particle: its own time, the tracer series on the device) is switched at run time in the
-    // gated instantiation; with winds from the model levels only the general kernel has it: single steps
+    // gated instantiations (pressure and model levels)
     const bool bound = c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1;
-    const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels && ctx->d_kz != nullptr && !bound
+    const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels && ctx->d_kz != nullptr && (!bound || lean_ok)
                                 : lean_ok && (movers & ~kOptionalModules) == kAdv;   // (exact sets: their own kernels; subsets: the gated one)
     if (bound)
       mask |= MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;

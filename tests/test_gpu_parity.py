@@ -1586,7 +1586,9 @@ _BATCH_CASES = [(c, None) for c in ("advect", "turb", "diff", "conv_sedi", "full
     # convection due in every fourth step only (CONV_DT): the steps between share launches, without it
     ("conv_sedi", "conv_sparse"),
     # boundary conditions (module_bound_cond before and after the other modules of a step): the gated instantiation
-    ("conv_sedi", "bound"), ("advect", "bound2")]
+    ("conv_sedi", "bound"), ("advect", "bound2"),
+    # ... with winds from the model levels: the gated lean model-level instantiation
+    ("zeta_full", "bound"), ("mlp_full", "bound2")]
 _BATCH_OVERRIDES = {"gas": dict(qnt_rp=-1, qnt_rhop=-1), "gas2": dict(qnt_rp=-1, qnt_rhop=-1, advect=2),
                     "turb_only": dict(turb_mesox=0.0, turb_mesoz=0.0), "every_third": dict(met_dt_out=540.0),
                     "eager_third": dict(met_dt_out=540.0), "sparse": dict(sort_dt=720.0, mixing_dt=720.0),

@@ -18,6 +18,8 @@ SETS = {
     "midpoint, diffusion, no convection": dict(advect=2, conv_cape=-999.0),
     "trajectories only (midpoint)": dict(advect=2, diffusion=0, conv_cape=-999.0, qnt_rp=-1, qnt_rhop=-1),
     "trajectories only (RK4)": dict(diffusion=0, conv_cape=-999.0, qnt_rp=-1, qnt_rhop=-1),
+    "C3z modules + boundary condition (mass)": dict(bound_lat0=-90.0, bound_lat1=90.0, bound_p0=1e10, bound_p1=-1e10,
+                                                    bound_dps=100.0, bound_mass=0.0),
 }
 print(f"{'':52s} {'one launch per step':>20s} {'20 steps per call':>20s}   (ms per step)")
 for name, over in SETS.items():
