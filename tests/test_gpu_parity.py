@@ -1600,9 +1600,10 @@ _BATCH_OVERRIDES = {"gas": dict(qnt_rp=-1, qnt_rhop=-1), "gas2": dict(qnt_rp=-1,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,advect", _BATCH_CASES, ids=[c if a is None else f"{c}-{a if isinstance(a, str) else 'advect%d' % a}"
-                                                           for c, a in _BATCH_CASES])
-def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
+# variant: None, an integrator (ADVECT) or a key of _BATCH_OVERRIDES
+@pytest.mark.parametrize("case,variant", _BATCH_CASES,
+                         ids=[c if v is None else f"{c}-{v if isinstance(v, str) else 'advect%d' % v}" for c, v in _BATCH_CASES])
+def test_run_timesteps_equals_the_step_by_step_loop(case, variant):
     """mphip_run_timesteps (the reference's time loop, trac.c:204-226, as one call): runs of steps with nothing
     scheduled between them share a kernel launch in which every particle takes its steps one after the other;
     same bits as one mphip_run_timestep per step -- state, uvwp and the counter of the random numbers --,
@@ -1610,10 +1611,10 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
     "full") not possible at all; winds from the model levels (zeta / pressure advection) share launches too, and so
     does every integrator (ADVECT 4, 2, 1).  Where sharing is possible it must happen: seven quiet steps, one launch."""
     ctl, clim, m0, m1, atm = cases.make_case(case, n=5003)
-    if isinstance(advect, str):
-        ctl = dict(ctl, **_BATCH_OVERRIDES[advect])
-    elif advect is not None:
-        ctl = dict(ctl, advect=advect)
+    if isinstance(variant, str):
+        ctl = dict(ctl, **_BATCH_OVERRIDES[variant])
+    elif variant is not None:
+        ctl = dict(ctl, advect=variant)
     o = B.Oracle(ctl, clim, m0, m1, atm)
     o.timesteps_init()
     times = cases.step_times(o.ctl)
@@ -1621,7 +1622,7 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
     for name, multi, interval in (("loop", None, 4), ("batched", 64, 4), ("pairs", 2, 4), ("no_resort", 64, 0), ("off", 0, 4)):
         s = hip.Simulation(ctl, clim, m0, m1, atm)
         s.set_option("locality_sort_interval", interval)
-        if advect == "eager_third":
+        if variant == "eager_third":
             s.set_option("lazy_meteo", 0)
         s.timesteps_init(0.0, 0.0)
         if multi is None:
@@ -1641,14 +1642,14 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, advect):
             s.run_timesteps(times[1], 7)
             launches, _ = s.profile_end()
             counts[name] = launches
-            if name == "no_resort" and advect in ("every_third", "eager_third", "conv_sparse"):
-                assert 1 < launches < 7, (case, advect, launches)
-            elif name == "no_resort" and advect == "sparse":
-                assert launches < counts["loop7"], (case, advect, launches, counts)
+            if name == "no_resort" and variant in ("every_third", "eager_third", "conv_sparse"):
+                assert 1 < launches < 7, (case, variant, launches)
+            elif name == "no_resort" and variant == "sparse":
+                assert launches < counts["loop7"], (case, variant, launches, counts)
             elif name == "no_resort" and case != "full":
-                assert launches == 1, (case, advect, launches)
-            if name == "off" or (case == "full" and advect != "sparse"):      # (module_mixing splits the launch of a step)
-                assert launches >= 7 if case == "full" else launches == 7, (case, advect, name, launches)
+                assert launches == 1, (case, variant, launches)
+            if name == "off" or (case == "full" and variant != "sparse"):      # (module_mixing splits the launch of a step)
+                assert launches >= 7 if case == "full" else launches == 7, (case, variant, name, launches)
             s.run_timesteps(times[8], 4)
         runs[name] = s.state()
         runs[name]["ctr"] = s.get_cache()["rng_ctr"]
