@@ -2812,7 +2812,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !scheduled(t)
       && !(c.isosurf >= 1 && c.isosurf <= 4)
       && !(c.diffusion && c.turb_pbl_scheme == 1)
-      // (every integrator has its multi-step instantiations)
+      && c.advect > 0   // (every integrator has its multi-step instantiations; without module_advect: single steps)
       && !ctx->fused_perm
       && !ctx->force_generic && !ctx->split_step;
     if (quiet) {

@@ -1588,7 +1588,9 @@ _BATCH_CASES = [(c, None) for c in ("advect", "turb", "diff", "conv_sedi", "full
     # boundary conditions (module_bound_cond before and after the other modules of a step): the gated instantiation
     ("conv_sedi", "bound"), ("advect", "bound2"),
     # ... with winds from the model levels: the gated lean model-level instantiation
-    ("zeta_full", "bound"), ("mlp_full", "bound2")]
+    ("zeta_full", "bound"), ("mlp_full", "bound2"),
+    # ADVECT 0 (the C ABI accepts it): no module_advect, no instantiation for several steps -- single steps
+    ("diff", 0)]
 _BATCH_OVERRIDES = {"gas": dict(qnt_rp=-1, qnt_rhop=-1), "gas2": dict(qnt_rp=-1, qnt_rhop=-1, advect=2),
                     "turb_only": dict(turb_mesox=0.0, turb_mesoz=0.0), "every_third": dict(met_dt_out=540.0),
                     "eager_third": dict(met_dt_out=540.0), "sparse": dict(sort_dt=720.0, mixing_dt=720.0),
@@ -1646,6 +1648,8 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, variant):
                 assert 1 < launches < 7, (case, variant, launches)
             elif name == "no_resort" and variant == "sparse":
                 assert launches < counts["loop7"], (case, variant, launches, counts)
+            elif name == "no_resort" and variant == 0:
+                assert launches == 7, (case, variant, launches)
             elif name == "no_resort" and case != "full":
                 assert launches == 1, (case, variant, launches)
             if name == "off" or (case == "full" and variant != "sparse"):      # (module_mixing splits the launch of a step)
