@@ -271,7 +271,13 @@ int mphip_run_timestep(mphip_ctx *ctx, double t);
  * mptrac_run_timestep(...)`) for `nsteps` consecutive steps starting at t_first: same results as nsteps calls of
  * mphip_run_timestep.  Steps with nothing scheduled between them may share one kernel launch (option
  * "multi_step" = most steps per launch, default 64; 0 = never) -- what small particle counts need, where a time
- * step is shorter than a launch.  A driver calls it for the steps up to its next output. */
+ * step is shorter than a launch.  A driver calls it for the steps up to its next output.
+ * What shares launches: every integrator (ADVECT 1 / 2 / 4) and every subset of turbulent / mesoscale diffusion,
+ * convection, sedimentation, with the loss / decay / deposition modules and boundary conditions, on pressure and on
+ * model levels.  A step at which module_sort, module_mixing or (CONV_DT > 0) module_convection is due runs on its own
+ * and a batch ends before it; module_meteo is deferred as in mphip_run_timestep, so a batch ends only behind a step that
+ * schedules it when the next one does not.  Single steps throughout: the first step (t == T_START), ISOSURF,
+ * TURB_PBL_SCHEME 1, ADVECT 0, the options "generic_kernel" / "split_step". */
 int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps);
 /* One reference module_* on its own (same state hand-over through the device
  * copy of cache->dt); `modules` is one MPHIP_MOD_* bit or an OR of the
