@@ -363,7 +363,9 @@ int mphip_comm_query(mphip_ctx *ctx, int *nranks, int *rank);
  *   row (measured: no effect on the step kernel);
  *   "sum_path" (default 0 = by crowding; 1, 2): tests -- force the group / the chain algorithm of the ordered sums;
  *   "chain_blocks": tuning -- workgroups of the chain walk of the ordered sums;
- *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel. */
+ *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel;
+ *   "big_grid" (default 0): tests -- take the instantiations with 64-bit byte offsets into the packed meteo records (what a
+ *     grid with more than 4 GB of wind records -- 178e6 cells -- takes by itself) on a grid that fits 32 bits too: same bits. */
 int mphip_set_option(mphip_ctx *ctx, const char *name, double value);
 int mphip_synchronize(mphip_ctx *ctx);
 

@@ -159,6 +159,7 @@ struct mphip_ctx {
   int step_blocks_multi = 32768;       // ... of a multi-step launch (mphip_run_timesteps)
   int xcd_map = 1;
   int split_step = 0;                 // experiment: advection and the modules behind it as two launches
+  int big_grid = 0;                   // option "big_grid": take the 64-bit-offset (kBigGrid) instantiations on a grid that fits 32 bits too (tests)
   int perm_records = 1;               // random permutations of the particle arrays through records (permute_random)
   void *d_prec = nullptr;             // ... their buffer
   size_t prec_cap = 0;
@@ -714,6 +715,21 @@ int check_fields(mphip_ctx *ctx, unsigned mask) {
 
 // nsteps > 1: that many consecutive time steps in one launch (kMultiStep instantiations; the caller has checked that
 // one exists for this module set, multi_step_mask)
+// The lean instantiations need a lat/lon grid with the pressure look-up table; cell indices are built with 24-bit
+// multiplies (cell32: columns below 2^24, cells below 2^32).  lean32_ok: 32-bit byte offsets into the packed grids
+// (the largest record has 24 bytes); lean64_ok: a grid beyond that -- or the option "big_grid" -- takes the kBigGrid
+// instantiations with 64-bit offsets.
+static bool lean_grid(const mphip_ctx *ctx) {
+  const unsigned long long cols = (unsigned long long) ctx->nx * ctx->ny;
+  return ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV && cols < (1ull << 24)
+    && cols * (unsigned long long) ctx->npl < (1ull << 32);
+}
+static bool fits32(const mphip_ctx *ctx) {
+  return (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);
+}
+static bool lean32_ok(const mphip_ctx *ctx) { return lean_grid(ctx) && fits32(ctx) && !ctx->big_grid; }
+static bool lean64_ok(const mphip_ctx *ctx) { return lean_grid(ctx) && (!fits32(ctx) || ctx->big_grid); }
+
 int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint64_t ctr_meso, uint64_t ctr_conv,
                 uint64_t ctr_pbl = 0, int nsteps = 1, double t_stride = 0, uint64_t ctr_stride = 0) {
   if (ctx->np == 0)
@@ -782,8 +798,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   const bool rare = (ml_ && !ml_fast) || rare_bits;
   // the specialised instantiations take module_timesteps / the dt store from the run-time mask
   // ... and run the lean code: lat/lon grid with a pressure look-up table
-  const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
-    && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // 32-bit byte offsets into the packed grids
+  const bool lean_ok = lean32_ok(ctx), big_ok = lean64_ok(ctx);
   // (the lean instantiations are keyed on the movers; loss / decay / deposition are run-time bits in all of them)
   // (ADVECT 2 and 1 -- midpoint, the reference's default, and Euler -- share the two-stage instantiations)
   const unsigned scheme = (mask & MPHIP_MOD_ADVECT) && ctx->ctl.advect != 4 ? kTwoStage : 0u;
@@ -793,14 +808,14 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // movers).  Everything else (single-module calls, the other rarely used modules) takes a general instantiation.
   constexpr unsigned kBound = MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
   unsigned sel = kMaskGeneric;
-  if (!(rare_bits & ~kBound) && (ml_fast || (ml_fast_bound && (mask & kBound))) && !ctx->force_generic && lean_ok) {
+  if (!(rare_bits & ~kBound) && (ml_fast || (ml_fast_bound && (mask & kBound))) && !ctx->force_generic && (lean_ok || big_ok)) {
     // model-level winds: the headline module set has lean instantiations (its subsets the gated one); the rest
     // stays with the general model-level kernels below
     const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
-    if (req == kAdvDiffConvSedi && !(mask & kBound))
+    if (req == kAdvDiffConvSedi && !(mask & kBound) && lean_ok)
       sel = req | kMLWinds | (nsteps > 1 ? kMultiStep : 0u);
-    else if ((req & ~kOptionalModules) == kAdv)   // (subsets, and every set with module_bound_cond)
-      sel = kAdvDiffConvSedi | kGated | kMLWinds | (nsteps > 1 ? kMultiStep : 0u);
+    else if ((req & ~kOptionalModules) == kAdv)   // (subsets, every set with module_bound_cond, and every set of a big grid)
+      sel = kAdvDiffConvSedi | kGated | kMLWinds | (big_ok ? kBigGrid : 0u) | (nsteps > 1 ? kMultiStep : 0u);
   } else if (!(rare_bits & ~kBound) && !ml_ && !ctx->force_generic && lean_ok) {
     const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
     // (kAdvTurbConvSedi has a kernel of its own for single steps only: several steps per launch take the gated one)
@@ -814,6 +829,12 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
       sel = req | scheme | (nsteps > 1 ? kMultiStep : 0u);
     else if ((req & ~kOptionalModules) == kAdv)
       sel = kAdvDiffConvSedi | kGated | scheme | (nsteps > 1 ? kMultiStep : 0u);
+  }
+  if (sel == kMaskGeneric && !(rare_bits & ~kBound) && !ml_ && !ctx->force_generic && big_ok) {
+    // a grid beyond 32-bit offsets: the gated instantiation with 64-bit ones serves every set of the time step's movers
+    const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
+    if ((req & ~kOptionalModules) == kAdv)
+      sel = kAdvDiffConvSedi | kGated | kBigGrid | scheme | (nsteps > 1 ? kMultiStep : 0u);
   }
   // module_wet_depo / module_dry_depo alone (the launch behind module_mixing): the kernel that packs the few
   // particles with anything to do into full waves
@@ -861,6 +882,12 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiffConvSedi | kTwoStage | kMultiStep)
     STEP_CASE(kAdvDiffConvSedi | kGated | kMultiStep)
     STEP_CASE(kAdvDiffConvSedi | kGated | kTwoStage | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kBigGrid)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kBigGrid | kTwoStage)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kBigGrid | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kBigGrid | kTwoStage | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kBigGrid | kMLWinds)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kBigGrid | kMLWinds | kMultiStep)
 #undef STEP_CASE
   default:
     if (nsteps > 1 && !(ml_fast && !rare && !ctx->force_generic))
@@ -2871,8 +2898,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     const bool ml_winds = c.advect_vert_coord >= 1 && c.advect_vert_coord <= 3;
     if (ml_winds && ensure_packed(ctx))
       return 1;
-    const bool lean_ok = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV
-      && (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);   // (launch_step's condition)
+    const bool lean_ok = lean32_ok(ctx) || lean64_ok(ctx);   // (launch_step's conditions; 64-bit offsets: the gated instantiations)
     // module_bound_cond (per particle: its own time, the tracer series on the device) is switched at run time in the
     // gated instantiations (pressure and model levels)
     const bool bound = c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1;
@@ -3201,6 +3227,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
   }
   if (strcmp(name, "split_step") == 0) {
     ctx->split_step = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "big_grid") == 0) {
+    ctx->big_grid = value != 0;
     return 0;
   }
   if (strcmp(name, "xcd_map") == 0) {

@@ -2716,7 +2716,19 @@ __device__ __forceinline__ T load_at(const void *base, unsigned byte_offset) {
   return *(const T *) ((const char *) base + byte_offset);
 }
 
+// ... and for grids whose packed arrays are larger than 4 GB (the kBigGrid instantiations, BIG = true below): the cell
+// index still fits 32 bits (launch_step checks), the byte offset does not
+template <class T>
+__device__ __forceinline__ T load_at64(const void *base, uint64_t byte_offset) {
+  return *(const T *) ((const char *) base + byte_offset);
+}
+
+template <bool BIG = false>
 __device__ __forceinline__ void load_wind_cached32(const DevMet &M, const Stencil &s, WindCache &w) {
+  if constexpr (BIG) {   // 64-bit addresses per lane: the gather of the general kernels
+    load_wind_cached(M, s, w);
+    return;
+  }
   if (s.ix != w.ix || s.iy != w.iy || s.ip != w.ip) {
 #pragma unroll
     for (int di = 0; di < 2; di++)
@@ -2822,13 +2834,18 @@ __device__ __forceinline__ double pair_time_2d_fast(const SurfA &c, const Stenci
 }
 
 // temperature at a stencil: as pair_time_3d, corner differences two at a time
+template <bool BIG = false>
 __device__ __forceinline__ double temp_fast(const DevMet &M, const Stencil &s, double wt) {
   double col[2][2][2];
 #pragma unroll
   for (int di = 0; di < 2; di++)
 #pragma unroll
     for (int dj = 0; dj < 2; dj++) {
-      const f32x4u q = load_at<f32x4u>(M.temp, 8u * cell32(M, s, di, dj));   // {t0,t1} at ip, {t0,t1} at ip + 1
+      f32x4u q;   // {t0,t1} at ip, {t0,t1} at ip + 1
+      if constexpr (BIG)
+        q = load_at64<f32x4u>(M.temp, (uint64_t) 8 * cell32(M, s, di, dj));
+      else
+        q = load_at<f32x4u>(M.temp, 8u * cell32(M, s, di, dj));
       const f32x2 d = __builtin_shufflevector(q, q, 0, 1) - __builtin_shufflevector(q, q, 2, 3);
       col[di][dj][0] = s.wp * (double) d[0] + (double) q[2];
       col[di][dj][1] = s.wp * (double) d[1] + (double) q[3];
@@ -2879,7 +2896,7 @@ __device__ __forceinline__ void position_fast(const DevMet &M, const Axes &A, Pa
 // module_advect on pressure levels (mptrac.c:3612-3677), STAGES = 4: classical Runge-Kutta (ADVECT 4);
 // STAGES = 2: the midpoint scheme (ADVECT 2, the reference's default) -- and, with `euler` set (wave-uniform,
 // from the control parameters), its first stage alone (ADVECT 1).  `hook(i)` runs behind the gathers of stage i.
-template <int STAGES, class Hook>
+template <int STAGES, bool BIG = false, class Hook>
 __device__ __forceinline__ void advect_fast(const DevMet &M, const Axes &A, Particle &P, Hook &hook, WindCache &wc,
                                             bool euler = false) {
   const double dt = P.dt;
@@ -2903,7 +2920,7 @@ __device__ __forceinline__ void advect_fast(const DevMet &M, const Axes &A, Part
     __builtin_amdgcn_s_setprio(MPHIP_SETPRIO);   // a wave on its way to a gather round goes first
 #endif
     stencil_3d_fast(M, A, x2, x0, x1, s);
-    load_wind_cached32(M, s, wc);
+    load_wind_cached32<BIG>(M, s, wc);
 #if MPHIP_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -3036,7 +3053,7 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
 }
 
 // module_diff_meso (mptrac.c:4280-4338) on the {u0,v0,u1,v1,w0,w1} records
-template <bool STREAM = false>
+template <bool STREAM = false, bool BIG = false>
 __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                                float &up, float &vp, float &wp, uint64_t ctr, uint64_t g,
                                                const double *pre, WindCache &wc, const double *ltab) {
@@ -3044,7 +3061,7 @@ __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const Dev
   Stencil s;
   raw_cell_fast(M, A, P.lon, P.lat, P.p, s);
   if (!STREAM) {
-    load_wind_cached32(M, s, wc);
+    load_wind_cached32<BIG>(M, s, wc);
     wind_cache_wait(wc);
   }
   const WindCorners &c = wc.c;
@@ -3059,10 +3076,17 @@ __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const Dev
     for (int j = 0; j < 2; j++) {
       f32x4u r0, r1, r2;
       if (STREAM) {   // (no corner cache in this instantiation: a corner is summed as it arrives)
-        const unsigned off = 24u * cell32(M, s, i, j);
-        r0 = load_at<f32x4u>(M.wind, off);
-        r1 = load_at<f32x4u>(M.wind, off + 16u);
-        r2 = load_at<f32x4u>(M.wind, off + 32u);
+        if constexpr (BIG) {
+          const uint64_t off = (uint64_t) 24 * cell32(M, s, i, j);
+          r0 = load_at64<f32x4u>(M.wind, off);
+          r1 = load_at64<f32x4u>(M.wind, off + 16);
+          r2 = load_at64<f32x4u>(M.wind, off + 32);
+        } else {
+          const unsigned off = 24u * cell32(M, s, i, j);
+          r0 = load_at<f32x4u>(M.wind, off);
+          r1 = load_at<f32x4u>(M.wind, off + 16u);
+          r2 = load_at<f32x4u>(M.wind, off + 32u);
+        }
       } else {
         r0 = c.r[i][j][0];
         r1 = c.r[i][j][1];
@@ -3117,6 +3141,7 @@ __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const Dev
 // module_convection (mptrac.c:4116-4170) and module_sedi (mptrac.c:5869-5882): both work at the horizontal
 // position module_diff_meso left, so one horizontal stencil serves the surface fields and the three
 // temperature columns
+template <bool BIG = false>
 __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                                unsigned mask, uint64_t ctr, uint64_t g, const double *pre, double rp,
                                                double rhop) {
@@ -3153,9 +3178,9 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
     }
     if (ptop != pbot && P.p >= ptop) {
       vert_fast(M, A, pbot, s);
-      const double tbot = temp_fast(M, s, wt);
+      const double tbot = temp_fast<BIG>(M, s, wt);
       vert_fast(M, A, ptop, s);
-      const double ttop = temp_fast(M, s, wt);
+      const double ttop = temp_fast<BIG>(M, s, wt);
       const double rhobot = fdiv(pbot, tbot);
       const double rhotop = fdiv(ptop, ttop);
       const double rs = pre ? *pre : uniform01(ctr + g);
@@ -3165,7 +3190,7 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
   }
   if (mask & MPHIP_MOD_SEDI) {
     vert_fast(M, A, P.p, s);
-    const double t = temp_fast(M, s, wt);
+    const double t = temp_fast<BIG>(M, s, wt);
     const double v_s = sedi(P.p, t, rp, rhop);
     P.p += dz2dp(v_s * P.dt * 1e-3, P.p);
   }

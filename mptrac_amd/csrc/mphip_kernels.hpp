@@ -141,6 +141,13 @@ constexpr bool kRuntimeMask = (CT == kMaskGeneric || CT == kMaskGenericPL || kGe
 constexpr unsigned kMLWinds = 1u << 27;
 template <unsigned CT>
 constexpr bool kLeanML = !kRuntimeMask<CT> && (CT & kMLWinds) != 0;
+// template mask only, on a lean instantiation: 64-bit byte offsets into the packed wind / temperature records (and
+// 64-bit column indices of the model-level fields) -- grids whose packed arrays exceed 4 GB (a 0.1 degree grid with
+// 137 levels: 21 GB of wind records).  Two or three more instructions per gather; carried by the gated instantiations
+// only (they serve every module set), so the kernels of the grids that fit 32 bits are what they were.
+constexpr unsigned kBigGrid = 1u << 28;
+template <unsigned CT>
+constexpr bool kBig = !kRuntimeMask<CT> && (CT & kBigGrid) != 0;
 template <unsigned CT>
 constexpr bool kModelLevels = kGenericML<CT> || kLeanML<CT>;
 constexpr unsigned kRareModules = MPHIP_MOD_ADVECT_INIT | MPHIP_MOD_ISOSURF_INIT | MPHIP_MOD_ISOSURF | MPHIP_MOD_DIFF_PBL
@@ -158,7 +165,7 @@ constexpr unsigned kGated = 1u << 25;
 // of steps with nothing between them -- no module_sort, mixing, output -- at small particle counts, where a step is
 // shorter than a kernel launch).  The state goes through memory between the steps as it does between launches.
 constexpr unsigned kMultiStep = 1u << 26;
-constexpr unsigned kTemplateFlags = kTwoStage | kGated | kMultiStep | kMLWinds;
+constexpr unsigned kTemplateFlags = kTwoStage | kGated | kMultiStep | kMLWinds | kBigGrid;
 constexpr unsigned kOptionalModules = MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kTailModules = MPHIP_MOD_LOSS_ZERO | MPHIP_MOD_DECAY | MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
@@ -307,6 +314,7 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
 
 // module_wet_depo / module_dry_depo of the lean kernels: the general value code on the lean stencil set-up
 // (one horizontal stencil at the final position serves both modules)
+template <bool BIG = false>
 __device__ __forceinline__ void wet_depo_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
                                               long long i, const Particle &P, Stencil &s) {
   if (above_every_cloud_top(M, P))
@@ -330,7 +338,7 @@ __device__ __forceinline__ void wet_depo_fast(const mphip_ctl_t &ctl, const DevM
   const double iwc = cloud_time_3d(c, s, wt, 2);
   const double swc = cloud_time_3d(c, s, wt, 3);
   const bool inside = (lwc > 0 || rwc > 0 || iwc > 0 || swc > 0);
-  const double t = temp_fast(M, s, wt);
+  const double t = temp_fast<BIG>(M, s, wt);
 
   double lambda = 0;
   if (inside) {
@@ -368,6 +376,7 @@ __device__ __forceinline__ void wet_depo_fast(const mphip_ctl_t &ctl, const DevM
   apply_loss(ctl, a, i, aux, ctl.qnt_mloss_wet, lambda);
 }
 
+template <bool BIG = false>
 __device__ __forceinline__ void dry_depo_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
                                               long long i, const Particle &P, Stencil &s) {
   if (above_every_surface_layer(ctl, M, P))
@@ -382,7 +391,7 @@ __device__ __forceinline__ void dry_depo_fast(const mphip_ctl_t &ctl, const DevM
   double v_dep;
   if (ctl.qnt_rp > 0 && ctl.qnt_rhop > 0) {   // "> 0" as the reference, mptrac.c:4769
     vert_fast(M, A, P.p, s);
-    const double t = temp_fast(M, s, wt);
+    const double t = temp_fast<BIG>(M, s, wt);
     v_dep = sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
   } else
     v_dep = ctl.dry_depo_vdep;
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
   extern __shared__ double s_axes[];
   const unsigned mask = kRuntimeMask<CT> ? S.mask : (CT & ~kTemplateFlags);
   // column indices of the model-level fields: 32 bits in the lean instantiations (launch_step's size check)
-  using MLCol = std::conditional_t<kLeanML<CT> && MPHIP_ML_OFF32, uint32_t, size_t>;
+  using MLCol = std::conditional_t<kLeanML<CT> && MPHIP_ML_OFF32 && !kBig<CT>, uint32_t, size_t>;
   const DevMet &M = S.met;
   const DevAtm &a = S.atm;
   const mphip_ctl_t &ctl = S.ctl;
@@ -701,10 +710,10 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
         advect_rk4_fast(M, A, P, pre, wc);
       else if (lean && (CT & kTwoStage)) {
         NoHook none;
-        advect_fast<2>(M, A, P, none, wc, ctl.advect == 1);
+        advect_fast<2, kBig<CT>>(M, A, P, none, wc, ctl.advect == 1);
       } else if (lean) {
         NoHook none;
-        advect_fast<4>(M, A, P, none, wc);
+        advect_fast<4, kBig<CT>>(M, A, P, none, wc);
       } else
         advect(ctl, M, A, P, wc);
     }
@@ -732,7 +741,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
       if (kGenericML<CT>)
         wind_cache_reset(wc, true);
       if (lean)   // (without a pressure-level advection before it there are no cached corners: the streaming version)
-        diff_meso_fast<!(CT & MPHIP_MOD_ADVECT) || kLeanML<CT>>(ctl, M, A, P, up, vp, wp, c_meso, g, early ? pre.meso : nullptr, wc, ltab);
+        diff_meso_fast<!(CT & MPHIP_MOD_ADVECT) || kLeanML<CT>, kBig<CT>>(ctl, M, A, P, up, vp, wp, c_meso, g, early ? pre.meso : nullptr, wc, ltab);
       else
         diff_meso(ctl, M, A, P, up, vp, wp, c_meso, g, early ? pre.meso : nullptr, wc, ltab);
       st_state(&a.up[i], up);
@@ -742,7 +751,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
     if (lean) {
       if (opt & (MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI)) {
         const bool sedi_on = (opt & MPHIP_MOD_SEDI) != 0;
-        conv_sedi_fast(ctl, M, A, P, opt, c_conv, g, early ? &pre.conv : nullptr,
+        conv_sedi_fast<kBig<CT>>(ctl, M, A, P, opt, c_conv, g, early ? &pre.conv : nullptr,
                        sedi_on ? ld_state(&a.q[ctl.qnt_rp][i]) : 0.0, sedi_on ? ld_state(&a.q[ctl.qnt_rhop][i]) : 0.0);
       }
     } else {
@@ -793,9 +802,9 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
         Stencil sd = stencil_zero();
         horiz_fast(M, A, P.lon, P.lat, sd);
         if (wet)
-          wet_depo_fast(ctl, M, A, a, i, P, sd);
+          wet_depo_fast<kBig<CT>>(ctl, M, A, a, i, P, sd);
         if (dry)
-          dry_depo_fast(ctl, M, A, a, i, P, sd);
+          dry_depo_fast<kBig<CT>>(ctl, M, A, a, i, P, sd);
       }
     } else {
       if (mask & MPHIP_MOD_WET_DEPO)

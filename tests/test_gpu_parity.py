@@ -1568,6 +1568,45 @@ def test_long_run_400_steps_with_prefetched_handovers():
     s.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,over", [("conv_sedi", {}), ("conv_sedi", dict(advect=2)), ("advect", dict(advect=1)),
+                                       ("turb", {}), ("full", {}), ("zeta_full", {}), ("mlp_full", dict(advect=2)),
+                                       ("conv_sedi", dict(bound_lat0=-60.0, bound_lat1=60.0, bound_p0=1100.0, bound_p1=200.0,
+                                                          bound_mass=2.0, bound_dps=300.0))],
+                         ids=["conv_sedi", "conv_sedi-midpoint", "advect-euler", "turb", "full", "zeta_full", "mlp_full-midpoint",
+                              "conv_sedi-bound"])
+def test_big_grid_instantiations_equal_the_lean_ones(case, over):
+    """Grids whose packed wind records exceed 4 GB take instantiations with 64-bit byte offsets (kBigGrid: the gated
+    kernels, pressure and model levels).  Option big_grid forces them on a grid that fits 32 bits: only the addressing
+    differs, so the results are the lean kernels' bit for bit -- single steps and steps that share a launch -- and the
+    oracle's within the bar."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=5003)
+    ctl = dict(ctl, **over)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    times = cases.step_times(o.ctl)
+    runs = {}
+    for name, big in (("lean", 0), ("big", 1)):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("big_grid", big)
+        s.timesteps_init(0.0, 0.0)
+        for t in times[:3]:
+            s.run_timestep(t)
+        s.run_timesteps(times[3], 7)
+        runs[name] = s.state()
+        runs[name]["ctr"] = s.get_cache()["rng_ctr"]
+        s.close()
+    for k in ("time", "lon", "lat", "p", "uvwp", "q"):
+        assert np.array_equal(runs["big"][k], runs["lean"][k], equal_nan=True), k
+    assert runs["big"]["ctr"] == runs["lean"]["ctr"]
+    for t in times[:10]:
+        o.run_timestep(t)
+    r = o.state()
+    assert np.array_equal(runs["big"]["time"], r["time"])
+    for k in ("lon", "lat", "p"):
+        assert cases.rel_err(runs["big"][k], r[k]) <= TOL, k
+
+
 _BATCH_CASES = [(c, None) for c in ("advect", "turb", "diff", "conv_sedi", "full", "zeta_full", "mlp_full")] + [
     # the reference's default integrator (midpoint) and Euler: two-stage instantiations; trajectories with winds
     # from the model levels: the gated lean model-level instantiation
