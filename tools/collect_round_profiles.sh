@@ -24,3 +24,6 @@ timeout 900 python tools/gpu_bench_sweep.py C3 > gpurun_out/${T}_sustained_480_s
 timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_C3_driver_args.json 2> /dev/null
 timeout 900 bash tools/piece_cost.sh ${T}pieces > gpurun_out/${T}_pieces.log 2>&1
 timeout 600 bash tools/profile_ml.sh ${T}z > gpurun_out/${T}_ml_counters.txt 2>&1
+timeout 900 python tools/gpu_config_matrix.py big_grid=1 > gpurun_out/${T}_config_matrix_big.txt 2>&1
+timeout 300 python tools/gpu_ml_subsets.py > gpurun_out/${T}_ml_subsets.txt 2>&1
+timeout 300 python tools/gpu_sparse_schedule.py > gpurun_out/${T}_sparse_schedule.txt 2>&1

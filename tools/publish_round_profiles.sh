@@ -19,6 +19,10 @@ done
 cp $G/${T}_config_matrix.txt $P/${T}_config_matrix.txt
 { echo; echo "# the same control sets through the general instantiation (option generic_kernel 1)"; cat $G/${T}_config_matrix_general.txt; } >> $P/${T}_config_matrix.txt
 cp $G/${T}_sustained_480_steps.txt $P/${T}_sustained_480_steps.txt
+[ -s $G/${T}_config_matrix_big.txt ] && { echo; echo "# the same control sets through the instantiations with 64-bit byte offsets (option big_grid 1: what a grid beyond 4 GB of wind records takes)"; cat $G/${T}_config_matrix_big.txt; } >> $P/${T}_config_matrix.txt
+[ -s $G/${T}_ml_subsets.txt ] && cp $G/${T}_ml_subsets.txt $P/${T}_model_level_subsets.txt
+[ -s $G/${T}_sparse_schedule.txt ] && cp $G/${T}_sparse_schedule.txt $P/${T}_sparse_schedule.txt
+[ -s $G/${T}_ml_counters.txt ] && cp $G/${T}_ml_counters.txt $P/${T}_c3z_sq_counters.txt
 cp $G/prof_${T}pieces/piece_cost.txt $P/${T}_piece_costs.txt
 python $R/tools/update_pmc_traffic.py $G/prof_$T C3 profiles/${T}_c3_summary.txt > /dev/null
 python - <<PY
