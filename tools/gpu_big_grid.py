@@ -2,7 +2,8 @@
 """A grid beyond 32-bit byte offsets, for real (GPU box): 1441 x 721 columns x 180 levels = 187e6 cells, 4.49 GB of packed
 wind records (the limit of the lean kernels' 32-bit offsets is 4.29 GB).  C3's modules (RK4, turbulent + mesoscale diffusion,
 convection, sedimentation), 10^5 particles, one single step + six steps that share a launch + three single steps, against
-the oracle.  The library takes the kBigGrid instantiations by itself (no option).  About 10 GB of host memory."""
+the oracle.  The library takes the kBigGrid instantiations by itself (no option).  About 10 GB of host memory.
+  python tools/gpu_big_grid.py zeta     the same with winds from the model levels (zeta coordinate; about 25 GB)"""
 import os
 import sys
 import time
@@ -23,15 +24,18 @@ cells = (GRID[0] + 1) * GRID[1] * GRID[2]
 print(f"grid {GRID[0] + 1} x {GRID[1]} x {GRID[2]} = {cells / 1e6:.1f}e6 cells, wind records {24 * cells / 2 ** 30:.2f} GiB "
       f"(32-bit offsets reach 4.00 GiB)", flush=True)
 assert 24 * cells >= 2 ** 32
-names = ("m", "rp", "rhop")
-ctl = dict(cases.CASES["conv_sedi"])
+zeta = "zeta" in sys.argv[1:]
+names = ("m", "rp", "rhop", "zeta") if zeta else ("m", "rp", "rhop")
+ctl = dict(cases.CASES["zeta_full" if zeta else "conv_sedi"])
 ctl.update(ctl_from_quantities(names))
-fields = ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel")
+fields = ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel") + (("pl", "ul", "vl", "zetal", "zeta_dotl") if zeta else ())
 t0 = time.time()
 m0 = synthetic_met(GRID, 0.0, 1.0, fields=fields)
 m1 = synthetic_met(GRID, 3600.0, 1.25, fields=fields)
 print(f"two synthetic snapshots in {time.time() - t0:.0f} s", flush=True)
 atm = synthetic_particles(100000, seed=11, quantities=names)
+if zeta:      # a vertical coordinate inside the range of the synthetic zetal field (as cases.make_case)
+    atm["q"][list(names).index("zeta")] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
 clim = cases.load_clim_tropo()
 B.lib().orc_set_num_threads(B.usable_cores())
 o = B.Oracle(ctl, clim, m0, m1, atm)
