@@ -156,6 +156,43 @@ def cpu_baseline(workload, ctl, clim, met0, met1, atm, n_sample, n_steps):
                       f"({cores} threads); 1 thread: first {n1} particles, {max(2, n_steps // 2)} steps"}
 
 
+def visible_gpus():
+    import ctypes
+    try:
+        n = ctypes.c_int(0)
+        return n.value if ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+def multi_gpu_probe(args):
+    """A one-GPU invocation on a box with several GPUs: the same workload once more over N = min(8, visible
+    GPUs) ranks, launched as the driver launches N > 1 (torch.distributed.run, one process per GPU, the
+    library's RCCL communicator), so that any multi-GPU box produces an N > 1 line without further action.  Not
+    part of `value`; None on a one-GPU box."""
+    import subprocess
+    ndev = visible_gpus()
+    if ndev < 2:
+        return None
+    n = min(8, ndev)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__), "--gpus", str(n),
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"n_gpus": n, "error": "timeout after 900 s"}
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    if res.returncode != 0 or len(lines) != 1:
+        return {"n_gpus": n, "error": res.stderr.decode()[-800:]}
+    line = json.loads(lines[0])
+    return {"n_gpus": line["n_gpus"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+            "scaling": line["scaling"], "rccl_ranks": line["config"]["rccl_ranks"], "reduction": line["config"]["reduction"],
+            "particles_total": line["config"]["particles_total"],
+            "kernel_ms_per_rank": line["roofline"]["kernel_ms_per_rank"]}
+
+
 def build_id():
     """Hash of the kernel sources: ties the committed PMC profile (profiles/pmc_traffic.json) to the build it
     was taken from."""
@@ -206,6 +243,9 @@ def main():
                          "same bits, the particle state and the meteo lines it uses stay in the caches from step to "
                          "step).  off: K mphip_run_timestep calls, one launch per step.  The line reports the step "
                          "kernel's time under both")
+    ap.add_argument("--no-multi-gpu-probe", action="store_true",
+                    help="N = 1 on a box with several GPUs: do not append the short run over min(8, visible GPUs) RCCL "
+                         "ranks (`multi_gpu_probe` in the line; outside the timed region, a separate launch)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="(diagnostic) do not bracket the step kernel with HIP events; roofline is then not reported")
     args = ap.parse_args()
@@ -443,6 +483,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, ctl, clim, met0, met1, atm,
                                                min(args.cpu_sample, n_local), args.cpu_steps)
+        if world == 1 and not use_dist and not args.no_multi_gpu_probe and not args.particles:
+            probe = multi_gpu_probe(args)
+            if probe is not None:
+                out["multi_gpu_probe"] = probe
         print(json.dumps(out), flush=True)
 
     sim.close()

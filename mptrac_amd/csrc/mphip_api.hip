@@ -719,13 +719,20 @@ int check_fields(mphip_ctx *ctx, unsigned mask) {
 // multiplies (cell32: columns below 2^24, cells below 2^32).  lean32_ok: 32-bit byte offsets into the packed grids
 // (the largest record has 24 bytes); lean64_ok: a grid beyond that -- or the option "big_grid" -- takes the kBigGrid
 // instantiations with 64-bit offsets.
+// With winds from the model levels (ADVECT_VERT_COORD 1..3) the lean kernels index the model-level records -- nml
+// levels per column, which need not be the np pressure levels of the same file (met_t::npl vs met_t::np,
+// mptrac.h:3862) -- so every size test takes the larger of the two level counts.
+static unsigned long long guard_levels(const mphip_ctx *ctx) {
+  const bool ml = ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3;
+  return (unsigned long long) (ml ? std::max(ctx->npl, ctx->nml) : ctx->npl);
+}
 static bool lean_grid(const mphip_ctx *ctx) {
   const unsigned long long cols = (unsigned long long) ctx->nx * ctx->ny;
   return ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV && cols < (1ull << 24)
-    && cols * (unsigned long long) ctx->npl < (1ull << 32);
+    && cols * guard_levels(ctx) < (1ull << 32);
 }
 static bool fits32(const mphip_ctx *ctx) {
-  return (unsigned long long) ctx->nx * ctx->ny * ctx->npl * 24ull < (1ull << 32);
+  return (unsigned long long) ctx->nx * ctx->ny * guard_levels(ctx) * 24ull < (1ull << 32);
 }
 static bool lean32_ok(const mphip_ctx *ctx) { return lean_grid(ctx) && fits32(ctx) && !ctx->big_grid; }
 static bool lean64_ok(const mphip_ctx *ctx) { return lean_grid(ctx) && (!fits32(ctx) || ctx->big_grid); }
@@ -787,12 +794,12 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   }
   const bool ml_ = ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3;   // winds from the model levels
   // model levels: the fast path needs monotonic height columns and none of the rarely used modules
-  const bool ml_fast = ml_ && ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels
+  const bool ml_fast = ml_ && ctx->pk.ml_monotonic && ctx->nml <= kLockstepMaxLevels
     && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT)) && !ctx->force_generic;
   // ... module_bound_cond is no obstacle where the gated lean model-level instantiation can run (it switches the module
   // at run time, as every gated instantiation does)
   constexpr unsigned kBoundBits = MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
-  const bool ml_fast_bound = ml_ && ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels
+  const bool ml_fast_bound = ml_ && ctx->pk.ml_monotonic && ctx->nml <= kLockstepMaxLevels
     && !(mask & (kRareModules & ~MPHIP_MOD_ADVECT_INIT & ~kBoundBits)) && !ctx->force_generic;
   const unsigned rare_bits = mask & kRareModules & ~(ml_fast ? MPHIP_MOD_ADVECT_INIT : 0u);
   const bool rare = (ml_ && !ml_fast) || rare_bits;
@@ -2902,7 +2909,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     // module_bound_cond (per particle: its own time, the tracer series on the device) is switched at run time in the
     // gated instantiations (pressure and model levels)
     const bool bound = c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1;
-    const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->npl <= kLockstepMaxLevels && ctx->d_kz != nullptr && (!bound || lean_ok)
+    const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->nml <= kLockstepMaxLevels && ctx->d_kz != nullptr && (!bound || lean_ok)
                                 : lean_ok && (movers & ~kOptionalModules) == kAdv;   // (exact sets: their own kernels; subsets: the gated one)
     if (bound)
       mask |= MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;

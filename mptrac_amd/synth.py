@@ -69,9 +69,10 @@ def make_axes(nx0, ny, npl, lon0=-180.0, lat_reverse=False):
     return lon, lat, pressure_from_z(z)
 
 
-def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_reverse=False):
+def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_reverse=False, model_levels=None):
     """Analytic snapshot.  ``amp`` scales the wind amplitudes so that two
-    snapshots differ and the time interpolation is exercised."""
+    snapshots differ and the time interpolation is exercised.  ``model_levels``:
+    number of model levels (met_t::npl; default: seven more than pressure levels)."""
     nx0, ny, npl = GRIDS[grid] if isinstance(grid, str) else grid
     lon, lat, p = make_axes(nx0, ny, npl, lon0, lat_reverse)
     want = set(FIELDS_3D + FIELDS_2D) - set(FIELDS_METEO_ONLY) if fields is None else set(fields)
@@ -103,7 +104,7 @@ def synthetic_met(grid="C1", time=0.0, amp=1.0, fields=None, lon0=-180.0, lat_re
     if want & set(FIELDS_ML):
         # terrain-following model levels: p = sigma_k * ps (sigma 1 -> ~2e-4), zeta = a potential-temperature-like
         # monotonic function of p that also varies horizontally and in time, winds analytic in (lon, lat, level)
-        npl_ml = npl + 7
+        npl_ml = npl + 7 if model_levels is None else int(model_levels)
         kk = np.arange(npl_ml, dtype=np.float64)[None, None, :]
         sigma = np.exp(-8.5 * kk / (npl_ml - 1))
         ps3 = (1013.25 - 30.0 * np.sin(lam) ** 2 * np.cos(phi))

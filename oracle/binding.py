@@ -34,7 +34,8 @@ class OrcAtm(C.Structure):
 
 class OrcCache(C.Structure):
     _fields_ = [("dt", _dp), ("rs", _dp), ("uvwp", _fp), ("rng_ctr", C.c_uint64),
-                ("iso_var", _dp), ("iso_ts", _dp), ("iso_ps", _dp), ("iso_n", C.c_int)]
+                ("iso_var", _dp), ("iso_ts", _dp), ("iso_ps", _dp), ("iso_n", C.c_int),
+                ("ip_global", C.POINTER(C.c_int64)), ("np_global", C.c_int64)]
 
 
 class OrcZm(C.Structure):
@@ -131,7 +132,9 @@ class Oracle:
     """CPU mirror of the simulation state; same call names as the product's
     ``Simulation`` so parity tests read symmetrically."""
 
-    def __init__(self, ctl_kw, clim, met0, met1, atm, rng_ctr=0):
+    def __init__(self, ctl_kw, clim, met0, met1, atm, rng_ctr=0, ip_global=None, np_global=None):
+        """ip_global / np_global: `atm` is a subsample of a run with np_global particles, particle i being that
+        run's particle ip_global[i] (random numbers follow the full run's slots; per-particle modules only)."""
         self.lib = lib()
         self.ctl = fill_ctl(OrcCtl(), **ctl_kw)
         time, lat, tropo = clim[:3]
@@ -184,7 +187,12 @@ class Oracle:
         self.uvwp = np.zeros((n, 3), dtype=np.float32)
         self.iso_var = np.zeros(n)
         self.cache = OrcCache(_ptr(self.dt, _dp), _ptr(self.rs, _dp), _ptr(self.uvwp, _fp), rng_ctr,
-                              _ptr(self.iso_var, _dp), None, None, 0)
+                              _ptr(self.iso_var, _dp), None, None, 0, None, 0)
+        if ip_global is not None:
+            self._ip_global = np.ascontiguousarray(ip_global, dtype=np.int64)
+            assert self._ip_global.shape == (n,) and np_global is not None and int(self._ip_global.max(initial=-1)) < np_global
+            self.cache.ip_global = _ptr(self._ip_global, C.POINTER(C.c_int64))
+            self.cache.np_global = int(np_global)
 
     def set_met(self, slot, met):
         self._mets[slot] = met      # keep arrays alive

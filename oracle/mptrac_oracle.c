@@ -407,6 +407,41 @@ void orc_module_rng(const orc_ctl_t *ctl, orc_cache_t *cache, size_t n, int meth
   }
 }
 
+/* The random numbers of one module for the particles of `atm`: n_per values per particle, slot
+ * rs[n_per * ip + k] as the modules read them (mptrac.c:4645-4647, 4322-4331, 4143).  Normally this is
+ * module_rng over n_per * np numbers.  With cache->ip_global set, `atm` holds a SUBSAMPLE of a run with
+ * cache->np_global particles and particle ip is that run's particle ip_global[ip]: it gets the numbers the
+ * full run's module_rng call puts into rs[n_per * ip_global[ip] + k] (the uniform at flat index f is Squares of
+ * counter + f, mptrac.c:5797-5810; the normal at f comes from the uniforms of the flat pair (f & ~1, f | 1),
+ * mptrac.c:5820-5826), and the counter advances by the full run's n + 1 (mptrac.c:5812). */
+static void module_random_numbers(const orc_ctl_t *ctl, orc_cache_t *cache, int np, int n_per, int method) {
+  if (!cache->ip_global) {
+    orc_module_rng(ctl, cache, (size_t) n_per * (size_t) np, method);
+    return;
+  }
+  if (ctl->rng_type != 1)
+    die("oracle restates RNG_TYPE=1 (Squares) only");
+  const uint64_t base = cache->rng_ctr;
+  double *rs = cache->rs;
+#pragma omp parallel for schedule(static)
+  for (int ip = 0; ip < np; ip++)
+    for (int k = 0; k < n_per; k++) {
+      const uint64_t f = (uint64_t) n_per * (uint64_t) cache->ip_global[ip] + (uint64_t) k;
+      double *out = &rs[(size_t) n_per * (size_t) ip + (size_t) k];
+      if (method != 1) {
+        *out = (double) orc_squares(base + f) / (double) UINT64_MAX;
+        continue;
+      }
+      const uint64_t e = f & ~(uint64_t) 1;
+      const double u0 = (double) orc_squares(base + e) / (double) UINT64_MAX;
+      const double u1 = (double) orc_squares(base + e + 1) / (double) UINT64_MAX;
+      const double r = sqrt(-2.0 * log(u0));
+      const double phi = 2.0 * M_PI * u1;
+      *out = (f & 1) ? r * sinf((float) phi) : r * cosf((float) phi);
+    }
+  cache->rng_ctr += (uint64_t) n_per * (uint64_t) cache->np_global + 1;
+}
+
 /* ---- module_timesteps (mptrac.c:5999-6073) ------------------------------ */
 
 void orc_module_timesteps(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
@@ -759,7 +794,7 @@ static double kz_blend(const orc_ctl_t *ctl, const orc_clim_t *clim, double time
 
 void orc_module_diff_turb(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim,
                           const orc_met_t *met0, const orc_met_t *met1, orc_atm_t *atm) {
-  orc_module_rng(ctl, cache, 3 * (size_t) atm->np, 1);
+  module_random_numbers(ctl, cache, atm->np, 3, 1);
   const int ct = met0->coord_type;
 #pragma omp parallel for schedule(static)
   for (int ip = 0; ip < atm->np; ip++) {
@@ -828,7 +863,7 @@ static inline double tvirt(double t, double h2o) {
 
 void orc_module_diff_pbl(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
                          const orc_met_t *met1, orc_atm_t *atm) {
-  orc_module_rng(ctl, cache, 3 * (size_t) atm->np, 1);
+  module_random_numbers(ctl, cache, atm->np, 3, 1);
   const int ct = met0->coord_type;
 #pragma omp parallel for schedule(static)
   for (int ip = 0; ip < atm->np; ip++) {
@@ -972,7 +1007,7 @@ void orc_module_diff_pbl(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met
 
 void orc_module_diff_meso(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
                           const orc_met_t *met1, orc_atm_t *atm) {
-  orc_module_rng(ctl, cache, 3 * (size_t) atm->np, 1);
+  module_random_numbers(ctl, cache, atm->np, 3, 1);
   const int ct = met0->coord_type;
   const float *u0 = met0->f3[ORC_U], *v0 = met0->f3[ORC_V], *w0 = met0->f3[ORC_W];
   const float *u1 = met1->f3[ORC_U], *v1 = met1->f3[ORC_V], *w1 = met1->f3[ORC_W];
@@ -1038,7 +1073,7 @@ void orc_module_diff_meso(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_me
 
 void orc_module_convection(const orc_ctl_t *ctl, orc_cache_t *cache, const orc_met_t *met0,
                            const orc_met_t *met1, orc_atm_t *atm) {
-  orc_module_rng(ctl, cache, (size_t) atm->np, 0);
+  module_random_numbers(ctl, cache, atm->np, 1, 0);
 #pragma omp parallel for schedule(static)
   for (int ip = 0; ip < atm->np; ip++) {
     if (cache->dt[ip] == 0)
@@ -1696,6 +1731,8 @@ void orc_run_timestep(orc_ctl_t *ctl, orc_cache_t *cache, const orc_clim_t *clim
     orc_module_advect_init(ctl, met0, met1, atm);
   }
   orc_module_timesteps(ctl, cache, met0, atm, t);
+  if (cache->ip_global && (ctl->sort_dt > 0 || (ctl->mixing_trop >= 0 && ctl->mixing_strat >= 0)))
+    die("a subsample (ip_global) cannot follow module_sort (slots are rebound) or module_mixing (cell means)");
   if (ctl->sort_dt > 0 && fmod(t, ctl->sort_dt) == 0)
     orc_module_sort(ctl, met0, atm, NULL, NULL);
   orc_module_position(cache, met0, met1, atm);

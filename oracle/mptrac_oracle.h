@@ -145,6 +145,13 @@ typedef struct {
   double *iso_ts;   /* [iso_n] balloon time series (ISOSURF 4) */
   double *iso_ps;   /* [iso_n] */
   int iso_n;
+  /* Subsample mode (NULL = off): `atm` holds np particles picked from a run with np_global particles, particle
+   * ip being that run's particle ip_global[ip].  The stochastic modules then draw, for every particle, the random
+   * numbers the full run binds to its slot (rs[3 * ip_global + k], mptrac.c:4645-4647) and advance the counter as
+   * the full run does, so a few thousand particles of a 10^7 or 10^8 run can be checked.  Only meaningful for
+   * per-particle modules (no module_sort, which rebinds slots, and no module_mixing). */
+  const int64_t *ip_global;
+  int64_t np_global;
 } orc_cache_t;
 
 /* A zonal-mean climatology, view of clim_zm_t (mptrac.h:3745-3776): vmr[ntime][np][nlat], compact. */

@@ -1,0 +1,291 @@
+"""BASELINE configs at their full sizes on the GPU box, checked against the oracle on a subsample.
+
+The stochastic modules bind the random numbers to the particle's slot of the whole run (rs[3 * ip + k],
+src/mptrac.c:4645-4647, 5797-5826), so a few thousand particles of a 10^7 or 10^8 run can only be checked by an
+oracle that draws the numbers of those slots: orc_cache_t::ip_global (oracle/mptrac_oracle.h; its agreement with
+a full oracle run is a CPU test, tests/test_host_logic.py::test_oracle_subsample_draws_the_full_runs_random_numbers).
+
+  * configs[2] (C3): 10^7 particles, 721 x 361 x 137, RK4 + turbulent + mesoscale diffusion + convection +
+    sedimentation, 20 steps through mphip_run_timesteps -- the very call bench.py times;
+  * configs[3] (C4): 10^8 particles as eight index-range shards of 1.25 x 10^7 (eight contexts on the one GPU of
+    the box, one host thread each, their gridded output summed through the all-reduce hook) against ONE context
+    holding all 10^8, and against the oracle on a subsample;
+  * every visible GPU (skipped on a one-GPU box): min(8, device count) ranks with the library's own RCCL
+    communicator, launched the way the driver launches bench.py.
+"""
+import ctypes
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import cases
+from mptrac_amd import hip
+from oracle import binding as B
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+TOL = 1e-10          # BASELINE north_star: positions within 1e-10 relative of the CPU reference
+
+
+def _c3_inputs(n, first=0, n_steps=20):
+    import bench
+    ctl, clim, met0, met1, atm, _, _ = bench.build_inputs("C3", 0, 1, n_steps + 1, particles=n)
+    if first:
+        from mptrac_amd.synth import synthetic_particles
+        atm = synthetic_particles(n, seed=12345, quantities=("m", "rp", "rhop"), first=first)
+    return ctl, clim, met0, met1, atm
+
+
+def _oracle_on_subsample(ctl, clim, met0, met1, atm_sub, pick, n_total, n_steps):
+    o = B.Oracle(ctl, clim, met0, met1, atm_sub, ip_global=pick, np_global=n_total)
+    o.timesteps_init()
+    for k in range(n_steps + 1):
+        o.run_timestep(k * o.ctl.dt_mod)
+    return o
+
+
+def _take(atm, idx):
+    return {k: (v[idx].copy() if k != "q" else v[:, idx].copy()) for k, v in atm.items()}
+
+
+def test_c3_at_1e7_on_its_own_grid_against_the_oracle_subsample():
+    """BASELINE configs[2] as bench.py runs it: 10^7 particles, 20 steps in one mphip_run_timesteps call."""
+    n, n_steps = 10 ** 7, 20
+    ctl, clim, met0, met1, atm = _c3_inputs(n)
+    s = hip.Simulation(ctl, clim, met0, met1, atm)
+    s.timesteps_init(0.0, 0.0)
+    dt = s.ctl.dt_mod
+    s.run_timestep(0.0)
+    s.run_timesteps(dt, n_steps)
+    g = s.state()
+    cnt, mean, _ = s.grid_sums(n_steps * dt)
+    ctr = s.get_cache()["rng_ctr"]
+    s.close()
+
+    pick = np.random.default_rng(20250930).choice(n, 5000, replace=False)
+    pick[:2] = (0, n - 1)
+    o = _oracle_on_subsample(ctl, clim, met0, met1, _take(atm, pick), pick, n, n_steps)
+    assert o.cache.rng_ctr == ctr                                         # the counter of the full run
+    for k, ref in (("lon", o.lon), ("lat", o.lat), ("p", o.p)):
+        err = cases.rel_err(g[k][pick], ref)
+        assert err <= TOL, (k, err)
+    assert np.array_equal(g["time"][pick], o.time)
+    assert np.array_equal(g["uvwp"][pick], o.uvwp)                         # float statistics: identical bits
+    assert np.array_equal(g["q"][:, pick], o.q)                            # m, rp, rhop untouched by these modules
+    # every particle took every step, stayed on the globe and is counted once
+    assert np.all(g["time"] == n_steps * dt)
+    for k in ("lon", "lat", "p"):
+        assert np.all(np.isfinite(g[k])), k
+    assert g["lon"].min() >= -180.0 and g["lon"].max() < 180.0 and np.abs(g["lat"]).max() <= 90.0 and g["p"].min() > 0.0
+    assert np.abs(g["lon"] - atm["lon"]).max() > 1.0                       # (they did move)
+    inside = _inside_output_grid(o.ctl, g)
+    assert int(cnt.sum()) == int(np.count_nonzero(inside))
+    assert abs(mean[0].sum() - g["q"][0][inside].sum()) <= 1e-9 * n
+
+
+def _inside_output_grid(ctl, g):
+    """The particles write_grid bins (mptrac.c:13847-13860) on the default output grid."""
+    z = 7.0 * np.log(1013.25 / g["p"])
+    return ((g["lon"] >= ctl.grid_lon0) & (g["lon"] < ctl.grid_lon1) & (g["lat"] >= ctl.grid_lat0)
+            & (g["lat"] < ctl.grid_lat1) & (z >= ctl.grid_z0) & (z < ctl.grid_z1))
+
+
+class _ThreadAllreduce:
+    """All-reduce over N contexts of one process, one host thread each: the partial sums meet on the host and
+    are added in rank order (what a collective over N processes does, through the hook of mphip_set_allreduce)."""
+
+    def __init__(self, nranks):
+        self.n = nranks
+        self.barrier = threading.Barrier(nranks)
+        self.parts = [None] * nranks
+        self.calls = [0] * nranks
+        self.rt = ctypes.CDLL("libamdhip64.so")
+        self.rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+
+    def hook(self, rank):
+        def fn(ptr, count):
+            host = np.empty(count)
+            assert self.rt.hipMemcpy(host.ctypes.data, ctypes.c_void_p(int(ptr)), count * 8, 2) == 0
+            self.parts[rank] = host
+            self.barrier.wait()
+            total = self.parts[0].copy()
+            for r in range(1, self.n):
+                total += self.parts[r]
+            self.barrier.wait()
+            assert self.rt.hipMemcpy(ctypes.c_void_p(int(ptr)), total.ctypes.data, count * 8, 1) == 0
+            self.calls[rank] += 1
+        return fn
+
+
+def test_c4_1e8_particles_as_eight_shards_equal_one_context_and_the_oracle_subsample():
+    """BASELINE configs[3] on one GPU: 10^8 particles sharded by index range over eight contexts (replicated
+    meteo grids, no exchange in the step, gridded output summed over the shards), against one context with all
+    10^8 particles.  Positions: identical bits (random numbers follow the global index).  Gridded output: counts
+    exact, sums to 1e-13 (eight partial sums instead of one serial sum)."""
+    world, n_shard, n_steps = 8, 12_500_000, 20
+    n = world * n_shard
+    ctl, clim, met0, met1, atm = _c3_inputs(n)
+    one = hip.Simulation(ctl, clim, met0, met1, atm)
+    one.timesteps_init(0.0, 0.0)
+    dt = one.ctl.dt_mod
+    one.run_timestep(0.0)
+    one.run_timesteps(dt, n_steps)
+    ref = one.state()
+    ref_cnt, ref_mean, ref_sig = one.grid_sums(n_steps * dt)
+    ctr = one.get_cache()["rng_ctr"]
+    one.close()
+    assert np.all(ref["time"] == n_steps * dt) and np.all(np.isfinite(ref["p"]))
+
+    pick = np.sort(np.random.default_rng(4).choice(n, 4000, replace=False))
+    pick[0], pick[-1] = 0, n - 1
+    o = _oracle_on_subsample(ctl, clim, met0, met1, _take(atm, pick), pick, n, n_steps)
+    assert o.cache.rng_ctr == ctr
+    for k, r in (("lon", o.lon), ("lat", o.lat), ("p", o.p)):
+        assert cases.rel_err(ref[k][pick], r) <= TOL, k
+    assert np.array_equal(ref["uvwp"][pick], o.uvwp)
+
+    ar = _ThreadAllreduce(world)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            lo, hi = hip.shard_range(n, rank, world)
+            s = hip.Simulation(ctl, clim, met0, met1, atm, shard=(lo, hi))
+            s.set_allreduce(ar.hook(rank))
+            s.timesteps_init(0.0, 0.0)
+            s.run_timestep(0.0)
+            s.run_timesteps(dt, n_steps)
+            g = s.state()
+            out = s.grid_sums(n_steps * dt)
+            results[rank] = (lo, hi, g, out)
+            s.close()
+        except BaseException as exc:      # noqa: BLE001  (a dead rank must not leave the others at the barrier)
+            errors.append((rank, repr(exc)))
+            ar.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert ar.calls == [1] * world          # one exchange: counts and sums travel in one buffer of doubles
+    for rank in range(world):
+        lo, hi, g, (cnt, mean, sig) = results[rank]
+        for k in ("time", "lon", "lat", "p"):
+            assert np.array_equal(g[k], ref[k][lo:hi]), (rank, k)
+        assert np.array_equal(g["uvwp"], ref["uvwp"][lo:hi]), rank
+        assert np.array_equal(g["q"], ref["q"][:, lo:hi]), rank
+        assert np.array_equal(cnt, ref_cnt), rank                      # every rank holds the reduced output
+        assert int(cnt.sum()) == int(ref_cnt.sum()) > 0.99 * n
+        assert cases.rel_err_strict(mean, ref_mean, floor=1e-30) <= 1e-13
+        assert cases.rel_err_strict(sig, ref_sig, floor=1e-30) <= 1e-13
+
+
+def _device_count():
+    rt = ctypes.CDLL("libamdhip64.so")
+    n = ctypes.c_int(0)
+    return n.value if rt.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+
+
+RCCL_WORKER = r"""
+import os, sys
+sys.path[:0] = [%(root)r, %(here)r]
+import numpy as np
+import torch
+import cases
+from mptrac_amd import dist as mdist, hip
+from oracle import binding as B
+
+rank, local_rank, world = mdist.env_rank_world()
+torch.cuda.set_device(local_rank)
+d = mdist.init_process_group("nccl")
+n = 40003
+ctl, clim, m0, m1, atm = cases.make_case("full", n=n)
+ctl["sort_dt"] = -999.0            # module_sort under sharding orders each shard (documented deviation)
+lo, hi = hip.shard_range(n, rank, world)
+s = hip.Simulation(ctl, clim, m0, m1, atm, device=local_rank, shard=(lo, hi))
+mdist.init_rccl(s, d)
+assert s.comm_query() == (world, rank), s.comm_query()
+s.timesteps_init(0.0, 0.0)
+# the same run in ONE context on this rank's own GPU, and the oracle
+one = hip.Simulation(ctl, clim, m0, m1, atm, device=local_rank)
+one.timesteps_init(0.0, 0.0)
+o = B.Oracle(ctl, clim, m0, m1, atm)
+o.timesteps_init()
+ts = cases.step_times(o.ctl)[:9]
+for t in ts:
+    s.run_timestep(t)
+    one.run_timestep(t)
+    o.run_timestep(t)
+g, h, r = s.state(), one.state(), o.state()
+for k in ("time", "lon", "lat", "p", "uvwp"):          # shard-invariant bits: nothing stochastic depends on the sharding
+    assert np.array_equal(g[k], h[k][lo:hi]), k
+# quantities pass through module_mixing: N partial sums instead of one serial sum
+assert cases.q_rows_err(o.ctl, g["q"], h["q"][:, lo:hi])[0] <= 1e-13
+for k in ("lon", "lat", "p"):
+    assert cases.rel_err(g[k], r[k][lo:hi]) <= 1e-10, k
+assert cases.q_rows_err(o.ctl, g["q"], r["q"][:, lo:hi])[0] <= 1e-10
+assert np.abs(g["q"][0] - atm["q"][0][lo:hi]).max() > 1e-6          # mixing + decay did something
+cnt, mean, sig = s.grid_sums(ts[-1])
+co, mo, so = o.grid_sums(ts[-1])
+assert np.array_equal(cnt, co) and cases.rel_err(mean, mo) <= 1e-12
+d.barrier()
+print("rank", rank, "of", world, "ok rccl_ranks", s.comm_query()[0], flush=True)
+s.close(); one.close()
+d.destroy_process_group()
+"""
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_rccl_ranks_on_every_visible_gpu(tmp_path):
+    """N = min(8, visible GPUs) processes, one per GPU, the library's RCCL communicator over xGMI: the in-step
+    exchange of module_mixing and the gridded-output reduction against the one-context run (identical positions,
+    quantities to 1e-13) and the oracle.  A one-GPU box cannot run it (RCCL wants one device per rank)."""
+    ndev = _device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} GPU visible: an N > 1 RCCL run needs one device per rank")
+    world = min(8, ndev)
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % {"root": ROOT, "here": HERE})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900).stdout.decode()
+    for rank in range(world):
+        assert f"rank {rank} of {world} ok rccl_ranks {world}" in out, out[-4000:]
+
+
+def test_bench_line_on_every_visible_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), at a reduced
+    particle count: the line reports the communicator's own rank count."""
+    ndev = _device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} GPU visible")
+    world = min(8, ndev)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "10", "--warmup", "2",
+                          "--particles", "1e6"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stderr.decode()[-4000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["config"]["rccl_ranks"] == world
+    assert line["config"]["particles_total"] == world * 10 ** 6 and line["value"] > 0
+    assert len(line["roofline"]["kernel_ms_per_rank"]) == world

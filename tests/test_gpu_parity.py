@@ -13,6 +13,7 @@ import pytest
 
 import cases
 from mptrac_amd import hip
+from mptrac_amd.ctl import ctl_from_quantities
 from mptrac_amd.synth import synthetic_met, synthetic_particles
 from oracle import binding as B
 
@@ -1371,6 +1372,36 @@ def test_model_levels_with_a_non_monotonic_height_column(case, field):
     for t in cases.step_times(o.ctl)[:8]:
         o.run_timestep(t)
         s.run_timestep(t)
+    _compare(o, s)
+    s.close()
+
+
+@pytest.mark.parametrize("model_levels", [23, 137])
+@pytest.mark.parametrize("case", ["zeta_full", "mlp_full"])
+def test_model_level_count_differs_from_the_pressure_levels(case, model_levels):
+    """met_t::npl (model levels) is independent of met_t::np (pressure levels, mptrac.h:3856-3862): fewer and many
+    more model levels than the 60 pressure levels of the grid, single steps and steps that share a launch."""
+    ctl = dict(cases.CASES[case])
+    names = cases.QUANTITIES_ML
+    ctl.update(ctl_from_quantities(names))
+    fields = cases.PRESSURE_LEVEL_FIELDS + ("pl", "ul", "vl", "wl", "zetal", "zeta_dotl")
+    m0 = synthetic_met("C1", 0.0, 1.0, fields=fields, model_levels=model_levels)
+    m1 = synthetic_met("C1", 3600.0, 1.25, fields=fields, model_levels=model_levels)
+    assert m0.npl == model_levels != m0.np
+    atm = synthetic_particles(6000, seed=5, quantities=names)
+    for name_q in ("zeta", "eta"):
+        atm["q"][list(names).index(name_q)] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
+    clim = cases.load_clim_tropo()
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, m0, m1, atm)
+    s.timesteps_init(0.0, 0.0)
+    ts = cases.step_times(o.ctl)
+    for t in ts[:10]:
+        o.run_timestep(t)
+    for t in ts[:3]:
+        s.run_timestep(t)
+    s.run_timesteps(ts[3], 7)
     _compare(o, s)
     s.close()
 

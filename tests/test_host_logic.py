@@ -109,6 +109,32 @@ def test_oracle_scheduler_equals_module_sequence():
         assert np.array_equal(v, b.state()[k]), k
 
 
+@pytest.mark.parametrize("n", [3001, 3000])
+def test_oracle_subsample_draws_the_full_runs_random_numbers(n):
+    """Subsample mode of the oracle (orc_cache_t::ip_global): a few particles of a large run get the random
+    numbers the full run binds to their slots, rs[3 * ip + k] (mptrac.c:4645-4647; flat Box-Muller pairs,
+    mptrac.c:5820-5826 -- with an odd particle count the last pair reaches the extra uniform of mptrac.c:5797),
+    and the counter advances as in the full run.  The picked particles of a full oracle run and the subsample
+    run agree in every bit, in any order of the list."""
+    ctl, clim, m0, m1, atm = cases.make_case("conv_sedi", n=n, grid="tiny")
+    full = B.Oracle(ctl, clim, m0, m1, atm)
+    pick = np.random.default_rng(7).choice(n, 257, replace=False)
+    pick[:3] = (n - 1, 0, n - 2)
+    sub_atm = {k: (v[pick].copy() if k != "q" else v[:, pick].copy()) for k, v in atm.items()}
+    sub = B.Oracle(ctl, clim, m0, m1, sub_atm, ip_global=pick, np_global=n)
+    full.timesteps_init()
+    sub.timesteps_init()
+    for t in cases.step_times(full.ctl)[:6]:
+        full.run_timestep(t)
+        sub.run_timestep(t)
+    assert sub.cache.rng_ctr == full.cache.rng_ctr
+    f, g = full.state(), sub.state()
+    for k in ("time", "lon", "lat", "p", "uvwp"):
+        assert np.array_equal(f[k][pick], g[k]), k
+    assert np.array_equal(f["q"][:, pick], g["q"])
+    assert np.abs(g["uvwp"]).max() > 0
+
+
 def test_grid_sums_are_additive_over_index_shards():
     """What the RCCL all-reduce relies on: per-shard sums add up to the global
     sums (counts exactly)."""

@@ -3,7 +3,9 @@
 wind records (the limit of the lean kernels' 32-bit offsets is 4.29 GB).  C3's modules (RK4, turbulent + mesoscale diffusion,
 convection, sedimentation), 10^5 particles, one single step + six steps that share a launch + three single steps, against
 the oracle.  The library takes the kBigGrid instantiations by itself (no option).  About 10 GB of host memory.
-  python tools/gpu_big_grid.py zeta     the same with winds from the model levels (zeta coordinate; about 25 GB)"""
+  python tools/gpu_big_grid.py zeta     the same with winds from the model levels (zeta coordinate; about 25 GB)
+  python tools/gpu_big_grid.py zeta27   27 pressure levels (0.63 GiB of records: 32-bit offsets would do) under 180 model
+                                        levels (4.18 GiB): the size tests must follow the model levels (met_t::npl > met_t::np)"""
 import os
 import sys
 import time
@@ -19,19 +21,23 @@ from mptrac_amd.ctl import ctl_from_quantities  # noqa: E402
 from mptrac_amd.synth import synthetic_met, synthetic_particles  # noqa: E402
 from oracle import binding as B  # noqa: E402
 
-GRID = (1440, 721, 180)
-cells = (GRID[0] + 1) * GRID[1] * GRID[2]
+few = "zeta27" in sys.argv[1:]
+GRID = (1440, 721, 27 if few else 180)
+ML = 180
+cells = (GRID[0] + 1) * GRID[1] * (ML if few else GRID[2])
 print(f"grid {GRID[0] + 1} x {GRID[1]} x {GRID[2]} = {cells / 1e6:.1f}e6 cells, wind records {24 * cells / 2 ** 30:.2f} GiB "
       f"(32-bit offsets reach 4.00 GiB)", flush=True)
 assert 24 * cells >= 2 ** 32
-zeta = "zeta" in sys.argv[1:]
+zeta = few or "zeta" in sys.argv[1:]
 names = ("m", "rp", "rhop", "zeta") if zeta else ("m", "rp", "rhop")
 ctl = dict(cases.CASES["zeta_full" if zeta else "conv_sedi"])
 ctl.update(ctl_from_quantities(names))
 fields = ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel") + (("pl", "ul", "vl", "zetal", "zeta_dotl") if zeta else ())
 t0 = time.time()
-m0 = synthetic_met(GRID, 0.0, 1.0, fields=fields)
-m1 = synthetic_met(GRID, 3600.0, 1.25, fields=fields)
+m0 = synthetic_met(GRID, 0.0, 1.0, fields=fields, model_levels=ML if few else None)
+m1 = synthetic_met(GRID, 3600.0, 1.25, fields=fields, model_levels=ML if few else None)
+if few:
+    assert m0.npl == ML and m0.np == 27 and 24 * m0.nx * m0.ny * m0.np < 2 ** 32
 print(f"two synthetic snapshots in {time.time() - t0:.0f} s", flush=True)
 atm = synthetic_particles(100000, seed=11, quantities=names)
 if zeta:      # a vertical coordinate inside the range of the synthetic zetal field (as cases.make_case)
