@@ -47,6 +47,11 @@ WORKLOADS = {
     "C3m": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1),
             ("m", "rp", "rhop", "t", "u", "v", "w", "zg", "pv", "ps", "pt"),
             ("u", "v", "w", "t", "ps", "pbl", "cape", "cin", "pel", "z", "pv", "pt")),
+    # C3 with the closure inside the boundary layer (TURB_PBL_SCHEME 1: module_diff_pbl) on top; the
+    # mesoscale part stays horizontal (the closure keeps uvwp[2] in m/s, module_diff_meso in hPa/s: with both vertical
+    # parts the reference itself drives pressures negative, tests/cases.py)
+    "C3p": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1, turb_pbl_scheme=1, turb_mesoz=0.0),
+            ("m", "rp", "rhop"), ("u", "v", "w", "t", "h2o", "ps", "pbl", "cape", "cin", "pel", "ess", "nss", "shf")),
     # BASELINE configs[4] / SURVEY C5: C3 + module_sort and inter-parcel mixing every step, decay, wet and dry
     # deposition (per-GPU part; the survey's control line)
     "C5": ("C3", 10 ** 7, dict(advect=4, dt_mod=180.0, diffusion=1, conv_cape=0.0, rng_type=1, sort_dt=180.0,
@@ -83,7 +88,7 @@ def algorithmic_bytes_per_pstep(workload, met, np_local):
     step can touch, once per launch."""
     state = {"C3": 64 + 24 + 16,   # time,lon,lat,p R+W; uvwp R+W; rp,rhop R
              "C3m": 64 + 24 + 16,  # (the step kernel's bytes; module_meteo is a separate kernel)
-             "C3d": 64 + 24 + 16,
+             "C3d": 64 + 24 + 16, "C3p": 64 + 24 + 16,
              "C5": 64 + 24 + 16 + 16, "C3x": 64 + 24 + 16 + 16, "C5n": 64 + 24 + 16 + 16,
              "C3z": 64 + 24 + 16 + 16,
              "C2": 64, "C1": 64}[workload]
@@ -117,6 +122,43 @@ def build_inputs(workload, rank, world, steps_total, particles=None):
     if "zeta" in quantities:      # a vertical coordinate inside the range of the synthetic zetal field
         atm["q"][list(quantities).index("zeta")] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
     return ctl, load_clim_tropo(), met0, met1, atm, n_per_gpu, n_total
+
+
+# What pins the oracle each module is checked against (tests/test_oracle_pins.py, tests/test_gpu_parity.py).
+# "reference": an artefact the reference's own tests hold is reproduced digit for digit through this module;
+# "restatement": no such artefact exists here (the reference's meteo files for them are not in the tree and the
+# reference cannot be built in this image) -- the HIP path is checked against a line-by-line restatement only.
+PARITY_PINS = {
+    "pinned_by_reference_goldens": [
+        "module_advect ADVECT 2 (dd_test, coord_test)", "module_position", "module_timesteps",
+        "module_diff_turb horizontal branch (coord_test)", "module_diff_meso (coord_test)",
+        "module_rng Squares + Box-Muller (coord_test, known-answer values)", "module_decay bookkeeping (dd_test)",
+        "sedi() (tools_test sedi.tab)", "intpol_met_* 2-D / 3-D / time (coord_test)", "write_grid (atm_test, dt_test, trac_test grids)",
+        "module_meteo t, u, v, w (coord_test), humidity macros (met_test)", "clim_tropo, locate_* (known-answer values)"],
+    "restatement_only": [
+        "module_advect ADVECT 4 (RK4: the headline integrator; old-latitude rule mptrac.c:3672 by review)",
+        "module_diff_turb vertical branch", "module_convection", "module_sedi inside a run", "module_mixing",
+        "module_wet_depo", "module_dry_depo", "model-level advection (intpol_met_4d_zeta)", "module_diff_pbl",
+        "module_isosurf", "module_bound_cond", "module_sort tie order (stable by index; GSL's is unspecified)"],
+}
+
+
+def alu_roof(workload, n_local, kernel_ms):
+    """"state both bounds honestly".  The fused step is bound by VALU issue, not by HBM: per-instruction
+    issue costs of gfx950 measured with the SIMDs full (tools/micro/valu_issue.hip -> profiles/r04_valu_issue.txt)
+    x the dynamic instruction mix of the kernel (rocprofv3 SQ_INSTS_VALU_* -> profiles/*_instruction_mix.txt) give
+    the cycles one wave needs per particle-step; every SIMD of the 256 CUs works through n / 64 / 1024 waves."""
+    f = os.path.join(ROOT, "profiles", "alu_model.json")
+    if not os.path.exists(f):
+        return None
+    m = json.load(open(f)).get(workload)
+    if not m:
+        return None
+    wave_steps_per_simd = n_local / 64.0 / 1024.0
+    model_ms = m["cycles_per_wave_step"] * wave_steps_per_simd / (m["sustained_clock_ghz"] * 1e9) * 1e3
+    return {"bound": "valu_issue", "model_ms_per_step": model_ms, "frac_alu": model_ms / kernel_ms if kernel_ms else None,
+            "cycles_per_wave_step": m["cycles_per_wave_step"], "valu_insts_per_64_particle_steps": m["valu_insts_per_64_particle_steps"],
+            "sustained_clock_ghz": m["sustained_clock_ghz"], "source": m["source"]}
 
 
 def cpu_model():
@@ -478,7 +520,17 @@ def main():
                          "bytes_per_particle_step": a_per,
                          # SURVEY 8(d) caveat: the fused step is fp64-VALU-bound, not HBM-bound; share of SIMD
                          # cycles executing VALU instructions from the committed rocprofv3 PMC profile
-                         "valu_busy_frac": valu_busy, "fp64_valu_frac": fp64_frac, "build_id": build_id()},
+                         "valu_busy_frac": valu_busy, "fp64_valu_frac": fp64_frac, "build_id": build_id(),
+                         # `achieved` / `frac` price SURVEY 8(d)'s ALGORITHMIC bytes per particle-step against the kernel's
+                         # time per step.  A launch that takes several steps per particle keeps the particle and most
+                         # of its meteo lines on the chip between them and moves fewer bytes than that (`traffic`):
+                         # the figure is an algorithmic throughput on the HBM scale, not a measured HBM share.  The
+                         # same pricing with one launch per step:
+                         "frac_one_launch_per_step": (bytes_per_launch / (single_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if single_ms else None,
+                         "basis": "algorithmic bytes per particle-step (SURVEY 8d) / kernel time per step",
+                         # the bound that actually holds: VALU issue (modelled from measured per-instruction costs)
+                         "alu": alu_roof(args.workload, n_local, kernel_ms_per_step) if not args.particles else None},
+            "parity": PARITY_PINS,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, ctl, clim, met0, met1, atm,

@@ -276,8 +276,9 @@ int mphip_run_timestep(mphip_ctx *ctx, double t);
  * convection, sedimentation, with the loss / decay / deposition modules and boundary conditions, on pressure and on
  * model levels.  A step at which module_sort, module_mixing or (CONV_DT > 0) module_convection is due runs on its own
  * and a batch ends before it; module_meteo is deferred as in mphip_run_timestep, so a batch ends only behind a step that
- * schedules it when the next one does not.  Single steps throughout: the first step (t == T_START), ISOSURF,
- * TURB_PBL_SCHEME 1, ADVECT 0, the options "generic_kernel" / "split_step". */
+ * schedules it when the next one does not.  module_isosurf and the boundary-layer closure (TURB_PBL_SCHEME 1) share
+ * launches on pressure-level winds.  Single steps throughout: the first step (t == T_START), ADVECT 0, ISOSURF or
+ * TURB_PBL_SCHEME 1 with winds from the model levels, the option "generic_kernel". */
 int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps);
 /* One reference module_* on its own (same state hand-over through the device
  * copy of cache->dt); `modules` is one MPHIP_MOD_* bit or an OR of the

@@ -75,7 +75,12 @@ def verify_async_loads(lib, verbose=False):
     load_wind_cached / wind_cache_wait); a library in which the compiler touched such a register before
     the wait would compute with stale data, so it is not kept."""
     from . import check_async_loads as chk
-    hazards, kernels, nloads = chk.check(lib)
+    try:
+        hazards, kernels, nloads = chk.check(lib)
+    except chk.ToolMissing as exc:      # (a box without the LLVM tools: a prebuilt library was checked where it was built)
+        if verbose:
+            print(f"machine-code check skipped: {exc}")
+        return
     if hazards:
         bad = lib + ".rejected"
         os.replace(lib, bad)

@@ -26,7 +26,7 @@ constexpr unsigned kAdvTurb = kAdv | MPHIP_MOD_DIFF_TURB;
 constexpr unsigned kAdvDiff = kAdvTurb | MPHIP_MOD_DIFF_MESO;
 constexpr unsigned kAdvTurbConvSedi = kAdvTurb | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kAdvDiffConvSedi = kAdvDiff | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
-// second launch of a split time step (option split_step): everything behind module_advect, dt from memory
+// every mover behind module_advect, dt from memory (single-module sequences of a caller)
 constexpr unsigned kDiffConvSediOnly = MPHIP_MOD_TIMESTEPS | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_CONVECTION
   | MPHIP_MOD_SEDI | MPHIP_MOD_POSITION2;
 constexpr unsigned kTailOnly = MPHIP_MOD_TIMESTEPS;   // no mover: a launch of loss / decay / deposition modules only
@@ -158,7 +158,6 @@ struct mphip_ctx {
   int step_blocks = 8192;             // upper bound of the step kernel's grid
   int step_blocks_multi = 32768;       // ... of a multi-step launch (mphip_run_timesteps)
   int xcd_map = 1;
-  int split_step = 0;                 // experiment: advection and the modules behind it as two launches
   int big_grid = 0;                   // option "big_grid": take the 64-bit-offset (kBigGrid) instantiations on a grid that fits 32 bits too (tests)
   int perm_records = 1;               // random permutations of the particle arrays through records (permute_random)
   void *d_prec = nullptr;             // ... their buffer
@@ -823,6 +822,12 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
       sel = req | kMLWinds | (nsteps > 1 ? kMultiStep : 0u);
     else if ((req & ~kOptionalModules) == kAdv)   // (subsets, every set with module_bound_cond, and every set of a big grid)
       sel = kAdvDiffConvSedi | kGated | kMLWinds | (big_ok ? kBigGrid : 0u) | (nsteps > 1 ? kMultiStep : 0u);
+  } else if (!(rare_bits & ~(kBound | MPHIP_MOD_DIFF_PBL | MPHIP_MOD_ISOSURF)) && (mask & (MPHIP_MOD_DIFF_PBL | MPHIP_MOD_ISOSURF)) && !ml_
+             && !ctx->force_generic && lean_ok) {
+    // the closure inside the boundary layer (TURB_PBL_SCHEME 1) and module_isosurf: gated instantiations of their own
+    const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound | MPHIP_MOD_DIFF_PBL | MPHIP_MOD_ISOSURF);
+    if ((req & ~kOptionalModules) == kAdv)
+      sel = kAdvDiffConvSedi | kGated | kPblClosure | scheme | (nsteps > 1 ? kMultiStep : 0u);
   } else if (!(rare_bits & ~kBound) && !ml_ && !ctx->force_generic && lean_ok) {
     const unsigned req = (mask | MPHIP_MOD_TIMESTEPS) & ~(kStoreDt | kTailModules | kBound);
     // (kAdvTurbConvSedi has a kernel of its own for single steps only: several steps per launch take the gated one)
@@ -889,6 +894,10 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiffConvSedi | kTwoStage | kMultiStep)
     STEP_CASE(kAdvDiffConvSedi | kGated | kMultiStep)
     STEP_CASE(kAdvDiffConvSedi | kGated | kTwoStage | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kPblClosure)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kPblClosure | kTwoStage)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kPblClosure | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kGated | kPblClosure | kTwoStage | kMultiStep)
     STEP_CASE(kAdvDiffConvSedi | kGated | kBigGrid)
     STEP_CASE(kAdvDiffConvSedi | kGated | kBigGrid | kTwoStage)
     STEP_CASE(kAdvDiffConvSedi | kGated | kBigGrid | kMultiStep)
@@ -2775,13 +2784,7 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   const bool sort_next = ctx->sort_ahead && ctx->np > 0 && ctx->ext_identity && c.sort_dt > 0
     && fmod(t_next, c.sort_dt) == 0 && c.direction * (t_next - c.t_stop) <= 0;
   if (!mixing_now) {
-    constexpr unsigned kFirst = MPHIP_MOD_TIMESTEPS | MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT;
-    if (ctx->split_step && (mask & ~kFirst & ~kTailModules) == (kDiffConvSediOnly & ~MPHIP_MOD_TIMESTEPS)
-        && (mask & kFirst) == kFirst) {
-      if (launch_step(ctx, (mask & kFirst) | MPHIP_MOD_POSITION2 | kStoreDt, t, 0, 0, 0)
-          || launch_step(ctx, (mask & ~kFirst) | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
-        return 1;
-    } else if (launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
+    if (launch_step(ctx, mask | tail, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
       return 1;
     if (sort_next && ahead_launch(ctx, t_next))
       return 1;
@@ -2844,11 +2847,9 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
         || (conv_on && c.conv_dt > 0 && fmod(tt, c.conv_dt) == 0);
     };
     const bool quiet = ctx->multi_step && ctx->np > 0 && t != c.t_start && !scheduled(t)
-      && !(c.isosurf >= 1 && c.isosurf <= 4)
-      && !(c.diffusion && c.turb_pbl_scheme == 1)
       && c.advect > 0   // (every integrator has its multi-step instantiations; without module_advect: single steps)
       && !ctx->fused_perm
-      && !ctx->force_generic && !ctx->split_step;
+      && !ctx->force_generic;
     if (quiet) {
       batch = nsteps - done;
       if (ctx->locality_interval > 0)
@@ -2879,12 +2880,17 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t n = (uint64_t) ctx->np_total;
     unsigned mask = MPHIP_MOD_TIMESTEPS | MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_POSITION2;
-    uint64_t per_step = 0, off_turb = 0, off_meso = 0, off_conv = 0;
+    uint64_t per_step = 0, off_turb = 0, off_meso = 0, off_conv = 0, off_pbl = 0;
     if (c.diffusion
         && (c.turb_dx_pbl > 0 || c.turb_dz_pbl > 0 || c.turb_dx_trop > 0 || c.turb_dz_trop > 0 || c.turb_dx_strat > 0
             || c.turb_dz_strat > 0)) {
       mask |= MPHIP_MOD_DIFF_TURB;
       off_turb = per_step;
+      per_step += 3 * n + 1;
+    }
+    const bool pbl_closure = c.diffusion && c.turb_pbl_scheme == 1;
+    if (pbl_closure) {     // (between module_diff_turb and module_diff_meso, mptrac.c:7893-7901)
+      off_pbl = per_step;
       per_step += 3 * n + 1;
     }
     if (c.diffusion && (c.turb_mesox > 0 || c.turb_mesoz > 0)) {
@@ -2911,6 +2917,14 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
     const bool bound = c.bound_lat0 < c.bound_lat1 && c.bound_p0 > c.bound_p1;
     const bool exact = ml_winds ? ctx->pk.ml_monotonic && ctx->nml <= kLockstepMaxLevels && ctx->d_kz != nullptr && (!bound || lean_ok)
                                 : lean_ok && (movers & ~kOptionalModules) == kAdv;   // (exact sets: their own kernels; subsets: the gated one)
+    // the closure inside the boundary layer has lean instantiations for pressure-level winds on grids within 32-bit
+    // offsets; anything else with it takes the general kernel, one step per launch
+    const bool isosurf = c.isosurf >= 1 && c.isosurf <= 4;     // (module_isosurf: the same instantiations)
+    const bool closure_ok = !(pbl_closure || isosurf) || (!ml_winds && lean32_ok(ctx));
+    if (pbl_closure)
+      mask |= MPHIP_MOD_DIFF_PBL;
+    if (isosurf)
+      mask |= MPHIP_MOD_ISOSURF;
     if (bound)
       mask |= MPHIP_MOD_BOUND_COND | MPHIP_MOD_BOUND_COND2;
     if (c.qnt_loss_rate >= 0)
@@ -2921,7 +2935,7 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
       mask |= MPHIP_MOD_WET_DEPO;
     if (c.dry_depo_vdep > 0)
       mask |= MPHIP_MOD_DRY_DEPO;
-    if (!exact) {     // no multi-step instantiation of this module set
+    if (!exact || !closure_ok) {     // no multi-step instantiation of this module set
       if (mphip_run_timestep(ctx, t))
         return 1;
       t += stride;
@@ -2934,8 +2948,8 @@ int mphip_run_timesteps(mphip_ctx *ctx, double t_first, int nsteps) {
       ctx->meteo_pending = false;
     else if (flush_meteo(ctx))
       return 1;
-    if (launch_step(ctx, mask, t, ctx->rng_ctr + off_turb, ctx->rng_ctr + off_meso, ctx->rng_ctr + off_conv, 0, batch, stride,
-                    per_step))
+    if (launch_step(ctx, mask, t, ctx->rng_ctr + off_turb, ctx->rng_ctr + off_meso, ctx->rng_ctr + off_conv,
+                    ctx->rng_ctr + off_pbl, batch, stride, per_step))
       return 1;
     ctx->rng_ctr += per_step * (uint64_t) batch;
     if (ctx->steps_since_resort < (1 << 29))
@@ -3230,10 +3244,6 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
   }
   if (strcmp(name, "perm_records") == 0) {
     ctx->perm_records = value != 0;
-    return 0;
-  }
-  if (strcmp(name, "split_step") == 0) {
-    ctx->split_step = value != 0;
     return 0;
   }
   if (strcmp(name, "big_grid") == 0) {

@@ -205,6 +205,17 @@ __device__ __forceinline__ double fdiv(double a, double b) {
 #endif
 }
 
+// 1 / b to an ulp or two (v_rcp_f64 + one Newton step + a residual correction)
+__device__ __forceinline__ double frcp_newton(double b) {
+#if MPHIP_EXACT_DIV
+  return 1.0 / b;
+#else
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+#endif
+}
+
 __device__ __forceinline__ double fsqrt(double x) {
 #if MPHIP_EXACT_DIV
   return sqrt(x);
@@ -2170,157 +2181,6 @@ __device__ __forceinline__ void diff_turb(const mphip_ctl_t &ctl, const DevMet &
   }
 }
 
-// module_diff_pbl, mptrac.c:4357-4583: Hanna / FLEXPART closure inside the
-// boundary layer (TURB_PBL_SCHEME 1)
-__device__ __forceinline__ double clampd(double v, double lo, double hi) {   // CLAMP, mptrac.h:756
-  return v < lo ? lo : (v > hi ? hi : v);
-}
-
-__device__ __forceinline__ double tvirt(double t, double h2o) {   // TVIRT, mptrac.h:2199
-  return t * (1. + (1. - kEps) * dmax(h2o, 0.1e-6));
-}
-
-__device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particle &P, float &up, float &vp,
-                                         float &wp, uint64_t ctr, uint64_t g, const double *ltab) {
-  const int ct = M.coord_type;
-  double dsigw_dz = 0.0, sig_u = 0.0, sig_v = 0.0, sig_w = 0.0, tau_u = 0.0, tau_v = 0.0, tau_w = 0.0;
-  Stencil s = stencil_zero();
-  stencil_2d(M, A, P.lon, P.lat, s);
-  SurfA ca;
-  load_sfa(M, s, ca);
-  const double wt = time_weight(M, P.time);
-  const double pbl = sfa_time_2d(ca, s, wt, 1);
-  if (P.p < pbl)
-    return;
-  const double ps = sfa_time_2d(ca, s, wt, 0);
-  if (!(ps > 0.0 && pbl > 0.0 && ps > pbl))
-    return;
-  const double p = dmin(P.p, ps);
-  const double zs = zfromp(ps);
-  const double z_raw = 1e3 * (zfromp(p) - zs);
-  const double zi = 1e3 * (zfromp(pbl) - zs);
-  if (!(zi > 1.0))
-    return;
-  const double z = clampd(z_raw, 0.0, zi);
-  const double zeta = clampd(z / zi, 1e-6, 1.0 - 1e-6);
-  const double z_m = dmax(z, 1.0);
-
-  SurfB cd;
-  load_sfb(M.sfd, M, s, cd);
-  const double ess = sfb_time_2d(cd, s, wt, 0);
-  const double nss = sfb_time_2d(cd, s, wt, 1);
-  Stencil s3;
-  stencil_3d(M, A, p, P.lon, P.lat, s3);   // at the clamped pressure
-  const double t = temp_time_3d(M, s3, wt);
-  const double h2o = pair_time_3d(M.h2o, M, s3, wt);
-
-  const double tv = tvirt(t, h2o);
-  const double thetav = tvirt(t * pow(1000. / p, kKappa), dmax(h2o, 0.1e-6));   // THETAVIRT, mptrac.h:2153
-  const double rho = rho_air(p, tv);
-  const double tau = sqrt(ess * ess + nss * nss);
-  if (!(rho > 0.0))
-    return;
-  const double ustar = sqrt(dmax(tau / rho, 0.0));
-  const double ust = dmax(1e-4, ustar);
-  const double shf = sfb_time_2d(cd, s, wt, 2);   // INTPOL_2D(shf, 1): same stencil again
-  double ol = 1e12;
-  if (fabs(shf) > 1e-6)
-    ol = thetav * rho * kCpd * (ust * ust) * ust / (kKarman * kG0 * shf);
-
-  if (zi / fabs(ol) < 1.0) {   // neutral
-    const double corr = z_m / ust;
-    const double sigw0 = 1.3 * ust * exp(-2e-4 * corr);
-    sig_u = dmax(2.0 * ust * exp(-3e-4 * corr), 1e-5);
-    sig_v = dmax(sigw0, 1e-5);
-    sig_w = dmax(sigw0, 1e-5);
-    dsigw_dz = -2e-4 * sigw0 / ust;
-    tau_u = 0.5 * z_m / sig_w / (1.0 + 1.5e-3 * corr);
-    tau_v = tau_u;
-    tau_w = tau_u;
-  } else if (ol < 0.0) {       // unstable
-    const double wstar_arg = -kG0 / thetav * shf / (rho * kCpd) * zi;
-    const double wstar = pow(dmax(wstar_arg, 0.0), 1.0 / 3.0);
-    double dsigw2_dz = 0.0;
-    sig_u = dmax(ust * pow(dmax(12.0 - 0.5 * zi / ol, 0.0), 1.0 / 3.0), 1e-6);
-    sig_v = sig_u;
-    if (zeta < 0.03) {
-      const double arg = dmax(3.0 * zeta - ol / zi, 1e-12);
-      sig_w = 0.96 * wstar * pow(arg, 1.0 / 3.0);
-      dsigw2_dz = 1.8432 * (wstar * wstar) / zi * pow(arg, -1.0 / 3.0);
-    } else if (zeta < 0.4) {
-      const double arg = dmax(3.0 * zeta - ol / zi, 1e-12);
-      const double s1 = 0.96 * pow(arg, 1.0 / 3.0);
-      const double s2 = 0.763 * pow(zeta, 0.175);
-      if (s1 < s2) {
-        sig_w = wstar * s1;
-        dsigw2_dz = 1.8432 * (wstar * wstar) / zi * pow(arg, -1.0 / 3.0);
-      } else {
-        sig_w = wstar * s2;
-        dsigw2_dz = 0.203759 * (wstar * wstar) / zi * pow(zeta, -0.65);
-      }
-    } else if (zeta < 0.96) {
-      sig_w = 0.722 * wstar * pow(1.0 - zeta, 0.207);
-      dsigw2_dz = -0.215812 * (wstar * wstar) / zi * pow(1.0 - zeta, -0.586);
-    } else {
-      sig_w = 0.37 * wstar;
-      dsigw2_dz = 0.0;
-    }
-    sig_w = dmax(sig_w, 1e-6);
-    dsigw_dz = sig_w > 1e-12 ? 0.5 * dsigw2_dz / sig_w : 0.0;
-    tau_u = 0.15 * zi / dmax(sig_u, 1e-12);
-    tau_v = tau_u;
-    if (z_m < fabs(ol)) {
-      const double denom = 0.55 - 0.38 * fabs(z_m / ol);
-      tau_w = 0.1 * z_m / (sig_w * dmax(denom, 0.05));
-    } else if (zeta < 0.1)
-      tau_w = 0.59 * z_m / sig_w;
-    else
-      tau_w = 0.15 * zi / sig_w * (1.0 - exp(-5.0 * zeta));
-  } else {                     // stable
-    sig_u = dmax(2.0 * ust * (1.0 - zeta), 1e-6);
-    sig_v = dmax(1.3 * ust * (1.0 - zeta), 1e-6);
-    sig_w = dmax(1.3 * ust * (1.0 - zeta), 1e-6);
-    dsigw_dz = -1.3 * ust / zi;
-    tau_u = 0.15 * zi / sig_u * sqrt(zeta);
-    tau_v = 0.467 * tau_u;
-    tau_w = 0.1 * zi / sig_w * pow(zeta, 0.8);
-  }
-  tau_u = dmax(tau_u, 10.0);
-  tau_v = dmax(tau_v, 10.0);
-  tau_w = dmax(tau_w, 30.0);
-  if (!(sig_u > 0.0 && sig_v > 0.0 && sig_w > 0.0 && tau_u > 0.0 && tau_v > 0.0 && tau_w > 0.0))
-    return;
-
-  double rs0, rs1, rs2;
-  normal_triple(ltab, ctr, g, rs0, rs1, rs2);
-  const double dt = P.dt, dt_abs = fabs(P.dt);
-  const double ru = exp(-dt_abs / tau_u);
-  const double ru2 = sqrt(dmax(0.0, 1.0 - ru * ru));
-  const double rv = exp(-dt_abs / tau_v);
-  const double rv2 = sqrt(dmax(0.0, 1.0 - rv * rv));
-  up = (float) (up * ru + sig_u * ru2 * rs0);
-  vp = (float) (vp * rv + sig_v * rv2 * rs1);
-  const double rw = exp(-dt_abs / tau_w);
-  const double rw2 = sqrt(dmax(0.0, 1.0 - rw * rw));
-  const double rhoaux = -1.0 / (1e3 * kH0);
-  wp = (float) (wp * rw + sig_w * rw2 * rs2 + tau_w * (1.0 - rw) * (2.0 * sig_w * dsigw_dz + rhoaux * (sig_w * sig_w)));
-  P.lon += dx2coord(ct, up * dt, P.lat);
-  P.lat += dy2coord(ct, vp * dt);
-  double znew = z + wp * dt;
-  while (znew < 0.0 || znew > zi) {
-    if (znew < 0.0) {
-      znew = -znew;
-      wp = -wp;
-    }
-    if (znew > zi) {
-      znew = 2.0 * zi - znew;
-      wp = -wp;
-    }
-  }
-  P.p = kP0 * exp(-(zs + znew / 1000.0) / kH0);   // P(z), mptrac.h:1784
-  P.p = clampd(P.p, pbl, ps);
-}
-
 // temporal correlation of module_diff_meso (mptrac.c:4310-4311): from the host for the regular time step
 __device__ __forceinline__ void meso_coeffs(const mphip_ctl_t &ctl, const DevMet &M, double dt, double &r, double &r2) {
   if (fabs(dt) == M.meso_dt) {
@@ -3194,6 +3054,255 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
     const double v_s = sedi(P.p, t, rp, rhop);
     P.p += dz2dp(v_s * P.dt * 1e-3, P.p);
   }
+}
+
+// ---- module_diff_pbl (mptrac.c:4343-4584; TURB_PBL_SCHEME 1) ------------------------------------------------------
+// Langevin turbulence inside the boundary layer with Hanna's (1982) profiles in the form FLEXPART uses them.  Per
+// particle below the boundary-layer top the module needs
+//   (1) the layer in metres above ground: its depth, the particle's height and relative height (PblLayer);
+//   (2) the surface-layer scales from the stresses and the heat flux: friction velocity, Obukhov length and, for a
+//       convective layer, the convective velocity (PblScales);
+//   (3) standard deviations and Lagrangian time scales of the three velocity components for one of three stability
+//       classes (PblTurbulence);
+//   (4) one Ornstein-Uhlenbeck step of the three perturbations with the drift correction of the vertical one, the
+//       displacement, and mirror reflections at the ground and at the layer top.
+// Laid out for a wave whose lanes sit at different heights and over different surfaces: the classes are three
+// functions that fill one record; powers of a common base share one logarithm and cube roots are cbrt; the piecewise
+// vertical profile of the convective class is a choice of (base, exponents, factors) followed by ONE evaluation
+// instead of a ladder of branches with a pow pair in each, and its two candidates near the ground are compared in
+// logarithms; a particle above every boundary-layer top of the two snapshots (DevMet::turb_skip, exact: a blend with
+// weights in [0, 1] is not below its smallest corner) leaves without a gather.
+__device__ __forceinline__ double clampd(double v, double lo, double hi) {   // CLAMP, mptrac.h:756
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+__device__ __forceinline__ double tvirt(double t, double h2o) {   // TVIRT, mptrac.h:2199
+  return t * (1. + (1. - kEps) * dmax(h2o, 0.1e-6));
+}
+
+struct PblLayer {
+  double depth;   // boundary-layer depth [m]
+  double h;       // height above ground inside [0, depth] [m]
+  double h1;      // ... but at least one metre
+  double eta;     // h / depth inside [1e-6, 1 - 1e-6]
+  double log_eta;
+};
+
+struct PblScales {
+  double ustar;     // friction velocity, at least 1e-4 m/s
+  double obukhov;   // Obukhov length [m]; 1e12 without a heat flux
+  double wstar;     // convective velocity scale [m/s] (convective class only)
+};
+
+struct PblTurbulence {   // component 0 / 1 / 2: along x, along y, vertical
+  double sigma[3];       // standard deviations [m/s]
+  double tl[3];          // Lagrangian time scales [s]
+  double dsigma_w;       // d sigma_w / dz [1/s]
+};
+
+// mptrac.c:4439-4449
+__device__ __forceinline__ void hanna_neutral(const PblLayer &L, const PblScales &K, PblTurbulence &T) {
+  const double x = fdiv(L.h1, K.ustar);
+  const double sw = 1.3 * K.ustar * exp(-2e-4 * x);
+  T.sigma[0] = dmax(2.0 * K.ustar * exp(-3e-4 * x), 1e-5);
+  T.sigma[1] = T.sigma[2] = dmax(sw, 1e-5);
+  T.dsigma_w = -2e-4 * x * fdiv(sw, L.h1);        // -2e-4 sw / u* with 1 / u* = x / h1
+  T.tl[0] = T.tl[1] = T.tl[2] = fdiv(0.5 * L.h1, T.sigma[2] * (1.0 + 1.5e-3 * x));
+}
+
+// mptrac.c:4451-4510.  sigma_w / w* over the relative height eta is piecewise c B^e:
+//   eta < 0.03, and up to 0.4 while it is the smaller one:  0.96  (3 eta - L / D)^(1/3)    "free convection"
+//   otherwise up to 0.4:                                    0.763 eta^0.175
+//   up to 0.96:                                             0.722 (1 - eta)^0.207
+//   above:                                                  0.37
+// and D / w*^2 d(sigma_w^2)/dz has the same shape with (1.8432, -1/3), (0.203759, -0.65), (-0.215812, -0.586), 0.
+__device__ __forceinline__ void hanna_convective(const PblLayer &L, const PblScales &K, PblTurbulence &T) {
+  const double third = 1.0 / 3.0;
+  const double l_over_d = fdiv(K.obukhov, L.depth);          // (negative)
+  T.sigma[0] = T.sigma[1] = dmax(K.ustar * cbrt(dmax(12.0 - fdiv(0.5, l_over_d), 0.0)), 1e-6);
+  const double log_free = log(dmax(3.0 * L.eta - l_over_d, 1e-12));
+  // log(0.96), log(0.763): the two candidates below eta = 0.4 compared without evaluating them
+  const bool free_smaller = -0.040821994520255166 + third * log_free < -0.27049724769768 + 0.175 * L.log_eta;
+  const bool free = (L.eta < 0.03) | ((L.eta < 0.4) & free_smaller);
+  const bool low = L.eta < 0.4, mid = L.eta < 0.96;
+  const double lb = low ? (free ? log_free : L.log_eta) : (mid ? log(1.0 - L.eta) : 0.0);
+  const double e_s = low ? (free ? third : 0.175) : 0.207, c_s = low ? (free ? 0.96 : 0.763) : (mid ? 0.722 : 0.37);
+  const double e_g = low ? (free ? -third : -0.65) : -0.586,
+               c_g = low ? (free ? 1.8432 : 0.203759) : (mid ? -0.215812 : 0.0);
+  const double shape = c_s * exp(e_s * lb), slope = c_g * exp(e_g * lb);
+  T.sigma[2] = dmax(K.wstar * shape, 1e-6);
+  const double inv_sw = frcp_newton(T.sigma[2]);
+  T.dsigma_w = 0.5 * fdiv(slope * (K.wstar * K.wstar), L.depth) * inv_sw;
+  T.tl[0] = T.tl[1] = fdiv(0.15 * L.depth, T.sigma[0]);
+  const double near_ground = fdiv(0.1 * L.h1 * inv_sw, dmax(0.55 - 0.38 * fabs(fdiv(L.h1, K.obukhov)), 0.05));
+  const double aloft = L.eta < 0.1 ? 0.59 * L.h1 * inv_sw : 0.15 * L.depth * inv_sw * (1.0 - exp(-5.0 * L.eta));
+  T.tl[2] = L.h1 < fabs(K.obukhov) ? near_ground : aloft;
+}
+
+// mptrac.c:4512-4522
+__device__ __forceinline__ void hanna_stable(const PblLayer &L, const PblScales &K, PblTurbulence &T) {
+  const double fade = 1.0 - L.eta;
+  T.sigma[0] = dmax(2.0 * K.ustar * fade, 1e-6);
+  T.sigma[1] = T.sigma[2] = dmax(1.3 * K.ustar * fade, 1e-6);
+  T.dsigma_w = -1.3 * fdiv(K.ustar, L.depth);
+  T.tl[0] = fdiv(0.15 * L.depth, T.sigma[0]) * fsqrt(L.eta);
+  T.tl[1] = 0.467 * T.tl[0];
+  T.tl[2] = fdiv(0.1 * L.depth, T.sigma[2]) * exp(0.8 * L.log_eta);
+}
+
+// LEAN: the stencils and gathers of the lean kernels (lat/lon grid with the pressure table, 32-bit offsets)
+template <bool LEAN = false>
+__device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particle &P, float &up, float &vp,
+                                         float &wp, uint64_t ctr, uint64_t g, const double *ltab) {
+  const double wt = time_weight(M, P.time);
+  if ((P.p < M.turb_skip) & (wt >= 0.0) & (wt <= 1.0))
+    return;
+  // (1) the layer (mptrac.c:4372-4398)
+  Stencil col = stencil_zero();
+  SurfA sa;
+  double ps, pbl;
+  if constexpr (LEAN) {
+    horiz_fast(M, A, P.lon, P.lat, col);
+    load_pair_2d32(M.sfa, M, col, sa);
+    pbl = pair_time_2d_fast(sa, col, wt, 1);
+  } else {
+    stencil_2d(M, A, P.lon, P.lat, col);
+    load_sfa(M, col, sa);
+    pbl = sfa_time_2d(sa, col, wt, 1);
+  }
+  if (P.p < pbl)
+    return;
+  ps = LEAN ? pair_time_2d_fast(sa, col, wt, 0) : sfa_time_2d(sa, col, wt, 0);
+  if (!(ps > 0.0 && pbl > 0.0 && ps > pbl))
+    return;
+  // heights above ground from pressure ratios: Z(p) - Z(ps) = H0 log(ps / p) (mptrac.h:2243)
+  const double p_in = dmin(P.p, ps);
+  PblLayer L;
+  L.depth = 1e3 * kH0 * log(fdiv(ps, pbl));
+  if (!(L.depth > 1.0))
+    return;
+  L.h = clampd(1e3 * kH0 * log(fdiv(ps, p_in)), 0.0, L.depth);
+  L.eta = clampd(fdiv(L.h, L.depth), 1e-6, 1.0 - 1e-6);
+  L.h1 = dmax(L.h, 1.0);
+  L.log_eta = log(L.eta);
+
+  // (2) the scales (mptrac.c:4400-4436): air density and virtual potential temperature at the particle, stresses and
+  // heat flux of the surface
+  SurfB sd;
+  load_sfb(M.sfd, M, col, sd);
+  const double stress_x = sfb_time_2d(sd, col, wt, 0), stress_y = sfb_time_2d(sd, col, wt, 1);
+  const double heat_flux = sfb_time_2d(sd, col, wt, 2);
+  Stencil cell = col;
+  double t, h2o;
+  if constexpr (LEAN) {
+    vert_fast(M, A, p_in, cell);
+    t = temp_fast(M, cell, wt);
+  } else {
+    stencil_3d(M, A, p_in, P.lon, P.lat, cell);
+    t = temp_time_3d(M, cell, wt);
+  }
+  h2o = pair_time_3d(M.h2o, M, cell, wt);
+  const double moist = 1. + (1. - kEps) * dmax(h2o, 0.1e-6);     // TVIRT's factor, mptrac.h:2199
+  const double rho = rho_air(p_in, t * moist);
+  if (!(rho > 0.0))
+    return;
+  const double theta_v = t * exp(kKappa * log(fdiv(1000., p_in))) * moist;   // THETAVIRT, mptrac.h:2153
+  PblScales K;
+  const double inv_rho = frcp_newton(rho);
+  K.ustar = dmax(1e-4, fsqrt(dmax(fsqrt(stress_x * stress_x + stress_y * stress_y) * inv_rho, 0.0)));
+  K.obukhov = fabs(heat_flux) > 1e-6 ? fdiv(theta_v * rho * kCpd * (K.ustar * K.ustar) * K.ustar, kKarman * kG0 * heat_flux) : 1e12;
+
+  // (3) the class (mptrac.c:4438-4523): neutral while the layer is shallower than |L|, else by the sign of L
+  PblTurbulence T;
+  if (L.depth < fabs(K.obukhov))
+    hanna_neutral(L, K, T);
+  else if (K.obukhov < 0.0) {
+    K.wstar = cbrt(dmax(fdiv(-kG0 * heat_flux * L.depth * inv_rho, theta_v * kCpd), 0.0));
+    hanna_convective(L, K, T);
+  } else
+    hanna_stable(L, K, T);
+  T.tl[0] = dmax(T.tl[0], 10.0);
+  T.tl[1] = dmax(T.tl[1], 10.0);
+  T.tl[2] = dmax(T.tl[2], 30.0);
+  bool usable = true;
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    usable &= (T.sigma[k] > 0.0) & (T.tl[k] > 0.0);
+  if (!usable)
+    return;
+
+  // (4) the step (mptrac.c:4531-4580)
+  double xi[3];
+  normal_triple(ltab, ctr, g, xi[0], xi[1], xi[2]);
+  double vel[3] = { (double) up, (double) vp, (double) wp };
+  const double dt = P.dt, span = fabs(P.dt);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double keep = exp(-fdiv(span, T.tl[k]));
+    double v = vel[k] * keep + T.sigma[k] * fsqrt(dmax(0.0, 1.0 - keep * keep)) * xi[k];
+    if (k == 2)   // drift of the vertical component: well-mixed condition + density gradient -1 / H
+      v += T.tl[2] * (1.0 - keep) * (2.0 * T.sigma[2] * T.dsigma_w - T.sigma[2] * T.sigma[2] * (1.0 / (1e3 * kH0)));
+    vel[k] = (double) (float) v;      // (the perturbations are stored in single precision, mptrac.h:3633)
+  }
+  P.lon += dx2coord(M.coord_type, vel[0] * dt, P.lat);
+  P.lat += dy2coord(M.coord_type, vel[1] * dt);
+  double h = L.h + vel[2] * dt;
+  bool flipped = false;
+  // mirrors at the ground and at the layer top, one after the other as the reference takes them (mptrac.c:4562-4573);
+  // a height the reference would mirror for ever (infinite: its loop does not end) or for very long is left to a bound
+  for (int mirrors = 0; mirrors < 4096 && (h < 0.0 || h > L.depth); mirrors++) {
+    h = h < 0.0 ? -h : 2.0 * L.depth - h;
+    flipped = !flipped;
+  }
+  up = (float) vel[0];
+  vp = (float) vel[1];
+  wp = flipped ? -(float) vel[2] : (float) vel[2];
+  // P(Z(ps) + h) = ps exp(-h / H0) (mptrac.h:1784, 2243)
+  P.p = clampd(ps * exp(h * (-1.0 / (1e3 * kH0))), pbl, ps);
+}
+
+// The closure as a function call.  Inlined into the fused step kernel its registers push the whole kernel into scratch
+// (the gated instantiation with the closure inlined: +0.35 ms per step on workload C3p although 98 % of the particles
+// never enter it, tools/gpu_pbl_cost.py); called, the kernel around it keeps the registers and the schedule of the
+// instantiation without the closure, and only the few waves with a particle near the ground pay for the call.
+// Arguments and results travel by value (a particle passed by reference would have to live in scratch memory); the
+// meteo descriptor is read through a pointer into the kernel's argument segment.
+struct PblState {
+  double time, lon, lat, p, dt;
+  float up, vp, wp;
+};
+
+__device__ __attribute__((noinline)) PblState diff_pbl_call(const DevMet *M, Axes A, PblState in, uint64_t ctr, uint64_t g,
+                                                            const double *ltab) {
+  Particle P;
+  P.time = in.time;
+  P.lon = in.lon;
+  P.lat = in.lat;
+  P.p = in.p;
+  P.dt = in.dt;
+  diff_pbl<true>(*M, A, P, in.up, in.vp, in.wp, ctr, g, ltab);
+  in.lon = P.lon;
+  in.lat = P.lat;
+  in.p = P.p;
+  return in;
+}
+
+// a particle above every boundary-layer top of the two snapshots (exact, see DevMet::turb_skip) has nothing to do there
+__device__ __forceinline__ bool above_every_boundary_layer(const DevMet &M, const Particle &P) {
+  const double wt = time_weight(M, P.time);
+  return (P.p < M.turb_skip) & (wt >= 0.0) & (wt <= 1.0);
+}
+
+// module_isosurf for the same instantiations, as a call as well
+__device__ __attribute__((noinline)) double isosurf_call(const mphip_ctl_t *ctl, const DevMet *M, Axes A, const DevAtm *a,
+                                                         double time, double p, double lon, double lat, double iso_var) {
+  Particle P;
+  P.time = time;
+  P.p = p;
+  P.lon = lon;
+  P.lat = lat;
+  P.dt = 0;
+  return isosurf_pressure(*ctl, *M, A, *a, P, iso_var);
 }
 
 }   // namespace mphip

@@ -165,7 +165,11 @@ constexpr unsigned kGated = 1u << 25;
 // of steps with nothing between them -- no module_sort, mixing, output -- at small particle counts, where a step is
 // shorter than a kernel launch).  The state goes through memory between the steps as it does between launches.
 constexpr unsigned kMultiStep = 1u << 26;
-constexpr unsigned kTemplateFlags = kTwoStage | kGated | kMultiStep | kMLWinds | kBigGrid;
+// template mask only, on the gated pressure-level instantiations: module_diff_pbl (TURB_PBL_SCHEME 1, the closure inside
+// the boundary layer) and module_isosurf are compiled in -- as function calls -- and switched by the run-time mask like
+// the four optional movers.  Instantiations of their own, so that runs without them keep the kernels they had.
+constexpr unsigned kPblClosure = 1u << 29;
+constexpr unsigned kTemplateFlags = kTwoStage | kGated | kMultiStep | kMLWinds | kBigGrid | kPblClosure;
 constexpr unsigned kOptionalModules = MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kTailModules = MPHIP_MOD_LOSS_ZERO | MPHIP_MOD_DECAY | MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
@@ -539,8 +543,11 @@ struct RngEarly {
 #ifndef MPHIP_ML_WAVES_PER_SIMD
 #define MPHIP_ML_WAVES_PER_SIMD 3   // the lean model-level instantiations: 148-158 VGPRs without scratch; at four waves (128 VGPRs) they spill 35-56 dwords: C3z 1.98 -> 1.81 ms per step (profiles/r04_variants.txt item 11)
 #endif
+#ifndef MPHIP_PBL_WAVES_PER_SIMD
+#define MPHIP_PBL_WAVES_PER_SIMD 4
+#endif
 template <unsigned CT>
-__global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRuntimeMask<CT> ? ((CT & kMultiStep) ? MPHIP_MULTI_WAVES_PER_SIMD
+__global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRuntimeMask<CT> && (CT & kPblClosure) ? MPHIP_PBL_WAVES_PER_SIMD : !kRuntimeMask<CT> ? ((CT & kMultiStep) ? MPHIP_MULTI_WAVES_PER_SIMD
                                                         : (CT & MPHIP_MOD_ADVECT) || CT == MPHIP_MOD_TIMESTEPS ? MPHIP_LEAN_WAVES_PER_SIMD : MPHIP_SPLITB_WAVES_PER_SIMD)
                                    : (CT == kMaskGenericPL ? MPHIP_STEP_WAVES_PER_SIMD : MPHIP_GENERIC_WAVES_PER_SIMD)) void step_kernel(
   const StepParams S) {
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
     constexpr bool multi = (!kRuntimeMask<CT> && (CT & kMultiStep) != 0) || CT == kMaskGenericMLMulti;
     const int nsteps = multi ? S.nsteps : 1;
     double t_now = S.t;
-    uint64_t c_turb = S.ctr_turb, c_meso = S.ctr_meso, c_conv = S.ctr_conv;
+    uint64_t c_turb = S.ctr_turb, c_meso = S.ctr_meso, c_conv = S.ctr_conv, c_pbl = S.ctr_pbl;
     // multi-step instantiations: the particle, its mesoscale wind perturbations and the wind corners it used last
     // stay in registers from one step to the next (the stores of every step remain; what a step would load is what
     // the step before stored, and the meteo arrays do not change inside a launch) -- the first Runge-Kutta stage
@@ -605,7 +612,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
     WindCache wc;
     float up = 0.f, vp = 0.f, wp = 0.f;
     for (int step = 0; step < nsteps; step++, t_now += S.t_stride, c_turb += S.ctr_stride, c_meso += S.ctr_stride,
-             c_conv += S.ctr_stride) {
+             c_conv += S.ctr_stride, c_pbl += S.ctr_stride) {
     const bool fused_sort = a.perm != nullptr;
     if (!multi || step == 0) {
     if (fused_sort) {   // the gather of module_sort_help (mptrac.c:5944-5949) for time, p, lon, lat
@@ -661,6 +668,11 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
       }
       if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))   // module_isosurf has check_dt = 0
         a.p[i] = isosurf_pressure(ctl, M, A, a, P, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
+      if constexpr (!kRuntimeMask<CT> && (CT & kPblClosure) != 0)
+        if (S.mask & MPHIP_MOD_ISOSURF) {
+          P.p = isosurf_call(&ctl, &M, A, &a, P.time, P.p, P.lon, P.lat, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
+          a.p[i] = P.p;
+        }
       continue;
     }
     // random numbers belong to the external slot (rs[3 * ip + k], mptrac.c:4645)
@@ -725,12 +737,34 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
       else
         diff_turb(ctl, M, A, *clim, P, c_turb, g, early ? pre.turb : nullptr, ltab);
     }
-    if (CT == kMaskGeneric && (mask & MPHIP_MOD_DIFF_PBL)) {
-      float up = a.up[i], vp = a.vp[i], wp = a.wp[i];
-      diff_pbl(M, A, P, up, vp, wp, S.ctr_pbl, g, ltab);
-      a.up[i] = up;
-      a.vp[i] = vp;
-      a.wp[i] = wp;
+#ifndef MPHIP_PBL_EMPTY
+#define MPHIP_PBL_EMPTY 0     // 1: experiment -- the kPblClosure instantiations without the closure's code
+#endif
+    constexpr bool lean_pbl = lean && (CT & kPblClosure) != 0 && !MPHIP_PBL_EMPTY;
+    if (((CT == kMaskGeneric && (mask & MPHIP_MOD_DIFF_PBL)) || (lean_pbl && (S.mask & MPHIP_MOD_DIFF_PBL)))
+        && !above_every_boundary_layer(M, P)) {
+      // (the perturbations live in the cache arrays; a multi-step launch with module_diff_meso holds them in registers)
+      const bool held = multi && (mask & MPHIP_MOD_DIFF_MESO);
+      if (!held) {
+        up = ld_state(&a.up[i]);
+        vp = ld_state(&a.vp[i]);
+        wp = ld_state(&a.wp[i]);
+      }
+      if constexpr (lean_pbl) {   // a call: the kernel keeps the registers of the instantiation without the closure
+        PblState st = { P.time, P.lon, P.lat, P.p, P.dt, up, vp, wp };
+        st = diff_pbl_call(&M, A, st, c_pbl, g, ltab);
+        P.lon = st.lon;
+        P.lat = st.lat;
+        P.p = st.p;
+        up = st.up;
+        vp = st.vp;
+        wp = st.wp;
+        wind_cache_reset(wc, true);   // (the cached corners do not cross the call: module_diff_meso gathers its own)
+      } else
+        diff_pbl<false>(M, A, P, up, vp, wp, c_pbl, g, ltab);
+      st_state(&a.up[i], up);
+      st_state(&a.vp[i], vp);
+      st_state(&a.wp[i], wp);
     }
     if (opt & MPHIP_MOD_DIFF_MESO) {
       if (!multi) {
@@ -762,6 +796,9 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
     }
     if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))
       P.p = isosurf_pressure(ctl, M, A, a, P, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
+    if constexpr (lean && (CT & kPblClosure) != 0)
+      if (S.mask & MPHIP_MOD_ISOSURF)
+        P.p = isosurf_call(&ctl, &M, A, &a, P.time, P.p, P.lon, P.lat, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
     if (mask & MPHIP_MOD_POSITION2) {
       if (lean)
         position_fast(M, A, P);

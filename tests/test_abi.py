@@ -117,6 +117,25 @@ def test_async_load_check_sees_a_register_touched_before_its_wait():
                ("1c", "v_mov_b32_e32 v3, v1"),          # the older load has returned
                ("20", "v_mov_b32_e32 v4, v2")]          # the younger one has not
     assert len(chk.check_kernel("k", partial)) == 1
+    # a load still in flight at the back-edge of a loop meets the instruction at the loop head (address 0x10: the
+    # branch at 0x20 jumps back by four instructions); with a wait in front of the back-edge it does not
+    loop = [("10", "v_mov_b32_e32 v5, v1"),
+            ("14", "v_add_u32_e32 v7, v7, v8"),
+            ("18", "global_load_dword v1, v[18:19], off"),
+            ("1c", "s_nop 0"),
+            ("20", "s_cbranch_scc1 65531"),
+            ("24", "s_waitcnt vmcnt(0)"),
+            ("28", "s_endpgm")]
+    assert len(chk.check_kernel("k", loop)) == 1
+    loop[3] = ("1c", "s_waitcnt vmcnt(0)")
+    assert chk.check_kernel("k", loop) == []
+    # ... and on the taken side of a forward branch that skips the wait of the other side
+    skip = [("10", "global_load_dword v1, v[18:19], off"),
+            ("14", "s_cbranch_vccz 1"),                    # -> 0x1c
+            ("18", "s_waitcnt vmcnt(0)"),
+            ("1c", "v_mov_b32_e32 v3, v1"),
+            ("20", "s_endpgm")]
+    assert len(chk.check_kernel("k", skip)) == 1
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="needs llvm-objdump")

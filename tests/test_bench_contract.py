@@ -41,6 +41,10 @@ def test_bench_prints_the_contract_line(extra):
         # (2e5 particles: the K steps go to the library as one call and share launches)
         assert r["step_kernel_launches_per_step"] <= 1 and r["kernel_ms"] == r["step_kernel_ms_per_step"]
         assert "mphip_run_timesteps" in cfg["time_loop"]
+    # both bounds stated: the HBM pricing under both launch regimes, the modelled VALU-issue roof (None at
+    # an overridden particle count: the committed instruction mix belongs to the workload's own), what pins the oracle
+    assert r["frac_one_launch_per_step"] > 0 and "alu" in r and "algorithmic" in r["basis"]
+    assert any("RK4" in m for m in d["parity"]["restatement_only"]) and d["parity"]["pinned_by_reference_goldens"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "particle-steps/s" and c["cores"] >= 1 and c["value"] > 1e4
     assert "sample" in c and c["value_1_thread"] > 0

@@ -274,6 +274,27 @@ def test_lean_instantiations_equal_the_general_code(over, advect):
         assert np.array_equal(runs[0][k], runs[1][k]), k
 
 
+@pytest.mark.parametrize("case", ["pbl", "pbl_meso"])
+@pytest.mark.parametrize("advect", [4, 2], ids=["rk4", "midpoint"])
+def test_lean_boundary_layer_closure_equals_the_general_code(case, advect):
+    """module_diff_pbl inside the gated lean instantiations (kPblClosure) and inside the general kernel: same bits;
+    and the closure moved particles (half of the case's particles start inside the boundary layer)."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=6001)
+    ctl.update(advect=advect)
+    runs = []
+    for generic in (0, 1):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("generic_kernel", generic)
+        s.timesteps_init(0.0, 0.0)
+        for t in cases.step_times(s.ctl)[:6]:
+            s.run_timestep(t)
+        runs.append(s.state())
+        s.close()
+    for k in ("time", "lon", "lat", "p", "q", "uvwp"):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+    assert np.count_nonzero(runs[0]["uvwp"][:, 2]) > 1000
+
+
 def test_met_swap_over_two_intervals():
     """mptrac_get_met's pointer swap (mptrac.c:6486-6499): 2 h with 3 snapshots."""
     ctl, clim, m0, m1, atm = cases.make_case("diff", n=3000)
@@ -1659,6 +1680,10 @@ _BATCH_CASES = [(c, None) for c in ("advect", "turb", "diff", "conv_sedi", "full
     ("conv_sedi", "bound"), ("advect", "bound2"),
     # ... with winds from the model levels: the gated lean model-level instantiation
     ("zeta_full", "bound"), ("mlp_full", "bound2"),
+    # the closure inside the boundary layer (TURB_PBL_SCHEME 1): gated instantiations of their own, in both integrators
+    ("pbl", None), ("pbl_meso", None), ("pbl_meso", 2),
+    # module_isosurf (isobaric, isopycnic, balloon; also on particles that are not released yet): the same instantiations
+    ("isosurf_p", None), ("isosurf_rho", None), ("isosurf_rho", 2), ("isosurf_balloon", None),
     # ADVECT 0 (the C ABI accepts it): no module_advect, no instantiation for several steps -- single steps
     ("diff", 0)]
 _BATCH_OVERRIDES = {"gas": dict(qnt_rp=-1, qnt_rhop=-1), "gas2": dict(qnt_rp=-1, qnt_rhop=-1, advect=2),
@@ -1689,10 +1714,12 @@ def test_run_timesteps_equals_the_step_by_step_loop(case, variant):
         ctl = dict(ctl, advect=variant)
     o = B.Oracle(ctl, clim, m0, m1, atm)
     o.timesteps_init()
+    cases.prepare(o)
     times = cases.step_times(o.ctl)
     runs, counts = {}, {}
     for name, multi, interval in (("loop", None, 4), ("batched", 64, 4), ("pairs", 2, 4), ("no_resort", 64, 0), ("off", 0, 4)):
         s = hip.Simulation(ctl, clim, m0, m1, atm)
+        cases.prepare(s)
         s.set_option("locality_sort_interval", interval)
         if variant == "eager_third":
             s.set_option("lazy_meteo", 0)
