@@ -102,8 +102,9 @@ int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr,
       close(ls);
       return 0;
     }
-    /* every peer says who it is first (hello_t); a connection that does not, or a rank that has been served
-     * already, is dropped without using up a place -- until world - 1 different ranks have their copy */
+    /* every peer says who it is first (hello_t) and acknowledges its copy with one byte; a connection that does
+     * neither is dropped without using up a place, and a rank whose copy got lost on the way is served again when it
+     * comes back (the buffer is the same every time) -- until world - 1 different ranks have acknowledged */
     int ok = 1, served = 0;
     unsigned char *seen = calloc((size_t) world, 1);
     if (!seen) {
@@ -120,12 +121,15 @@ int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr,
       const int fd = accept(ls, NULL, NULL);
       if (fd < 0)
         continue;
-      struct timeval tv = { 5, 0 };
+      struct timeval tv = { 1, 0 };      /* (a peer sends its hello at once: a silent connection holds the server for a second at most) */
       setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
       hello_t hello;
+      char ack = 0;
       if (recv_all(fd, (char *) &hello, sizeof(hello)) && hello.magic == HELLO_MAGIC && hello.world == world && hello.rank >= 1
-          && hello.rank < world && hello.bytes == (unsigned long long) n && !seen[hello.rank]) {
-        if (send_all(fd, buf, n)) {
+          && hello.rank < world && hello.bytes == (unsigned long long) n) {
+        struct timeval tv_ack = { 5, 0 };
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv_ack, sizeof(tv_ack));
+        if (send_all(fd, buf, n) && recv_all(fd, &ack, 1) && ack == 1 && !seen[hello.rank]) {
           seen[hello.rank] = 1;
           served++;
         }
@@ -147,8 +151,14 @@ int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr,
     if (connect(fd, (struct sockaddr *) &sa, sizeof(sa)) == 0) {
       struct timeval tv = { rendezvous_timeout(), 0 };
       setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
-      const hello_t hello = { HELLO_MAGIC, rank, world, (unsigned long long) n };
-      const int ok = send_all(fd, (const char *) &hello, sizeof(hello)) && recv_all(fd, buf, n);
+      hello_t hello;
+      memset(&hello, 0, sizeof(hello));      /* (padding bytes included: nothing uninitialised goes over the wire) */
+      hello.magic = HELLO_MAGIC;
+      hello.rank = rank;
+      hello.world = world;
+      hello.bytes = (unsigned long long) n;
+      const char ack = 1;
+      const int ok = send_all(fd, (const char *) &hello, sizeof(hello)) && recv_all(fd, buf, n) && send_all(fd, &ack, 1);
       close(fd);
       if (ok)
         return 1;
