@@ -316,91 +316,109 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
   apply_loss(ctl, a, i, aux, ctl.qnt_mloss_dry, v_dep / dz);
 }
 
-// module_wet_depo / module_dry_depo of the lean kernels: the general value code on the lean stencil set-up
-// (one horizontal stencil at the final position serves both modules)
-template <bool BIG = false>
-__device__ __forceinline__ void wet_depo_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
-                                              long long i, const Particle &P, Stencil &s) {
-  if (above_every_cloud_top(M, P))
+// module_wet_depo (mptrac.c:6170-6289) and module_dry_depo (mptrac.c:4753-4796) of the lean kernels as ONE function:
+// the general value code on the lean stencil set-up, with the gathers of the two modules in two rounds instead of
+// five dependent ones -- the surface records both start from ({pct, pcb, cl} and {ps, pbl}: one horizontal stencil
+// at the final position serves both), then the level records at the particle (the cloud-water record of the wet part
+// and ONE temperature for both parts: they interpolate it at the same stencil).  `wet(aux, rate)` / `dry(aux, rate)`
+// receive the factor exp(-dt lambda) and the loss rate of a particle the module acts on, wet first
+// (mptrac.c:7983-7993): the kernels that move the particles apply it at once (depo_pair_fast), the launch beside
+// module_mixing keeps it for later.
+template <bool BIG = false, class WetSink, class DrySink>
+__device__ __forceinline__ void depo_pair_factor(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
+                                                 long long i, const Particle &P, Stencil &s, bool want_wet, bool want_dry,
+                                                 WetSink &&wet, DrySink &&dry) {
+  want_wet = want_wet && !above_every_cloud_top(M, P);
+  want_dry = want_dry && !above_every_surface_layer(ctl, M, P);
+  if (!(want_wet | want_dry))
     return;
-  SurfB c2;
-  load_sfb(M.sfc, M, s, c2);
   const double wt = time_weight(M, P.time);
-  const double pct = sfb_time_2d(c2, s, wt, 0);
-  if (!isfinite(pct) || P.p <= pct)
-    return;
-  const double pcb = sfb_time_2d(c2, s, wt, 1);
-  const double cl = sfb_time_2d(c2, s, wt, 2);
-  const double Is = pow(1. / ctl.wet_depo_pre[0] * cl, 1. / ctl.wet_depo_pre[1]);
-  if (Is < 0.01)
-    return;
-  vert_fast(M, A, P.p, s);
-  CloudCorners c;
-  load_cloud(M, s, c);
-  const double lwc = cloud_time_3d(c, s, wt, 0);
-  const double rwc = cloud_time_3d(c, s, wt, 1);
-  const double iwc = cloud_time_3d(c, s, wt, 2);
-  const double swc = cloud_time_3d(c, s, wt, 3);
-  const bool inside = (lwc > 0 || rwc > 0 || iwc > 0 || swc > 0);
-  const double t = temp_fast<BIG>(M, s, wt);
-
-  double lambda = 0;
-  if (inside) {
-    double eta;
-    if (t > kWdTLiquid)
-      eta = 1;
-    else if (t <= kWdTIce)
-      eta = ctl.wet_depo_ic_ret_ratio;
-    else
-      eta = lin(kWdTLiquid, 1, kWdTIce, ctl.wet_depo_ic_ret_ratio, t);
-    if (ctl.wet_depo_ic_a > 0)
-      lambda = ctl.wet_depo_ic_a * pow(Is, ctl.wet_depo_ic_b) * eta;
-    else if (ctl.wet_depo_ic_h[0] > 0) {
-      double h = ctl.wet_depo_ic_h[0] * exp(ctl.wet_depo_ic_h[1] * (1. / t - 1. / kTRef));
-      if (ctl.wet_depo_so2_ph > 0) {
-        const double H_ion = pow(10., -ctl.wet_depo_so2_ph);
-        const double K_1 = kSO2K1Ref * exp(kSO2K1Temp * (1. / t - 1. / kTRef));
-        const double K_2 = kSO2K2Ref * exp(kSO2K2Temp * (1. / t - 1. / kTRef));
-        h *= (1. + K_1 / H_ion + K_1 * K_2 / (H_ion * H_ion));
-      }
-      const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
-      lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
-    }
-  } else {
-    const double eta = (t > kWdTLiquidBC) ? 1 : ctl.wet_depo_bc_ret_ratio;
-    if (ctl.wet_depo_bc_a > 0)
-      lambda = ctl.wet_depo_bc_a * pow(Is, ctl.wet_depo_bc_b) * eta;
-    else if (ctl.wet_depo_bc_h[0] > 0) {
-      const double h = ctl.wet_depo_bc_h[0] * exp(ctl.wet_depo_bc_h[1] * (1. / t - 1. / kTRef));
-      const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
-      lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
+  SurfB c2;
+  SurfA c1;
+  if (want_wet)
+    load_sfb(M.sfc, M, s, c2);
+  if (want_dry)
+    load_pair_2d32(M.sfa, M, s, c1);
+  bool wet_go = false, dry_go = false;
+  double pct = 0, pcb = 0, Is = 0, dz_dry = 0;
+  if (want_wet) {
+    pct = sfb_time_2d(c2, s, wt, 0);
+    if (isfinite(pct) && P.p > pct) {
+      pcb = sfb_time_2d(c2, s, wt, 1);
+      const double cl = sfb_time_2d(c2, s, wt, 2);
+      Is = pow(1. / ctl.wet_depo_pre[0] * cl, 1. / ctl.wet_depo_pre[1]);
+      wet_go = !(Is < 0.01);
     }
   }
-  const double aux = exp(-P.dt * lambda);
-  apply_loss(ctl, a, i, aux, ctl.qnt_mloss_wet, lambda);
+  if (want_dry) {
+    const double ps = pair_time_2d_fast(c1, s, wt, 0);
+    dry_go = !(P.p < ps - ctl.dry_depo_dp);
+    if (dry_go)
+      dz_dry = 1000. * (zfromp(ps - ctl.dry_depo_dp) - zfromp(ps));
+  }
+  if (!(wet_go | dry_go))
+    return;
+  const bool dry_sedi = dry_go && ctl.qnt_rp > 0 && ctl.qnt_rhop > 0;   // "> 0" as the reference, mptrac.c:4769
+  double t = 0;
+  CloudCorners c;
+  if (wet_go | dry_sedi) {
+    vert_fast(M, A, P.p, s);
+    if (wet_go)
+      load_cloud(M, s, c);
+    t = temp_fast<BIG>(M, s, wt);
+  }
+  if (wet_go) {
+    const double lwc = cloud_time_3d(c, s, wt, 0);
+    const double rwc = cloud_time_3d(c, s, wt, 1);
+    const double iwc = cloud_time_3d(c, s, wt, 2);
+    const double swc = cloud_time_3d(c, s, wt, 3);
+    const bool inside = (lwc > 0 || rwc > 0 || iwc > 0 || swc > 0);
+    double lambda = 0;
+    if (inside) {
+      double eta;
+      if (t > kWdTLiquid)
+        eta = 1;
+      else if (t <= kWdTIce)
+        eta = ctl.wet_depo_ic_ret_ratio;
+      else
+        eta = lin(kWdTLiquid, 1, kWdTIce, ctl.wet_depo_ic_ret_ratio, t);
+      if (ctl.wet_depo_ic_a > 0)
+        lambda = ctl.wet_depo_ic_a * pow(Is, ctl.wet_depo_ic_b) * eta;
+      else if (ctl.wet_depo_ic_h[0] > 0) {
+        double h = ctl.wet_depo_ic_h[0] * exp(ctl.wet_depo_ic_h[1] * (1. / t - 1. / kTRef));
+        if (ctl.wet_depo_so2_ph > 0) {
+          const double H_ion = pow(10., -ctl.wet_depo_so2_ph);
+          const double K_1 = kSO2K1Ref * exp(kSO2K1Temp * (1. / t - 1. / kTRef));
+          const double K_2 = kSO2K2Ref * exp(kSO2K2Temp * (1. / t - 1. / kTRef));
+          h *= (1. + K_1 / H_ion + K_1 * K_2 / (H_ion * H_ion));
+        }
+        const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
+        lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
+      }
+    } else {
+      const double eta = (t > kWdTLiquidBC) ? 1 : ctl.wet_depo_bc_ret_ratio;
+      if (ctl.wet_depo_bc_a > 0)
+        lambda = ctl.wet_depo_bc_a * pow(Is, ctl.wet_depo_bc_b) * eta;
+      else if (ctl.wet_depo_bc_h[0] > 0) {
+        const double h = ctl.wet_depo_bc_h[0] * exp(ctl.wet_depo_bc_h[1] * (1. / t - 1. / kTRef));
+        const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
+        lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
+      }
+    }
+    wet(exp(-P.dt * lambda), lambda);
+  }
+  if (dry_go) {
+    const double v_dep = dry_sedi ? sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]) : ctl.dry_depo_vdep;
+    dry(exp(-P.dt * v_dep / dz_dry), v_dep / dz_dry);
+  }
 }
 
 template <bool BIG = false>
-__device__ __forceinline__ void dry_depo_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
-                                              long long i, const Particle &P, Stencil &s) {
-  if (above_every_surface_layer(ctl, M, P))
-    return;
-  SurfA c2;
-  load_pair_2d32(M.sfa, M, s, c2);
-  const double wt = time_weight(M, P.time);
-  const double ps = pair_time_2d_fast(c2, s, wt, 0);
-  if (P.p < ps - ctl.dry_depo_dp)
-    return;
-  const double dz = 1000. * (zfromp(ps - ctl.dry_depo_dp) - zfromp(ps));
-  double v_dep;
-  if (ctl.qnt_rp > 0 && ctl.qnt_rhop > 0) {   // "> 0" as the reference, mptrac.c:4769
-    vert_fast(M, A, P.p, s);
-    const double t = temp_fast<BIG>(M, s, wt);
-    v_dep = sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
-  } else
-    v_dep = ctl.dry_depo_vdep;
-  const double aux = exp(-P.dt * v_dep / dz);
-  apply_loss(ctl, a, i, aux, ctl.qnt_mloss_dry, v_dep / dz);
+__device__ __forceinline__ void depo_pair_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, const DevAtm &a,
+                                               long long i, const Particle &P, Stencil &s, bool want_wet, bool want_dry) {
+  depo_pair_factor<BIG>(ctl, M, A, a, i, P, s, want_wet, want_dry,
+                        [&](double aux, double rate) { apply_loss(ctl, a, i, aux, ctl.qnt_mloss_wet, rate); },
+                        [&](double aux, double rate) { apply_loss(ctl, a, i, aux, ctl.qnt_mloss_dry, rate); });
 }
 
 // One thread per particle, grid-stride.  Workgroup b of the launch is mapped
@@ -838,10 +856,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
       if (wet || dry) {
         Stencil sd = stencil_zero();
         horiz_fast(M, A, P.lon, P.lat, sd);
-        if (wet)
-          wet_depo_fast<kBig<CT>>(ctl, M, A, a, i, P, sd);
-        if (dry)
-          dry_depo_fast<kBig<CT>>(ctl, M, A, a, i, P, sd);
+        depo_pair_fast<kBig<CT>>(ctl, M, A, a, i, P, sd, wet, dry);
       }
     } else {
       if (mask & MPHIP_MOD_WET_DEPO)
@@ -863,7 +878,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
 // comparisons against the bounds of DevMet::pct_skip / ps_skip: only p, time and dt are read), packs their
 // numbers into a list in LDS, and then works through the list: full waves for the stencils, the gathers and the
 // pow / exp of the modules, none for the rest.  Same arithmetic per particle as
-// the fused kernel (wet_depo_fast, dry_depo_fast); lean configurations only (launch_step).  (module_mixing's
+// the fused kernel (depo_pair_fast); lean configurations only (launch_step).  (module_mixing's
 // relaxation inside the first pass of this kernel was measured as well: 2.36 against 2.28 ms per step of C5 --
 // its dependent gathers delay the list and the barrier behind it.)
 // ---------------------------------------------------------------------------
@@ -924,10 +939,107 @@ __global__ __launch_bounds__(256, MPHIP_DEPO_WAVES_PER_SIMD) void depo_kernel(co
     const bool dry = (tmask & MPHIP_MOD_DRY_DEPO) && !above_every_surface_layer(ctl, M, P);
     Stencil sd = stencil_zero();
     horiz_fast(M, A, P.lon, P.lat, sd);
-    if (wet)
-      wet_depo_fast(ctl, M, A, a, ip, P, sd);
-    if (dry)
-      dry_depo_fast(ctl, M, A, a, ip, P, sd);
+    depo_pair_fast(ctl, M, A, a, ip, P, sd, wet, dry);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The deposition launch in two parts around module_mixing.  module_wet_depo and module_dry_depo multiply the mass of a
+// particle by factors that depend on where the particle is, not on the mass; the positions are final when the
+// launch that moves the particles has ended, before module_mixing.  depo_factor_kernel therefore runs BESIDE
+// module_mixing, on a stream of its own: the busy particles of a workgroup packed into full waves as in depo_kernel,
+// their factors and rates into a list (one slice per workgroup); depo_apply_kernel runs behind the relaxation and
+// only multiplies -- in the reference's order, wet then dry (mptrac.c:7983-7993), with the same operations as
+// apply_loss on the relaxed masses, so the bits are those of the deposition launch behind module_mixing.
+// ---------------------------------------------------------------------------
+struct DepoList {
+  int *idx;        // [np] particle (offset inside its workgroup's range) of every entry; slice of workgroup b at b * per_block
+  int *flags;      // bit 0: module_wet_depo acts, bit 1: module_dry_depo acts
+  double *f[4];    // aux and rate of the wet part, aux and rate of the dry part
+  int *count;      // [workgroups] entries of every slice
+};
+
+__global__ __launch_bounds__(256, MPHIP_DEPO_WAVES_PER_SIMD) void depo_factor_kernel(const StepParams S, const DepoList L) {
+  extern __shared__ double s_axes[];
+  __shared__ int s_count;
+  const DevMet &M = S.met;
+  const DevAtm &a = S.atm;
+  const mphip_ctl_t &ctl = S.ctl;
+  const Axes A = load_axes(M, s_axes);
+  int *s_list = (int *) (s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8);
+  if (threadIdx.x == 0)
+    s_count = 0;
+  __syncthreads();
+  const unsigned tmask = S.mask;
+  const int nb = S.nblocks_logical;
+  const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
+  const long long first = (long long) lb * S.per_block;
+  long long last = first + S.per_block;
+  if (last > a.np)
+    last = a.np;
+  const int lane = threadIdx.x & 63;
+  for (long long i = first + threadIdx.x; i < first + S.per_block; i += 256) {   // (whole waves stay together)
+    bool busy = false;
+    if (i < last && a.dt[i] != 0) {   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
+      Particle P;
+      P.time = a.time[i];
+      P.p = a.p[i];
+      busy = ((tmask & MPHIP_MOD_WET_DEPO) && !above_every_cloud_top(M, P))
+        || ((tmask & MPHIP_MOD_DRY_DEPO) && !above_every_surface_layer(ctl, M, P));
+    }
+    const unsigned long long mine = __ballot(busy);
+    int at = 0;
+    if (lane == 0 && mine)
+      at = atomicAdd(&s_count, __builtin_popcountll(mine));
+    at = __builtin_amdgcn_readfirstlane(at);
+    if (busy)
+      s_list[at + __builtin_popcountll(mine & ((1ull << lane) - 1))] = (int) (i - first);
+  }
+  __syncthreads();
+  const int total = s_count;
+  if (threadIdx.x == 0)
+    L.count[lb] = total;
+  for (int t = threadIdx.x; t < total; t += 256) {
+    const int off = s_list[t];
+    const long long ip = first + off;
+    Particle P;
+    P.time = a.time[ip];
+    P.lon = a.lon[ip];
+    P.lat = a.lat[ip];
+    P.p = a.p[ip];
+    P.dt = a.dt[ip];
+    Stencil sd = stencil_zero();
+    horiz_fast(M, A, P.lon, P.lat, sd);
+    int flags = 0;
+    double f0 = 1, f1 = 0, f2 = 1, f3 = 0;
+    depo_pair_factor(ctl, M, A, a, ip, P, sd, (tmask & MPHIP_MOD_WET_DEPO) != 0, (tmask & MPHIP_MOD_DRY_DEPO) != 0,
+                     [&](double aux, double rate) { flags |= 1; f0 = aux; f1 = rate; },
+                     [&](double aux, double rate) { flags |= 2; f2 = aux; f3 = rate; });
+    L.idx[first + t] = off;
+    L.flags[first + t] = flags;
+    L.f[0][first + t] = f0;
+    L.f[1][first + t] = f1;
+    L.f[2][first + t] = f2;
+    L.f[3][first + t] = f3;
+  }
+}
+
+__global__ __launch_bounds__(256) void depo_apply_kernel(const StepParams S, const DepoList L) {
+  const DevAtm &a = S.atm;
+  const mphip_ctl_t &ctl = S.ctl;
+  const int nb = S.nblocks_logical;
+  const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
+  const long long first = (long long) lb * S.per_block;
+  const int total = L.count[lb];
+  for (int t = threadIdx.x; t < total; t += 256) {
+    const int flags = L.flags[first + t];
+    if (!flags)
+      continue;
+    const long long ip = first + L.idx[first + t];
+    if (flags & 1)
+      apply_loss(ctl, a, ip, L.f[0][first + t], ctl.qnt_mloss_wet, L.f[1][first + t]);
+    if (flags & 2)
+      apply_loss(ctl, a, ip, L.f[2][first + t], ctl.qnt_mloss_dry, L.f[3][first + t]);
   }
 }
 

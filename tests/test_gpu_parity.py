@@ -295,6 +295,26 @@ def test_lean_boundary_layer_closure_equals_the_general_code(case, advect):
     assert np.count_nonzero(runs[0]["uvwp"][:, 2]) > 1000
 
 
+def test_deposition_factors_beside_mixing_equal_the_launch_behind_it():
+    """Option depo_beside_mixing: module_wet_depo / module_dry_depo of a mixing step as factors computed beside
+    module_mixing (own stream) and applied behind the relaxation -- the bits of the deposition launch behind it."""
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=20011)
+    ctl.update(mixing_dt=180.0, sort_dt=180.0)
+    runs = []
+    for beside in (0, 1):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("depo_beside_mixing", beside)
+        s.timesteps_init(0.0, 0.0)
+        for t in cases.step_times(s.ctl)[:8]:
+            s.run_timestep(t)
+        runs.append(s.state())
+        s.close()
+    for k in ("time", "lon", "lat", "p", "q", "uvwp"):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+    wet, dry = (list(cases.QUANTITIES).index(k) for k in ("mloss_wet", "mloss_dry"))
+    assert runs[0]["q"][wet].max() > 0 and runs[0]["q"][dry].max() > 0
+
+
 def test_met_swap_over_two_intervals():
     """mptrac_get_met's pointer swap (mptrac.c:6486-6499): 2 h with 3 snapshots."""
     ctl, clim, m0, m1, atm = cases.make_case("diff", n=3000)
