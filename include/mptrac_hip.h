@@ -365,6 +365,9 @@ int mphip_comm_query(mphip_ctx *ctx, int *nranks, int *rank);
  *   "sum_path" (default 0 = by crowding; 1, 2): tests -- force the group / the chain algorithm of the ordered sums;
  *   "chain_blocks": tuning -- workgroups of the chain walk of the ordered sums;
  *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel;
+ *   "sort_repair" (default 1): the module_sort that runs ahead repairs the order of the previous module_sort (only the
+ *     particles that changed their cell are sorted, then merged with the others) instead of sorting from scratch; same
+ *     permutation;
  *   "depo_beside_mixing" (default 0): in a time step with module_mixing, compute the factors of module_wet_depo /
  *     module_dry_depo beside module_mixing (a second stream) and apply them behind the relaxation; same results
  *   "big_grid" (default 0): tests -- take the instantiations with 64-bit byte offsets into the packed meteo records (what a

@@ -185,6 +185,15 @@ struct mphip_ctx {
   uint32_t *d_counts = nullptr;
   size_t counts_cap = 0;
   int sorted_buf = -1;                // which d_keys/d_vals pair holds the last result
+  // module_sort as a repair of the previous order (repair_* kernels): valid while the particles are stored in the order
+  // of the last module_sort (stored_is_sorted) -- its sorted keys are then non-decreasing along the slots
+  bool sort_repair = true;            // option "sort_repair"
+  bool ahead_priority = false;        // option "ahead_priority": the stream of the sort ahead at the highest priority (C5: no difference, profiles/r05_variants.txt item 3)
+  bool stored_is_sorted = false;
+  long long sorted_n = 0;
+  uint32_t *rep_sk = nullptr, *rep_mk[2] = {}, *rep_fk = nullptr, *rep_tiles = nullptr, *rep_nm = nullptr;
+  int *rep_si = nullptr, *rep_mi[2] = {}, *rep_fv = nullptr;
+  long long rep_cap = 0;
   // module_sort of the NEXT time step, started beside the rest of this one (option "sort_ahead"): once the launch
   // that moves the particles has run, their positions are final for this step -- module_mixing and the deposition
   // modules only change quantities -- so the keys and the radix sort of the next step's module_sort (and its
@@ -1299,6 +1308,40 @@ int sort_pairs(mphip_ctx *ctx, int tile, int *result_buf, const double *timestep
                       true);
 }
 
+// ---- module_sort as a repair of the previous order ---------------------------------------------------------------
+// key_prev: the sorted keys of the module_sort whose order the particles are stored in; the new keys are in
+// ctx->d_keys[0] (sort_keys).  Leaves the sorted (key, slot) pairs in ctx->d_keys[0] / d_vals[0].
+int repair_sort(mphip_ctx *ctx, const uint32_t *key_prev, long long n, int key_bits, int *cur_out) {
+  if (n > ctx->rep_cap) {
+    const size_t m = (size_t) n;
+    if (dev_alloc(ctx, &ctx->rep_sk, m) || dev_alloc(ctx, &ctx->rep_si, m) || dev_alloc(ctx, &ctx->rep_fk, m)
+        || dev_alloc(ctx, &ctx->rep_fv, m) || dev_alloc(ctx, &ctx->rep_mk[0], m) || dev_alloc(ctx, &ctx->rep_mk[1], m)
+        || dev_alloc(ctx, &ctx->rep_mi[0], m) || dev_alloc(ctx, &ctx->rep_mi[1], m)
+        || dev_alloc(ctx, &ctx->rep_tiles, (m + kRepairTile - 1) / kRepairTile) || dev_alloc(ctx, &ctx->rep_nm, (size_t) 2))
+      return 1;
+    ctx->rep_cap = n;
+  }
+  const int ntiles = (int) ((n + kRepairTile - 1) / kRepairTile);
+  const uint32_t *key_new = ctx->d_keys[0];
+  hipLaunchKernelGGL(repair_count_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, key_new, key_prev, n, ctx->rep_tiles);
+  hipLaunchKernelGGL(repair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->rep_tiles, ntiles, n, ctx->rep_nm);
+  hipLaunchKernelGGL(repair_split_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, key_new, key_prev, n,
+                     (const uint32_t *) ctx->rep_tiles, ctx->rep_mk[0], ctx->rep_mi[0], ctx->rep_sk, ctx->rep_si);
+  HIPCHK(hipGetLastError());
+  int mc = 0;     // the movers: the stable radix sort over as many pairs as there are (the count stays on the device)
+  if (radix_passes(ctx, ctx->rep_mk, ctx->rep_mi, n, key_bits, &mc, ctx->rep_nm))
+    return 1;
+  const int nmerge = (int) ((n + kMergeTile - 1) / kMergeTile);
+  hipLaunchKernelGGL(repair_merge_kernel, dim3(nmerge), dim3(256), 0, ctx->stream, (const uint32_t *) ctx->rep_sk,
+                     (const int *) ctx->rep_si, (const uint32_t *) ctx->rep_mk[mc], (const int *) ctx->rep_mi[mc],
+                     (const uint32_t *) ctx->rep_nm, n, ctx->rep_fk, ctx->rep_fv);
+  HIPCHK(hipGetLastError());
+  std::swap(ctx->d_keys[0], ctx->rep_fk);
+  std::swap(ctx->d_vals[0], ctx->rep_fv);
+  *cur_out = 0;
+  return 0;
+}
+
 // ---- module_sort ahead of time (mphip_ctx::sort_ahead) -----------------------------------------------------
 
 // the sort buffers of the context <-> the buffers of the sort that runs ahead
@@ -1329,7 +1372,14 @@ int ahead_drop(mphip_ctx *ctx) {
 int ahead_launch(mphip_ctx *ctx, double t_next, const BoxArgs *box = nullptr) {
   const long long n = ctx->np;
   if (!ctx->ahead_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&ctx->ahead_stream, hipStreamNonBlocking));
+    // (with the order repair the sort ahead is little work in few workgroups: at a higher priority they do not queue
+    //  behind the thousands of workgroups of the deposition launch)
+    int prio_low = 0, prio_high = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (ctx->ahead_priority && prio_high != prio_low) {
+      HIPCHK(hipStreamCreateWithPriority(&ctx->ahead_stream, hipStreamNonBlocking, prio_high));
+    } else
+      HIPCHK(hipStreamCreateWithFlags(&ctx->ahead_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ahead_mark, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ahead_done, hipEventDisableTiming));
   }
@@ -1341,6 +1391,10 @@ int ahead_launch(mphip_ctx *ctx, double t_next, const BoxArgs *box = nullptr) {
       return 1;
     ctx->ahead_cap = n;
   }
+  // the particles are stored in the order of the last module_sort: its sorted keys (in the buffers of the context, which
+  // the sort ahead does not touch) let this one repair that order instead of sorting from scratch
+  const uint32_t *key_prev = ctx->sort_repair && ctx->stored_is_sorted && ctx->sorted_buf >= 0 && ctx->sorted_n == n
+    ? ctx->d_keys[ctx->sorted_buf] : nullptr;
   // the sort code runs as it is, on the other stream and the other buffers
   hipStream_t main_stream = ctx->stream;
   ahead_swap_buffers(ctx);
@@ -1354,7 +1408,8 @@ int ahead_launch(mphip_ctx *ctx, double t_next, const BoxArgs *box = nullptr) {
   if (!rc && !box)
     rc = sort_keys(ctx, 0, &t_next, nullptr);
   if (!rc)
-    rc = radix_passes(ctx, ctx->d_keys, ctx->d_vals, n, bits_for(sort_key_range(ctx, 0)), &cur, nullptr, true);
+    rc = key_prev ? repair_sort(ctx, key_prev, n, bits_for(sort_key_range(ctx, 0)), &cur)
+                  : radix_passes(ctx, ctx->d_keys, ctx->d_vals, n, bits_for(sort_key_range(ctx, 0)), &cur, nullptr, true);
   ctx->stream = main_stream;
   ahead_swap_buffers(ctx);
   if (rc)
@@ -1424,6 +1479,7 @@ int restore_external_order(mphip_ctx *ctx) {
   if (permute_random(ctx, g, ctx->d_ext, ctx->np, true))
     return 1;
   perm_swap(ctx, true);
+  ctx->stored_is_sorted = false;
   ctx->ext_identity = true;
   ctx->steps_since_resort = 1 << 30;
   return 0;
@@ -1456,6 +1512,7 @@ int locality_sort(mphip_ctx *ctx) {
   }
   perm_swap(ctx, true);
   std::swap(ctx->d_ext, ctx->d_ext_alt);
+  ctx->stored_is_sorted = false;
   ctx->ext_identity = false;
   ctx->steps_since_resort = 0;
   return 0;
@@ -1482,6 +1539,8 @@ int do_sort(mphip_ctx *ctx, const double *timestep_t = nullptr) {
       return 1;
   }
   ctx->sorted_buf = cur;
+  ctx->stored_is_sorted = true;      // (once the gather below -- or the step launch that carries it -- has run)
+  ctx->sorted_n = n;
   const PermGeom pg = perm_geom(n);
   if (timestep_t && ctx->fuse_sort) {
     // inside mphip_run_timestep the step launch that follows reads time, p, lon, lat through the
@@ -2103,6 +2162,9 @@ void mphip_destroy(mphip_ctx *ctx) {
     (void) hipEventDestroy(ctx->depo_mark);
     (void) hipEventDestroy(ctx->depo_done);
   }
+  for (void *q : { (void *) ctx->rep_sk, (void *) ctx->rep_si, (void *) ctx->rep_fk, (void *) ctx->rep_fv, (void *) ctx->rep_mk[0],
+                   (void *) ctx->rep_mk[1], (void *) ctx->rep_mi[0], (void *) ctx->rep_mi[1], (void *) ctx->rep_tiles, (void *) ctx->rep_nm })
+    dev_free(q);
   dev_free(ctx->depo_list.idx);
   dev_free(ctx->depo_list.flags);
   for (auto q : ctx->depo_list.f)
@@ -2594,11 +2656,13 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
     dev_free(ctx->d_kz_alt);
     ctx->d_kz = ctx->d_kz_alt = nullptr;
     ctx->sorted_buf = -1;
+    ctx->stored_is_sorted = false;
   }
   ctx->meteo_pending = false;   // the uploaded quantity arrays replace whatever module_meteo would have written
   if (!fresh && restore_external_order(ctx))   // keep cache->uvwp with its slot across a re-upload
     return 1;
   ctx->ext_identity = true;
+  ctx->stored_is_sorted = false;     // (the caller's particles: in no order this library knows of)
   ctx->steps_since_resort = 1 << 30;
   ctx->np = np;
   ctx->nq = nq;
@@ -3341,6 +3405,14 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (!(value == 0 || (value >= 8 && value <= kRadixMaxBits)))
       return fail(ctx, "sort_bits must be 0 (automatic), 8, 9 or 10");
     ctx->sort_bits = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "ahead_priority") == 0) {   // (before the first sort ahead: the stream is created then)
+    ctx->ahead_priority = value != 0;
+    return 0;
+  }
+  if (strcmp(name, "sort_repair") == 0) {   // 0: the module_sort that runs ahead always sorts from scratch
+    ctx->sort_repair = value != 0;
     return 0;
   }
   if (strcmp(name, "depo_beside_mixing") == 0) {   // 0: the deposition modules of a mixing step as one launch behind module_mixing

@@ -1505,6 +1505,166 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
   }
 }
 
+// ---------------------------------------------------------------------------
+// module_sort as a REPAIR of the previous order (mptrac.c:5887-5957 sorts from scratch every SORT_DT).
+// When module_sort runs in every step the particles are stored in the order of the previous sort, key_prev[j] (the
+// sorted keys of that sort) is non-decreasing along the slots j, and most particles are still in the cell they were
+// in: a particle whose new key equals key_prev at its slot is a "stayer".  The stayers, taken in slot order, are a
+// sorted sequence already (same keys as before, ties in slot order = the stable order); the others ("movers", ~15 % per
+// step on workload C5) are compacted in slot order, sorted by the stable radix sort -- a few hundred thousand pairs
+// instead of 10^7 -- and the two sorted sequences are merged by (key, slot).  The result is exactly the stable sort of
+// all (key, slot) pairs: same permutation, same keys as the full sort (tests compare the bits with it and the oracle).
+//   repair_count_kernel   movers of every tile of 1024 slots
+//   repair_scan_kernel    exclusive prefix of the tile counts (one workgroup), the number of movers
+//   repair_split_kernel   movers -> (mk, mi), stayers -> (sk, si), both in slot order
+//   (radix passes over the movers, number of pairs on the device)
+//   repair_merge_kernel   merge path: every workgroup produces 2048 consecutive pairs of the result from the two
+//                         sub-ranges a diagonal search assigns to it (coalesced reads and writes, the merge in LDS)
+// ---------------------------------------------------------------------------
+constexpr int kRepairTile = 1024;     // slots per workgroup of the count / split kernels (256 threads x 4 consecutive slots)
+constexpr int kMergeTile = 2048;      // pairs per workgroup of the merge kernel (256 threads x 8)
+
+__global__ __launch_bounds__(256) void repair_count_kernel(const uint32_t *__restrict__ key_new, const uint32_t *__restrict__ key_prev,
+                                                           long long n, uint32_t *__restrict__ tile_count) {
+  __shared__ uint32_t wsum[4];
+  const long long base = (long long) blockIdx.x * kRepairTile + 4 * threadIdx.x;
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (base + k < n)
+      c += key_new[base + k] != key_prev[base + k];
+  uint32_t total;
+  (void) block_exclusive_scan(c, wsum, &total);
+  if (threadIdx.x == 0)
+    tile_count[blockIdx.x] = total;
+}
+
+// counts[0 .. ntiles) -> exclusive prefix in place; nm[0] = their sum (the movers), nm[1] = n - sum (the stayers)
+__global__ __launch_bounds__(1024) void repair_scan_kernel(uint32_t *__restrict__ counts, int ntiles, long long n,
+                                                           uint32_t *__restrict__ nm) {
+  __shared__ uint32_t wsum[16];
+  const int per = (ntiles + 1023) / 1024;
+  const int first = threadIdx.x * per;
+  uint32_t sum = 0;
+  for (int k = first; k < first + per && k < ntiles; k++)
+    sum += counts[k];
+  uint32_t total;
+  uint32_t off = block_exclusive_scan(sum, wsum, &total);
+  for (int k = first; k < first + per && k < ntiles; k++) {
+    const uint32_t c = counts[k];
+    counts[k] = off;
+    off += c;
+  }
+  if (threadIdx.x == 0) {
+    nm[0] = total;
+    nm[1] = (uint32_t) (n - (long long) total);
+  }
+}
+
+__global__ __launch_bounds__(256) void repair_split_kernel(const uint32_t *__restrict__ key_new, const uint32_t *__restrict__ key_prev,
+                                                           long long n, const uint32_t *__restrict__ tile_offset,
+                                                           uint32_t *__restrict__ mk, int *__restrict__ mi,
+                                                           uint32_t *__restrict__ sk, int *__restrict__ si) {
+  __shared__ uint32_t wsum[4];
+  const long long tile0 = (long long) blockIdx.x * kRepairTile;
+  const long long base = tile0 + 4 * threadIdx.x;
+  uint32_t key[4];
+  bool mover[4];
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    key[k] = base + k < n ? key_new[base + k] : 0u;
+    mover[k] = base + k < n && key[k] != key_prev[base + k];
+    c += mover[k];
+  }
+  uint32_t total;
+  const uint32_t before = block_exclusive_scan(c, wsum, &total);      // movers of this tile in front of the thread's slots
+  uint32_t m = tile_offset[blockIdx.x] + before;                       // ... of the whole sequence
+  uint32_t st = (uint32_t) (base - (long long) m);                     // stayers in front = slots in front - movers in front
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (base + k >= n)
+      break;
+    if (mover[k]) {
+      mk[m] = key[k];
+      mi[m] = (int) (base + k);
+      m++;
+    } else {
+      sk[st] = key[k];
+      si[st] = (int) (base + k);
+      st++;
+    }
+  }
+}
+
+__device__ __forceinline__ uint64_t key_slot(const uint32_t *__restrict__ k, const int *__restrict__ i, uint32_t at) {
+  return ((uint64_t) k[at] << 32) | (uint32_t) i[at];
+}
+
+// number of elements taken from A (the stayers) among the first d of the merged sequence
+__device__ __forceinline__ uint32_t merge_diagonal(const uint32_t *__restrict__ ak, const int *__restrict__ ai, uint32_t na,
+                                                   const uint32_t *__restrict__ bk, const int *__restrict__ bi, uint32_t nb,
+                                                   uint32_t d) {
+  uint32_t lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (key_slot(ak, ai, mid) < key_slot(bk, bi, d - 1 - mid))
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void repair_merge_kernel(const uint32_t *__restrict__ sk, const int *__restrict__ si,
+                                                           const uint32_t *__restrict__ mk, const int *__restrict__ mi,
+                                                           const uint32_t *__restrict__ nm, long long n,
+                                                           uint32_t *__restrict__ keys_out, int *__restrict__ vals_out) {
+  __shared__ uint64_t s_pair[kMergeTile];
+  __shared__ uint32_t s_split[2];
+  const uint32_t nb = nm[0], na = nm[1];
+  const uint32_t d0 = (uint32_t) blockIdx.x * kMergeTile;
+  if ((long long) d0 >= n)
+    return;
+  const uint32_t d1 = (uint32_t) ((long long) d0 + kMergeTile < n ? d0 + kMergeTile : n);
+  if (threadIdx.x < 2)
+    s_split[threadIdx.x] = merge_diagonal(sk, si, na, mk, mi, nb, threadIdx.x == 0 ? d0 : d1);
+  __syncthreads();
+  const uint32_t a0 = s_split[0], a1 = s_split[1], b0 = d0 - a0, b1 = d1 - a1;
+  const uint32_t la = a1 - a0, lb = b1 - b0;          // la + lb = d1 - d0 <= kMergeTile
+  // the two sub-ranges side by side in LDS: [0, la) from the stayers, [la, la + lb) from the movers
+  for (uint32_t j = threadIdx.x; j < la; j += 256)
+    s_pair[j] = key_slot(sk, si, a0 + j);
+  for (uint32_t j = threadIdx.x; j < lb; j += 256)
+    s_pair[la + j] = key_slot(mk, mi, b0 + j);
+  __syncthreads();
+  // every thread merges eight consecutive results: its own diagonal inside the tile, then a serial merge
+  constexpr int kPer = kMergeTile / 256;
+  const uint32_t t0 = (uint32_t) threadIdx.x * kPer;
+  if (t0 >= la + lb)
+    return;
+  uint32_t lo = t0 > lb ? t0 - lb : 0u, hi = t0 < la ? t0 : la;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (s_pair[mid] < s_pair[la + (t0 - 1 - mid)])
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  uint32_t ia = lo, ib = t0 - lo;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    if (t0 + k >= la + lb)
+      break;
+    const bool take_a = ib >= lb || (ia < la && s_pair[ia] < s_pair[la + ib]);
+    const uint64_t v = take_a ? s_pair[ia] : s_pair[la + ib];
+    ia += take_a;
+    ib += !take_a;
+    keys_out[d0 + t0 + k] = (uint32_t) (v >> 32);
+    vals_out[d0 + t0 + k] = (int) (uint32_t) v;
+  }
+}
+
 // Fused re-ordering of every per-particle array in one pass.
 //   gather : out[i] = in[perm[i]]     (module_sort_help, mptrac.c:5944-5949,
 //                                      and the internal locality order)

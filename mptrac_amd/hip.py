@@ -364,6 +364,13 @@ class Simulation:
         self._chk(self.L.mphip_get_sort(self.h, _ptr(keys, _dp), _ptr(perm, C.POINTER(C.c_int))))
         return keys, perm
 
+    def get_sort(self):
+        """Sorted keys and permutation of the last module_sort (mphip_get_sort), without sorting again."""
+        keys = np.empty(self.n)
+        perm = np.empty(self.n, dtype=np.int32)
+        self._chk(self.L.mphip_get_sort(self.h, _ptr(keys, _dp), _ptr(perm, C.POINTER(C.c_int))))
+        return keys, perm
+
     def grid_sums(self, t, out=None):
         """Counts, sums of q and of q^2 per output cell (mphip_grid_sums).  `out` = (cnt, mean, sigma) of an
         earlier call: the arrays are filled again instead of allocated (a caller that writes one output after the

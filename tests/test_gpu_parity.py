@@ -295,6 +295,38 @@ def test_lean_boundary_layer_closure_equals_the_general_code(case, advect):
     assert np.count_nonzero(runs[0]["uvwp"][:, 2]) > 1000
 
 
+@pytest.mark.parametrize("n", [20011, 300000])
+def test_module_sort_by_order_repair_equals_the_sort_from_scratch(n):
+    """module_sort in every step: the sort that runs ahead repairs the order of the previous one (stayers / movers /
+    merge) -- same keys and permutation as the stable sort from scratch, hence the same bits everywhere (random numbers
+    follow the slots); checked against the run without the repair, against the oracle, and the last sort's keys and
+    permutation against the oracle's (ties by index)."""
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=n)
+    ctl.update(sort_dt=180.0, mixing_dt=180.0)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    runs = []
+    times = cases.step_times(o.ctl)[:9]
+    for repair in (1, 0):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("sort_repair", repair)
+        s.timesteps_init(0.0, 0.0)
+        for t in times:
+            s.run_timestep(t)
+        runs.append(s.state())
+        runs[-1]["ctr"] = s.get_cache()["rng_ctr"]
+        if repair:
+            keys, perm = s.get_sort()
+        s.close()
+    for k in ("time", "lon", "lat", "p", "q", "uvwp"):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+    for t in times[:-1]:
+        o.run_timestep(t)
+    # the sort of the last step on the oracle: keys / permutation of module_sort at that time, then the rest of the step
+    ko, po = o.sort()
+    assert np.array_equal(keys, ko[po]) and np.array_equal(perm, po)
+
+
 def test_deposition_factors_beside_mixing_equal_the_launch_behind_it():
     """Option depo_beside_mixing: module_wet_depo / module_dry_depo of a mixing step as factors computed beside
     module_mixing (own stream) and applied behind the relaxation -- the bits of the deposition launch behind it."""
