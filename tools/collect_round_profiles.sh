@@ -27,3 +27,7 @@ timeout 600 bash tools/profile_ml.sh ${T}z > gpurun_out/${T}_ml_counters.txt 2>&
 timeout 900 python tools/gpu_config_matrix.py big_grid=1 > gpurun_out/${T}_config_matrix_big.txt 2>&1
 timeout 300 python tools/gpu_ml_subsets.py > gpurun_out/${T}_ml_subsets.txt 2>&1
 timeout 300 python tools/gpu_sparse_schedule.py > gpurun_out/${T}_sparse_schedule.txt 2>&1
+# HBM counters of every kernel of the workloads with several kernels per step / other step kernels (bench.py quotes them)
+timeout 1500 bash tools/profile_traffic.sh $T C5 C3z C2 C3m C3p > gpurun_out/${T}_traffic_all.log 2>&1
+timeout 300 python bench.py --workload C3p --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3p.json
+timeout 300 python tools/gpu_pbl_cost.py > gpurun_out/${T}_pbl_cost.txt 2>&1

@@ -13,7 +13,7 @@ cp $G/prof_${T}mem/summary.txt $P/${T}_c3_mempipe_summary.txt
 for w in C5 C3z C3m C2; do
   cp $(ls $G/prof_${T}_$w/*kernel_stats.csv $G/prof_${T}_$w/*/*kernel_stats.csv 2>/dev/null | head -1) $P/${T}_$(echo $w | tr A-Z a-z)_kernel_stats.csv
 done
-for w in C1 C2 C3 C3_1e5 C3_1e6 C3_1e8 C3_driver_args C3_one_launch_per_step C3m C3x C3z C5; do
+for w in C1 C2 C3 C3_1e5 C3_1e6 C3_1e8 C3_driver_args C3_one_launch_per_step C3m C3x C3z C3p C5; do
   [ -s $G/${T}_bench_$w.json ] && tail -1 $G/${T}_bench_$w.json > $P/${T}_bench_$(echo $w | tr A-Z a-z).json
 done
 cp $G/${T}_config_matrix.txt $P/${T}_config_matrix.txt
@@ -25,6 +25,27 @@ cp $G/${T}_sustained_480_steps.txt $P/${T}_sustained_480_steps.txt
 [ -s $G/${T}_ml_counters.txt ] && cp $G/${T}_ml_counters.txt $P/${T}_c3z_sq_counters.txt
 cp $G/prof_${T}pieces/piece_cost.txt $P/${T}_piece_costs.txt
 python $R/tools/update_pmc_traffic.py $G/prof_$T C3 profiles/${T}_c3_summary.txt > /dev/null
+[ -s $G/${T}_pbl_cost.txt ] && cp $G/${T}_pbl_cost.txt $P/${T}_pbl_cost.txt
+# the other workloads: HBM bytes per time step over ALL their kernels (tools/profile_traffic.sh, tools/traffic_all.py)
+python - <<PY
+import json, os
+f = "$P/pmc_traffic.json"
+d = json.load(open(f))
+how = {}
+for w in ("C5", "C3z", "C2", "C3m", "C3p"):
+    t = "$G/traffic_${T}_%s/traffic.json" % w
+    s = "$G/traffic_${T}_%s/summary.txt" % w
+    if os.path.exists(t):
+        d[w] = json.load(open(t))["traffic_bytes_per_step"]
+        how[w] = "profiles/${T}_traffic_%s.txt" % w.lower()
+        if os.path.exists(s):
+            open("$P/${T}_traffic_%s.txt" % w.lower(), "w").write(open(s).read())
+d["_how_other_workloads"] = ("FETCH_SIZE x the same calibration factor + WRITE_SIZE summed over EVERY kernel of the timed "
+                             "region of bench.py --steps 10 (step kernels, module_sort, module_mixing, deposition, gridded "
+                             "output), per time step (tools/profile_traffic.sh, tools/traffic_all.py): " + json.dumps(how))
+json.dump(d, open(f, "w"), indent=1)
+PY
+python $R/tools/alu_model.py $P/${T}_c3_instruction_mix.txt C3 > /dev/null
 python - <<PY
 import json
 d = json.load(open("$P/pmc_traffic.json"))
