@@ -205,17 +205,6 @@ __device__ __forceinline__ double fdiv(double a, double b) {
 #endif
 }
 
-// 1 / b to an ulp or two (v_rcp_f64 + one Newton step + a residual correction)
-__device__ __forceinline__ double frcp_newton(double b) {
-#if MPHIP_EXACT_DIV
-  return 1.0 / b;
-#else
-  double r = __builtin_amdgcn_rcp(b);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-  return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-#endif
-}
-
 __device__ __forceinline__ double fsqrt(double x) {
 #if MPHIP_EXACT_DIV
   return sqrt(x);
@@ -3100,14 +3089,18 @@ struct PblTurbulence {   // component 0 / 1 / 2: along x, along y, vertical
   double dsigma_w;       // d sigma_w / dz [1/s]
 };
 
+// (The perturbations are stored in single precision: a difference in the last bits of the double that is rounded to
+// them can flip a float, and the 1e-7 of that flip is what the positions then inherit.  The expressions below therefore
+// keep the reference's operands and IEEE divisions / square roots wherever a value feeds the perturbations; the
+// restructuring is in what is evaluated, not in how a value is rounded.)
 // mptrac.c:4439-4449
 __device__ __forceinline__ void hanna_neutral(const PblLayer &L, const PblScales &K, PblTurbulence &T) {
-  const double x = fdiv(L.h1, K.ustar);
+  const double x = L.h1 / K.ustar;
   const double sw = 1.3 * K.ustar * exp(-2e-4 * x);
   T.sigma[0] = dmax(2.0 * K.ustar * exp(-3e-4 * x), 1e-5);
   T.sigma[1] = T.sigma[2] = dmax(sw, 1e-5);
-  T.dsigma_w = -2e-4 * x * fdiv(sw, L.h1);        // -2e-4 sw / u* with 1 / u* = x / h1
-  T.tl[0] = T.tl[1] = T.tl[2] = fdiv(0.5 * L.h1, T.sigma[2] * (1.0 + 1.5e-3 * x));
+  T.dsigma_w = -2e-4 * sw / K.ustar;
+  T.tl[0] = T.tl[1] = T.tl[2] = 0.5 * L.h1 / T.sigma[2] / (1.0 + 1.5e-3 * x);
 }
 
 // mptrac.c:4451-4510.  sigma_w / w* over the relative height eta is piecewise c B^e:
@@ -3118,9 +3111,8 @@ __device__ __forceinline__ void hanna_neutral(const PblLayer &L, const PblScales
 // and D / w*^2 d(sigma_w^2)/dz has the same shape with (1.8432, -1/3), (0.203759, -0.65), (-0.215812, -0.586), 0.
 __device__ __forceinline__ void hanna_convective(const PblLayer &L, const PblScales &K, PblTurbulence &T) {
   const double third = 1.0 / 3.0;
-  const double l_over_d = fdiv(K.obukhov, L.depth);          // (negative)
-  T.sigma[0] = T.sigma[1] = dmax(K.ustar * cbrt(dmax(12.0 - fdiv(0.5, l_over_d), 0.0)), 1e-6);
-  const double log_free = log(dmax(3.0 * L.eta - l_over_d, 1e-12));
+  T.sigma[0] = T.sigma[1] = dmax(K.ustar * cbrt(dmax(12.0 - 0.5 * L.depth / K.obukhov, 0.0)), 1e-6);
+  const double log_free = log(dmax(3.0 * L.eta - K.obukhov / L.depth, 1e-12));
   // log(0.96), log(0.763): the two candidates below eta = 0.4 compared without evaluating them
   const bool free_smaller = -0.040821994520255166 + third * log_free < -0.27049724769768 + 0.175 * L.log_eta;
   const bool free = (L.eta < 0.03) | ((L.eta < 0.4) & free_smaller);
@@ -3131,11 +3123,10 @@ __device__ __forceinline__ void hanna_convective(const PblLayer &L, const PblSca
                c_g = low ? (free ? 1.8432 : 0.203759) : (mid ? -0.215812 : 0.0);
   const double shape = c_s * exp(e_s * lb), slope = c_g * exp(e_g * lb);
   T.sigma[2] = dmax(K.wstar * shape, 1e-6);
-  const double inv_sw = frcp_newton(T.sigma[2]);
-  T.dsigma_w = 0.5 * fdiv(slope * (K.wstar * K.wstar), L.depth) * inv_sw;
-  T.tl[0] = T.tl[1] = fdiv(0.15 * L.depth, T.sigma[0]);
-  const double near_ground = fdiv(0.1 * L.h1 * inv_sw, dmax(0.55 - 0.38 * fabs(fdiv(L.h1, K.obukhov)), 0.05));
-  const double aloft = L.eta < 0.1 ? 0.59 * L.h1 * inv_sw : 0.15 * L.depth * inv_sw * (1.0 - exp(-5.0 * L.eta));
+  T.dsigma_w = 0.5 * (slope * (K.wstar * K.wstar) / L.depth) / T.sigma[2];
+  T.tl[0] = T.tl[1] = 0.15 * L.depth / T.sigma[0];
+  const double near_ground = 0.1 * L.h1 / (T.sigma[2] * dmax(0.55 - 0.38 * fabs(L.h1 / K.obukhov), 0.05));
+  const double aloft = L.eta < 0.1 ? 0.59 * L.h1 / T.sigma[2] : 0.15 * L.depth / T.sigma[2] * (1.0 - exp(-5.0 * L.eta));
   T.tl[2] = L.h1 < fabs(K.obukhov) ? near_ground : aloft;
 }
 
@@ -3144,10 +3135,10 @@ __device__ __forceinline__ void hanna_stable(const PblLayer &L, const PblScales 
   const double fade = 1.0 - L.eta;
   T.sigma[0] = dmax(2.0 * K.ustar * fade, 1e-6);
   T.sigma[1] = T.sigma[2] = dmax(1.3 * K.ustar * fade, 1e-6);
-  T.dsigma_w = -1.3 * fdiv(K.ustar, L.depth);
-  T.tl[0] = fdiv(0.15 * L.depth, T.sigma[0]) * fsqrt(L.eta);
+  T.dsigma_w = -1.3 * K.ustar / L.depth;
+  T.tl[0] = 0.15 * L.depth / T.sigma[0] * sqrt(L.eta);
   T.tl[1] = 0.467 * T.tl[0];
-  T.tl[2] = fdiv(0.1 * L.depth, T.sigma[2]) * exp(0.8 * L.log_eta);
+  T.tl[2] = 0.1 * L.depth / T.sigma[2] * exp(0.8 * L.log_eta);
 }
 
 // LEAN: the stencils and gathers of the lean kernels (lat/lon grid with the pressure table, 32-bit offsets)
@@ -3175,14 +3166,14 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   ps = LEAN ? pair_time_2d_fast(sa, col, wt, 0) : sfa_time_2d(sa, col, wt, 0);
   if (!(ps > 0.0 && pbl > 0.0 && ps > pbl))
     return;
-  // heights above ground from pressure ratios: Z(p) - Z(ps) = H0 log(ps / p) (mptrac.h:2243)
   const double p_in = dmin(P.p, ps);
+  const double ground_km = zfromp(ps);
   PblLayer L;
-  L.depth = 1e3 * kH0 * log(fdiv(ps, pbl));
+  L.depth = 1e3 * (zfromp(pbl) - ground_km);
   if (!(L.depth > 1.0))
     return;
-  L.h = clampd(1e3 * kH0 * log(fdiv(ps, p_in)), 0.0, L.depth);
-  L.eta = clampd(fdiv(L.h, L.depth), 1e-6, 1.0 - 1e-6);
+  L.h = clampd(1e3 * (zfromp(p_in) - ground_km), 0.0, L.depth);
+  L.eta = clampd(L.h / L.depth, 1e-6, 1.0 - 1e-6);
   L.h1 = dmax(L.h, 1.0);
   L.log_eta = log(L.eta);
 
@@ -3202,22 +3193,20 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
     t = temp_time_3d(M, cell, wt);
   }
   h2o = pair_time_3d(M.h2o, M, cell, wt);
-  const double moist = 1. + (1. - kEps) * dmax(h2o, 0.1e-6);     // TVIRT's factor, mptrac.h:2199
-  const double rho = rho_air(p_in, t * moist);
+  const double rho = rho_air(p_in, tvirt(t, h2o));
   if (!(rho > 0.0))
     return;
-  const double theta_v = t * exp(kKappa * log(fdiv(1000., p_in))) * moist;   // THETAVIRT, mptrac.h:2153
+  const double theta_v = tvirt(t * pow(1000. / p_in, kKappa), dmax(h2o, 0.1e-6));   // THETAVIRT, mptrac.h:2153
   PblScales K;
-  const double inv_rho = frcp_newton(rho);
-  K.ustar = dmax(1e-4, fsqrt(dmax(fsqrt(stress_x * stress_x + stress_y * stress_y) * inv_rho, 0.0)));
-  K.obukhov = fabs(heat_flux) > 1e-6 ? fdiv(theta_v * rho * kCpd * (K.ustar * K.ustar) * K.ustar, kKarman * kG0 * heat_flux) : 1e12;
+  K.ustar = dmax(1e-4, sqrt(dmax(sqrt(stress_x * stress_x + stress_y * stress_y) / rho, 0.0)));
+  K.obukhov = fabs(heat_flux) > 1e-6 ? theta_v * rho * kCpd * (K.ustar * K.ustar) * K.ustar / (kKarman * kG0 * heat_flux) : 1e12;
 
   // (3) the class (mptrac.c:4438-4523): neutral while the layer is shallower than |L|, else by the sign of L
   PblTurbulence T;
   if (L.depth < fabs(K.obukhov))
     hanna_neutral(L, K, T);
   else if (K.obukhov < 0.0) {
-    K.wstar = cbrt(dmax(fdiv(-kG0 * heat_flux * L.depth * inv_rho, theta_v * kCpd), 0.0));
+    K.wstar = cbrt(dmax(-kG0 / theta_v * heat_flux / (rho * kCpd) * L.depth, 0.0));
     hanna_convective(L, K, T);
   } else
     hanna_stable(L, K, T);
@@ -3238,10 +3227,10 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   const double dt = P.dt, span = fabs(P.dt);
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const double keep = exp(-fdiv(span, T.tl[k]));
-    double v = vel[k] * keep + T.sigma[k] * fsqrt(dmax(0.0, 1.0 - keep * keep)) * xi[k];
+    const double keep = exp(-span / T.tl[k]);
+    double v = vel[k] * keep + T.sigma[k] * sqrt(dmax(0.0, 1.0 - keep * keep)) * xi[k];
     if (k == 2)   // drift of the vertical component: well-mixed condition + density gradient -1 / H
-      v += T.tl[2] * (1.0 - keep) * (2.0 * T.sigma[2] * T.dsigma_w - T.sigma[2] * T.sigma[2] * (1.0 / (1e3 * kH0)));
+      v += T.tl[2] * (1.0 - keep) * (2.0 * T.sigma[2] * T.dsigma_w + (-1.0 / (1e3 * kH0)) * (T.sigma[2] * T.sigma[2]));
     vel[k] = (double) (float) v;      // (the perturbations are stored in single precision, mptrac.h:3633)
   }
   P.lon += dx2coord(M.coord_type, vel[0] * dt, P.lat);
@@ -3257,8 +3246,7 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   up = (float) vel[0];
   vp = (float) vel[1];
   wp = flipped ? -(float) vel[2] : (float) vel[2];
-  // P(Z(ps) + h) = ps exp(-h / H0) (mptrac.h:1784, 2243)
-  P.p = clampd(ps * exp(h * (-1.0 / (1e3 * kH0))), pbl, ps);
+  P.p = clampd(kP0 * exp(-(ground_km + h / 1000.0) / kH0), pbl, ps);   // P(z), mptrac.h:1784
 }
 
 // The closure as a function call.  Inlined into the fused step kernel its registers push the whole kernel into scratch

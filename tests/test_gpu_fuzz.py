@@ -79,6 +79,13 @@ def draw(seed):
         tables["oh"] = refclim.synthetic_zonal_mean(seed, scale=1e-13)
         tables["ho2"] = refclim.synthetic_zonal_mean(seed + 1, np_=7, nlat=13, scale=1e-12)
         ctl.update(oh_chem_beta=float(r2.choice([0.0, 0.6])))
+    # (round 5, drawn last so that every earlier draw of a seed stays what it was) module_sort / module_mixing in EVERY
+    # step: the sort that runs ahead then repairs the previous order
+    if r2.random() < 0.3:
+        if "sort_dt" in ctl:
+            ctl["sort_dt"] = ctl["dt_mod"]
+        if "mixing_dt" in ctl and r2.random() < 0.5:
+            ctl["mixing_dt"] = ctl["dt_mod"]
     ctl["_tables"] = tables
     ctl.update(ctl_from_quantities(names), advect_vert_coord=vert)
     if not sedi:
