@@ -214,9 +214,10 @@ def multi_gpu_probe(args):
     part of `value`; None on a one-GPU box."""
     import subprocess
     ndev = visible_gpus()
-    if ndev < 2:
+    forced = os.environ.get("MPTRAC_PROBE_RANKS")      # (dry run of this path on a one-GPU box: MPTRAC_PROBE_RANKS=1)
+    if ndev < 2 and not forced:
         return None
-    n = min(8, ndev)
+    n = int(forced) if forced else min(8, ndev)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__), "--gpus", str(n),
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--no-cpu-baseline"]

@@ -11,7 +11,10 @@ Prints the relative deviations on the way; fails above the 1e-10 bar.
                                        after a meteo hand-over points into fields that have changed
   python tools/gpu_soak.py fullbatched the full module set (module_sort every 1800 s, mixing every 900 s, module_meteo
                                        quantities) handed over twenty steps at a time: launches are shared between
-                                       the steps at which the sort or the mixing is due"""
+                                       the steps at which the sort or the mixing is due
+  python tools/gpu_soak.py everystep   the full module set with module_sort and module_mixing in EVERY step (the schedule of
+                                       BASELINE configs[4]): the sort that runs ahead repairs the previous order 400 times
+                                       in a row, across the meteo hand-overs"""
 import os
 import sys
 import time
@@ -29,6 +32,7 @@ from oracle import binding as B  # noqa: E402
 
 zeta = "zeta" in sys.argv[1:]
 fullbatched = "fullbatched" in sys.argv[1:]
+everystep = "everystep" in sys.argv[1:]
 batched = "batched" in sys.argv[1:] or zeta or fullbatched
 if fullbatched:
     names = ("m", "vmr", "rp", "rhop", "loss_rate", "mloss_decay", "mloss_wet", "mloss_dry", "aoa", "t", "u", "ps", "theta")
@@ -50,6 +54,8 @@ else:
     ctl = dict(cases.CASES["full"])
     ctl.update(ctl_from_quantities(names))
     ctl.update(t_stop=4 * 18000.0, dt_met=18000.0, met_dt_out=0.1, sort_dt=1800.0, mixing_dt=900.0)
+    if everystep:
+        ctl.update(sort_dt=ctl["dt_mod"], mixing_dt=ctl["dt_mod"])
 fields = None if zeta else tuple(cases.PRESSURE_LEVEL_FIELDS) + tuple(FIELDS_METEO_ONLY)   # (None: model-level fields too)
 mets = [synthetic_met("C1", 18000.0 * k, 1.0 + 0.1 * k, fields=fields) for k in range(6)]
 atm = synthetic_particles(100000, seed=7, quantities=names)
