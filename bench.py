@@ -223,9 +223,9 @@ def multi_gpu_probe(args):
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--workload", args.workload, "--no-cpu-baseline"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     try:
-        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
     except subprocess.TimeoutExpired:
-        return {"n_gpus": n, "error": "timeout after 900 s"}
+        return {"n_gpus": n, "error": "timeout after 420 s"}
     lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
     if res.returncode != 0 or len(lines) != 1:
         return {"n_gpus": n, "error": res.stderr.decode()[-800:]}
