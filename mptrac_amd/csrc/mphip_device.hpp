@@ -1835,13 +1835,32 @@ __device__ __forceinline__ f32x4u window_record(const float *__restrict__ h2, CO
 }
 
 // stencil_4d on a packed height field; `hint` is any earlier vertical index (e.g. of the previous stage)
+#ifndef MPHIP_ML_HORIZ_FAST
+#define MPHIP_ML_HORIZ_FAST 1
+#endif
+__device__ __forceinline__ bool lat_fast(const DevMet &M, const Axes &A, double lat2, int &iy, double &y1, double &yinv);
 template <class COL = size_t>
 __device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, const float *__restrict__ h2, double ts,
                                                 double height, double lon, double lat, int hint, Stencil4 &s) {
   double lon2, lat2;
-  check_horizontal(M, A, lon, lat, lon2, lat2);
-  const AxisHit hy = hit_lat(M, A, lat2);
-  s.ix = locate_lon(M, A, lon2);
+  AxisHit hy;
+  bool guessed = false;
+#if MPHIP_ML_HORIZ_FAST
+  if constexpr (std::is_same<COL, uint32_t>::value) {
+    // the lean instantiations (32-bit columns: a lat/lon grid with the look-up tables, launch_step): the horizontal
+    // indices from verified guesses, as the pressure-level kernels take them (lon_fast / lat_fast)
+    lat2 = vmin_s(vmax_s(lat, M.latmin), M.latmax);
+    lon2 = lon + (lon < M.lon_first ? 360.0 : (lon > M.lon_last ? -360.0 : 0.0));
+    s.ix = clamp0_s((int) ((lon2 - M.lon_first) * M.inv_dlon0), M.nx - 2);
+    guessed = (fabs(lon) < 360.0) & lat_fast(M, A, lat2, hy.i, hy.x1, hy.inv);
+    hy.x0 = A.lat[hy.i];
+  }
+#endif
+  if (!guessed) {
+    check_horizontal(M, A, lon, lat, lon2, lat2);
+    hy = hit_lat(M, A, lat2);
+    s.ix = locate_lon(M, A, lon2);
+  }
   s.iy = hy.i;
   const int n = M.npl;
   const COL c00 = col_ml_as<COL>(M, s.ix, s.iy), c10 = col_ml_as<COL>(M, s.ix + 1, s.iy),
