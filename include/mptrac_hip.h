@@ -365,6 +365,9 @@ int mphip_comm_query(mphip_ctx *ctx, int *nranks, int *rank);
  *   "sum_path" (default 0 = by crowding; 1, 2): tests -- force the group / the chain algorithm of the ordered sums;
  *   "chain_blocks": tuning -- workgroups of the chain walk of the ordered sums;
  *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel;
+ *   "lds_tile" (default 0 = off; 64 ... 2400): cells of an LDS tile of wind records that runs of pure trajectory steps
+ *     (mphip_run_timesteps with module_timesteps, module_position, module_advect only) stage per workgroup; same results,
+ *     measured slower than the default gathers;
  *   "sort_repair" (default 1): the module_sort that runs ahead repairs the order of the previous module_sort (only the
  *     particles that changed their cell are sorted, then merged with the others) instead of sorting from scratch; same
  *     permutation;

@@ -187,6 +187,8 @@ struct mphip_ctx {
   int sorted_buf = -1;                // which d_keys/d_vals pair holds the last result
   // module_sort as a repair of the previous order (repair_* kernels): valid while the particles are stored in the order
   // of the last module_sort (stored_is_sorted) -- its sorted keys are then non-decreasing along the slots
+  // option "lds_tile": cells of the LDS wind tile of traj_tile_kernel (0: off); runs of pure trajectory steps only
+  int lds_tile = 0;
   bool sort_repair = true;            // option "sort_repair"
   bool ahead_priority = false;        // option "ahead_priority": the stream of the sort ahead at the highest priority (C5: no difference, profiles/r05_variants.txt item 3)
   bool stored_is_sorted = false;
@@ -933,6 +935,21 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     if (ctx->prof)
       HIPCHK(hipEventRecord(e1, ctx->stream));
     return 0;
+  }
+  // pure trajectories, several steps per launch: the kernel that stages the wind grid through an LDS tile (option lds_tile)
+  if (ctx->lds_tile > 0 && nsteps > 1 && (sel == (kAdv | kMultiStep) || sel == (kAdv | kTwoStage | kMultiStep))
+      && !(mask & (kTailModules | kBound)) && !ctx->fused_perm) {
+    const size_t tile_lds = ((axes_lds_bytes(ctx) + 15) & ~(size_t) 15) + (size_t) ctx->lds_tile * 24;
+    if (tile_lds <= 64 * 1024) {
+      if (sel & kTwoStage)
+        hipLaunchKernelGGL(traj_tile_kernel<2>, dim3(nb), dim3(256), tile_lds, ctx->stream, S, ctx->lds_tile);
+      else
+        hipLaunchKernelGGL(traj_tile_kernel<4>, dim3(nb), dim3(256), tile_lds, ctx->stream, S, ctx->lds_tile);
+      HIPCHK(hipGetLastError());
+      if (ctx->prof)
+        HIPCHK(hipEventRecord(e1, ctx->stream));
+      return 0;
+    }
   }
   switch (sel) {
 #define STEP_CASE(M)                                                                                  \
@@ -3405,6 +3422,12 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (!(value == 0 || (value >= 8 && value <= kRadixMaxBits)))
       return fail(ctx, "sort_bits must be 0 (automatic), 8, 9 or 10");
     ctx->sort_bits = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "lds_tile") == 0) {   // cells of the LDS wind tile for runs of pure trajectory steps (24 bytes each; 0: off)
+    if (value != 0 && (value < 64 || value > 2400))
+      return fail(ctx, "lds_tile must be 0 or 64 ... 2400 cells");
+    ctx->lds_tile = (int) value;
     return 0;
   }
   if (strcmp(name, "ahead_priority") == 0) {   // (before the first sort ahead: the stream is created then)

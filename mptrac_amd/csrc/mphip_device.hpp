@@ -2591,13 +2591,55 @@ __device__ __forceinline__ T load_at64(const void *base, uint64_t byte_offset) {
   return *(const T *) ((const char *) base + byte_offset);
 }
 
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+// A box of wind records staged in LDS (north_star's "met grids staged through LDS tiles per thread-block", SURVEY x1;
+// traj_tile_kernel): columns [x0, x0 + nx) x [y0, y0 + ny), levels [z0, z0 + nz), level index fastest as in the grid.
+struct WindTile {
+  const float *rec;   // 6 floats per cell {u0,v0,u1,v1,w0,w1}
+  int x0, y0, z0, nx, ny, nz;
+};
+
 template <bool BIG = false>
-__device__ __forceinline__ void load_wind_cached32(const DevMet &M, const Stencil &s, WindCache &w) {
+__device__ __forceinline__ void load_wind_cached32(const DevMet &M, const Stencil &s, WindCache &w,
+                                                   const WindTile *tile = nullptr) {
   if constexpr (BIG) {   // 64-bit addresses per lane: the gather of the general kernels
     load_wind_cached(M, s, w);
     return;
   }
   if (s.ix != w.ix || s.iy != w.iy || s.ip != w.ip) {
+    if (tile) {   // (a compile-time null in every kernel but the one that stages a tile)
+      const int tx = s.ix - tile->x0, ty = s.iy - tile->y0, tz = s.ip - tile->z0;
+      if (tx >= 0 && ty >= 0 && tz >= 0 && tx + 1 < tile->nx && ty + 1 < tile->ny && tz + 1 < tile->nz) {
+#pragma unroll
+        for (int di = 0; di < 2; di++)
+#pragma unroll
+          for (int dj = 0; dj < 2; dj++) {
+            // levels tz and tz + 1 of the column: twelve consecutive floats, 8-byte aligned
+            const f32x2s *q = (const f32x2s *) (tile->rec + 6 * (((tx + di) * tile->ny + ty + dj) * tile->nz + tz));
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              const f32x2s lo = q[2 * k], hi = q[2 * k + 1];
+              w.c.r[di][dj][k] = f32x4u{ lo[0], lo[1], hi[0], hi[1] };
+            }
+          }
+      } else {
+        // outside the tile: ordinary loads the compiler waits for by itself (the asynchronous gathers below rely on
+        // registers nobody else touches until wind_cache_wait -- not the case where a second path writes them)
+#pragma unroll
+        for (int di = 0; di < 2; di++)
+#pragma unroll
+          for (int dj = 0; dj < 2; dj++) {
+            const unsigned off = 24u * cell32(M, s, di, dj);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+              w.c.r[di][dj][k] = load_at<f32x4u>(M.wind, off + 16u * (unsigned) k);
+          }
+      }
+      w.ix = s.ix;
+      w.iy = s.iy;
+      w.ip = s.ip;
+      return;
+    }
 #pragma unroll
     for (int di = 0; di < 2; di++)
 #pragma unroll
@@ -2766,7 +2808,7 @@ __device__ __forceinline__ void position_fast(const DevMet &M, const Axes &A, Pa
 // from the control parameters), its first stage alone (ADVECT 1).  `hook(i)` runs behind the gathers of stage i.
 template <int STAGES, bool BIG = false, class Hook>
 __device__ __forceinline__ void advect_fast(const DevMet &M, const Axes &A, Particle &P, Hook &hook, WindCache &wc,
-                                            bool euler = false) {
+                                            bool euler = false, const WindTile *tile = nullptr) {
   const double dt = P.dt;
   const DegPerMetre dm = deg_per_metre(P.lat);   // every stage converts at the latitude the step starts from
   double u = 0, v = 0, w = 0, um = 0, vm = 0, wm = 0;
@@ -2788,7 +2830,7 @@ __device__ __forceinline__ void advect_fast(const DevMet &M, const Axes &A, Part
     __builtin_amdgcn_s_setprio(MPHIP_SETPRIO);   // a wave on its way to a gather round goes first
 #endif
     stencil_3d_fast(M, A, x2, x0, x1, s);
-    load_wind_cached32<BIG>(M, s, wc);
+    load_wind_cached32<BIG>(M, s, wc, tile);
 #if MPHIP_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif

@@ -871,6 +871,120 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
 }
 
 // ---------------------------------------------------------------------------
+// Trajectories with the wind grid staged through an LDS tile per workgroup (north_star: "the two bracketing met_t
+// pressure-level grids staged through LDS tiles per thread-block").  What it serves: runs of time steps
+// that are module_timesteps + module_position + module_advect only (pure trajectories, the reference's most common
+// use), handed over as one launch (mphip_run_timesteps).  A workgroup takes its particles 256 at a time; for each
+// round it finds the bounding box of the particles' stencil cells (wave reductions + LDS atomics), widens it by one
+// column / level on every side, stages that box of two-snapshot wind records once (cooperative, contiguous along the
+// levels; at most `tile_cells` records, levels cut first) and then lets every particle take ALL its steps: a
+// Runge-Kutta stage whose stencil lies inside the tile reads its eight corner records from LDS, any other one from
+// global memory as the other kernels do (load_wind_cached32).  Same arithmetic on the same records: the bits of the
+// kernels without a tile (test_lds_tile_trajectories_equal_the_launches_without_a_tile).  Option "lds_tile";
+// measured in profiles/r05_variants.txt item 6.
+// ---------------------------------------------------------------------------
+#ifndef MPHIP_TILE_WAVES_PER_SIMD
+#define MPHIP_TILE_WAVES_PER_SIMD 3   // 20 KB of axes + a 24 KB tile: three workgroups per CU
+#endif
+template <int STAGES>
+__global__ __launch_bounds__(256, MPHIP_TILE_WAVES_PER_SIMD) void traj_tile_kernel(const StepParams S, int tile_cells) {
+  extern __shared__ double s_axes[];
+  __shared__ int s_lo[3], s_hi[3];
+  const DevMet &M = S.met;
+  const DevAtm &a = S.atm;
+  const mphip_ctl_t &ctl = S.ctl;
+  const Axes A = load_axes(M, s_axes);
+  float *s_tile = (float *) (s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8);
+  const int nb = S.nblocks_logical;
+  const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
+  const long long first = (long long) lb * S.per_block;
+  long long last = first + S.per_block;
+  if (last > a.np)
+    last = a.np;
+  for (long long base = first; base < last; base += 256) {   // (block-uniform: every thread meets every barrier)
+    const long long i = base + threadIdx.x;
+    const bool live = i < last;
+    if (threadIdx.x < 3) {
+      s_lo[threadIdx.x] = 1 << 30;
+      s_hi[threadIdx.x] = -1;
+    }
+    __syncthreads();   // (also: the axes are in place / the tile of the round before is no longer read)
+    Particle P;
+    P.time = P.lon = P.lat = P.p = P.dt = 0;
+    int lo[3] = { 1 << 30, 1 << 30, 1 << 30 }, hi[3] = { -1, -1, -1 };
+    if (live) {
+      P.time = ld_state(&a.time[i]);
+      P.lon = ld_state(&a.lon[i]);
+      P.lat = ld_state(&a.lat[i]);
+      P.p = ld_state(&a.p[i]);
+      Stencil s0;
+      stencil_3d_fast(M, A, P.p, P.lon, P.lat, s0);   // the cell the first stage will start in
+      lo[0] = hi[0] = s0.ix;
+      lo[1] = hi[1] = s0.iy;
+      lo[2] = hi[2] = s0.ip;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      for (int sft = 32; sft > 0; sft >>= 1) {
+        lo[d] = min(lo[d], __shfl_xor(lo[d], sft));
+        hi[d] = max(hi[d], __shfl_xor(hi[d], sft));
+      }
+      if ((threadIdx.x & 63) == 0) {
+        atomicMin(&s_lo[d], lo[d]);
+        atomicMax(&s_hi[d], hi[d]);
+      }
+    }
+    __syncthreads();
+    WindTile T;
+    T.rec = s_tile;
+    T.x0 = max(s_lo[0] - 1, 0);
+    T.y0 = max(s_lo[1] - 1, 0);
+    T.z0 = max(s_lo[2] - 1, 0);
+    T.nx = min(s_hi[0] + 2, M.nx - 1) - T.x0 + 1;     // (+ 1: the upper corner of a stencil, + 1: the halo)
+    T.ny = min(s_hi[1] + 2, M.ny - 1) - T.y0 + 1;
+    T.nz = min(s_hi[2] + 2, M.np - 1) - T.z0 + 1;
+    if (T.nx * T.ny * 2 > tile_cells) {               // too many columns (a round across the date line ...): a part of them
+      const int side = max(2, (int) sqrtf((float) (tile_cells / 2)));
+      T.nx = min(T.nx, side);
+      T.ny = min(T.ny, max(2, tile_cells / 2 / T.nx));
+    }
+    T.nz = min(T.nz, tile_cells / (T.nx * T.ny));
+    {
+      const f32x2s *src = (const f32x2s *) M.wind;
+      f32x2s *dst = (f32x2s *) s_tile;
+      const int per_col = T.nz * 3, total = T.nx * T.ny * per_col;
+      for (int f = threadIdx.x; f < total; f += 256) {
+        const int col = f / per_col, within = f - col * per_col;
+        const int cx = col / T.ny, cy = col - cx * T.ny;
+        dst[f] = src[((size_t) (__umul24((unsigned) (T.x0 + cx), (unsigned) M.ny) + (unsigned) (T.y0 + cy)) * (size_t) M.np
+                      + (size_t) T.z0) * 3 + (size_t) within];
+      }
+    }
+    __syncthreads();
+    if (!live)
+      continue;
+    double t_now = S.t;
+    for (int step = 0; step < S.nsteps; step++, t_now += S.t_stride) {
+      P.dt = (S.mask & MPHIP_MOD_TIMESTEPS) ? timestep_of(ctl, M, A, P.time, P.lon, P.lat, t_now) : a.dt[i];
+      if ((S.mask & MPHIP_MOD_TIMESTEPS) && (S.mask & kStoreDt))
+        a.dt[i] = P.dt;
+      if (P.dt == 0)   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
+        continue;
+      WindCache wc;
+      wind_cache_reset(wc, true);
+      position_fast(M, A, P);
+      NoHook none;
+      advect_fast<STAGES, false>(M, A, P, none, wc, STAGES == 2 && ctl.advect == 1, &T);
+      position_fast(M, A, P);
+      st_state(&a.time[i], P.time);
+      st_state(&a.lon[i], P.lon);
+      st_state(&a.lat[i], P.lat);
+      st_state(&a.p[i], P.p);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Deposition launch (module_wet_depo and / or module_dry_depo alone: what follows module_mixing in a time step).
 // Most particles leave these modules at once -- above every cloud top, above the surface layer -- but in the
 // stored orders every wave holds a few that do not, and a wave pays for a gather round whatever the number of

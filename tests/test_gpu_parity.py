@@ -327,6 +327,48 @@ def test_module_sort_by_order_repair_equals_the_sort_from_scratch(n):
     assert np.array_equal(keys, ko[po]) and np.array_equal(perm, po)
 
 
+@pytest.mark.parametrize("advect", [4, 2, 1], ids=["rk4", "midpoint", "euler"])
+@pytest.mark.parametrize("tile", [1024, 96])
+def test_lds_tile_trajectories_equal_the_launches_without_a_tile(advect, tile):
+    """Option lds_tile (the wind grid staged through an LDS tile per workgroup, traj_tile_kernel): runs of
+    pure trajectory steps read their corner records from the tile where the stencil lies inside it and from global memory
+    otherwise -- the bits of the launches without a tile, and the oracle's positions; with particles across the date
+    line and at the poles, some of them released later, a tile far too small for a workgroup's box (96 cells), and the
+    internal re-sort in between."""
+    ctl, clim, m0, m1, atm = cases.make_case("advect", n=30011, fields=("u", "v", "w", "ps"), quantities=("m",))
+    ctl.update(advect=advect)
+    atm["lon"][:2000] = np.linspace(-180.0, 179.99, 2000)
+    atm["lat"][:1000] = 89.95
+    atm["lat"][1000:2000] = -89.95
+    atm["time"][::11] = 540.0
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    times = cases.step_times(o.ctl)[:14]
+    runs = []
+    for cells in (0, tile):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("lds_tile", cells)
+        s.set_option("locality_sort_interval", 5)
+        s.timesteps_init(atm["time"].min(), atm["time"].max())
+        s.run_timestep(times[0])
+        s.synchronize()
+        s.profile_begin()
+        s.run_timesteps(times[1], 4)
+        launches, _ = s.profile_end()
+        assert launches == 1
+        s.run_timesteps(times[5], 9)
+        runs.append(s.state())
+        s.close()
+    for k in ("time", "lon", "lat", "p", "q"):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+    for t in times:
+        o.run_timestep(t)
+    r = o.state()
+    assert np.array_equal(runs[1]["time"], r["time"])
+    for k in ("lon", "lat", "p"):
+        assert cases.rel_err(runs[1][k], r[k]) <= TOL, k
+
+
 def test_deposition_factors_beside_mixing_equal_the_launch_behind_it():
     """Option depo_beside_mixing: module_wet_depo / module_dry_depo of a mixing step as factors computed beside
     module_mixing (own stream) and applied behind the relaxation -- the bits of the deposition launch behind it."""
