@@ -365,6 +365,9 @@ int mphip_comm_query(mphip_ctx *ctx, int *nranks, int *rank);
  *   "sum_path" (default 0 = by crowding; 1, 2): tests -- force the group / the chain algorithm of the ordered sums;
  *   "chain_blocks": tuning -- workgroups of the chain walk of the ordered sums;
  *   "generic_kernel" (default 0): tuning aid, never pick a specialised kernel;
+ *   "mix_exchange_levels" (default 0): with several ranks, exchange the cell sums of module_mixing only for the band of
+ *     grid levels that holds particles on any rank (a small all-reduce of the per-level occupancy, read by the host, then
+ *     the band); same results, a third of the bytes on the default grid, one host synchronisation per mixing step;
  *   "lds_tile" (default 0 = off; 64 ... 2400): cells of an LDS tile of wind records that runs of pure trajectory steps
  *     (mphip_run_timesteps with module_timesteps, module_position, module_advect only) stage per workgroup; same results,
  *     measured slower than the default gathers;

@@ -222,6 +222,15 @@ struct mphip_ctx {
   size_t sums_cap = 0;
 
   int *d_cnt = nullptr;               // particles per mixing cell (32-bit: the reference's `int count[]`)
+  // exchange of the occupied levels only (exchange_occupied_levels): per-level occupancy, the dense band, what was found
+  // option "mix_exchange_levels" (default 0): measured with a one-rank communicator, the band costs 0.14 ms per step (the
+  // host reads the occupancy: the one synchronisation in the step path; pack / unpack) against a MODELLED saving of
+  // 0.15-0.2 ms on eight GPUs -- undecidable without xGMI, so the whole-grid all-reduce stays the default
+  bool mix_exchange_levels = false;
+  double *d_occ = nullptr, *h_occ = nullptr, *d_band = nullptr;
+  int *d_band_cnt = nullptr;
+  size_t band_cap = 0;
+  int mix_band_lo = -1, mix_band_hi = -1;
   size_t cnt_cap = 0;
   int deterministic_sums = 1;         // cell sums in the reference's serial order (0: floating-point atomics)
   int sum_path = 0;                   // ordered sums: 0 = by crowding, 1 = groups of cells per wave, 2 = a lane per (cell, value)
@@ -1947,6 +1956,65 @@ int mixing_cells(mphip_ctx *ctx, const MixPlan &P) {
   return 0;
 }
 
+// The exchange of a mixing step restricted to the band of levels that holds particles on any rank (SURVEY 8e (2):
+// 5.83e6 boxes x 12 B = 70 MB per mixed quantity and step for the default grid; the particles of BASELINE configs[4]
+// occupy 31 of its 90 levels).  A small all-reduce of the per-level occupancy first (nz doubles), its result read by
+// the host -- the one synchronisation of the step path, taken only by runs of several ranks --, then pack, all-reduce
+// of the band, unpack.  The boxes outside the band hold no particle on any rank: nothing to add there, and every box
+// inside adds the same partial sums in the same order as the exchange of the whole grid (identical bits:
+// test_mixing_exchange_of_the_occupied_levels_equals_the_whole_grid).  Falls back to the whole grid when the band
+// covers four fifths of it.
+int exchange_occupied_levels(mphip_ctx *ctx, int nq, size_t ntot, int nz) {
+  const size_t ncol = ntot / (size_t) nz;
+  if (!ctx->d_occ) {
+    if (dev_alloc(ctx, &ctx->d_occ, (size_t) 256))
+      return 1;
+    HIPCHK(hipHostMalloc((void **) &ctx->h_occ, 256 * sizeof(double), hipHostMallocDefault));
+  }
+  HIPCHK(hipMemsetAsync(ctx->d_occ, 0, (size_t) nz * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(level_occupancy_kernel, dim3(std::min<size_t>(1024, (ntot + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const int *) ctx->d_cnt, ntot, nz, ctx->d_occ);
+  HIPCHK(hipGetLastError());
+  if (run_allreduce(ctx, ctx->d_occ, (size_t) nz))
+    return 1;
+  HIPCHK(hipMemcpyAsync(ctx->h_occ, ctx->d_occ, (size_t) nz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int lo = nz, hi = -1;
+  for (int l = 0; l < nz; l++)
+    if (ctx->h_occ[l] > 0) {
+      lo = std::min(lo, l);
+      hi = std::max(hi, l);
+    }
+  ctx->mix_band_lo = lo;
+  ctx->mix_band_hi = hi;
+  if (hi < lo)        // no particle in any box on any rank: nothing to exchange
+    return 0;
+  const int nl = hi - lo + 1;
+  if (5 * nl >= 4 * nz)
+    return run_allreduce(ctx, ctx->d_sums, (size_t) nq * ntot, ctx->d_cnt, ntot, ctx->d_sums + (size_t) nq * ntot);
+  const size_t per = ncol * (size_t) nl;
+  // dense buffers: [sums of the quantities | scratch for a doubles-only hook] and the counts
+  if (((size_t) nq + 1) * per > ctx->band_cap) {
+    if (dev_alloc(ctx, &ctx->d_band, ((size_t) nq + 1) * per) || dev_alloc(ctx, &ctx->d_band_cnt, per))
+      return 1;
+    ctx->band_cap = ((size_t) nq + 1) * per;
+  }
+  const int blocks = (int) std::min<size_t>(8192, ((size_t) nq * per + 255) / 256);
+  hipLaunchKernelGGL(pack_levels_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double *) ctx->d_sums,
+                     ctx->d_band, ncol, nz, lo, nl, nq, false, (double *) nullptr);
+  hipLaunchKernelGGL(pack_levels_kernel<int>, dim3(blocks), dim3(256), 0, ctx->stream, (const int *) ctx->d_cnt,
+                     ctx->d_band_cnt, ncol, nz, lo, nl, 1, false, (int *) nullptr);
+  HIPCHK(hipGetLastError());
+  if (run_allreduce(ctx, ctx->d_band, (size_t) nq * per, ctx->d_band_cnt, per, ctx->d_band + (size_t) nq * per))
+    return 1;
+  hipLaunchKernelGGL(pack_levels_kernel<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double *) nullptr,
+                     ctx->d_band, ncol, nz, lo, nl, nq, true, ctx->d_sums);
+  hipLaunchKernelGGL(pack_levels_kernel<int>, dim3(blocks), dim3(256), 0, ctx->stream, (const int *) nullptr,
+                     ctx->d_band_cnt, ncol, nz, lo, nl, 1, true, ctx->d_cnt);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int mixing_sums(mphip_ctx *ctx, const MixPlan &P) {
   const MixSet &mq = P.mq;
   const size_t ntot = P.ntot;
@@ -1966,6 +2034,10 @@ int mixing_sums(mphip_ctx *ctx, const MixPlan &P) {
     }
   }
   // one exchange per mixing step: the sums of every mixed quantity and the cell counts
+  const bool exchange = ctx->comm != nullptr || ctx->allreduce != nullptr;
+  const int nz = ctx->ctl.mixing_nz;
+  if (exchange && ctx->mix_exchange_levels && nz >= 8 && nz <= 256 && ntot >= ((size_t) 1 << 18))
+    return exchange_occupied_levels(ctx, mq.n, ntot, nz);
   return run_allreduce(ctx, ctx->d_sums, (size_t) mq.n * ntot, ctx->d_cnt, ntot, ctx->d_sums + (size_t) mq.n * ntot);
 }
 
@@ -2226,6 +2298,11 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_cell);
   dev_free(ctx->d_sums);
   dev_free(ctx->d_cnt);
+  dev_free(ctx->d_occ);
+  dev_free(ctx->d_band);
+  dev_free(ctx->d_band_cnt);
+  if (ctx->h_occ)
+    (void) hipHostFree(ctx->h_occ);
   dev_free(ctx->d_lists);
   dev_free(ctx->d_grid_kernel);
   dev_free(ctx->d_rec);
@@ -3422,6 +3499,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     if (!(value == 0 || (value >= 8 && value <= kRadixMaxBits)))
       return fail(ctx, "sort_bits must be 0 (automatic), 8, 9 or 10");
     ctx->sort_bits = (int) value;
+    return 0;
+  }
+  if (strcmp(name, "mix_exchange_levels") == 0) {   // 0: the exchange of a mixing step covers the whole grid
+    ctx->mix_exchange_levels = value != 0;
     return 0;
   }
   if (strcmp(name, "lds_tile") == 0) {   // cells of the LDS wind tile for runs of pure trajectory steps (24 bytes each; 0: off)

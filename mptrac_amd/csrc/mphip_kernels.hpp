@@ -2643,6 +2643,42 @@ __global__ __launch_bounds__(256) void cell_sum_chains_kernel(VALS vals, const i
 }
 
 // counts <-> doubles around an all-reduce hook that only knows doubles (tests, staged host collectives)
+// ---- the exchange of module_mixing's cell sums between ranks, restricted to the occupied levels ----------------------
+// Boxes are indexed (column, level) with the level fastest; the particles of a run occupy a band of levels (0.5-30 km of
+// a grid that spans -5 ... 85 km: a third of it), the same band on every rank (index-range shards are spread over the
+// globe alike).  level_occupancy_kernel marks the levels that hold a particle on this rank (summed over the ranks: on
+// any rank); pack / unpack move the band [lo, hi] of every column into a dense buffer and back, so that the all-reduce
+// carries (hi - lo + 1) / nz of the bytes.
+__global__ void level_occupancy_kernel(const int *__restrict__ cnt, size_t ntot, int nz, double *__restrict__ occ) {
+  __shared__ unsigned s_occ[256];
+  for (int l = threadIdx.x; l < 256; l += blockDim.x)
+    s_occ[l] = 0;
+  __syncthreads();
+  for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < ntot; i += (size_t) gridDim.x * blockDim.x)
+    if (cnt[i] > 0)
+      s_occ[(int) (i % (size_t) nz)] = 1;      // (a benign race: everybody writes the same value)
+  __syncthreads();
+  for (int l = threadIdx.x; l < nz; l += blockDim.x)
+    if (s_occ[l])
+      occ[l] = 1.0;                            // (likewise)
+}
+
+// dense[(q * ncol + c) * nl + (l - lo)] <-> full[q * ntot + c * nz + l] for lo <= l <= hi (nl = hi - lo + 1); T = double / int
+template <class T>
+__global__ void pack_levels_kernel(const T *__restrict__ full, T *__restrict__ dense, size_t ncol, int nz, int lo, int nl,
+                                   int nq, bool unpack, T *__restrict__ full_out) {
+  const size_t per = ncol * (size_t) nl, total = per * (size_t) nq;
+  for (size_t j = blockIdx.x * (size_t) blockDim.x + threadIdx.x; j < total; j += (size_t) gridDim.x * blockDim.x) {
+    const size_t q = j / per, r = j - q * per, c = r / (size_t) nl;
+    const int l = (int) (r - c * (size_t) nl);
+    const size_t at = q * ncol * (size_t) nz + c * (size_t) nz + (size_t) (lo + l);
+    if (unpack)
+      full_out[at] = dense[j];
+    else
+      dense[j] = full[at];
+  }
+}
+
 __global__ void int_to_double_kernel(const int *__restrict__ in, double *__restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
     out[i] = (double) in[i];

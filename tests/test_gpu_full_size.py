@@ -192,6 +192,73 @@ def test_c4_1e8_particles_as_eight_shards_equal_one_context_and_the_oracle_subsa
         assert cases.rel_err_strict(sig, ref_sig, floor=1e-30) <= 1e-13
 
 
+def test_mixing_exchange_of_the_occupied_levels_equals_the_whole_grid():
+    """N > 1 ranks exchange the cell sums of module_mixing only for the band of levels that holds particles on any
+    rank (exchange_occupied_levels: a small all-reduce of the per-level occupancy, then pack / all-reduce / unpack of the
+    band).  Three index-range shards on the one GPU (three contexts, one host thread each, the all-reduce hook) on the
+    reference's default 360 x 180 x 90 mixing grid: identical bits with the exchange of the whole grid, the hook sees a
+    third of the bytes, and the quantities agree with ONE context holding all particles to 1e-13 (three partial sums
+    instead of one serial sum)."""
+    world, n = 3, 60003
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=n)
+    ctl.update(sort_dt=-999.0, mixing_dt=180.0, mixing_nx=360, mixing_ny=180, mixing_nz=90)
+    times = None
+    one = hip.Simulation(ctl, clim, m0, m1, atm)
+    one.timesteps_init(0.0, 0.0)
+    times = cases.step_times(one.ctl)[:6]
+    for t in times:
+        one.run_timestep(t)
+    ref = one.state()
+    one.close()
+    results = {}
+    for levels in (1, 0):     # (option mix_exchange_levels; 0 is the default)
+        ar = _ThreadAllreduce(world)
+        counts_seen = [[] for _ in range(world)]
+        out, errors = [None] * world, []
+
+        def rank_main(rank, levels=levels, ar=ar, counts_seen=counts_seen, out=out, errors=errors):
+            try:
+                lo, hi = hip.shard_range(n, rank, world)
+                s = hip.Simulation(ctl, clim, m0, m1, atm, shard=(lo, hi))
+                s.set_option("mix_exchange_levels", levels)
+                inner = ar.hook(rank)
+
+                def hook(ptr, count):
+                    counts_seen[rank].append(count)
+                    inner(ptr, count)
+                s.set_allreduce(hook)
+                s.timesteps_init(0.0, 0.0)
+                for t in times:
+                    s.run_timestep(t)
+                out[rank] = (lo, hi, s.state())
+                s.close()
+            except BaseException as exc:      # noqa: BLE001
+                errors.append((rank, repr(exc)))
+                ar.barrier.abort()
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        results[levels] = (out, counts_seen)
+    full = 360 * 180 * 90
+    whole, band = results[0][1][0], results[1][1][0]
+    assert whole and all(c % full == 0 for c in whole)                 # the whole grid: sums of the mixed quantities, then counts
+    assert 90 in band and all(c == 90 or c % (360 * 180) == 0 for c in band)   # the occupancy, then whole levels of every column
+    assert sum(band) < 0.5 * sum(whole)
+    for rank in range(world):
+        lo, hi, g1 = results[1][0][rank]
+        _, _, g0 = results[0][0][rank]
+        for k in ("time", "lon", "lat", "p", "q", "uvwp"):
+            assert np.array_equal(g1[k], g0[k]), (rank, k)
+        for k in ("time", "lon", "lat", "p", "uvwp"):
+            assert np.array_equal(g1[k], ref[k][lo:hi]), (rank, k)
+        err = float(np.max(np.abs(g1["q"] - ref["q"][:, lo:hi]) / np.maximum(np.abs(ref["q"][:, lo:hi]).max(axis=1, keepdims=True), 1e-300)))
+        assert err <= 1e-13, (rank, err)
+    assert np.abs(ref["q"][0] - atm["q"][0]).max() > 1e-6          # (mixing and the loss modules did something)
+
+
 def _device_count():
     rt = ctypes.CDLL("libamdhip64.so")
     n = ctypes.c_int(0)
