@@ -10,6 +10,10 @@ a full oracle run is a CPU test, tests/test_host_logic.py::test_oracle_subsample
   * configs[3] (C4): 10^8 particles as eight index-range shards of 1.25 x 10^7 (eight contexts on the one GPU of
     the box, one host thread each, their gridded output summed through the all-reduce hook) against ONE context
     holding all 10^8, and against the oracle on a subsample;
+  * configs[4] (C5), the part one GPU runs: 10^7 particles with module_sort, inter-parcel mixing on the default boxes,
+    decay and deposition in every step -- against the oracle running ALL particles (no subsample can follow the sort and
+    the mixing);
+  * module_mixing's exchange between ranks restricted to the occupied levels (three contexts through the hook);
   * every visible GPU (skipped on a one-GPU box): min(8, device count) ranks with the library's own RCCL
     communicator, launched the way the driver launches bench.py.
 """
@@ -98,6 +102,48 @@ def _inside_output_grid(ctl, g):
     z = 7.0 * np.log(1013.25 / g["p"])
     return ((g["lon"] >= ctl.grid_lon0) & (g["lon"] < ctl.grid_lon1) & (g["lat"] >= ctl.grid_lat0)
             & (g["lat"] < ctl.grid_lat1) & (z >= ctl.grid_z0) & (z < ctl.grid_z1))
+
+
+def test_c5_at_1e7_with_the_default_mixing_grid_against_the_full_oracle():
+    """BASELINE configs[4], the part one GPU runs, at its own size: 10^7 particles on 721 x 361 x 137 with module_sort and
+    inter-parcel mixing (default 360 x 180 x 90 boxes) in every step, decay, wet and dry deposition.  module_sort rebinds
+    the random-number slots and module_mixing couples the particles, so no subsample can follow: the oracle runs ALL
+    particles for three calls of the time step (two of them move the particles; the second module_sort is the order
+    repair at full size).  Positions and quantities <= 1e-10, the last sort's keys and permutation identical."""
+    import bench
+    n = 10 ** 7
+    ctl, clim, met0, met1, atm, _, _ = bench.build_inputs("C5", 0, 1, 4, particles=n)
+    B.lib().orc_set_num_threads(B.usable_cores())
+    o = B.Oracle(ctl, clim, met0, met1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, met0, met1, atm)
+    s.timesteps_init(0.0, 0.0)
+    dt = s.ctl.dt_mod
+    for k in range(3):
+        s.run_timestep(k * dt)
+    g = s.state()
+    keys, perm = s.get_sort()
+    ctr = s.get_cache()["rng_ctr"]
+    s.close()
+    for k in range(2):
+        o.run_timestep(k * dt)
+    before = o.state()
+    ko, po = o.sort()                       # module_sort of the third call: keys and permutation (ties by index)
+    assert np.array_equal(perm, po) and np.array_equal(keys, ko[po])
+    # (o.sort() has re-ordered the oracle's particles; put them back and let the third call run as a whole)
+    for name in ("time", "lon", "lat", "p"):
+        getattr(o, name)[:] = before[name]
+    o.q[:] = before["q"]
+    o.run_timestep(2 * dt)
+    r = o.state()
+    assert o.cache.rng_ctr == ctr
+    assert np.array_equal(g["time"], r["time"])
+    for k in ("lon", "lat", "p"):
+        err = cases.rel_err(g[k], r[k])
+        assert err <= TOL, (k, err)
+    err, row = cases.q_rows_err(o.ctl, g["q"], r["q"])
+    assert err <= TOL, (row, err)
+    assert np.abs(r["q"][0] - atm["q"][0][po]).max() > 1e-6          # (mixing, decay and deposition did something)
 
 
 class _ThreadAllreduce:
