@@ -371,6 +371,9 @@ int mphip_comm_query(mphip_ctx *ctx, int *nranks, int *rank);
  *   "lds_tile" (default 0 = off; 64 ... 2400): cells of an LDS tile of wind records that runs of pure trajectory steps
  *     (mphip_run_timesteps with module_timesteps, module_position, module_advect only) stage per workgroup; same results,
  *     measured slower than the default gathers;
+ *   "emit_keys" (default 1): in a time step with module_mixing, the launch that moves the particles also writes the keys
+ *     of the next step's module_sort, its module_timesteps and module_mixing's box index (otherwise a kernel of their own
+ *     behind it); same values;
  *   "sort_repair" (default 1): the module_sort that runs ahead repairs the order of the previous module_sort (only the
  *     particles that changed their cell are sorted, then merged with the others) instead of sorting from scratch; same
  *     permutation;

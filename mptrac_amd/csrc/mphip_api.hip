@@ -189,6 +189,7 @@ struct mphip_ctx {
   // of the last module_sort (stored_is_sorted) -- its sorted keys are then non-decreasing along the slots
   // option "lds_tile": cells of the LDS wind tile of traj_tile_kernel (0: off); runs of pure trajectory steps only
   int lds_tile = 0;
+  bool emit_keys = true;              // option "emit_keys": the launch that moves the particles writes the keys of the sort ahead
   bool sort_repair = true;            // option "sort_repair"
   bool ahead_priority = false;        // option "ahead_priority": the stream of the sort ahead at the highest priority (C5: no difference, profiles/r05_variants.txt item 3)
   bool stored_is_sorted = false;
@@ -781,7 +782,8 @@ static bool depo_split_ok(const mphip_ctx *ctx, unsigned tail) {
 }
 
 int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint64_t ctr_meso, uint64_t ctr_conv,
-                uint64_t ctr_pbl = 0, int nsteps = 1, double t_stride = 0, uint64_t ctr_stride = 0, int depo_mode = kDepoWhole) {
+                uint64_t ctr_pbl = 0, int nsteps = 1, double t_stride = 0, uint64_t ctr_stride = 0, int depo_mode = kDepoWhole,
+                const EmitKeys *emit = nullptr, bool *emitted = nullptr) {
   if (ctx->np == 0)
     return 0;
   if (ensure_packed(ctx) || check_fields(ctx, mask))
@@ -795,6 +797,9 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   StepParams S;
+  memset(&S.emit, 0, sizeof(S.emit));
+  if (emitted)
+    *emitted = false;
   S.ctl = ctx->ctl;
   S.met = dev_met(ctx);
   S.atm = dev_atm(ctx);
@@ -945,6 +950,13 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
       HIPCHK(hipEventRecord(e1, ctx->stream));
     return 0;
   }
+  // the headline module set, one step per launch, and the caller wants the keys of the sort ahead from this launch
+  if (emit && emit->keys && sel == kAdvDiffConvSedi && nsteps == 1) {
+    sel |= kEmitKeys;
+    S.emit = *emit;
+    if (emitted)
+      *emitted = true;
+  }
   // pure trajectories, several steps per launch: the kernel that stages the wind grid through an LDS tile (option lds_tile)
   if (ctx->lds_tile > 0 && nsteps > 1 && (sel == (kAdv | kMultiStep) || sel == (kAdv | kTwoStage | kMultiStep))
       && !(mask & (kTailModules | kBound)) && !ctx->fused_perm) {
@@ -993,6 +1005,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     STEP_CASE(kAdvDiffConvSedi | kTwoStage | kMultiStep)
     STEP_CASE(kAdvDiffConvSedi | kGated | kMultiStep)
     STEP_CASE(kAdvDiffConvSedi | kGated | kTwoStage | kMultiStep)
+    STEP_CASE(kAdvDiffConvSedi | kEmitKeys)
     STEP_CASE(kAdvDiffConvSedi | kGated | kPblClosure)
     STEP_CASE(kAdvDiffConvSedi | kGated | kPblClosure | kTwoStage)
     STEP_CASE(kAdvDiffConvSedi | kGated | kPblClosure | kMultiStep)
@@ -1395,7 +1408,8 @@ int ahead_drop(mphip_ctx *ctx) {
 // the second stream, behind the kernels queued on the main stream so far
 // (box: module_mixing of the current step is still to come -- the key kernel then runs on the main stream and
 // leaves the box index of every particle in box->cell on the way, one pass over the particle arrays less)
-int ahead_launch(mphip_ctx *ctx, double t_next, const BoxArgs *box = nullptr) {
+// stream, events and buffers of the sort ahead
+int ahead_ensure(mphip_ctx *ctx) {
   const long long n = ctx->np;
   if (!ctx->ahead_stream) {
     // (with the order repair the sort ahead is little work in few workgroups: at a higher priority they do not queue
@@ -1417,6 +1431,14 @@ int ahead_launch(mphip_ctx *ctx, double t_next, const BoxArgs *box = nullptr) {
       return 1;
     ctx->ahead_cap = n;
   }
+  return 0;
+}
+
+// (keys_ready: the launch that moved the particles has written keys, dt and box index already -- EmitKeys)
+int ahead_launch(mphip_ctx *ctx, double t_next, const BoxArgs *box = nullptr, bool keys_ready = false) {
+  const long long n = ctx->np;
+  if (ahead_ensure(ctx))
+    return 1;
   // the particles are stored in the order of the last module_sort: its sorted keys (in the buffers of the context, which
   // the sort ahead does not touch) let this one repair that order instead of sorting from scratch
   const uint32_t *key_prev = ctx->sort_repair && ctx->stored_is_sorted && ctx->sorted_buf >= 0 && ctx->sorted_n == n
@@ -1425,13 +1447,13 @@ int ahead_launch(mphip_ctx *ctx, double t_next, const BoxArgs *box = nullptr) {
   hipStream_t main_stream = ctx->stream;
   ahead_swap_buffers(ctx);
   int cur = 0, rc = 0;
-  if (box)
+  if (box && !keys_ready)
     rc = sort_keys(ctx, 0, &t_next, box);
   if (!rc && (hipEventRecord(ctx->ahead_mark, main_stream) != hipSuccess
               || hipStreamWaitEvent(ctx->ahead_stream, ctx->ahead_mark, 0) != hipSuccess))
     rc = fail(ctx, "stream hand-over of the sort ahead of time failed");
   ctx->stream = ctx->ahead_stream;
-  if (!rc && !box)
+  if (!rc && !box && !keys_ready)
     rc = sort_keys(ctx, 0, &t_next, nullptr);
   if (!rc)
     rc = key_prev ? repair_sort(ctx, key_prev, n, bits_for(sort_key_range(ctx, 0)), &cur)
@@ -3025,7 +3047,32 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   }
   if (tail && (mask & MPHIP_MOD_TIMESTEPS))
     mask |= kStoreDt;
-  if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl))
+  // the keys of the sort ahead, its module_timesteps and module_mixing's box index from the launch that moves the
+  // particles (EmitKeys) instead of a kernel of their own behind it, where an instantiation for it exists
+  EmitKeys ek;
+  memset(&ek, 0, sizeof(ek));
+  bool emitted = false;
+  if (sort_next && ctx->ahead_box && ctx->emit_keys) {
+    MixPlan plan;
+    bool act = false;
+    if (mixing_plan(ctx, t, &plan, &act) || ahead_ensure(ctx))
+      return 1;
+    if (act) {
+      ek.keys = ctx->ahead_keys[0];
+      ek.dt_next = ctx->ahead_dt;
+      ek.cell = ctx->d_cell;
+      ek.grid = plan.box.grid;
+      ek.box_t0 = plan.box.t0;
+      ek.box_t1 = plan.box.t1;
+      ek.ens = plan.box.ens;
+      ek.ngrid = plan.box.ngrid;
+      ek.direction = (double) c.direction;
+      ek.t_start = c.t_start;
+      ek.t_stop = c.t_stop;
+      ek.t_next = t_next;
+    }
+  }
+  if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl, 1, 0, 0, kDepoWhole, &ek, &emitted))
     return 1;
   // the deposition modules: their factors beside module_mixing (positions are final), applied behind the relaxation
   const bool depo_split = tail && depo_split_ok(ctx, tail);
@@ -3039,7 +3086,7 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
     const BoxArgs box = { ctx->d_cell, plan.box.grid, plan.box.t0, plan.box.t1, plan.box.ens, plan.box.ngrid };
     if (!ctx->ahead_box)
       cells_ready = false;
-    if (ahead_launch(ctx, t_next, cells_ready ? &box : nullptr))
+    if (ahead_launch(ctx, t_next, cells_ready ? &box : nullptr, emitted && cells_ready))
       return 1;
   }
   if (do_mixing(ctx, t, cells_ready))
@@ -3515,6 +3562,10 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
     ctx->ahead_priority = value != 0;
     return 0;
   }
+  if (strcmp(name, "emit_keys") == 0) {   // 0: the keys of the sort ahead always come from a kernel of their own
+    ctx->emit_keys = value != 0;
+    return 0;
+  }
   if (strcmp(name, "sort_repair") == 0) {   // 0: the module_sort that runs ahead always sorts from scratch
     ctx->sort_repair = value != 0;
     return 0;
@@ -3635,6 +3686,7 @@ int mphip_test_piece(mphip_ctx *ctx, int piece, int reps, double *checksum) {
   if (!ctx->have_clim)
     return fail(ctx, "climatological tropopause data were not uploaded");
   StepParams S;
+  memset(&S.emit, 0, sizeof(S.emit));
   S.ctl = ctx->ctl;
   S.met = dev_met(ctx);
   S.atm = dev_atm(ctx);

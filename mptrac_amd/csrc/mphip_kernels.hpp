@@ -101,7 +101,23 @@ __device__ inline void mix_relax_one(const mphip_ctl_t &ctl, const DevClim &clim
   }
 }
 
+// What the key kernel of the module_sort that runs ahead would compute in a pass of its own behind the launch that
+// moves the particles -- the sort key of the next step's module_sort, its module_timesteps, and the box index of this
+// step's module_mixing -- written by that launch itself, from the position it has in registers (kEmitKeys
+// instantiation; keys == NULL: off).  Same functions on the same values as sort_key_kernel<true>.
+struct EmitKeys {
+  uint32_t *keys;         // key of module_sort (mptrac.c:5913-5920) of every slot
+  double *dt_next;        // module_timesteps of the next step (mptrac.c:6016-6041)
+  int *cell;              // box of module_mixing (mptrac.c:5245-5281), NULL: not wanted
+  BoxGrid grid;
+  double box_t0, box_t1;
+  const double *ens;
+  int ngrid;
+  double direction, t_start, t_stop, t_next;
+};
+
 struct StepParams {
+  EmitKeys emit;
   mphip_ctl_t ctl;
   DevMet met;
   DevAtm atm;
@@ -169,7 +185,9 @@ constexpr unsigned kMultiStep = 1u << 26;
 // the boundary layer) and module_isosurf are compiled in -- as function calls -- and switched by the run-time mask like
 // the four optional movers.  Instantiations of their own, so that runs without them keep the kernels they had.
 constexpr unsigned kPblClosure = 1u << 29;
-constexpr unsigned kTemplateFlags = kTwoStage | kGated | kMultiStep | kMLWinds | kBigGrid | kPblClosure;
+// template mask only: the launch also writes what the key kernel of the sort ahead would (StepParams::emit)
+constexpr unsigned kEmitKeys = 1u << 22;
+constexpr unsigned kTemplateFlags = kTwoStage | kGated | kMultiStep | kMLWinds | kBigGrid | kPblClosure | kEmitKeys;
 constexpr unsigned kOptionalModules = MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI;
 constexpr unsigned kTailModules = MPHIP_MOD_LOSS_ZERO | MPHIP_MOD_DECAY | MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
 constexpr unsigned kMovers = MPHIP_MOD_POSITION | MPHIP_MOD_ADVECT | MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_DIFF_PBL
@@ -486,6 +504,21 @@ __device__ __forceinline__ void pin(double &x) {
 #define MPHIP_RNG_BALANCED 1
 #endif
 
+__device__ __forceinline__ void emit_sort_keys(const EmitKeys &E, const DevMet &M, const Axes &A, long long i,
+                                               const Particle &P) {
+  if (E.cell)
+    E.cell[i] = box_cell(E.grid, E.box_t0, E.box_t1, P.time, P.lon, P.lat, P.p, E.ens, i, E.ngrid);
+  double dt = 0.0;   // module_timesteps of the next step, mptrac.c:6016-6041
+  if (E.direction * (P.time - E.t_start) >= 0 && E.direction * (P.time - E.t_stop) <= 0 && E.direction * (P.time - E.t_next) < 0)
+    dt = E.t_next - P.time;
+  if (M.local && (P.lon <= A.lon[0] || P.lon >= A.lon[M.nx - 1] || P.lat <= M.latmin || P.lat >= M.latmax))
+    dt = 0.0;
+  E.dt_next[i] = dt;
+  Stencil s;
+  raw_cell_fast(M, A, P.lon, P.lat, P.p, s);
+  E.keys[i] = (uint32_t) ((s.ix * M.ny + s.iy) * M.np + s.ip);
+}
+
 struct RngEarly {
   unsigned mask;
   uint64_t ctr_turb, ctr_meso, ctr_conv, g;
@@ -686,6 +719,9 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
       }
       if (CT == kMaskGeneric && (mask & MPHIP_MOD_ISOSURF))   // module_isosurf has check_dt = 0
         a.p[i] = isosurf_pressure(ctl, M, A, a, P, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
+      if constexpr (!kRuntimeMask<CT> && (CT & kEmitKeys) != 0)
+        if (S.emit.keys)
+          emit_sort_keys(S.emit, M, A, i, P);
       if constexpr (!kRuntimeMask<CT> && (CT & kPblClosure) != 0)
         if (S.mask & MPHIP_MOD_ISOSURF) {
           P.p = isosurf_call(&ctl, &M, A, &a, P.time, P.p, P.lon, P.lat, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
@@ -831,6 +867,9 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
       st_state(&a.lat[i], P.lat);
       st_state(&a.p[i], P.p);
     }
+    if constexpr (lean && (CT & kEmitKeys) != 0)
+      if (S.emit.keys)
+        emit_sort_keys(S.emit, M, A, i, P);
 
     // module_bound_cond: in the instantiation with every module, and -- switched by the run-time mask -- in the
     // gated lean instantiations and the one without movers (the launch behind module_mixing)
