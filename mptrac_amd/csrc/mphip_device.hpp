@@ -3117,10 +3117,11 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
 //   (4) one Ornstein-Uhlenbeck step of the three perturbations with the drift correction of the vertical one, the
 //       displacement, and mirror reflections at the ground and at the layer top.
 // Laid out for a wave whose lanes sit at different heights and over different surfaces: the classes are three
-// functions that fill one record; the piecewise vertical profile of the convective class is a choice of (segment ->
-// base, exponents, factors) followed by ONE pair of powers instead of a ladder of branches with a pow pair in each; a
-// particle above every boundary-layer top of the two snapshots (DevMet::turb_skip, exact: a blend with weights in
-// [0, 1] is not below its smallest corner) leaves without a gather.
+// functions that fill one record; powers of a common base share one logarithm and cube roots are cbrt; the piecewise
+// vertical profile of the convective class is a choice of (base, exponents, factors) followed by ONE evaluation
+// instead of a ladder of branches with a pow pair in each, and its two candidates near the ground are compared in
+// logarithms; a particle above every boundary-layer top of the two snapshots (DevMet::turb_skip, exact: a blend with
+// weights in [0, 1] is not below its smallest corner) leaves without a gather.
 __device__ __forceinline__ double clampd(double v, double lo, double hi) {   // CLAMP, mptrac.h:756
   return v < lo ? lo : (v > hi ? hi : v);
 }
@@ -3134,6 +3135,7 @@ struct PblLayer {
   double h;       // height above ground inside [0, depth] [m]
   double h1;      // ... but at least one metre
   double eta;     // h / depth inside [1e-6, 1 - 1e-6]
+  double log_eta;
 };
 
 struct PblScales {
@@ -3169,29 +3171,22 @@ __device__ __forceinline__ void hanna_neutral(const PblLayer &L, const PblScales
 //   up to 0.96:                                             0.722 (1 - eta)^0.207
 //   above:                                                  0.37
 // and D / w*^2 d(sigma_w^2)/dz has the same shape with (1.8432, -1/3), (0.203759, -0.65), (-0.215812, -0.586), 0.
-// The segment is a choice of (base, two exponents, two factors) followed by ONE pair of powers -- with the library's
-// pow on the reference's own arguments: the value goes into a single-precision perturbation (see above), and
-// exp(e log B) or a cube root for the same power differ from it in the last bits.
 __device__ __forceinline__ void hanna_convective(const PblLayer &L, const PblScales &K, PblTurbulence &T) {
 #pragma clang fp contract(off)
   const double third = 1.0 / 3.0;
-  T.sigma[0] = T.sigma[1] = dmax(K.ustar * pow(dmax(12.0 - 0.5 * L.depth / K.obukhov, 0.0), third), 1e-6);
-  const double free_base = dmax(3.0 * L.eta - K.obukhov / L.depth, 1e-12);
-  // the segment: 0 free convection at the ground, 1 the same further up while it is the smaller candidate, 2 the
-  // eta^0.175 law, 3 the upper part, 4 the top (between 0.03 and 0.4 the candidates' values decide, mptrac.c:4466-4476)
-  int seg = L.eta < 0.03 ? 0 : (L.eta < 0.4 ? 2 : (L.eta < 0.96 ? 3 : 4));
-  if (seg == 2 && 0.96 * pow(free_base, third) < 0.763 * pow(L.eta, 0.175))
-    seg = 1;
-  const bool free = seg <= 1;
-  const double base = free ? free_base : (seg == 2 ? L.eta : (seg == 3 ? 1.0 - L.eta : 1.0));
-  const double e_s = free ? third : (seg == 2 ? 0.175 : 0.207), c_s = free ? 0.96 : (seg == 2 ? 0.763 : 0.722);
-  const double e_g = free ? -third : (seg == 2 ? -0.65 : -0.586), c_g = free ? 1.8432 : (seg == 2 ? 0.203759 : -0.215812);
-  const double ps = pow(base, e_s), pg = pow(base, e_g);
-  // (the reference's grouping of the factors, segment by segment: mptrac.c:4463, 4470-4476, 4479)
-  const double sw = (seg == 1 || seg == 2) ? K.wstar * (c_s * ps) : (seg == 4 ? 0.37 * K.wstar : c_s * K.wstar * ps);
-  const double slope = seg == 4 ? 0.0 : c_g * (K.wstar * K.wstar) / L.depth * pg;
-  T.sigma[2] = dmax(sw, 1e-6);
-  T.dsigma_w = 0.5 * slope / T.sigma[2];
+  T.sigma[0] = T.sigma[1] = dmax(K.ustar * cbrt(dmax(12.0 - 0.5 * L.depth / K.obukhov, 0.0)), 1e-6);
+  const double log_free = log(dmax(3.0 * L.eta - K.obukhov / L.depth, 1e-12));
+  // log(0.96), log(0.763): the two candidates below eta = 0.4 compared without evaluating them
+  const bool free_smaller = -0.040821994520255166 + third * log_free < -0.27049724769768 + 0.175 * L.log_eta;
+  const bool free = (L.eta < 0.03) | ((L.eta < 0.4) & free_smaller);
+  const bool low = L.eta < 0.4, mid = L.eta < 0.96;
+  const double lb = low ? (free ? log_free : L.log_eta) : (mid ? log(1.0 - L.eta) : 0.0);
+  const double e_s = low ? (free ? third : 0.175) : 0.207, c_s = low ? (free ? 0.96 : 0.763) : (mid ? 0.722 : 0.37);
+  const double e_g = low ? (free ? -third : -0.65) : -0.586,
+               c_g = low ? (free ? 1.8432 : 0.203759) : (mid ? -0.215812 : 0.0);
+  const double shape = c_s * exp(e_s * lb), slope = c_g * exp(e_g * lb);
+  T.sigma[2] = dmax(K.wstar * shape, 1e-6);
+  T.dsigma_w = 0.5 * (slope * (K.wstar * K.wstar) / L.depth) / T.sigma[2];
   T.tl[0] = T.tl[1] = 0.15 * L.depth / T.sigma[0];
   const double near_ground = 0.1 * L.h1 / (T.sigma[2] * dmax(0.55 - 0.38 * fabs(L.h1 / K.obukhov), 0.05));
   const double aloft = L.eta < 0.1 ? 0.59 * L.h1 / T.sigma[2] : 0.15 * L.depth / T.sigma[2] * (1.0 - exp(-5.0 * L.eta));
@@ -3207,15 +3202,13 @@ __device__ __forceinline__ void hanna_stable(const PblLayer &L, const PblScales 
   T.dsigma_w = -1.3 * K.ustar / L.depth;
   T.tl[0] = 0.15 * L.depth / T.sigma[0] * sqrt(L.eta);
   T.tl[1] = 0.467 * T.tl[0];
-  T.tl[2] = 0.1 * L.depth / T.sigma[2] * pow(L.eta, 0.8);
+  T.tl[2] = 0.1 * L.depth / T.sigma[2] * exp(0.8 * L.log_eta);
 }
 
 // LEAN: the stencils and gathers of the lean kernels (lat/lon grid with the pressure table, 32-bit offsets)
 template <bool LEAN = false>
 __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particle &P, float &up, float &vp,
                                          float &wp, uint64_t ctr, uint64_t g, const double *ltab) {
-  // (no fused multiply-adds in what feeds the single-precision perturbations: the reference's gcc build rounds every
-  //  product, and half an ulp of the double in front of a float rounding is what flips a float)
 #pragma clang fp contract(off)
   const double wt = time_weight(M, P.time);
   if ((P.p < M.turb_skip) & (wt >= 0.0) & (wt <= 1.0))
@@ -3247,6 +3240,7 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   L.h = clampd(1e3 * (zfromp(p_in) - ground_km), 0.0, L.depth);
   L.eta = clampd(L.h / L.depth, 1e-6, 1.0 - 1e-6);
   L.h1 = dmax(L.h, 1.0);
+  L.log_eta = log(L.eta);
 
   // (2) the scales (mptrac.c:4400-4436): air density and virtual potential temperature at the particle, stresses and
   // heat flux of the surface
@@ -3277,7 +3271,7 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   if (L.depth < fabs(K.obukhov))
     hanna_neutral(L, K, T);
   else if (K.obukhov < 0.0) {
-    K.wstar = pow(dmax(-kG0 / theta_v * heat_flux / (rho * kCpd) * L.depth, 0.0), 1.0 / 3.0);
+    K.wstar = cbrt(dmax(-kG0 / theta_v * heat_flux / (rho * kCpd) * L.depth, 0.0));
     hanna_convective(L, K, T);
   } else
     hanna_stable(L, K, T);
