@@ -49,7 +49,7 @@ for k in list(range(1, steps + 1)) * (2 if replay else 1):
     sim.synchronize()
     wall = (time.perf_counter() - t0) * 1e3
     n, ms = sim.profile_end()
-    out.append((k, ms, wall))   # all launches of the step (one, or two with split_step=1)
+    out.append((k, ms, wall))   # all launches of the step (one; what tools measured as two was the removed option split_step)
 for k, ms, wall in out:
     print(f"step {k:3d}  kernel {ms:7.4f} ms   wall {wall:7.3f} ms")
 tail = sorted(ms for _, ms, _ in out[len(out) // 2:])
