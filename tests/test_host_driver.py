@@ -88,8 +88,7 @@ def test_trac_refuses_to_run_without_a_device(tmp_path):
                                       (("GRID_NC_QUANT[1]", "3"), "quantisation of netCDF output"),
                                       (("GRID_TYPE", "2"), "Set GRID_TYPE to 0 or 1"),
                                       (("ADVECT_VERT_COORD", "2"), "requires meteo data on model levels"),
-                                      (("RNG_TYPE", "0"), "RNG_TYPE 1"),
-                                      (("QNT_NAME[2]", "tnat"), "tnat")])
+                                      (("RNG_TYPE", "0"), "RNG_TYPE 1")])
 def test_trac_rejects_what_it_does_not_implement(tmp_path, args, msg):
     """Control keys of the reference this host layer has no code for stop the run with a message instead of
     being ignored (the reference ignores unknown keys, so a silent drop would look like a normal run)."""
