@@ -366,6 +366,7 @@ def test_control_file_lookup_rules(tmp_path):
     assert scan(b"ADVECT", default=b"2") == (2.0, "2")
     assert scan(b"atm_basename")[1] == "atm"                     # names are case-insensitive
     assert scan(b"DT_MOD", default=b"180", filename=b"-") == (180.0, "180")   # '-': arguments only
+    C.CDLL(None).fflush(None)    # (scan_ctl echoes the settings through C stdio: inside this test's capture, not at exit)
 
 
 def test_species_presets_and_rejected_keys(tmp_path):
