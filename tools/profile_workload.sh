@@ -1,13 +1,13 @@
 #!/bin/bash
 # Kernel time and the basic SQ / TA / TD counters of the step kernel for one bench workload.
-# Usage: tools/profile_workload.sh <tag> <workload> [kernel regex, default step_kernel]
+# Usage: tools/profile_workload.sh <tag> <workload> [kernel regex, default step_kernel] [further bench.py arguments]
 set -u
-TAG=${1:-wl}; WL=${2:-C3}; KRE=${3:-step_kernel}
+TAG=${1:-wl}; WL=${2:-C3}; KRE=${3:-step_kernel}; MORE=${4:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --workload $WL --steps 6 --warmup 1 --no-cpu-baseline --device-warmup-ms 0"
+BENCH="python $ROOT/bench.py --workload $WL --steps 6 --warmup 1 --no-cpu-baseline --device-warmup-ms 0 $MORE"
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o s -- $BENCH > "$OUT/stats.log" 2>&1
 pmc() {
   local name=$1; shift
