@@ -6,7 +6,8 @@ oracle that draws the numbers of those slots: orc_cache_t::ip_global (oracle/mpt
 a full oracle run is a CPU test, tests/test_host_logic.py::test_oracle_subsample_draws_the_full_runs_random_numbers).
 
   * configs[2] (C3): 10^7 particles, 721 x 361 x 137, RK4 + turbulent + mesoscale diffusion + convection +
-    sedimentation, 20 steps through mphip_run_timesteps -- the very call bench.py times;
+    sedimentation, 20 steps through mphip_run_timesteps -- the very call bench.py times; the same with winds from the
+    model levels (bench workload C3z) and with the boundary-layer closure (C3p);
   * configs[3] (C4): 10^8 particles as eight index-range shards of 1.25 x 10^7 (eight contexts on the one GPU of
     the box, one host thread each, their gridded output summed through the all-reduce hook) against ONE context
     holding all 10^8, and against the oracle on a subsample;
@@ -37,9 +38,9 @@ sys.path.insert(0, ROOT)
 TOL = 1e-10          # BASELINE north_star: positions within 1e-10 relative of the CPU reference
 
 
-def _c3_inputs(n, first=0, n_steps=20):
+def _c3_inputs(n, first=0, n_steps=20, workload="C3"):
     import bench
-    ctl, clim, met0, met1, atm, _, _ = bench.build_inputs("C3", 0, 1, n_steps + 1, particles=n)
+    ctl, clim, met0, met1, atm, _, _ = bench.build_inputs(workload, 0, 1, n_steps + 1, particles=n)
     if first:
         from mptrac_amd.synth import synthetic_particles
         atm = synthetic_particles(n, seed=12345, quantities=("m", "rp", "rhop"), first=first)
@@ -91,6 +92,46 @@ def test_c3_at_1e7_on_its_own_grid_against_the_oracle_subsample():
     inside = _inside_output_grid(o.ctl, g)
     assert int(cnt.sum()) == int(np.count_nonzero(inside))
     assert abs(mean[0].sum() - g["q"][0][inside].sum()) <= 1e-9 * n
+
+
+@pytest.mark.parametrize("workload", ["C3z", "C3p"])
+def test_c3_variants_at_1e7_against_the_oracle_subsample(workload):
+    """The two other step kernels bench.py times on the 721 x 361 x 137 grid at their own size: winds from the model
+    levels (ADVECT_VERT_COORD 1, intpol_met_4d_zeta: mptrac.c:2808-2981, 3681-3757 -- workload C3z) and the
+    boundary-layer closure (TURB_PBL_SCHEME 1, module_diff_pbl: mptrac.c:4343-4584 -- workload C3p); 10^7 particles,
+    20 steps in one mphip_run_timesteps call, 5 000 of them against the oracle."""
+    n, n_steps = 10 ** 7, 20
+    ctl, clim, met0, met1, atm = _c3_inputs(n, workload=workload)
+    s = hip.Simulation(ctl, clim, met0, met1, atm)
+    s.timesteps_init(0.0, 0.0)
+    dt = s.ctl.dt_mod
+    s.run_timestep(0.0)
+    s.synchronize()
+    s.profile_begin()
+    s.run_timesteps(dt, n_steps)
+    launches, _ = s.profile_end()
+    g = s.state()
+    ctr = s.get_cache()["rng_ctr"]
+    s.close()
+    assert launches == 1                                                  # (the lean instantiations: the steps share a launch)
+
+    pick = np.random.default_rng(20250930).choice(n, 5000, replace=False)
+    pick[:2] = (0, n - 1)
+    o = _oracle_on_subsample(ctl, clim, met0, met1, _take(atm, pick), pick, n, n_steps)
+    assert o.cache.rng_ctr == ctr
+    for k, ref in (("lon", o.lon), ("lat", o.lat), ("p", o.p)):
+        err = cases.rel_err(g[k][pick], ref)
+        assert err <= TOL, (workload, k, err)
+    assert np.array_equal(g["time"][pick], o.time)
+    assert np.array_equal(g["uvwp"][pick], o.uvwp)
+    err, row = cases.q_rows_err(o.ctl, g["q"][:, pick], o.q)               # (C3z: the zeta coordinate is advected)
+    assert err <= TOL, (workload, row, err)
+    assert np.all(g["time"] == n_steps * dt)
+    for k in ("lon", "lat", "p"):
+        assert np.all(np.isfinite(g[k])), k
+    assert g["lon"].min() >= -180.0 and g["lon"].max() < 180.0 and np.abs(g["lat"]).max() <= 90.0 and g["p"].min() > 0.0
+    moved = np.abs(g["p"][pick] - atm["p"][pick]) > 1e-3
+    assert np.count_nonzero(moved) > 4000
 
 
 def _inside_output_grid(ctl, g):
