@@ -14,6 +14,7 @@ a full oracle run is a CPU test, tests/test_host_logic.py::test_oracle_subsample
   * configs[4] (C5), the part one GPU runs: 10^7 particles with module_sort, inter-parcel mixing on the default boxes,
     decay and deposition in every step -- against the oracle running ALL particles (no subsample can follow the sort and
     the mixing);
+  * mixing in every step without module_sort (bench workload C3x), all particles in the oracle;
   * module_mixing's exchange between ranks restricted to the occupied levels (three contexts through the hook).
 (Every visible GPU with the library's own RCCL communicator: tests/test_zz_every_visible_gpu.py.)
 """
@@ -182,6 +183,40 @@ def test_c5_at_1e7_with_the_default_mixing_grid_against_the_full_oracle():
     err, row = cases.q_rows_err(o.ctl, g["q"], r["q"])
     assert err <= TOL, (row, err)
     assert np.abs(r["q"][0] - atm["q"][0][po]).max() > 1e-6          # (mixing, decay and deposition did something)
+
+
+def test_mixing_without_module_sort_at_1e7_against_the_full_oracle():
+    """Inter-parcel mixing in every step WITHOUT module_sort (bench workload C3x): the particles stay in the caller's
+    order as far as the caller can see, the library stores them in its internal locality order, and the ordered cell
+    sums of module_mixing (mptrac.c:5169-5347) have to follow the caller's index through that order -- the other
+    branch of the ordered sums than configs[4] takes.  10^7 particles, the default boxes, all particles in the oracle;
+    three calls one at a time, then five steps in one mphip_run_timesteps call."""
+    import bench
+    n = 10 ** 7
+    ctl, clim, met0, met1, atm, _, _ = bench.build_inputs("C3x", 0, 1, 9, particles=n)
+    B.lib().orc_set_num_threads(B.usable_cores())
+    o = B.Oracle(ctl, clim, met0, met1, atm)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, met0, met1, atm)
+    s.timesteps_init(0.0, 0.0)
+    dt = s.ctl.dt_mod
+    for k in range(3):
+        s.run_timestep(k * dt)
+    s.run_timesteps(3 * dt, 5)
+    g = s.state()
+    ctr = s.get_cache()["rng_ctr"]
+    s.close()
+    for k in range(8):
+        o.run_timestep(k * dt)
+    r = o.state()
+    assert o.cache.rng_ctr == ctr
+    assert np.array_equal(g["time"], r["time"]) and np.array_equal(g["uvwp"], r["uvwp"])
+    for k in ("lon", "lat", "p"):
+        err = cases.rel_err(g[k], r[k])
+        assert err <= TOL, (k, err)
+    err, row = cases.q_rows_err(o.ctl, g["q"], r["q"])
+    assert err <= TOL, (row, err)
+    assert np.abs(r["q"][0] - atm["q"][0]).max() > 1e-6               # (mixing did something)
 
 
 class _ThreadAllreduce:
