@@ -60,10 +60,13 @@ def _take(atm, idx):
     return {k: (v[idx].copy() if k != "q" else v[:, idx].copy()) for k, v in atm.items()}
 
 
-def test_c3_at_1e7_on_its_own_grid_against_the_oracle_subsample():
-    """BASELINE configs[2] as bench.py runs it: 10^7 particles, 20 steps in one mphip_run_timesteps call."""
-    n, n_steps = 10 ** 7, 20
-    ctl, clim, met0, met1, atm = _c3_inputs(n)
+@pytest.mark.parametrize("n_steps", [20, 65])
+def test_c3_at_1e7_on_its_own_grid_against_the_oracle_subsample(n_steps):
+    """BASELINE configs[2] as bench.py runs it: 10^7 particles, 20 steps in one mphip_run_timesteps call (the
+    driver's arguments) -- and 65, bench.py's default 60 and a few more: the call then contains the re-sort of the
+    internal locality order (every 60 steps), which splits the launch and moves every particle to another slot."""
+    n = 10 ** 7
+    ctl, clim, met0, met1, atm = _c3_inputs(n, n_steps=n_steps)
     s = hip.Simulation(ctl, clim, met0, met1, atm)
     s.timesteps_init(0.0, 0.0)
     dt = s.ctl.dt_mod
