@@ -139,6 +139,50 @@ def test_c3_variants_at_1e7_against_the_oracle_subsample(workload):
     assert np.count_nonzero(moved) > 4000
 
 
+def test_c3_at_1e7_across_two_meteo_hand_overs():
+    """configs[2] over three meteo intervals of one hour: 10^7 particles, 45 steps, the next snapshot uploaded beside the
+    steps and handed over between two calls (mphip_prefetch_met / mphip_commit_met: get_met's swap of the two time
+    levels, mptrac.c:6403-6491), the steps of an interval in one mphip_run_timesteps call; 5 000 particles against
+    the oracle that swaps its snapshots the same way."""
+    from mptrac_amd.synth import synthetic_met
+    import bench
+    n = 10 ** 7
+    ctl, clim, _, _, atm, _, _ = bench.build_inputs("C3", 0, 1, 1, particles=n)
+    fields = bench.WORKLOADS["C3"][4]
+    ctl.update(dt_met=3600.0, t_stop=3 * 3600.0)
+    mets = [synthetic_met("C3", 3600.0 * k, 1.0 + 0.1 * k, fields=fields) for k in range(4)]
+    pick = np.random.default_rng(20250930).choice(n, 5000, replace=False)
+    o = B.Oracle(ctl, clim, mets[0], mets[1], _take(atm, pick), ip_global=pick, np_global=n)
+    o.timesteps_init()
+    s = hip.Simulation(ctl, clim, mets[0], mets[1], atm)
+    s.timesteps_init(0.0, 0.0)
+    s.prefetch_met(mets[2])
+    dt = s.ctl.dt_mod
+    times = [k * dt for k in range(46)]
+    imet, pending = 0, []
+    for t in times:
+        if t > mets[imet + 1].time:
+            s.run_timesteps(pending[0], len(pending))
+            pending = []
+            imet += 1
+            o.swap_met(mets[imet + 1])
+            s.commit_met()
+            if imet + 2 < len(mets):
+                s.prefetch_met(mets[imet + 2])
+        o.run_timestep(t)
+        pending.append(t)
+    s.run_timesteps(pending[0], len(pending))
+    g = s.state()
+    ctr = s.get_cache()["rng_ctr"]
+    s.close()
+    assert imet == 2 and o.cache.rng_ctr == ctr
+    for k, ref in (("lon", o.lon), ("lat", o.lat), ("p", o.p)):
+        err = cases.rel_err(g[k][pick], ref)
+        assert err <= TOL, (k, err)
+    assert np.array_equal(g["time"][pick], o.time) and np.array_equal(g["uvwp"][pick], o.uvwp)
+    assert np.all(g["time"] == times[-1])
+
+
 def _inside_output_grid(ctl, g):
     """The particles write_grid bins (mptrac.c:13847-13860) on the default output grid."""
     z = 7.0 * np.log(1013.25 / g["p"])
