@@ -3,6 +3,8 @@ stochastic modules, convection, sedimentation, sort, mixing, decay, wet / dry de
 isosurface mode, meteo quantities (climatology ones included), trace gases with surface time series, direction, grid orientation, vertical coordinate of the advection) and runs 12 steps through
 mphip_run_timestep (even seeds) or mphip_run_timesteps in pieces of one to five steps (odd seeds).  Catches interactions between modules and between the kernel instantiations that the
 named cases do not cover."""
+import os
+
 import numpy as np
 import pytest
 
@@ -117,7 +119,9 @@ def _contexts(seed):
     t0, t1 = (0.0, 7200.0) if ctl["direction"] == 1 else (-7200.0, 0.0)
     m0 = synthetic_met(geom["grid"], t0, 1.0, fields=fields, lon0=geom["lon0"], lat_reverse=geom["lat_reverse"])
     m1 = synthetic_met(geom["grid"], t1, 1.25, fields=fields, lon0=geom["lon0"], lat_reverse=geom["lat_reverse"])
-    atm = synthetic_particles(6000, seed=100 + seed, quantities=names, lon=(geom["lon0"], geom["lon0"] + 360.0))
+    # (MPTRAC_FUZZ_PARTICLES: campaigns with more particles per seed -- more tiles per sort, fuller mixing boxes)
+    n = int(os.environ.get("MPTRAC_FUZZ_PARTICLES", "6000"))
+    atm = synthetic_particles(n, seed=100 + seed, quantities=names, lon=(geom["lon0"], geom["lon0"] + 360.0))
     for nq in ("zeta", "eta"):
         if nq in names:      # a vertical coordinate inside the range of the synthetic zetal field
             atm["q"][list(names).index(nq)] = 320.0 + 1680.0 * ((atm["lat"] + 85.0) / 170.0)
