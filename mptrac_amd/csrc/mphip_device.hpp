@@ -13,9 +13,55 @@
 #include <stdint.h>
 
 #include "../../include/mptrac_hip.h"
-#include "mphip_logtab.hpp"
+#include "mphip_libm.h"
+#include "mphip_libmtab.h"
 
 namespace mphip {
+
+// ---- exp / log / pow with the C library's bits (mphip_libm.h) ---------------
+// The three 128-entry tables as one object in device memory: {invc, logc} of log, {tail, scale} of exp, {invc, logc,
+// logctail} of pow -- 7 kB.  Kernels that call them per particle copy the part they use to LDS (the step kernel: log
+// and exp, 4 kB; with the boundary-layer closure all of it); everything else reads the object through the caches.
+// A table pointer (`lt` below, `ltab` in the modules) is the address of the object or of such a copy.
+struct LibmBlob {
+  double log_tab[2 * MPHIP_LIBM_N];
+  uint64_t exp_tab[2 * MPHIP_LIBM_N];
+  double pow_tab[3 * MPHIP_LIBM_N];
+};
+static __device__ const LibmBlob g_libm = { { MPHIP_LIBM_LOG_TAB_INIT }, { MPHIP_LIBM_EXP_TAB_INIT }, { MPHIP_LIBM_POW_TAB_INIT } };
+constexpr int kLibmLogExpDoubles = 4 * MPHIP_LIBM_N;     // log + exp, what the lean kernels copy
+constexpr int kLibmDoubles = 7 * MPHIP_LIBM_N;           // all three
+
+__device__ __forceinline__ const double *libm_tables() {
+  return g_libm.log_tab;
+}
+
+__device__ __forceinline__ double libm_log(const double *lt, double x) {
+  return mphip_libm_log(lt, x);
+}
+
+__device__ __forceinline__ double libm_exp(const double *lt, double x) {
+  return mphip_libm_exp((const uint64_t *) (lt + 2 * MPHIP_LIBM_N), x);
+}
+
+__device__ __forceinline__ double libm_pow(const double *lt, double x, double y) {
+  const mphip_libm_tabs T = { (const uint64_t *) (lt + 2 * MPHIP_LIBM_N), lt, lt + 4 * MPHIP_LIBM_N };
+  return mphip_libm_pow(&T, x, y);
+}
+
+// the same from the object in device memory (call sites outside the per-particle hot loops: calls, so that the
+// rarely taken branches of the library's algorithms do not weigh on the registers of the kernels around them)
+__device__ __noinline__ double libm_log(double x) {
+  return libm_log(libm_tables(), x);
+}
+
+__device__ __noinline__ double libm_exp(double x) {
+  return libm_exp(libm_tables(), x);
+}
+
+__device__ __noinline__ double libm_pow(double x, double y) {
+  return libm_pow(libm_tables(), x, y);
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -90,7 +136,6 @@ struct DevMet {
   // module_diff_meso: r = 1 - 2 |dt| / DT_MET and sqrt(1 - r^2) for |dt| = meso_dt = |DT_MOD| (every particle of a
   // step but the last, shortened one), from the host -- IEEE division and square root as the reference's
   double meso_dt, meso_r, meso_r2;
-  const double *logtab;          // table of log_tab() (kLogTabN x 3 doubles), copied to LDS by the step kernel
 };
 
 struct DevAtm {
@@ -262,6 +307,20 @@ __device__ __forceinline__ double fma_k(double x, double y, double c) {
   return r;
 }
 
+// The IEEE square root (correctly rounded) for 0 <= x < 2^1000, x not subnormal: the hardware's reciprocal square
+// root estimate, one coupled Newton step for sqrt(x) and 1 / (2 sqrt(x)), and two residual corrections -- the sequence
+// the compiler emits for sqrt() without its range scaling (the arguments here are -2 log u <= 89 and 1 - r^2 <= 1).
+__device__ __forceinline__ double sqrt_rn(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return x == 0.0 || x == __builtin_inf() ? x : g;
+}
+
 // 1 / b to an ulp or two (rcp + two Newton steps)
 __device__ __forceinline__ double frcp(double b) {
   double r = __builtin_amdgcn_rcp(b);
@@ -366,7 +425,7 @@ __device__ __forceinline__ double dz2dp(double dz, double p) {   // mptrac.h:941
 }
 
 __device__ __forceinline__ double zfromp(double p) {   // mptrac.h:2243
-  return kH0 * log(kP0 / p);
+  return kH0 * libm_log(kP0 / p);
 }
 
 __device__ __forceinline__ double lin(double x0, double y0, double x1, double y1, double x) {   // mptrac.h:1351
@@ -1119,7 +1178,7 @@ __device__ inline double clim_oh(const mphip_ctl_t &ctl, const DevZm &Z, double 
     return oh;
   const double csza = cos_sza(t, lon_ref, lat_ref);
   const double denom = (csza >= csza_thresh) ? csza : csza_thresh;
-  return oh * exp(-ctl.oh_chem_beta / denom);
+  return oh * libm_exp(-ctl.oh_chem_beta / denom);
 }
 
 // nat_temperature, mptrac.c:8334-8355
@@ -1206,15 +1265,15 @@ __device__ __forceinline__ double pbl_weight(const mphip_ctl_t &ctl, double p, d
 // 1 / (s T) and 1 / ((T + 120) rho v r) with s = (T / 296.16)^1.5: eta = c s / (T + 120), rho = 100 p / (RA T),
 // K = 2 eta / (rho v r), and 1 / K, 1 / eta follow by products -- a few ulp from the reference's operation order
 // on a velocity that moves the pressure by parts per million.
-__device__ __forceinline__ double sedi(double p, double T, double rp, double rhop) {
+__device__ __forceinline__ double sedi(double p, double T, double rp, double rhop, const double *lt) {
   const double r = rp * 1e-6;
 #if MPHIP_EXACT_DIV
   const double rho = rho_air(p, T);
-  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * pow(T / 296.16, 1.5);
+  const double eta = 1.8325e-5 * (416.16 / (T + 120.)) * libm_pow(T / 296.16, 1.5);
   const double v = fsqrt(div_const(8. * kKB * T, kPi * kMAir, 1.0 / (kPi * kMAir)));
   const double lambda = fdiv(2. * eta, rho * v);
   const double K = fdiv(lambda, r);
-  const double G = 1. + K * (1.249 + 0.42 * exp(fdiv(-0.87, K)));
+  const double G = 1. + K * (1.249 + 0.42 * libm_exp(lt, fdiv(-0.87, K)));
   return fdiv(2. * (r * r) * (rhop - rho) * kG0, 9. * eta) * G;
 #else
   const double tr = T * (1.0 / 296.16);   // x^1.5 = x sqrt(x): within 2 ulp of pow()
@@ -1228,7 +1287,7 @@ __device__ __forceinline__ double sedi(double p, double T, double rp, double rho
   const double arvr = a * rho * v * r;
   const double K = (2. * c) * s * frcp(arvr);
   const double inv_K = (0.5 / c) * arvr * inv_s;
-  const double G = 1. + K * (1.249 + 0.42 * exp(-0.87 * inv_K));
+  const double G = 1. + K * (1.249 + 0.42 * libm_exp(lt, -0.87 * inv_K));
   // 2 r^2 (rhop - rho) g / (9 eta) with 1 / eta = a / (c s)
   return (2. * kG0 / (9. * c)) * (r * r) * (rhop - rho) * (a * inv_s) * G;
 #endif
@@ -1321,52 +1380,66 @@ __device__ __forceinline__ float libm_sincosf(float y, int which) {
   return which ? cv : sv;
 }
 
-// log(X 2^-64) for X = (double) of a non-zero 64-bit integer, i.e. log(u) of the uniform behind a Box-Muller
-// radius: table-driven (tools/gen_log_table.py; `tab` = kLogTabN x {1/c, -log(1/c) hi, lo}, in LDS in the
-// lean kernels, in global memory otherwise), no division, ~27 instructions.  Within 1.4 ulp of the exact
-// logarithm (CPU check of the same arithmetic over 2 x 10^7 arguments; the C library is within 0.52).
-__device__ __forceinline__ double log_tab(const double *__restrict__ tab, double X) {
-  const int hx = __double2hiint(X);
-  const int t = hx - 0x3fe60000;                       // x = 2^k z, z in [0.6875, 1.375)
-  const int i = (t >> 13) & (kLogTabN - 1);
-  const int k = t >> 20;
-  const double z = __hiloint2double(hx - (t & (int) 0xfff00000), __double2loint(X));
-  const double *e = tab + 3 * i;
-  const double invc = e[0], lh = e[1], ll = e[2];
-  const double r = __builtin_fma(z, invc, -1.0);     // |r| <= 2^-7, one rounding
-  const double kd = (double) (k - 64);
-  double p = r * (1.0 / 7) - 1.0 / 6;                  // (one SGPR constant per instruction on gfx950)
-  p = fma_k(r, p, 1.0 / 5);
-  p = fma_k(r, p, -1.0 / 4);
-  p = fma_k(r, p, 1.0 / 3);
-  p = fma_k(r, p, -1.0 / 2);
-  const double w = __builtin_fma(kd, kLn2Hi, lh);     // k ln2_hi is exact (trailing zeros)
-  const double hi = w + r;
-  const double lo = ((w - hi) + r) + __builtin_fma(kd, kLn2Lo, ll);
-  return __builtin_fma(r * r, p, lo) + hi;
-}
-
 // (double) r of a 64-bit integer in three instructions (both halves convert exactly, the fma rounds once)
 __device__ __forceinline__ double u64_to_double(uint64_t r) {
-  return __builtin_fma((double) (uint32_t) (r >> 32), 0x1p32, (double) (uint32_t) r);
+  return __builtin_fma(__uint2double_rn((uint32_t) (r >> 32)), 0x1p32, __uint2double_rn((uint32_t) r));
+}
+
+// log u of the two uniforms u = X 2^-64 (X = (double) of a 64-bit draw; u = 0 -> -inf) behind two Box-Muller radii,
+// the C library's bits.  Its algorithm has a second polynomial for arguments next to 1, and one uniform in sixteen
+// is there: evaluated where the call stands, every wavefront would run both polynomials for both arguments.  Here
+// both take the table path first (harmless where it does not apply), and the lanes with an argument next to 1 then
+// share ONE copy of that polynomial in a loop that runs once per wavefront, seldom twice.
+__device__ __forceinline__ void libm_log_unit_pair(const double *__restrict__ lt, double xa, double xb, double &la, double &lb) {
+  const double ua = xa * 0x1p-64, ub = xb * 0x1p-64;     // exact
+  const uint64_t ia = mphip_libm_bits(ua), ib = mphip_libm_bits(ub);
+  la = mphip_libm_log_away(lt, ia);
+  lb = mphip_libm_log_away(lt, ib);
+  // (a zero draw, one in 2^64, joins the lanes that are sent round again)
+  bool pa = mphip_libm_log_is_near_one(ia) | (xa == 0.0), pb = mphip_libm_log_is_near_one(ib) | (xb == 0.0);
+  while (pa | pb) {
+    const double x = pa ? ua : ub;
+    const double v = x == 1.0 ? 0.0 : (x == 0.0 ? -__builtin_inf() : mphip_libm_log_near_one(x));
+    if (pa) {
+      la = v;
+      pa = false;
+    } else {
+      lb = v;
+      pb = false;
+    }
+  }
 }
 
 // Element i of the array module_rng(..., method = 1) would have produced for
 // base counter c0 (mptrac.c:5821-5826): Box-Muller over the flat pairs
 // (2j, 2j+1) of the uniform stream.
 // y = (c0 + 2j) * key
-__device__ __forceinline__ void normal_pair_from(const double *__restrict__ ltab, uint64_t y, double &even, double &odd) {
-  const uint64_t ra = squares_from(y), rb = squares_from(y + kSquaresKey);
-#if MPHIP_EXACT_DIV
-  const double r = sqrt(-2.0 * log((double) ra * 0x1p-64));
-#else
-  const double r = fsqrt(-2.0 * (ra == 0 ? -__builtin_inf() : log_tab(ltab, u64_to_double(ra))));
-#endif
+__device__ __forceinline__ void box_muller(double log_u, uint64_t rb, double &even, double &odd) {
+  // sqrt(-2 log u) with the IEEE square root: the reference's bits (u = 0 -> inf as there)
+  const double r = sqrt_rn(-2.0 * log_u);
   const float phif = (float) (u64_to_double(rb) * (2.0 * kPi * 0x1p-64));   // 2 pi u, u = r 2^-64 (exact scaling)
   float sv, cv;
   libm_sincosf_both(phif, sv, cv);
   even = r * cv;
   odd = r * sv;
+}
+
+__device__ __forceinline__ void normal_pair_from(const double *__restrict__ ltab, uint64_t y, double &even, double &odd) {
+  const uint64_t ra = squares_from(y), rb = squares_from(y + kSquaresKey);
+  box_muller(libm_log(ltab, u64_to_double(ra) * 0x1p-64), rb, even, odd);
+}
+
+// two consecutive pairs (the four draws behind a triple of normals)
+__device__ __forceinline__ void normal_two_pairs_from(const double *__restrict__ ltab, uint64_t y, double &ea, double &oa,
+                                                      double &eb, double &ob) {
+  // (the draws of the two angles are taken where they are used, not ahead of the logarithms: two registers each that
+  // would be live through them, in a kernel that has none to spare)
+  double la, lb;
+  libm_log_unit_pair(ltab, u64_to_double(squares_from(y)), u64_to_double(squares_from(y + 2 * kSquaresKey)), la, lb);
+  asm volatile("" : "+v"(la), "+v"(lb));
+  box_muller(la, squares_from(y + kSquaresKey), ea, oa);
+  asm volatile("" : "+v"(ea), "+v"(oa), "+v"(lb));
+  box_muller(lb, squares_from(y + 3 * kSquaresKey), eb, ob);
 }
 
 __device__ __forceinline__ void normal_pair(const double *__restrict__ ltab, uint64_t c0, uint64_t j2, double &even,
@@ -1385,8 +1458,7 @@ __device__ __forceinline__ void normal_triple(const double *__restrict__ ltab, u
   const bool odd = (i0 & 1) != 0;
   const uint64_t y = (c0 + (i0 & ~1ull)) * kSquaresKey;
   double ea, oa, eb, ob;
-  normal_pair_from(ltab, y, ea, oa);
-  normal_pair_from(ltab, y + 2 * kSquaresKey, eb, ob);
+  normal_two_pairs_from(ltab, y, ea, oa, eb, ob);
   r0 = odd ? oa : ea;
   r1 = odd ? eb : oa;
   r2 = odd ? ob : eb;
@@ -2323,7 +2395,7 @@ __device__ __forceinline__ void convection(const mphip_ctl_t &ctl, const DevMet 
 // module_sedi, mptrac.c:5869-5882
 __device__ __forceinline__ void sedimentation(const DevMet &M, const Axes &A, Particle &P, double rp, double rhop) {
   const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
-  const double v_s = sedi(P.p, t, rp, rhop);
+  const double v_s = sedi(P.p, t, rp, rhop, libm_tables());
   P.p += dz2dp(div_const(v_s * P.dt, 1000., 1e-3), P.p);
 }
 
@@ -2337,11 +2409,11 @@ __device__ __forceinline__ double pw_of(double p, double h2o) {   // PW, mptrac.
 }
 
 __device__ __forceinline__ double psat_of(double t) {   // PSAT, mptrac.h:1808
-  return 6.112 * exp(17.62 * (t - kT0) / (243.12 + t - kT0));
+  return 6.112 * libm_exp(17.62 * (t - kT0) / (243.12 + t - kT0));
 }
 
 __device__ __forceinline__ double psice_of(double t) {   // PSICE, mptrac.h:1832
-  return 6.112 * exp(22.46 * (t - kT0) / (272.62 + t - kT0));
+  return 6.112 * libm_exp(22.46 * (t - kT0) / (272.62 + t - kT0));
 }
 
 __device__ __forceinline__ double sh_of(double h2o) {   // SH, mptrac.h:2024
@@ -2349,17 +2421,17 @@ __device__ __forceinline__ double sh_of(double h2o) {   // SH, mptrac.h:2024
 }
 
 __device__ __forceinline__ double tdew_of(double p, double h2o) {   // TDEW, mptrac.h:2075
-  const double l = log(pw_of(p, h2o) / 6.112);
+  const double l = libm_log(pw_of(p, h2o) / 6.112);
   return kT0 + 243.12 * l / (17.62 - l);
 }
 
 __device__ __forceinline__ double tice_of(double p, double h2o) {   // TICE, mptrac.h:2100
-  const double l = log(pw_of(p, h2o) / 6.112);
+  const double l = libm_log(pw_of(p, h2o) / 6.112);
   return kT0 + 272.62 * l / (22.46 - l);
 }
 
 __device__ __forceinline__ double theta_of(double p, double t) {   // THETA, mptrac.h:2124
-  return t * pow(1000. / p, kKappa);
+  return t * libm_pow(1000. / p, kKappa);
 }
 
 __device__ __forceinline__ double zeta_of(double ps, double p, double t) {   // ZETA, mptrac.h:2293
@@ -2389,7 +2461,7 @@ __device__ __forceinline__ double isosurf_pressure(const mphip_ctl_t &ctl, const
     return iso_var;
   if (ctl.isosurf == 2 || ctl.isosurf == 3) {
     const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
-    return ctl.isosurf == 2 ? iso_var * t : 1000. * pow(iso_var / t, -1. / kKappa);
+    return ctl.isosurf == 2 ? iso_var * t : 1000. * libm_pow(iso_var / t, -1. / kKappa);
   }
   if (ctl.isosurf == 4) {
     const int n = a.iso_n;
@@ -3054,7 +3126,7 @@ __device__ __forceinline__ void diff_meso_fast(const mphip_ctl_t &ctl, const Dev
 template <bool BIG = false>
 __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const DevMet &M, const Axes &A, Particle &P,
                                                unsigned mask, uint64_t ctr, uint64_t g, const double *pre, double rp,
-                                               double rhop) {
+                                               double rhop, const double *ltab) {
   Stencil s = stencil_zero();
   horiz_fast(M, A, P.lon, P.lat, s);
   const double wt = time_weight(M, P.time);
@@ -3101,7 +3173,7 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
   if (mask & MPHIP_MOD_SEDI) {
     vert_fast(M, A, P.p, s);
     const double t = temp_fast<BIG>(M, s, wt);
-    const double v_s = sedi(P.p, t, rp, rhop);
+    const double v_s = sedi(P.p, t, rp, rhop, ltab);
     P.p += dz2dp(v_s * P.dt * 1e-3, P.p);
   }
 }
@@ -3117,10 +3189,12 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
 //   (4) one Ornstein-Uhlenbeck step of the three perturbations with the drift correction of the vertical one, the
 //       displacement, and mirror reflections at the ground and at the layer top.
 // Laid out for a wave whose lanes sit at different heights and over different surfaces: the classes are three
-// functions that fill one record; powers of a common base share one logarithm and cube roots are cbrt; the piecewise
-// vertical profile of the convective class is a choice of (base, exponents, factors) followed by ONE evaluation
-// instead of a ladder of branches with a pow pair in each, and its two candidates near the ground are compared in
-// logarithms; a particle above every boundary-layer top of the two snapshots (DevMet::turb_skip, exact: a blend with
+// functions that fill one record; the piecewise vertical profile of the convective class is a choice of (base,
+// exponents, factors) followed by ONE evaluation of the pair of powers instead of a ladder of branches with a pow
+// pair in each.  Every exp, log and pow is the C library's (libm_*, mphip_libm.h) on the reference's operands, and
+// products keep the reference's association: the values that are rounded to the single-precision perturbations are
+// then the reference's doubles whenever the particle's position and the interpolated fields are.
+// A particle above every boundary-layer top of the two snapshots (DevMet::turb_skip, exact: a blend with
 // weights in [0, 1] is not below its smallest corner) leaves without a gather.
 __device__ __forceinline__ double clampd(double v, double lo, double hi) {   // CLAMP, mptrac.h:756
   return v < lo ? lo : (v > hi ? hi : v);
@@ -3135,7 +3209,6 @@ struct PblLayer {
   double h;       // height above ground inside [0, depth] [m]
   double h1;      // ... but at least one metre
   double eta;     // h / depth inside [1e-6, 1 - 1e-6]
-  double log_eta;
 };
 
 struct PblScales {
@@ -3155,11 +3228,11 @@ struct PblTurbulence {   // component 0 / 1 / 2: along x, along y, vertical
 // keep the reference's operands and IEEE divisions / square roots wherever a value feeds the perturbations; the
 // restructuring is in what is evaluated, not in how a value is rounded.)
 // mptrac.c:4439-4449
-__device__ __forceinline__ void hanna_neutral(const PblLayer &L, const PblScales &K, PblTurbulence &T) {
+__device__ __forceinline__ void hanna_neutral(const PblLayer &L, const PblScales &K, PblTurbulence &T, const double *lt) {
 #pragma clang fp contract(off)
   const double x = L.h1 / K.ustar;
-  const double sw = 1.3 * K.ustar * exp(-2e-4 * x);
-  T.sigma[0] = dmax(2.0 * K.ustar * exp(-3e-4 * x), 1e-5);
+  const double sw = 1.3 * K.ustar * libm_exp(lt, -2e-4 * x);
+  T.sigma[0] = dmax(2.0 * K.ustar * libm_exp(lt, -3e-4 * x), 1e-5);
   T.sigma[1] = T.sigma[2] = dmax(sw, 1e-5);
   T.dsigma_w = -2e-4 * sw / K.ustar;
   T.tl[0] = T.tl[1] = T.tl[2] = 0.5 * L.h1 / T.sigma[2] / (1.0 + 1.5e-3 * x);
@@ -3171,30 +3244,36 @@ __device__ __forceinline__ void hanna_neutral(const PblLayer &L, const PblScales
 //   up to 0.96:                                             0.722 (1 - eta)^0.207
 //   above:                                                  0.37
 // and D / w*^2 d(sigma_w^2)/dz has the same shape with (1.8432, -1/3), (0.203759, -0.65), (-0.215812, -0.586), 0.
-__device__ __forceinline__ void hanna_convective(const PblLayer &L, const PblScales &K, PblTurbulence &T) {
+// Which factor meets w* first differs between the pieces in the reference (c w* B^e below 0.03 and above 0.4,
+// w* (c B^e) between, where the two candidates are compared as c B^e): kept, a product is rounded once per step.
+__device__ __forceinline__ void hanna_convective(const PblLayer &L, const PblScales &K, PblTurbulence &T, const double *lt) {
 #pragma clang fp contract(off)
   const double third = 1.0 / 3.0;
-  T.sigma[0] = T.sigma[1] = dmax(K.ustar * cbrt(dmax(12.0 - 0.5 * L.depth / K.obukhov, 0.0)), 1e-6);
-  const double log_free = log(dmax(3.0 * L.eta - K.obukhov / L.depth, 1e-12));
-  // log(0.96), log(0.763): the two candidates below eta = 0.4 compared without evaluating them
-  const bool free_smaller = -0.040821994520255166 + third * log_free < -0.27049724769768 + 0.175 * L.log_eta;
-  const bool free = (L.eta < 0.03) | ((L.eta < 0.4) & free_smaller);
-  const bool low = L.eta < 0.4, mid = L.eta < 0.96;
-  const double lb = low ? (free ? log_free : L.log_eta) : (mid ? log(1.0 - L.eta) : 0.0);
-  const double e_s = low ? (free ? third : 0.175) : 0.207, c_s = low ? (free ? 0.96 : 0.763) : (mid ? 0.722 : 0.37);
-  const double e_g = low ? (free ? -third : -0.65) : -0.586,
-               c_g = low ? (free ? 1.8432 : 0.203759) : (mid ? -0.215812 : 0.0);
-  const double shape = c_s * exp(e_s * lb), slope = c_g * exp(e_g * lb);
-  T.sigma[2] = dmax(K.wstar * shape, 1e-6);
-  T.dsigma_w = 0.5 * (slope * (K.wstar * K.wstar) / L.depth) / T.sigma[2];
-  T.tl[0] = T.tl[1] = 0.15 * L.depth / T.sigma[0];
+  T.sigma[0] = T.sigma[1] = dmax(K.ustar * libm_pow(lt, dmax(12.0 - 0.5 * L.depth / K.obukhov, 0.0), third), 1e-6);
+  const bool low = L.eta < 0.4, mid = L.eta < 0.96, candidates = low & !(L.eta < 0.03);
+  const double base_free = dmax(3.0 * L.eta - K.obukhov / L.depth, 1e-12);
+  // the power of the piece's own base ... (above 0.96 none is needed: base 1)
+  const double pw_piece = libm_pow(lt, low ? base_free : (mid ? 1.0 - L.eta : 1.0), low ? third : 0.207);
+  // ... and, where two candidates compete, the other one's
+  const double s1 = 0.96 * pw_piece;
+  const double s2 = candidates ? 0.763 * libm_pow(lt, L.eta, 0.175) : 0.0;
+  const bool free = low & (!candidates | (s1 < s2));
+  const double sig_w = low ? (candidates ? K.wstar * (free ? s1 : s2) : 0.96 * K.wstar * pw_piece)
+                           : (mid ? 0.722 * K.wstar * pw_piece : 0.37 * K.wstar);
+  const double base_g = low ? (free ? base_free : L.eta) : 1.0 - L.eta;
+  const double e_g = low ? (free ? -third : -0.65) : -0.586;
+  const double c_g = low ? (free ? 1.8432 : 0.203759) : -0.215812;
+  const double grad = mid ? c_g * (K.wstar * K.wstar) / L.depth * libm_pow(lt, base_g, e_g) : 0.0;   // d(sigma_w^2)/dz
+  T.sigma[2] = dmax(sig_w, 1e-6);
+  T.dsigma_w = 0.5 * grad / T.sigma[2];
+  T.tl[0] = T.tl[1] = 0.15 * L.depth / dmax(T.sigma[0], 1e-12);
   const double near_ground = 0.1 * L.h1 / (T.sigma[2] * dmax(0.55 - 0.38 * fabs(L.h1 / K.obukhov), 0.05));
-  const double aloft = L.eta < 0.1 ? 0.59 * L.h1 / T.sigma[2] : 0.15 * L.depth / T.sigma[2] * (1.0 - exp(-5.0 * L.eta));
+  const double aloft = L.eta < 0.1 ? 0.59 * L.h1 / T.sigma[2] : 0.15 * L.depth / T.sigma[2] * (1.0 - libm_exp(lt, -5.0 * L.eta));
   T.tl[2] = L.h1 < fabs(K.obukhov) ? near_ground : aloft;
 }
 
 // mptrac.c:4512-4522
-__device__ __forceinline__ void hanna_stable(const PblLayer &L, const PblScales &K, PblTurbulence &T) {
+__device__ __forceinline__ void hanna_stable(const PblLayer &L, const PblScales &K, PblTurbulence &T, const double *lt) {
 #pragma clang fp contract(off)
   const double fade = 1.0 - L.eta;
   T.sigma[0] = dmax(2.0 * K.ustar * fade, 1e-6);
@@ -3202,7 +3281,7 @@ __device__ __forceinline__ void hanna_stable(const PblLayer &L, const PblScales 
   T.dsigma_w = -1.3 * K.ustar / L.depth;
   T.tl[0] = 0.15 * L.depth / T.sigma[0] * sqrt(L.eta);
   T.tl[1] = 0.467 * T.tl[0];
-  T.tl[2] = 0.1 * L.depth / T.sigma[2] * exp(0.8 * L.log_eta);
+  T.tl[2] = 0.1 * L.depth / T.sigma[2] * libm_pow(lt, L.eta, 0.8);
 }
 
 // LEAN: the stencils and gathers of the lean kernels (lat/lon grid with the pressure table, 32-bit offsets)
@@ -3232,15 +3311,14 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   if (!(ps > 0.0 && pbl > 0.0 && ps > pbl))
     return;
   const double p_in = dmin(P.p, ps);
-  const double ground_km = zfromp(ps);
+  const double ground_km = kH0 * libm_log(ltab, kP0 / ps);                 // Z(), mptrac.h:2243
   PblLayer L;
-  L.depth = 1e3 * (zfromp(pbl) - ground_km);
+  L.depth = 1e3 * (kH0 * libm_log(ltab, kP0 / pbl) - ground_km);
   if (!(L.depth > 1.0))
     return;
-  L.h = clampd(1e3 * (zfromp(p_in) - ground_km), 0.0, L.depth);
+  L.h = clampd(1e3 * (kH0 * libm_log(ltab, kP0 / p_in) - ground_km), 0.0, L.depth);
   L.eta = clampd(L.h / L.depth, 1e-6, 1.0 - 1e-6);
   L.h1 = dmax(L.h, 1.0);
-  L.log_eta = log(L.eta);
 
   // (2) the scales (mptrac.c:4400-4436): air density and virtual potential temperature at the particle, stresses and
   // heat flux of the surface
@@ -3261,20 +3339,20 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   const double rho = rho_air(p_in, tvirt(t, h2o));
   if (!(rho > 0.0))
     return;
-  const double theta_v = tvirt(t * pow(1000. / p_in, kKappa), dmax(h2o, 0.1e-6));   // THETAVIRT, mptrac.h:2153
+  const double theta_v = tvirt(t * libm_pow(ltab, 1000. / p_in, kKappa), dmax(h2o, 0.1e-6));   // THETAVIRT, mptrac.h:2153
   PblScales K;
   K.ustar = dmax(1e-4, sqrt(dmax(sqrt(stress_x * stress_x + stress_y * stress_y) / rho, 0.0)));
   K.obukhov = fabs(heat_flux) > 1e-6 ? theta_v * rho * kCpd * (K.ustar * K.ustar) * K.ustar / (kKarman * kG0 * heat_flux) : 1e12;
 
   // (3) the class (mptrac.c:4438-4523): neutral while the layer is shallower than |L|, else by the sign of L
   PblTurbulence T;
-  if (L.depth < fabs(K.obukhov))
-    hanna_neutral(L, K, T);
+  if (L.depth / fabs(K.obukhov) < 1.0)
+    hanna_neutral(L, K, T, ltab);
   else if (K.obukhov < 0.0) {
-    K.wstar = cbrt(dmax(-kG0 / theta_v * heat_flux / (rho * kCpd) * L.depth, 0.0));
-    hanna_convective(L, K, T);
+    K.wstar = libm_pow(ltab, dmax(-kG0 / theta_v * heat_flux / (rho * kCpd) * L.depth, 0.0), 1.0 / 3.0);
+    hanna_convective(L, K, T, ltab);
   } else
-    hanna_stable(L, K, T);
+    hanna_stable(L, K, T, ltab);
   T.tl[0] = dmax(T.tl[0], 10.0);
   T.tl[1] = dmax(T.tl[1], 10.0);
   T.tl[2] = dmax(T.tl[2], 30.0);
@@ -3292,7 +3370,7 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   const double dt = P.dt, span = fabs(P.dt);
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const double keep = exp(-span / T.tl[k]);
+    const double keep = libm_exp(ltab, -span / T.tl[k]);
     double v = vel[k] * keep + T.sigma[k] * sqrt(dmax(0.0, 1.0 - keep * keep)) * xi[k];
     if (k == 2)   // drift of the vertical component: well-mixed condition + density gradient -1 / H
       v += T.tl[2] * (1.0 - keep) * (2.0 * T.sigma[2] * T.dsigma_w + (-1.0 / (1e3 * kH0)) * (T.sigma[2] * T.sigma[2]));
@@ -3311,7 +3389,7 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
   up = (float) vel[0];
   vp = (float) vel[1];
   wp = flipped ? -(float) vel[2] : (float) vel[2];
-  P.p = clampd(kP0 * exp(-(ground_km + h / 1000.0) / kH0), pbl, ps);   // P(z), mptrac.h:1784
+  P.p = clampd(kP0 * libm_exp(ltab, -(ground_km + h / 1000.0) / kH0), pbl, ps);   // P(z), mptrac.h:1784
 }
 
 // The closure as a function call.  Inlined into the fused step kernel its registers push the whole kernel into scratch

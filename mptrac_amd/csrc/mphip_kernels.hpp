@@ -262,7 +262,7 @@ __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M
     return;
   const double pcb = sfb_time_2d(c2, s, wt, 1);
   const double cl = sfb_time_2d(c2, s, wt, 2);
-  const double Is = pow(1. / ctl.wet_depo_pre[0] * cl, 1. / ctl.wet_depo_pre[1]);
+  const double Is = libm_pow(1. / ctl.wet_depo_pre[0] * cl, 1. / ctl.wet_depo_pre[1]);
   if (Is < 0.01)
     return;
   stencil_3d(M, A, P.p, P.lon, P.lat, s);
@@ -285,13 +285,13 @@ __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M
     else
       eta = lin(kWdTLiquid, 1, kWdTIce, ctl.wet_depo_ic_ret_ratio, t);
     if (ctl.wet_depo_ic_a > 0)
-      lambda = ctl.wet_depo_ic_a * pow(Is, ctl.wet_depo_ic_b) * eta;
+      lambda = ctl.wet_depo_ic_a * libm_pow(Is, ctl.wet_depo_ic_b) * eta;
     else if (ctl.wet_depo_ic_h[0] > 0) {
-      double h = ctl.wet_depo_ic_h[0] * exp(ctl.wet_depo_ic_h[1] * (1. / t - 1. / kTRef));
+      double h = ctl.wet_depo_ic_h[0] * libm_exp(ctl.wet_depo_ic_h[1] * (1. / t - 1. / kTRef));
       if (ctl.wet_depo_so2_ph > 0) {
-        const double H_ion = pow(10., -ctl.wet_depo_so2_ph);
-        const double K_1 = kSO2K1Ref * exp(kSO2K1Temp * (1. / t - 1. / kTRef));
-        const double K_2 = kSO2K2Ref * exp(kSO2K2Temp * (1. / t - 1. / kTRef));
+        const double H_ion = libm_pow(10., -ctl.wet_depo_so2_ph);
+        const double K_1 = kSO2K1Ref * libm_exp(kSO2K1Temp * (1. / t - 1. / kTRef));
+        const double K_2 = kSO2K2Ref * libm_exp(kSO2K2Temp * (1. / t - 1. / kTRef));
         h *= (1. + K_1 / H_ion + K_1 * K_2 / (H_ion * H_ion));
       }
       const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
@@ -300,14 +300,14 @@ __device__ __forceinline__ void wet_depo(const mphip_ctl_t &ctl, const DevMet &M
   } else {
     const double eta = (t > kWdTLiquidBC) ? 1 : ctl.wet_depo_bc_ret_ratio;
     if (ctl.wet_depo_bc_a > 0)
-      lambda = ctl.wet_depo_bc_a * pow(Is, ctl.wet_depo_bc_b) * eta;
+      lambda = ctl.wet_depo_bc_a * libm_pow(Is, ctl.wet_depo_bc_b) * eta;
     else if (ctl.wet_depo_bc_h[0] > 0) {
-      const double h = ctl.wet_depo_bc_h[0] * exp(ctl.wet_depo_bc_h[1] * (1. / t - 1. / kTRef));
+      const double h = ctl.wet_depo_bc_h[0] * libm_exp(ctl.wet_depo_bc_h[1] * (1. / t - 1. / kTRef));
       const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
       lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
     }
   }
-  const double aux = exp(-P.dt * lambda);
+  const double aux = libm_exp(-P.dt * lambda);
   apply_loss(ctl, a, i, aux, ctl.qnt_mloss_wet, lambda);
 }
 
@@ -327,10 +327,10 @@ __device__ __forceinline__ void dry_depo(const mphip_ctl_t &ctl, const DevMet &M
   double v_dep;
   if (ctl.qnt_rp > 0 && ctl.qnt_rhop > 0) {   // "> 0" as the reference, mptrac.c:4769
     const double t = temperature_at(M, A, P.time, P.p, P.lon, P.lat);
-    v_dep = sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]);
+    v_dep = sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i], libm_tables());
   } else
     v_dep = ctl.dry_depo_vdep;
-  const double aux = exp(-P.dt * v_dep / dz);
+  const double aux = libm_exp(-P.dt * v_dep / dz);
   apply_loss(ctl, a, i, aux, ctl.qnt_mloss_dry, v_dep / dz);
 }
 
@@ -364,7 +364,7 @@ __device__ __forceinline__ void depo_pair_factor(const mphip_ctl_t &ctl, const D
     if (isfinite(pct) && P.p > pct) {
       pcb = sfb_time_2d(c2, s, wt, 1);
       const double cl = sfb_time_2d(c2, s, wt, 2);
-      Is = pow(1. / ctl.wet_depo_pre[0] * cl, 1. / ctl.wet_depo_pre[1]);
+      Is = libm_pow(1. / ctl.wet_depo_pre[0] * cl, 1. / ctl.wet_depo_pre[1]);
       wet_go = !(Is < 0.01);
     }
   }
@@ -401,13 +401,13 @@ __device__ __forceinline__ void depo_pair_factor(const mphip_ctl_t &ctl, const D
       else
         eta = lin(kWdTLiquid, 1, kWdTIce, ctl.wet_depo_ic_ret_ratio, t);
       if (ctl.wet_depo_ic_a > 0)
-        lambda = ctl.wet_depo_ic_a * pow(Is, ctl.wet_depo_ic_b) * eta;
+        lambda = ctl.wet_depo_ic_a * libm_pow(Is, ctl.wet_depo_ic_b) * eta;
       else if (ctl.wet_depo_ic_h[0] > 0) {
-        double h = ctl.wet_depo_ic_h[0] * exp(ctl.wet_depo_ic_h[1] * (1. / t - 1. / kTRef));
+        double h = ctl.wet_depo_ic_h[0] * libm_exp(ctl.wet_depo_ic_h[1] * (1. / t - 1. / kTRef));
         if (ctl.wet_depo_so2_ph > 0) {
-          const double H_ion = pow(10., -ctl.wet_depo_so2_ph);
-          const double K_1 = kSO2K1Ref * exp(kSO2K1Temp * (1. / t - 1. / kTRef));
-          const double K_2 = kSO2K2Ref * exp(kSO2K2Temp * (1. / t - 1. / kTRef));
+          const double H_ion = libm_pow(10., -ctl.wet_depo_so2_ph);
+          const double K_1 = kSO2K1Ref * libm_exp(kSO2K1Temp * (1. / t - 1. / kTRef));
+          const double K_2 = kSO2K2Ref * libm_exp(kSO2K2Temp * (1. / t - 1. / kTRef));
           h *= (1. + K_1 / H_ion + K_1 * K_2 / (H_ion * H_ion));
         }
         const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
@@ -416,18 +416,18 @@ __device__ __forceinline__ void depo_pair_factor(const mphip_ctl_t &ctl, const D
     } else {
       const double eta = (t > kWdTLiquidBC) ? 1 : ctl.wet_depo_bc_ret_ratio;
       if (ctl.wet_depo_bc_a > 0)
-        lambda = ctl.wet_depo_bc_a * pow(Is, ctl.wet_depo_bc_b) * eta;
+        lambda = ctl.wet_depo_bc_a * libm_pow(Is, ctl.wet_depo_bc_b) * eta;
       else if (ctl.wet_depo_bc_h[0] > 0) {
-        const double h = ctl.wet_depo_bc_h[0] * exp(ctl.wet_depo_bc_h[1] * (1. / t - 1. / kTRef));
+        const double h = ctl.wet_depo_bc_h[0] * libm_exp(ctl.wet_depo_bc_h[1] * (1. / t - 1. / kTRef));
         const double dz = 1e3 * (zfromp(pct) - zfromp(pcb));
         lambda = h * kRI * t * Is / 3.6e6 / dz * eta;
       }
     }
-    wet(exp(-P.dt * lambda), lambda);
+    wet(libm_exp(-P.dt * lambda), lambda);
   }
   if (dry_go) {
-    const double v_dep = dry_sedi ? sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i]) : ctl.dry_depo_vdep;
-    dry(exp(-P.dt * v_dep / dz_dry), v_dep / dz_dry);
+    const double v_dep = dry_sedi ? sedi(P.p, t, a.q[ctl.qnt_rp][i], a.q[ctl.qnt_rhop][i], libm_tables()) : ctl.dry_depo_vdep;
+    dry(libm_exp(-P.dt * v_dep / dz_dry), v_dep / dz_dry);
   }
 }
 
@@ -621,13 +621,14 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
       dst[i] = src[i];
     clim = (const DevClim *) dst;
   }
-  // ... and the table of the lean logarithm behind it (3 kB)
-  const double *ltab = M.logtab;   // (the general instantiations read it from global memory)
-  if (!kRuntimeMask<CT> && (mask & (MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO))) {
+  // ... and the tables of the C library's log and exp behind it (4 kB; with the boundary-layer closure pow's too, 7 kB)
+  const double *ltab = libm_tables();   // (the general instantiations read them from device memory)
+  if (!kRuntimeMask<CT> && (mask & (MPHIP_MOD_DIFF_TURB | MPHIP_MOD_DIFF_MESO | MPHIP_MOD_SEDI))) {
     double *dst = s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8
       + sizeof(DevClim) / sizeof(double);
-    for (int i = threadIdx.x; i < 3 * kLogTabN; i += blockDim.x)
-      dst[i] = M.logtab[i];
+    const double *src = libm_tables();
+    for (int i = threadIdx.x; i < ((CT & kPblClosure) ? kLibmDoubles : kLibmLogExpDoubles); i += blockDim.x)
+      dst[i] = src[i];
     ltab = dst;
   }
   __syncthreads();
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
       if (opt & (MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI)) {
         const bool sedi_on = (opt & MPHIP_MOD_SEDI) != 0;
         conv_sedi_fast<kBig<CT>>(ctl, M, A, P, opt, c_conv, g, early ? &pre.conv : nullptr,
-                       sedi_on ? ld_state(&a.q[ctl.qnt_rp][i]) : 0.0, sedi_on ? ld_state(&a.q[ctl.qnt_rhop][i]) : 0.0);
+                       sedi_on ? ld_state(&a.q[ctl.qnt_rp][i]) : 0.0, sedi_on ? ld_state(&a.q[ctl.qnt_rhop][i]) : 0.0, ltab);
       }
     } else {
       if (opt & MPHIP_MOD_CONVECTION)
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
     if (tmask & MPHIP_MOD_DECAY) {   // module_decay, mptrac.c:4241-4261
       const double w = tropo_weight(ctl, *clim, P.time, P.lat, P.p);
       const double tdec = w * ctl.tdec_trop + (1 - w) * ctl.tdec_strat;
-      const double aux = exp(-P.dt / tdec);
+      const double aux = libm_exp(ltab, -P.dt / tdec);
       apply_loss(ctl, a, i, aux, ctl.qnt_mloss_decay, 1. / tdec);
     }
     if (lean) {
@@ -2971,8 +2972,8 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
     dst[i] = src[i];
   const DevClim &clim = *(const DevClim *) dst;
   double *ltab = dst + sizeof(DevClim) / sizeof(double);
-  for (int i = threadIdx.x; i < 3 * kLogTabN; i += blockDim.x)
-    ltab[i] = M.logtab[i];
+  for (int i = threadIdx.x; i < kLibmLogExpDoubles; i += blockDim.x)
+    ltab[i] = libm_tables()[i];
   __syncthreads();
   const int nb = S.nblocks_logical;
   const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
@@ -3008,7 +3009,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
         acc += wind_time_3d(c, s, wt, 0) + wind_time_3d(c, s, wt, 1) + wind_time_3d(c, s, wt, 2);
       } else if (PIECE == 4) {
         double r0, r1, r2;
-        normal_triple(M.logtab, S.ctr_turb + (uint64_t) r, g, r0, r1, r2);   // (table in global memory)
+        normal_triple(libm_tables(), S.ctr_turb + (uint64_t) r, g, r0, r1, r2);   // (table in device memory)
         acc += r0 + r1 + r2;
       } else if (PIECE == 5) {
         Particle Q = P;
@@ -3031,7 +3032,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
       } else if (PIECE == 9) {
         acc += tropo_weight(ctl, clim, P.time + r, lat, p);
       } else if (PIECE == 10) {
-        acc += sedi(p, 220.0 + r, 1.0, 1000.0);
+        acc += sedi(p, 220.0 + r, 1.0, 1000.0, ltab);
       } else if (PIECE == 11) {
         acc += uniform01(S.ctr_conv + g + (uint64_t) r);
       } else if (PIECE == 12) {   // module_diff_turb as a whole
@@ -3104,7 +3105,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
         Q.lon = lon;
         Q.lat = lat;
         Q.p = p;
-        conv_sedi_fast(ctl, M, A, Q, MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI, S.ctr_conv + (uint64_t) r, g, nullptr, 1.0, 1000.0);
+        conv_sedi_fast(ctl, M, A, Q, MPHIP_MOD_CONVECTION | MPHIP_MOD_SEDI, S.ctr_conv + (uint64_t) r, g, nullptr, 1.0, 1000.0, ltab);
         acc += Q.p;
       } else if (PIECE == 22) {
         Particle Q = P;
@@ -3131,7 +3132,7 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
         normal_pair_from(ltab, (S.ctr_turb + g + (uint64_t) r) * kSquaresKey, ee, rr);
         acc += rr + ee;
       } else if (PIECE == 25) {
-        acc += log_tab(ltab, u64_to_double(squares(S.ctr_turb + g + (uint64_t) r) | 1));
+        acc += libm_log(ltab, u64_to_double(squares(S.ctr_turb + g + (uint64_t) r) | 1) * 0x1p-64);
       } else if (PIECE == 26) {
         float sv, cv;
         libm_sincosf_both((float) (6.28 * uniform01(S.ctr_turb + g + (uint64_t) r)), sv, cv);
@@ -3144,9 +3145,31 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
   }
 }
 
+// out[i] = exp(x[i]) / log(x[i]) / pow(x[i], y[i]) / sqrt(x[i]) (op 0 / 1 / 2 / 3) as the kernels evaluate them: the C
+// library's functions of mphip_libm.h and the square root of the Box-Muller radius; op + 16: tables copied to LDS first
+__global__ __launch_bounds__(256) void test_libm_kernel(int op, const double *__restrict__ x, const double *__restrict__ y,
+                                                         long long n, double *__restrict__ out) {
+  __shared__ double s_tab[kLibmDoubles];
+  const double *lt = libm_tables();
+  if (op & 16) {
+    for (int i = threadIdx.x; i < kLibmDoubles; i += blockDim.x)
+      s_tab[i] = lt[i];
+    __syncthreads();
+    lt = s_tab;
+  }
+  for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
+    switch (op & 15) {
+    case 0: out[i] = libm_exp(lt, x[i]); break;
+    case 1: out[i] = libm_log(lt, x[i]); break;
+    case 2: out[i] = libm_pow(lt, x[i], y[i]); break;
+    default: out[i] = sqrt_rn(x[i]); break;
+    }
+  }
+}
+
 // out[i], i < n: what module_rng(ctl, rs, n, method) leaves in rs[i]
-__global__ void test_rng_kernel(uint64_t ctr, long long n, int method, double *__restrict__ out,
-                                const double *__restrict__ ltab) {
+__global__ void test_rng_kernel(uint64_t ctr, long long n, int method, double *__restrict__ out) {
+  const double *ltab = libm_tables();
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
     if (method == 0)
       out[i] = uniform01(ctr + (uint64_t) i);

@@ -117,6 +117,8 @@ def load(build=True):
     L.mphip_test_sincosf.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _fp, _fp]
     L.mphip_test_rng.argtypes = [C.c_void_p, C.c_uint64, C.c_longlong, C.c_int, _dp]
     L.mphip_test_piece.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+    if hasattr(L, "mphip_test_libm"):      # (absent from libraries built before round 6: A/B runs through MPHIP_LIB)
+        L.mphip_test_libm.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_longlong, _dp]
     if L.mphip_sizeof_ctl() != C.sizeof(MphipCtl):
         raise MphipError("mphip_ctl_t layout mismatch between header and Python mirror")
     if L.mphip_sizeof_met() != C.sizeof(MphipMet):
@@ -463,4 +465,14 @@ class Simulation:
     def test_rng(self, ctr, n, method):
         out = np.empty(n)
         self._chk(self.L.mphip_test_rng(self.h, ctr, n, method, _ptr(out, _dp)))
+        return out
+
+    def test_libm(self, fn, x, y=None, lds=False):
+        """exp / log / pow / sqrt of the arrays as the kernels evaluate them (mphip_libm.h; tables from LDS if asked)."""
+        op = {"exp": 0, "log": 1, "pow": 2, "sqrt": 3}[fn] + (16 if lds else 0)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float64)
+        out = np.empty_like(x)
+        self._chk(self.L.mphip_test_libm(self.h, op, _ptr(x, _dp), _ptr(y, _dp) if y is not None else None, len(x), _ptr(out, _dp)))
         return out

@@ -385,6 +385,14 @@ void orc_libm_sincosf(const float *x, size_t n, float *cos_out, float *sin_out) 
   }
 }
 
+/* the C library's double functions over arrays: op 0 exp(x), 1 log(x), 2 pow(x, y), 3 sqrt(x) -- the checker of
+ * the device's restatements (csrc/mphip_libm.h) */
+void orc_libm_f64(int op, const double *x, const double *y, size_t n, double *out) {
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; i++)
+    out[i] = op == 0 ? exp(x[i]) : op == 1 ? log(x[i]) : op == 2 ? pow(x[i], y[i]) : sqrt(x[i]);
+}
+
 /* module_rng, RNG_TYPE=1 branch: n+1 uniforms, counter advanced by n+1, then
  * Box-Muller over flat pairs with single-precision trig (mptrac.c:5797-5827) */
 void orc_module_rng(const orc_ctl_t *ctl, orc_cache_t *cache, size_t n, int method) {

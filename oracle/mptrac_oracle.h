@@ -195,6 +195,7 @@ double orc_pbl_weight(const orc_ctl_t *ctl, double p, double pbl, double ps); /*
 uint64_t orc_squares(uint64_t ctr);                              /* mptrac.c:5797-5809 */
 /* the C library's cosf / sinf, as module_rng calls them (mptrac.c:5824-5825) */
 void orc_libm_sincosf(const float *x, size_t n, float *cos_out, float *sin_out);
+void orc_libm_f64(int op, const double *x, const double *y, size_t n, double *out);
 void orc_intpol_met_time_3d(const orc_met_t *met0, const orc_met_t *met1, int field,
                             double ts, double p, double lon, double lat, double *var);
 void orc_intpol_met_time_2d(const orc_met_t *met0, const orc_met_t *met1, int field,

@@ -1,0 +1,164 @@
+"""A second opinion on the oracle where no reference-held golden exists (VERDICT r05 "missing" 4): the
+modules restated a second time, in numpy, from the text of the reference (tests/refmodules.py, not derived from
+oracle/), against the oracle on 1000 particles -- ADVECT 4 with its old-latitude rule (and 2 / 1 through the same
+code), both branches of module_diff_turb incl. the displaced latitude of the vertical probes, module_convection,
+module_sedi, module_mixing, wet and dry deposition.  Bar: 1e-13 relative (numpy's exp / log / pow are not glibc's)."""
+import numpy as np
+import pytest
+
+import cases
+import refmodules as R
+from oracle import binding as B
+
+N = 1000
+TOL = 1e-13
+
+
+def _oracle(name, seed=4711, **over):
+    ctl, clim, m0, m1, atm = cases.make_case(name, n=N, seed=seed)
+    ctl.update(over)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    t = cases.step_times(o.ctl)[1]          # (the first call of the time loop has dt = 0)
+    o.module("timesteps", t)
+    return o, R.Ref(o.ctl, clim, m0, m1), t
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+
+
+def _qdict(o, names):
+    return {k: o.q[getattr(o.ctl, "qnt_" + k)].copy() for k in names if getattr(o.ctl, "qnt_" + k) >= 0}
+
+
+@pytest.mark.parametrize("advect", [4, 2, 1])
+def test_advect_pressure_levels(advect):
+    """ADVECT 4 is the headline integrator and appears in no reference test; 2 is pinned by the dd_test golden, so the
+    same numpy code agreeing on all three ties the four-stage loop to the pinned one."""
+    o, ref, _ = _oracle("advect", advect=advect)
+    # a few particles next to the poles and across the date line (DX2DEG's cut-off, FMOD of the longitude)
+    o.lat[:4] = (89.9995, -89.9995, 89.99, -89.99)
+    o.lon[4:8] = (179.999, -179.999, 359.5, -200.0)
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    o.module("advect")
+    time, lon, lat, p = ref.advect(*s0, o.dt.copy())
+    assert np.array_equal(time, o.time)
+    assert _rel(lon, o.lon) <= TOL and _rel(lat, o.lat) <= TOL and _rel(p, o.p) <= TOL
+    assert np.max(np.abs(lon - s0[1])) > 1e-3          # (the particles did move)
+
+
+def test_old_latitude_rule_is_observable():
+    """mptrac.c:3672-3673: only ADVECT 2 converts the final longitude step at the latitude of its last node; the
+    restatement with the rule swapped differs from the oracle by far more than the bar -- the check above can see it."""
+    o, ref, _ = _oracle("advect", advect=4)
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    o.module("advect")
+    orig = R.DX2DEG
+    calls = []
+
+    def swapped(dx, lat):
+        calls.append(1)
+        return orig(dx, lat + 0.01) if len(calls) == 4 else orig(dx, lat)    # the final step at a displaced latitude
+    R.DX2DEG = swapped
+    try:
+        _, lon, _, _ = ref.advect(*s0, o.dt.copy())
+    finally:
+        R.DX2DEG = orig
+    assert _rel(lon, o.lon) > 1e-9
+
+
+@pytest.mark.parametrize("case,over", [("turb", {}), ("turb", dict(turb_dx_trop=50.0, turb_dx_strat=0.0, turb_dz_strat=0.1)),
+                                       ("conv_sedi", {})])
+def test_diff_turb_both_branches(case, over):
+    o, ref, _ = _oracle(case, **over)
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    o.module("diff_turb")
+    rs = o.rs[:3 * N].copy()
+    lon, lat, p = ref.diff_turb(*s0, o.dt.copy(), rs)
+    assert _rel(lon, o.lon) <= TOL and _rel(lat, o.lat) <= TOL and _rel(p, o.p) <= TOL
+    assert np.max(np.abs(p - s0[3])) > 1e-6
+
+
+def test_vertical_probes_use_the_displaced_latitude():
+    """The weights of the two probes of dKz/dz are evaluated after the horizontal part moved the particle
+    (mptrac.c:4639-4641 write atm->lat, 4668-4684 read it): with the old latitude the restatement leaves the bar."""
+    o, ref, _ = _oracle("turb", turb_dx_trop=5e7, turb_dx_strat=5e7, turb_dz_trop=1.0, turb_dz_strat=0.1)      # (steps of ~100 km)
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    o.module("diff_turb")
+    rs = o.rs[:3 * N].copy()
+    _, _, p = ref.diff_turb(*s0, o.dt.copy(), rs)
+    assert _rel(p, o.p) <= TOL
+    tw = ref.tropo_weight
+    ref.tropo_weight = lambda t, lat, pp: tw(t, s0[2], pp)       # every weight at the old latitude
+    _, _, p_old = ref.diff_turb(*s0, o.dt.copy(), rs)
+    assert _rel(p_old, o.p) > 1e-11
+
+
+@pytest.mark.parametrize("case,over", [("conv_sedi", {}), ("conv_thresh", {}), ("conv_sedi", dict(conv_mix_pbl=0, conv_cape=120.0))])
+def test_convection(case, over):
+    o, ref, _ = _oracle(case, **over)
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    o.module("convection")
+    p = ref.convection(*s0, o.rs[:N].copy())
+    assert _rel(p, o.p) <= TOL
+    moved = np.count_nonzero(p != s0[3])
+    assert 0 < moved < N                       # some particles are mixed, some are not
+
+
+def test_sedimentation():
+    o, ref, _ = _oracle("conv_sedi")
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    rp, rhop = o.q[o.ctl.qnt_rp].copy(), o.q[o.ctl.qnt_rhop].copy()
+    o.module("sedi")
+    p = ref.sedimentation(*s0, o.dt.copy(), rp, rhop)
+    assert _rel(p, o.p) <= TOL and np.max(np.abs(p - s0[3]) / s0[3]) > 1e-9
+
+
+def test_mixing():
+    o, ref, t = _oracle("full", mixing_nx=6, mixing_ny=3, mixing_nz=4)       # (boxes that hold several of the 1000 particles)
+    o.time[:] = t                                                            # module_mixing runs behind the movers
+    o.time[::50] = 0.0                                                       # ... and leaves out other times
+    names = [k for k in ("m", "vmr") if getattr(o.ctl, "qnt_" + k) >= 0]
+    o.q[o.ctl.qnt_vmr][:] = np.random.default_rng(5).uniform(1e-10, 3e-9, N)  # (the case starts from a constant ratio)
+    rows = [o.q[getattr(o.ctl, "qnt_" + k)].copy() for k in names]
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    o.module("mixing", t)
+    new = ref.mixing(t, *s0, rows)
+    for k, a, before in zip(names, new, rows):
+        got = o.q[getattr(o.ctl, "qnt_" + k)]
+        scale = float(np.max(np.abs(got)))
+        assert float(np.max(np.abs(a - got))) <= TOL * scale, k
+        assert np.count_nonzero(got != before) > N // 2, k
+
+
+def _scale(o, k, got):
+    """a lost mass m (1 - aux) is a small difference of numbers near one: held to the scale of the mass itself"""
+    ref_row = o.q[o.ctl.qnt_m] if k.startswith("mloss") else got
+    return max(float(np.max(np.abs(ref_row))), 1e-300)
+
+
+@pytest.mark.parametrize("case", ["full", "wet_henry"])
+def test_wet_and_dry_deposition(case):
+    o, ref, _ = _oracle(case)
+    names = ("m", "vmr", "loss_rate", "mloss_wet", "mloss_dry")
+    o.p[::10] = ref.time_2d("ps", o.time, o.lon, o.lat)[::10] - np.linspace(0.0, 40.0, N)[::10]   # some inside the surface layer
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    dt = o.dt.copy()
+    q0 = _qdict(o, names)
+    o.module("wet_depo")
+    act, aux, lam = ref.wet_depo(*s0, dt)
+    q1 = ref.apply_loss(q0, act, aux, lam, "mloss_wet")
+    assert 0 < np.count_nonzero(act) < N
+    for k, v in q1.items():
+        got = o.q[getattr(o.ctl, "qnt_" + k)]
+        assert float(np.max(np.abs(v - got))) <= TOL * _scale(o, k, got), ("wet", k)
+    rp = o.q[o.ctl.qnt_rp].copy() if o.ctl.qnt_rp >= 0 else None
+    rhop = o.q[o.ctl.qnt_rhop].copy() if o.ctl.qnt_rhop >= 0 else None
+    o.module("dry_depo")
+    act, aux, rate = ref.dry_depo(*s0, dt, rp, rhop)
+    q2 = ref.apply_loss(q1, act, aux, rate, "mloss_dry")
+    assert 0 < np.count_nonzero(act) < N
+    for k, v in q2.items():
+        got = o.q[getattr(o.ctl, "qnt_" + k)]
+        assert float(np.max(np.abs(v - got))) <= TOL * _scale(o, k, got), ("dry", k)
