@@ -373,12 +373,12 @@ int mphip_comm_query(mphip_ctx *ctx, int *nranks, int *rank);
  *     measured slower than the default gathers;
  *   "emit_keys" (default 1): in a time step with module_mixing, the launch that moves the particles also writes the keys
  *     of the next step's module_sort, its module_timesteps and module_mixing's box index (otherwise a kernel of their own
- *     behind it); same values;
+ *     behind it); same values.  Taken for the headline module set only -- ADVECT 4 with turbulent + mesoscale diffusion,
+ *     convection and sedimentation, no module_bound_cond; every other set (ADVECT 2 / 1, subsets of the movers, the
+ *     boundary condition) keeps the separate key kernel;
  *   "sort_repair" (default 1): the module_sort that runs ahead repairs the order of the previous module_sort (only the
  *     particles that changed their cell are sorted, then merged with the others) instead of sorting from scratch; same
- *     permutation;
- *   "depo_beside_mixing" (default 0): in a time step with module_mixing, compute the factors of module_wet_depo /
- *     module_dry_depo beside module_mixing (a second stream) and apply them behind the relaxation; same results
+ *     permutation
  *   "big_grid" (default 0): tests -- take the instantiations with 64-bit byte offsets into the packed meteo records (what a
  *     grid with more than 4 GB of wind records -- 178e6 cells -- takes by itself) on a grid that fits 32 bits too: same bits. */
 int mphip_set_option(mphip_ctx *ctx, const char *name, double value);

@@ -78,8 +78,10 @@ def verify_async_loads(lib, verbose=False):
     try:
         hazards, kernels, nloads = chk.check(lib)
     except chk.ToolMissing as exc:      # (a box without the LLVM tools: a prebuilt library was checked where it was built)
-        if verbose:
-            print(f"machine-code check skipped: {exc}")
+        # never silent: a library that was compiled here and could not be checked is reported as unverified
+        import sys
+        print(f"mptrac_amd.build: machine-code check of {os.path.basename(lib)} NOT run ({exc}); the library is unverified",
+              file=sys.stderr)
         return
     if hazards:
         bad = lib + ".rejected"
@@ -99,31 +101,36 @@ MET_CONV_BIN = os.path.join(LIBDIR, "met_conv")
 HOST_DIMS = {"NP": 200000, "NQ": 15, "EX": 364, "EY": 186, "EP": 64}
 
 
-def build_host(force=False, verbose=False, dims=None):
+def build_host(force=False, verbose=False, dims=None, outdir=None):
     """Host-side C library (the reference's mptrac_* interface on the C ABI)
-    and the trac driver.  Plain gcc; links against libmptrac_hip.so."""
+    and the trac driver.  Plain gcc; links against libmptrac_hip.so.
+    `outdir`: a second build beside the default one (production extents: tools/gpu_trac_dropin.py)."""
     os.makedirs(LIBDIR, exist_ok=True)
     dims = dict(HOST_DIMS, **(dims or {}))
+    out = outdir or LIBDIR
+    os.makedirs(out, exist_ok=True)
+    host_lib, trac_bin = os.path.join(out, "libmptrac.so"), os.path.join(out, "trac")
     src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "mptrac.h", "trac.c", "atm2grid.c", "atm_conv.c", "met_conv.c", "ctlfile.c", "nc_classic.c",
                                                "nc_classic.h", "nc_internal.h", "nc_hdf5.c", "rendezvous.c", "output.c")]
     lib_src = [os.path.join(HOST_DIR, f) for f in ("mptrac.c", "ctlfile.c", "nc_classic.c", "nc_hdf5.c", "rendezvous.c", "output.c")]
-    if not (force or _stale(HOST_LIB, src) or _stale(TRAC_BIN, src)):
-        return HOST_LIB, TRAC_BIN
+    if not (force or _stale(host_lib, src) or _stale(trac_bin, src)):
+        return host_lib, trac_bin
     defs = [f"-D{k}={v}" for k, v in dims.items()]
     defs.append('-DMPTRAC_AMD_DATA_DIR="%s"' % os.path.join(HERE, "data"))
     common = ["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-W", "-Wno-format-security", "-fPIC", "-mcmodel=medium",
               *defs]
     rpath = ["-L" + LIBDIR, "-lmptrac_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread", "-lz"]
-    cmds = [common + ["-shared", "-o", HOST_LIB] + lib_src + rpath,
-            common + ["-o", TRAC_BIN, os.path.join(HOST_DIR, "trac.c")] + lib_src + rpath,
-            common + ["-o", ATM2GRID_BIN, os.path.join(HOST_DIR, "atm2grid.c")] + lib_src + rpath,
-            common + ["-o", ATM_CONV_BIN, os.path.join(HOST_DIR, "atm_conv.c")] + lib_src + rpath,
-            common + ["-o", MET_CONV_BIN, os.path.join(HOST_DIR, "met_conv.c")] + lib_src + rpath]
+    cmds = [common + ["-shared", "-o", host_lib] + lib_src + rpath,
+            common + ["-o", trac_bin, os.path.join(HOST_DIR, "trac.c")] + lib_src + rpath]
+    if outdir is None:
+        cmds += [common + ["-o", ATM2GRID_BIN, os.path.join(HOST_DIR, "atm2grid.c")] + lib_src + rpath,
+                 common + ["-o", ATM_CONV_BIN, os.path.join(HOST_DIR, "atm_conv.c")] + lib_src + rpath,
+                 common + ["-o", MET_CONV_BIN, os.path.join(HOST_DIR, "met_conv.c")] + lib_src + rpath]
     for cmd in cmds:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return HOST_LIB, TRAC_BIN
+    return host_lib, trac_bin
 
 
 if __name__ == "__main__":

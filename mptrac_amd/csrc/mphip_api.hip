@@ -164,17 +164,6 @@ struct mphip_ctx {
   int multi_step = 64;                // mphip_run_timesteps: most time steps per launch (0 = always one by one)
   bool force_generic = false;
   bool compact_depo = true;           // deposition-only launches through depo_kernel (0: the fused kernel's tail)
-  // option "depo_beside_mixing" (default 0): the deposition launch of a step with module_mixing as two kernels -- the
-  // factors beside module_mixing on a stream of its own, their application behind the relaxation (depo_factor_kernel /
-  // depo_apply_kernel) -- instead of depo_kernel behind module_mixing.  Same bits; measured on C5 (round 5,
-  // profiles/r05_variants.txt item 2): 2.18 against 2.14 ms per step -- the kernels of a C5 step fill the machine
-  // whichever stream they sit on, the factors only moved from behind the relaxation to beside the radix sort
-  bool depo_beside_mixing = false;
-  hipStream_t depo_stream = nullptr;
-  hipEvent_t depo_mark = nullptr, depo_done = nullptr;
-  DepoList depo_list = {};
-  long long depo_cap = 0;
-  int depo_blocks_cap = 0;
   int sort_bits = 0;                  // digit width of the radix sort (0 = fewest passes; 8, 9, 10: tuning / tests)
   int steps_since_resort = 1 << 30;
 
@@ -766,21 +755,8 @@ static bool fits32(const mphip_ctx *ctx) {
 static bool lean32_ok(const mphip_ctx *ctx) { return lean_grid(ctx) && fits32(ctx) && !ctx->big_grid; }
 static bool lean64_ok(const mphip_ctx *ctx) { return lean_grid(ctx) && (!fits32(ctx) || ctx->big_grid); }
 
-// the deposition-only launch in its two parts around module_mixing (depo_mode): kDepoFactors on ctx->depo_stream, behind
-// the kernels queued on the main stream so far; kDepoApply on the main stream, behind the factors
-enum { kDepoWhole = 0, kDepoFactors = 1, kDepoApply = 2 };
-
-// can the deposition modules of `tail` run as depo_factor_kernel + depo_apply_kernel?  (launch_step's conditions for
-// depo_kernel: nothing but the two modules, a lean configuration, pressure-level winds)
-static bool depo_split_ok(const mphip_ctx *ctx, unsigned tail) {
-  constexpr unsigned kDepo = MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
-  const bool ml = ctx->ctl.advect_vert_coord >= 1 && ctx->ctl.advect_vert_coord <= 3;
-  return ctx->depo_beside_mixing && ctx->compact_depo && (tail & kDepo) && !(tail & ~kDepo) && !ml && !ctx->force_generic
-    && lean32_ok(ctx) && ctx->np > 0;
-}
-
 int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint64_t ctr_meso, uint64_t ctr_conv,
-                uint64_t ctr_pbl = 0, int nsteps = 1, double t_stride = 0, uint64_t ctr_stride = 0, int depo_mode = kDepoWhole,
+                uint64_t ctr_pbl = 0, int nsteps = 1, double t_stride = 0, uint64_t ctr_stride = 0,
                 const EmitKeys *emit = nullptr, bool *emitted = nullptr) {
   if (ctx->np == 0)
     return 0;
@@ -900,46 +876,6 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   // particles with anything to do into full waves
   constexpr unsigned kDepo = MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
   const size_t depo_lds = ((axes_lds_bytes(ctx) + 15) & ~(size_t) 15) + (size_t) per_block * sizeof(int);
-  if (depo_mode != kDepoWhole && !(sel == kTailOnly && (mask & kDepo) && !(mask & ~kDepo) && !ctx->fused_perm && depo_lds <= 64 * 1024))
-    return fail(ctx, "internal: the deposition launch cannot be split here");
-  if (depo_mode != kDepoWhole) {
-    if (ctx->np > ctx->depo_cap) {
-      DepoList &L = ctx->depo_list;
-      const size_t n = (size_t) ctx->np;
-      if (dev_alloc(ctx, &L.idx, n) || dev_alloc(ctx, &L.flags, n) || dev_alloc(ctx, &L.f[0], n) || dev_alloc(ctx, &L.f[1], n)
-          || dev_alloc(ctx, &L.f[2], n) || dev_alloc(ctx, &L.f[3], n))
-        return 1;
-      ctx->depo_cap = ctx->np;
-    }
-    if (nb > ctx->depo_blocks_cap) {
-      if (dev_alloc(ctx, &ctx->depo_list.count, (size_t) nb))
-        return 1;
-      ctx->depo_blocks_cap = nb;
-    }
-    if (!ctx->depo_stream) {
-      HIPCHK(hipStreamCreateWithFlags(&ctx->depo_stream, hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&ctx->depo_mark, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&ctx->depo_done, hipEventDisableTiming));
-    }
-    if (depo_mode == kDepoFactors) {   // (not a launch of the main stream: the bracket of the profile belongs to the other part)
-      HIPCHK(hipEventRecord(ctx->depo_mark, ctx->stream));
-      HIPCHK(hipStreamWaitEvent(ctx->depo_stream, ctx->depo_mark, 0));
-      hipLaunchKernelGGL(depo_factor_kernel, dim3(nb), dim3(256), depo_lds, ctx->depo_stream, S, ctx->depo_list);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(ctx->depo_done, ctx->depo_stream));
-      if (ctx->prof)
-        ctx->ev_used -= 2;
-      return 0;
-    }
-    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->depo_done, 0));
-    if (ctx->prof)      // (the bracket starts behind the wait: the time of the kernel, not of what it waited for)
-      HIPCHK(hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(depo_apply_kernel, dim3(nb), dim3(256), 0, ctx->stream, S, ctx->depo_list);
-    HIPCHK(hipGetLastError());
-    if (ctx->prof)
-      HIPCHK(hipEventRecord(e1, ctx->stream));
-    return 0;
-  }
   if (sel == kTailOnly && (mask & kDepo) && !(mask & ~kDepo) && ctx->compact_depo && !ctx->fused_perm
       && depo_lds <= 64 * 1024) {
     hipLaunchKernelGGL(depo_kernel, dim3(nb), dim3(256), depo_lds, ctx->stream, S);
@@ -1997,7 +1933,11 @@ int mixing_cells(mphip_ctx *ctx, const MixPlan &P) {
 // covers four fifths of it.
 int exchange_occupied_levels(mphip_ctx *ctx, int nq, size_t ntot, int nz) {
   const size_t ncol = ntot / (size_t) nz;
-  if (!ctx->d_occ) {
+  if (!ctx->d_occ || !ctx->h_occ) {      // (both: a failed host allocation must not leave the pair half made)
+    if (ctx->h_occ) {
+      (void) hipHostFree(ctx->h_occ);
+      ctx->h_occ = nullptr;
+    }
     if (dev_alloc(ctx, &ctx->d_occ, (size_t) 256))
       return 1;
     HIPCHK(hipHostMalloc((void **) &ctx->h_occ, 256 * sizeof(double), hipHostMallocDefault));
@@ -2269,20 +2209,9 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_axes);
   ctx->pk.release();
   ctx->pk_next.release();
-  if (ctx->depo_stream) {
-    (void) hipStreamSynchronize(ctx->depo_stream);
-    (void) hipStreamDestroy(ctx->depo_stream);
-    (void) hipEventDestroy(ctx->depo_mark);
-    (void) hipEventDestroy(ctx->depo_done);
-  }
   for (void *q : { (void *) ctx->rep_sk, (void *) ctx->rep_si, (void *) ctx->rep_fk, (void *) ctx->rep_fv, (void *) ctx->rep_mk[0],
                    (void *) ctx->rep_mk[1], (void *) ctx->rep_mi[0], (void *) ctx->rep_mi[1], (void *) ctx->rep_tiles, (void *) ctx->rep_nm })
     dev_free(q);
-  dev_free(ctx->depo_list.idx);
-  dev_free(ctx->depo_list.flags);
-  for (auto q : ctx->depo_list.f)
-    dev_free(q);
-  dev_free(ctx->depo_list.count);
   if (ctx->ahead_stream) {
     (void) hipStreamSynchronize(ctx->ahead_stream);
     (void) hipStreamDestroy(ctx->ahead_stream);
@@ -3080,11 +3009,7 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
       ek.t_next = t_next;
     }
   }
-  if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl, 1, 0, 0, kDepoWhole, &ek, &emitted))
-    return 1;
-  // the deposition modules: their factors beside module_mixing (positions are final), applied behind the relaxation
-  const bool depo_split = tail && depo_split_ok(ctx, tail);
-  if (depo_split && launch_step(ctx, tail, t, 0, 0, 0, 0, 1, 0, 0, kDepoFactors))
+  if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl, 1, 0, 0, &ek, &emitted))
     return 1;
   bool cells_ready = false;
   if (sort_next) {   // ... beside module_mixing and the deposition launch
@@ -3099,7 +3024,7 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
   }
   if (do_mixing(ctx, t, cells_ready))
     return 1;
-  if (tail && launch_step(ctx, tail, t, 0, 0, 0, 0, 1, 0, 0, depo_split ? kDepoApply : kDepoWhole))
+  if (tail && launch_step(ctx, tail, t, 0, 0, 0, 0))
     return 1;
   return meteo_now ? schedule_meteo(ctx) : 0;
 }
@@ -3576,10 +3501,6 @@ int mphip_set_option(mphip_ctx *ctx, const char *name, double value) {
   }
   if (strcmp(name, "sort_repair") == 0) {   // 0: the module_sort that runs ahead always sorts from scratch
     ctx->sort_repair = value != 0;
-    return 0;
-  }
-  if (strcmp(name, "depo_beside_mixing") == 0) {   // 0: the deposition modules of a mixing step as one launch behind module_mixing
-    ctx->depo_beside_mixing = value != 0;
     return 0;
   }
   if (strcmp(name, "compact_depo") == 0) {   // 0: deposition-only launches run the tail of the fused kernel

@@ -1382,7 +1382,11 @@ __device__ __forceinline__ float libm_sincosf(float y, int which) {
 
 // (double) r of a 64-bit integer in three instructions (both halves convert exactly, the fma rounds once)
 __device__ __forceinline__ double u64_to_double(uint64_t r) {
-  return __builtin_fma(__uint2double_rn((uint32_t) (r >> 32)), 0x1p32, __uint2double_rn((uint32_t) r));
+  // (the conversion of the high word as an instruction of its own: written as a cast, the optimiser widens it back
+  // into a 64-bit conversion of r >> 32 and adds a zero high part, one fp64 addition per call)
+  double hi;
+  asm("v_cvt_f64_u32_e32 %0, %1" : "=v"(hi) : "v"((uint32_t) (r >> 32)));
+  return __builtin_fma(hi, 0x1p32, (double) (uint32_t) r);
 }
 
 // log u of the two uniforms u = X 2^-64 (X = (double) of a 64-bit draw; u = 0 -> -inf) behind two Box-Muller radii,

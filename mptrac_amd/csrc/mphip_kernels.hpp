@@ -1098,106 +1098,6 @@ __global__ __launch_bounds__(256, MPHIP_DEPO_WAVES_PER_SIMD) void depo_kernel(co
 }
 
 // ---------------------------------------------------------------------------
-// The deposition launch in two parts around module_mixing.  module_wet_depo and module_dry_depo multiply the mass of a
-// particle by factors that depend on where the particle is, not on the mass; the positions are final when the
-// launch that moves the particles has ended, before module_mixing.  depo_factor_kernel therefore runs BESIDE
-// module_mixing, on a stream of its own: the busy particles of a workgroup packed into full waves as in depo_kernel,
-// their factors and rates into a list (one slice per workgroup); depo_apply_kernel runs behind the relaxation and
-// only multiplies -- in the reference's order, wet then dry (mptrac.c:7983-7993), with the same operations as
-// apply_loss on the relaxed masses, so the bits are those of the deposition launch behind module_mixing.
-// ---------------------------------------------------------------------------
-struct DepoList {
-  int *idx;        // [np] particle (offset inside its workgroup's range) of every entry; slice of workgroup b at b * per_block
-  int *flags;      // bit 0: module_wet_depo acts, bit 1: module_dry_depo acts
-  double *f[4];    // aux and rate of the wet part, aux and rate of the dry part
-  int *count;      // [workgroups] entries of every slice
-};
-
-__global__ __launch_bounds__(256, MPHIP_DEPO_WAVES_PER_SIMD) void depo_factor_kernel(const StepParams S, const DepoList L) {
-  extern __shared__ double s_axes[];
-  __shared__ int s_count;
-  const DevMet &M = S.met;
-  const DevAtm &a = S.atm;
-  const mphip_ctl_t &ctl = S.ctl;
-  const Axes A = load_axes(M, s_axes);
-  int *s_list = (int *) (s_axes + ((axes_doubles(M) * 8 + (size_t) M.lut_size * 2 + 15) & ~(size_t) 15) / 8);
-  if (threadIdx.x == 0)
-    s_count = 0;
-  __syncthreads();
-  const unsigned tmask = S.mask;
-  const int nb = S.nblocks_logical;
-  const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
-  const long long first = (long long) lb * S.per_block;
-  long long last = first + S.per_block;
-  if (last > a.np)
-    last = a.np;
-  const int lane = threadIdx.x & 63;
-  for (long long i = first + threadIdx.x; i < first + S.per_block; i += 256) {   // (whole waves stay together)
-    bool busy = false;
-    if (i < last && a.dt[i] != 0) {   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
-      Particle P;
-      P.time = a.time[i];
-      P.p = a.p[i];
-      busy = ((tmask & MPHIP_MOD_WET_DEPO) && !above_every_cloud_top(M, P))
-        || ((tmask & MPHIP_MOD_DRY_DEPO) && !above_every_surface_layer(ctl, M, P));
-    }
-    const unsigned long long mine = __ballot(busy);
-    int at = 0;
-    if (lane == 0 && mine)
-      at = atomicAdd(&s_count, __builtin_popcountll(mine));
-    at = __builtin_amdgcn_readfirstlane(at);
-    if (busy)
-      s_list[at + __builtin_popcountll(mine & ((1ull << lane) - 1))] = (int) (i - first);
-  }
-  __syncthreads();
-  const int total = s_count;
-  if (threadIdx.x == 0)
-    L.count[lb] = total;
-  for (int t = threadIdx.x; t < total; t += 256) {
-    const int off = s_list[t];
-    const long long ip = first + off;
-    Particle P;
-    P.time = a.time[ip];
-    P.lon = a.lon[ip];
-    P.lat = a.lat[ip];
-    P.p = a.p[ip];
-    P.dt = a.dt[ip];
-    Stencil sd = stencil_zero();
-    horiz_fast(M, A, P.lon, P.lat, sd);
-    int flags = 0;
-    double f0 = 1, f1 = 0, f2 = 1, f3 = 0;
-    depo_pair_factor(ctl, M, A, a, ip, P, sd, (tmask & MPHIP_MOD_WET_DEPO) != 0, (tmask & MPHIP_MOD_DRY_DEPO) != 0,
-                     [&](double aux, double rate) { flags |= 1; f0 = aux; f1 = rate; },
-                     [&](double aux, double rate) { flags |= 2; f2 = aux; f3 = rate; });
-    L.idx[first + t] = off;
-    L.flags[first + t] = flags;
-    L.f[0][first + t] = f0;
-    L.f[1][first + t] = f1;
-    L.f[2][first + t] = f2;
-    L.f[3][first + t] = f3;
-  }
-}
-
-__global__ __launch_bounds__(256) void depo_apply_kernel(const StepParams S, const DepoList L) {
-  const DevAtm &a = S.atm;
-  const mphip_ctl_t &ctl = S.ctl;
-  const int nb = S.nblocks_logical;
-  const int lb = S.xcd_map ? (int) (blockIdx.x % 8) * (nb / 8) + (int) (blockIdx.x / 8) : (int) blockIdx.x;
-  const long long first = (long long) lb * S.per_block;
-  const int total = L.count[lb];
-  for (int t = threadIdx.x; t < total; t += 256) {
-    const int flags = L.flags[first + t];
-    if (!flags)
-      continue;
-    const long long ip = first + L.idx[first + t];
-    if (flags & 1)
-      apply_loss(ctl, a, ip, L.f[0][first + t], ctl.qnt_mloss_wet, L.f[1][first + t]);
-    if (flags & 2)
-      apply_loss(ctl, a, ip, L.f[2][first + t], ctl.qnt_mloss_dry, L.f[3][first + t]);
-  }
-}
-
-// ---------------------------------------------------------------------------
 // packing of the two bracketing snapshots
 // ---------------------------------------------------------------------------
 

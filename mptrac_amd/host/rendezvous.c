@@ -129,9 +129,15 @@ int mptrac_amd_bcast(void *buf, size_t n, int rank, int world, const char *addr,
           && hello.rank < world && hello.bytes == (unsigned long long) n) {
         struct timeval tv_ack = { 5, 0 };
         setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv_ack, sizeof(tv_ack));
-        if (send_all(fd, buf, n) && recv_all(fd, &ack, 1) && ack == 1 && !seen[hello.rank]) {
-          seen[hello.rank] = 1;
-          served++;
+        /* a rank counts as served once the blob went out: the peer returns as soon as it has the blob (its
+         * acknowledgement is advisory -- it only keeps the connection open until the copy is complete), so a lost or
+         * late acknowledgement must not leave rank 0 waiting for a peer that has moved on */
+        if (send_all(fd, buf, n)) {
+          (void) recv_all(fd, &ack, 1);
+          if (!seen[hello.rank]) {
+            seen[hello.rank] = 1;
+            served++;
+          }
         }
       }
       close(fd);

@@ -29,8 +29,9 @@ def test_bench_prints_the_contract_line(extra):
     assert ("none" in cfg["device_warmup"]) == ("--device-warmup-ms" in extra and extra[extra.index("--device-warmup-ms") + 1] == "0")
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert r["kernel_ms"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-9 * r["achieved"]
+    # (2e5 particles touch ~100 MB of meteo records: inside the Infinity Cache, no share of the HBM roof is claimed)
+    assert r["kernel_ms"] > 0 and r["frac"] is None and "Infinity Cache" in r["frac_note"] and r["frac_one_launch_per_step"] is None
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_step"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-9 * r["achieved"]
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.02 and "traffic" in r
     # one rank: no communicator; the per-rank kernel times the driver reads are there
     assert cfg["rccl_ranks"] == 0 and len(r["kernel_ms_per_rank"]) == 1
@@ -43,7 +44,7 @@ def test_bench_prints_the_contract_line(extra):
         assert "mphip_run_timesteps" in cfg["time_loop"]
     # both bounds stated: the HBM pricing under both launch regimes, the modelled VALU-issue roof (None at
     # an overridden particle count: the committed instruction mix belongs to the workload's own), what pins the oracle
-    assert r["frac_one_launch_per_step"] > 0 and "alu" in r and "algorithmic" in r["basis"]
+    assert "alu" in r and "algorithmic" in r["basis"]
     assert any("RK4" in m for m in d["parity"]["restatement_only"]) and d["parity"]["pinned_by_reference_goldens"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "particle-steps/s" and c["cores"] >= 1 and c["value"] > 1e4

@@ -98,14 +98,16 @@ def test_c3_at_1e7_on_its_own_grid_against_the_oracle_subsample(n_steps):
     assert abs(mean[0].sum() - g["q"][0][inside].sum()) <= 1e-9 * n
 
 
-@pytest.mark.parametrize("workload", ["C3z", "C3p", "C3d", "C3m"])
+@pytest.mark.parametrize("workload", ["C3z", "C3p", "C3d", "C3m", "C2"])
 def test_c3_variants_at_1e7_against_the_oracle_subsample(workload):
     """The two other step kernels bench.py times on the 721 x 361 x 137 grid at their own size: winds from the model
     levels (ADVECT_VERT_COORD 1, intpol_met_4d_zeta: mptrac.c:2808-2981, 3681-3757 -- workload C3z) and the
     boundary-layer closure (TURB_PBL_SCHEME 1, module_diff_pbl: mptrac.c:4343-4584 -- workload C3p), the reference's
     default integrator (ADVECT 2, C3d) and module_meteo in every step (C3m); 10^7 particles, 20 steps in one
-    mphip_run_timesteps call, 5 000 of them against the oracle."""
-    n, n_steps = 10 ** 7, 20
+    mphip_run_timesteps call, 5 000 of them against the oracle.  C2: BASELINE configs[1] as it stands -- 10^6 particles,
+    advection + turbulent diffusion only (the lean "advect + turb" instantiation), 361 x 181 x 137."""
+    import bench
+    n, n_steps = bench.WORKLOADS[workload][1], 20
     ctl, clim, met0, met1, atm = _c3_inputs(n, workload=workload)
     s = hip.Simulation(ctl, clim, met0, met1, atm)
     s.timesteps_init(0.0, 0.0)

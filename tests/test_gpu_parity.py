@@ -20,7 +20,6 @@ from oracle import binding as B
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10          # north_star tolerance for positions / quantities
-TOL_UVWP = 1e-6      # cache->uvwp is stored as float
 
 
 def _pair(name, n=10000, grid="C1", **kw):
@@ -44,7 +43,7 @@ def _compare(o, s, tol=TOL):
         # every quantity row on its own scale (vmr ~ 3e-9, loss_rate ~ 4e-6 ... are far below 1)
         err, row = cases.q_rows_err(o.ctl, g["q"], r["q"])
         assert err <= tol, ("q", row, err)
-    assert cases.rel_err(g["uvwp"], r["uvwp"]) <= TOL_UVWP
+    assert np.array_equal(g["uvwp"], r["uvwp"])      # cache->uvwp (single precision): the oracle's bits
     assert s.get_cache()["rng_ctr"] == o.cache.rng_ctr
 
 
@@ -405,26 +404,6 @@ def test_lds_tile_trajectories_equal_the_launches_without_a_tile(advect, tile):
     assert np.array_equal(runs[1]["time"], r["time"])
     for k in ("lon", "lat", "p"):
         assert cases.rel_err(runs[1][k], r[k]) <= TOL, k
-
-
-def test_deposition_factors_beside_mixing_equal_the_launch_behind_it():
-    """Option depo_beside_mixing: module_wet_depo / module_dry_depo of a mixing step as factors computed beside
-    module_mixing (own stream) and applied behind the relaxation -- the bits of the deposition launch behind it."""
-    ctl, clim, m0, m1, atm = cases.make_case("full", n=20011)
-    ctl.update(mixing_dt=180.0, sort_dt=180.0)
-    runs = []
-    for beside in (0, 1):
-        s = hip.Simulation(ctl, clim, m0, m1, atm)
-        s.set_option("depo_beside_mixing", beside)
-        s.timesteps_init(0.0, 0.0)
-        for t in cases.step_times(s.ctl)[:8]:
-            s.run_timestep(t)
-        runs.append(s.state())
-        s.close()
-    for k in ("time", "lon", "lat", "p", "q", "uvwp"):
-        assert np.array_equal(runs[0][k], runs[1][k]), k
-    wet, dry = (list(cases.QUANTITIES).index(k) for k in ("mloss_wet", "mloss_dry"))
-    assert runs[0]["q"][wet].max() > 0 and runs[0]["q"][dry].max() > 0
 
 
 def test_met_swap_over_two_intervals():
