@@ -249,7 +249,7 @@ def build_id():
     h = hashlib.sha1()
     csrc = os.path.join(ROOT, "mptrac_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".hpp")):
+        if name.endswith((".hip", ".hpp", ".h")):
             h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:12]
 

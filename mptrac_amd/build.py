@@ -36,7 +36,7 @@ def _stale(target, sources):
 
 
 def hip_sources():
-    src = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))]
+    src = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
     src.append(os.path.join(os.path.dirname(HERE), "include", "mptrac_hip.h"))
     return src
 

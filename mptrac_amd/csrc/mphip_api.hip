@@ -178,6 +178,9 @@ struct mphip_ctx {
   // option "lds_tile": cells of the LDS wind tile of traj_tile_kernel (0: off); runs of pure trajectory steps only
   int lds_tile = 0;
   bool emit_keys = true;              // option "emit_keys": the launch that moves the particles writes the keys of the sort ahead
+  unsigned char *d_depo_busy = nullptr;   // EmitKeys::depo_busy (np bytes) ...
+  long long depo_busy_cap = 0;
+  bool depo_busy_valid = false;       // ... written by the last launch and not yet used by the deposition launch of its step
   bool sort_repair = true;            // option "sort_repair"
   bool ahead_priority = false;        // option "ahead_priority": the stream of the sort ahead at the highest priority (C5: no difference, profiles/r05_variants.txt item 3)
   bool stored_is_sorted = false;
@@ -772,6 +775,7 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   }
   StepParams S;
   memset(&S.emit, 0, sizeof(S.emit));
+  S.depo_busy = nullptr;
   if (emitted)
     *emitted = false;
   S.ctl = ctx->ctl;
@@ -878,6 +882,8 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
   const size_t depo_lds = ((axes_lds_bytes(ctx) + 15) & ~(size_t) 15) + (size_t) per_block * sizeof(int);
   if (sel == kTailOnly && (mask & kDepo) && !(mask & ~kDepo) && ctx->compact_depo && !ctx->fused_perm
       && depo_lds <= 64 * 1024) {
+    S.depo_busy = ctx->depo_busy_valid ? ctx->d_depo_busy : nullptr;
+    ctx->depo_busy_valid = false;
     hipLaunchKernelGGL(depo_kernel, dim3(nb), dim3(256), depo_lds, ctx->stream, S);
     HIPCHK(hipGetLastError());
     ctx->fused_perm = nullptr;
@@ -886,11 +892,13 @@ int launch_step(mphip_ctx *ctx, unsigned mask, double t, uint64_t ctr_turb, uint
     return 0;
   }
   // the headline module set, one step per launch, and the caller wants the keys of the sort ahead from this launch
+  ctx->depo_busy_valid = false;     // (any other launch: positions may move, the flags of an earlier one are void)
   if (emit && emit->keys && sel == kAdvDiffConvSedi && nsteps == 1) {
     sel |= kEmitKeys;
     S.emit = *emit;
     if (emitted)
       *emitted = true;
+    ctx->depo_busy_valid = emit->depo_busy != nullptr;
   }
   // pure trajectories, several steps per launch: the kernel that stages the wind grid through an LDS tile (option lds_tile)
   if (ctx->lds_tile > 0 && nsteps > 1 && (sel == (kAdv | kMultiStep) || sel == (kAdv | kTwoStage | kMultiStep))
@@ -2251,6 +2259,7 @@ void mphip_destroy(mphip_ctx *ctx) {
   dev_free(ctx->d_cell);
   dev_free(ctx->d_sums);
   dev_free(ctx->d_cnt);
+  dev_free(ctx->d_depo_busy);
   dev_free(ctx->d_occ);
   dev_free(ctx->d_band);
   dev_free(ctx->d_band_cnt);
@@ -2711,6 +2720,7 @@ int mphip_update_atm(mphip_ctx *ctx, long long np, long long ip0, long long np_t
     ctx->sorted_buf = -1;
     ctx->stored_is_sorted = false;
   }
+  ctx->depo_busy_valid = false;
   ctx->meteo_pending = false;   // the uploaded quantity arrays replace whatever module_meteo would have written
   if (!fresh && restore_external_order(ctx))   // keep cache->uvwp with its slot across a re-upload
     return 1;
@@ -3007,6 +3017,16 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
       ek.t_start = c.t_start;
       ek.t_stop = c.t_stop;
       ek.t_next = t_next;
+      constexpr unsigned kDepo = MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
+      if ((tail & kDepo) && !(tail & ~kDepo) && ctx->compact_depo) {   // the deposition launch behind module_mixing will be depo_kernel
+        if (ctx->np > ctx->depo_busy_cap) {
+          if (dev_alloc(ctx, &ctx->d_depo_busy, (size_t) ctx->np))
+            return 1;
+          ctx->depo_busy_cap = ctx->np;
+        }
+        ek.depo_busy = ctx->d_depo_busy;
+        ek.depo_mask = tail;
+      }
     }
   }
   if (launch_step(ctx, mask, t, ctr_turb, ctr_meso, ctr_conv, ctr_pbl, 1, 0, 0, &ek, &emitted))
@@ -3640,6 +3660,7 @@ int mphip_test_piece(mphip_ctx *ctx, int piece, int reps, double *checksum) {
     return fail(ctx, "climatological tropopause data were not uploaded");
   StepParams S;
   memset(&S.emit, 0, sizeof(S.emit));
+  S.depo_busy = nullptr;
   S.ctl = ctx->ctl;
   S.met = dev_met(ctx);
   S.atm = dev_atm(ctx);

@@ -114,6 +114,11 @@ struct EmitKeys {
   const double *ens;
   int ngrid;
   double direction, t_start, t_stop, t_next;
+  // for the deposition launch behind module_mixing (depo_kernel): 1 where module_wet_depo / module_dry_depo (the bits of
+  // depo_mask) have anything to do with the particle -- decided from dt, time and p, which this launch holds in
+  // registers and the deposition launch would read again for every particle (NULL: not wanted)
+  unsigned char *depo_busy;
+  unsigned depo_mask;
 };
 
 struct StepParams {
@@ -128,6 +133,7 @@ struct StepParams {
   int nblocks_logical;    // multiple of 8
   long long per_block;    // particles per logical block, multiple of 256
   int xcd_map;            // 1: workgroup b -> logical block (b % 8) * (n / 8) + b / 8
+  const unsigned char *depo_busy;   // depo_kernel: EmitKeys::depo_busy of the launch that moved the particles (NULL: none)
   uint64_t ctr_turb, ctr_meso, ctr_conv, ctr_pbl;   // base counters of the module_rng calls
   // several consecutive time steps in one launch (kMultiStep instantiations, mphip_run_timesteps): step s runs
   // with model time t + s t_stride (accumulated as the caller's loop would) and counters + s ctr_stride
@@ -504,8 +510,12 @@ __device__ __forceinline__ void pin(double &x) {
 #define MPHIP_RNG_BALANCED 1
 #endif
 
-__device__ __forceinline__ void emit_sort_keys(const EmitKeys &E, const DevMet &M, const Axes &A, long long i,
-                                               const Particle &P) {
+__device__ __forceinline__ void emit_sort_keys(const EmitKeys &E, const mphip_ctl_t &ctl, const DevMet &M, const Axes &A,
+                                               long long i, const Particle &P) {
+  if (E.depo_busy)      // (P.dt: the time step of THIS step, the guard of the deposition modules' particle loop)
+    E.depo_busy[i] = P.dt != 0
+      && (((E.depo_mask & MPHIP_MOD_WET_DEPO) && !above_every_cloud_top(M, P))
+          || ((E.depo_mask & MPHIP_MOD_DRY_DEPO) && !above_every_surface_layer(ctl, M, P)));
   if (E.cell)
     E.cell[i] = box_cell(E.grid, E.box_t0, E.box_t1, P.time, P.lon, P.lat, P.p, E.ens, i, E.ngrid);
   double dt = 0.0;   // module_timesteps of the next step, mptrac.c:6016-6041
@@ -722,7 +732,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
         a.p[i] = isosurf_pressure(ctl, M, A, a, P, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
       if constexpr (!kRuntimeMask<CT> && (CT & kEmitKeys) != 0)
         if (S.emit.keys)
-          emit_sort_keys(S.emit, M, A, i, P);
+          emit_sort_keys(S.emit, ctl, M, A, i, P);
       if constexpr (!kRuntimeMask<CT> && (CT & kPblClosure) != 0)
         if (S.mask & MPHIP_MOD_ISOSURF) {
           P.p = isosurf_call(&ctl, &M, A, &a, P.time, P.p, P.lon, P.lat, ctl.isosurf <= 3 ? a.iso[i] : 0.0);
@@ -870,7 +880,7 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
     }
     if constexpr (lean && (CT & kEmitKeys) != 0)
       if (S.emit.keys)
-        emit_sort_keys(S.emit, M, A, i, P);
+        emit_sort_keys(S.emit, ctl, M, A, i, P);
 
     // module_bound_cond: in the instantiation with every module, and -- switched by the run-time mask -- in the
     // gated lean instantiations and the one without movers (the launch behind module_mixing)
@@ -1063,7 +1073,9 @@ __global__ __launch_bounds__(256, MPHIP_DEPO_WAVES_PER_SIMD) void depo_kernel(co
   // which particles have anything to do: p, time and dt only
   for (long long i = first + threadIdx.x; i < first + S.per_block; i += 256) {   // (whole waves stay together)
     bool busy = false;
-    if (i < last && a.dt[i] != 0) {   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
+    if (S.depo_busy)                  // decided by the launch that moved the particles (EmitKeys::depo_busy)
+      busy = i < last && S.depo_busy[i] != 0;
+    else if (i < last && a.dt[i] != 0) {   // guard of PARTICLE_LOOP(..., check_dt = 1), mptrac.h:1759
       Particle P;
       P.time = a.time[i];
       P.p = a.p[i];

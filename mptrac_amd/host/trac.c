@@ -79,18 +79,27 @@ int main(int argc, char *argv[]) {
 
     /* ---- loop over time steps (trac.c:131-163) ---- */
     const double w0 = wall();
+    double w_met = 0, w_step = 0, w_out = 0;   /* where the wall time of the loop goes, by call */
     long nsteps = 0;
     for (double t = ctl->t_start; ctl->direction * (t - ctl->t_stop) < ctl->dt_mod;
          t += ctl->direction * ctl->dt_mod) {
       if (ctl->direction * (t - ctl->t_stop) > 0)
         t = ctl->t_stop;
+      const double a0 = wall();
       mptrac_get_met(ctl, clim, t, &met0, &met1, dd);
+      const double a1 = wall();
       if (ctl->dt_mod > fabs(met0->lon[1] - met0->lon[0]) * 111132. / 150.)
         WARN("Violation of CFL criterion! Check DT_MOD!");
       mptrac_run_timestep(ctl, cache, clim, &met0, &met1, atm, depo, t, dd);
+      const double a2 = wall();
       mptrac_write_output(dirname, ctl, met0, met1, atm, depo, t);
+      const double a3 = wall();
+      w_met += a1 - a0;
+      w_step += a2 - a1;
+      w_out += a3 - a2;
       nsteps++;
     }
+    const double a4 = wall();
     mptrac_update_host(NULL, NULL, NULL, NULL, NULL, atm);   /* also drains the device queue */
     const double w1 = wall();
 
@@ -102,6 +111,14 @@ int main(int argc, char *argv[]) {
     LOG(1, "MEMORY_METEO = %g MByte", 2 * sizeof(met_t) / 1024. / 1024.);
     LOG(1, "TIMER_TIMESTEPS = %.3f s    (%ld calls, %.3e particle-steps/s)", w1 - w0, nsteps,
         nsteps > 1 ? (double) atm->np * (double) (nsteps - 1) / (w1 - w0) : 0.0);
+    /* ... by call of the loop (the device works beside the host: time steps are queued, and whoever needs their
+     * result first -- a meteo hand-over, an output, the final download -- waits for them) */
+    LOG(1, "TIMER_GET_MET = %.3f s    (meteo files read, converted and handed to the device)", w_met);
+    LOG(1, "TIMER_RUN_TIMESTEP = %.3f s", w_step);
+    LOG(1, "TIMER_WRITE_OUTPUT = %.3f s", w_out);
+    LOG(1, "TIMER_UPDATE_HOST = %.3f s    (rest of the queue + final download)", w1 - a4);
+    LOG(1, "TIMER_WITHOUT_MET_AND_OUTPUT = %.3f s    (%.3e particle-steps/s)", w1 - w0 - w_met - w_out,
+        nsteps > 1 && w1 - w0 - w_met - w_out > 0 ? (double) atm->np * (double) (nsteps - 1) / (w1 - w0 - w_met - w_out) : 0.0);
 
     mptrac_free(ctl, cache, clim, met0, met1, atm, depo, dd);
   }

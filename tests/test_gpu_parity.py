@@ -1669,6 +1669,38 @@ def test_sort_ahead_of_time_is_not_observable(sort_dt):
             assert np.array_equal(a, b)
 
 
+def test_keys_and_deposition_flags_from_the_step_kernel_are_not_observable():
+    """BASELINE configs[4]'s schedule (module_sort and module_mixing in every step, decay, both deposition modules): the
+    launch that moves the particles also writes the keys of the next module_sort, its module_timesteps, module_mixing's
+    box and -- round 6 -- which particles the deposition launch behind module_mixing has to look at (EmitKeys, option
+    emit_keys, default on).  With the option off a key kernel and the deposition launch derive all of that again from
+    the stored state: the same bits, with particles released later (dt = 0 in the first steps), and the oracle's."""
+    ctl, clim, m0, m1, atm = cases.make_case("full", n=30011)
+    ctl = dict(ctl, sort_dt=180.0, mixing_dt=180.0)
+    atm["time"][::7] = 540.0
+    atm["p"][::5] = 1013.25 * np.exp(-np.linspace(0.01, 1.5, len(atm["p"][::5])) / 7.0)      # a fifth near the ground: both modules busy
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    times = cases.step_times(o.ctl)[:9]
+    runs = []
+    for emit in (1, 0):
+        s = hip.Simulation(ctl, clim, m0, m1, atm)
+        s.set_option("emit_keys", emit)
+        s.timesteps_init(atm["time"].min(), atm["time"].max())
+        for t in times:
+            s.run_timestep(t)
+        runs.append(s.state())
+        if emit:
+            for t in times:
+                o.run_timestep(t)
+            _compare(o, s)
+        s.close()
+    for k in ("time", "lon", "lat", "p", "q", "uvwp"):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+    wet, dry = (list(cases.QUANTITIES).index(k) for k in ("mloss_wet", "mloss_dry"))
+    assert runs[0]["q"][wet].max() > 0 and runs[0]["q"][dry].max() > 0
+
+
 def test_deposition_launch_with_packed_waves_equals_the_fused_tail():
     """The deposition modules behind module_mixing run in a kernel of their own that first packs the particles
     with anything to do into full waves (option compact_depo, default on); with the option off they run as the

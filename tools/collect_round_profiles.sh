@@ -1,6 +1,7 @@
 set -u
 cd $GRAFT_REPO_ROOT
 T=${1:-r03}
+MODE=${2:-all}      # "core": the bench lines, kernel statistics, instruction mix and HBM counters only
 timeout 900 bash tools/profile.sh $T > gpurun_out/${T}_profile.log 2>&1
 timeout 300 python tools/summarize_prof.py gpurun_out/prof_$T > gpurun_out/prof_$T/summary.txt 2>&1
 timeout 900 bash tools/profile_valu_mix.sh ${T}mix > gpurun_out/${T}_mix.log 2>&1
@@ -18,16 +19,16 @@ timeout 300 python bench.py --workload C1 --steps 200 --no-cpu-baseline 2>/dev/n
 timeout 300 python bench.py --particles 1e5 --steps 200 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3_1e5.json
 timeout 300 python bench.py --particles 1e6 --steps 200 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3_1e6.json
 timeout 300 python bench.py --steps 20 --warmup 5 --multi-step off --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3_one_launch_per_step.json
-timeout 900 python tools/gpu_config_matrix.py > gpurun_out/${T}_config_matrix.txt 2>&1
-timeout 900 python tools/gpu_config_matrix.py generic_kernel=1 > gpurun_out/${T}_config_matrix_general.txt 2>&1
-timeout 900 python tools/gpu_bench_sweep.py C3 > gpurun_out/${T}_sustained_480_steps.txt 2>&1
+[ $MODE = core ] || timeout 900 python tools/gpu_config_matrix.py > gpurun_out/${T}_config_matrix.txt 2>&1
+[ $MODE = core ] || timeout 900 python tools/gpu_config_matrix.py generic_kernel=1 > gpurun_out/${T}_config_matrix_general.txt 2>&1
+[ $MODE = core ] || timeout 900 python tools/gpu_bench_sweep.py C3 > gpurun_out/${T}_sustained_480_steps.txt 2>&1
 timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_C3_driver_args.json 2> /dev/null
-timeout 900 bash tools/piece_cost.sh ${T}pieces > gpurun_out/${T}_pieces.log 2>&1
+[ $MODE = core ] || timeout 900 bash tools/piece_cost.sh ${T}pieces > gpurun_out/${T}_pieces.log 2>&1
 timeout 600 bash tools/profile_ml.sh ${T}z > gpurun_out/${T}_ml_counters.txt 2>&1
-timeout 900 python tools/gpu_config_matrix.py big_grid=1 > gpurun_out/${T}_config_matrix_big.txt 2>&1
-timeout 300 python tools/gpu_ml_subsets.py > gpurun_out/${T}_ml_subsets.txt 2>&1
-timeout 300 python tools/gpu_sparse_schedule.py > gpurun_out/${T}_sparse_schedule.txt 2>&1
+[ $MODE = core ] || timeout 900 python tools/gpu_config_matrix.py big_grid=1 > gpurun_out/${T}_config_matrix_big.txt 2>&1
+[ $MODE = core ] || timeout 300 python tools/gpu_ml_subsets.py > gpurun_out/${T}_ml_subsets.txt 2>&1
+[ $MODE = core ] || timeout 300 python tools/gpu_sparse_schedule.py > gpurun_out/${T}_sparse_schedule.txt 2>&1
 # HBM counters of every kernel of the workloads with several kernels per step / other step kernels (bench.py quotes them)
-timeout 1500 bash tools/profile_traffic.sh $T C5 C3z C2 C3m C3p > gpurun_out/${T}_traffic_all.log 2>&1
+timeout 1800 bash tools/profile_traffic.sh $T C5 C3z C2 C3m C3p C3x > gpurun_out/${T}_traffic_all.log 2>&1
 timeout 300 python bench.py --workload C3p --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${T}_bench_C3p.json
-timeout 300 python tools/gpu_pbl_cost.py > gpurun_out/${T}_pbl_cost.txt 2>&1
+[ $MODE = core ] || timeout 300 python tools/gpu_pbl_cost.py > gpurun_out/${T}_pbl_cost.txt 2>&1

@@ -59,7 +59,9 @@ def main():
               f"C3 meteorology 721 x 361 x 137 as MET_TYPE 1 files (inputs generated in {t_gen:.0f} s)"]
     env = dict(os.environ, TMPDIR="/tmp")
     for name, extra in (("outputs every hour (1 grid + 1 particle file per interval)", {}),
-                        ("no outputs", {"ATM_BASENAME": "-", "GRID_BASENAME": "-"})):
+                        ("no outputs", {"ATM_BASENAME": "-", "GRID_BASENAME": "-"}),
+                        ("no outputs, next meteo file read beside the time steps (HIP_MET_PREFETCH 1)",
+                         {"ATM_BASENAME": "-", "GRID_BASENAME": "-", "HIP_MET_PREFETCH": 1})):
         hf.write_ctl(os.path.join(tmp, "trac.ctl"), dict(keys, **extra))
         open(os.path.join(tmp, "dirlist"), "w").write(tmp + "\n")
         for rep in range(2):      # (the second run reads the meteo files from the page cache)
@@ -72,6 +74,11 @@ def main():
             line = [ln for ln in text.splitlines() if "TIMER_TIMESTEPS" in ln][-1].strip()
             report.append(f"{name}, run {rep + 1}: {line}   (process wall {wall:.1f} s)")
             print(report[-1], flush=True)
+            if rep == 1:      # where the loop's wall time went, by call (trac.c)
+                for ln in text.splitlines():
+                    if any(k in ln for k in ("TIMER_GET_MET", "TIMER_RUN_TIMESTEP", "TIMER_WRITE_OUTPUT", "TIMER_UPDATE_HOST",
+                                             "TIMER_WITHOUT_MET_AND_OUTPUT", "MEMORY_METEO", "MEMORY_ATM")):
+                        report.append("        " + ln.strip())
     if not args.no_trace:
         hf.write_ctl(os.path.join(tmp, "trac.ctl"), keys)
         prof = os.path.join(out_root, "trace")

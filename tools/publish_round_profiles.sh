@@ -16,14 +16,14 @@ done
 for w in C1 C2 C3 C3_1e5 C3_1e6 C3_1e8 C3_driver_args C3_one_launch_per_step C3m C3x C3z C3p C5; do
   [ -s $G/${T}_bench_$w.json ] && tail -1 $G/${T}_bench_$w.json > $P/${T}_bench_$(echo $w | tr A-Z a-z).json
 done
-cp $G/${T}_config_matrix.txt $P/${T}_config_matrix.txt
-{ echo; echo "# the same control sets through the general instantiation (option generic_kernel 1)"; cat $G/${T}_config_matrix_general.txt; } >> $P/${T}_config_matrix.txt
-cp $G/${T}_sustained_480_steps.txt $P/${T}_sustained_480_steps.txt
+[ -s $G/${T}_config_matrix.txt ] && cp $G/${T}_config_matrix.txt $P/${T}_config_matrix.txt
+[ -s $G/${T}_config_matrix_general.txt ] && { echo; echo "# the same control sets through the general instantiation (option generic_kernel 1)"; cat $G/${T}_config_matrix_general.txt; } >> $P/${T}_config_matrix.txt
+[ -s $G/${T}_sustained_480_steps.txt ] && cp $G/${T}_sustained_480_steps.txt $P/${T}_sustained_480_steps.txt
 [ -s $G/${T}_config_matrix_big.txt ] && { echo; echo "# the same control sets through the instantiations with 64-bit byte offsets (option big_grid 1: what a grid beyond 4 GB of wind records takes)"; cat $G/${T}_config_matrix_big.txt; } >> $P/${T}_config_matrix.txt
 [ -s $G/${T}_ml_subsets.txt ] && cp $G/${T}_ml_subsets.txt $P/${T}_model_level_subsets.txt
 [ -s $G/${T}_sparse_schedule.txt ] && cp $G/${T}_sparse_schedule.txt $P/${T}_sparse_schedule.txt
 [ -s $G/${T}_ml_counters.txt ] && cp $G/${T}_ml_counters.txt $P/${T}_c3z_sq_counters.txt
-cp $G/prof_${T}pieces/piece_cost.txt $P/${T}_piece_costs.txt
+[ -s $G/prof_${T}pieces/piece_cost.txt ] && cp $G/prof_${T}pieces/piece_cost.txt $P/${T}_piece_costs.txt
 python $R/tools/update_pmc_traffic.py $G/prof_$T C3 profiles/${T}_c3_summary.txt > /dev/null
 [ -s $G/${T}_pbl_cost.txt ] && cp $G/${T}_pbl_cost.txt $P/${T}_pbl_cost.txt
 # the other workloads: HBM bytes per time step over ALL their kernels (tools/profile_traffic.sh, tools/traffic_all.py)
@@ -32,7 +32,7 @@ import json, os
 f = "$P/pmc_traffic.json"
 d = json.load(open(f))
 how = {}
-for w in ("C5", "C3z", "C2", "C3m", "C3p"):
+for w in ("C5", "C3z", "C2", "C3m", "C3p", "C3x"):
     t = "$G/traffic_${T}_%s/traffic.json" % w
     s = "$G/traffic_${T}_%s/summary.txt" % w
     if os.path.exists(t):
