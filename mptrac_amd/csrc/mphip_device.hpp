@@ -1442,7 +1442,6 @@ __device__ __forceinline__ void normal_two_pairs_from(const double *__restrict__
   libm_log_unit_pair(ltab, u64_to_double(squares_from(y)), u64_to_double(squares_from(y + 2 * kSquaresKey)), la, lb);
   asm volatile("" : "+v"(la), "+v"(lb));
   box_muller(la, squares_from(y + kSquaresKey), ea, oa);
-  asm volatile("" : "+v"(ea), "+v"(oa), "+v"(lb));
   box_muller(lb, squares_from(y + 3 * kSquaresKey), eb, ob);
 }
 
