@@ -14,6 +14,7 @@
 #include <pthread.h>
 #include <strings.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "../../include/mptrac_hip.h"
 #include "nc_classic.h"
@@ -1204,6 +1205,63 @@ void mptrac_write_atm(const char *filename, const ctl_t *ctl, const atm_t *atm, 
 /* meteo I/O: the reference's raw binary format (MET_TYPE 1, version 104)     */
 /* -------------------------------------------------------------------------- */
 
+/* Level fields are read by a few threads side by side: each takes a slab of longitudes, reads its part of the block
+ * with pread() and clamps / scatters it into the member of met_t -- a 0.5 degree x 137 level snapshot is 1.9 GB, and one
+ * thread moves that at 1.4 GB/s (profiles/r06_trac_dropin.txt: the drop-in driver at 10^7 particles is bound by this
+ * reader, not by the time steps).  MPTRAC_AMD_IO_THREADS sets the number (default: 8 or the cores there are; 1 = serial). */
+typedef struct {
+  int fd;
+  off_t off;             /* file offset of the block */
+  const met_t *met;
+  float *field, *buf;
+  size_t lev, stride;
+  float lo, hi;
+  int ix0, ix1, ok;
+} met_slab_t;
+
+static void *met_slab_main(void *arg) {
+  met_slab_t *s = (met_slab_t *) arg;
+  const size_t per_ix = (size_t) s->met->ny * s->lev;
+  char *dst = (char *) (s->buf + (size_t) s->ix0 * per_ix);
+  size_t left = (size_t) (s->ix1 - s->ix0) * per_ix * sizeof(float);
+  off_t at = s->off + (off_t) ((size_t) s->ix0 * per_ix * sizeof(float));
+  s->ok = 1;
+  while (left > 0) {
+    const ssize_t got = pread(s->fd, dst, left, at);
+    if (got <= 0) {
+      s->ok = 0;
+      return NULL;
+    }
+    dst += got;
+    at += got;
+    left -= (size_t) got;
+  }
+  if (s->field) {
+    size_t k = (size_t) s->ix0 * per_ix;
+    for (int ix = s->ix0; ix < s->ix1; ix++)
+      for (int iy = 0; iy < s->met->ny; iy++) {
+        float *cell = s->field + ((size_t) ix * EY + (size_t) iy) * s->stride;
+        for (size_t ip = 0; ip < s->lev; ip++, k++)
+          cell[ip] = fminf(fmaxf(s->buf[k], s->lo), s->hi);
+      }
+  }
+  return NULL;
+}
+
+static int met_io_threads(void) {
+  static int n;
+  if (!n) {
+    const char *e = getenv("MPTRAC_AMD_IO_THREADS");
+    long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    n = e ? atoi(e) : (int) (cores < 8 ? cores : 8);
+    if (n < 1)
+      n = 1;
+    if (n > 64)
+      n = 64;
+  }
+  return n;
+}
+
 /* One field of a MET_TYPE 1 file: compact [nx][ny] or [nx][ny][np] floats <-> the fixed-extent member of met_t
  * (nlev = 0: surface field).  On reading, level fields are limited to [lo, hi] as the reference does
  * (read_met_bin_3d); dst == NULL skips the block, src == NULL writes zeros. */
@@ -1211,6 +1269,31 @@ static void met_block(FILE *f, const int write, const met_t *met, float *field, 
                       const float hi, float *buf) {
   const size_t lev = nlev > 0 ? (size_t) nlev : 1, stride = nlev > 0 ? EP : 1;
   const size_t n = (size_t) met->nx * (size_t) met->ny * lev;
+  const int nthreads = met_io_threads();
+  if (!write && nlev > 0 && nthreads > 1 && met->nx >= 2 * nthreads) {
+    met_slab_t slab[64];
+    pthread_t th[64];
+    const off_t off = ftello(f);
+    int started = 0;
+    for (int t = 0; t < nthreads; t++) {
+      slab[t] = (met_slab_t) { fileno(f), off, met, field, buf, lev, stride, lo, hi,
+                               (int) ((long) met->nx * t / nthreads), (int) ((long) met->nx * (t + 1) / nthreads), 0 };
+      if (pthread_create(&th[t], NULL, met_slab_main, &slab[t]) != 0)
+        break;
+      started++;
+    }
+    for (int t = started; t < nthreads; t++)     /* (threads that could not be started: their slabs here) */
+      met_slab_main(&slab[t]);
+    int ok = 1;
+    for (int t = 0; t < nthreads; t++) {
+      if (t < started)
+        pthread_join(th[t], NULL);
+      ok &= slab[t].ok;
+    }
+    if (!ok || fseeko(f, off + (off_t) (n * sizeof(float)), SEEK_SET) != 0)
+      ERRMSG("Error while reading!");
+    return;
+  }
   if (!write)
     get_items(f, buf, sizeof(float), n);
   size_t k = 0;
@@ -1231,7 +1314,8 @@ static void met_block(FILE *f, const int write, const met_t *met, float *field, 
 /* the 24 surface and 13 level fields in file order (version 104 of the format) */
 static void met_bin_body(FILE *f, int write, met_t *met) {
   float *buf;
-  ALLOC(buf, float, (size_t) met->nx * (size_t) met->ny * (size_t) met->np);
+  if ((buf = malloc((size_t) met->nx * (size_t) met->ny * (size_t) met->np * sizeof(float))) == NULL)     /* (not zeroed: every block is read or written in full) */
+    ERRMSG("Out of memory!");
   float *surface[24] = { &met->ps[0][0], &met->ts[0][0], &met->zs[0][0], &met->us[0][0], &met->vs[0][0], &met->ess[0][0],
     &met->nss[0][0], &met->shf[0][0], &met->lsm[0][0], &met->sst[0][0], &met->pbl[0][0], &met->pt[0][0], &met->tt[0][0],
     &met->zt[0][0], &met->h2ot[0][0], &met->pct[0][0], &met->pcb[0][0], &met->cl[0][0], &met->plcl[0][0],
