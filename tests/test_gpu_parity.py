@@ -3,8 +3,10 @@ against the CPU oracle on the same seeded inputs.
 
 Bars (BASELINE.json north_star): indices and sort order bit-exact; positions
 and quantities within 1e-10 relative, |d| / max(|ref|, 1), under the fixed
-Squares stream.  The tolerances are written at each assert; measured errors
-are ~1e-15 (device libm vs glibc at the ulp level).
+Squares stream; the random numbers and the single-precision perturbations
+cache->uvwp bit-exact.  The tolerances are written at each assert; measured errors
+are ~1e-15 (reciprocal-multiply weights and fused multiply-adds of the device code;
+exp / log / pow are the C library's bits since round 6).
 """
 import ctypes as C
 
