@@ -3018,7 +3018,10 @@ int mphip_run_timestep(mphip_ctx *ctx, double t) {
       ek.t_stop = c.t_stop;
       ek.t_next = t_next;
       constexpr unsigned kDepo = MPHIP_MOD_WET_DEPO | MPHIP_MOD_DRY_DEPO;
-      if ((tail & kDepo) && !(tail & ~kDepo) && ctx->compact_depo) {   // the deposition launch behind module_mixing will be depo_kernel
+#ifndef MPHIP_DEPO_FLAGS
+#define MPHIP_DEPO_FLAGS 1      // 0: experiment -- the deposition launch decides from dt, time, p itself (profiles/r06_ab_depo_flags.txt)
+#endif
+      if (MPHIP_DEPO_FLAGS && (tail & kDepo) && !(tail & ~kDepo) && ctx->compact_depo) {   // the deposition launch behind module_mixing will be depo_kernel
         if (ctx->np > ctx->depo_busy_cap) {
           if (dev_alloc(ctx, &ctx->d_depo_busy, (size_t) ctx->np))
             return 1;

@@ -3085,10 +3085,14 @@ __global__ void test_rng_kernel(uint64_t ctr, long long n, int method, double *_
   for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x) {
     if (method == 0)
       out[i] = uniform01(ctr + (uint64_t) i);
-    else {
+    else if (method == 1) {
       double e, o;
       normal_pair(ltab, ctr, (uint64_t) i & ~1ull, e, o);
       out[i] = (i & 1) ? o : e;
+    } else {      // method 2: the same normals the way the modules take them -- rs[3 g .. 3 g + 2] of particle g at once
+      double r[3];
+      normal_triple(ltab, ctr, (uint64_t) (i / 3), r[0], r[1], r[2]);
+      out[i] = r[i % 3];
     }
   }
 }

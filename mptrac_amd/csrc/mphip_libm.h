@@ -24,10 +24,8 @@
 
 #ifdef __HIPCC__
 #define MPHIP_LIBM_FN __device__ __forceinline__
-#define MPHIP_LIBM_NOINLINE_FN __device__ __noinline__
 #else
 #define MPHIP_LIBM_FN static inline
-#define MPHIP_LIBM_NOINLINE_FN static
 #endif
 
 /* the tables a call site hands over (global memory, or a copy in LDS) */
@@ -55,10 +53,6 @@ MPHIP_LIBM_FN double mphip_libm_from_bits(uint64_t u) {
   c.u = u;
   return c.d;
 #endif
-}
-
-MPHIP_LIBM_FN uint32_t mphip_libm_hi(double x) {
-  return (uint32_t) (mphip_libm_bits(x) >> 32);
 }
 
 MPHIP_LIBM_FN double mphip_libm_from_words(uint32_t hi, uint32_t lo) {

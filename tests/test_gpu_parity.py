@@ -87,12 +87,12 @@ def test_sincosf_is_bit_identical_to_libm():
     s.close()
 
 
-@pytest.mark.parametrize("ctr,n", [(0, 7), (7, 6), (123456789012, 30001), (2 ** 40 + 3, 4096)])
+@pytest.mark.parametrize("ctr,n", [(0, 7), (7, 6), (123456789012, 30001), (2 ** 40 + 3, 4096), (987654321, 3000000)])
 def test_rng_stream_matches_module_rng(ctr, n):
     o, s = _pair("advect", n=max(n // 3 + 1, 16))
-    for method in (0, 1):
+    for method in (0, 1, 2):      # 2: the normals as the modules draw them (a particle's triple at once: libm_log_unit_pair)
         o.cache.rng_ctr = ctr
-        o.lib.orc_module_rng(C.byref(o.ctl), C.byref(o.cache), C.c_size_t(n), method)
+        o.lib.orc_module_rng(C.byref(o.ctl), C.byref(o.cache), C.c_size_t(n), min(method, 1))
         ref = o.rs[:n].copy()
         dev = s.test_rng(ctr, n, method)
         # uniforms and normals: the reference's bits (Box-Muller through the C library's log, the IEEE square root

@@ -452,3 +452,36 @@ def test_met_conv_netcdf_to_binary_and_back(tmp_path):
     assert np.array_equal(g.variables["x"][:], f.variables["x"][:]) and np.allclose(g.variables["lev"][:], f.variables["plev"][:], rtol=1e-15)
     f.close()
     g.close()
+
+
+def test_met_bin_reader_threads_give_the_same_file(tmp_path):
+    """MET_TYPE 1 level fields are read by several threads side by side (one pread per longitude slab,
+    MPTRAC_AMD_IO_THREADS; mptrac_amd/host/mptrac.c: met_slab_main): a file read with 1, 3 and 8 threads and written
+    back is the same file, byte for byte -- with the limits the reference applies on reading (negative humidities and
+    cloud fractions above one are cut, mptrac.c:9172-9177) -- and a file cut short is refused by every reader."""
+    import subprocess
+    import hostfiles as hf
+    from mptrac_amd import build
+    from mptrac_amd.synth import synthetic_met
+    import cases
+    build.build_host()
+    m = synthetic_met("tiny", 0.0, 1.0, fields=cases.PRESSURE_LEVEL_FIELDS)
+    m.f3["h2o"][::3, ::2, ::5] = -1e-6          # the reader's lower limit
+    m.f3["lwc"][1::4, :, 2] = -0.5
+    src = str(tmp_path / "met_2000_01_01_00.bin")
+    hf.write_met_bin(src, m)
+    outs = []
+    for threads in (1, 3, 8):
+        dst = str(tmp_path / ("out%d_2000_01_01_00.bin" % threads))
+        r = subprocess.run([build.MET_CONV_BIN, "-", src, "1", dst, "1"], capture_output=True, text=True, timeout=120,
+                           env=dict(os.environ, MPTRAC_AMD_IO_THREADS=str(threads)))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+        outs.append(open(dst, "rb").read())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == os.path.getsize(src)
+    assert outs[0] != open(src, "rb").read()                 # (the negative values were cut)
+    cut = str(tmp_path / "cut_2000_01_01_00.bin")
+    open(cut, "wb").write(open(src, "rb").read()[:-(m.nx * m.ny * m.np * 4 * 2 + 100)])
+    for threads in (1, 8):
+        r = subprocess.run([build.MET_CONV_BIN, "-", cut, "1", str(tmp_path / "x.bin"), "1"], capture_output=True, text=True,
+                           timeout=120, env=dict(os.environ, MPTRAC_AMD_IO_THREADS=str(threads)))
+        assert r.returncode != 0 and "Error while reading" in r.stdout + r.stderr, (threads, r.stdout[-500:])
