@@ -396,9 +396,11 @@ int mphip_profile_end(mphip_ctx *ctx, long long *launches, double *kernel_ms);
 int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, float *cos_out,
                        float *sin_out);
 int mphip_test_rng(mphip_ctx *ctx, uint64_t ctr, long long n, int method, double *out);
-/* out[i] = exp(x[i]) (op 0), log(x[i]) (1), pow(x[i], y[i]) (2), sqrt(x[i]) (3) as the kernels evaluate them: the
- * restatement of the C library's exp / log / pow the reference's CPU build links (src/mptrac.c:4531-4546, 5822;
- * csrc/mphip_libm.h) and the square root of the Box-Muller radius; op + 16 reads the tables from an LDS copy.
+/* out[i] = exp(x[i]) (op 0), log(x[i]) (1), pow(x[i], y[i]) (2), sqrt(x[i]) (3), cos(x[i]) (4), sin(x[i]) (5) as the
+ * kernels evaluate them: the restatement of the C library's exp / log / pow the reference's CPU build links
+ * (src/mptrac.c:4531-4546, 5822; csrc/mphip_libm.h), the square root of the Box-Muller radius, and the library's
+ * cos / sin of DX2DEG / ZETA (mptrac.h:904, 2293; the reference-rounding build and module_meteo); op + 16 reads the
+ * exp / log / pow tables from an LDS copy.
  * x, y, out are host arrays of n doubles. */
 int mphip_test_libm(mphip_ctx *ctx, int op, const double *x, const double *y, long long n, double *out);
 /* Profiling aid: run building block `piece` of the step kernel (stencil set-up, one Runge-Kutta stage's

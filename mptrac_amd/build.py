@@ -1,6 +1,7 @@
 """Build recipe of the in-tree native libraries (gfx950 only).
 
-  lib/libmptrac_hip.so   the HIP back end + C ABI (csrc/mphip_api.hip)
+  lib/libmptrac_hip.so         the HIP back end + C ABI (csrc/mphip_api.hip)
+  lib/libmptrac_hip_exact.so   the same sources with the reference's roundings (EXACT_FLAGS): same ABI, same kernels
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with
 the tree to the GPU box.
@@ -13,6 +14,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 HIP_LIB = os.path.join(LIBDIR, "libmptrac_hip.so")
+# The reference-rounding build: every division of the reference an IEEE division (the default multiplies by reciprocals
+# of grid constants rounded once on the host and uses a rcp + Newton quotient), the C library's square root and cosine
+# calls, and no contraction of a multiply and an add into a fused multiply-add (the reference's default CPU build, gcc
+# -O3 without -march, has none; the fused operations inside exp / log / pow are the C library's own and stay).  What
+# this build computes is the oracle's bits except for the longitude increment's cos(latitude) (the device library's
+# against glibc's: one ulp in 0.1 % of the particles after 20 steps); tools/gpu_bit_census.py, DESIGN.md section 2.
+EXACT_LIB = os.path.join(LIBDIR, "libmptrac_hip_exact.so")
+EXACT_FLAGS = ["-DMPHIP_EXACT_DIV=1", "-ffp-contract=off"]
 
 # -disable-machine-licm: the machine-level loop-invariant code motion parks the ~60 double constants of
 # the polynomial kernels (sincosf, log, exp, cos) in VGPR pairs for the whole particle loop; without it the
@@ -54,20 +63,44 @@ def build_variant(name, extra_flags, verbose=False):
     return out
 
 
-def build_hip(force=False, verbose=False, extra_flags=()):
-    if os.environ.get("MPHIP_LIB"):
-        return os.environ["MPHIP_LIB"]
+def _build_lib(target, flags, force, verbose):
     os.makedirs(LIBDIR, exist_ok=True)
-    if force or _stale(HIP_LIB, hip_sources()):
+    if force or _stale(target, hip_sources()):
         if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
-            if os.path.exists(HIP_LIB):
-                return HIP_LIB       # prebuilt library shipped with the tree
-        cmd = [_hipcc(), *HIPCC_FLAGS, *extra_flags, "-o", HIP_LIB, os.path.join(CSRC, "mphip_api.hip")]
+            if os.path.exists(target):
+                return target       # prebuilt library shipped with the tree
+        cmd = [_hipcc(), *HIPCC_FLAGS, *flags, "-o", target, os.path.join(CSRC, "mphip_api.hip")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        verify_async_loads(HIP_LIB, verbose)
-    return HIP_LIB
+        verify_async_loads(target, verbose)
+    return target
+
+
+def exact_requested():
+    return os.environ.get("MPTRAC_AMD_EXACT", "0") not in ("", "0")
+
+
+def build_hip(force=False, verbose=False, extra_flags=()):
+    """The library the package loads: MPHIP_LIB=<path> (tuning builds), MPTRAC_AMD_EXACT=1 (the reference-rounding
+    build), else lib/libmptrac_hip.so."""
+    if os.environ.get("MPHIP_LIB"):
+        return os.environ["MPHIP_LIB"]
+    if exact_requested():
+        return build_hip_exact(force, verbose)
+    return _build_lib(HIP_LIB, list(extra_flags), force, verbose)
+
+
+def build_hip_exact(force=False, verbose=False):
+    return _build_lib(EXACT_LIB, EXACT_FLAGS, force, verbose)
+
+
+def build_hip_both(force=False, verbose=False):
+    """Both libraries, compiled side by side (each is one translation unit: ~3 minutes of one core)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as pool:
+        jobs = [pool.submit(_build_lib, HIP_LIB, [], force, verbose), pool.submit(build_hip_exact, force, verbose)]
+        return [j.result() for j in jobs]
 
 
 def verify_async_loads(lib, verbose=False):

@@ -749,7 +749,7 @@ static unsigned long long guard_levels(const mphip_ctx *ctx) {
 }
 static bool lean_grid(const mphip_ctx *ctx) {
   const unsigned long long cols = (unsigned long long) ctx->nx * ctx->ny;
-  return ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV && cols < (1ull << 24)
+  return ctx->coord_type == 0 && ctx->lut_size > 0 && cols < (1ull << 24)
     && cols * guard_levels(ctx) < (1ull << 32);
 }
 static bool fits32(const mphip_ctx *ctx) {
@@ -1280,7 +1280,7 @@ int sort_keys(mphip_ctx *ctx, int tile, const double *timestep_t, const BoxArgs 
   TimestepArgs ts = { (double) ctx->ctl.direction, ctx->ctl.t_start, ctx->ctl.t_stop, timestep_t ? *timestep_t : 0.0 };
   BoxArgs none;
   memset(&none, 0, sizeof(none));
-  const bool lean = ctx->coord_type == 0 && ctx->lut_size > 0 && !MPHIP_EXACT_DIV && !ctx->force_generic;
+  const bool lean = ctx->coord_type == 0 && ctx->lut_size > 0 && !ctx->force_generic;
   if (lean)
     hipLaunchKernelGGL(sort_key_kernel<true>, dim3(grid_for(ctx->np)), dim3(256), axes_lds_bytes(ctx), ctx->stream, M, a, tile,
                        tile_zbits(ctx, tile), ctx->d_keys[0], (int *) nullptr, ts, timestep_t ? ctx->d_dt : nullptr,
@@ -3630,7 +3630,7 @@ int mphip_test_sincosf(mphip_ctx *ctx, uint32_t bits_first, uint32_t count, floa
 }
 
 int mphip_test_libm(mphip_ctx *ctx, int op, const double *x, const double *y, long long n, double *out) {
-  if (!ctx || !x || !out || n < 0 || ((op & 15) == 2 && !y) || (op & ~31) || (op & 15) > 3)
+  if (!ctx || !x || !out || n < 0 || ((op & 15) == 2 && !y) || (op & ~31) || (op & 15) > 5)
     return 1;
   HIPCHK(hipSetDevice(ctx->device));
   const size_t bytes = (size_t) std::max<long long>(n, 1) * sizeof(double);

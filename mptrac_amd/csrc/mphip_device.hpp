@@ -63,6 +63,22 @@ __device__ __noinline__ double libm_pow(double x, double y) {
   return libm_pow(libm_tables(), x, y);
 }
 
+// sin and cos of the C library for |x| < 2.426 (mphip_libm.h; every latitude in radians, ZETA's argument); the device
+// library's beyond.  Calls: they serve the reference-rounding build (DX2DEG) and module_meteo, not the headline path.
+static __device__ const double g_sincos_tab[440] = { MPHIP_LIBM_SINCOS_TAB_INIT };
+
+__device__ __noinline__ double libm_cos(double x) {
+  int handled;
+  const double r = mphip_libm_cos(g_sincos_tab, x, &handled);
+  return handled ? r : cos(x);
+}
+
+__device__ __noinline__ double libm_sin(double x) {
+  int handled;
+  const double r = mphip_libm_sin(g_sincos_tab, x, &handled);
+  return handled ? r : sin(x);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- constants (mptrac.h:255-345, 430-460, 535) ---------------------------
@@ -201,12 +217,17 @@ __device__ __forceinline__ Axes load_axes(const DevMet &M, double *smem) {
   return A;
 }
 
-// MPHIP_EXACT_DIV = 1 keeps every IEEE division of the reference; the default
-// multiplies by reciprocals that were rounded once on the host where the
-// divisor is a grid constant (interval widths, 1000, pi * RE, time1 - time0).
-// That moves interpolation weights by at most one ulp (positions ~1e-15
-// relative, far inside the 1e-10 bar); indices that are observable (sort key,
-// mixing / output cells) always use the exact form.
+// Two builds of these sources (mptrac_amd/build.py):
+//   libmptrac_hip.so        MPHIP_EXACT_DIV = 0.  Where the divisor is a grid constant (interval widths, 1000, pi * RE,
+//                           time1 - time0) the kernels multiply by a reciprocal the host rounded once; quotients of
+//                           variables are rcp + Newton (fdiv), cos(latitude) a polynomial, and the compiler contracts
+//                           a * b + c.  A weight moves by at most an ulp: positions within 1e-15 of the oracle's after
+//                           20 steps, 97 % of them its bits.  Indices that are observable (sort key, mixing / output
+//                           cells) always use the exact form.
+//   libmptrac_hip_exact.so  MPHIP_EXACT_DIV = 1 and -ffp-contract=off: every division of the reference an IEEE
+//                           division, its sqrt / cos / sin calls the C library's (sqrt_rn, libm_cos, libm_sin), no
+//                           contraction -- the lean kernels included.  Positions, quantities and perturbations are the
+//                           oracle's bits (tests/test_gpu_exact_library.py); the step costs ~40 % more on workload C3.
 #ifndef MPHIP_EXACT_DIV
 #define MPHIP_EXACT_DIV 0
 #endif
@@ -377,7 +398,7 @@ __device__ __forceinline__ double dx2deg(double dx, double lat) {   // mptrac.h:
   if (lat < -89.999 || lat > 89.999)
     return 0;
 #if MPHIP_EXACT_DIV
-  return dx * 180. / (kPi * kRE * cos(deg2rad(lat)));
+  return dx * 180. / (kPi * kRE * libm_cos(deg2rad(lat)));
 #else
   return (dx * 180.) * frcp(kPi * kRE * cos_latitude(deg2rad(lat)));
 #endif
@@ -1926,7 +1947,11 @@ __device__ __forceinline__ void stencil_4d_fast(const DevMet &M, const Axes &A, 
     // indices from verified guesses, as the pressure-level kernels take them (lon_fast / lat_fast)
     lat2 = vmin_s(vmax_s(lat, M.latmin), M.latmax);
     lon2 = lon + (lon < M.lon_first ? 360.0 : (lon > M.lon_last ? -360.0 : 0.0));
+#if MPHIP_EXACT_DIV
+    s.ix = locate_reg(A.lon, M.nx, lon2);
+#else
     s.ix = clamp0_s((int) ((lon2 - M.lon_first) * M.inv_dlon0), M.nx - 2);
+#endif
     guessed = (fabs(lon) < 360.0) & lat_fast(M, A, lat2, hy.i, hy.x1, hy.inv);
     hy.x0 = A.lat[hy.i];
   }
@@ -2438,11 +2463,11 @@ __device__ __forceinline__ double theta_of(double p, double t) {   // THETA, mpt
 }
 
 __device__ __forceinline__ double zeta_of(double ps, double p, double t) {   // ZETA, mptrac.h:2293
-  return (p / ps <= 0.3 ? 1. : sin(kPi / 2. * (1. - p / ps) / (1. - 0.3))) * theta_of(p, t);
+  return (p / ps <= 0.3 ? 1. : libm_sin(kPi / 2. * (1. - p / ps) / (1. - 0.3))) * theta_of(p, t);
 }
 
 __device__ __forceinline__ double lapse_rate(double t, double h2o) {   // lapse_rate, mptrac.c:3324-3338
-  const double a = kRA * t * t, r = sh_of(h2o) / (1. - sh_of(h2o));
+  const double a = kRA * (t * t), r = sh_of(h2o) / (1. - sh_of(h2o));   // (RA * SQR(t): the square first)
   return 1e3 * kG0 * (a + kLv * r * t) / (kCpd * a + kLv * kLv * r * kEps);
 }
 
@@ -2520,27 +2545,50 @@ __device__ __forceinline__ bool in_boundary_region(const mphip_ctl_t &ctl, const
 // Metre -> degree factors of one latitude: DX2DEG(dx, lat) = dx * kx, DY2DEG(dy) = dy * ky with dx, dy in
 // metres (mptrac.h:904-906, 922; the / 1000 of DX2COORD folded in).  One cosine and one reciprocal serve
 // every conversion at that latitude (the four of a Runge-Kutta step use the same one, mptrac.c:3628, 3672).
+// (MPHIP_EXACT_DIV: the record keeps the divisor pi RE cos(lat) and every conversion divides as the reference does.)
 struct DegPerMetre {
-  double kx;
+  double kx;   // degrees per metre along x -- with MPHIP_EXACT_DIV: pi RE cos(lat); 0 next to the poles
 };
 
 __device__ __forceinline__ DegPerMetre deg_per_metre(double lat) {
 #pragma clang fp contract(off)
   DegPerMetre d;
+#if MPHIP_EXACT_DIV
+  d.kx = (lat < -89.999 || lat > 89.999) ? 0.0 : kPi * kRE * libm_cos(deg2rad(lat));
+#else
   const double c = kPi * kRE * cos_latitude_k(deg2rad(lat));
   d.kx = (lat < -89.999 || lat > 89.999) ? 0.0 : kMetresToDeg * frcp(c);
+#endif
   return d;
 }
 
 // (contraction off: the product is rounded before the caller adds it, as in dx2coord / dy2coord of the general code)
 __device__ __forceinline__ double dx2deg_k(const DegPerMetre &d, double dx_metres) {
 #pragma clang fp contract(off)
+#if MPHIP_EXACT_DIV
+  return d.kx == 0.0 ? 0.0 : dx_metres / 1000.0 * 180. / d.kx;
+#else
   return dx_metres * d.kx;
+#endif
 }
 
 __device__ __forceinline__ double dy2deg_k(double dy_metres) {
 #pragma clang fp contract(off)
+#if MPHIP_EXACT_DIV
+  return dy_metres / 1000.0 * 180. / (kPi * kRE);
+#else
   return dy_metres * kDegPerMetreY;
+#endif
+}
+
+// a stencil weight: numerator x the reciprocal interval width the host rounded once -- with MPHIP_EXACT_DIV the
+// quotient by the width itself (the *_fast functions below hand back the one or the other as `inv`)
+__device__ __forceinline__ double weight_of(double num, double inv) {
+#if MPHIP_EXACT_DIV
+  return num / inv;
+#else
+  return num * inv;
+#endif
 }
 
 // ---- stencil set-up ---------------------------------------------------------
@@ -2549,9 +2597,15 @@ __device__ __forceinline__ double dy2deg_k(double dy_metres) {
 // longitude needs FMOD (|lon| >= 360)
 __device__ __forceinline__ bool lon_fast(const DevMet &M, const Axes &A, double lon, int &ix, double &wx) {
   double lon2 = lon + (lon < M.lon_first ? 360.0 : (lon > M.lon_last ? -360.0 : 0.0));
+#if MPHIP_EXACT_DIV
+  ix = locate_reg(A.lon, M.nx, lon2);
+  const double lx1 = A.lon[ix + 1];
+  wx = (lx1 - lon2) / (lx1 - A.lon[ix]);
+#else
   ix = clamp0_s((int) ((lon2 - M.lon_first) * M.inv_dlon0), M.nx - 2);
   const double lx1 = A.lon[ix + 1], linv = A.inv_lon[ix];
   wx = (lx1 - lon2) * linv;
+#endif
   return fabs(lon) < 360.0;
 }
 
@@ -2563,7 +2617,11 @@ __device__ __forceinline__ bool lat_fast(const DevMet &M, const Axes &A, double 
   iy = clamp0_s((int) ((lat2 - M.lat_x0) * M.lat_inv_dx), M.ny - 2);
   const double y0 = A.lat[iy];
   y1 = A.lat[iy + 1];
+#if MPHIP_EXACT_DIV
+  yinv = y1 - y0;
+#else
   yinv = A.inv_lat[iy];
+#endif
   return (vmin(y0, y1) <= lat_s) & (lat_s < vmax(y0, y1));
 }
 
@@ -2576,7 +2634,11 @@ __device__ __forceinline__ bool p_fast(const DevMet &M, const Axes &A, double p,
   ip = g + (ps >= node ? M.p_step : 0);
   const double p0 = A.p[ip];
   p1 = A.p[ip + 1];
+#if MPHIP_EXACT_DIV
+  pinv = p1 - p0;
+#else
   pinv = A.inv_p[ip];
+#endif
   return (vmin(p0, p1) <= ps) & (ps < vmax(p0, p1)) & (p == p);   // (a NaN takes the general path: index n - 2)
 }
 
@@ -2587,7 +2649,7 @@ __device__ __forceinline__ void horiz_fast(const DevMet &M, const Axes &A, doubl
   double y1, yinv;
   bool ok = lon_fast(M, A, lon, s.ix, s.wx);
   ok &= lat_fast(M, A, lat2, s.iy, y1, yinv);
-  s.wy = (y1 - lat2) * yinv;
+  s.wy = weight_of(y1 - lat2, yinv);
   if (!ok) {
     Stencil g = stencil_zero();
     stencil_2d(M, A, lon, lat, g);
@@ -2602,7 +2664,7 @@ __device__ __forceinline__ void horiz_fast(const DevMet &M, const Axes &A, doubl
 __device__ __forceinline__ void vert_fast(const DevMet &M, const Axes &A, double p, Stencil &s) {
   double p1, pinv;
   const bool ok = p_fast(M, A, p, s.ip, p1, pinv);
-  s.wp = (p1 - p) * pinv;
+  s.wp = weight_of(p1 - p, pinv);
   if (!ok) {
     const AxisHit hp = hit_p(M, A, p);
     s.ip = hp.i;
@@ -2617,8 +2679,8 @@ __device__ __forceinline__ void stencil_3d_fast(const DevMet &M, const Axes &A, 
   bool ok = lon_fast(M, A, lon, s.ix, s.wx);
   ok &= lat_fast(M, A, lat2, s.iy, y1, yinv);
   ok &= p_fast(M, A, p, s.ip, p1, pinv);
-  s.wy = (y1 - lat2) * yinv;
-  s.wp = (p1 - p) * pinv;
+  s.wy = weight_of(y1 - lat2, yinv);
+  s.wp = weight_of(p1 - p, pinv);
   if (!ok)
     stencil_3d(M, A, p, lon, lat, s);
 }
@@ -3000,7 +3062,7 @@ __device__ __forceinline__ void diff_turb_fast(const mphip_ctl_t &ctl, const Dev
     const double p_dn = p_save + dz2dp(-eps_km, p_save);
     const double Kz_up = kz_blend(ctl, pt, vmax(ptop, vmin(ps, p_up)), pbl, ps);
     const double Kz_dn = kz_blend(ctl, pt, vmax(ptop, vmin(ps, p_dn)), pbl, ps);
-    const double dKz_dz = (Kz_up - Kz_dn) * (1.0 / (2.0 * eps_km * 1e3));
+    const double dKz_dz = div_const(Kz_up - Kz_dn, 2.0 * eps_km * 1e3, 1.0 / (2.0 * eps_km * 1e3));
     const double dlnrho_dz = -1.0 / (1e3 * kH0);
     const double w_drift = dKz_dz + Kz * dlnrho_dz;
     const double dz_drift = w_drift * dt_abs * 1e-3;
@@ -3177,7 +3239,7 @@ __device__ __forceinline__ void conv_sedi_fast(const mphip_ctl_t &ctl, const Dev
     vert_fast(M, A, P.p, s);
     const double t = temp_fast<BIG>(M, s, wt);
     const double v_s = sedi(P.p, t, rp, rhop, ltab);
-    P.p += dz2dp(v_s * P.dt * 1e-3, P.p);
+    P.p += dz2dp(div_const(v_s * P.dt, 1000., 1e-3), P.p);
   }
 }
 
@@ -3204,6 +3266,7 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) {   // 
 }
 
 __device__ __forceinline__ double tvirt(double t, double h2o) {   // TVIRT, mptrac.h:2199
+#pragma clang fp contract(off)
   return t * (1. + (1. - kEps) * dmax(h2o, 0.1e-6));
 }
 
@@ -3339,7 +3402,7 @@ __device__ __forceinline__ void diff_pbl(const DevMet &M, const Axes &A, Particl
     t = temp_time_3d(M, cell, wt);
   }
   h2o = pair_time_3d(M.h2o, M, cell, wt);
-  const double rho = rho_air(p_in, tvirt(t, h2o));
+  const double rho = 100. * p_in / (kRA * tvirt(t, h2o));   // RHO, mptrac.h:1961, as the IEEE quotient (rho_air's is not)
   if (!(rho > 0.0))
     return;
   const double theta_v = tvirt(t * libm_pow(ltab, 1000. / p_in, kKappa), dmax(h2o, 0.1e-6));   // THETAVIRT, mptrac.h:2153

@@ -756,7 +756,10 @@ __global__ __launch_bounds__(256, kLeanML<CT> ? MPHIP_ML_WAVES_PER_SIMD : !kRunt
     // the specialised instantiations run the lean versions (lat/lon grid, pressure table: launch_step)
     constexpr bool lean = !kRuntimeMask<CT>;
     if (!kModelLevels<CT> && !(multi && MPHIP_MULTI_KEEP_WIND))   // (model-level winds: the corners are first needed by module_diff_meso -- defined there,
-      wind_cache_reset(wc, CT != kMaskGeneric);   //  or 48 registers would be held through the whole advection)
+      wind_cache_reset(wc, CT != kMaskGeneric && (lean || !MPHIP_EXACT_DIV));   //  or 48 registers would be held through the whole advection)
+    // (MPHIP_EXACT_DIV: the general kernels gather with plain loads -- with the IEEE division sequences between the
+    // asynchronous gathers and their wait the register allocator reuses their registers, which the machine-code
+    // check of the build refuses)
     if (mask & MPHIP_MOD_POSITION) {
       if (lean)
         position_fast(M, A, P);
@@ -3057,8 +3060,9 @@ __global__ __launch_bounds__(256, MPHIP_STEP_WAVES_PER_SIMD) void piece_kernel(c
   }
 }
 
-// out[i] = exp(x[i]) / log(x[i]) / pow(x[i], y[i]) / sqrt(x[i]) (op 0 / 1 / 2 / 3) as the kernels evaluate them: the C
-// library's functions of mphip_libm.h and the square root of the Box-Muller radius; op + 16: tables copied to LDS first
+// out[i] = exp(x[i]) / log(x[i]) / pow(x[i], y[i]) / sqrt(x[i]) / cos(x[i]) / sin(x[i]) (op 0 .. 5) as the kernels
+// evaluate them: the C library's functions of mphip_libm.h and the square root of the Box-Muller radius; op + 16: exp /
+// log / pow tables copied to LDS first
 __global__ __launch_bounds__(256) void test_libm_kernel(int op, const double *__restrict__ x, const double *__restrict__ y,
                                                          long long n, double *__restrict__ out) {
   __shared__ double s_tab[kLibmDoubles];
@@ -3074,6 +3078,8 @@ __global__ __launch_bounds__(256) void test_libm_kernel(int op, const double *__
     case 0: out[i] = libm_exp(lt, x[i]); break;
     case 1: out[i] = libm_log(lt, x[i]); break;
     case 2: out[i] = libm_pow(lt, x[i], y[i]); break;
+    case 4: out[i] = libm_cos(x[i]); break;
+    case 5: out[i] = libm_sin(x[i]); break;
     default: out[i] = sqrt_rn(x[i]); break;
     }
   }

@@ -349,4 +349,127 @@ MPHIP_LIBM_FN double mphip_libm_pow(const mphip_libm_tabs *T, double x, double y
   return mphip_libm_exp_core(T->exp_tab, ehi, elo, 1, sign_bias);
 }
 
+/* ---- sin and cos for |x| < 2.426265 (high word below 0x400368fd: every latitude in radians, ZETA's argument) ----
+ * glibc's sysdeps/ieee754/dbl-64/s_sin.c (`__sin_fma` / `__cos_fma`; IBM Accurate Mathematical Library): the argument
+ * is split at a multiple of 1 / 128 by adding 1.5 x 2^45, sin and cos of that multiple come from a table with their
+ * tails, the rest from two short polynomials; next to pi / 2 the co-function of (pi / 2 - |x|) is taken, and below
+ * 0.126 a Taylor polynomial.  Fused operations as the machine code of the two variants has them (glibc 2.35):
+ *   do_cos(x, dx):  t = fma(xx, sn5, sn3); s = fma(x xx, t, x); c = xx fma(xx, fma(xx, cs6, cs4), cs2);
+ *                   cor = fnma(s, sn, fnma(c, cs, fnma(s, ssn, ccs))); cs + cor
+ *   do_sin(x, dx):  s = x + fma(x xx, t, dx); c = fma(x, dx, xx fma(...)); cor = fma(s, cs, fnma(c, sn, fma(s, ccs, ssn))); sn + cor
+ *   Taylor:         p = fma chain s5..s1; a + fma(xx, fms(p, a, 0.5 da), da)
+ * Outside the range the functions return NaN with *handled = 0 (the caller takes another path). */
+#define MPHIP_SC_SN3 (-0x1.5555555555515p-3)
+#define MPHIP_SC_SN5 0x1.11110e829872fp-7
+#define MPHIP_SC_CS2 0x1.0000000000000p-1
+#define MPHIP_SC_CS4 (-0x1.5555555555535p-5)
+#define MPHIP_SC_CS6 0x1.6c16bedd9e239p-10
+#define MPHIP_SC_S1 (-0x1.5555555555555p-3)
+#define MPHIP_SC_S2 0x1.1111111110ecep-7
+#define MPHIP_SC_S3 (-0x1.a01a019db08b8p-13)
+#define MPHIP_SC_S4 0x1.71de27b9a7ed9p-19
+#define MPHIP_SC_S5 (-0x1.addffc2fcdf59p-26)
+#define MPHIP_SC_HP0 0x1.921fb54442d18p+0
+#define MPHIP_SC_HP1 0x1.1a62633145c07p-54
+#define MPHIP_SC_BIG 0x1.8000000000000p+45
+#define MPHIP_SC_TAYLOR_BELOW 0x1.020c49ba5e354p-3
+
+MPHIP_LIBM_FN double mphip_libm_fabs(double x) {
+  return mphip_libm_from_bits(mphip_libm_bits(x) & 0x7fffffffffffffffULL);
+}
+
+MPHIP_LIBM_FN double mphip_libm_copysign(double mag, double sgn) {
+  return mphip_libm_from_bits((mphip_libm_bits(mag) & 0x7fffffffffffffffULL) | (mphip_libm_bits(sgn) & 0x8000000000000000ULL));
+}
+
+/* cos(ax + dx) for ax >= 0 (the caller has folded the sign of its argument into dx) */
+MPHIP_LIBM_FN double mphip_libm_do_cos(const double *tab, double ax, double dx) {
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+  const double u = MPHIP_SC_BIG + ax;
+  const int k = (int) ((uint32_t) mphip_libm_bits(u) << 2);
+  const double x = ax - (u - MPHIP_SC_BIG) + dx;
+  const double xx = x * x;
+  const double t = MPHIP_LIBM_FMA(xx, MPHIP_SC_SN5, MPHIP_SC_SN3);
+  const double s = MPHIP_LIBM_FMA(x * xx, t, x);
+  const double c = xx * MPHIP_LIBM_FMA(xx, MPHIP_LIBM_FMA(xx, MPHIP_SC_CS6, MPHIP_SC_CS4), MPHIP_SC_CS2);
+  const double sn = tab[k], ssn = tab[k + 1], cs = tab[k + 2], ccs = tab[k + 3];
+  const double cor = MPHIP_LIBM_FMA(-s, sn, MPHIP_LIBM_FMA(-c, cs, MPHIP_LIBM_FMA(-s, ssn, ccs)));
+  return cs + cor;
+}
+
+MPHIP_LIBM_FN double mphip_libm_taylor_sin(double a, double da) {
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+  const double xx = a * a;
+  double p = MPHIP_LIBM_FMA(xx, MPHIP_SC_S5, MPHIP_SC_S4);
+  p = MPHIP_LIBM_FMA(xx, p, MPHIP_SC_S3);
+  p = MPHIP_LIBM_FMA(xx, p, MPHIP_SC_S2);
+  p = MPHIP_LIBM_FMA(xx, p, MPHIP_SC_S1);
+  const double half_da = da * 0.5;
+  return a + MPHIP_LIBM_FMA(xx, MPHIP_LIBM_FMA(p, a, -half_da), da);
+}
+
+/* sin(a + da), any sign of a */
+MPHIP_LIBM_FN double mphip_libm_do_sin(const double *tab, double a, double da) {
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+  const double aa = mphip_libm_fabs(a);
+  if (aa < MPHIP_SC_TAYLOR_BELOW)
+    return mphip_libm_taylor_sin(a, da);
+  const double dx = a <= 0.0 ? -da : da;
+  const double u = MPHIP_SC_BIG + aa;
+  const int k = (int) ((uint32_t) mphip_libm_bits(u) << 2);
+  const double x = aa - (u - MPHIP_SC_BIG);
+  const double xx = x * x;
+  const double t = MPHIP_LIBM_FMA(xx, MPHIP_SC_SN5, MPHIP_SC_SN3);
+  const double s = x + MPHIP_LIBM_FMA(x * xx, t, dx);
+  const double c = MPHIP_LIBM_FMA(x, dx, xx * MPHIP_LIBM_FMA(xx, MPHIP_LIBM_FMA(xx, MPHIP_SC_CS6, MPHIP_SC_CS4), MPHIP_SC_CS2));
+  const double sn = tab[k], ssn = tab[k + 1], cs = tab[k + 2], ccs = tab[k + 3];
+  const double cor = MPHIP_LIBM_FMA(s, cs, MPHIP_LIBM_FMA(-c, sn, MPHIP_LIBM_FMA(s, ccs, ssn)));
+  return mphip_libm_copysign(sn + cor, a);
+}
+
+MPHIP_LIBM_FN double mphip_libm_cos(const double *sincos_tab, double x, int *handled) {
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+  const uint32_t k = (uint32_t) (mphip_libm_bits(x) >> 32) & 0x7fffffffu;
+  *handled = 1;
+  if (k < 0x3e400000u)      /* |x| < 2^-27 */
+    return 1.0;
+  if (k < 0x3feb6000u)      /* |x| < 0.855469 */
+    return mphip_libm_do_cos(sincos_tab, mphip_libm_fabs(x), 0.0);
+  if (k < 0x400368fdu) {    /* |x| < 2.426265: sin(pi / 2 - |x|) */
+    const double y = MPHIP_SC_HP0 - mphip_libm_fabs(x);
+    const double a = y + MPHIP_SC_HP1;
+    const double da = (y - a) + MPHIP_SC_HP1;
+    return mphip_libm_do_sin(sincos_tab, a, da);
+  }
+  *handled = 0;
+  return mphip_libm_from_bits(0x7ff8000000000000ULL);
+}
+
+MPHIP_LIBM_FN double mphip_libm_sin(const double *sincos_tab, double x, int *handled) {
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+  const uint32_t k = (uint32_t) (mphip_libm_bits(x) >> 32) & 0x7fffffffu;
+  *handled = 1;
+  if (k < 0x3e500000u)      /* |x| < 2^-26 */
+    return x;
+  if (k < 0x3feb6000u)
+    return mphip_libm_do_sin(sincos_tab, x, 0.0);
+  if (k < 0x400368fdu) {    /* cos(pi / 2 - |x|) with the sign of x */
+    const double t = MPHIP_SC_HP0 - mphip_libm_fabs(x);
+    const double r = mphip_libm_do_cos(sincos_tab, mphip_libm_fabs(t), t >= 0.0 ? MPHIP_SC_HP1 : -MPHIP_SC_HP1);
+    return mphip_libm_copysign(r, x);
+  }
+  *handled = 0;
+  return mphip_libm_from_bits(0x7ff8000000000000ULL);
+}
+
 #endif

@@ -61,7 +61,10 @@ def _close_live_contexts():
 
 
 def lib_path():
-    return _build.HIP_LIB
+    """The library load() takes: MPHIP_LIB, or with MPTRAC_AMD_EXACT=1 the reference-rounding build, else the default."""
+    if os.environ.get("MPHIP_LIB"):
+        return os.environ["MPHIP_LIB"]
+    return _build.EXACT_LIB if _build.exact_requested() else _build.HIP_LIB
 
 
 def load(build=True):
@@ -69,7 +72,7 @@ def load(build=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build_hip() if build else _build.HIP_LIB
+    path = _build.build_hip() if build else lib_path()
     if not os.path.exists(path):
         raise MphipError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(path)
@@ -469,7 +472,7 @@ class Simulation:
 
     def test_libm(self, fn, x, y=None, lds=False):
         """exp / log / pow / sqrt of the arrays as the kernels evaluate them (mphip_libm.h; tables from LDS if asked)."""
-        op = {"exp": 0, "log": 1, "pow": 2, "sqrt": 3}[fn] + (16 if lds else 0)
+        op = {"exp": 0, "log": 1, "pow": 2, "sqrt": 3, "cos": 4, "sin": 5}[fn] + (16 if lds else 0)
         x = np.ascontiguousarray(x, dtype=np.float64)
         if y is not None:
             y = np.ascontiguousarray(y, dtype=np.float64)

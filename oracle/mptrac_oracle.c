@@ -390,7 +390,7 @@ void orc_libm_sincosf(const float *x, size_t n, float *cos_out, float *sin_out) 
 void orc_libm_f64(int op, const double *x, const double *y, size_t n, double *out) {
 #pragma omp parallel for schedule(static)
   for (size_t i = 0; i < n; i++)
-    out[i] = op == 0 ? exp(x[i]) : op == 1 ? log(x[i]) : op == 2 ? pow(x[i], y[i]) : sqrt(x[i]);
+    out[i] = op == 0 ? exp(x[i]) : op == 1 ? log(x[i]) : op == 2 ? pow(x[i], y[i]) : op == 4 ? cos(x[i]) : op == 5 ? sin(x[i]) : sqrt(x[i]);
 }
 
 /* module_rng, RNG_TYPE=1 branch: n+1 uniforms, counter advanced by n+1, then

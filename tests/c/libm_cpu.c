@@ -74,6 +74,39 @@ size_t cmp_pow(const double *x, const double *y, size_t n, size_t *first_bad) {
   return bad;
 }
 
+/* sin / cos inside the restated range |x| < 2.426265 (arguments outside are skipped by the caller's sets) */
+size_t cmp_cos(const double *x, size_t n, size_t *first_bad) {
+  size_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+  for (size_t i = 0; i < n; i++) {
+    int handled;
+    const double v = mphip_libm_cos(mphip_libm_sincos_tab, x[i], &handled);
+    if (!handled || !same(v, cos(x[i]))) {
+      bad++;
+#pragma omp critical
+      if (i < *first_bad)
+        *first_bad = i;
+    }
+  }
+  return bad;
+}
+
+size_t cmp_sin(const double *x, size_t n, size_t *first_bad) {
+  size_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+  for (size_t i = 0; i < n; i++) {
+    int handled;
+    const double v = mphip_libm_sin(mphip_libm_sincos_tab, x[i], &handled);
+    if (!handled || !same(v, sin(x[i]))) {
+      bad++;
+#pragma omp critical
+      if (i < *first_bad)
+        *first_bad = i;
+    }
+  }
+  return bad;
+}
+
 /* the table header against the constants the algorithms carry as literals */
 int check_constants(void) {
   const double k[8] = { MPHIP_EXP_INVLN2N, MPHIP_EXP_SHIFT, MPHIP_EXP_NEGLN2HIN, MPHIP_EXP_NEGLN2LON,

@@ -53,3 +53,19 @@ def same_bits(a, b):
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+
+
+def sincos_sets(rng, n):
+    """Arguments of cos / sin inside the range the restatement covers (high word below 0x400368fd, |x| < 2.42626):
+    latitudes in radians, both table branches, the Taylor branch below 0.126, the co-function branch next to pi / 2."""
+    import numpy as np
+    lim = float.fromhex("0x1.368fcffffffffp+1")
+    sets = [("whole range", rng.uniform(-lim, lim, 2 * n)),
+            ("latitudes", np.deg2rad(rng.uniform(-90.0, 90.0, 2 * n))),
+            ("small", rng.uniform(-0.2, 0.2, n)),
+            ("next to pi/2", (np.pi / 2 + rng.uniform(-0.3, 0.3, n)) * rng.choice([-1.0, 1.0], n)),
+            ("tiny", rng.uniform(-1.0, 1.0, n // 4) * 2.0 ** rng.integers(-60, -2, n // 4)),
+            ("edges", np.array([0.0, -0.0, 0.126, -0.126, 0.12599999, 0.855469, 0.8554687, 0.8554686903953552, lim, -lim,
+                                1.5707963267948966, -1.5707963267948966, 1.5707963267948968, 2.0 ** -27, 2.0 ** -26,
+                                1e-300, np.deg2rad(89.999), np.deg2rad(-89.999)]))]
+    return [(name, np.ascontiguousarray(x, dtype=np.float64)) for name, x in sets]

@@ -104,6 +104,9 @@ def _seeds():
     span = os.environ.get("MPTRAC_FUZZ_SEEDS")
     if span:
         a, b = (int(x) for x in span.split(":"))
+        only = os.environ.get("MPTRAC_FUZZ_ONLY")       # e.g. turb_pbl_scheme: the seeds whose draw sets that parameter
+        if only:
+            return [s for s in range(a, b) if draw(s)[0].get(only)]
         return range(a, b)
     return range(48)
 

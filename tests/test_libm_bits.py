@@ -38,7 +38,7 @@ def lib():
         cmd.insert(1, "-mfma")
     subprocess.check_call(cmd)
     L = C.CDLL(so)
-    for f in (L.cmp_exp, L.cmp_log, L.cmp_pow):
+    for f in (L.cmp_exp, L.cmp_log, L.cmp_pow, L.cmp_cos, L.cmp_sin):
         f.restype = C.c_size_t
     return L
 
@@ -85,6 +85,19 @@ def test_restated_exp_log_pow_have_the_librarys_bits(lib):
     assert total > 1e8
 
 
+def test_restated_cos_sin_have_the_librarys_bits(lib):
+    """glibc's cos / sin (s_sin.c) inside |x| < 2.426 -- DX2DEG's cos(latitude) of the reference-rounding build and
+    ZETA's sin: the restatement of mphip_libm.h against the running library, 3 x 10^7 arguments each."""
+    rng = np.random.default_rng(20261001)
+    total = 0
+    for name, x in libm_args.sincos_sets(rng, 4_000_000):
+        for fn in ("cos", "sin"):
+            bad, where = _run(lib, fn, x)
+            assert bad == 0, (fn, name, bad, where)
+        total += len(x)
+    assert total > 2.5e7
+
+
 def test_the_check_has_teeth(lib):
     """The same comparison against arguments shifted by one ulp finds differences -- the counters do count."""
     rng = np.random.default_rng(3)
@@ -102,7 +115,8 @@ def test_polynomial_literals_of_the_header_are_the_librarys(lib):
     tab = open(os.path.join(CSRC, "mphip_libmtab.h")).read()
     hexf = r"-?0x[01]\.[0-9a-f]+p[+-]?\d+"
     literals = {float.fromhex(m) for m in re.findall(hexf, text)}
-    for array in ("mphip_libm_exp_k", "mphip_libm_ln2", "mphip_libm_log_a", "mphip_libm_log_b", "mphip_libm_pow_a"):
+    for array in ("mphip_libm_exp_k", "mphip_libm_ln2", "mphip_libm_log_a", "mphip_libm_log_b", "mphip_libm_pow_a",
+                  "mphip_libm_sincos_k"):
         body = re.search(array + r"\[\d+\] = \{(.*?)\};", tab, re.S).group(1)
         values = [float.fromhex(m) for m in re.findall(hexf, body)]
         assert values, array
@@ -132,3 +146,4 @@ def test_committed_tables_are_the_running_librarys():
     pow_tab = [float.fromhex(v) for v in init("MPHIP_LIBM_POW_TAB_INIT")]
     lib_pow = found["pow"]["tab"]
     assert pow_tab == [lib_pow[4 * i + k] for i in range(128) for k in (0, 2, 3)]
+    assert [float.fromhex(v) for v in init("MPHIP_LIBM_SINCOS_TAB_INIT")] == found["sincos"]["tab"]

@@ -10,6 +10,13 @@ log / pow were picked by the authors' search so that k ln2_hi + log c is exact),
 this image ships, located by their leading constants and checked for internal consistency.  Nothing else is taken
 from the library; the polynomial coefficients sit in the same data blocks and are read with them.
 
+sin / cos (used by the reference-rounding build only: DX2DEG's cos(latitude), ZETA's sin) are glibc's own
+sysdeps/ieee754/dbl-64/s_sin.c (IBM Accurate Mathematical Library, LGPL; algorithm published there and in
+"usncs.h" / "sincostab.c"): for |x| < 2.426 a 440-entry table {sin, its tail, cos, its tail} at k / 128 and two short
+polynomials.  The table is read from the library like the others (located by its first entry {0, 0, 1, 0} and checked
+against sin / cos of k / 128); the eleven polynomial constants, pi/2 in two parts and the shifter 1.5 x 2^45 are the
+published ones, and each is checked to be present in the library's read-only data.
+
 Layouts (the published headers math_config.h / glibc sysdeps/ieee754/dbl-64/math_config.h):
   exp_data      { invln2N, shift, negln2hiN, negln2loN, poly[4], exp2_shift, exp2_poly[5], uint64 tab[2 * 128] }
   log_data      { ln2hi, ln2lo, poly[5], poly1[11], {invc, logc} tab[128], {chi, clo} tab2[128] }
@@ -94,11 +101,34 @@ def locate(sections):
                     found["pow"] = dict(addr=addr + off, poly=poly, tab=tab)
             except struct.error:
                 pass
-    missing = {"exp", "log", "pow"} - set(found)
+    sig_sincos = struct.pack("<4d", 0.0, 0.0, 1.0, 0.0)
+    for buf, addr in sections:
+        for off in find_all(buf, sig_sincos):
+            try:
+                tab = doubles(buf, off, 440)
+            except struct.error:
+                continue
+            if all(abs(tab[4 * k] - math.sin(k / 128)) < 1e-15 and abs(tab[4 * k + 2] - math.cos(k / 128)) < 1e-15
+                   and abs(tab[4 * k + 1]) < 2e-16 and abs(tab[4 * k + 3]) < 2e-16 for k in range(110)) and "sincos" not in found:
+                found["sincos"] = dict(addr=addr + off, tab=tab)
+    if "sincos" in found:
+        every = b"".join(buf for buf, _ in sections)
+        for name, v in SINCOS_K:
+            if not find_all(every, struct.pack("<d", float.fromhex(v))):
+                raise SystemExit("sin / cos constant %s = %s is not in the library's read-only data" % (name, v))
+    missing = {"exp", "log", "pow", "sincos"} - set(found)
     if missing:
         raise SystemExit("not found in the library's read-only data: %s" % sorted(missing))
     found["ln2"] = (ln2hi, ln2lo)
     return found
+
+
+# s_sin.c / usncs.h: sn3, sn5, cs2, cs4, cs6 (table path), s1..s5 (Taylor path), hp0 + hp1 = pi / 2, big = 1.5 x 2^45, 0.126
+SINCOS_K = [("sn3", "-0x1.5555555555515p-3"), ("sn5", "0x1.11110e829872fp-7"), ("cs2", "0x1.0000000000000p-1"),
+            ("cs4", "-0x1.5555555555535p-5"), ("cs6", "0x1.6c16bedd9e239p-10"), ("s1", "-0x1.5555555555555p-3"),
+            ("s2", "0x1.1111111110ecep-7"), ("s3", "-0x1.a01a019db08b8p-13"), ("s4", "0x1.71de27b9a7ed9p-19"),
+            ("s5", "-0x1.addffc2fcdf59p-26"), ("hp0", "0x1.921fb54442d18p+0"), ("hp1", "0x1.1a62633145c07p-54"),
+            ("big", "0x1.8000000000000p+45"), ("taylor_below", "0x1.020c49ba5e354p-3")]
 
 
 def hexd(v):
@@ -138,12 +168,20 @@ def main():
         w("/* pow: {invc, logc, logctail} x 128 (the library's unused pad member dropped) */\n")
         w("#define MPHIP_LIBM_POW_TAB_INIT \\\n")
         w(", \\\n".join("  %s, %s, %s" % (hexd(pw["tab"][4 * i]), hexd(pw["tab"][4 * i + 2]), hexd(pw["tab"][4 * i + 3])) for i in range(N)) + "\n\n")
+        sc = f["sincos"]
+        w("/* sin / cos: sn3, sn5, cs2, cs4, cs6, s1..s5, hp0, hp1, big, 0.126 */\n")
+        w("static const double mphip_libm_sincos_k[%d] = {\n  %s\n};\n" % (len(SINCOS_K), ",\n  ".join(v for _, v in SINCOS_K)))
+        w("/* sin / cos: {sin, tail, cos, tail} of k / 128, k = 0 .. 109 */\n")
+        w("#define MPHIP_LIBM_SINCOS_TAB_INIT \\\n")
+        w(", \\\n".join("  %s, %s, %s, %s" % tuple(hexd(v) for v in sc["tab"][4 * k:4 * k + 4]) for k in range(110)) + "\n\n")
         w("#ifndef __HIPCC__\n")
         w("static const double mphip_libm_log_tab[2 * MPHIP_LIBM_N] = { MPHIP_LIBM_LOG_TAB_INIT };\n")
         w("static const uint64_t mphip_libm_exp_tab[2 * MPHIP_LIBM_N] = { MPHIP_LIBM_EXP_TAB_INIT };\n")
         w("static const double mphip_libm_pow_tab[3 * MPHIP_LIBM_N] = { MPHIP_LIBM_POW_TAB_INIT };\n")
+        w("static const double mphip_libm_sincos_tab[440] = { MPHIP_LIBM_SINCOS_TAB_INIT };\n")
         w("#endif\n\n#endif\n")
-    print("wrote %s: exp_data @%#x, log_data @%#x, pow_log_data @%#x of %s" % (OUT, e["addr"], lg["addr"], pw["addr"], path))
+    print("wrote %s: exp_data @%#x, log_data @%#x, pow_log_data @%#x, sincostab @%#x of %s"
+          % (OUT, e["addr"], lg["addr"], pw["addr"], f["sincos"]["addr"], path))
 
 
 if __name__ == "__main__":
