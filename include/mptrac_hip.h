@@ -184,6 +184,8 @@ typedef int (*mphip_allreduce_fn)(void *device_buffer, size_t count, void *user)
 
 size_t mphip_sizeof_ctl(void);
 size_t mphip_sizeof_met(void);
+/* "mptrac_amd <version> (gfx950)" -- or "(gfx950, reference rounding)" from libmptrac_hip_exact.so, the build of the
+ * same sources and the same ABI whose results are the CPU reference's bits ("Two libraries") */
 const char *mphip_version(void);
 
 /* mptrac_alloc / mptrac_free: device side (acc enter/exit data,

@@ -26,8 +26,9 @@ EXACT_FLAGS = ["-DMPHIP_EXACT_DIV=1", "-ffp-contract=off"]
 # -disable-machine-licm: the machine-level loop-invariant code motion parks the ~60 double constants of
 # the polynomial kernels (sincosf, log, exp, cos) in VGPR pairs for the whole particle loop; without it the
 # fused step kernel needs 144 instead of 207 VGPRs and runs three waves per SIMD without scratch
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
-               "-mllvm", "-disable-machine-licm"]
+# -fvisibility=hidden: the C ABI of include/mptrac_hip.h is what the library exports (mphip_device.hpp)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-munsafe-fp-atomics",
+               "-mllvm", "-disable-machine-licm", "-Wl,--version-script=" + os.path.join(CSRC, "abi.map")]
 
 
 def _hipcc():
@@ -45,7 +46,7 @@ def _stale(target, sources):
 
 
 def hip_sources():
-    src = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
+    src = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h", ".map"))]
     src.append(os.path.join(os.path.dirname(HERE), "include", "mptrac_hip.h"))
     return src
 

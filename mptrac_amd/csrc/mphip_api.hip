@@ -2156,7 +2156,11 @@ size_t mphip_sizeof_met(void) {
 }
 
 const char *mphip_version(void) {
+#if MPHIP_EXACT_DIV
+  return "mptrac_amd 0.1 (gfx950, reference rounding)";   // libmptrac_hip_exact.so (mptrac_amd/build.py:EXACT_FLAGS)
+#else
   return "mptrac_amd 0.1 (gfx950)";
+#endif
 }
 
 int mphip_create(mphip_ctx **out, int device) {

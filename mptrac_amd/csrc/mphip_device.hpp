@@ -12,7 +12,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The libraries are compiled with -fvisibility=hidden: only the C ABI is exported.  (Two builds of these sources can then
+// live in one process -- LD_PRELOAD=libmptrac_hip_exact.so in front of a program linked against libmptrac_hip.so --
+// without the kernels' host stubs of one interposing on the other's.)
+#pragma GCC visibility push(default)
 #include "../../include/mptrac_hip.h"
+#pragma GCC visibility pop
 #include "mphip_libm.h"
 #include "mphip_libmtab.h"
 

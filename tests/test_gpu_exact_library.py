@@ -46,3 +46,26 @@ def test_the_comparison_sees_the_default_builds_last_bits():
     longitudes and pressures, all within 1e-15) -- the check above is not vacuous."""
     r, = _census(["advect"], exact=False)
     assert r["lon"] > 0 and r["p"] > 0 and r["uvwp"] == 0 and r["worst"] < 2e-15
+
+
+def test_the_c_driver_with_the_library_in_front_writes_the_oracles_bits(tmp_path):
+    """trac is linked against libmptrac_hip.so by name; started with the reference-rounding build in front of it
+    (LD_PRELOAD: same ABI -- the switch a C user has) it announces that build, and the particle files of a two-hour run
+    with turbulent diffusion, convection and the boundary-layer closure hold the oracle's positions bit for bit."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hostfiles as hf
+    import test_host_driver as D
+    from mptrac_amd import build as b
+    tmp = str(tmp_path)
+    trac, mets, atm = D._setup(tmp, n=3000, hours=2, pbl=True)
+    res = subprocess.run([trac, os.path.join(tmp, "dirlist"), "trac.ctl", "atm_in"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, LD_PRELOAD=b.build_hip_exact()))
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    assert "reference rounding" in res.stdout + res.stderr
+    snaps = D._oracle(mets, atm, 2, pbl=True)
+    for hour in (0, 1, 2):
+        got = hf.read_atm_bin(os.path.join(tmp, "atm_2022_06_02_%02d_00_00.bin" % hour), len(D.QUANT))
+        ref = snaps[D.T0 + 3600.0 * hour]
+        for k in ("time", "lon", "lat", "p", "q"):
+            assert np.array_equal(got[k], ref[k]), (hour, k, int(np.count_nonzero(got[k] != ref[k])))

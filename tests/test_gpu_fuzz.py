@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import cases
+from mptrac_amd import build as _build
 from mptrac_amd import hip
 from mptrac_amd.ctl import ctl_from_quantities
 from mptrac_amd.synth import FIELDS_METEO_ONLY, FIELDS_ML, synthetic_met, synthetic_particles
@@ -192,6 +193,12 @@ def test_random_module_combination(seed):
     worst = {k: cases.rel_err(g[k], r[k]) for k in ("lon", "lat", "p")}
     err, row = cases.q_rows_err(o.ctl, g["q"], r["q"])      # every quantity row on its own scale
     worst[names[row] if len(names) else "q"] = err
+    if _build.exact_requested():
+        # MPTRAC_AMD_EXACT=1, the reference-rounding build: positions and perturbations are the oracle's bits; the
+        # quantities too, but for sums whose order the device does not fix (module_mixing's atomic cell sums)
+        bits = {k: int(np.count_nonzero(g[k] != r[k])) for k in ("lon", "lat", "p", "uvwp")}
+        if any(bits.values()) or max(worst.values()) > 1e-13:
+            pytest.fail(f"seed {seed} (reference-rounding build): values that are not the oracle's bits {bits}, {worst}; {ctl}")
     if max(worst.values()) > 1e-10:
         pytest.fail(f"seed {seed}: {worst} (bar 1e-10); {_first_divergence(seed)}; {ctl}")
     assert cases.rel_err(g["uvwp"], r["uvwp"]) <= 1e-6
