@@ -484,6 +484,9 @@ def main():
                 fp64_frac = prof.get("_fp64_valu_frac", {}).get(args.workload)
         if args.particles:      # the committed PMC profile belongs to the workload's own particle count
             traffic = valu_busy = fp64_frac = None
+        other_library = os.path.basename(hip.lib_path()) != "libmptrac_hip.so"
+        if other_library:       # ... and to the default build (MPTRAC_AMD_EXACT=1: the reference-rounding build; MPHIP_LIB)
+            traffic = valu_busy = fp64_frac = None
         out = {
             "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -501,6 +504,9 @@ def main():
                                      if args.workload == "C5" else args.workload)),
                        "particles_per_gpu": n_local, "particles_total": n_total,
                        **({"particles_override": True} if args.particles else {}),
+                       # libmptrac_hip.so unless another build was asked for; the reference-rounding build
+                       # (MPTRAC_AMD_EXACT=1: the CPU reference's bits) measured beside it: profiles/r06_ab_exact_library.txt
+                       "library": os.path.basename(hip.lib_path()),
                        "grid": [met0.nx, met0.ny, met0.np], "dt_mod": dt,
                        "parallelism": f"index-range shards x{world}, replicated met, grid-output all-reduce",
                        "reduction": reduction, "rccl_ranks": rccl_ranks,

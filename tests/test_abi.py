@@ -27,6 +27,26 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/mptrac_hip.h but not exported"
 
 
+def test_both_builds_export_the_c_abi_and_nothing_else():
+    """libmptrac_hip.so and libmptrac_hip_exact.so (the reference-rounding build, mptrac_amd/build.py): the same dynamic
+    symbols -- every declaration of the header, and nothing beside mphip_* (csrc/abi.map: two builds in one process,
+    LD_PRELOAD in front of the C driver, must not interpose on each other's kernel handles)."""
+    import subprocess
+    from mptrac_amd import build as b
+    b.build_hip_both()
+    exported = []
+    for lib in (b.HIP_LIB, b.EXACT_LIB):
+        out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+        names = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+        assert names and all(n.startswith("mphip_") for n in names), [n for n in names if not n.startswith("mphip_")][:5]
+        assert set(declared_symbols()) <= set(names)
+        exported.append(names)
+    assert exported[0] == exported[1]
+    L = C.CDLL(b.EXACT_LIB)
+    L.mphip_version.restype = C.c_char_p
+    assert b"reference rounding" in L.mphip_version() and b"reference rounding" not in hip.load().mphip_version()
+
+
 def test_struct_layouts_match_the_python_mirrors():
     L = hip.load()
     assert L.mphip_sizeof_ctl() == C.sizeof(hip.MphipCtl)
@@ -142,7 +162,9 @@ def test_async_load_check_sees_a_register_touched_before_its_wait():
 def test_built_library_touches_no_register_before_its_load_was_waited_for():
     """csrc/mphip_device.hpp issues the corner gathers as inline assembly and waits for them in a later statement;
     the machine code of the library that ships must not touch those registers in between."""
+    from mptrac_amd import build as b
     from mptrac_amd import check_async_loads as chk
-    hazards, kernels, nloads = chk.check(hip.load(build=False)._name)
-    assert kernels > 50 and nloads > 1000
-    assert hazards == [], hazards[:3]
+    for lib in (hip.load(build=False)._name, b.build_hip_exact()):      # both builds ship
+        hazards, kernels, nloads = chk.check(lib)
+        assert kernels > 50 and nloads > 1000
+        assert hazards == [], (lib, hazards[:3])
