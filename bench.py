@@ -556,6 +556,9 @@ def main():
         dropin = os.path.join(ROOT, "profiles", "trac_dropin.json")
         if world == 1 and args.workload == "C3" and not args.particles and os.path.exists(dropin):
             out["dropin_trac"] = json.load(open(dropin))      # (a recorded measurement of the C driver at this size, labelled as such)
+        exact = os.path.join(ROOT, "profiles", "exact_library.json")
+        if world == 1 and args.workload == "C3" and not args.particles and not other_library and os.path.exists(exact):
+            out["reference_rounding_build"] = json.load(open(exact))      # (the second library of the tree; recorded, labelled as such)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, ctl, clim, met0, met1, atm,
                                                min(args.cpu_sample, n_local), args.cpu_steps)
