@@ -146,6 +146,9 @@ PARITY_PINS = {
         "module_diff_turb vertical branch", "module_convection", "module_sedi inside a run", "module_mixing",
         "module_wet_depo", "module_dry_depo", "model-level advection (intpol_met_4d_zeta)", "module_diff_pbl",
         "module_isosurf", "module_bound_cond", "module_sort tie order (stable by index; GSL's is unspecified)"],
+    # (no reference-held golden can be generated here; every entry of restatement_only but the sort's tie order is stated
+    # a second time in numpy from the reference's text and agrees with the oracle to 1e-13)
+    "second_opinion": "tests/refmodules.py + tests/test_oracle_second_opinion.py",
 }
 
 

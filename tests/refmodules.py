@@ -9,6 +9,11 @@ from the text of the reference (src/mptrac.c, src/mptrac.h; line ranges at each 
   module_sedi + sedi()                                         mptrac.c:5869-5882, 12506-12535
   module_mixing + module_mixing_help                           mptrac.c:5169-5347
   module_wet_depo, module_dry_depo                             mptrac.c:6155-6290, 4738-4797
+  module_diff_pbl (TURB_PBL_SCHEME 1: Hanna's closure)         mptrac.c:4343-4584
+  module_advect on model levels (zeta / eta), intpol_met_4d_zeta, locate_vert / locate_irr_float
+                                                               mptrac.c:3681-3757, 2808-2981, 3525-3594
+  module_isosurf_init / module_isosurf (ISOSURF 1-4)           mptrac.c:4886-5005
+  module_bound_cond (region, surface layer, mass / vmr / age)  mptrac.c:3789-3881
 
 Vectorised over the particles (one numpy array per scalar of the C loops), same operation order, IEEE doubles;
 the float arrays of met_t are widened where C widens them.  The random numbers of the stochastic modules are an input
@@ -23,6 +28,15 @@ RA = 1e3 * RI / MA
 M_AIR_MOLECULE = 4.8096e-26
 T_REF, WD_T_LIQUID, WD_T_ICE, WD_T_LIQUID_BC = 298.15, 273.15, 238.15, 270.0
 SO2_K1_REF, SO2_K1_TEMP, SO2_K2_REF, SO2_K2_TEMP = 1.23e-2, 2.01e3, 6e-8, 1.12e3
+CPD, KARMAN, KAPPA, EPS = 1003.5, 0.40, 0.286, 18.01528 / MA
+
+
+def TVIRT(t, h2o):             # mptrac.h:2199
+    return t * (1.0 + (1.0 - EPS) * np.maximum(h2o, 0.1e-6))
+
+
+def RHO(p, t):                 # mptrac.h:1961
+    return 100.0 * p / (RA * t)
 
 
 def Z(p):                      # mptrac.h:2243
@@ -75,6 +89,97 @@ def locate_reg(xx, x):
     with np.errstate(invalid="ignore"):
         i = np.trunc((x - xx[0]) / (xx[1] - xx[0]))
     return np.clip(np.nan_to_num(i, nan=0.0), 0, n - 2).astype(np.int64)
+
+
+def locate_irr_float(cols, x, ig):
+    """mptrac.c:3525-3555 for one float column per particle (cols[n][np]): the guess ig if it brackets x, else the
+    bisection as written"""
+    n, npts = cols.shape
+    rows = np.arange(n)
+    a, b = cols[rows, ig], cols[rows, ig + 1]
+    guessed = ((a <= x) & (x < b)) | ((a >= x) & (x > b))
+    mid = (npts - 1) >> 1
+    asc = cols[:, mid] < cols[:, mid + 1]
+    ilo = np.zeros(n, dtype=np.int64)
+    ihi = np.full(n, npts - 1, dtype=np.int64)
+    while True:
+        active = ihi > ilo + 1
+        if not active.any():
+            break
+        i = (ihi + ilo) >> 1
+        v = cols[rows, i]
+        up = np.where(asc, v > x, v <= x)
+        ihi = np.where(active & up, i, ihi)
+        ilo = np.where(active & ~up, i, ilo)
+    return np.where(guessed, ig, ilo)
+
+
+class Weights4:
+    """ci[3] / cw[4] of intpol_met_4d_zeta with init = 1 (mptrac.c:2824-2943); h0 / h1: the height fields
+    (zetal or pl) of the two snapshots, float [nx][ny][npl]"""
+
+    def __init__(self, met0, met1, h0, h1, ts, height, lon, lat):
+        lon2 = FMOD(lon, 360.0)
+        lon2 = np.where(lon2 < met0.lon[0], lon2 + 360.0, np.where(lon2 > met0.lon[-1], lon2 - 360.0, lon2))
+        lo, hi = (met0.lat[0], met0.lat[-1]) if met0.lat[0] < met0.lat[-1] else (met0.lat[-1], met0.lat[0])
+        lat2 = np.minimum(np.maximum(lat, lo), hi)
+        ix, iy = locate_reg(met0.lon, lon2), locate_irr(met0.lat, lat2)
+        n = len(ix)
+        ind = []
+        for h in (h0, h1):                          # locate_vert: each column starts from the one before
+            g = np.zeros(n, dtype=np.int64)
+            for dx, dy in ((0, 0), (1, 0), (0, 1), (1, 1)):
+                g = locate_irr_float(h[ix + dx, iy + dy, :], height, g)
+                ind.append(g)
+        iz, kmax = np.minimum.reduce(ind), np.maximum.reduce(ind)
+        wt = (ts - met0.time) / (met1.time - met0.time)
+        wx = (lon2 - met0.lon[ix]) / (met0.lon[ix + 1] - met0.lon[ix])
+        wy = (lat2 - met0.lat[iy]) / (met0.lat[iy + 1] - met0.lat[iy])
+
+        def level(k):      # time, then latitude, then longitude (the float difference of the snapshots first)
+            def corner(dx, dy):
+                a0, a1 = h0[ix + dx, iy + dy, k], h1[ix + dx, iy + dy, k]
+                return wt * (a1 - a0).astype(np.float64) + a0.astype(np.float64)
+            h00, h01, h10, h11 = corner(0, 0), corner(0, 1), corner(1, 0), corner(1, 1)
+            lo_ = wy * (h01 - h00) + h00
+            hi_ = wy * (h11 - h10) + h10
+            return wx * (hi_ - lo_) + lo_
+
+        bot, top = level(iz), level(iz + 1)
+        falling = h0[0, 0, 0] > h0[0, 0, 1]
+        rising = h0[0, 0, 0] < h0[0, 0, 1]
+        while True:
+            if falling:
+                go = ((bot <= height) | (top > height)) & (bot >= height) & (iz < kmax)
+            elif rising:
+                go = ((bot >= height) | (top < height)) & (bot <= height) & (iz < kmax)
+            else:
+                go = np.zeros(n, dtype=bool)
+            if not go.any():
+                break
+            iz = np.where(go, iz + 1, iz)
+            nxt = level(iz + 1)
+            bot = np.where(go, top, bot)
+            top = np.where(go, nxt, top)
+        with np.errstate(all="ignore"):
+            wz = (height - bot) / (top - bot)
+        self.ix, self.iy, self.iz, self.wx, self.wy, self.wz, self.wt = ix, iy, iz, wx, wy, wz, wt
+        self.walked = int(np.count_nonzero(iz > np.minimum.reduce(ind)))      # (particles whose level search left the lowest column index)
+
+
+def value_4d(a0, a1, w):
+    """value part of intpol_met_4d_zeta (mptrac.c:2945-2980): time, longitude, latitude, vertical"""
+    def corner(dx, dy, dz):
+        x0, x1 = a0[w.ix + dx, w.iy + dy, w.iz + dz], a1[w.ix + dx, w.iy + dy, w.iz + dz]
+        return w.wt * (x1 - x0).astype(np.float64) + x0.astype(np.float64)
+    c = {(dx, dy, dz): corner(dx, dy, dz) for dx in (0, 1) for dy in (0, 1) for dz in (0, 1)}
+    a00 = w.wx * (c[1, 0, 0] - c[0, 0, 0]) + c[0, 0, 0]
+    a10 = w.wx * (c[1, 1, 0] - c[0, 1, 0]) + c[0, 1, 0]
+    a01 = w.wx * (c[1, 0, 1] - c[0, 0, 1]) + c[0, 0, 1]
+    a11 = w.wx * (c[1, 1, 1] - c[0, 1, 1]) + c[0, 1, 1]
+    aux0 = w.wy * (a10 - a00) + a00
+    aux1 = w.wy * (a11 - a01) + a01
+    return w.wz * (aux1 - aux0) + aux0
 
 
 class Weights:
@@ -205,6 +310,39 @@ class Ref:
         new_lon = lon + DX2DEG(dt * um / 1000.0, x1 if n_nodes == 2 else lat)
         return time + dt, new_lon, lat + DY2DEG(dt * vm / 1000.0), p + dt * wm
 
+    # -- module_advect, zeta / eta branch (mptrac.c:3681-3757) ---------------------------------------------------------
+    def advect_ml(self, time, lon, lat, p, dt):
+        """Returns (time, lon, lat, p, zeta): pressure -> vertical coordinate, the integrator in that coordinate, and back"""
+        f0, f1 = self.m0.f3, self.m1.f3
+        n_nodes = self.c.advect
+        zeta = value_4d(f0["zetal"], f1["zetal"], Weights4(self.m0, self.m1, f0["pl"], f1["pl"], time, p, lon, lat))
+        u, v, wd = [None] * 4, [None] * 4, [None] * 4
+        um = vm = wm = 0.0
+        x1 = lat
+        for i in range(n_nodes):
+            if i == 0:
+                dts, x0, x1, x2 = 0.0 * dt, lon, lat, zeta
+            else:
+                dts = (1.0 if i == 3 else 0.5) * dt
+                x0 = lon + DX2DEG(dts * u[i - 1] / 1000.0, lat)
+                x1 = lat + DY2DEG(dts * v[i - 1] / 1000.0)
+                x2 = zeta + dts * wd[i - 1]
+            w4 = Weights4(self.m0, self.m1, f0["zetal"], f1["zetal"], time + dts, x2, x0, x1)
+            self.ml_walked = getattr(self, "ml_walked", 0) + w4.walked
+            u[i], v[i], wd[i] = (value_4d(f0[k], f1[k], w4) for k in ("ul", "vl", "zeta_dotl"))
+            k = 1.0
+            if n_nodes == 2:
+                k = 0.0 if i == 0 else 1.0
+            elif n_nodes == 4:
+                k = 1.0 / 6.0 if i in (0, 3) else 2.0 / 6.0
+            um, vm, wm = um + k * u[i], vm + k * v[i], wm + k * wd[i]
+        new_time = time + dt
+        new_lon = lon + DX2DEG(dt * um / 1000.0, x1 if n_nodes == 2 else lat)
+        new_lat = lat + DY2DEG(dt * vm / 1000.0)
+        new_zeta = zeta + dt * wm
+        w4 = Weights4(self.m0, self.m1, f0["zetal"], f1["zetal"], new_time, new_zeta, new_lon, new_lat)
+        return new_time, new_lon, new_lat, value_4d(f0["pl"], f1["pl"], w4), new_zeta
+
     # -- module_diff_turb (mptrac.c:4588-4734), TURB_PBL_SCHEME 0 ------------------------------------------------
     def diff_turb(self, time, lon, lat, p, dt, rs):
         c = self.c
@@ -243,6 +381,161 @@ class Ref:
                 ptrial = np.where(over, ps * ps / ptrial, np.where(under, ptop * ptop / ptrial, ptrial))
         new_p = np.where(Kz > 0, np.maximum(ptop, np.minimum(ps, ptrial)), p)
         return new_lon, new_lat, new_p
+
+    # -- module_diff_pbl (mptrac.c:4343-4584), TURB_PBL_SCHEME 1 ------------------------------------------------------
+    def diff_pbl(self, time, lon, lat, p, dt, uvwp, rs):
+        """Returns (lon, lat, p, uvwp [float32, n x 3], acted): every particle evaluated through all three stability
+        classes, the results selected as the reference's if / else ladder and its `continue`s select them."""
+        with np.errstate(all="ignore"):
+            w2 = Weights(self.m0, None, lon, lat, three_d=False)
+            pbl = self.time_2d("pbl", time, lon, lat, w2)
+            ps = self.time_2d("ps", time, lon, lat, w2)
+            act = ~(p < pbl) & (ps > 0.0) & (pbl > 0.0) & (ps > pbl)
+            pc = np.minimum(p, ps)
+            zs = Z(ps)
+            z_raw = 1e3 * (Z(pc) - zs)
+            zi = 1e3 * (Z(pbl) - zs)
+            act &= zi > 1.0
+            z = np.where(z_raw < 0.0, 0.0, np.where(z_raw > zi, zi, z_raw))                  # CLAMP
+            q = z / zi
+            zeta = np.where(q < 1e-6, 1e-6, np.where(q > 1.0 - 1e-6, 1.0 - 1e-6, q))
+            z_m = np.maximum(z, 1.0)
+            ess = self.time_2d("ess", time, lon, lat, w2)
+            nss = self.time_2d("nss", time, lon, lat, w2)
+            w3 = Weights(self.m0, pc, lon, lat)                                         # INTPOL_3D(t, 1) at the clamped pressure
+            t = self.time_3d("t", time, pc, lon, lat, w3)
+            h2o = self.time_3d("h2o", time, pc, lon, lat, w3)
+            tv = TVIRT(t, h2o)
+            thetav = TVIRT(t * np.power(1000.0 / pc, KAPPA), np.maximum(h2o, 0.1e-6))      # THETAVIRT
+            rho = RHO(pc, tv)
+            tau = np.sqrt(ess * ess + nss * nss)
+            act &= rho > 0.0
+            ust = np.maximum(1e-4, np.sqrt(np.maximum(tau / rho, 0.0)))
+            shf = self.time_2d("shf", time, lon, lat, w2)
+            ol = np.where(np.abs(shf) > 1e-6, thetav * rho * CPD * (ust * ust) * ust / (KARMAN * G0 * shf), 1e12)
+            third = 1.0 / 3.0
+
+            # neutral
+            corr = z_m / ust
+            sigw0 = 1.3 * ust * np.exp(-2e-4 * corr)
+            n_su = np.maximum(2.0 * ust * np.exp(-3e-4 * corr), 1e-5)
+            n_sv = n_sw = np.maximum(sigw0, 1e-5)
+            n_ds = -2e-4 * sigw0 / ust
+            n_tu = 0.5 * z_m / n_sw / (1.0 + 1.5e-3 * corr)
+
+            # unstable
+            wstar = np.power(np.maximum(-G0 / thetav * shf / (rho * CPD) * zi, 0.0), third)
+            u_su = np.maximum(ust * np.power(np.maximum(12.0 - 0.5 * zi / ol, 0.0), third), 1e-6)
+            arg = np.maximum(3.0 * zeta - ol / zi, 1e-12)
+            pa, pam = np.power(arg, third), np.power(arg, -third)
+            a_sw, a_d2 = 0.96 * wstar * pa, 1.8432 * (wstar * wstar) / zi * pam               # zeta < 0.03
+            s1, s2 = 0.96 * pa, 0.763 * np.power(zeta, 0.175)                                # 0.03 <= zeta < 0.4
+            b_sw = np.where(s1 < s2, wstar * s1, wstar * s2)
+            b_d2 = np.where(s1 < s2, a_d2, 0.203759 * (wstar * wstar) / zi * np.power(zeta, -0.65))
+            c_sw = 0.722 * wstar * np.power(1.0 - zeta, 0.207)                               # 0.4 <= zeta < 0.96
+            c_d2 = -0.215812 * (wstar * wstar) / zi * np.power(1.0 - zeta, -0.586)
+            u_sw = np.where(zeta < 0.03, a_sw, np.where(zeta < 0.4, b_sw, np.where(zeta < 0.96, c_sw, 0.37 * wstar)))
+            u_d2 = np.where(zeta < 0.03, a_d2, np.where(zeta < 0.4, b_d2, np.where(zeta < 0.96, c_d2, 0.0)))
+            u_sw = np.maximum(u_sw, 1e-6)
+            u_ds = np.where(u_sw > 1e-12, 0.5 * u_d2 / u_sw, 0.0)
+            u_tu = 0.15 * zi / np.maximum(u_su, 1e-12)
+            denom = 0.55 - 0.38 * np.abs(z_m / ol)
+            u_tw = np.where(z_m < np.abs(ol), 0.1 * z_m / (u_sw * np.maximum(denom, 0.05)),
+                            np.where(zeta < 0.1, 0.59 * z_m / u_sw, 0.15 * zi / u_sw * (1.0 - np.exp(-5.0 * zeta))))
+
+            # stable
+            s_su = np.maximum(2.0 * ust * (1.0 - zeta), 1e-6)
+            s_sv = s_sw = np.maximum(1.3 * ust * (1.0 - zeta), 1e-6)
+            s_ds = -1.3 * ust / zi
+            s_tu = 0.15 * zi / s_su * np.sqrt(zeta)
+            s_tv = 0.467 * s_tu
+            s_tw = 0.1 * zi / s_sw * np.power(zeta, 0.8)
+
+            neutral, unstable = zi / np.abs(ol) < 1.0, ol < 0.0
+            pick = lambda n, u, st: np.where(neutral, n, np.where(unstable, u, st))      # noqa: E731
+            sig_u, sig_v, sig_w = pick(n_su, u_su, s_su), pick(n_sv, u_su, s_sv), pick(n_sw, u_sw, s_sw)
+            dsigw_dz = pick(n_ds, u_ds, s_ds)
+            tau_u = np.maximum(pick(n_tu, u_tu, s_tu), 10.0)
+            tau_v = np.maximum(pick(n_tu, u_tu, s_tv), 10.0)
+            tau_w = np.maximum(pick(n_tu, u_tw, s_tw), 30.0)
+            act &= (sig_u > 0.0) & (sig_v > 0.0) & (sig_w > 0.0) & (tau_u > 0.0) & (tau_v > 0.0) & (tau_w > 0.0)
+
+            dt_abs = np.abs(dt)
+            up, vp, wp = (uvwp[:, k].astype(np.float64) for k in range(3))
+            ru = np.exp(-dt_abs / tau_u)
+            rv = np.exp(-dt_abs / tau_v)
+            rw = np.exp(-dt_abs / tau_w)
+            ru2, rv2, rw2 = (np.sqrt(np.maximum(0.0, 1.0 - r * r)) for r in (ru, rv, rw))
+            new_u = (up * ru + sig_u * ru2 * rs[0::3]).astype(np.float32)
+            new_v = (vp * rv + sig_v * rv2 * rs[1::3]).astype(np.float32)
+            rhoaux = -1.0 / (1e3 * H0)
+            new_w = (wp * rw + sig_w * rw2 * rs[2::3]
+                     + tau_w * (1.0 - rw) * (2.0 * sig_w * dsigw_dz + rhoaux * (sig_w * sig_w))).astype(np.float32)
+            new_lon = lon + DX2DEG(new_u.astype(np.float64) * dt / 1000.0, lat)
+            new_lat = lat + DY2DEG(new_v.astype(np.float64) * dt / 1000.0)
+            znew = z + new_w.astype(np.float64) * dt
+            for _ in range(64):        # (the reference's while loop; the cases here need a handful of reflections)
+                below = act & (znew < 0.0)
+                znew = np.where(below, -znew, znew)
+                new_w = np.where(below, -new_w, new_w)
+                above = act & (znew > zi)
+                znew = np.where(above, 2.0 * zi - znew, znew)
+                new_w = np.where(above, -new_w, new_w)
+            assert not np.any(act & ((znew < 0.0) | (znew > zi)))
+            pn = P0 * np.exp(-(zs + znew / 1000.0) / H0)
+            pn = np.where(pn < pbl, pbl, np.where(pn > ps, ps, pn))
+        self.pbl_classes = {"neutral": int(np.count_nonzero(act & neutral)), "unstable": int(np.count_nonzero(act & ~neutral & unstable)),
+                            "stable": int(np.count_nonzero(act & ~neutral & ~unstable)),
+                            "free_convection_profile": int(np.count_nonzero(act & ~neutral & unstable & (zeta < 0.4) & ((zeta < 0.03) | (s1 < s2))))}
+        out = uvwp.copy()
+        for k, v in enumerate((new_u, new_v, new_w)):
+            out[:, k] = np.where(act, v, uvwp[:, k])
+        return np.where(act, new_lon, lon), np.where(act, new_lat, lat), np.where(act, pn, p), out, act
+
+    # -- module_isosurf_init / module_isosurf (mptrac.c:4886-5005) ------------------------------------------------------
+    def isosurf_init(self, time, lon, lat, p):
+        mode = self.c.isosurf
+        if mode == 1:
+            return p.copy()
+        t = self.time_3d("t", time, p, lon, lat)
+        return p / t if mode == 2 else t * np.power(1000.0 / p, KAPPA)          # THETA, mptrac.h:2124
+
+    def isosurf(self, time, lon, lat, p, iso_var, balloon=None):
+        mode = self.c.isosurf
+        if mode == 1:
+            return iso_var.copy()
+        if mode in (2, 3):
+            t = self.time_3d("t", time, p, lon, lat)
+            return iso_var * t if mode == 2 else 1000.0 * np.power(iso_var / t, -1.0 / KAPPA)
+        ts, ps = (np.asarray(a, dtype=np.float64) for a in balloon)
+        idx = np.minimum(locate_irr(ts, time), len(ts) - 2)
+        mid = LIN(ts[idx], ps[idx], ts[idx + 1], ps[idx + 1], time)
+        return np.where(time <= ts[0], ps[0], np.where(time >= ts[-1], ps[-1], mid))
+
+    # -- module_bound_cond (mptrac.c:3789-3881): the region test and mass / volume mixing ratio / age of air -----------------
+    def bound_cond(self, time, lon, lat, p):
+        """Returns (inside, mass, vmr, age): the values the module writes where `inside` (None where the control
+        parameters switch a quantity off)"""
+        c = self.c
+        inside = ~((lat < c.bound_lat0) | (lat > c.bound_lat1) | (p > c.bound_p0) | (p < c.bound_p1))
+        if c.bound_dps > 0 or c.bound_dzs > 0 or c.bound_zetas > 0 or c.bound_pbl:
+            w2 = Weights(self.m0, None, lon, lat, three_d=False)
+            ps = self.time_2d("ps", time, lon, lat, w2)
+            if c.bound_dps > 0:
+                inside &= ~(p < ps - c.bound_dps)
+            if c.bound_dzs > 0:
+                inside &= ~(Z(p) > Z(ps) + c.bound_dzs)
+            if c.bound_zetas > 0:
+                t = self.time_3d("t", time, p, lon, lat)
+                with np.errstate(all="ignore"):                                  # ZETA, mptrac.h:2293
+                    zeta = np.where(p / ps <= 0.3, 1.0, np.sin(np.pi / 2.0 * (1.0 - p / ps) / (1.0 - 0.3))) \
+                        * (t * np.power(1000.0 / p, KAPPA))
+                inside &= ~(zeta > c.bound_zetas)
+            if c.bound_pbl:
+                inside &= ~(p < self.time_2d("pbl", time, lon, lat, w2))
+        mass = c.bound_mass + c.bound_mass_trend * time if c.qnt_m >= 0 and c.bound_mass >= 0 else None
+        vmr = c.bound_vmr + c.bound_vmr_trend * time if c.qnt_vmr >= 0 and c.bound_vmr >= 0 else None
+        return inside, mass, vmr, (time.copy() if c.qnt_aoa >= 0 else None)
 
     # -- module_convection (mptrac.c:4102-4171) -----------------------------------------------------------------
     def convection(self, time, lon, lat, p, rs):

@@ -2,7 +2,9 @@
 modules restated a second time, in numpy, from the text of the reference (tests/refmodules.py, not derived from
 oracle/), against the oracle on 1000 particles -- ADVECT 4 with its old-latitude rule (and 2 / 1 through the same
 code), both branches of module_diff_turb incl. the displaced latitude of the vertical probes, module_convection,
-module_sedi, module_mixing, wet and dry deposition.  Bar: 1e-13 relative (numpy's exp / log / pow are not glibc's)."""
+module_sedi, module_mixing, wet and dry deposition, the boundary-layer closure module_diff_pbl (all three stability
+classes), the advection on model levels (zeta / eta: intpol_met_4d_zeta with its level search), module_isosurf and the
+region test of module_bound_cond.  Bar: 1e-13 relative (numpy's exp / log / pow are not glibc's)."""
 import numpy as np
 import pytest
 
@@ -162,3 +164,102 @@ def test_wet_and_dry_deposition(case):
     for k, v in q2.items():
         got = o.q[getattr(o.ctl, "qnt_" + k)]
         assert float(np.max(np.abs(v - got))) <= TOL * _scale(o, k, got), ("dry", k)
+
+
+@pytest.mark.parametrize("case,seed", [("pbl", 4711), ("pbl", 99), ("pbl_meso", 7)])
+def test_boundary_layer_closure(case, seed):
+    """module_diff_pbl (TURB_PBL_SCHEME 1, mptrac.c:4343-4584) appears in no reference test and was "HIP vs oracle only":
+    the numpy statement evaluates every particle through all three stability classes and selects as the reference's
+    ladder does.  Positions to 1e-13; the single-precision perturbations the module stores must be the oracle's bits."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=4000, seed=seed)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    ts = cases.step_times(o.ctl)
+    for t in ts[:3]:                       # a few full steps first: perturbations of every size and sign
+        o.run_timestep(t)
+    o.module("timesteps", ts[3])
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    uv0 = o.uvwp.copy()
+    o.module("diff_pbl")
+    ref = R.Ref(o.ctl, clim, m0, m1)
+    lon, lat, p, uv, act = ref.diff_pbl(*s0, o.dt.copy(), uv0, o.rs[:3 * 4000].copy())
+    assert _rel(lon, o.lon) <= TOL and _rel(lat, o.lat) <= TOL and _rel(p, o.p) <= TOL
+    assert np.array_equal(uv, o.uvwp)
+    assert np.array_equal(act, o.p != s0[3]) or np.count_nonzero(act != (o.p != s0[3])) <= 2      # (a reflected height may land on the old pressure)
+    if case == "pbl":
+        k = ref.pbl_classes
+        assert min(k["neutral"], k["unstable"], k["stable"], k["free_convection_profile"]) > 10, k
+    assert 100 < np.count_nonzero(act) < 4000
+
+
+@pytest.mark.parametrize("case", ["advect_zeta", "advect_zeta_midpoint", "advect_eta"])
+def test_advect_model_levels(case):
+    """module_advect's zeta / eta branch (mptrac.c:3681-3757) with intpol_met_4d_zeta (2808-2981: the eight column
+    searches of locate_vert, the walk to the level pair that brackets the height after the horizontal and time blend, the
+    float difference of the two snapshots) -- no reference test runs it, and it was "HIP vs oracle only"."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=3000, seed=4711)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    ts = cases.step_times(o.ctl)
+    for t in ts[:2]:
+        o.run_timestep(t)
+    o.module("timesteps", ts[2])
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    o.module("advect")
+    ref = R.Ref(o.ctl, clim, m0, m1)
+    time, lon, lat, p, zeta = ref.advect_ml(*s0, o.dt.copy())
+    row = o.ctl.qnt_zeta if o.ctl.advect_vert_coord == 1 else o.ctl.qnt_eta
+    assert np.array_equal(time, o.time)
+    assert _rel(lon, o.lon) <= TOL and _rel(lat, o.lat) <= TOL and _rel(p, o.p) <= TOL and _rel(zeta, o.q[row]) <= TOL
+    assert np.max(np.abs(lon - s0[1])) > 1e-3 and np.max(np.abs(p - s0[3])) > 1e-3
+    assert ref.ml_walked > 0          # some stencils needed the walk beyond the lowest of the eight column indices
+
+
+@pytest.mark.parametrize("case", ["isosurf_p", "isosurf_rho", "isosurf_theta", "isosurf_balloon"])
+def test_isosurface_modes(case):
+    """module_isosurf_init stores pressure / density / potential temperature, module_isosurf puts the particle back on
+    that surface after the movers (mptrac.c:4886-5005); mode 4 follows a balloon's pressure record."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=N, seed=11)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    cases.prepare(o)
+    o.timesteps_init()
+    ts = cases.step_times(o.ctl)
+    o.module("timesteps", ts[1])
+    ref = R.Ref(o.ctl, clim, m0, m1)
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    if o.ctl.isosurf != 4:
+        o.module("isosurf_init")
+        iso = ref.isosurf_init(*s0)
+        assert _rel(iso, o.iso_var) <= TOL
+    else:
+        iso = None
+    o.module("advect")
+    s1 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    o.module("isosurf")
+    p = ref.isosurf(*s1, iso, balloon=cases.BALLOON)
+    assert _rel(p, o.p) <= TOL
+    if o.ctl.isosurf != 1:
+        assert np.max(np.abs(o.p - s0[3])) > 1e-6
+
+
+@pytest.mark.parametrize("case", ["bound", "bound_pbl_zeta"])
+def test_boundary_condition_region_and_values(case):
+    """module_bound_cond (mptrac.c:3789-3881): latitude / pressure box, surface layer by pressure depth, height, zeta and
+    boundary-layer top; mass and volume mixing ratio with their trends, age of air."""
+    ctl, clim, m0, m1, atm = cases.make_case(case, n=N, seed=5)
+    o = B.Oracle(ctl, clim, m0, m1, atm)
+    o.timesteps_init()
+    ts = cases.step_times(o.ctl)
+    o.module("timesteps", ts[1])
+    ref = R.Ref(o.ctl, clim, m0, m1)
+    o.p[::7] = ref.time_2d("ps", o.time, o.lon, o.lat)[::7] - np.linspace(0.0, 60.0, N)[::7]      # some next to the ground
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    before = o.q.copy()
+    o.module("bound_cond")
+    inside, mass, vmr, age = ref.bound_cond(*s0)
+    assert 0 < np.count_nonzero(inside) < N
+    for row, new in ((o.ctl.qnt_m, mass), (o.ctl.qnt_vmr, vmr), (o.ctl.qnt_aoa, age)):
+        if row >= 0 and new is not None:
+            want = np.where(inside, new, before[row])
+            assert np.allclose(o.q[row], want, rtol=1e-15, atol=0.0), row
+            assert np.array_equal(o.q[row] != before[row], inside & (want != before[row]))
