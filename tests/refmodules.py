@@ -296,10 +296,15 @@ class Ref:
                 x1 = lat + DY2DEG(dts * v[i - 1] / 1000.0)
                 x2 = p + dts * w[i - 1]
             tm = time + dts
-            wts = Weights(self.m0, x2, x0, x1)
-            u[i] = self.time_3d("u", tm, x2, x0, x1, wts)
-            v[i] = self.time_3d("v", tm, x2, x0, x1, wts)
-            w[i] = self.time_3d("w", tm, x2, x0, x1, wts)
+            if self.c.advect_vert_coord == 2:      # winds from the model levels, located by their pressure (mptrac.c:3647-3657)
+                f0, f1 = self.m0.f3, self.m1.f3
+                w4 = Weights4(self.m0, self.m1, f0["pl"], f1["pl"], tm, x2, x0, x1)
+                u[i], v[i], w[i] = (value_4d(f0[k], f1[k], w4) for k in ("ul", "vl", "wl"))
+            else:
+                wts = Weights(self.m0, x2, x0, x1)
+                u[i] = self.time_3d("u", tm, x2, x0, x1, wts)
+                v[i] = self.time_3d("v", tm, x2, x0, x1, wts)
+                w[i] = self.time_3d("w", tm, x2, x0, x1, wts)
             k = 1.0
             if n_nodes == 2:
                 k = 0.0 if i == 0 else 1.0

@@ -263,3 +263,16 @@ def test_boundary_condition_region_and_values(case):
             want = np.where(inside, new, before[row])
             assert np.allclose(o.q[row], want, rtol=1e-15, atol=0.0), row
             assert np.array_equal(o.q[row] != before[row], inside & (want != before[row]))
+
+
+@pytest.mark.parametrize("case", ["advect_mlp", "advect_mlp_midpoint"])
+def test_advect_pressure_with_model_level_winds(case):
+    """ADVECT_VERT_COORD 2 (mptrac.c:3647-3657): the pressure-level integrator with u, v, omega from the model levels,
+    located by the level pressures through intpol_met_4d_zeta."""
+    o, ref, _ = _oracle(case)
+    s0 = (o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    o.module("advect")
+    time, lon, lat, p = ref.advect(*s0, o.dt.copy())
+    assert np.array_equal(time, o.time)
+    assert _rel(lon, o.lon) <= TOL and _rel(lat, o.lat) <= TOL and _rel(p, o.p) <= TOL
+    assert np.max(np.abs(lon - s0[1])) > 1e-3
