@@ -10,6 +10,8 @@
  *     ifeq ($(HIP),1)
  *       CFLAGS  += -DMPTRAC_HIP -I$(MPTRAC_AMD)/include
  *       LDFLAGS += -L$(MPTRAC_AMD)/mptrac_amd/lib -lmptrac_hip -Wl,-rpath,$(MPTRAC_AMD)/mptrac_amd/lib
+ *     (-lmptrac_hip_exact instead: the build of the same sources whose results are the CPU build's bits, INTEGRATION.md
+ *     "Two libraries, one ABI")
  *     endif
  *
  * Every member of ctl_t / met_t / clim_t / cache_t / atm_t named here exists in the reference's mptrac.h:
