@@ -2,7 +2,8 @@
 IEEE divisions instead of reciprocal products, the C library's cos / sin, no contraction; mptrac_amd/build.py:EXACT_FLAGS)
 against the oracle: not within a tolerance but BIT FOR BIT -- positions, quantities and the single-precision
 perturbations of the named cases after their 21 steps (10 000 particles each).  The default build trades those last bits
-for 8 % of the step; this one is what a run that must reproduce the CPU build's numbers links.
+for speed (0.80 against 1.15 ms per step on workload C3, DESIGN.md sections 2 and 4); this one is what a run that must
+reproduce the CPU build's numbers links.
 A process loads one of the two libraries, so the comparison runs in a child with MPTRAC_AMD_EXACT=1
 (tools/gpu_bit_census.py)."""
 import json
