@@ -15,11 +15,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 HIP_LIB = os.path.join(LIBDIR, "libmptrac_hip.so")
 # The reference-rounding build: every division of the reference an IEEE division (the default multiplies by reciprocals
-# of grid constants rounded once on the host and uses a rcp + Newton quotient), the C library's square root and cosine
-# calls, and no contraction of a multiply and an add into a fused multiply-add (the reference's default CPU build, gcc
-# -O3 without -march, has none; the fused operations inside exp / log / pow are the C library's own and stay).  What
-# this build computes is the oracle's bits except for the longitude increment's cos(latitude) (the device library's
-# against glibc's: one ulp in 0.1 % of the particles after 20 steps); tools/gpu_bit_census.py, DESIGN.md section 2.
+# of grid constants rounded once on the host and uses a rcp + Newton quotient), the C library's square root, cosine and
+# sine (restated in csrc/mphip_libm.h like exp / log / pow), and no contraction of a multiply and an add into a fused
+# multiply-add (the reference's default CPU build, gcc -O3 without -march, has none; the fused operations inside the
+# library functions are the C library's own and stay).  What this build computes is the oracle's bits: positions,
+# quantities and cache->uvwp (tests/test_gpu_exact_library.py, tools/gpu_bit_census.py).
 EXACT_LIB = os.path.join(LIBDIR, "libmptrac_hip_exact.so")
 EXACT_FLAGS = ["-DMPHIP_EXACT_DIV=1", "-ffp-contract=off"]
 
