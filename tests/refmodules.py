@@ -14,6 +14,8 @@ from the text of the reference (src/mptrac.c, src/mptrac.h; line ranges at each 
                                                                mptrac.c:3681-3757, 2808-2981, 3525-3594
   module_isosurf_init / module_isosurf (ISOSURF 1-4)           mptrac.c:4886-5005
   module_bound_cond (region, surface layer, mass / vmr / age)  mptrac.c:3789-3881
+  module_meteo: the interpolated fields and the derived quantities (humidity macros, theta, zeta, lapse rate ...)
+                                                               mptrac.c:5062-5165, mptrac.h:1278-1316 (the climatologies: tests/refclim.py)
 
 Vectorised over the particles (one numpy array per scalar of the C loops), same operation order, IEEE doubles;
 the float arrays of met_t are widened where C widens them.  The random numbers of the stochastic modules are an input
@@ -541,6 +543,30 @@ class Ref:
         mass = c.bound_mass + c.bound_mass_trend * time if c.qnt_m >= 0 and c.bound_mass >= 0 else None
         vmr = c.bound_vmr + c.bound_vmr_trend * time if c.qnt_vmr >= 0 and c.bound_vmr >= 0 else None
         return inside, mass, vmr, (time.copy() if c.qnt_aoa >= 0 else None)
+
+    # -- module_meteo (mptrac.c:5062-5165): fields and derived quantities, by the reference's quantity names ------------------
+    def meteo(self, time, lon, lat, p):
+        w3 = Weights(self.m0, p, lon, lat)                                       # INTPOL_TIME_ALL: one set of indices and weights
+        f = {k: self.time_3d(k, time, p, lon, lat, w3) for k in ("z", "t", "u", "v", "w", "pv", "h2o", "o3", "lwc", "rwc", "iwc", "swc", "cc")
+             if k in self.m0.f3}
+        f.update({k: self.time_2d(k, time, lon, lat, w3) for k in self.m0.f2})
+        T0, LV = 273.15, 2501000.0
+        t, h2o, u, v = f["t"], f["h2o"], f["u"], f["v"]
+        hh = np.maximum(h2o, 0.1e-6)
+        pw = p * hh / (1.0 + (1.0 - EPS) * hh)                                    # PW, mptrac.h:1859
+        psat = 6.112 * np.exp(17.62 * (t - T0) / (243.12 + t - T0))              # PSAT, 1808
+        psice = 6.112 * np.exp(22.46 * (t - T0) / (272.62 + t - T0))             # PSICE, 1832
+        theta = t * np.power(1000.0 / p, KAPPA)
+        sh = EPS * hh                                                            # SH, 2024
+        a, r = RA * (t * t), sh / (1.0 - sh)                                     # lapse_rate, mptrac.c:3324-3338
+        with np.errstate(all="ignore"):
+            zeta = np.where(p / f["ps"] <= 0.3, 1.0, np.sin(np.pi / 2.0 * (1.0 - p / f["ps"]) / (1.0 - 0.3))) * theta
+            lw = np.log(pw / 6.112)
+        out = dict(f, zg=f.get("z"), p=p, rho=RHO(p, t), vh=np.sqrt(u * u + v * v), vz=-1e3 * H0 / p * f["w"], psat=psat, psice=psice,
+                   pw=pw, sh=sh, rh=pw / psat * 100.0, rhice=pw / psice * 100.0, theta=theta, zeta_d=zeta, tvirt=TVIRT(t, h2o),
+                   lapse=1e3 * G0 * (a + LV * r * t) / (CPD * a + LV * LV * r * EPS),
+                   tdew=T0 + 243.12 * lw / (17.62 - lw), tice=T0 + 272.62 * lw / (22.46 - lw))
+        return out
 
     # -- module_convection (mptrac.c:4102-4171) -----------------------------------------------------------------
     def convection(self, time, lon, lat, p, rs):

@@ -3,8 +3,8 @@ modules restated a second time, in numpy, from the text of the reference (tests/
 oracle/), against the oracle on 1000 particles -- ADVECT 4 with its old-latitude rule (and 2 / 1 through the same
 code), both branches of module_diff_turb incl. the displaced latitude of the vertical probes, module_convection,
 module_sedi, module_mixing, wet and dry deposition, the boundary-layer closure module_diff_pbl (all three stability
-classes), the advection on model levels (zeta / eta: intpol_met_4d_zeta with its level search), module_isosurf and the
-region test of module_bound_cond.  Bar: 1e-13 relative (numpy's exp / log / pow are not glibc's)."""
+classes), the advection on model levels (zeta / eta: intpol_met_4d_zeta with its level search), module_isosurf, the
+region test of module_bound_cond and module_meteo's fields and derived quantities.  Bar: 1e-13 relative (numpy's exp / log / pow are not glibc's)."""
 import numpy as np
 import pytest
 
@@ -276,3 +276,27 @@ def test_advect_pressure_with_model_level_winds(case):
     assert np.array_equal(time, o.time)
     assert _rel(lon, o.lon) <= TOL and _rel(lat, o.lat) <= TOL and _rel(p, o.p) <= TOL
     assert np.max(np.abs(lon - s0[1])) > 1e-3
+
+
+@pytest.mark.parametrize("case", ["meteo", "meteo_gated"])
+def test_meteo_fields_and_derived_quantities(case):
+    """module_meteo (mptrac.c:5062-5165): every interpolated field and every derived quantity the two cases carry -- the
+    humidity macros, potential temperature, the diagnosed zeta, virtual temperature, the moist lapse rate (RA SQR(t):
+    the square first), dew and frost point."""
+    o, ref, _ = _oracle(case)
+    names = cases.CASE_QUANTITIES[case]
+    o.module("meteo")
+    want = ref.meteo(o.time.copy(), o.lon.copy(), o.lat.copy(), o.p.copy())
+    checked = 0
+    for row, name in enumerate(names):
+        if name in ("m", "rp", "rhop"):
+            continue
+        assert name in want, name
+        got = o.q[row]
+        fin = np.isfinite(got)                      # (sst is NaN over land: the nearest-corner rule on both sides)
+        assert np.array_equal(fin, np.isfinite(want[name])), name
+        scale = max(float(np.max(np.abs(got[fin]))), 1e-300)
+        assert float(np.max(np.abs(want[name][fin] - got[fin]))) <= TOL * scale, name
+        assert np.ptp(got[fin]) > 0, name
+        checked += 1
+    assert checked == len(names) - sum(n in ("m", "rp", "rhop") for n in names)
