@@ -568,6 +568,11 @@ class Ref:
                    tdew=T0 + 243.12 * lw / (17.62 - lw), tice=T0 + 272.62 * lw / (22.46 - lw))
         return out
 
+    # -- module_sort's key (mptrac.c:5913-5919): the un-wrapped longitude, as written ------------------------------------------
+    def sort_keys(self, lon, lat, p):
+        m = self.m0
+        return ((locate_reg(m.lon, lon) * len(m.lat) + locate_irr(m.lat, lat)) * len(m.p) + locate_irr(m.p, p)).astype(np.float64)
+
     # -- module_convection (mptrac.c:4102-4171) -----------------------------------------------------------------
     def convection(self, time, lon, lat, p, rs):
         c = self.c

@@ -300,3 +300,20 @@ def test_meteo_fields_and_derived_quantities(case):
         assert np.ptp(got[fin]) > 0, name
         checked += 1
     assert checked == len(names) - sum(n in ("m", "rp", "rhop") for n in names)
+
+
+def test_sort_keys_and_a_stable_order():
+    """module_sort's box index (mptrac.c:5913-5919: locate_reg on the longitude as it is, not wrapped) and the order it
+    induces; ties keep their index order here (GSL's gsl_sort_index leaves them unspecified)."""
+    o, ref, _ = _oracle("full")
+    o.lon[:6] = (-190.0, 185.0, 359.9, -180.0, 179.99999, 540.0)          # outside the axis: the end cells
+    for k in (400, 20, 777):                                              # ... and three particles in the box of a fourth: ties
+        o.lon[k], o.lat[k], o.p[k] = o.lon[50] + 1e-3, o.lat[50] - 1e-3, o.p[50] * (1.0 + 1e-5)
+    lon, lat, p, q0 = o.lon.copy(), o.lat.copy(), o.p.copy(), o.q.copy()
+    keys, perm = o.sort()
+    want = ref.sort_keys(lon, lat, p)
+    assert np.array_equal(keys, want)
+    order = np.argsort(want, kind="stable")
+    assert np.array_equal(perm, order)
+    assert np.array_equal(o.lon, lon[order]) and np.array_equal(o.p, p[order]) and np.array_equal(o.q, q0[:, order])
+    assert len(np.unique(want)) <= len(want) - 3                          # (the ties are there)
